@@ -1,0 +1,425 @@
+"""ctypes bindings used by the tests ONLY: the CPU oracle (oracle/liboracle.so, our restatement)
+and, when present, the unmodified reference compiled under oracle/_ref/ (see oracle/Makefile).
+
+Nothing in prima_cpp_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+F32, F16, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 8, 12, 13, 14, 15
+TYPE_NAMES = {F32: "f32", F16: "f16", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K", Q8_K: "q8_K"}
+BLOCK = {Q8_0: (32, 34), Q4_K: (256, 144), Q5_K: (256, 176), Q6_K: (256, 210), Q8_K: (256, 292),
+         F16: (1, 2), F32: (1, 4)}
+QUANT_TYPES = [Q4_K, Q5_K, Q6_K, Q8_0]
+
+
+def row_size(t, k):
+    n, b = BLOCK[t]
+    assert k % n == 0
+    return k // n * b
+
+
+def vec_dot_type(t):
+    return {F32: F32, F16: F16, Q8_0: Q8_0}.get(t, Q8_K)
+
+
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp) if a is not None else None
+
+
+class TensorT(C.Structure):
+    _fields_ = [("type", C.c_int32), ("pad_", C.c_int32), ("data", C.c_void_p)]
+
+
+class ModelDesc(C.Structure):
+    """Field order shared by orc_model_desc / ref_model_desc / pm355_model_desc."""
+    _fields_ = [("arch", C.c_int32), ("n_layer", C.c_int32), ("n_embd", C.c_int32), ("n_head", C.c_int32),
+                ("n_head_kv", C.c_int32), ("head_dim", C.c_int32), ("n_ff", C.c_int32), ("n_vocab", C.c_int32),
+                ("n_ctx", C.c_int32), ("n_ctx_orig", C.c_int32),
+                ("rms_eps", C.c_float), ("rope_freq_base", C.c_float), ("rope_freq_scale", C.c_float),
+                ("pad_", C.c_int32),
+                ("attn_norm", C.POINTER(TensorT)), ("wq", C.POINTER(TensorT)), ("wk", C.POINTER(TensorT)),
+                ("wv", C.POINTER(TensorT)), ("wo", C.POINTER(TensorT)), ("ffn_norm", C.POINTER(TensorT)),
+                ("ffn_gate", C.POINTER(TensorT)), ("ffn_up", C.POINTER(TensorT)), ("ffn_down", C.POINTER(TensorT)),
+                ("bq", C.POINTER(TensorT)), ("bk", C.POINTER(TensorT)), ("bv", C.POINTER(TensorT)),
+                ("tok_embd", TensorT), ("out_norm", TensorT), ("output", TensorT),
+                ("rope_freqs", C.c_void_p)]
+
+
+def build_oracle():
+    """Compile oracle/liboracle.so (and oracle/_ref when /root/reference exists)."""
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "all"], check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+class _Lib:
+    """Common wrapper: oracle ('orc_') and reference harness ('ref_') expose the same op API."""
+
+    def __init__(self, path, prefix):
+        self.lib = C.CDLL(path)
+        self.prefix = prefix
+        self.path = path
+
+    def fn(self, name, restype=None, argtypes=None):
+        f = getattr(self.lib, name)
+        f.restype = restype
+        if argtypes is not None:
+            f.argtypes = argtypes
+        return f
+
+    # --- ops with identical signatures in both libs -------------------------------------
+    def mul_mat(self, t, W, K, N, x, n_threads=1):
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, K)
+        out = np.empty((x.shape[0], N), dtype=np.float32)
+        if self.prefix == "ref_":
+            f = self.fn("ref_mul_mat", C.c_int, [C.c_int, _vp, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, C.c_int])
+            assert f(t, _ptr(W), K, N, _ptr(x), x.shape[0], _ptr(out), n_threads) == 0
+        else:
+            f = self.fn("orc_mul_mat", None, [C.c_int, _vp, C.c_int64, C.c_int64, _vp, C.c_int64, _vp])
+            f(t, _ptr(W), K, N, _ptr(x), x.shape[0], _ptr(out))
+        return out
+
+    def rms_norm(self, x, w, eps):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        rows, n = x.reshape(-1, x.shape[-1]).shape
+        out = np.empty_like(x)
+        f = self.fn(self.prefix + "rms_norm", None if self.prefix == "orc_" else C.c_int,
+                    [_vp, _vp, C.c_int64, C.c_int64, C.c_float, _vp])
+        w = None if w is None else np.ascontiguousarray(w, dtype=np.float32)
+        f(_ptr(x), _ptr(w), n, rows, eps, _ptr(out))
+        return out
+
+    def rope(self, x, pos, freq_factors=None, n_dims=None, mode=0, n_ctx_orig=8192, freq_base=10000.0,
+             freq_scale=1.0, ext_factor=0.0, attn_factor=1.0, beta_fast=32.0, beta_slow=1.0):
+        x = np.ascontiguousarray(x, dtype=np.float32)        # [ntok, heads, d]
+        ntok, heads, d = x.shape
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        ff = None if freq_factors is None else np.ascontiguousarray(freq_factors, dtype=np.float32)
+        out = np.empty_like(x)
+        f = self.fn(self.prefix + "rope", None if self.prefix == "orc_" else C.c_int,
+                    [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp])
+        f(_ptr(x), d, heads, ntok, _ptr(pos), _ptr(ff), n_dims or d, mode, n_ctx_orig, freq_base, freq_scale,
+          ext_factor, attn_factor, beta_fast, beta_slow, _ptr(out))
+        return out
+
+    def soft_max_ext(self, x, mask, scale, max_bias=0.0):
+        x = np.ascontiguousarray(x, dtype=np.float32)        # [heads, nr, nc]
+        heads, nr, nc = x.shape
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.float32)
+        out = np.empty_like(x)
+        f = self.fn(self.prefix + "soft_max_ext", None if self.prefix == "orc_" else C.c_int,
+                    [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float, _vp])
+        f(_ptr(x), _ptr(m), nc, nr, heads, scale, max_bias, _ptr(out))
+        return out
+
+    def silu_mul(self, g, u):
+        g = np.ascontiguousarray(g, dtype=np.float32)
+        u = None if u is None else np.ascontiguousarray(u, dtype=np.float32)
+        out = np.empty_like(g)
+        f = self.fn(self.prefix + "silu_mul", None if self.prefix == "orc_" else C.c_int, [_vp, _vp, C.c_int64, _vp])
+        f(_ptr(g), _ptr(u), g.size, _ptr(out))
+        return out
+
+    # --- model -----------------------------------------------------------------------------
+    def model_new(self, desc):
+        f = self.fn(self.prefix + "model_new", _vp, [C.POINTER(ModelDesc)])
+        h = f(C.byref(desc))
+        assert h
+        return h
+
+    def model_free(self, h):
+        self.fn(self.prefix + "model_free", None, [_vp])(h)
+
+    def model_kv_clear(self, h):
+        self.fn(self.prefix + "model_kv_clear", None, [_vp])(h)
+
+    def model_eval(self, h, desc, tokens=None, embd=None, pos0=0, layer_lo=0, layer_hi=None, with_head=True,
+                   n_threads=4):
+        layer_hi = desc.n_layer if layer_hi is None else layer_hi
+        if tokens is not None:
+            tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+            T = tokens.size
+        else:
+            embd = np.ascontiguousarray(embd, dtype=np.float32)
+            T = embd.shape[0]
+        hidden = np.empty((T, desc.n_embd), dtype=np.float32)
+        logits = np.empty(desc.n_vocab, dtype=np.float32) if with_head else None
+        f = self.fn(self.prefix + "model_eval", C.c_int,
+                    [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int])
+        rc = f(h, _ptr(tokens), _ptr(embd), T, pos0, layer_lo, layer_hi, int(with_head), _ptr(hidden),
+               _ptr(logits), n_threads)
+        assert rc == 0, rc
+        return hidden, logits
+
+    def model_kv(self, h, desc, il, which):
+        f = self.fn(self.prefix + "model_kv_ptr", _vp, [_vp, C.c_int, C.c_int])
+        p = f(h, il, which)
+        n = desc.head_dim * desc.n_head_kv * desc.n_ctx
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint16)), shape=(n,)).copy()
+
+
+class Oracle(_Lib):
+    def __init__(self):
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        super().__init__(path, "orc_")
+
+    def quantize_row_q8_K(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(row_size(Q8_K, x.size), dtype=np.uint8)
+        self.fn("orc_quantize_row_q8_K", None, [_vp, _vp, C.c_int64])(_ptr(x), _ptr(out), x.size)
+        return out
+
+    def quantize_row_q8_0(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(row_size(Q8_0, x.size), dtype=np.uint8)
+        self.fn("orc_quantize_row_q8_0", None, [_vp, _vp, C.c_int64])(_ptr(x), _ptr(out), x.size)
+        return out
+
+    def quantize_act(self, t, x):
+        vdt = vec_dot_type(t)
+        if vdt == Q8_K:
+            return self.quantize_row_q8_K(x)
+        if vdt == Q8_0:
+            return self.quantize_row_q8_0(x)
+        raise ValueError(t)
+
+    def dequantize_row(self, t, blocks, k):
+        out = np.empty(k, dtype=np.float32)
+        self.fn("orc_dequantize_row", None, [C.c_int, _vp, _vp, C.c_int64])(t, _ptr(blocks), _ptr(out), k)
+        return out
+
+    def vec_dot(self, t, n, w, a):
+        return self.fn("orc_vec_dot", C.c_float, [C.c_int, C.c_int64, _vp, _vp])(t, n, _ptr(w), _ptr(a))
+
+    def int_partials(self, t, n, w, a):
+        nb = n // BLOCK[t][0]
+        isum = np.empty(nb, dtype=np.int32)
+        msum = np.empty(nb, dtype=np.int32)
+        self.fn("orc_vec_dot_int_partials", None, [C.c_int, C.c_int64, _vp, _vp, _vp, _vp])(
+            t, n, _ptr(w), _ptr(a), _ptr(isum), _ptr(msum))
+        return isum, msum
+
+    def f32_to_f16(self, x):
+        f = self.fn("orc_f32_to_f16", C.c_uint16, [C.c_float])
+        return np.array([f(float(v)) for v in np.asarray(x, dtype=np.float32).ravel()], dtype=np.uint16)
+
+    def f16_to_f32(self, h):
+        f = self.fn("orc_f16_to_f32", C.c_float, [C.c_uint16])
+        return np.array([f(int(v)) for v in np.asarray(h, dtype=np.uint16).ravel()], dtype=np.float32)
+
+
+def ref_path(flavour):
+    return os.path.join(ORACLE_DIR, "_ref", f"libggml_ref_{flavour}.so")
+
+
+def have_ref(flavour="scalar"):
+    return os.path.exists(ref_path(flavour))
+
+
+def best_ref_flavour():
+    flags = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    flags = line
+                    break
+    except OSError:
+        pass
+    need512 = ["avx512f", "avx512bw", "avx512dq", "avx512vl", "avx512cd", "avx512_vnni"]
+    if all(x in flags for x in need512) and have_ref("avx512"):
+        return "avx512"
+    if "avx2" in flags and "fma" in flags and "f16c" in flags and have_ref("avx2"):
+        return "avx2"
+    return "scalar" if have_ref("scalar") else None
+
+
+class Ref(_Lib):
+    """The unmodified reference (ggml CPU backend) + our ref_ops.c harness."""
+
+    def __init__(self, flavour="scalar"):
+        super().__init__(ref_path(flavour), "ref_")
+        self.flavour = flavour
+        # ggml needs its fp16 tables initialised before raw quantize calls (ggml_init does it: ggml.c:3478)
+        class IP(C.Structure):
+            _fields_ = [("mem_size", C.c_size_t), ("mem_buffer", C.c_void_p), ("no_alloc", C.c_bool)]
+        init = self.fn("ggml_init", _vp, [IP])
+        ctx = init(IP(1 << 20, None, False))
+        self.fn("ggml_free", None, [_vp])(ctx)
+
+    def quantize_row_q8_K(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.zeros(row_size(Q8_K, x.size), dtype=np.uint8)
+        self.fn("quantize_row_q8_K", None, [_vp, _vp, C.c_int64])(_ptr(x), _ptr(out), x.size)
+        return out
+
+    def quantize_row_q8_0(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.zeros(row_size(Q8_0, x.size), dtype=np.uint8)
+        self.fn("quantize_row_q8_0", None, [_vp, _vp, C.c_int64])(_ptr(x), _ptr(out), x.size)
+        return out
+
+    def quantize_weights(self, t, w):
+        """ggml_quantize_chunk (ggml.c:21826): f32 [nrows, k] -> packed blocks."""
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        nrows, k = w.shape
+        out = np.zeros(nrows * row_size(t, k), dtype=np.uint8)
+        f = self.fn("ggml_quantize_chunk", C.c_size_t, [C.c_int, _vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp])
+        n = f(t, _ptr(w), _ptr(out), 0, nrows, k, None)
+        assert n == out.size
+        return out
+
+    def dequantize_row(self, t, blocks, k):
+        out = np.empty(k, dtype=np.float32)
+        name = {Q4_K: "dequantize_row_q4_K", Q5_K: "dequantize_row_q5_K", Q6_K: "dequantize_row_q6_K",
+                Q8_0: "dequantize_row_q8_0"}[t]
+        self.fn(name, None, [_vp, _vp, C.c_int64])(_ptr(blocks), _ptr(out), k)
+        return out
+
+    def vec_dot(self, t, n, w, a):
+        name = {Q4_K: "ggml_vec_dot_q4_K_q8_K", Q5_K: "ggml_vec_dot_q5_K_q8_K", Q6_K: "ggml_vec_dot_q6_K_q8_K",
+                Q8_0: "ggml_vec_dot_q8_0_q8_0"}[t]
+        s = C.c_float(0)
+        self.fn(name, None, [C.c_int, _fp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int])(
+            n, C.byref(s), 0, _ptr(w), 0, _ptr(a), 0, 1)
+        return s.value
+
+    def fp32_to_fp16_row(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(x.size, dtype=np.uint16)
+        self.fn("ggml_fp32_to_fp16_row", None, [_vp, _vp, C.c_int64])(_ptr(x), _ptr(out), x.size)
+        return out
+
+    def fp16_to_fp32_row(self, h):
+        h = np.ascontiguousarray(h, dtype=np.uint16)
+        out = np.empty(h.size, dtype=np.float32)
+        self.fn("ggml_fp16_to_fp32_row", None, [_vp, _vp, C.c_int64])(_ptr(h), _ptr(out), h.size)
+        return out
+
+    def time_layer_matvecs(self, mats, n_threads, reps=3):
+        """mats: list of (type, K, N, uint8 array). Returns seconds per pass."""
+        n = len(mats)
+        types = (C.c_int32 * n)(*[m[0] for m in mats])
+        Ks = (C.c_int64 * n)(*[m[1] for m in mats])
+        Ns = (C.c_int64 * n)(*[m[2] for m in mats])
+        datas = (C.c_void_p * n)(*[m[3].ctypes.data for m in mats])
+        f = self.fn("ref_time_layer_matvecs", C.c_double, [C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int])
+        return f(n, types, Ks, Ns, datas, n_threads, reps)
+
+    def build_info(self):
+        return self.fn("ref_build_info", C.c_char_p, [])().decode()
+
+
+# --------------------------------------------------------------------------------------------
+# synthetic data
+# --------------------------------------------------------------------------------------------
+
+def rand_blocks(t, nrows, k, rng, scale=None):
+    """Random VALID quant blocks (every bit pattern of the packed fields, finite fp16 scales).
+
+    Exercises all nibble/high-bit/6-bit-scale paths harder than quantized gaussians do.
+    `scale` sets the magnitude of the fp16 super-block scale d (default gives |w| ~ 1/sqrt(k))."""
+    nper, bs = BLOCK[t]
+    nb = nrows * (k // nper)
+    raw = rng.integers(0, 256, size=(nb, bs), dtype=np.uint8)
+    if scale is None:
+        scale = 1.0 / np.sqrt(k)
+
+    def f16(vals):
+        return np.asarray(vals, dtype=np.float16).view(np.uint8).reshape(nb, 2)
+    if t == Q8_0:
+        raw[:, 0:2] = f16(rng.uniform(0.5, 1.5, nb) * scale / 64.0)
+    elif t in (Q4_K, Q5_K):
+        qmax = 15 if t == Q4_K else 31
+        raw[:, 0:2] = f16(rng.uniform(0.5, 1.5, nb) * scale / (qmax * 32.0))
+        raw[:, 2:4] = f16(rng.uniform(0.5, 1.5, nb) * scale / (2 * 32.0))
+    elif t == Q6_K:
+        raw[:, 208:210] = f16(rng.uniform(0.5, 1.5, nb) * scale / (32.0 * 64.0))
+    else:
+        raise ValueError(t)
+    return raw.reshape(-1)
+
+
+def tiny_model(rng, arch=0, n_layer=2, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=320, n_ctx=64,
+               types=None, quantize=None, rope_freqs=False):
+    """Build a small Llama/Qwen2-shaped model with the Q4_K_M-style type mixture.
+
+    quantize(t, w_f32[rows, k]) -> uint8 blocks; defaults to random valid blocks when None."""
+    head_dim = n_embd // n_head
+    types = types or {}
+    keep = []
+
+    def mk(name, k, n, il=0):
+        t = types.get(name, Q4_K)
+        if quantize is not None:
+            w = rng.normal(0, 1.0 / np.sqrt(k), size=(n, k)).astype(np.float32)
+            data = quantize(t, w)
+        else:
+            data = rand_blocks(t, n, k, rng)
+        keep.append(data)
+        return TensorT(t, 0, data.ctypes.data)
+
+    def mkf(n, mean=1.0, std=0.02):
+        data = (mean + rng.normal(0, std, size=n)).astype(np.float32)
+        keep.append(data)
+        return TensorT(F32, 0, data.ctypes.data)
+
+    def arr(items):
+        a = (TensorT * len(items))(*items)
+        keep.append(a)
+        return a
+
+    d = ModelDesc()
+    d.arch, d.n_layer, d.n_embd, d.n_head, d.n_head_kv, d.head_dim = arch, n_layer, n_embd, n_head, n_head_kv, head_dim
+    d.n_ff, d.n_vocab, d.n_ctx, d.n_ctx_orig = n_ff, n_vocab, n_ctx, 8192
+    d.rms_eps = 1e-5 if arch == 0 else 1e-6
+    d.rope_freq_base = 500000.0 if arch == 0 else 1000000.0
+    d.rope_freq_scale = 1.0
+    E, Eq, Ekv = n_embd, head_dim * n_head, head_dim * n_head_kv
+    d.attn_norm = arr([mkf(E) for _ in range(n_layer)])
+    d.wq = arr([mk("attn_q", E, Eq) for _ in range(n_layer)])
+    d.wk = arr([mk("attn_k", E, Ekv) for _ in range(n_layer)])
+    vt = [types.get("attn_v", [Q6_K, Q5_K][il % 2]) for il in range(n_layer)]
+    d.wv = arr([_typed(rng, vt[il], E, Ekv, keep, quantize) for il in range(n_layer)])
+    d.wo = arr([mk("attn_output", Eq, E) for _ in range(n_layer)])
+    d.ffn_norm = arr([mkf(E) for _ in range(n_layer)])
+    d.ffn_gate = arr([mk("ffn_gate", E, n_ff) for _ in range(n_layer)])
+    d.ffn_up = arr([mk("ffn_up", E, n_ff) for _ in range(n_layer)])
+    dt = [types.get("ffn_down", [Q6_K, Q4_K][il % 2]) for il in range(n_layer)]
+    d.ffn_down = arr([_typed(rng, dt[il], n_ff, E, keep, quantize) for il in range(n_layer)])
+    if arch == 1:
+        d.bq = arr([mkf(Eq, 0.0, 0.1) for _ in range(n_layer)])
+        d.bk = arr([mkf(Ekv, 0.0, 0.1) for _ in range(n_layer)])
+        d.bv = arr([mkf(Ekv, 0.0, 0.1) for _ in range(n_layer)])
+    d.tok_embd = _typed(rng, types.get("token_embd", Q4_K), E, n_vocab, keep, quantize, scale=1.0)
+    d.out_norm = mkf(E)
+    d.output = _typed(rng, types.get("output", Q6_K), E, n_vocab, keep, quantize)
+    if rope_freqs:
+        ff = (1.0 + rng.uniform(0, 7, size=head_dim // 2)).astype(np.float32)
+        keep.append(ff)
+        d.rope_freqs = ff.ctypes.data
+    d._keep = keep
+    return d
+
+
+def _typed(rng, t, k, n, keep, quantize, scale=None):
+    if quantize is not None:
+        w = rng.normal(0, (scale or 1.0) / np.sqrt(k), size=(n, k)).astype(np.float32)
+        data = quantize(t, w)
+    else:
+        data = rand_blocks(t, n, k, rng, scale=None if scale is None else scale)
+    keep.append(data)
+    return TensorT(t, 0, data.ctypes.data)
