@@ -1,0 +1,137 @@
+// c_api.hip — extern "C" surface of libprima_mi355.so (see include/prima_mi355.h).
+#include "../../include/prima_mi355.h"
+#include "pm355_device.h"
+#include "pm355_kernels.h"
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[256] = "";
+static int fail(int code, const char * what, hipError_t e = hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+    return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(PM355_E_HIP, #expr, e_); } while (0)
+static inline hipStream_t S(pm355_stream_t s) { return (hipStream_t) s; }
+
+extern "C" {
+
+const char * pm355_version(void) { return "prima_mi355 0.1 (gfx950)"; }
+const char * pm355_last_error(void) { return g_err; }
+
+int pm355_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+int pm355_set_device(int d) { HIP_TRY(hipSetDevice(d)); return 0; }
+int pm355_device_info(int d, char * name, size_t name_len, size_t * free_b, size_t * total_b, int * cus) {
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, d));
+    if (name && name_len) { strncpy(name, p.name, name_len - 1); name[name_len - 1] = 0; }
+    if (cus) *cus = p.multiProcessorCount;
+    if (free_b || total_b) {
+        int cur = 0; hipGetDevice(&cur); hipSetDevice(d);
+        size_t f = 0, t = 0; hipError_t e = hipMemGetInfo(&f, &t); hipSetDevice(cur);
+        if (e != hipSuccess) return fail(PM355_E_HIP, "hipMemGetInfo", e);
+        if (free_b) *free_b = f;
+        if (total_b) *total_b = t;
+    }
+    return 0;
+}
+int pm355_sync(pm355_stream_t s) { HIP_TRY(s ? hipStreamSynchronize(S(s)) : hipDeviceSynchronize()); return 0; }
+
+void * pm355_malloc(size_t n) { void * p = nullptr; return hipMalloc(&p, n) == hipSuccess ? p : nullptr; }
+void   pm355_free(void * p) { if (p) (void) hipFree(p); }
+void * pm355_host_malloc(size_t n) { void * p = nullptr; return hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+void   pm355_host_free(void * p) { if (p) (void) hipHostFree(p); }
+int pm355_memcpy_h2d(void * d, const void * s, size_t n, pm355_stream_t st) { HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, S(st))); return 0; }
+int pm355_memcpy_d2h(void * d, const void * s, size_t n, pm355_stream_t st) { HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, S(st))); return 0; }
+int pm355_memcpy_d2d(void * d, const void * s, size_t n, pm355_stream_t st) { HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, S(st))); return 0; }
+int pm355_memset(void * d, int v, size_t n, pm355_stream_t st) { HIP_TRY(hipMemsetAsync(d, v, n, S(st))); return 0; }
+
+size_t pm355_row_size(int type, int64_t K) { return pm_weight_row_bytes(type, K); }
+size_t pm355_q8_K_row_size(int64_t K) { return pm_q8k_row_bytes((int) K); }
+size_t pm355_q8_0_row_size(int64_t K) { return pm_q80_row_bytes((int) K); }
+
+int pm355_repack_rows(int type, const void * src, void * dst, int64_t K, int64_t nrows, int to_dev, pm355_stream_t st) {
+    if (pm_weight_row_bytes(type, K) == 0) return fail(PM355_E_UNSUPPORTED, "repack: type");
+    pm_launch_repack(type, src, dst, K, nrows, to_dev, S(st));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int pm355_quantize_q8_K(const float * x, void * yq, int64_t K, int64_t rows, pm355_stream_t st) {
+    if (K <= 0 || K % 256) return fail(PM355_E_SHAPE, "quantize_q8_K: K % 256");
+    pm_launch_quantize_q8k(x, yq, (int) K, (int) rows, S(st));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pm355_quantize_q8_0(const float * x, void * yq, int64_t K, int64_t rows, pm355_stream_t st) {
+    if (K <= 0 || K % 32) return fail(PM355_E_SHAPE, "quantize_q8_0: K % 32");
+    pm_launch_quantize_q80(x, yq, (int) K, (int) rows, S(st));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// row-SoA activation -> reference block layout (test hook; tiny)
+__global__ void act_to_blocks_kernel(int act_type, const uint8_t * yq, uint8_t * out, int K, int rows, size_t in_row) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (act_type == PM_Q8_K) {
+        const int nblk = K / 256;
+        if (i >= (long) rows * nblk) return;
+        const int row = (int) (i / nblk), b = (int) (i % nblk);
+        const uint8_t * r = yq + (size_t) row * in_row;
+        uint8_t * o = out + ((size_t) row * nblk + b) * PM_BS_Q8_K;
+        *(float *) o = ((const float *) (r + K))[b];
+        for (int j = 0; j < 256; ++j) o[4 + j] = r[b * 256 + j];
+        for (int j = 0; j < 16; ++j) ((int16_t *) (o + 260))[j] = ((const int16_t *) (r + K + nblk * 4))[b * 16 + j];
+    } else {
+        const int nblk = K / 32;
+        if (i >= (long) rows * nblk) return;
+        const int row = (int) (i / nblk), b = (int) (i % nblk);
+        const uint8_t * r = yq + (size_t) row * in_row;
+        uint8_t * o = out + ((size_t) row * nblk + b) * PM_BS_Q8_0;
+        *(uint16_t *) o = ((const uint16_t *) (r + K))[b];
+        for (int j = 0; j < 32; ++j) o[2 + j] = r[b * 32 + j];
+    }
+}
+int pm355_act_to_ggml_blocks(int act_type, const void * yq, void * out, int64_t K, int64_t rows, pm355_stream_t st) {
+    if (act_type != PM_Q8_K && act_type != PM_Q8_0) return fail(PM355_E_UNSUPPORTED, "act_to_ggml_blocks: type");
+    const long n = rows * (act_type == PM_Q8_K ? K / 256 : K / 32);
+    const size_t in_row = act_type == PM_Q8_K ? pm_q8k_row_bytes((int) K) : pm_q80_row_bytes((int) K);
+    hipLaunchKernelGGL(act_to_blocks_kernel, dim3((unsigned) ((n + 63) / 64)), dim3(64), 0, S(st),
+                       act_type, (const uint8_t *) yq, (uint8_t *) out, (int) K, (int) rows, in_row);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int pm355_rms_norm(const float * x, const float * w, float * y, void * yq, int64_t K, int64_t rows, float eps, pm355_stream_t st) {
+    if (K <= 0 || K % 256) return fail(PM355_E_SHAPE, "rms_norm: K % 256");
+    pm_launch_rmsnorm_q8k(x, w, y, yq, (int) K, (int) rows, eps, S(st));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int gemv_rc(int rc) {
+    switch (rc) {
+        case 0: return 0;
+        case -1: return fail(PM355_E_UNSUPPORTED, "mul_mat_vec_q: weight type");
+        case -2: return fail(PM355_E_SHAPE, "mul_mat_vec_q: K not a multiple of the block size");
+        case -3: return fail(PM355_E_ALIGN, "mul_mat_vec_q: K % 2048 != 0 for Q6_K row-SoA");
+        case -4: return fail(PM355_E_RANGE, "mul_mat_vec_q: K too large");
+        default: return fail(PM355_E_HIP, "mul_mat_vec_q: launch", hipGetLastError());
+    }
+}
+int pm355_mul_mat_vec_q(int type, const void * W, const void * W2, int64_t K, int64_t N, const void * xq, int ncols,
+                        float * y, int64_t y_stride, const float * bias, const float * resid, pm355_stream_t st) {
+    if (ncols < 1 || ncols > 8) return fail(PM355_E_RANGE, "mul_mat_vec_q: ncols must be 1..8");
+    pm_gemv_args a = {};
+    a.type = type; a.K = (int) K; a.N = (int) N; a.W = W; a.W2 = W2; a.xq = xq; a.ncols = ncols;
+    a.y = y; a.y_stride = (size_t) y_stride; a.bias = bias; a.resid = resid; a.dbg_int = nullptr;
+    return gemv_rc(pm_launch_gemv(a, S(st)));
+}
+int pm355_mul_mat_vec_q_dbg(int type, const void * W, int64_t K, int64_t N, const void * xq, float * y,
+                            int32_t * ip, int64_t * upr, pm355_stream_t st) {
+    if (upr) *upr = K / (type == PM_Q6_K ? 64 : 32);
+    pm_gemv_args a = {};
+    a.type = type; a.K = (int) K; a.N = (int) N; a.W = W; a.xq = xq; a.ncols = 1; a.y = y; a.y_stride = (size_t) N; a.dbg_int = ip;
+    return gemv_rc(pm_launch_gemv(a, S(st)));
+}
+
+} // extern "C"

@@ -1,0 +1,94 @@
+// pm355_device.h — device-side helpers shared by the gfx950 kernels (wave64, CDNA4).
+//
+// GGUF block formats consumed here (reference: ggml/src/ggml-common.h:187-191, :286-335):
+//   Q4_K 144 B / 256 w : half d | half dmin | u8 scales[12] | u8 qs[128]         (native layout in HBM)
+//   Q5_K 176 B / 256 w : half d | half dmin | u8 scales[12] | u8 qh[32] | u8 qs[128]   (native)
+//   Q6_K 210 B / 256 w : u8 ql[128] | u8 qh[64] | i8 scales[16] | half d         (row-SoA in HBM, see repack.hip)
+//   Q8_0  34 B /  32 w : half d | i8 qs[32]                                      (row-SoA in HBM)
+//   Q8_K 292 B / 256 a : float d | i8 qs[256] | i16 bsums[16]                    (activations, native)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#define PM_QK_K 256
+#define PM_WAVE 64
+
+enum pm_type : int { PM_F32 = 0, PM_F16 = 1, PM_Q8_0 = 8, PM_Q4_K = 12, PM_Q5_K = 13, PM_Q6_K = 14, PM_Q8_K = 15 };
+
+#define PM_BS_Q8_0 34
+#define PM_BS_Q4_K 144
+#define PM_BS_Q5_K 176
+#define PM_BS_Q6_K 210
+#define PM_BS_Q8_K 292
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// ---- loads --------------------------------------------------------------------------------------
+// Weights are streamed exactly once per token: non-temporal (global_load ... nt) keeps them from
+// displacing the activation / KV working set in L2 (MI355X_MICROARCH.md "nt-weights").
+__device__ __forceinline__ u32x4 ld_nt16(const void * p) { return __builtin_nontemporal_load((const u32x4 *) p); }
+__device__ __forceinline__ u32x2 ld_nt8(const void * p)  { return __builtin_nontemporal_load((const u32x2 *) p); }
+__device__ __forceinline__ uint32_t ld_nt4(const void * p) { return __builtin_nontemporal_load((const uint32_t *) p); }
+__device__ __forceinline__ uint16_t ld_nt2(const void * p) { return __builtin_nontemporal_load((const uint16_t *) p); }
+
+__device__ __forceinline__ float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __half_as_ushort(__float2half_rn(f)); }   // RNE, == GGML_FP32_TO_FP16
+
+// v_dot4_i32_i8: 4 x (i8 * i8) + acc
+__device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int acc) {
+    return __builtin_amdgcn_sdot4((int) a, (int) b, acc, false);
+}
+
+// ---- DPP wave reductions (no LDS traffic) ----------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float v) {
+    // old = 0 with the selected row mask and bound_ctrl: lanes that receive nothing add 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
+}
+
+// Sum over the 64 lanes of a wave; the total is returned in EVERY lane (via readlane 63).
+// Fixed combination order -> bitwise deterministic.
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);         // row_half_mirror : 8-lane groups complete
+    v += dpp_f<0x140>(v);         // row_mirror      : 16-lane rows complete
+    v += dpp_f<0x142, 0xA>(v);    // row_bcast15 -> rows 1 and 3
+    v += dpp_f<0x143, 0xC>(v);    // row_bcast31 -> rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// max over aligned groups of 8 lanes, result in all 8 lanes
+__device__ __forceinline__ float group8_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    return v;
+}
+__device__ __forceinline__ int group8_min_i(int v) {
+    v = min(v, dpp_i<0xB1>(v));
+    v = min(v, dpp_i<0x4E>(v));
+    v = min(v, dpp_i<0x141>(v));
+    return v;
+}
+
+// round-to-nearest-even of |v| <= 4194303 (reference: nearest_int, ggml-quants.c:1638-1644)
+__device__ __forceinline__ int nearest_int_rne(float v) {
+    float t = v + 12582912.f;
+    return (__builtin_bit_cast(int, t) & 0x007fffff) - 0x00400000;
+}
+
+// 6-bit scale / min number `j` (0..7) of a K-quant super-block; s = the 12 scale bytes as 3 dwords
+// (reference: get_scale_min_k4, ggml-quants.c:1898-1906)
+__device__ __forceinline__ void k4_scale_min(uint32_t s0, uint32_t s1, uint32_t s2, int j, int & sc, int & mn) {
+    const int sh = 8 * (j & 3);
+    const uint32_t b0 = (s0 >> sh) & 0xFF, b1 = (s1 >> sh) & 0xFF, b2 = (s2 >> sh) & 0xFF;
+    if (j < 4) { sc = b0 & 63; mn = b1 & 63; }
+    else       { sc = (b2 & 0x0F) | ((b0 >> 6) << 4); mn = (b2 >> 4) | ((b1 >> 6) << 4); }
+}

@@ -1,0 +1,32 @@
+// pm355_kernels.h — internal launcher prototypes (host side) for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// bytes of one quantized ACTIVATION row in the library's internal row-SoA layout (quantize.hip)
+static inline size_t pm_q8k_row_bytes(int K) { return (size_t) K + (size_t) (K / 256) * 4 + (size_t) (K / 16) * 2; }
+static inline size_t pm_q80_row_bytes(int K) { return (size_t) K + (size_t) (K / 32) * 2; }
+
+// bytes of one WEIGHT row (same as ggml_row_size for every supported type; repacking is row-local)
+size_t pm_weight_row_bytes(int type, int64_t K);
+
+void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStream_t st);
+void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStream_t st);
+void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st);
+
+// weight repack (row-local, bijective):  GGUF block order <-> HBM row-SoA (Q6_K, Q8_0); identity for the rest
+void pm_launch_repack(int type, const void * src, void * dst, int64_t K, int64_t nrows, int to_device_layout, hipStream_t st);
+
+// y[N] = W[N,K] . xq (+bias)(+resid);  optional second matrix W2 (same type/shape): y = silu(W.x) * (W2.x)
+struct pm_gemv_args {
+    int type; int K; int N;
+    const void * W; const void * W2;
+    const void * xq;            // quantized activation row(s) (Q8_K row-SoA, or Q8_0 row-SoA for Q8_0 weights)
+    int ncols;                  // 1..8 activation columns (rows of xq, stride = row bytes)
+    float * y; size_t y_stride; // y[col * y_stride + n]
+    const float * bias;         // [N] or null
+    const float * resid;        // same indexing as y, or null
+    int32_t * dbg_int;          // debug: per (row, unit) {isum, msum} pairs, or null
+};
+int pm_launch_gemv(const pm_gemv_args & a, hipStream_t st);

@@ -1,0 +1,164 @@
+// quantize.hip — activation quantizers for the decode path (gfx950).
+//
+//   f32 row -> Q8_K  (reference: quantize_row_q8_K_ref, ggml/src/ggml-quants.c:3785-3826)
+//   f32 row -> Q8_0  (reference: quantize_row_q8_0_ref, ggml/src/ggml-quants.c:848-871)
+//   rms_norm(x) * w -> f32 and/or Q8_K in one pass
+//              (reference: ggml_compute_forward_rms_norm_f32 ggml.c:11950 + ggml_compute_forward_mul_f32 :10077)
+//
+// Bit-exact with the reference for q / bsums / d: same float operations in the same order per
+// element (iscale = -127/max; nearest_int(iscale*x); d = 1/iscale), and the same "first element with
+// the largest |x| decides the sign" rule, implemented as (wave max) + (wave min over candidate index).
+//
+// Device layout of a quantized activation row ("row-SoA", internal to this library; K values):
+//   Q8_K : int8 qs[K] | float d[K/256] | int16 bsums[K/16]       -> pm_q8k_row_bytes(K)
+//   Q8_0 : int8 qs[K] | half  d[K/32]                            -> pm_q80_row_bytes(K)
+// HBM-bound, trivially small (K <= 32k): one wave per 256-value block, 4 values per lane (16-B loads).
+#include "pm355_device.h"
+#include "pm355_kernels.h"
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_keep_f(float v) {   // lanes outside ROW_MASK / out of range keep v
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_keep_i(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_keep_f<0xB1>(v));
+    v = fmaxf(v, dpp_keep_f<0x4E>(v));
+    v = fmaxf(v, dpp_keep_f<0x141>(v));
+    v = fmaxf(v, dpp_keep_f<0x140>(v));
+    v = fmaxf(v, dpp_keep_f<0x142, 0xA>(v));
+    v = fmaxf(v, dpp_keep_f<0x143, 0xC>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+    v = min(v, dpp_keep_i<0xB1>(v));
+    v = min(v, dpp_keep_i<0x4E>(v));
+    v = min(v, dpp_keep_i<0x141>(v));
+    v = min(v, dpp_keep_i<0x140>(v));
+    v = min(v, dpp_keep_i<0x142, 0xA>(v));
+    v = min(v, dpp_keep_i<0x143, 0xC>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// One wave quantizes one 256-value block held as 4 consecutive values per lane.
+__device__ __forceinline__ void q8k_block_from_regs(const float v[4], int lane, uint8_t * row_out, int K, int blk) {
+    float a0 = fabsf(v[0]), a1 = fabsf(v[1]), a2 = fabsf(v[2]), a3 = fabsf(v[3]);
+    const float amax = wave_max(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+    int8_t  * qs    = (int8_t *) row_out;
+    float   * dd    = (float *) (row_out + K);
+    int16_t * bsums = (int16_t *) (row_out + K + (K / PM_QK_K) * 4);
+    uint32_t packed = 0;
+    int psum = 0;
+    if (amax != 0.0f) {
+        // lowest index with |x| == amax; low bit carries its sign
+        int key = 0x7fffffff;
+        if (a3 == amax) key = ((4 * lane + 3) << 1) | (v[3] < 0.0f);
+        if (a2 == amax) key = ((4 * lane + 2) << 1) | (v[2] < 0.0f);
+        if (a1 == amax) key = ((4 * lane + 1) << 1) | (v[1] < 0.0f);
+        if (a0 == amax) key = ((4 * lane + 0) << 1) | (v[0] < 0.0f);
+        key = wave_min_i(key);
+        const float vmax = (key & 1) ? -amax : amax;
+        const float iscale = -127.f / vmax;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int q = nearest_int_rne(iscale * v[i]);
+            q = q > 127 ? 127 : q;
+            psum += q;
+            packed |= (uint32_t) (q & 0xFF) << (8 * i);
+        }
+        if (lane == 0) dd[blk] = 1 / iscale;
+    } else if (lane == 0) {
+        dd[blk] = 0.0f;
+    }
+    ((uint32_t *) (qs + (size_t) blk * PM_QK_K))[lane] = packed;
+    // bsums: 16 values = 4 lanes (one quad)
+    psum += dpp_i<0xB1>(psum);
+    psum += dpp_i<0x4E>(psum);
+    if ((lane & 3) == 0) bsums[blk * 16 + (lane >> 2)] = (int16_t) psum;
+}
+
+__global__ __launch_bounds__(256) void quantize_q8k_kernel(const float * __restrict__ x, uint8_t * __restrict__ y,
+                                                           int K, int rows, size_t y_row_bytes) {
+    const int lane = threadIdx.x & 63;
+    const int nblk = K / PM_QK_K;
+    const long wave = (long) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= (long) rows * nblk) return;
+    const int row = (int) (wave / nblk), blk = (int) (wave % nblk);
+    const float4 f = ((const float4 *) (x + (size_t) row * K + (size_t) blk * PM_QK_K))[lane];
+    const float v[4] = {f.x, f.y, f.z, f.w};
+    q8k_block_from_regs(v, lane, y + (size_t) row * y_row_bytes, K, blk);
+}
+
+// Q8_0: 32-value blocks, 8 lanes x 4 values; amax over the 8-lane group.
+__global__ __launch_bounds__(256) void quantize_q80_kernel(const float * __restrict__ x, uint8_t * __restrict__ y,
+                                                           int K, int rows, size_t y_row_bytes) {
+    const long t = (long) blockIdx.x * 256 + threadIdx.x;        // one thread = 4 values
+    const long per_row = K / 4;
+    if (t >= (long) rows * per_row) return;
+    const int row = (int) (t / per_row), i4 = (int) (t % per_row);
+    const float4 f = ((const float4 *) (x + (size_t) row * K))[i4];
+    float amax = fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w)));
+    amax = group8_max(amax);
+    const float d  = amax / 127;
+    const float id = d ? 1.0f / d : 0.0f;
+    uint8_t * ro = y + (size_t) row * y_row_bytes;
+    const float v[4] = {f.x, f.y, f.z, f.w};
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) packed |= (uint32_t) ((int) roundf(v[i] * id) & 0xFF) << (8 * i);
+    ((uint32_t *) ro)[i4] = packed;
+    if ((i4 & 7) == 0) ((uint16_t *) (ro + K))[i4 >> 3] = f2h(d);
+}
+
+// rms_norm (+ weight) fused with Q8_K quantization. One 256-thread workgroup per row.
+// Optionally also writes the normalised f32 row (ynorm != nullptr).
+__global__ __launch_bounds__(256) void rmsnorm_q8k_kernel(const float * __restrict__ x, const float * __restrict__ w,
+                                                          float * __restrict__ ynorm, uint8_t * __restrict__ yq,
+                                                          int K, float eps, size_t yq_row_bytes) {
+    __shared__ double red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nblk = K / PM_QK_K;
+    const float * xr = x + (size_t) row * K;
+    // pass 1: sum of squares; products rounded to f32 like the reference, accumulated in f64
+    double s = 0.0;
+    for (int blk = wv; blk < nblk; blk += 4) {
+        const float4 f = ((const float4 *) (xr + (size_t) blk * PM_QK_K))[lane];
+        s += (double) (f.x * f.x); s += (double) (f.y * f.y); s += (double) (f.z * f.z); s += (double) (f.w * f.w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+    const float mean  = (float) (tot / K);
+    const float scale = 1.0f / sqrtf(mean + eps);
+    // pass 2: normalise (+weight), write f32 and/or quantize (x is L2/L1 resident: K*4 <= 128 KB)
+    for (int blk = wv; blk < nblk; blk += 4) {
+        const float4 f = ((const float4 *) (xr + (size_t) blk * PM_QK_K))[lane];
+        float v[4] = {f.x * scale, f.y * scale, f.z * scale, f.w * scale};
+        if (w) {
+            const float4 g = ((const float4 *) (w + (size_t) blk * PM_QK_K))[lane];
+            v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
+        }
+        if (ynorm) ((float4 *) (ynorm + (size_t) row * K + (size_t) blk * PM_QK_K))[lane] = make_float4(v[0], v[1], v[2], v[3]);
+        if (yq) q8k_block_from_regs(v, lane, yq + (size_t) row * yq_row_bytes, K, blk);
+    }
+}
+
+// ---- host launchers -------------------------------------------------------------------------------
+void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStream_t st) {
+    const long waves = (long) rows * (K / PM_QK_K);
+    hipLaunchKernelGGL(quantize_q8k_kernel, dim3((unsigned) ((waves + 3) / 4)), dim3(256), 0, st,
+                       x, (uint8_t *) y, K, rows, pm_q8k_row_bytes(K));
+}
+void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStream_t st) {
+    const long n = (long) rows * (K / 4);
+    hipLaunchKernelGGL(quantize_q80_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st,
+                       x, (uint8_t *) y, K, rows, pm_q80_row_bytes(K));
+}
+void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(rmsnorm_q8k_kernel, dim3(rows), dim3(256), 0, st, x, w, ynorm, (uint8_t *) yq, K, eps, pm_q8k_row_bytes(K));
+}

@@ -1,0 +1,115 @@
+"""Op-level host mirror of the reference interface for the hot path (ggml op names and argument
+meaning; see include/prima_mi355.h for the reference function each one replaces).
+
+Tensors are torch CUDA tensors used purely as device memory handles; all compute happens in
+libprima_mi355.so on the current torch stream.
+"""
+import numpy as np
+import torch
+
+from . import lib as L
+from .lib import F16, F32, Q4_K, Q5_K, Q6_K, Q8_0, Q8_K, check, ptr, stream_ptr  # noqa: F401
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise L.PM355Error("no HIP device visible; prima_cpp_amd has no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class QWeight:
+    """A quantized weight matrix [N rows, K cols] resident in HBM in the library's layout."""
+
+    def __init__(self, qtype, K, N, data):
+        self.type, self.K, self.N, self.data = qtype, K, N, data
+
+    @property
+    def nbytes(self):
+        return self.data.numel()
+
+
+def upload_weight(qtype, blocks, K, N):
+    """ggml_backend_tensor_set semantics: host GGUF-order bytes -> HBM (H2D copy + row-local repack)."""
+    lib = L.load()
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1)
+    assert blocks.size == L.row_size(qtype, K) * N, (blocks.size, L.row_size(qtype, K) * N)
+    raw = torch.from_numpy(blocks).to(_dev())
+    if qtype in (Q6_K, Q8_0):
+        dst = torch.empty_like(raw)
+        check(lib.pm355_repack_rows(qtype, ptr(raw), ptr(dst), K, N, 1, stream_ptr()), "repack_rows")
+        return QWeight(qtype, K, N, dst)
+    return QWeight(qtype, K, N, raw)
+
+
+def download_weight(w):
+    """ggml_backend_tensor_get semantics: HBM layout -> host GGUF-order bytes."""
+    lib = L.load()
+    if w.type in (Q6_K, Q8_0):
+        tmp = torch.empty_like(w.data)
+        check(lib.pm355_repack_rows(w.type, ptr(w.data), ptr(tmp), w.K, w.N, 0, stream_ptr()), "repack_rows")
+        return tmp.cpu().numpy()
+    return w.data.cpu().numpy()
+
+
+def quantize_act(x, act_type=Q8_K):
+    """x: f32 [rows, K] (or [K]) -> device buffer of quantized rows (library row-SoA layout)."""
+    lib = L.load()
+    x = x.contiguous().view(-1, x.shape[-1])
+    rows, K = x.shape
+    rb = lib.pm355_q8_K_row_size(K) if act_type == Q8_K else lib.pm355_q8_0_row_size(K)
+    out = torch.empty(rows * rb, dtype=torch.uint8, device=x.device)
+    fn = lib.pm355_quantize_q8_K if act_type == Q8_K else lib.pm355_quantize_q8_0
+    check(fn(ptr(x), ptr(out), K, rows, stream_ptr()), "quantize")
+    return out
+
+
+def act_to_ggml_blocks(yq, act_type, K, rows):
+    """Quantized activation rows -> numpy bytes in the reference's block_q8_K / block_q8_0 layout (tests)."""
+    lib = L.load()
+    out = torch.empty(rows * L.row_size(act_type, K), dtype=torch.uint8, device=yq.device)
+    check(lib.pm355_act_to_ggml_blocks(act_type, ptr(yq), ptr(out), K, rows, stream_ptr()), "act_to_ggml_blocks")
+    return out.cpu().numpy()
+
+
+def rms_norm(x, w, eps, want_f32=True, want_q8=False):
+    lib = L.load()
+    x2 = x.contiguous().view(-1, x.shape[-1])
+    rows, K = x2.shape
+    y = torch.empty_like(x2) if want_f32 else None
+    yq = torch.empty(rows * lib.pm355_q8_K_row_size(K), dtype=torch.uint8, device=x.device) if want_q8 else None
+    check(lib.pm355_rms_norm(ptr(x2), ptr(w), ptr(y), ptr(yq), K, rows, float(eps), stream_ptr()), "rms_norm")
+    if want_f32 and want_q8:
+        return y.view_as(x), yq
+    return y.view_as(x) if want_f32 else yq
+
+
+def vec_dot_act_type(qtype):
+    return Q8_0 if qtype == Q8_0 else Q8_K
+
+
+def mul_mat_vec(w, x=None, xq=None, w2=None, bias=None, resid=None, ncols=1):
+    """ggml_mul_mat(W, x) for ncols <= 8 f32 activation columns x [ncols, K] (quantized on device to the
+    reference's vec_dot_type first), or pre-quantized xq. Returns f32 [ncols, N]."""
+    lib = L.load()
+    if xq is None:
+        x2 = x.contiguous().view(-1, w.K)
+        ncols = x2.shape[0]
+        xq = quantize_act(x2, vec_dot_act_type(w.type))
+    y = torch.empty((ncols, w.N), dtype=torch.float32, device=w.data.device)
+    check(lib.pm355_mul_mat_vec_q(w.type, ptr(w.data), ptr(w2.data) if w2 is not None else None, w.K, w.N, ptr(xq),
+                                  ncols, ptr(y), w.N, ptr(bias), ptr(resid), stream_ptr()), "mul_mat_vec_q")
+    return y
+
+
+def mul_mat_vec_dbg(w, xq):
+    """Returns (y f32 [N], int partials int32 [N, units, 2])."""
+    import ctypes as C
+    lib = L.load()
+    upr = C.c_int64(0)
+    units = w.K // (64 if w.type == Q6_K else 32)
+    y = torch.empty(w.N, dtype=torch.float32, device=w.data.device)
+    ip = torch.zeros((w.N, units, 2), dtype=torch.int32, device=w.data.device)
+    check(lib.pm355_mul_mat_vec_q_dbg(w.type, ptr(w.data), w.K, w.N, ptr(xq), ptr(y), ptr(ip), C.addressof(upr),
+                                      stream_ptr()), "mul_mat_vec_q_dbg")
+    assert upr.value == units
+    return y, ip
