@@ -97,6 +97,90 @@ PM355_API int pm355_mul_mat_vec_q(int type, const void * W, const void * W2, int
 PM355_API int pm355_mul_mat_vec_q_dbg(int type, const void * W, int64_t K, int64_t N, const void * xq, float * y,
                                       int32_t * int_partials, int64_t * units_per_row, pm355_stream_t stream);
 
+/* remaining per-layer ops (prima_cpp_amd/csrc/layer_ops.hip); positions are read from DEVICE memory (pos0[0] =
+ * position of token 0 of the batch) so captured graphs can be replayed */
+typedef struct {
+    int32_t n_dims, mode /* 0 = NORM (llama), 2 = NEOX (qwen2) */, n_ctx_orig;
+    float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+} pm355_rope_params;                     /* == ggml_rope_ext arguments (ggml/include/ggml.h:1497) */
+
+/* replaces ggml_compute_forward_get_rows_{q,f32} (ggml/src/ggml.c:13288, :13414): out[t] = dequant(table[tokens[t]]) */
+PM355_API int pm355_get_rows(int type, const void * table, int64_t K, const int32_t * d_tokens, int n_tokens,
+                             float * out, pm355_stream_t stream);
+/* replaces ggml_compute_forward_rope_f32 (ggml/src/ggml.c:14143) on Q and K + llm_build_kv_store
+ * (src/llama.cpp:9673-9718): K -> F16 cache rows [n_ctx][Hkv*dh], V -> F16 transposed cache [Hkv*dh][n_ctx].
+ * q_out may alias q. k_out_f32 optional (rotated K in f32, for tests / node equivalence). */
+PM355_API int pm355_rope_kv_store(const float * q, const float * k, const float * v, float * q_out, float * k_out_f32,
+                                  void * k_cache, void * v_cache, const int32_t * d_pos0, const float * freq_factors,
+                                  int n_tokens, int n_head, int n_head_kv, int head_dim, int n_ctx,
+                                  const pm355_rope_params * rp, pm355_stream_t stream);
+/* replaces llm_build_kqv's MUL_MAT(k,q) -> SOFT_MAX_EXT -> MUL_MAT(v,kq) chain (src/llama.cpp:10062-10148) for
+ * causal single-sequence decode; out: [n_tokens][n_head*head_dim] f32 */
+PM355_API int pm355_attn_decode(const float * q, const void * k_cache, const void * v_cache, const int32_t * d_pos0,
+                                float * out, int n_tokens, int n_head, int n_head_kv, int head_dim, int n_ctx,
+                                float kq_scale, pm355_stream_t stream);
+/* greedy sampler (src/llama-sampling.cpp:390-397): index of the first maximum */
+PM355_API int pm355_argmax(const float * x, int64_t n, int32_t * d_index, float * d_value, pm355_stream_t stream);
+/* ggml_compute_forward_add_f32 / mul_f32 (row-broadcast of b over a), silu(*u), scale */
+PM355_API int pm355_add(const float * a, const float * b, float * y, int64_t n, int64_t nb, pm355_stream_t stream);
+PM355_API int pm355_mul(const float * a, const float * b, float * y, int64_t n, int64_t nb, pm355_stream_t stream);
+PM355_API int pm355_silu_mul(const float * g, const float * u, float * y, int64_t n, pm355_stream_t stream);
+PM355_API int pm355_scale(const float * a, float * y, float s, int64_t n, pm355_stream_t stream);
+/* synthetic weights generated directly in HBM (bench): random VALID blocks of `type`, |w| ~ scale */
+PM355_API int pm355_fill_random_blocks(int type, void * dst, int64_t K, int64_t nrows, uint64_t seed, float scale,
+                                       pm355_stream_t stream);
+
+/* ---- (B) engine: resident decoder for one layer window --------------------------------------------- */
+typedef struct pm355_model pm355_model;
+
+typedef struct {                          /* llm_load_hparams (src/llama.cpp:5823) subset */
+    int32_t arch;                         /* 0 = llama (rope NORM, optional rope_freqs), 1 = qwen2 (rope NEOX, qkv bias) */
+    int32_t n_layer, n_embd, n_head, n_head_kv, head_dim, n_ff, n_vocab, n_ctx, n_ctx_orig;
+    float   rms_eps, rope_freq_base, rope_freq_scale;
+    int32_t pad_;
+} pm355_hparams;
+
+enum pm355_tensor_kind { PM355_T_ATTN_NORM = 0, PM355_T_WQ, PM355_T_WK, PM355_T_WV, PM355_T_WO, PM355_T_FFN_NORM,
+                         PM355_T_FFN_GATE, PM355_T_FFN_UP, PM355_T_FFN_DOWN, PM355_T_BQ, PM355_T_BK, PM355_T_BV,
+                         PM355_T_TOK_EMBD, PM355_T_OUT_NORM, PM355_T_OUTPUT, PM355_T_ROPE_FREQS, PM355_T_COUNT };
+enum { PM355_HAS_EMBD = 1, PM355_HAS_HEAD = 2 };
+
+/* A model holds the tensors of layers [layer_lo, layer_hi) — the window prima.cpp's piped-ring assigns to this
+ * rank (this_layer_is_mine, src/llama.cpp:3838-3852) — plus tok_embd (HAS_EMBD) and output_norm/output (HAS_HEAD). */
+PM355_API pm355_model * pm355_model_new(const pm355_hparams * hp, int layer_lo, int layer_hi, int flags);
+PM355_API void pm355_model_free(pm355_model * m);
+PM355_API const char * pm355_model_error(pm355_model * m);
+/* ggml_backend_tensor_set semantics with async staging: host bytes in GGUF block order are streamed through
+ * pinned double buffers (hipMemcpyAsync) and re-ordered into the HBM layout on the device
+ * (replaces load_all_data's synchronous upload, src/llama.cpp:5418-5640). layer = -1 for per-model tensors. */
+PM355_API int pm355_model_set_tensor(pm355_model * m, int kind, int layer, int type, const void * host_data, size_t nbytes);
+/* synthetic tensor generated in HBM (no host traffic) */
+PM355_API int pm355_model_fill_tensor(pm355_model * m, int kind, int layer, int type, uint64_t seed, float scale);
+/* allocate KV cache (F16, zero-cleared: llama_kv_cache_init src/llama.cpp:3889-3992) + scratch for max_tokens per call */
+PM355_API int pm355_model_finalize(pm355_model * m, int max_tokens);
+PM355_API size_t pm355_model_weight_bytes(const pm355_model * m);     /* matmul weight bytes read per token */
+PM355_API size_t pm355_model_kv_bytes_per_pos(const pm355_model * m); /* KV bytes read per cached position */
+PM355_API int pm355_model_kv_clear(pm355_model * m, pm355_stream_t stream);
+PM355_API void * pm355_model_kv_ptr(pm355_model * m, int layer, int which /*0=K,1=V*/);
+/* One pass of the window over n_tokens tokens at positions pos0.. (causal, single sequence).
+ *   input : d_tokens (int32, needs HAS_EMBD) or d_x_in (f32 [n_tokens][n_embd], the activation handed over by the
+ *           previous rank: llama_recv_tensors src/llama.cpp:18054)
+ *   output: d_x_out (f32 [n_tokens][n_embd], residual stream after layer_hi-1; may be NULL), and with HAS_HEAD
+ *           d_logits (f32 [n_vocab], LAST token) / d_argmax (int32) when non-NULL.
+ * Equivalent of the per-sub-graph body of llama_decode_internal's ring loop (src/llama.cpp:18503-18564). */
+PM355_API int pm355_model_decode(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, int n_tokens, int pos0,
+                                 float * d_x_out, float * d_logits, int32_t * d_argmax, pm355_stream_t stream);
+/* Device-resident greedy loop (needs HAS_EMBD|HAS_HEAD and the whole model in one window): starting from the token
+ * in d_tokens_io[0] at position pos0, generate n_steps tokens; step i reads d_tokens_io[i], writes d_tokens_io[i+1].
+ * One captured hipGraph per step, replayed; no host synchronisation inside. */
+PM355_API int pm355_model_generate(pm355_model * m, int32_t * d_tokens_io, int pos0, int n_steps, int use_graph,
+                                   pm355_stream_t stream);
+/* single-token step with the position held in device memory (graph-replayable building block of the piped ring):
+ * x_in/x_out as above, position = internal device counter set by pm355_model_set_pos and advanced by `advance`. */
+PM355_API int pm355_model_set_pos(pm355_model * m, int pos, pm355_stream_t stream);
+PM355_API int pm355_model_step(pm355_model * m, const int32_t * d_token, const float * d_x_in, float * d_x_out,
+                               float * d_logits, int32_t * d_argmax, int advance, int use_graph, pm355_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

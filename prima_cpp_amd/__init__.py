@@ -5,4 +5,4 @@ The product is `libprima_mi355.so` (hand-written HIP for gfx950, C ABI in includ
 binding used by tests/ and bench.py: ctypes over the C ABI, torch for device memory / streams /
 torch.distributed. There is NO CPU fallback: every op raises if the HIP library is missing.
 """
-from .lib import (F16, F32, Q4_K, Q5_K, Q6_K, Q8_0, Q8_K, PM355Error, lib, lib_path, load, row_size)  # noqa: F401
+from .lib import (F16, F32, Q4_K, Q5_K, Q6_K, Q8_0, Q8_K, PM355Error, lib_path, load, row_size)  # noqa: F401

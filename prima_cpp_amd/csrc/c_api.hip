@@ -2,6 +2,7 @@
 #include "../../include/prima_mi355.h"
 #include "pm355_device.h"
 #include "pm355_kernels.h"
+#include "pm355_layer_ops.h"
 #include <stdio.h>
 #include <string.h>
 
@@ -132,6 +133,43 @@ int pm355_mul_mat_vec_q_dbg(int type, const void * W, int64_t K, int64_t N, cons
     pm_gemv_args a = {};
     a.type = type; a.K = (int) K; a.N = (int) N; a.W = W; a.xq = xq; a.ncols = 1; a.y = y; a.y_stride = (size_t) N; a.dbg_int = ip;
     return gemv_rc(pm_launch_gemv(a, S(st)));
+}
+
+int pm355_get_rows(int type, const void * table, int64_t K, const int32_t * d_tokens, int n_tokens, float * out, pm355_stream_t st) {
+    if (!pm_weight_row_bytes(type, K)) return fail(PM355_E_UNSUPPORTED, "get_rows: type");
+    pm_launch_embed(type, table, (int) K, d_tokens, n_tokens, out, S(st));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pm355_rope_kv_store(const float * q, const float * k, const float * v, float * q_out, float * k_out_f32,
+                        void * kc, void * vc, const int32_t * d_pos0, const float * ff, int n_tokens, int H, int Hkv, int dh,
+                        int n_ctx, const pm355_rope_params * rp, pm355_stream_t st) {
+    if (!rp || rp->n_dims % 2 || rp->n_dims > dh || dh % 2) return fail(PM355_E_SHAPE, "rope: n_dims");
+    pm_rope_cfg c;
+    c.n_dims = rp->n_dims; c.mode = rp->mode; c.n_ctx_orig = rp->n_ctx_orig; c.freq_base = rp->freq_base; c.freq_scale = rp->freq_scale;
+    c.ext_factor = rp->ext_factor; c.attn_factor = rp->attn_factor; c.beta_fast = rp->beta_fast; c.beta_slow = rp->beta_slow;
+    pm_rope_params(c);
+    pm_launch_rope_kv_store(q, k, v, q_out, k_out_f32, kc, vc, d_pos0, ff, n_tokens, H, Hkv, dh, n_ctx, c, S(st));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pm355_attn_decode(const float * q, const void * kc, const void * vc, const int32_t * d_pos0, float * out, int n_tokens,
+                      int H, int Hkv, int dh, int n_ctx, float kq_scale, pm355_stream_t st) {
+    if (pm_launch_attn_decode(q, kc, vc, d_pos0, out, n_tokens, H, Hkv, dh, n_ctx, kq_scale, S(st)))
+        return fail(PM355_E_RANGE, "attn_decode: n_ctx/head_dim unsupported (LDS budget 150 KB, multiples of 8)");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pm355_argmax(const float * x, int64_t n, int32_t * d_index, float * d_value, pm355_stream_t st) {
+    pm_launch_argmax(x, (int) n, d_index, d_value, S(st)); HIP_TRY(hipGetLastError()); return 0;
+}
+int pm355_add(const float * a, const float * b, float * y, int64_t n, int64_t nb, pm355_stream_t st) { pm_launch_add(a, b, y, n, nb, S(st)); HIP_TRY(hipGetLastError()); return 0; }
+int pm355_mul(const float * a, const float * b, float * y, int64_t n, int64_t nb, pm355_stream_t st) { pm_launch_mul(a, b, y, n, nb, S(st)); HIP_TRY(hipGetLastError()); return 0; }
+int pm355_silu_mul(const float * g, const float * u, float * y, int64_t n, pm355_stream_t st) { pm_launch_silu_mul(g, u, y, n, S(st)); HIP_TRY(hipGetLastError()); return 0; }
+int pm355_scale(const float * a, float * y, float s, int64_t n, pm355_stream_t st) { pm_launch_scale(a, y, s, n, S(st)); HIP_TRY(hipGetLastError()); return 0; }
+int pm355_fill_random_blocks(int type, void * dst, int64_t K, int64_t nrows, uint64_t seed, float scale, pm355_stream_t st) {
+    if (!pm_weight_row_bytes(type, K)) return fail(PM355_E_UNSUPPORTED, "fill_random_blocks: type");
+    pm_launch_fill_random_blocks(type, dst, K, nrows, seed, scale, S(st)); HIP_TRY(hipGetLastError()); return 0;
 }
 
 } // extern "C"

@@ -1,0 +1,450 @@
+// engine.hip — resident decoder for one piped-ring layer window (C ABI part (B) of include/prima_mi355.h).
+//
+// What it replaces in the reference (per token, per rank): llama_build_graph + ggml_backend_sched_alloc_graph +
+// llama_graph_compute + the D2H/H2D activation bounce of llama_decode_internal's ring loop
+// (src/llama.cpp:18455-18564). Here the layer window's kernel sequence is fixed at finalize() time,
+// positions live in device memory, and the whole single-token step is one hipGraph that is replayed.
+//
+// HBM layout: all weights of the window resident (288 GB per GPU: Llama-3-70B Q4_K_M is 42.5 GB),
+// one allocation per tensor in the layouts of mmvq.hip / repack.hip; KV cache F16, K [n_ctx][Hkv*dh],
+// V transposed [Hkv*dh][n_ctx] per layer (reference layout without flash-attn, src/llama.cpp:9707-9714).
+#include "../../include/prima_mi355.h"
+#include "pm355_device.h"
+#include "pm355_kernels.h"
+#include "pm355_layer_ops.h"
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+struct Tensor { void * d = nullptr; int type = -1; int64_t K = 0, N = 0; size_t bytes = 0; };
+
+struct Layer { Tensor t[12]; void * kc = nullptr; void * vc = nullptr; };
+
+} // namespace
+
+struct pm355_model {
+    pm355_hparams hp;
+    int lo, hi, flags;
+    std::vector<Layer> layers;            // hi - lo
+    Tensor tok_embd, out_norm, output, rope_freqs;
+    int max_tokens = 0;
+    bool finalized = false;
+    pm_rope_cfg rope;
+    // scratch (device)
+    float * x = nullptr, * x1 = nullptr, * q = nullptr, * k = nullptr, * v = nullptr, * att = nullptr, * h = nullptr;
+    float * logits = nullptr, * xn = nullptr;
+    uint8_t * aq_k = nullptr, * aq_0 = nullptr;     // quantized activation scratch (Q8_K / Q8_0), sized for max(K)
+    int32_t * d_pos = nullptr, * d_tok = nullptr;
+    // staging for set_tensor
+    void * pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2]; void * dstage = nullptr; size_t stage_bytes = 0;
+    hipStream_t up_stream = nullptr;
+    // graphs
+    hipGraphExec_t step_exec = nullptr; const void * g_in = nullptr; void * g_out = nullptr; void * g_logits = nullptr;
+    void * g_argmax = nullptr; const void * g_tok = nullptr; int g_adv = -1; hipStream_t g_stream = nullptr;
+    char err[256];
+};
+
+namespace {
+
+int tensor_shape(const pm355_model * m, int kind, int64_t & K, int64_t & N) {
+    const pm355_hparams & h = m->hp;
+    const int64_t E = h.n_embd, Eq = (int64_t) h.head_dim * h.n_head, Ekv = (int64_t) h.head_dim * h.n_head_kv, F = h.n_ff;
+    switch (kind) {
+        case PM355_T_ATTN_NORM: case PM355_T_FFN_NORM: case PM355_T_OUT_NORM: K = E; N = 1; return 0;
+        case PM355_T_WQ: K = E; N = Eq; return 0;
+        case PM355_T_WK: case PM355_T_WV: K = E; N = Ekv; return 0;
+        case PM355_T_WO: K = Eq; N = E; return 0;
+        case PM355_T_FFN_GATE: case PM355_T_FFN_UP: K = E; N = F; return 0;
+        case PM355_T_FFN_DOWN: K = F; N = E; return 0;
+        case PM355_T_BQ: K = Eq; N = 1; return 0;
+        case PM355_T_BK: case PM355_T_BV: K = Ekv; N = 1; return 0;
+        case PM355_T_TOK_EMBD: case PM355_T_OUTPUT: K = E; N = h.n_vocab; return 0;
+        case PM355_T_ROPE_FREQS: K = h.head_dim / 2; N = 1; return 0;
+    }
+    return -1;
+}
+
+Tensor * tensor_slot(pm355_model * m, int kind, int layer) {
+    if (kind < 12) {
+        if (layer < m->lo || layer >= m->hi) return nullptr;
+        return &m->layers[layer - m->lo].t[kind];
+    }
+    switch (kind) {
+        case PM355_T_TOK_EMBD: return &m->tok_embd;
+        case PM355_T_OUT_NORM: return &m->out_norm;
+        case PM355_T_OUTPUT: return &m->output;
+        case PM355_T_ROPE_FREQS: return &m->rope_freqs;
+    }
+    return nullptr;
+}
+
+int seterr(pm355_model * m, int code, const char * msg) { snprintf(m->err, sizeof(m->err), "%s", msg); return code; }
+
+int alloc_tensor(pm355_model * m, Tensor * t, int kind, int type) {
+    int64_t K, N;
+    if (tensor_shape(m, kind, K, N)) return PM355_E_UNSUPPORTED;
+    const size_t rb = pm_weight_row_bytes(type, K);
+    if (!rb) return PM355_E_UNSUPPORTED;
+    if (t->d) { (void) hipFree(t->d); t->d = nullptr; }
+    t->type = type; t->K = K; t->N = N; t->bytes = rb * (size_t) N;
+    if (hipMalloc(&t->d, t->bytes + 256) != hipSuccess) return PM355_E_NOMEM;    // +256: tail slack for 16-B vector reads
+    return 0;
+}
+
+bool is_matrix(int kind) {
+    return (kind >= PM355_T_WQ && kind <= PM355_T_WO) || (kind >= PM355_T_FFN_GATE && kind <= PM355_T_FFN_DOWN) ||
+           kind == PM355_T_TOK_EMBD || kind == PM355_T_OUTPUT;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// synthetic data in HBM
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pm_hash(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (uint32_t) x;
+}
+// every dword random; then the fp16 scale fields are overwritten with finite values of magnitude ~scale
+__global__ void fill_random_blocks_kernel(int type, uint32_t * dst, long n_dwords, long nb_total, long nb_row, uint64_t seed, float scale) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_dwords) dst[i] = pm_hash(seed * 0x9E3779B97F4A7C15ULL + (uint64_t) i);
+}
+__global__ void fix_scales_kernel(int type, uint8_t * dst, long nb_total, long nb_row, long row_bytes, uint64_t seed, float scale) {
+    const long b = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb_total) return;
+    const long row = b / nb_row, bi = b % nb_row;
+    uint8_t * r = dst + row * row_bytes;
+    const float u = 0.5f + (float) (pm_hash(seed ^ (0xABCDEF12345ULL + (uint64_t) b)) & 0xFFFF) / 65536.0f;   // [0.5, 1.5)
+    if (type == PM_Q4_K || type == PM_Q5_K) {
+        uint16_t * h = (uint16_t *) (r + bi * (type == PM_Q4_K ? PM_BS_Q4_K : PM_BS_Q5_K));
+        const float qmax = type == PM_Q4_K ? 15.f : 31.f;
+        h[0] = f2h(u * scale / (qmax * 32.f));
+        h[1] = f2h(u * scale / 64.f);
+    } else if (type == PM_Q6_K) {
+        ((uint16_t *) (r + nb_row * 208))[bi] = f2h(u * scale / 2048.f);
+    } else if (type == PM_Q8_0) {
+        ((uint16_t *) (r + nb_row * 32))[bi] = f2h(u * scale / 64.f);
+    }
+}
+__global__ void fill_random_f32_kernel(float * dst, long n, uint64_t seed, float mean, float amp) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = mean + amp * ((float) (pm_hash(seed + (uint64_t) i) & 0xFFFFFF) / 8388608.0f - 1.0f);
+}
+__global__ void fill_random_f16_kernel(uint16_t * dst, long n, uint64_t seed, float amp) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = f2h(amp * ((float) (pm_hash(seed + (uint64_t) i) & 0xFFFFFF) / 8388608.0f - 1.0f));
+}
+
+void pm_launch_fill_random_blocks(int type, void * dst, int64_t K, int64_t nrows, uint64_t seed, float scale, hipStream_t st) {
+    const size_t rb = pm_weight_row_bytes(type, K);
+    const long n = (long) (rb * nrows);
+    if (type == PM_F32) { hipLaunchKernelGGL(fill_random_f32_kernel, dim3((unsigned) ((n / 4 + 255) / 256)), dim3(256), 0, st, (float *) dst, n / 4, seed, 0.0f, scale); return; }
+    if (type == PM_F16) { hipLaunchKernelGGL(fill_random_f16_kernel, dim3((unsigned) ((n / 2 + 255) / 256)), dim3(256), 0, st, (uint16_t *) dst, n / 2, seed, scale); return; }
+    const long nd = (n + 3) / 4;
+    const long nb_row = type == PM_Q8_0 ? K / 32 : K / 256;
+    hipLaunchKernelGGL(fill_random_blocks_kernel, dim3((unsigned) ((nd + 255) / 256)), dim3(256), 0, st, type, (uint32_t *) dst, nd, nb_row * nrows, nb_row, seed, scale);
+    hipLaunchKernelGGL(fix_scales_kernel, dim3((unsigned) ((nb_row * nrows + 255) / 256)), dim3(256), 0, st, type, (uint8_t *) dst, nb_row * nrows, nb_row, (long) rb, seed, scale);
+}
+void pm_launch_fill_random_f32(float * dst, int64_t n, uint64_t seed, float mean, float amp, hipStream_t st) {
+    hipLaunchKernelGGL(fill_random_f32_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, dst, (long) n, seed, mean, amp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// the window's kernel sequence
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// quantize `src` [T][K] into the activation format(s) the given weights need; returns pointers
+struct ActQ { const void * k = nullptr; const void * z = nullptr; };
+ActQ quantize_for(pm355_model * m, const float * src, int K, int T, const Tensor * const * ws, int nw, hipStream_t st) {
+    ActQ a; bool need_k = false, need_0 = false;
+    for (int i = 0; i < nw; ++i) if (ws[i] && ws[i]->d) { if (ws[i]->type == PM_Q8_0) need_0 = true; else need_k = true; }
+    if (need_k) { pm_launch_quantize_q8k(src, m->aq_k, K, T, st); a.k = m->aq_k; }
+    if (need_0) { pm_launch_quantize_q80(src, m->aq_0, K, T, st); a.z = m->aq_0; }
+    return a;
+}
+
+ActQ norm_quantize_for(pm355_model * m, const float * src, const float * w, int K, int T, const Tensor * const * ws, int nw, hipStream_t st) {
+    bool need_0 = false;
+    for (int i = 0; i < nw; ++i) if (ws[i] && ws[i]->d && ws[i]->type == PM_Q8_0) need_0 = true;
+    if (!need_0) {
+        pm_launch_rmsnorm_q8k(src, w, nullptr, m->aq_k, K, T, m->hp.rms_eps, st);
+        ActQ a; a.k = m->aq_k; return a;
+    }
+    pm_launch_rmsnorm_q8k(src, w, m->xn, nullptr, K, T, m->hp.rms_eps, st);
+    return quantize_for(m, m->xn, K, T, ws, nw, st);
+}
+
+int gemv(const Tensor & w, const Tensor * w2, const ActQ & a, int T, float * y, const float * bias, const float * resid, hipStream_t st) {
+    pm_gemv_args g = {};
+    g.type = w.type; g.K = (int) w.K; g.N = (int) w.N; g.W = w.d; g.W2 = w2 ? w2->d : nullptr;
+    g.xq = w.type == PM_Q8_0 ? a.z : a.k; g.ncols = T; g.y = y; g.y_stride = (size_t) w.N; g.bias = bias; g.resid = resid;
+    return pm_launch_gemv(g, st);
+}
+
+// x_in -> x_out for layers [lo, hi); positions from device memory d_pos (pos of token 0)
+int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, int T, float * d_x_out,
+               float * d_logits, int32_t * d_argmax, hipStream_t st) {
+    const pm355_hparams & hp = m->hp;
+    const int E = hp.n_embd, H = hp.n_head, Hkv = hp.n_head_kv, dh = hp.head_dim, F = hp.n_ff;
+    const int Eq = H * dh;
+    const float kq_scale = 1.0f / sqrtf((float) dh);
+    const float * cur = d_x_in;
+    if (d_tokens) {
+        if (!(m->flags & PM355_HAS_EMBD) || !m->tok_embd.d) return seterr(m, PM355_E_UNSUPPORTED, "decode: tokens given but window has no tok_embd");
+        pm_launch_embed(m->tok_embd.type, m->tok_embd.d, E, d_tokens, T, m->x, st);
+        cur = m->x;
+    }
+    if (!cur) return seterr(m, PM355_E_SHAPE, "decode: neither tokens nor x_in");
+    float * bufs[2] = {m->x, m->x1};
+    for (int il = m->lo; il < m->hi; ++il) {
+        Layer & L = m->layers[il - m->lo];
+        const Tensor * qkv[3] = {&L.t[PM355_T_WQ], &L.t[PM355_T_WK], &L.t[PM355_T_WV]};
+        // attn_norm (+weight), quantized for q/k/v in the same pass when only Q8_K is needed
+        ActQ a = norm_quantize_for(m, cur, (const float *) L.t[PM355_T_ATTN_NORM].d, E, T, qkv, 3, st);
+        int rc = 0;
+        rc |= gemv(L.t[PM355_T_WQ], nullptr, a, T, m->q, (const float *) L.t[PM355_T_BQ].d, nullptr, st);
+        rc |= gemv(L.t[PM355_T_WK], nullptr, a, T, m->k, (const float *) L.t[PM355_T_BK].d, nullptr, st);
+        rc |= gemv(L.t[PM355_T_WV], nullptr, a, T, m->v, (const float *) L.t[PM355_T_BV].d, nullptr, st);
+        if (rc) return seterr(m, rc, "decode: qkv gemv");
+        pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, (const float *) m->rope_freqs.d,
+                                T, H, Hkv, dh, hp.n_ctx, m->rope, st);
+        if (pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
+            return seterr(m, PM355_E_RANGE, "decode: n_ctx too large for the decode-attention kernel");
+        const Tensor * wo[1] = {&L.t[PM355_T_WO]};
+        a = quantize_for(m, m->att, Eq, T, wo, 1, st);
+        float * x_mid = (cur == bufs[0]) ? bufs[1] : bufs[0];                 // ffn_inp = wo.att + inpSA
+        if (gemv(L.t[PM355_T_WO], nullptr, a, T, x_mid, nullptr, cur, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: wo gemv");
+        const Tensor * gu[2] = {&L.t[PM355_T_FFN_GATE], &L.t[PM355_T_FFN_UP]};
+        a = norm_quantize_for(m, x_mid, (const float *) L.t[PM355_T_FFN_NORM].d, E, T, gu, 2, st);
+        if (L.t[PM355_T_FFN_GATE].type != L.t[PM355_T_FFN_UP].type)
+            return seterr(m, PM355_E_UNSUPPORTED, "decode: ffn_gate and ffn_up of different types");
+        if (gemv(L.t[PM355_T_FFN_GATE], &L.t[PM355_T_FFN_UP], a, T, m->h, nullptr, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: gate/up gemv");
+        const Tensor * dn[1] = {&L.t[PM355_T_FFN_DOWN]};
+        a = quantize_for(m, m->h, F, T, dn, 1, st);
+        // `cur` is dead after the wo GEMV consumed it as residual, so the other scratch buffer can be reused
+        float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : ((x_mid == bufs[0]) ? bufs[1] : bufs[0]);
+        if (gemv(L.t[PM355_T_FFN_DOWN], nullptr, a, T, x_next, nullptr, x_mid, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: down gemv");
+        cur = x_next;
+    }
+    if (d_x_out && cur != d_x_out) (void) hipMemcpyAsync(d_x_out, cur, (size_t) T * E * 4, hipMemcpyDeviceToDevice, st);
+    if ((d_logits || d_argmax) && (m->flags & PM355_HAS_HEAD)) {
+        if (!m->output.d || !m->out_norm.d) return seterr(m, PM355_E_UNSUPPORTED, "decode: head tensors missing");
+        const float * last = cur + (size_t) (T - 1) * E;
+        const Tensor * ow[1] = {&m->output};
+        ActQ a = norm_quantize_for(m, last, (const float *) m->out_norm.d, E, 1, ow, 1, st);
+        float * lg = d_logits ? d_logits : m->logits;
+        if (gemv(m->output, nullptr, a, 1, lg, nullptr, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: lm_head gemv");
+        if (d_argmax) pm_launch_argmax(lg, hp.n_vocab, d_argmax, nullptr, st);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : seterr(m, PM355_E_HIP, "decode: kernel launch failed");
+}
+
+} // namespace
+
+extern "C" {
+
+pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flags) {
+    if (!hp || lo < 0 || hi > hp->n_layer || lo > hi) return nullptr;
+    if (hp->head_dim % 8 || hp->n_embd % 256 || hp->n_head % hp->n_head_kv) return nullptr;
+    pm355_model * m = new pm355_model();
+    m->hp = *hp; m->lo = lo; m->hi = hi; m->flags = flags;
+    m->layers.resize(hi - lo);
+    m->err[0] = 0;
+    m->rope.n_dims = hp->head_dim; m->rope.mode = hp->arch == 1 ? 2 : 0; m->rope.n_ctx_orig = hp->n_ctx_orig;
+    m->rope.freq_base = hp->rope_freq_base; m->rope.freq_scale = hp->rope_freq_scale;
+    m->rope.ext_factor = 0.0f; m->rope.attn_factor = 1.0f; m->rope.beta_fast = 32.0f; m->rope.beta_slow = 1.0f;
+    pm_rope_params(m->rope);
+    return m;
+}
+
+void pm355_model_free(pm355_model * m) {
+    if (!m) return;
+    (void) hipDeviceSynchronize();
+    if (m->step_exec) (void) hipGraphExecDestroy(m->step_exec);
+    for (auto & L : m->layers) { for (auto & t : L.t) if (t.d) (void) hipFree(t.d); if (L.kc) (void) hipFree(L.kc); if (L.vc) (void) hipFree(L.vc); }
+    Tensor * g[4] = {&m->tok_embd, &m->out_norm, &m->output, &m->rope_freqs};
+    for (auto t : g) if (t->d) (void) hipFree(t->d);
+    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->dstage};
+    for (auto p : s) if (p) (void) hipFree(p);
+    for (int i = 0; i < 2; ++i) if (m->pin[i]) { (void) hipHostFree(m->pin[i]); (void) hipEventDestroy(m->pin_ev[i]); }
+    if (m->up_stream) (void) hipStreamDestroy(m->up_stream);
+    delete m;
+}
+
+int pm355_model_set_tensor(pm355_model * m, int kind, int layer, int type, const void * host, size_t nbytes) {
+    Tensor * t = tensor_slot(m, kind, layer);
+    if (!t) return seterr(m, PM355_E_RANGE, "set_tensor: tensor not in this window");
+    int rc = alloc_tensor(m, t, kind, type);
+    if (rc) return seterr(m, rc, "set_tensor: alloc");
+    if (nbytes != t->bytes) return seterr(m, PM355_E_SHAPE, "set_tensor: byte size does not match type/shape");
+    // pinned double-buffered staging: host -> pinned (CPU memcpy) -> device (hipMemcpyAsync) -> repack kernel
+    const size_t CH = 32u << 20;
+    if (!m->up_stream) {
+        if (hipStreamCreateWithFlags(&m->up_stream, hipStreamNonBlocking) != hipSuccess) return seterr(m, PM355_E_HIP, "set_tensor: stream");
+        for (int i = 0; i < 2; ++i) {
+            if (hipHostMalloc(&m->pin[i], CH, hipHostMallocDefault) != hipSuccess) return seterr(m, PM355_E_NOMEM, "set_tensor: pinned");
+            (void) hipEventCreateWithFlags(&m->pin_ev[i], hipEventDisableTiming);
+        }
+    }
+    const bool repack = (type == PM_Q6_K || type == PM_Q8_0) && is_matrix(kind);
+    const size_t rb = pm_weight_row_bytes(type, t->K);
+    const size_t rows_per_chunk = repack ? (CH / rb ? CH / rb : 1) : 0;
+    const size_t chunk = repack ? rows_per_chunk * rb : CH;
+    if (repack && chunk > CH) return seterr(m, PM355_E_RANGE, "set_tensor: row larger than staging chunk");
+    if (repack && m->stage_bytes < CH) {
+        if (m->dstage) (void) hipFree(m->dstage);
+        if (hipMalloc(&m->dstage, 2 * CH) != hipSuccess) return seterr(m, PM355_E_NOMEM, "set_tensor: device staging");
+        m->stage_bytes = CH;
+    }
+    size_t off = 0; int b = 0;
+    while (off < nbytes) {
+        const size_t n = nbytes - off < chunk ? nbytes - off : chunk;
+        (void) hipEventSynchronize(m->pin_ev[b]);                       // previous use of this pinned buffer done
+        memcpy(m->pin[b], (const char *) host + off, n);
+        if (repack) {
+            char * ds = (char *) m->dstage + (size_t) b * CH;
+            (void) hipMemcpyAsync(ds, m->pin[b], n, hipMemcpyHostToDevice, m->up_stream);
+            pm_launch_repack(type, ds, (char *) t->d + off, t->K, (int64_t) (n / rb), 1, m->up_stream);
+        } else {
+            (void) hipMemcpyAsync((char *) t->d + off, m->pin[b], n, hipMemcpyHostToDevice, m->up_stream);
+        }
+        (void) hipEventRecord(m->pin_ev[b], m->up_stream);
+        off += n; b ^= 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : seterr(m, PM355_E_HIP, "set_tensor: upload failed");
+}
+
+int pm355_model_fill_tensor(pm355_model * m, int kind, int layer, int type, uint64_t seed, float scale) {
+    Tensor * t = tensor_slot(m, kind, layer);
+    if (!t) return seterr(m, PM355_E_RANGE, "fill_tensor: tensor not in this window");
+    int rc = alloc_tensor(m, t, kind, type);
+    if (rc) return seterr(m, rc, "fill_tensor: alloc");
+    if (!is_matrix(kind)) {
+        if (type != PM_F32) return seterr(m, PM355_E_UNSUPPORTED, "fill_tensor: 1-D tensors are F32");
+        const bool norm = kind == PM355_T_ATTN_NORM || kind == PM355_T_FFN_NORM || kind == PM355_T_OUT_NORM;
+        pm_launch_fill_random_f32((float *) t->d, t->K, seed, norm ? 1.0f : (kind == PM355_T_ROPE_FREQS ? 4.0f : 0.0f),
+                                  norm ? 0.05f : (kind == PM355_T_ROPE_FREQS ? 3.0f : scale), nullptr);
+    } else {
+        pm_launch_fill_random_blocks(type, t->d, t->K, t->N, seed, scale, nullptr);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : seterr(m, PM355_E_HIP, "fill_tensor");
+}
+
+int pm355_model_finalize(pm355_model * m, int max_tokens) {
+    if (m->up_stream) (void) hipStreamSynchronize(m->up_stream);
+    (void) hipDeviceSynchronize();
+    const pm355_hparams & hp = m->hp;
+    const size_t E = hp.n_embd, Eq = (size_t) hp.head_dim * hp.n_head, Ekv = (size_t) hp.head_dim * hp.n_head_kv, F = hp.n_ff;
+    const size_t T = max_tokens < 1 ? 1 : max_tokens;
+    m->max_tokens = (int) T;
+    for (int il = m->lo; il < m->hi; ++il) {
+        Layer & L = m->layers[il - m->lo];
+        for (int kd : {PM355_T_ATTN_NORM, PM355_T_WQ, PM355_T_WK, PM355_T_WV, PM355_T_WO, PM355_T_FFN_NORM, PM355_T_FFN_GATE, PM355_T_FFN_UP, PM355_T_FFN_DOWN})
+            if (!L.t[kd].d) return seterr(m, PM355_E_SHAPE, "finalize: a layer tensor is missing");
+        const size_t kvb = Ekv * (size_t) hp.n_ctx * 2;
+        if (hipMalloc(&L.kc, kvb + 256) != hipSuccess || hipMalloc(&L.vc, kvb + 256) != hipSuccess) return seterr(m, PM355_E_NOMEM, "finalize: kv cache");
+        (void) hipMemset(L.kc, 0, kvb + 256); (void) hipMemset(L.vc, 0, kvb + 256);
+    }
+    const size_t maxK = F > Eq ? (F > E ? F : E) : (Eq > E ? Eq : E);
+    auto A = [&](void ** p, size_t n) { return hipMalloc(p, n + 256) == hipSuccess; };
+    bool ok = A((void **) &m->x, T * E * 4) && A((void **) &m->x1, T * E * 4) && A((void **) &m->xn, T * E * 4) &&
+              A((void **) &m->q, T * Eq * 4) && A((void **) &m->k, T * Ekv * 4) && A((void **) &m->v, T * Ekv * 4) &&
+              A((void **) &m->att, T * Eq * 4) && A((void **) &m->h, T * F * 4) && A((void **) &m->logits, (size_t) hp.n_vocab * 4) &&
+              A((void **) &m->aq_k, T * pm_q8k_row_bytes((int) ((maxK + 255) / 256 * 256))) &&
+              A((void **) &m->aq_0, T * pm_q80_row_bytes((int) ((maxK + 31) / 32 * 32))) &&
+              A((void **) &m->d_pos, 64) && A((void **) &m->d_tok, 64 + T * 4);
+    if (!ok) return seterr(m, PM355_E_NOMEM, "finalize: scratch");
+    (void) hipMemset(m->d_pos, 0, 64);
+    (void) hipDeviceSynchronize();
+    m->finalized = true;
+    return hipGetLastError() == hipSuccess ? 0 : seterr(m, PM355_E_HIP, "finalize");
+}
+
+size_t pm355_model_weight_bytes(const pm355_model * m) {
+    size_t n = 0;
+    for (auto & L : m->layers) for (int kd = 0; kd < 12; ++kd) n += L.t[kd].bytes;
+    if (m->flags & PM355_HAS_HEAD) n += m->output.bytes + m->out_norm.bytes;
+    return n;
+}
+size_t pm355_model_kv_bytes_per_pos(const pm355_model * m) {
+    return (size_t) (m->hi - m->lo) * 2 * (size_t) m->hp.head_dim * m->hp.n_head_kv * 2;
+}
+int pm355_model_kv_clear(pm355_model * m, pm355_stream_t st) {
+    const size_t kvb = (size_t) m->hp.head_dim * m->hp.n_head_kv * (size_t) m->hp.n_ctx * 2;
+    for (auto & L : m->layers) { (void) hipMemsetAsync(L.kc, 0, kvb, (hipStream_t) st); (void) hipMemsetAsync(L.vc, 0, kvb, (hipStream_t) st); }
+    return 0;
+}
+void * pm355_model_kv_ptr(pm355_model * m, int layer, int which) {
+    if (layer < m->lo || layer >= m->hi) return nullptr;
+    return which ? m->layers[layer - m->lo].vc : m->layers[layer - m->lo].kc;
+}
+const char * pm355_model_error(pm355_model * m) { return m->err; }
+
+int pm355_model_set_pos(pm355_model * m, int pos, pm355_stream_t st) {
+    if (!m->finalized) return seterr(m, PM355_E_SHAPE, "set_pos: model not finalized");
+    pm_launch_set_pos(m->d_pos, pos, (hipStream_t) st);      // value travels as a kernel argument: capture-safe, no host buffer
+    return 0;
+}
+
+int pm355_model_decode(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, int T, int pos0,
+                       float * d_x_out, float * d_logits, int32_t * d_argmax, pm355_stream_t st) {
+    if (!m->finalized) return seterr(m, PM355_E_SHAPE, "decode: model not finalized");
+    if (T < 1 || T > m->max_tokens) return seterr(m, PM355_E_RANGE, "decode: n_tokens exceeds finalize(max_tokens)");
+    if (pos0 < 0 || pos0 + T > m->hp.n_ctx) return seterr(m, PM355_E_RANGE, "decode: position outside n_ctx");
+    int rc = pm355_model_set_pos(m, pos0, st);
+    if (rc) return rc;
+    return run_window(m, d_tokens, d_x_in, T, d_x_out, d_logits, d_argmax, (hipStream_t) st);
+}
+
+int pm355_model_step(pm355_model * m, const int32_t * d_token, const float * d_x_in, float * d_x_out,
+                     float * d_logits, int32_t * d_argmax, int advance, int use_graph, pm355_stream_t pst) {
+    if (!m->finalized) return seterr(m, PM355_E_SHAPE, "step: model not finalized");
+    hipStream_t st = (hipStream_t) pst;
+    if (!use_graph) {
+        int rc = run_window(m, d_token, d_x_in, 1, d_x_out, d_logits, d_argmax, st);
+        if (rc) return rc;
+        if (advance) pm_launch_inc_pos(m->d_pos, advance, st);
+        return 0;
+    }
+    const bool same = m->step_exec && m->g_in == d_x_in && m->g_out == d_x_out && m->g_logits == d_logits &&
+                      m->g_argmax == d_argmax && m->g_tok == d_token && m->g_adv == advance;
+    if (!same) {
+        if (m->step_exec) { (void) hipGraphExecDestroy(m->step_exec); m->step_exec = nullptr; }
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) return seterr(m, PM355_E_HIP, "step: begin capture");
+        int rc = run_window(m, d_token, d_x_in, 1, d_x_out, d_logits, d_argmax, st);
+        if (!rc && advance) pm_launch_inc_pos(m->d_pos, advance, st);
+        hipError_t e = hipStreamEndCapture(st, &g);
+        if (rc || e != hipSuccess || !g) { if (g) (void) hipGraphDestroy(g); return rc ? rc : seterr(m, PM355_E_HIP, "step: end capture"); }
+        e = hipGraphInstantiate(&m->step_exec, g, nullptr, nullptr, 0);
+        (void) hipGraphDestroy(g);
+        if (e != hipSuccess) { m->step_exec = nullptr; return seterr(m, PM355_E_HIP, "step: graph instantiate"); }
+        m->g_in = d_x_in; m->g_out = d_x_out; m->g_logits = d_logits; m->g_argmax = d_argmax; m->g_tok = d_token; m->g_adv = advance;
+    }
+    return hipGraphLaunch(m->step_exec, st) == hipSuccess ? 0 : seterr(m, PM355_E_HIP, "step: graph launch");
+}
+
+// d_tokens_io[i] -> d_tokens_io[i+1]: the per-step graph reads its token from m->d_tok[0] and writes argmax to
+// m->d_tok[1]; two tiny D2D copies per step move tokens in and out (all on the stream, no host sync).
+int pm355_model_generate(pm355_model * m, int32_t * d_io, int pos0, int n_steps, int use_graph, pm355_stream_t pst) {
+    if (!m->finalized) return seterr(m, PM355_E_SHAPE, "generate: model not finalized");
+    if (!(m->flags & PM355_HAS_EMBD) || !(m->flags & PM355_HAS_HEAD)) return seterr(m, PM355_E_UNSUPPORTED, "generate: needs EMBD and HEAD");
+    if (pos0 < 0 || pos0 + n_steps > m->hp.n_ctx) return seterr(m, PM355_E_RANGE, "generate: position outside n_ctx");
+    hipStream_t st = (hipStream_t) pst;
+    int rc = pm355_model_set_pos(m, pos0, pst);
+    if (rc) return rc;
+    for (int i = 0; i < n_steps; ++i) {
+        (void) hipMemcpyAsync(m->d_tok, d_io + i, 4, hipMemcpyDeviceToDevice, st);
+        rc = pm355_model_step(m, m->d_tok, nullptr, nullptr, nullptr, m->d_tok + 1, 1, use_graph, pst);
+        if (rc) return rc;
+        (void) hipMemcpyAsync(d_io + i + 1, m->d_tok + 1, 4, hipMemcpyDeviceToDevice, st);
+    }
+    return 0;
+}
+
+} // extern "C"

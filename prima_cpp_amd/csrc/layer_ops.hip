@@ -1,0 +1,318 @@
+// layer_ops.hip — the non-GEMV ops of one transformer layer at decode (n_tokens small), gfx950.
+//
+// Reference semantics restated per kernel (paths relative to the reference repo):
+//   embed_rows      ggml_compute_forward_get_rows_q / _f32   ggml/src/ggml.c:13288, :13414 (+ dequantize_row_*)
+//   rope_kv_store   ggml_compute_forward_rope_f32 ggml.c:14143 (NORM + NEOX, freq_factors, YaRN) followed by
+//                   llm_build_kv_store src/llama.cpp:9673 (K -> F16 rows, V -> F16 TRANSPOSED [channel][n_ctx])
+//   attn_decode     llm_build_kqv src/llama.cpp:10062-10148: MUL_MAT(K f16, q->f16) ; SOFT_MAX_EXT(scale, causal mask) ;
+//                   MUL_MAT(V^T f16, p->f16) with the reference's rounding points (q and p are rounded to F16
+//                   before the dot: ggml.c:12445-12473 with vec_dot_type F16)
+//   argmax          greedy sampler llama_sampler_greedy (src/llama-sampling.cpp:390-397): first maximum wins
+//   add / silu_mul / scale / cpy  the elementwise nodes of build_llama (ggml.c:9002, :11581, :10077)
+// All are HBM/latency-bound byte movers; positions (pos) are read from DEVICE memory so that a captured
+// hipGraph can be replayed for every token without re-recording.
+#include "pm355_device.h"
+#include "pm355_kernels.h"
+#include "pm355_layer_ops.h"
+
+// ------------------------------------------------------------------------------------------------
+// generic element dequantization from the HBM layouts (slow path: embedding row lookup only)
+// ------------------------------------------------------------------------------------------------
+__device__ float pm_dequant_elem(int type, const uint8_t * row, int K, int i) {
+    switch (type) {
+    case PM_F32: return ((const float *) row)[i];
+    case PM_F16: return h2f(((const uint16_t *) row)[i]);
+    case PM_Q8_0: {                       // row-SoA: qs[K] | half d[K/32]
+        const float d = h2f(((const uint16_t *) (row + K))[i >> 5]);
+        return (float) ((const int8_t *) row)[i] * d;
+    }
+    case PM_Q4_K:
+    case PM_Q5_K: {
+        const int b = i >> 8, e = i & 255, s = e >> 5, l = e & 31;     // sub-block s, element l
+        const uint8_t * blk = row + (long) b * (type == PM_Q4_K ? PM_BS_Q4_K : PM_BS_Q5_K);
+        const uint32_t * h = (const uint32_t *) blk;
+        int sc, mn;
+        k4_scale_min(h[1], h[2], h[3], s, sc, mn);
+        const float d = h2f((uint16_t) (h[0] & 0xFFFF)), dmin = h2f((uint16_t) (h[0] >> 16));
+        const uint8_t * qs = blk + (type == PM_Q4_K ? 16 : 48);
+        int q = qs[32 * (s >> 1) + l];
+        q = (s & 1) ? (q >> 4) : (q & 0xF);
+        if (type == PM_Q5_K) q += ((blk[16 + l] >> s) & 1) << 4;
+        const float ds = d * (float) sc, ms = dmin * (float) mn;
+        return ds * (float) q - ms;
+    }
+    case PM_Q6_K: {                       // row-SoA: ql[nb][128] | qh[nb][64] | sc[nb][16] | d[nb]
+        const long nb = K / 256;
+        const int b = i >> 8, e = i & 255, hh = e >> 7, r = e & 127, k = r >> 5, l = r & 31;
+        const uint8_t lq = row[(long) b * 128 + 64 * hh + 32 * (k & 1) + l];
+        const uint8_t hq = row[nb * 128 + (long) b * 64 + 32 * hh + l];
+        const int q = (int) (((k & 2) ? (lq >> 4) : (lq & 0xF)) | (((hq >> (2 * k)) & 3) << 4)) - 32;
+        const int sc = (int) (int8_t) row[nb * 192 + (long) b * 16 + 8 * hh + 2 * k + (l >> 4)];
+        const float d = h2f(((const uint16_t *) (row + nb * 208))[b]);
+        return d * (float) sc * (float) q;
+    }
+    }
+    return 0.0f;
+}
+
+__global__ __launch_bounds__(256) void embed_rows_kernel(int type, const uint8_t * table, long row_bytes, int K,
+                                                         const int32_t * tokens, int n_tok, float * out) {
+    const int t = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tok || i >= K) return;
+    out[(long) t * K + i] = pm_dequant_elem(type, table + (long) tokens[t] * row_bytes, K, i);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE (+ KV store). One 64-thread workgroup per (head, token): lane = rotation pair index.
+// theta is built by the reference's running product (theta *= theta_scale per pair) so that the f32
+// rounding sequence is identical; cosf/sinf are the device libm (<= 2 ulp from glibc).
+// ------------------------------------------------------------------------------------------------
+struct RopeP {
+    int n_dims, mode, n_ctx_orig;
+    float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
+};
+
+__device__ __forceinline__ void rope_cs(const RopeP & r, float pos, int pair, const float * ff, float & c, float & s) {
+    float theta = pos;
+    for (int j = 0; j < pair; ++j) theta *= r.theta_scale;
+    const float f = ff ? ff[pair] : 1.0f;
+    const float te = theta / f;
+    float ti = r.freq_scale * te, th = ti, ms = r.attn_factor;
+    if (r.ext_factor != 0.0f) {
+        const float y = ((float) pair - r.corr0) / fmaxf(0.001f, r.corr1 - r.corr0);   // i0/2 == pair
+        const float ramp = 1 - fminf(1, fmaxf(0, y));
+        const float mix = ramp * r.ext_factor;
+        th = ti * (1 - mix) + te * mix;
+        ms *= 1.0f + 0.1f * logf(1.0f / r.freq_scale);
+    }
+    c = cosf(th) * ms;
+    s = sinf(th) * ms;
+}
+
+// q: [n_tok][H*dh] f32 (rotated in place into q_out), k: [n_tok][Hkv*dh], v: [n_tok][Hkv*dh]
+// K cache: f16 [n_ctx][Hkv*dh]; V cache: f16 [Hkv*dh][n_ctx] (transposed, as in the reference without flash-attn)
+__global__ __launch_bounds__(64) void rope_kv_store_kernel(const float * q, const float * k, const float * v,
+                                                           float * q_out, float * k_out_f32,
+                                                           uint16_t * kc, uint16_t * vc,
+                                                           const int32_t * pos0_ptr, const float * freq_factors,
+                                                           int H, int Hkv, int dh, int n_ctx, RopeP r) {
+    const int head = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    const int pos = *pos0_ptr + t;
+    const bool is_q = head < H;
+    const int hh = is_q ? head : head - H;
+    const float * src = is_q ? q + ((long) t * H + hh) * dh : k + ((long) t * Hkv + hh) * dh;
+    const bool neox = r.mode & 2;
+    const int half = r.n_dims / 2;
+    for (int pair = lane; pair < dh / 2; pair += 64) {
+        float o0, o1; int a, b;
+        if (pair < half) {
+            a = neox ? pair : 2 * pair;
+            b = neox ? pair + half : 2 * pair + 1;
+            float c, s;
+            rope_cs(r, (float) pos, pair, freq_factors, c, s);
+            const float x0 = src[a], x1 = src[b];
+            o0 = x0 * c - x1 * s;
+            o1 = x0 * s + x1 * c;
+        } else {                         // dims beyond n_dims pass through
+            a = r.n_dims + 2 * (pair - half); b = a + 1;
+            o0 = src[a]; o1 = src[b];
+        }
+        if (is_q) {
+            float * d = q_out + ((long) t * H + hh) * dh;
+            d[a] = o0; d[b] = o1;
+        } else {
+            if (k_out_f32) { float * d = k_out_f32 + ((long) t * Hkv + hh) * dh; d[a] = o0; d[b] = o1; }
+            uint16_t * d = kc + (long) pos * Hkv * dh + (long) hh * dh;
+            d[a] = f2h(o0); d[b] = f2h(o1);
+        }
+    }
+    if (!is_q) {                         // V: plain F32 -> F16, transposed store
+        for (int e = lane; e < dh; e += 64) {
+            const int c = hh * dh + e;
+            vc[(long) c * n_ctx + pos] = f2h(v[((long) t * Hkv + hh) * dh + e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode attention: one 256-thread workgroup per (query head, token).
+//   LDS: q as f16-rounded floats [dh] | scores/probabilities [n_ctx]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_decode_kernel(const float * q, const uint16_t * kc, const uint16_t * vc,
+                                                          const int32_t * pos0_ptr, float * out,
+                                                          int H, int Hkv, int dh, int n_ctx, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float redf[8];
+    __shared__ double redd[4];
+    float * qs = (float *) smem;                 // [dh]
+    float * sc = qs + dh;                        // [n_ctx]
+    const int h = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hk = h / (H / Hkv);
+    const int n_kv = *pos0_ptr + t + 1;          // causal: keys 0..pos
+    for (int e = tid; e < dh; e += 256) qs[e] = h2f(f2h(q[((long) t * H + h) * dh + e]));
+    __syncthreads();
+    // ---- scores
+    float lmax = -INFINITY;
+    for (int i = tid; i < n_kv; i += 256) {
+        const uint16_t * kr = kc + (long) i * Hkv * dh + (long) hk * dh;
+        float acc = 0.0f;
+        for (int e = 0; e < dh; e += 8) {
+            const u32x4 kk = *(const u32x4 *) (kr + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc += h2f((uint16_t) (kk[j] & 0xFFFF)) * qs[e + 2 * j];
+                acc += h2f((uint16_t) (kk[j] >> 16)) * qs[e + 2 * j + 1];
+            }
+        }
+        const float s = acc * scale;             // mask is 0 for visible keys
+        sc[i] = s;
+        lmax = fmaxf(lmax, s);
+    }
+    // block max
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    if (lane == 0) redf[wave] = lmax;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    // ---- exp and sum (f64 accumulate like the reference)
+    double lsum = 0.0;
+    for (int i = tid; i < n_kv; i += 256) {
+        const float e = expf(sc[i] - mx);
+        sc[i] = e;
+        lsum += (double) e;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+    if (lane == 0) redd[wave] = lsum;
+    __syncthreads();
+    const double tot = (redd[0] + redd[1]) + (redd[2] + redd[3]);
+    const float inv = (float) (1.0 / tot);
+    const int n_pad = (n_kv + 7) & ~7;
+    for (int i = tid; i < n_pad; i += 256) sc[i] = i < n_kv ? h2f(f2h(sc[i] * inv)) : 0.0f;   // p rounded to F16
+    __syncthreads();
+    // ---- out[e] = sum_i V^T[hk*dh+e][i] * p[i]; wave w owns e = w, w+4, ...; 8 keys per lane per step
+    for (int e = wave; e < dh; e += 4) {
+        const uint16_t * vr = vc + (long) (hk * dh + e) * n_ctx;
+        float acc = 0.0f;
+        for (int i = lane * 8; i < n_pad; i += 512) {
+            const u32x4 vv = *(const u32x4 *) (vr + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc += h2f((uint16_t) (vv[j] & 0xFFFF)) * sc[i + 2 * j];
+                acc += h2f((uint16_t) (vv[j] >> 16)) * sc[i + 2 * j + 1];
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[((long) t * H + h) * dh + e] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// argmax over n floats, first maximum wins. Single workgroup of 1024 threads (n ~ 128k: ~2 us).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void argmax_kernel(const float * x, int n, int32_t * out_idx, float * out_val) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float best = -INFINITY; int idx = 0x7fffffff;
+    for (int i = tid; i < n; i += 1024) {
+        const float v = x[i];
+        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off); const int oi = __shfl_xor(idx, off);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        *out_idx = idx;
+        if (out_val) *out_val = best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small elementwise kernels (node-equivalent fallbacks used by the ggml-backend plug-in)
+// ------------------------------------------------------------------------------------------------
+__global__ void add_kernel(const float * a, const float * b, float * y, long n, long nb) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a[i] + b[i % nb];
+}
+__global__ void mul_kernel(const float * a, const float * b, float * y, long n, long nb) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a[i] * b[i % nb];
+}
+__global__ void silu_mul_kernel(const float * g, const float * u, float * y, long n) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float s = g[i] / (1.0f + expf(-g[i])); y[i] = u ? s * u[i] : s; }
+}
+__global__ void scale_kernel(const float * a, float * y, float s, long n) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a[i] * s;
+}
+__global__ void inc_pos_kernel(int32_t * pos, int by) { *pos += by; }
+__global__ void set_pos_kernel(int32_t * pos, int v) { *pos = v; }
+
+// ---- launchers -------------------------------------------------------------------------------------
+void pm_launch_embed(int type, const void * table, int K, const int32_t * tokens, int n_tok, float * out, hipStream_t st) {
+    hipLaunchKernelGGL(embed_rows_kernel, dim3((K + 255) / 256, n_tok), dim3(256), 0, st,
+                       type, (const uint8_t *) table, (long) pm_weight_row_bytes(type, K), K, tokens, n_tok, out);
+}
+
+void pm_rope_params(pm_rope_cfg & c) {
+    // host-side constants exactly as ggml_compute_forward_rope_f32 computes them (ggml.c:14196-14199)
+    c.theta_scale = powf(c.freq_base, -2.0f / c.n_dims);
+    auto corr_dim = [&](float n_rot) {
+        return c.n_dims * logf(c.n_ctx_orig / (n_rot * 2 * (float) M_PI)) / (2 * logf(c.freq_base));
+    };
+    c.corr0 = fmaxf(0, floorf(corr_dim(c.beta_fast)));
+    c.corr1 = fminf((float) (c.n_dims - 1), ceilf(corr_dim(c.beta_slow)));
+}
+
+void pm_launch_rope_kv_store(const float * q, const float * k, const float * v, float * q_out, float * k_out_f32,
+                             void * kc, void * vc, const int32_t * pos0, const float * freq_factors,
+                             int n_tok, int H, int Hkv, int dh, int n_ctx, const pm_rope_cfg & c, hipStream_t st) {
+    RopeP r;
+    r.n_dims = c.n_dims; r.mode = c.mode; r.n_ctx_orig = c.n_ctx_orig; r.theta_scale = c.theta_scale;
+    r.freq_scale = c.freq_scale; r.ext_factor = c.ext_factor; r.attn_factor = c.attn_factor; r.corr0 = c.corr0; r.corr1 = c.corr1;
+    hipLaunchKernelGGL(rope_kv_store_kernel, dim3(H + Hkv, n_tok), dim3(64), 0, st,
+                       q, k, v, q_out, k_out_f32, (uint16_t *) kc, (uint16_t *) vc, pos0, freq_factors, H, Hkv, dh, n_ctx, r);
+}
+
+int pm_launch_attn_decode(const float * q, const void * kc, const void * vc, const int32_t * pos0, float * out,
+                          int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st) {
+    const size_t lds = (size_t) (dh + n_ctx) * 4;
+    if (lds > 150 * 1024 || dh % 8 || n_ctx % 8) return -1;
+    if (lds > 48 * 1024) {
+        static bool set = false;
+        if (!set) { (void) hipFuncSetAttribute((const void *) attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set = true; }
+    }
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(H, n_tok), dim3(256), lds, st,
+                       q, (const uint16_t *) kc, (const uint16_t *) vc, pos0, out, H, Hkv, dh, n_ctx, scale);
+    return 0;
+}
+
+void pm_launch_argmax(const float * x, int n, int32_t * idx, float * val, hipStream_t st) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, x, n, idx, val);
+}
+void pm_launch_add(const float * a, const float * b, float * y, long n, long nb, hipStream_t st) {
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, a, b, y, n, nb);
+}
+void pm_launch_mul(const float * a, const float * b, float * y, long n, long nb, hipStream_t st) {
+    hipLaunchKernelGGL(mul_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, a, b, y, n, nb);
+}
+void pm_launch_silu_mul(const float * g, const float * u, float * y, long n, hipStream_t st) {
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, g, u, y, n);
+}
+void pm_launch_scale(const float * a, float * y, float s, long n, hipStream_t st) {
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, a, y, s, n);
+}
+void pm_launch_set_pos(int32_t * pos, int v, hipStream_t st) {
+    hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, st, pos, v);
+}
+void pm_launch_inc_pos(int32_t * pos, int by, hipStream_t st) {
+    hipLaunchKernelGGL(inc_pos_kernel, dim3(1), dim3(1), 0, st, pos, by);
+}

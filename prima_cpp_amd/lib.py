@@ -31,6 +31,9 @@ _SIGS = {
     "pm355_device_count": (_i32, []),
     "pm355_set_device": (_i32, [_i32]),
     "pm355_sync": (_i32, [_vp]),
+    "pm355_memcpy_d2d": (_i32, [_vp, _vp, _sz, _vp]),
+    "pm355_memcpy_h2d": (_i32, [_vp, _vp, _sz, _vp]),
+    "pm355_memcpy_d2h": (_i32, [_vp, _vp, _sz, _vp]),
     "pm355_row_size": (_sz, [_i32, _i64]),
     "pm355_q8_K_row_size": (_sz, [_i64]),
     "pm355_q8_0_row_size": (_sz, [_i64]),
@@ -60,7 +63,7 @@ def load():
     return _lib
 
 
-def lib():
+def get():
     return load()
 
 

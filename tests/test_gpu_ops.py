@@ -33,8 +33,9 @@ def _acts(rng, k, kind):
         x = rng.normal(0, 0.1, k).astype(np.float32)
         x[5::256] = -3.0
         x[9::256] = 3.0
-        x[300] = 3.0      # second block: positive one comes first
-        x[261] = 0.0
+        if k > 300:
+            x[300] = 3.0      # second block: positive one comes first
+            x[261] = 0.0
         return x
     if kind == "halfway":
         return ((np.arange(k) % 255 - 127).astype(np.float32) * 0.5).astype(np.float32)
