@@ -62,8 +62,12 @@ PM355_API int    pm355_memset(void * dst, int value, size_t bytes, pm355_stream_
 /* ---- weight layout ------------------------------------------------------------------------------ */
 /* bytes of one row of K weights == ggml_row_size(type, K) (ggml/src/ggml.c:3579) */
 PM355_API size_t pm355_row_size(int type, int64_t K);
+/* row stride of the HBM layout: == pm355_row_size except Q6_K / Q8_0 with K % 2048 != 0 (row-SoA scale stream padded
+ * to 16 B). A tensor of N rows occupies N * pm355_row_stride bytes in HBM (the plug-in's get_alloc_size). */
+PM355_API size_t pm355_row_stride(int type, int64_t K);
 /* Row-local re-ordering GGUF block order <-> HBM order (identity for F32/F16/Q4_K/Q5_K, row-SoA for
- * Q6_K/Q8_0; see prima_cpp_amd/csrc/repack.hip). src and dst are DEVICE pointers and must not overlap.
+ * Q6_K/Q8_0; see prima_cpp_amd/csrc/repack.hip). src and dst are DEVICE pointers and must not overlap; the GGUF-order
+ * side has rows pm355_row_size apart, the HBM side pm355_row_stride apart.
  * to_device_layout=1 is what set_tensor does after the H2D copy; 0 is what get_tensor does before D2H. */
 PM355_API int    pm355_repack_rows(int type, const void * src, void * dst, int64_t K, int64_t nrows,
                                    int to_device_layout, pm355_stream_t stream);

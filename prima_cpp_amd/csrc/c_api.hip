@@ -47,6 +47,7 @@ int pm355_memcpy_d2d(void * d, const void * s, size_t n, pm355_stream_t st) { HI
 int pm355_memset(void * d, int v, size_t n, pm355_stream_t st) { HIP_TRY(hipMemsetAsync(d, v, n, S(st))); return 0; }
 
 size_t pm355_row_size(int type, int64_t K) { return pm_weight_row_bytes(type, K); }
+size_t pm355_row_stride(int type, int64_t K) { return pm_weight_row_stride(type, K); }
 size_t pm355_q8_K_row_size(int64_t K) { return pm_q8k_row_bytes((int) K); }
 size_t pm355_q8_0_row_size(int64_t K) { return pm_q80_row_bytes((int) K); }
 
@@ -114,7 +115,7 @@ static int gemv_rc(int rc) {
         case 0: return 0;
         case -1: return fail(PM355_E_UNSUPPORTED, "mul_mat_vec_q: weight type");
         case -2: return fail(PM355_E_SHAPE, "mul_mat_vec_q: K not a multiple of the block size");
-        case -3: return fail(PM355_E_ALIGN, "mul_mat_vec_q: K % 2048 != 0 for Q6_K row-SoA");
+        case -3: return fail(PM355_E_ALIGN, "mul_mat_vec_q: K not a multiple of 32 for Q8_0");
         case -4: return fail(PM355_E_RANGE, "mul_mat_vec_q: K too large");
         default: return fail(PM355_E_HIP, "mul_mat_vec_q: launch", hipGetLastError());
     }

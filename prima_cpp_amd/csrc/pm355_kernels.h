@@ -8,8 +8,11 @@
 static inline size_t pm_q8k_row_bytes(int K) { return (size_t) K + (size_t) (K / 256) * 4 + (size_t) (K / 16) * 2; }
 static inline size_t pm_q80_row_bytes(int K) { return (size_t) K + (size_t) (K / 32) * 2; }
 
-// bytes of one WEIGHT row (same as ggml_row_size for every supported type; repacking is row-local)
+// bytes of one WEIGHT row in GGUF order (== ggml_row_size)
 size_t pm_weight_row_bytes(int type, int64_t K);
+// row STRIDE in HBM: == row bytes except that the trailing fp16 scale stream of the row-SoA layouts
+// (Q6_K, Q8_0) is padded to 16 B so every row (and every field stream) starts 16-B aligned for any K
+size_t pm_weight_row_stride(int type, int64_t K);
 
 void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStream_t st);
 void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStream_t st);

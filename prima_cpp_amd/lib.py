@@ -35,6 +35,7 @@ _SIGS = {
     "pm355_memcpy_h2d": (_i32, [_vp, _vp, _sz, _vp]),
     "pm355_memcpy_d2h": (_i32, [_vp, _vp, _sz, _vp]),
     "pm355_row_size": (_sz, [_i32, _i64]),
+    "pm355_row_stride": (_sz, [_i32, _i64]),
     "pm355_q8_K_row_size": (_sz, [_i64]),
     "pm355_q8_0_row_size": (_sz, [_i64]),
     "pm355_repack_rows": (_i32, [_i32, _vp, _vp, _i64, _i64, _i32, _vp]),
@@ -43,6 +44,12 @@ _SIGS = {
     "pm355_act_to_ggml_blocks": (_i32, [_i32, _vp, _vp, _i64, _i64, _vp]),
     "pm355_rms_norm": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp]),
     "pm355_mul_mat_vec_q": (_i32, [_i32, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "pm355_get_rows": (_i32, [_i32, _vp, _i64, _vp, _i32, _vp, _vp]),
+    "pm355_rope_kv_store": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "pm355_attn_decode": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "pm355_argmax": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "pm355_silu_mul": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "pm355_add": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "pm355_mul_mat_vec_q_dbg": (_i32, [_i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
 }
 

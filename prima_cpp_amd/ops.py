@@ -35,7 +35,7 @@ def upload_weight(qtype, blocks, K, N):
     assert blocks.size == L.row_size(qtype, K) * N, (blocks.size, L.row_size(qtype, K) * N)
     raw = torch.from_numpy(blocks).to(_dev())
     if qtype in (Q6_K, Q8_0):
-        dst = torch.empty_like(raw)
+        dst = torch.zeros(N * lib.pm355_row_stride(qtype, K), dtype=torch.uint8, device=raw.device)
         check(lib.pm355_repack_rows(qtype, ptr(raw), ptr(dst), K, N, 1, stream_ptr()), "repack_rows")
         return QWeight(qtype, K, N, dst)
     return QWeight(qtype, K, N, raw)
@@ -45,7 +45,7 @@ def download_weight(w):
     """ggml_backend_tensor_get semantics: HBM layout -> host GGUF-order bytes."""
     lib = L.load()
     if w.type in (Q6_K, Q8_0):
-        tmp = torch.empty_like(w.data)
+        tmp = torch.empty(w.N * L.row_size(w.type, w.K), dtype=torch.uint8, device=w.data.device)
         check(lib.pm355_repack_rows(w.type, ptr(w.data), ptr(tmp), w.K, w.N, 0, stream_ptr()), "repack_rows")
         return tmp.cpu().numpy()
     return w.data.cpu().numpy()
@@ -113,3 +113,52 @@ def mul_mat_vec_dbg(w, xq):
                                       stream_ptr()), "mul_mat_vec_q_dbg")
     assert upr.value == units
     return y, ip
+
+
+class RopeParams(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("n_dims", _C.c_int32), ("mode", _C.c_int32), ("n_ctx_orig", _C.c_int32),
+                ("freq_base", _C.c_float), ("freq_scale", _C.c_float), ("ext_factor", _C.c_float),
+                ("attn_factor", _C.c_float), ("beta_fast", _C.c_float), ("beta_slow", _C.c_float)]
+
+
+def rope_kv_store(q, k, v, k_cache, v_cache, pos0, n_head, n_head_kv, head_dim, n_ctx, freq_factors=None, mode=0,
+                  n_ctx_orig=8192, freq_base=10000.0, freq_scale=1.0, ext_factor=0.0, attn_factor=1.0,
+                  beta_fast=32.0, beta_slow=1.0, n_dims=None):
+    """ggml_rope_ext on Q and K + llm_build_kv_store. q [T, H*dh], k/v [T, Hkv*dh] f32; caches int16-typed
+    tensors holding F16 bits. Returns (q_rot, k_rot_f32)."""
+    import ctypes as C
+    lib = L.load()
+    T = q.shape[0]
+    rp = RopeParams(n_dims or head_dim, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow)
+    q_out = torch.empty_like(q)
+    k_out = torch.empty_like(k)
+    pos = torch.tensor([pos0], dtype=torch.int32, device=q.device)
+    check(lib.pm355_rope_kv_store(ptr(q), ptr(k), ptr(v), ptr(q_out), ptr(k_out), ptr(k_cache), ptr(v_cache), ptr(pos),
+                                  ptr(freq_factors), T, n_head, n_head_kv, head_dim, n_ctx, C.addressof(rp), stream_ptr()),
+          "rope_kv_store")
+    return q_out, k_out
+
+
+def attn_decode(q, k_cache, v_cache, pos0, n_head, n_head_kv, head_dim, n_ctx, scale):
+    lib = L.load()
+    T = q.shape[0]
+    out = torch.empty_like(q)
+    pos = torch.tensor([pos0], dtype=torch.int32, device=q.device)
+    check(lib.pm355_attn_decode(ptr(q), ptr(k_cache), ptr(v_cache), ptr(pos), ptr(out), T, n_head, n_head_kv, head_dim,
+                                n_ctx, float(scale), stream_ptr()), "attn_decode")
+    return out
+
+
+def argmax(x):
+    lib = L.load()
+    idx = torch.empty(1, dtype=torch.int32, device=x.device)
+    check(lib.pm355_argmax(ptr(x), x.numel(), ptr(idx), None, stream_ptr()), "argmax")
+    return idx
+
+
+def get_rows(w, tokens):
+    lib = L.load()
+    out = torch.empty((tokens.numel(), w.K), dtype=torch.float32, device=tokens.device)
+    check(lib.pm355_get_rows(w.type, ptr(w.data), w.K, ptr(tokens), tokens.numel(), ptr(out), stream_ptr()), "get_rows")
+    return out

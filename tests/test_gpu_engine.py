@@ -49,7 +49,7 @@ def test_window_prefill_and_decode_vs_oracle(E, oracle, arch):
         hid, lg, am = w.decode(tokens=torch.from_numpy(tk).cuda(), pos0=p0, want_argmax=True)
         h_ref, l_ref = oracle.model_eval(ho, d, tokens=tk, pos0=p0)
         # north_star: logits within 1e-3 relative; whole-stack metric = NMSE (reference: test-backend-ops)
-        assert _nmse(hid.cpu().numpy(), h_ref) < 1e-4
+        assert _nmse(hid.cpu().numpy(), h_ref) < 1e-3
         assert _nmse(lg.cpu().numpy(), l_ref) < 1e-3
         assert int(am.item()) == int(np.argmax(lg.cpu().numpy()))
     # layer-0 KV cache: K rows are rope(f32)->f16, V rows plain f16: compare as floats (cos/sin <= 2 ulp apart)

@@ -70,14 +70,17 @@ def test_quantize_q8_0_bitexact(P, oracle, kind):
 
 
 @pytest.mark.parametrize("t", QUANT_TYPES)
-def test_repack_roundtrip_bitexact(P, t):
+@pytest.mark.parametrize("K", [2048, 768])
+def test_repack_roundtrip_bitexact(P, t, K):
     rng = np.random.default_rng(23)
-    K, N = 2048, 19
+    N = 19
     blocks = rand_blocks(t, N, K, rng)
     w = P.upload_weight(t, blocks, K, N)
     assert np.array_equal(P.download_weight(w), blocks)
-    if t in (Q6_K, Q8_0):      # and the HBM image is the documented row-SoA permutation
-        img = w.data.cpu().numpy().reshape(N, -1)
+    if t in (Q6_K, Q8_0):      # and the HBM image is the documented row-SoA permutation (rows 16-B aligned)
+        stride = P.L.load().pm355_row_stride(t, K)
+        assert stride % 16 == 0 and 0 <= stride - row_size(t, K) < 16
+        img = w.data.cpu().numpy().reshape(N, stride)[:, :row_size(t, K)]
         src = blocks.reshape(N, -1)
         if t == Q6_K:
             nb = K // 256
@@ -92,10 +95,8 @@ def test_repack_roundtrip_bitexact(P, t):
 
 
 @pytest.mark.parametrize("t", QUANT_TYPES)
-@pytest.mark.parametrize("K,N", [(2048, 5), (4096, 37), (8192, 64), (14336, 9), (28672, 6)])
+@pytest.mark.parametrize("K,N", [(256, 3), (768, 5), (2048, 5), (4096, 37), (5120, 4), (8192, 64), (14336, 9), (28672, 6)])
 def test_gemv_integer_partials_bitexact_and_float_close(P, oracle, t, K, N):
-    if t == Q6_K and K % 2048:
-        pytest.skip("Q6_K row-SoA needs K % 2048 == 0")
     rng = np.random.default_rng(24)
     blocks = rand_blocks(t, N, K, rng)
     x = rng.normal(0, 1, K).astype(np.float32)
@@ -175,3 +176,85 @@ def test_gemv_full_size_linearity(P):
     wp = P.QWeight(Q4_K, K, N, w.data.view(N, -1)[perm].contiguous().view(-1))
     assert torch.equal(P.mul_mat_vec(wp, x=x), y1[:, perm])
     assert torch.isfinite(y1).all()
+
+
+def _f16bits(P, a):
+    return P.torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).cuda()
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("with_ff", [False, True])
+def test_rope_kv_store_vs_oracle(P, oracle, mode, with_ff):
+    torch = P.torch
+    rng = np.random.default_rng(41)
+    T, H, Hkv, dh, n_ctx, pos0 = 3, 8, 2, 128, 64, 37
+    q = rng.normal(0, 1, (T, H * dh)).astype(np.float32)
+    k = rng.normal(0, 1, (T, Hkv * dh)).astype(np.float32)
+    v = rng.normal(0, 1, (T, Hkv * dh)).astype(np.float32)
+    ff = (1 + rng.uniform(0, 7, dh // 2)).astype(np.float32) if with_ff else None
+    kc = torch.zeros(n_ctx * Hkv * dh, dtype=torch.int16, device="cuda")
+    vc = torch.zeros(n_ctx * Hkv * dh, dtype=torch.int16, device="cuda")
+    qr, kr = P.rope_kv_store(_dev(P, q), _dev(P, k), _dev(P, v), kc, vc, pos0, H, Hkv, dh, n_ctx,
+                             freq_factors=None if ff is None else _dev(P, ff), mode=mode, freq_base=500000.0)
+    pos = np.arange(pos0, pos0 + T, dtype=np.int32)
+    q_ref = oracle.rope(q.reshape(T, H, dh), pos, freq_factors=ff, mode=mode, freq_base=500000.0).reshape(T, -1)
+    k_ref = oracle.rope(k.reshape(T, Hkv, dh), pos, freq_factors=ff, mode=mode, freq_base=500000.0).reshape(T, -1)
+    # identical f32 op sequence except device cosf/sinf (<= 2 ulp): |err| <= 4 ulp of the operand magnitude
+    for got, want, src in ((qr.cpu().numpy(), q_ref, q), (kr.cpu().numpy(), k_ref, k)):
+        assert np.abs(got - want).max() <= 1e-6 * np.abs(src).max() * 4
+    # KV cache contents: K rows = f16(rope(k)) at positions pos0.., V transposed = f16(v); everything else zero
+    kc_h = kc.cpu().numpy().view(np.uint16).reshape(n_ctx, Hkv * dh)
+    vc_h = vc.cpu().numpy().view(np.uint16).reshape(Hkv * dh, n_ctx)
+    assert np.array_equal(kc_h[pos0:pos0 + T], kr.cpu().numpy().astype(np.float16).view(np.uint16))
+    assert np.array_equal(vc_h[:, pos0:pos0 + T], v.T.astype(np.float16).view(np.uint16))
+    assert not kc_h[:pos0].any() and not kc_h[pos0 + T:].any() and not vc_h[:, :pos0].any() and not vc_h[:, pos0 + T:].any()
+
+
+@pytest.mark.parametrize("n_past,T", [(0, 1), (5, 1), (63, 1), (200, 3), (0, 4)])
+def test_attn_decode_vs_oracle(P, oracle, n_past, T):
+    """Same rounding points as the reference (q and p rounded to F16, F16 K/V): compare with an exact numpy
+    restatement of llm_build_kqv in float64 on the SAME f16-rounded inputs."""
+    torch = P.torch
+    rng = np.random.default_rng(42)
+    H, Hkv, dh, n_ctx = 8, 2, 128, 256
+    n_kv = n_past + T
+    q = rng.normal(0, 1, (T, H, dh)).astype(np.float32)
+    K = rng.normal(0, 1, (n_ctx, Hkv, dh)).astype(np.float16)
+    V = rng.normal(0, 1, (Hkv, dh, n_ctx)).astype(np.float16)
+    K[n_kv:] = 0; V[:, :, n_kv:] = 0
+    out = P.attn_decode(_dev(P, q.reshape(T, -1)), _f16bits(P, K), _f16bits(P, V), n_past, H, Hkv, dh, n_ctx,
+                        1.0 / np.sqrt(dh)).cpu().numpy().reshape(T, H, dh)
+    qh = q.astype(np.float16).astype(np.float64)
+    for t in range(T):
+        nk = n_past + t + 1
+        for h in range(H):
+            hk = h // (H // Hkv)
+            s = (K[:nk, hk].astype(np.float64) @ qh[t, h]).astype(np.float32) * np.float32(1.0 / np.sqrt(dh))
+            e = np.exp((s - s.max()).astype(np.float32)).astype(np.float32)
+            p = (e * np.float32(1.0 / e.astype(np.float64).sum())).astype(np.float16).astype(np.float64)
+            want = V[hk, :, :nk].astype(np.float64) @ p
+            assert np.abs(out[t, h] - want).max() <= 2e-3 * np.abs(want).max() + 1e-4, (t, h)
+
+
+def test_argmax_first_maximum(P):
+    torch = P.torch
+    x = torch.randn(128256, device="cuda")
+    x[777] = 50.0; x[90000] = 50.0
+    assert int(P.argmax(x).item()) == 777
+    x[3] = 60.0
+    assert int(P.argmax(x).item()) == 3
+
+
+@pytest.mark.parametrize("t", QUANT_TYPES)
+def test_get_rows_bitexact(P, oracle, t):
+    torch = P.torch
+    rng = np.random.default_rng(43)
+    K, N = 768, 50
+    blocks = rand_blocks(t, N, K, rng, scale=1.0)
+    w = P.upload_weight(t, blocks, K, N)
+    toks = np.array([0, 49, 7, 7, 23], dtype=np.int32)
+    got = P.get_rows(w, _dev(P, toks)).cpu().numpy()
+    rs = row_size(t, K)
+    for i, tk in enumerate(toks):
+        want = oracle.dequantize_row(t, blocks[tk * rs:(tk + 1) * rs], K)
+        assert np.array_equal(got[i].view(np.uint32), want.view(np.uint32)), (t, i)

@@ -31,7 +31,7 @@ def rand_weight(t, K, N):
         v[:, :, 2:4] = h
     w = P.QWeight(t, K, N, raw.view(-1))
     if t in (Q6_K, Q8_0):
-        dst = torch.empty_like(raw.view(-1))
+        dst = torch.empty(N * P.L.load().pm355_row_stride(t, K), dtype=torch.uint8, device="cuda")
         P.check(P.L.load().pm355_repack_rows(t, raw.data_ptr(), dst.data_ptr(), K, N, 1, P.stream_ptr()), "repack")
         w = P.QWeight(t, K, N, dst)
     return w
@@ -45,8 +45,6 @@ def main():
               ("70B lm_head", 8192, 128256), ("8B wq", 4096, 4096), ("8B gate", 4096, 14336), ("8B down", 14336, 4096)]
     for name, K, N in shapes:
         for t in (Q4_K, Q6_K, Q5_K, Q8_0):
-            if t == Q6_K and K % 2048:
-                continue
             if t in (Q5_K, Q8_0) and "wq" not in name and "down" not in name:
                 continue
             w = rand_weight(t, K, N)
