@@ -1,0 +1,270 @@
+#!/usr/bin/env python
+"""bench.py — decode tokens/s of the quantized decode hot path on MI355X.
+
+Workload (BASELINE.json: metric quoted on Llama-3-70B Q4_K_M, which fits one GPU): synthetic
+Llama-3-70B-shaped weights with the Q4_K_M type mixture generated directly in HBM, synthetic prompt,
+batch-1 greedy decode. One "step" = every in-flight sequence advances by one token:
+  N = 1 : one sequence, one token per step (whole model on the GPU, one hipGraph replay per token);
+  N > 1 : piped-ring layer split, one rank per GPU, N sequences in flight staggered by one rank
+          (N micro-steps per step; activations handed on with RCCL send/recv), N tokens per step.
+Per-GPU HBM traffic per step is the same for every N (each rank streams its window N times) -> "weak".
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with two extra objects:
+  roofline     — dominant kernel (Q4_K gate/up mat-vec) timed live with HIP events on its launch stream
+  cpu_baseline — the UNMODIFIED reference ggml CPU backend (oracle/_ref) timed on this host's cores on a
+                 bounded sample of the same workload (N=1, rank 0 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="llama3-70b", choices=["llama3-70b", "llama3-8b", "qwen2.5-72b"])
+    ap.add_argument("--n-ctx", type=int, default=4096)
+    ap.add_argument("--prompt", type=int, default=16)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def model_cfg(name):
+    import prima_cpp_amd.engine as E
+    if name == "llama3-70b":
+        return E.LLAMA3_70B, E.q4_k_m_types, "Llama-3-70B Q4_K_M"
+    if name == "llama3-8b":
+        return E.LLAMA3_8B, E.q4_k_m_types, "Llama-3-8B Q4_K_M"
+    return E.QWEN25_72B, E.q6_k_types, "Qwen2.5-72B Q6_K"
+
+
+def layer_bytes(hp, mixture):
+    from prima_cpp_amd.lib import row_size
+    import prima_cpp_amd.engine as E
+    Ed, Eq, Ekv, F = hp["n_embd"], hp["head_dim"] * hp["n_head"], hp["head_dim"] * hp["n_head_kv"], hp["n_ff"]
+    shape = {E.T_WQ: (Ed, Eq), E.T_WK: (Ed, Ekv), E.T_WV: (Ed, Ekv), E.T_WO: (Eq, Ed), E.T_FFN_GATE: (Ed, F),
+             E.T_FFN_UP: (Ed, F), E.T_FFN_DOWN: (F, Ed)}
+    out = []
+    for il in range(hp["n_layer"]):
+        t = mixture(hp, il)
+        out.append(sum(row_size(t[k], kk) * n for k, (kk, n) in shape.items()) + 2 * Ed * 4)
+    return out
+
+
+def cpu_baseline(hp, mixture, seconds):
+    """Reference ggml CPU backend (unmodified sources, prebuilt under oracle/_ref) on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _bind as B
+    import prima_cpp_amd.engine as E
+    flavour = B.best_ref_flavour()
+    if flavour is None:
+        return None
+    ref = B.Ref(flavour)
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    Ed, Eq, Ekv, F = hp["n_embd"], hp["head_dim"] * hp["n_head"], hp["head_dim"] * hp["n_head_kv"], hp["n_ff"]
+    shape = {E.T_WQ: (Ed, Eq), E.T_WK: (Ed, Ekv), E.T_WV: (Ed, Ekv), E.T_WO: (Eq, Ed), E.T_FFN_GATE: (Ed, F),
+             E.T_FFN_UP: (Ed, F), E.T_FFN_DOWN: (F, Ed)}
+    # distinct layer compositions of the mixture, weighted by how often they occur
+    comps = {}
+    for il in range(hp["n_layer"]):
+        key = tuple(sorted(mixture(hp, il).items()))
+        comps[key] = comps.get(key, 0) + 1
+    t_token, t_spent, desc = 0.0, 0.0, []
+    budget = seconds / (len(comps) + 1)
+    for key, count in comps.items():
+        mats = [(t, shape[k][0], shape[k][1], B.rand_blocks(t, shape[k][1], shape[k][0], rng)) for k, t in key]
+        t0 = time.time()
+        one = ref.time_layer_matvecs(mats, cores, reps=2)
+        reps = max(1, min(20, int(budget / max(one, 1e-3))))
+        best = min(one, ref.time_layer_matvecs(mats, cores, reps=reps))
+        t_spent += time.time() - t0
+        t_token += best * count
+        desc.append(f"{count}x layer[{','.join(B.TYPE_NAMES[t] for _, t in key)}]")
+        del mats
+    out_t = B.Q6_K
+    n_v = hp["n_vocab"]
+    sub = 8                                                  # lm_head sampled on 1/8 of its rows
+    mats = [(out_t, Ed, n_v // sub, B.rand_blocks(out_t, n_v // sub, Ed, rng))]
+    t_token += ref.time_layer_matvecs(mats, cores, reps=3) * sub
+    desc.append(f"lm_head[q6_K] on 1/{sub} of its rows")
+    return {"value": 1.0 / t_token, "unit": "tokens/s", "cores": cores, "kind": "reference",
+            "sample": "7 quantized mat-vecs of one layer per distinct Q4_K_M layer composition (" + " + ".join(desc) +
+                      f"), random valid blocks, reference ggml CPU backend ({ref.build_info()}), {cores} threads, "
+                      "best of repeated passes, scaled by layer counts to one token (mat-vecs only: norms/rope/"
+                      "attention excluded, which favours the CPU)"}
+
+
+def probe_dominant_kernel(win, hp, iters=40):
+    """Average duration of the dominant kernel (Q4_K gate/up mat-vec pair: 2 x [n_ff x n_embd] read once) measured with
+    HIP events on the stream it is launched on, rotating over the real layers' weights (no cache reuse)."""
+    import ctypes as C
+    import prima_cpp_amd.engine as E
+    import prima_cpp_amd.ops as P
+    from prima_cpp_amd.lib import Q4_K, row_size
+    lib = P.L.load()
+    Ed, F = hp["n_embd"], hp["n_ff"]
+    x = torch.randn(1, Ed, device="cuda")
+    xq = P.quantize_act(x, P.Q8_K)
+    y = torch.empty(F, dtype=torch.float32, device="cuda")
+    tp = C.c_void_p
+    lib.pm355_model_tensor_ptr.restype = tp
+    lib.pm355_model_tensor_ptr.argtypes = [tp, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    ptrs = []
+    for il in range(win.lo, win.hi):
+        ty = C.c_int(0)
+        g = lib.pm355_model_tensor_ptr(win.h, E.T_FFN_GATE, il, C.byref(ty))
+        u = lib.pm355_model_tensor_ptr(win.h, E.T_FFN_UP, il, C.byref(ty))
+        if ty.value == Q4_K:
+            ptrs.append((g, u))
+    if not ptrs:
+        return None
+    st = torch.cuda.current_stream()
+
+    def run(n):
+        for i in range(n):
+            g, u = ptrs[i % len(ptrs)]
+            P.check(lib.pm355_mul_mat_vec_q(Q4_K, g, u, Ed, F, P.ptr(xq), 1, P.ptr(y), F, None, None, st.cuda_stream), "probe")
+    run(len(ptrs))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    run(iters)
+    e1.record(st)
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    nbytes = 2 * row_size(Q4_K, Ed) * F
+    return {"kernel": "gemv_q_kernel<Q4_K, PAIR> (ffn_gate+ffn_up mat-vec with fused silu*mul)", "bytes_per_launch": nbytes,
+            "avg_us": us, "gbs": nbytes / us / 1e3}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    import prima_cpp_amd.engine as E
+    from prima_cpp_amd.ring import EngineCompute, RingDriver, partition_layers
+    hp, mixture, model_name = model_cfg(a.model)
+    from prima_cpp_amd.lib import Q6_K, row_size
+    lb = layer_bytes(hp, mixture)
+    head_b = row_size(Q6_K, hp["n_embd"]) * hp["n_vocab"] + hp["n_embd"] * 4
+    wins = partition_layers(lb, head_b, world)
+    lo, hi = wins[rank]
+    flags = (E.HAS_EMBD | E.HAS_HEAD) if rank == 0 else 0
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        win = E.Window(hp, lo=lo, hi=hi, flags=flags, n_ctx=a.n_ctx)
+        win.fill_synthetic(mixture, seed=1234)
+        win.finalize(max_tokens=1, n_seq=world)
+        use_graph = not a.no_graph
+        comp = EngineCompute(win, world, use_graph=use_graph)
+        drv = RingDriver(comp, rank, world)
+        rng = np.random.default_rng(1234)
+        prompt = rng.integers(0, hp["n_vocab"], size=(world, a.prompt))
+        prompt[:, 0] = 128000 % hp["n_vocab"]            # BOS first, like llama-bench
+
+        def one_step(step_idx):
+            """every in-flight sequence advances one token: `world` micro-steps on every rank"""
+            for j in range(world):
+                forced = None
+                if rank == 0:
+                    seq = (drv.m) % world
+                    if step_idx < a.prompt:
+                        forced = int(prompt[seq, step_idx])
+                drv.micro_step(forced_token=forced)
+
+        def sync():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        # prompt (token by token through the same path) + warmup, untimed
+        n_pre = a.prompt + a.warmup
+        assert n_pre + a.steps + 2 <= a.n_ctx, "n_ctx too small for prompt+warmup+steps"
+        for s in range(n_pre):
+            one_step(s)
+        sync()
+        t0 = time.perf_counter()
+        for s in range(a.steps):
+            one_step(n_pre + s)
+        sync()
+        t1 = time.perf_counter()
+        dt = t1 - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        drv.flush()
+        sync()
+
+        tokens = a.steps * world
+        value = tokens / dt
+        result = None
+        if rank == 0:
+            total_w = sum(lb) + head_b
+            n_kv_mid = a.prompt + a.warmup + a.steps // 2
+            kv_b = hp["n_layer"] * 2 * hp["head_dim"] * hp["n_head_kv"] * 2 * n_kv_mid
+            result = {
+                "metric": "decode_tokens_per_s", "value": round(value, 3), "unit": "tokens/s", "n_gpus": world,
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8xint4->int32, f32 accumulate",
+                "data": "synthetic",
+                "config": {"workload": f"{model_name} batch-1 greedy decode, {a.prompt}-token synthetic prompt, "
+                                       f"{world} sequence(s) in flight, n_ctx {a.n_ctx}, F16 KV cache",
+                           "parallelism": "single GPU" if world == 1 else f"piped-ring layer split pp{world} "
+                                          f"(windows {wins}), RCCL send/recv",
+                           "weights_bytes_per_token": total_w, "kv_bytes_per_token_mid_run": kv_b,
+                           "hip_graph": use_graph},
+                "hbm_roofline_tokens_per_s": round(HBM_PEAK_GBS * 1e9 / total_w * world, 2),
+                "frac_of_hbm_roofline_weights_only": round(value * total_w / world / (HBM_PEAK_GBS * 1e9), 4),
+                "frac_of_hbm_roofline_weights_plus_kv": round(value * (total_w + kv_b) / world / (HBM_PEAK_GBS * 1e9), 4),
+            }
+            pr = probe_dominant_kernel(win, hp)
+            if pr:
+                result["roofline"] = {"bound": "hbm", "achieved": round(pr["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(pr["gbs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                                      "kernel": pr["kernel"], "bytes_per_launch": pr["bytes_per_launch"],
+                                      "avg_launch_us": round(pr["avg_us"], 2)}
+            if world == 1 and not a.no_cpu_baseline:
+                try:
+                    cb = cpu_baseline(hp, mixture, a.cpu_seconds)
+                except Exception as e:                       # the baseline is a reported extra, never fatal
+                    cb = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "reference", "sample": f"failed: {e}"}
+                if cb:
+                    if cb.get("value"):
+                        cb["value"] = round(cb["value"], 4)
+                    result["cpu_baseline"] = cb
+        win.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

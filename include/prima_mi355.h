@@ -162,10 +162,14 @@ PM355_API int pm355_model_set_tensor(pm355_model * m, int kind, int layer, int t
 PM355_API int pm355_model_fill_tensor(pm355_model * m, int kind, int layer, int type, uint64_t seed, float scale);
 /* allocate KV cache (F16, zero-cleared: llama_kv_cache_init src/llama.cpp:3889-3992) + scratch for max_tokens per call */
 PM355_API int pm355_model_finalize(pm355_model * m, int max_tokens);
+/* same with n_seq independent sequences (one KV slab + one position counter each): the sequences that are in flight
+ * around the piped ring at the same time */
+PM355_API int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq);
 PM355_API size_t pm355_model_weight_bytes(const pm355_model * m);     /* matmul weight bytes read per token */
 PM355_API size_t pm355_model_kv_bytes_per_pos(const pm355_model * m); /* KV bytes read per cached position */
 PM355_API int pm355_model_kv_clear(pm355_model * m, pm355_stream_t stream);
 PM355_API void * pm355_model_kv_ptr(pm355_model * m, int layer, int which /*0=K,1=V*/);
+PM355_API void * pm355_model_tensor_ptr(pm355_model * m, int kind, int layer, int * type_out);  /* HBM-layout device pointer */
 /* One pass of the window over n_tokens tokens at positions pos0.. (causal, single sequence).
  *   input : d_tokens (int32, needs HAS_EMBD) or d_x_in (f32 [n_tokens][n_embd], the activation handed over by the
  *           previous rank: llama_recv_tensors src/llama.cpp:18054)
@@ -181,7 +185,19 @@ PM355_API int pm355_model_generate(pm355_model * m, int32_t * d_tokens_io, int p
                                    pm355_stream_t stream);
 /* single-token step with the position held in device memory (graph-replayable building block of the piped ring):
  * x_in/x_out as above, position = internal device counter set by pm355_model_set_pos and advanced by `advance`. */
-PM355_API int pm355_model_set_pos(pm355_model * m, int pos, pm355_stream_t stream);
+PM355_API int pm355_model_set_pos(pm355_model * m, int pos, pm355_stream_t stream);       /* sequence 0, made current */
+PM355_API int pm355_model_set_seq_pos(pm355_model * m, int seq, int pos, pm355_stream_t stream);
+PM355_API int pm355_model_set_seq(pm355_model * m, int seq, pm355_stream_t stream);       /* choose the current sequence */
+/* result_norm + lm_head (+ greedy argmax) on one hidden row: build_llama's last sub-graph (src/llama.cpp:11191-11215),
+ * which rank 0 runs on the activation returned by the last rank of the ring */
+PM355_API int pm355_model_head(pm355_model * m, const float * d_x_row, float * d_logits, int32_t * d_argmax,
+                               pm355_stream_t stream);
+/* step with ring controls: after the window, position[current seq] += advance and current seq = (seq + rotate) % n_seq.
+ * head_first != 0 (rank 0 of the ring): first apply the head to d_x_in (the last rank's activation) writing d_argmax /
+ * d_logits, then embed the token at d_token (may alias d_argmax) and run the window into d_x_out. */
+PM355_API int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * d_x_in, float * d_x_out,
+                                  float * d_logits, int32_t * d_argmax, int advance, int rotate_seq, int head_first,
+                                  int use_graph, pm355_stream_t stream);
 PM355_API int pm355_model_step(pm355_model * m, const int32_t * d_token, const float * d_x_in, float * d_x_out,
                                float * d_logits, int32_t * d_argmax, int advance, int use_graph, pm355_stream_t stream);
 

@@ -150,13 +150,13 @@ int pm355_rope_kv_store(const float * q, const float * k, const float * v, float
     c.n_dims = rp->n_dims; c.mode = rp->mode; c.n_ctx_orig = rp->n_ctx_orig; c.freq_base = rp->freq_base; c.freq_scale = rp->freq_scale;
     c.ext_factor = rp->ext_factor; c.attn_factor = rp->attn_factor; c.beta_fast = rp->beta_fast; c.beta_slow = rp->beta_slow;
     pm_rope_params(c);
-    pm_launch_rope_kv_store(q, k, v, q_out, k_out_f32, kc, vc, d_pos0, ff, n_tokens, H, Hkv, dh, n_ctx, c, S(st));
+    pm_launch_rope_kv_store(q, k, v, q_out, k_out_f32, kc, vc, d_pos0, nullptr, 0, ff, n_tokens, H, Hkv, dh, n_ctx, c, S(st));
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int pm355_attn_decode(const float * q, const void * kc, const void * vc, const int32_t * d_pos0, float * out, int n_tokens,
                       int H, int Hkv, int dh, int n_ctx, float kq_scale, pm355_stream_t st) {
-    if (pm_launch_attn_decode(q, kc, vc, d_pos0, out, n_tokens, H, Hkv, dh, n_ctx, kq_scale, S(st)))
+    if (pm_launch_attn_decode(q, kc, vc, d_pos0, nullptr, 0, out, n_tokens, H, Hkv, dh, n_ctx, kq_scale, S(st)))
         return fail(PM355_E_RANGE, "attn_decode: n_ctx/head_dim unsupported (LDS budget 150 KB, multiples of 8)");
     HIP_TRY(hipGetLastError());
     return 0;

@@ -37,13 +37,14 @@ struct pm355_model {
     float * x = nullptr, * x1 = nullptr, * q = nullptr, * k = nullptr, * v = nullptr, * att = nullptr, * h = nullptr;
     float * logits = nullptr, * xn = nullptr;
     uint8_t * aq_k = nullptr, * aq_0 = nullptr;     // quantized activation scratch (Q8_K / Q8_0), sized for max(K)
-    int32_t * d_pos = nullptr, * d_tok = nullptr;
+    int32_t * d_pos = nullptr, * d_tok = nullptr, * d_ctl = nullptr;   // d_pos[n_seq]; d_ctl = {current seq, n_seq}
+    int n_seq = 1;
     // staging for set_tensor
     void * pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2]; void * dstage = nullptr; size_t stage_bytes = 0;
     hipStream_t up_stream = nullptr, cap_stream = nullptr;
-    // graphs
-    hipGraphExec_t step_exec = nullptr; const void * g_in = nullptr; void * g_out = nullptr; void * g_logits = nullptr;
-    void * g_argmax = nullptr; const void * g_tok = nullptr; int g_adv = -1; hipStream_t g_stream = nullptr;
+    // captured single-token step graphs, keyed on everything that is baked into the kernel arguments
+    struct StepGraph { const void * in, * tok; void * out, * logits, * argmax; int adv, rot, head; hipGraphExec_t exec; };
+    std::vector<StepGraph> graphs;
     char err[256];
 };
 
@@ -196,6 +197,17 @@ int gemv(const Tensor & w, const Tensor * w2, const ActQ & a, int T, float * y, 
     return pm_launch_gemv(g, st);
 }
 
+// result_norm + lm_head (+ greedy argmax) on ONE hidden row (build_llama's last sub-graph, src/llama.cpp:11191-11215)
+int run_head(pm355_model * m, const float * x_row, float * d_logits, int32_t * d_argmax, hipStream_t st) {
+    if (!m->output.d || !m->out_norm.d) return seterr(m, PM355_E_UNSUPPORTED, "head: output / output_norm missing");
+    const Tensor * ow[1] = {&m->output};
+    ActQ a = norm_quantize_for(m, x_row, (const float *) m->out_norm.d, m->hp.n_embd, 1, ow, 1, st);
+    float * lg = d_logits ? d_logits : m->logits;
+    if (gemv(m->output, nullptr, a, 1, lg, nullptr, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "head: lm_head gemv");
+    if (d_argmax) pm_launch_argmax(lg, m->hp.n_vocab, d_argmax, nullptr, st);
+    return 0;
+}
+
 // x_in -> x_out for layers [lo, hi); positions from device memory d_pos (pos of token 0)
 int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, int T, float * d_x_out,
                float * d_logits, int32_t * d_argmax, hipStream_t st) {
@@ -222,9 +234,10 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         rc |= gemv(L.t[PM355_T_WK], nullptr, a, T, m->k, (const float *) L.t[PM355_T_BK].d, nullptr, st);
         rc |= gemv(L.t[PM355_T_WV], nullptr, a, T, m->v, (const float *) L.t[PM355_T_BV].d, nullptr, st);
         if (rc) return seterr(m, rc, "decode: qkv gemv");
-        pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, (const float *) m->rope_freqs.d,
-                                T, H, Hkv, dh, hp.n_ctx, m->rope, st);
-        if (pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
+        const long kv_stride = (long) hp.n_ctx * Hkv * dh;
+        pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride,
+                                (const float *) m->rope_freqs.d, T, H, Hkv, dh, hp.n_ctx, m->rope, st);
+        if (pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
             return seterr(m, PM355_E_RANGE, "decode: n_ctx too large for the decode-attention kernel");
         const Tensor * wo[1] = {&L.t[PM355_T_WO]};
         a = quantize_for(m, m->att, Eq, T, wo, 1, st);
@@ -244,13 +257,8 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
     }
     if (d_x_out && cur != d_x_out) (void) hipMemcpyAsync(d_x_out, cur, (size_t) T * E * 4, hipMemcpyDeviceToDevice, st);
     if ((d_logits || d_argmax) && (m->flags & PM355_HAS_HEAD)) {
-        if (!m->output.d || !m->out_norm.d) return seterr(m, PM355_E_UNSUPPORTED, "decode: head tensors missing");
-        const float * last = cur + (size_t) (T - 1) * E;
-        const Tensor * ow[1] = {&m->output};
-        ActQ a = norm_quantize_for(m, last, (const float *) m->out_norm.d, E, 1, ow, 1, st);
-        float * lg = d_logits ? d_logits : m->logits;
-        if (gemv(m->output, nullptr, a, 1, lg, nullptr, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: lm_head gemv");
-        if (d_argmax) pm_launch_argmax(lg, hp.n_vocab, d_argmax, nullptr, st);
+        int rc = run_head(m, cur + (size_t) (T - 1) * E, d_logits, d_argmax, st);
+        if (rc) return rc;
     }
     return hip_ok() ? 0 : seterr(m, PM355_E_HIP, "decode: kernel launch failed");
 }
@@ -276,11 +284,11 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
 void pm355_model_free(pm355_model * m) {
     if (!m) return;
     (void) hipDeviceSynchronize();
-    if (m->step_exec) (void) hipGraphExecDestroy(m->step_exec);
+    for (auto & g : m->graphs) (void) hipGraphExecDestroy(g.exec);
     for (auto & L : m->layers) { for (auto & t : L.t) if (t.d) (void) hipFree(t.d); if (L.kc) (void) hipFree(L.kc); if (L.vc) (void) hipFree(L.vc); }
     Tensor * g[4] = {&m->tok_embd, &m->out_norm, &m->output, &m->rope_freqs};
     for (auto t : g) if (t->d) (void) hipFree(t->d);
-    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->dstage};
+    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->dstage};
     for (auto p : s) if (p) (void) hipFree(p);
     for (int i = 0; i < 2; ++i) if (m->pin[i]) { (void) hipHostFree(m->pin[i]); (void) hipEventDestroy(m->pin_ev[i]); }
     if (m->up_stream) (void) hipStreamDestroy(m->up_stream);
@@ -349,8 +357,12 @@ int pm355_model_fill_tensor(pm355_model * m, int kind, int layer, int type, uint
     return hip_ok() ? 0 : seterr(m, PM355_E_HIP, "fill_tensor");
 }
 
-int pm355_model_finalize(pm355_model * m, int max_tokens) {
+int pm355_model_finalize(pm355_model * m, int max_tokens) { return pm355_model_finalize_seqs(m, max_tokens, 1); }
+
+int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
     (void) hipGetLastError();
+    if (n_seq < 1 || n_seq > 64) return seterr(m, PM355_E_RANGE, "finalize: n_seq must be 1..64");
+    m->n_seq = n_seq;
     if (m->up_stream) (void) hipStreamSynchronize(m->up_stream);
     (void) hipDeviceSynchronize();
     const pm355_hparams & hp = m->hp;
@@ -361,7 +373,7 @@ int pm355_model_finalize(pm355_model * m, int max_tokens) {
         Layer & L = m->layers[il - m->lo];
         for (int kd : {PM355_T_ATTN_NORM, PM355_T_WQ, PM355_T_WK, PM355_T_WV, PM355_T_WO, PM355_T_FFN_NORM, PM355_T_FFN_GATE, PM355_T_FFN_UP, PM355_T_FFN_DOWN})
             if (!L.t[kd].d) return seterr(m, PM355_E_SHAPE, "finalize: a layer tensor is missing");
-        const size_t kvb = Ekv * (size_t) hp.n_ctx * 2;
+        const size_t kvb = Ekv * (size_t) hp.n_ctx * 2 * (size_t) n_seq;
         if (hipMalloc(&L.kc, kvb + 256) != hipSuccess || hipMalloc(&L.vc, kvb + 256) != hipSuccess) return seterr(m, PM355_E_NOMEM, "finalize: kv cache");
         (void) hipMemset(L.kc, 0, kvb + 256); (void) hipMemset(L.vc, 0, kvb + 256);
     }
@@ -372,9 +384,10 @@ int pm355_model_finalize(pm355_model * m, int max_tokens) {
               A((void **) &m->att, T * Eq * 4) && A((void **) &m->h, T * F * 4) && A((void **) &m->logits, (size_t) hp.n_vocab * 4) &&
               A((void **) &m->aq_k, T * pm_q8k_row_bytes((int) ((maxK + 255) / 256 * 256))) &&
               A((void **) &m->aq_0, T * pm_q80_row_bytes((int) ((maxK + 31) / 32 * 32))) &&
-              A((void **) &m->d_pos, 64) && A((void **) &m->d_tok, 64 + T * 4);
+              A((void **) &m->d_pos, 64 * 4) && A((void **) &m->d_ctl, 64) && A((void **) &m->d_tok, 64 + T * 4);
     if (!ok) return seterr(m, PM355_E_NOMEM, "finalize: scratch");
-    (void) hipMemset(m->d_pos, 0, 64);
+    (void) hipMemset(m->d_pos, 0, 64 * 4);
+    { const int32_t ctl[2] = {0, n_seq}; (void) hipMemcpy(m->d_ctl, ctl, 8, hipMemcpyHostToDevice); }
     (void) hipDeviceSynchronize();
     m->finalized = true;
     return hip_ok() ? 0 : seterr(m, PM355_E_HIP, "finalize");
@@ -390,7 +403,7 @@ size_t pm355_model_kv_bytes_per_pos(const pm355_model * m) {
     return (size_t) (m->hi - m->lo) * 2 * (size_t) m->hp.head_dim * m->hp.n_head_kv * 2;
 }
 int pm355_model_kv_clear(pm355_model * m, pm355_stream_t st) {
-    const size_t kvb = (size_t) m->hp.head_dim * m->hp.n_head_kv * (size_t) m->hp.n_ctx * 2;
+    const size_t kvb = (size_t) m->hp.head_dim * m->hp.n_head_kv * (size_t) m->hp.n_ctx * 2 * (size_t) m->n_seq;
     for (auto & L : m->layers) { (void) hipMemsetAsync(L.kc, 0, kvb, (hipStream_t) st); (void) hipMemsetAsync(L.vc, 0, kvb, (hipStream_t) st); }
     return 0;
 }
@@ -399,11 +412,38 @@ void * pm355_model_kv_ptr(pm355_model * m, int layer, int which) {
     return which ? m->layers[layer - m->lo].vc : m->layers[layer - m->lo].kc;
 }
 const char * pm355_model_error(pm355_model * m) { return m->err; }
+void * pm355_model_tensor_ptr(pm355_model * m, int kind, int layer, int * type_out) {
+    Tensor * t = tensor_slot(m, kind, layer);
+    if (!t || !t->d) return nullptr;
+    if (type_out) *type_out = t->type;
+    return t->d;
+}
 
 int pm355_model_set_pos(pm355_model * m, int pos, pm355_stream_t st) {
     if (!m->finalized) return seterr(m, PM355_E_SHAPE, "set_pos: model not finalized");
-    pm_launch_set_pos(m->d_pos, pos, (hipStream_t) st);      // value travels as a kernel argument: capture-safe, no host buffer
+    return pm355_model_set_seq_pos(m, -1, pos, st);
+}
+
+// seq >= 0: set that sequence's position (does not change the current sequence); seq == -1: sequence 0 and make it current
+int pm355_model_set_seq_pos(pm355_model * m, int seq, int pos, pm355_stream_t st) {
+    if (!m->finalized) return seterr(m, PM355_E_SHAPE, "set_seq_pos: model not finalized");
+    if (seq >= m->n_seq) return seterr(m, PM355_E_RANGE, "set_seq_pos: seq >= n_seq");
+    // values travel as kernel arguments: capture-safe, no host buffer lifetime to manage
+    if (seq < 0) { pm_launch_set_i32(m->d_ctl, 0, (hipStream_t) st); seq = 0; }
+    pm_launch_set_i32(m->d_pos + seq, pos, (hipStream_t) st);
     return 0;
+}
+int pm355_model_set_seq(pm355_model * m, int seq, pm355_stream_t st) {
+    if (!m->finalized || seq < 0 || seq >= m->n_seq) return seterr(m, PM355_E_RANGE, "set_seq: bad sequence id");
+    pm_launch_set_i32(m->d_ctl, seq, (hipStream_t) st);
+    return 0;
+}
+int pm355_model_head(pm355_model * m, const float * d_x_row, float * d_logits, int32_t * d_argmax, pm355_stream_t st) {
+    if (!m->finalized || !(m->flags & PM355_HAS_HEAD)) return seterr(m, PM355_E_UNSUPPORTED, "head: window has no head");
+    (void) hipGetLastError();
+    int rc = run_head(m, d_x_row, d_logits, d_argmax, (hipStream_t) st);
+    if (rc) return rc;
+    return hip_ok() ? 0 : seterr(m, PM355_E_HIP, "head: kernel launch failed");
 }
 
 int pm355_model_decode(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, int T, int pos0,
@@ -416,20 +456,41 @@ int pm355_model_decode(pm355_model * m, const int32_t * d_tokens, const float * 
     return run_window(m, d_tokens, d_x_in, T, d_x_out, d_logits, d_argmax, (hipStream_t) st);
 }
 
+// head_first != 0 (ring rank 0): d_x_in is the LAST rank's activation; apply the head to it (-> d_argmax / d_logits),
+// then embed the token found at d_token (which may be d_argmax itself) and run the window -> d_x_out.
+static int step_body(pm355_model * m, const int32_t * d_token, const float * d_x_in, float * d_x_out,
+                     float * d_logits, int32_t * d_argmax, int advance, int rotate, int head_first, hipStream_t st) {
+    int rc;
+    if (head_first) {
+        (void) hipGetLastError();
+        rc = run_head(m, d_x_in, d_logits, d_argmax, st);
+        if (rc) return rc;
+        rc = run_window(m, d_token, nullptr, 1, d_x_out, nullptr, nullptr, st);
+    } else {
+        rc = run_window(m, d_token, d_token ? nullptr : d_x_in, 1, d_x_out, d_logits, d_argmax, st);
+    }
+    if (rc) return rc;
+    if (advance || rotate) pm_launch_advance(m->d_pos, m->d_ctl, advance, rotate, st);
+    return 0;
+}
+
 int pm355_model_step(pm355_model * m, const int32_t * d_token, const float * d_x_in, float * d_x_out,
                      float * d_logits, int32_t * d_argmax, int advance, int use_graph, pm355_stream_t pst) {
+    return pm355_model_step_ex(m, d_token, d_x_in, d_x_out, d_logits, d_argmax, advance, 0, 0, use_graph, pst);
+}
+
+int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * d_x_in, float * d_x_out,
+                        float * d_logits, int32_t * d_argmax, int advance, int rotate, int head_first, int use_graph,
+                        pm355_stream_t pst) {
     if (!m->finalized) return seterr(m, PM355_E_SHAPE, "step: model not finalized");
+    if (head_first && (!(m->flags & PM355_HAS_HEAD) || !d_token || !d_x_in)) return seterr(m, PM355_E_SHAPE, "step: head_first needs HEAD, d_token and d_x_in");
     hipStream_t st = (hipStream_t) pst;
-    if (!use_graph) {
-        int rc = run_window(m, d_token, d_x_in, 1, d_x_out, d_logits, d_argmax, st);
-        if (rc) return rc;
-        if (advance) pm_launch_inc_pos(m->d_pos, advance, st);
-        return 0;
-    }
-    const bool same = m->step_exec && m->g_in == d_x_in && m->g_out == d_x_out && m->g_logits == d_logits &&
-                      m->g_argmax == d_argmax && m->g_tok == d_token && m->g_adv == advance;
-    if (!same) {
-        if (m->step_exec) { (void) hipGraphExecDestroy(m->step_exec); m->step_exec = nullptr; }
+    if (!use_graph) return step_body(m, d_token, d_x_in, d_x_out, d_logits, d_argmax, advance, rotate, head_first, st);
+    hipGraphExec_t exec = nullptr;
+    for (auto & g : m->graphs)
+        if (g.in == d_x_in && g.tok == d_token && g.out == d_x_out && g.logits == d_logits && g.argmax == d_argmax &&
+            g.adv == advance && g.rot == rotate && g.head == head_first) { exec = g.exec; break; }
+    if (!exec) {
         hipGraph_t g = nullptr;
         // capture on a private stream (the legacy default stream cannot capture); nothing executes during capture,
         // the instantiated graph is then launched on the caller's stream
@@ -437,16 +498,16 @@ int pm355_model_step(pm355_model * m, const int32_t * d_token, const float * d_x
             return seterr(m, PM355_E_HIP, "step: capture stream");
         hipStream_t cs = m->cap_stream;
         if (hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) != hipSuccess) return seterr(m, PM355_E_HIP, "step: begin capture");
-        int rc = run_window(m, d_token, d_x_in, 1, d_x_out, d_logits, d_argmax, cs);
-        if (!rc && advance) pm_launch_inc_pos(m->d_pos, advance, cs);
+        int rc = step_body(m, d_token, d_x_in, d_x_out, d_logits, d_argmax, advance, rotate, head_first, cs);
         hipError_t e = hipStreamEndCapture(cs, &g);
         if (rc || e != hipSuccess || !g) { if (g) (void) hipGraphDestroy(g); return rc ? rc : seterr(m, PM355_E_HIP, "step: end capture"); }
-        e = hipGraphInstantiate(&m->step_exec, g, nullptr, nullptr, 0);
+        e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
         (void) hipGraphDestroy(g);
-        if (e != hipSuccess) { m->step_exec = nullptr; return seterr(m, PM355_E_HIP, "step: graph instantiate"); }
-        m->g_in = d_x_in; m->g_out = d_x_out; m->g_logits = d_logits; m->g_argmax = d_argmax; m->g_tok = d_token; m->g_adv = advance;
+        if (e != hipSuccess) return seterr(m, PM355_E_HIP, "step: graph instantiate");
+        if (m->graphs.size() >= 8) { (void) hipGraphExecDestroy(m->graphs.front().exec); m->graphs.erase(m->graphs.begin()); }
+        m->graphs.push_back({d_x_in, d_token, d_x_out, d_logits, d_argmax, advance, rotate, head_first, exec});
     }
-    return hipGraphLaunch(m->step_exec, st) == hipSuccess ? 0 : seterr(m, PM355_E_HIP, "step: graph launch");
+    return hipGraphLaunch(exec, st) == hipSuccess ? 0 : seterr(m, PM355_E_HIP, "step: graph launch");
 }
 
 // d_tokens_io[i] -> d_tokens_io[i+1]: the per-step graph reads its token from m->d_tok[0] and writes argmax to

@@ -95,10 +95,13 @@ __device__ __forceinline__ void rope_cs(const RopeP & r, float pos, int pair, co
 __global__ __launch_bounds__(64) void rope_kv_store_kernel(const float * q, const float * k, const float * v,
                                                            float * q_out, float * k_out_f32,
                                                            uint16_t * kc, uint16_t * vc,
-                                                           const int32_t * pos0_ptr, const float * freq_factors,
+                                                           const int32_t * pos0_ptr, const int32_t * seq_ptr, long seq_stride,
+                                                           const float * freq_factors,
                                                            int H, int Hkv, int dh, int n_ctx, RopeP r) {
     const int head = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
-    const int pos = *pos0_ptr + t;
+    const int seq = seq_ptr ? *seq_ptr : 0;              // multi-sequence: one KV slab and one position per sequence
+    const int pos = pos0_ptr[seq] + t;
+    kc += (long) seq * seq_stride; vc += (long) seq * seq_stride;
     const bool is_q = head < H;
     const int hh = is_q ? head : head - H;
     const float * src = is_q ? q + ((long) t * H + hh) * dh : k + ((long) t * Hkv + hh) * dh;
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(64) void rope_kv_store_kernel(const float * q, cons
 //   LDS: q as f16-rounded floats [dh] | scores/probabilities [n_ctx]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float * q, const uint16_t * kc, const uint16_t * vc,
-                                                          const int32_t * pos0_ptr, float * out,
-                                                          int H, int Hkv, int dh, int n_ctx, float scale) {
+                                                          const int32_t * pos0_ptr, const int32_t * seq_ptr, long seq_stride,
+                                                          float * out, int H, int Hkv, int dh, int n_ctx, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float redf[8];
     __shared__ double redd[4];
@@ -149,7 +152,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float * q, const
     float * sc = qs + dh;                        // [n_ctx]
     const int h = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hk = h / (H / Hkv);
-    const int n_kv = *pos0_ptr + t + 1;          // causal: keys 0..pos
+    const int seq = seq_ptr ? *seq_ptr : 0;
+    kc += (long) seq * seq_stride; vc += (long) seq * seq_stride;
+    const int n_kv = pos0_ptr[seq] + t + 1;      // causal: keys 0..pos
     for (int e = tid; e < dh; e += 256) qs[e] = h2f(f2h(q[((long) t * H + h) * dh + e]));
     __syncthreads();
     // ---- scores
@@ -253,8 +258,13 @@ __global__ void scale_kernel(const float * a, float * y, float s, long n) {
     const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = a[i] * s;
 }
-__global__ void inc_pos_kernel(int32_t * pos, int by) { *pos += by; }
-__global__ void set_pos_kernel(int32_t * pos, int v) { *pos = v; }
+// ctl = {seq, n_seq}; pos[seq] += by; then seq = (seq + rotate) % n_seq
+__global__ void advance_kernel(int32_t * pos, int32_t * ctl, int by, int rotate) {
+    const int s = ctl[0];
+    pos[s] += by;
+    if (rotate) ctl[0] = (s + rotate) % ctl[1];
+}
+__global__ void set_i32_kernel(int32_t * p, int v) { *p = v; }
 
 // ---- launchers -------------------------------------------------------------------------------------
 void pm_launch_embed(int type, const void * table, int K, const int32_t * tokens, int n_tok, float * out, hipStream_t st) {
@@ -273,16 +283,18 @@ void pm_rope_params(pm_rope_cfg & c) {
 }
 
 void pm_launch_rope_kv_store(const float * q, const float * k, const float * v, float * q_out, float * k_out_f32,
-                             void * kc, void * vc, const int32_t * pos0, const float * freq_factors,
+                             void * kc, void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride,
+                             const float * freq_factors,
                              int n_tok, int H, int Hkv, int dh, int n_ctx, const pm_rope_cfg & c, hipStream_t st) {
     RopeP r;
     r.n_dims = c.n_dims; r.mode = c.mode; r.n_ctx_orig = c.n_ctx_orig; r.theta_scale = c.theta_scale;
     r.freq_scale = c.freq_scale; r.ext_factor = c.ext_factor; r.attn_factor = c.attn_factor; r.corr0 = c.corr0; r.corr1 = c.corr1;
     hipLaunchKernelGGL(rope_kv_store_kernel, dim3(H + Hkv, n_tok), dim3(64), 0, st,
-                       q, k, v, q_out, k_out_f32, (uint16_t *) kc, (uint16_t *) vc, pos0, freq_factors, H, Hkv, dh, n_ctx, r);
+                       q, k, v, q_out, k_out_f32, (uint16_t *) kc, (uint16_t *) vc, pos0, seq, seq_stride, freq_factors, H, Hkv, dh, n_ctx, r);
 }
 
-int pm_launch_attn_decode(const float * q, const void * kc, const void * vc, const int32_t * pos0, float * out,
+int pm_launch_attn_decode(const float * q, const void * kc, const void * vc, const int32_t * pos0,
+                          const int32_t * seq, long seq_stride, float * out,
                           int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st) {
     const size_t lds = (size_t) (dh + n_ctx) * 4;
     if (lds > 150 * 1024 || dh % 8 || n_ctx % 8) return -1;
@@ -291,7 +303,7 @@ int pm_launch_attn_decode(const float * q, const void * kc, const void * vc, con
         if (!set) { (void) hipFuncSetAttribute((const void *) attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set = true; }
     }
     hipLaunchKernelGGL(attn_decode_kernel, dim3(H, n_tok), dim3(256), lds, st,
-                       q, (const uint16_t *) kc, (const uint16_t *) vc, pos0, out, H, Hkv, dh, n_ctx, scale);
+                       q, (const uint16_t *) kc, (const uint16_t *) vc, pos0, seq, seq_stride, out, H, Hkv, dh, n_ctx, scale);
     return 0;
 }
 
@@ -310,9 +322,9 @@ void pm_launch_silu_mul(const float * g, const float * u, float * y, long n, hip
 void pm_launch_scale(const float * a, float * y, float s, long n, hipStream_t st) {
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, a, y, s, n);
 }
-void pm_launch_set_pos(int32_t * pos, int v, hipStream_t st) {
-    hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, st, pos, v);
+void pm_launch_set_i32(int32_t * p, int v, hipStream_t st) {
+    hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, st, p, v);
 }
-void pm_launch_inc_pos(int32_t * pos, int by, hipStream_t st) {
-    hipLaunchKernelGGL(inc_pos_kernel, dim3(1), dim3(1), 0, st, pos, by);
+void pm_launch_advance(int32_t * pos, int32_t * ctl, int by, int rotate, hipStream_t st) {
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, pos, ctl, by, rotate);
 }

@@ -12,16 +12,18 @@ void pm_rope_params(pm_rope_cfg & c);
 
 void pm_launch_embed(int type, const void * table, int K, const int32_t * tokens, int n_tok, float * out, hipStream_t st);
 void pm_launch_rope_kv_store(const float * q, const float * k, const float * v, float * q_out, float * k_out_f32,
-                             void * kc, void * vc, const int32_t * pos0, const float * freq_factors,
+                             void * kc, void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride,
+                             const float * freq_factors,
                              int n_tok, int H, int Hkv, int dh, int n_ctx, const pm_rope_cfg & c, hipStream_t st);
-int  pm_launch_attn_decode(const float * q, const void * kc, const void * vc, const int32_t * pos0, float * out,
+int  pm_launch_attn_decode(const float * q, const void * kc, const void * vc, const int32_t * pos0,
+                           const int32_t * seq, long seq_stride, float * out,
                            int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st);
 void pm_launch_argmax(const float * x, int n, int32_t * idx, float * val, hipStream_t st);
 void pm_launch_add(const float * a, const float * b, float * y, long n, long nb, hipStream_t st);
 void pm_launch_mul(const float * a, const float * b, float * y, long n, long nb, hipStream_t st);
 void pm_launch_silu_mul(const float * g, const float * u, float * y, long n, hipStream_t st);
 void pm_launch_scale(const float * a, float * y, float s, long n, hipStream_t st);
-void pm_launch_inc_pos(int32_t * pos, int by, hipStream_t st);
-void pm_launch_set_pos(int32_t * pos, int v, hipStream_t st);
+void pm_launch_set_i32(int32_t * p, int v, hipStream_t st);
+void pm_launch_advance(int32_t * pos, int32_t * ctl, int by, int rotate, hipStream_t st);
 void pm_launch_fill_random_blocks(int type, void * dst, int64_t K, int64_t nrows, uint64_t seed, float scale, hipStream_t st);
 void pm_launch_fill_random_f32(float * dst, int64_t n, uint64_t seed, float mean, float amp, hipStream_t st);

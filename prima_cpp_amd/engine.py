@@ -64,6 +64,11 @@ def _lib():
             "pm355_model_set_tensor": (_i32, [_vp, _i32, _i32, _i32, _vp, _sz]),
             "pm355_model_fill_tensor": (_i32, [_vp, _i32, _i32, _i32, C.c_uint64, C.c_float]),
             "pm355_model_finalize": (_i32, [_vp, _i32]),
+            "pm355_model_finalize_seqs": (_i32, [_vp, _i32, _i32]),
+            "pm355_model_set_seq_pos": (_i32, [_vp, _i32, _i32, _vp]),
+            "pm355_model_set_seq": (_i32, [_vp, _i32, _vp]),
+            "pm355_model_head": (_i32, [_vp, _vp, _vp, _vp, _vp]),
+            "pm355_model_step_ex": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
             "pm355_model_weight_bytes": (_sz, [_vp]),
             "pm355_model_kv_bytes_per_pos": (_sz, [_vp]),
             "pm355_model_kv_clear": (_i32, [_vp, _vp]),
@@ -179,8 +184,9 @@ class Window:
         if rope_freqs and hp["arch"] == 0:
             self.fill_tensor(T_ROPE_FREQS, -1, F32, seed + 11, 0.0)
 
-    def finalize(self, max_tokens=1):
-        self._chk(self.lib.pm355_model_finalize(self.h, max_tokens), "finalize")
+    def finalize(self, max_tokens=1, n_seq=1):
+        self.n_seq = n_seq
+        self._chk(self.lib.pm355_model_finalize_seqs(self.h, max_tokens, n_seq), "finalize")
 
     # ---- info ----------------------------------------------------------------------------------
     @property
@@ -222,6 +228,20 @@ class Window:
 
     def set_pos(self, pos):
         self._chk(self.lib.pm355_model_set_pos(self.h, pos, stream_ptr()), "set_pos")
+
+    def set_seq_pos(self, seq, pos):
+        self._chk(self.lib.pm355_model_set_seq_pos(self.h, seq, pos, stream_ptr()), "set_seq_pos")
+
+    def set_seq(self, seq):
+        self._chk(self.lib.pm355_model_set_seq(self.h, seq, stream_ptr()), "set_seq")
+
+    def head(self, x_row, logits=None, argmax=None):
+        self._chk(self.lib.pm355_model_head(self.h, ptr(x_row), ptr(logits), ptr(argmax), stream_ptr()), "head")
+
+    def step_ex(self, token=None, x_in=None, x_out=None, logits=None, argmax=None, advance=1, rotate=0, head_first=False,
+                use_graph=True):
+        self._chk(self.lib.pm355_model_step_ex(self.h, ptr(token), ptr(x_in), ptr(x_out), ptr(logits), ptr(argmax), advance,
+                                               rotate, int(head_first), int(use_graph), stream_ptr()), "step_ex")
 
     def step(self, token=None, x_in=None, x_out=None, logits=None, argmax=None, advance=1, use_graph=True):
         self._chk(self.lib.pm355_model_step(self.h, ptr(token), ptr(x_in), ptr(x_out), ptr(logits), ptr(argmax), advance,

@@ -1,0 +1,140 @@
+"""world_size-2 / 3 CPU (gloo) tests of the piped-ring schedule with a fake window: the staggered,
+multi-sequence ring must reproduce exactly what a single process computing every sequence serially does."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+E = 16
+VOCAB = 97
+
+
+def _layer(x, il, pos):
+    """deterministic fake layer: depends on layer id, position and input (exact in fp32 integer range)"""
+    return torch.remainder(x * 3.0 + float(il * 7 + pos), 1009.0)
+
+
+def _embed(tok):
+    return (torch.arange(E, dtype=torch.float32) * 5.0 + float(tok)).view(1, E)
+
+
+def _head(x):
+    return int(torch.remainder(x.sum(), VOCAB).item())
+
+
+class FakeCompute:
+    device = "cpu"
+    n_embd = E
+
+    def __init__(self, lo, hi, world):
+        self.lo, self.hi = lo, hi
+        self.pos = [0] * world
+        self.tok = [None] * world
+        self.generated = [[] for _ in range(world)]
+
+    def _window(self, seq, x):
+        for il in range(self.lo, self.hi):
+            x = _layer(x, il, self.pos[seq])
+        self.pos[seq] += 1
+        return x.clone()
+
+    def first_rank_step(self, seq, x_last, forced_token):
+        if x_last is not None:
+            t = _head(x_last)
+            self.generated[seq].append(t)
+            self.tok[seq] = t
+        if forced_token is not None:
+            self.tok[seq] = forced_token
+        return self._window(seq, _embed(self.tok[seq]))
+
+    def rank_step(self, seq, x_in):
+        return self._window(seq, x_in)
+
+
+def _serial(n_layer, world, first_tokens, n_rounds):
+    out = []
+    for s in range(world):
+        tok, gen = first_tokens[s], []
+        for pos in range(n_rounds):
+            x = _embed(tok)
+            for il in range(n_layer):
+                x = _layer(x, il, pos)
+            tok = _head(x)
+            gen.append(tok)
+        out.append(gen)
+    return out
+
+
+def _worker(rank, world, port, n_layer, n_rounds, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from prima_cpp_amd.ring import RingDriver, partition_layers
+    wins = partition_layers([10 + (i % 3) for i in range(n_layer)], 12, world)
+    lo, hi = wins[rank]
+    comp = FakeCompute(lo, hi, world)
+    drv = RingDriver(comp, rank, world)
+    first = [11 + 3 * s for s in range(world)]
+    # n_rounds full rounds + one extra round on rank 0 so the last tokens are produced by the head
+    total = world * (n_rounds + 1)
+    for m in range(total):
+        forced = first[m] if (rank == 0 and m < world) else None
+        drv.micro_step(forced_token=forced)
+    drv.flush()
+    if rank == 0:
+        q.put(comp.generated)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ring_schedule_matches_serial(world):
+    n_layer, n_rounds = 7, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_layer, n_rounds, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = _serial(n_layer, world, [11 + 3 * s for s in range(world)], n_rounds)
+    for s in range(world):
+        assert got[s][:n_rounds] == want[s], (s, got[s], want[s])
+
+
+def test_ring_world1_matches_serial():
+    from prima_cpp_amd.ring import RingDriver
+    comp = FakeCompute(0, 5, 1)
+    drv = RingDriver(comp, 0, 1)
+    for m in range(7):
+        drv.micro_step(forced_token=11 if m == 0 else None)
+    assert comp.generated[0][:6] == _serial(5, 1, [11], 6)[0]
+
+
+def test_partition_layers_balances_bytes():
+    from prima_cpp_amd.ring import partition_layers
+    lb = [513] * 80
+    wins = partition_layers(lb, 862, 8)
+    assert wins[0][0] == 0 and wins[-1][1] == 80 and all(a[1] == b[0] for a, b in zip(wins, wins[1:]))
+    loads = [sum(lb[lo:hi]) + (862 if i == 0 else 0) for i, (lo, hi) in enumerate(wins)]
+    assert max(loads) <= 11 * 513          # 80 layers + head over 8 ranks: nobody gets more than 11 layers' worth
+    assert partition_layers([1, 1, 1], 0, 3) == [(0, 1), (1, 2), (2, 3)]
