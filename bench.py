@@ -66,6 +66,20 @@ def layer_bytes(hp, mixture):
     return out
 
 
+def usable_cores():
+    """Threads the CPU baseline may use: affinity mask capped by the cgroup CPU quota (the GPU box exposes 256 logical
+    CPUs but a cpu.max quota of 16; oversubscribing ggml's spin-barrier thread pool is catastrophically slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            if q != "max":
+                n = max(1, min(n, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(hp, mixture, seconds):
     """Reference ggml CPU backend (unmodified sources, prebuilt under oracle/_ref) on this host's cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -75,7 +89,7 @@ def cpu_baseline(hp, mixture, seconds):
     if flavour is None:
         return None
     ref = B.Ref(flavour)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     rng = np.random.default_rng(0)
     Ed, Eq, Ekv, F = hp["n_embd"], hp["head_dim"] * hp["n_head"], hp["head_dim"] * hp["n_head_kv"], hp["n_ff"]
     shape = {E.T_WQ: (Ed, Eq), E.T_WK: (Ed, Ekv), E.T_WV: (Ed, Ekv), E.T_WO: (Eq, Ed), E.T_FFN_GATE: (Ed, F),
