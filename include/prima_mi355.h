@@ -123,6 +123,12 @@ PM355_API int pm355_rope_kv_store(const float * q, const float * k, const float 
 PM355_API int pm355_attn_decode(const float * q, const void * k_cache, const void * v_cache, const int32_t * d_pos0,
                                 float * out, int n_tokens, int n_head, int n_head_kv, int head_dim, int n_ctx,
                                 float kq_scale, pm355_stream_t stream);
+/* single-token fusion of the two entries above (rope on q,k + KV store + attention in ONE launch; what the engine
+ * uses at decode). q/k/v are the raw projections of ONE token; the caches receive the new K row / V column. */
+PM355_API int pm355_attn_rope_fused(const float * q, const float * k, const float * v, void * k_cache, void * v_cache,
+                                    const int32_t * d_pos0, const float * freq_factors, float * out,
+                                    int n_head, int n_head_kv, int head_dim, int n_ctx, float kq_scale,
+                                    const pm355_rope_params * rp, pm355_stream_t stream);
 /* greedy sampler (src/llama-sampling.cpp:390-397): index of the first maximum */
 PM355_API int pm355_argmax(const float * x, int64_t n, int32_t * d_index, float * d_value, pm355_stream_t stream);
 /* ggml_compute_forward_add_f32 / mul_f32 (row-broadcast of b over a), silu(*u), scale */

@@ -161,6 +161,19 @@ int pm355_attn_decode(const float * q, const void * kc, const void * vc, const i
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_attn_rope_fused(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * d_pos0,
+                          const float * ff, float * out, int H, int Hkv, int dh, int n_ctx, float kq_scale,
+                          const pm355_rope_params * rp, pm355_stream_t st) {
+    if (!rp || rp->n_dims % 2 || rp->n_dims > dh) return fail(PM355_E_SHAPE, "attn_rope_fused: n_dims");
+    pm_rope_cfg c;
+    c.n_dims = rp->n_dims; c.mode = rp->mode; c.n_ctx_orig = rp->n_ctx_orig; c.freq_base = rp->freq_base; c.freq_scale = rp->freq_scale;
+    c.ext_factor = rp->ext_factor; c.attn_factor = rp->attn_factor; c.beta_fast = rp->beta_fast; c.beta_slow = rp->beta_slow;
+    pm_rope_params(c);
+    if (pm_launch_attn_rope_fused(q, k, v, kc, vc, d_pos0, nullptr, 0, ff, out, H, Hkv, dh, n_ctx, kq_scale, c, S(st)))
+        return fail(PM355_E_UNSUPPORTED, "attn_rope_fused: head_dim must be 64/128/256, n_ctx % 8 == 0 and fit LDS");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 int pm355_argmax(const float * x, int64_t n, int32_t * d_index, float * d_value, pm355_stream_t st) {
     pm_launch_argmax(x, (int) n, d_index, d_value, S(st)); HIP_TRY(hipGetLastError()); return 0;
 }

@@ -15,6 +15,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -39,6 +40,7 @@ struct pm355_model {
     uint8_t * aq_k = nullptr, * aq_0 = nullptr;     // quantized activation scratch (Q8_K / Q8_0), sized for max(K)
     int32_t * d_pos = nullptr, * d_tok = nullptr, * d_ctl = nullptr;   // d_pos[n_seq]; d_ctl = {current seq, n_seq}
     int n_seq = 1;
+    bool no_fuse = false;                 // PM355_NO_FUSE=1: node-by-node kernels (debug / A-B)
     // staging for set_tensor
     void * pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2]; void * dstage = nullptr; size_t stage_bytes = 0;
     hipStream_t up_stream = nullptr, cap_stream = nullptr;
@@ -235,10 +237,16 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         rc |= gemv(L.t[PM355_T_WV], nullptr, a, T, m->v, (const float *) L.t[PM355_T_BV].d, nullptr, st);
         if (rc) return seterr(m, rc, "decode: qkv gemv");
         const long kv_stride = (long) hp.n_ctx * Hkv * dh;
+        bool fused_attn = false;
+        if (T == 1 && !m->no_fuse)
+            fused_attn = pm_launch_attn_rope_fused(m->q, m->k, m->v, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride,
+                                                   (const float *) m->rope_freqs.d, m->att, H, Hkv, dh, hp.n_ctx, kq_scale, m->rope, st) == 0;
+        if (!fused_attn) {
         pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride,
                                 (const float *) m->rope_freqs.d, T, H, Hkv, dh, hp.n_ctx, m->rope, st);
         if (pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
             return seterr(m, PM355_E_RANGE, "decode: n_ctx too large for the decode-attention kernel");
+        }
         const Tensor * wo[1] = {&L.t[PM355_T_WO]};
         a = quantize_for(m, m->att, Eq, T, wo, 1, st);
         float * x_mid = (cur == bufs[0]) ? bufs[1] : bufs[0];                 // ffn_inp = wo.att + inpSA
@@ -278,6 +286,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     m->rope.freq_base = hp->rope_freq_base; m->rope.freq_scale = hp->rope_freq_scale;
     m->rope.ext_factor = 0.0f; m->rope.attn_factor = 1.0f; m->rope.beta_fast = 32.0f; m->rope.beta_slow = 1.0f;
     pm_rope_params(m->rope);
+    { const char * e = getenv("PM355_NO_FUSE"); m->no_fuse = e && e[0] == '1'; }
     return m;
 }
 

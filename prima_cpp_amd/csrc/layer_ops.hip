@@ -214,6 +214,151 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float * q, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// single-token decode attention with RoPE and the KV store fused in (one launch per layer instead of two,
+// and no dependent load chains: every phase issues independent loads).
+//   grid = H query heads, 256 threads. Each workgroup rotates its own q and (redundantly, 64 pairs) the k of its
+//   KV head for the current position; the first query head of each KV group also writes the F16 K row / V column.
+//   The current position's key/value are taken from LDS, never re-read from the cache (no inter-workgroup hazard).
+//   PV: thread = (channel e, part); each thread streams its own V^T row with 16-B loads - no cross-lane reduction.
+// Same rounding points as attn_decode_kernel / the reference (q, p -> F16; K, V F16; f32 accumulate).
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_rope_fused_kernel(const float * q, const float * k, const float * v,
+                                                              uint16_t * kc, uint16_t * vc,
+                                                              const int32_t * pos0_ptr, const int32_t * seq_ptr, long seq_stride,
+                                                              const float * freq_factors, float * out,
+                                                              int H, int Hkv, int n_ctx, float scale, RopeP r) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float redf[8];
+    __shared__ double redd[4];
+    constexpr int PARTS = 256 / DH;
+    float * qs   = (float *) smem;               // [DH]  f16-rounded rotated q
+    float * kcur = qs + DH;                      // [DH]  f16-rounded rotated k of this position
+    float * vcur = kcur + DH;                    // [DH]  f16-rounded v of this position
+    float * cs   = vcur + DH;                    // [DH]  cos/sin per pair
+    float * part = cs + DH;                      // [256] PV partials
+    float * sc   = part + 256;                   // [n_ctx] scores / probabilities
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hk = h / (H / Hkv);
+    const int seq = seq_ptr ? *seq_ptr : 0;
+    kc += (long) seq * seq_stride; vc += (long) seq * seq_stride;
+    const int pos = pos0_ptr[seq];
+    const bool neox = r.mode & 2;
+    const int half = r.n_dims / 2;
+    if (tid < DH / 2) {
+        float c = 1.0f, s_ = 0.0f;
+        if (tid < half) rope_cs(r, (float) pos, tid, freq_factors, c, s_);
+        cs[2 * tid] = c; cs[2 * tid + 1] = s_;
+    }
+    __syncthreads();
+    // rotate q (threads 0..DH/2-1) and k (threads DH/2..DH-1); v copy (threads DH..2DH-1 when available)
+    if (tid < DH) {
+        const bool is_k = tid >= DH / 2;
+        const int pair = is_k ? tid - DH / 2 : tid;
+        const float * src = is_k ? k + (long) hk * DH : q + (long) h * DH;
+        int a, b; float o0, o1;
+        if (pair < half) {
+            a = neox ? pair : 2 * pair; b = neox ? pair + half : 2 * pair + 1;
+            const float c = cs[2 * pair], s_ = cs[2 * pair + 1];
+            const float x0 = src[a], x1 = src[b];
+            o0 = x0 * c - x1 * s_; o1 = x0 * s_ + x1 * c;
+        } else {
+            a = r.n_dims + 2 * (pair - half); b = a + 1; o0 = src[a]; o1 = src[b];
+        }
+        const uint16_t h0 = f2h(o0), h1 = f2h(o1);
+        float * dst = is_k ? kcur : qs;
+        dst[a] = h2f(h0); dst[b] = h2f(h1);
+        if (is_k && h % (H / Hkv) == 0) {
+            uint16_t * d = kc + (long) pos * Hkv * DH + (long) hk * DH;
+            d[a] = h0; d[b] = h1;
+        }
+    }
+    for (int e = tid; e < DH; e += 256) {
+        const uint16_t hv = f2h(v[(long) hk * DH + e]);
+        vcur[e] = h2f(hv);
+        if (h % (H / Hkv) == 0) vc[(long) (hk * DH + e) * n_ctx + pos] = hv;
+    }
+    __syncthreads();
+    // ---- scores: cached keys 0..pos-1 (thread per key), current key from LDS (thread 255 of the first sweep)
+    const int n_kv = pos + 1;
+    float lmax = -INFINITY;
+    for (int i = tid; i < pos; i += 256) {
+        const uint16_t * kr = kc + (long) i * Hkv * DH + (long) hk * DH;
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int e = 0; e < DH; e += 8) {
+            const u32x4 kk = *(const u32x4 *) (kr + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc += h2f((uint16_t) (kk[j] & 0xFFFF)) * qs[e + 2 * j];
+                acc += h2f((uint16_t) (kk[j] >> 16)) * qs[e + 2 * j + 1];
+            }
+        }
+        const float s_ = acc * scale;
+        sc[i] = s_;
+        lmax = fmaxf(lmax, s_);
+    }
+    if (tid == 255) {
+        float acc = 0.0f;
+        for (int e = 0; e < DH; ++e) acc += kcur[e] * qs[e];
+        const float s_ = acc * scale;
+        sc[pos] = s_;
+        lmax = fmaxf(lmax, s_);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    if (lane == 0) redf[wave] = lmax;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    double lsum = 0.0;
+    for (int i = tid; i < n_kv; i += 256) {
+        const float e = expf(sc[i] - mx);
+        sc[i] = e;
+        lsum += (double) e;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+    if (lane == 0) redd[wave] = lsum;
+    __syncthreads();
+    const double tot = (redd[0] + redd[1]) + (redd[2] + redd[3]);
+    const float inv = (float) (1.0 / tot);
+    const int n_pad = (pos + 7) & ~7;                                  // cached part, padded to the 16-B load width
+    float p_cur = 0.0f;
+    for (int i = tid; i < n_pad + 1; i += 256) {
+        if (i < pos) sc[i] = h2f(f2h(sc[i] * inv));
+        else if (i < n_pad) { if (i != pos) sc[i] = 0.0f; }
+    }
+    __syncthreads();
+    p_cur = h2f(f2h(sc[pos] * inv));                                   // sc[pos] still holds exp(): untouched above
+    __syncthreads();
+    if (pos < n_pad && tid == 0) sc[pos] = 0.0f;                       // cache column `pos` must not contribute twice
+    __syncthreads();
+    // ---- PV: thread (e, part) streams V^T[hk*DH+e][8*chunk ..] for chunk = part, part+PARTS, ...
+    {
+        const int e = tid % DH, pt = tid / DH;
+        const uint16_t * vr = vc + (long) (hk * DH + e) * n_ctx;
+        float acc = 0.0f;
+        for (int i = pt * 8; i < n_pad; i += PARTS * 8) {
+            const u32x4 vv = *(const u32x4 *) (vr + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc += h2f((uint16_t) (vv[j] & 0xFFFF)) * sc[i + 2 * j];
+                acc += h2f((uint16_t) (vv[j] >> 16)) * sc[i + 2 * j + 1];
+            }
+        }
+        part[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < DH) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) acc += part[pt * DH + tid];
+        acc += vcur[tid] * p_cur;
+        out[(long) h * DH + tid] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // argmax over n floats, first maximum wins. Single workgroup of 1024 threads (n ~ 128k: ~2 us).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void argmax_kernel(const float * x, int n, int32_t * out_idx, float * out_val) {
@@ -304,6 +449,26 @@ int pm_launch_attn_decode(const float * q, const void * kc, const void * vc, con
     }
     hipLaunchKernelGGL(attn_decode_kernel, dim3(H, n_tok), dim3(256), lds, st,
                        q, (const uint16_t *) kc, (const uint16_t *) vc, pos0, seq, seq_stride, out, H, Hkv, dh, n_ctx, scale);
+    return 0;
+}
+
+int pm_launch_attn_rope_fused(const float * q, const float * k, const float * v, void * kc, void * vc,
+                               const int32_t * pos0, const int32_t * seq, long seq_stride, const float * freq_factors,
+                               float * out, int H, int Hkv, int dh, int n_ctx, float scale, const pm_rope_cfg & c, hipStream_t st) {
+    if ((dh != 64 && dh != 128 && dh != 256) || n_ctx % 8) return -1;
+    const size_t lds = (size_t) (4 * dh + 256 + n_ctx + 8) * 4;
+    if (lds > 150 * 1024) return -1;
+    RopeP r;
+    r.n_dims = c.n_dims; r.mode = c.mode; r.n_ctx_orig = c.n_ctx_orig; r.theta_scale = c.theta_scale;
+    r.freq_scale = c.freq_scale; r.ext_factor = c.ext_factor; r.attn_factor = c.attn_factor; r.corr0 = c.corr0; r.corr1 = c.corr1;
+    auto launch = [&](auto kern) {
+        if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipLaunchKernelGGL(kern, dim3(H), dim3(256), lds, st, q, k, v, (uint16_t *) kc, (uint16_t *) vc, pos0, seq, seq_stride,
+                           freq_factors, out, H, Hkv, n_ctx, scale, r);
+    };
+    if (dh == 64) launch(attn_rope_fused_kernel<64>);
+    else if (dh == 128) launch(attn_rope_fused_kernel<128>);
+    else launch(attn_rope_fused_kernel<256>);
     return 0;
 }
 

@@ -18,6 +18,9 @@ void pm_launch_rope_kv_store(const float * q, const float * k, const float * v, 
 int  pm_launch_attn_decode(const float * q, const void * kc, const void * vc, const int32_t * pos0,
                            const int32_t * seq, long seq_stride, float * out,
                            int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st);
+int  pm_launch_attn_rope_fused(const float * q, const float * k, const float * v, void * kc, void * vc,
+                                const int32_t * pos0, const int32_t * seq, long seq_stride, const float * freq_factors,
+                                float * out, int H, int Hkv, int dh, int n_ctx, float scale, const pm_rope_cfg & c, hipStream_t st);
 void pm_launch_argmax(const float * x, int n, int32_t * idx, float * val, hipStream_t st);
 void pm_launch_add(const float * a, const float * b, float * y, long n, long nb, hipStream_t st);
 void pm_launch_mul(const float * a, const float * b, float * y, long n, long nb, hipStream_t st);

@@ -47,6 +47,7 @@ _SIGS = {
     "pm355_get_rows": (_i32, [_i32, _vp, _i64, _vp, _i32, _vp, _vp]),
     "pm355_rope_kv_store": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pm355_attn_decode": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "pm355_attn_rope_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "pm355_argmax": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "pm355_silu_mul": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "pm355_add": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp]),

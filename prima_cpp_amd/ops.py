@@ -162,3 +162,18 @@ def get_rows(w, tokens):
     out = torch.empty((tokens.numel(), w.K), dtype=torch.float32, device=tokens.device)
     check(lib.pm355_get_rows(w.type, ptr(w.data), w.K, ptr(tokens), tokens.numel(), ptr(out), stream_ptr()), "get_rows")
     return out
+
+
+def attn_rope_fused(q, k, v, k_cache, v_cache, pos0, n_head, n_head_kv, head_dim, n_ctx, scale, freq_factors=None, mode=0,
+                    n_ctx_orig=8192, freq_base=10000.0, freq_scale=1.0, ext_factor=0.0, attn_factor=1.0,
+                    beta_fast=32.0, beta_slow=1.0, n_dims=None):
+    """Single-token rope + KV store + attention in one launch. q [H*dh], k/v [Hkv*dh] raw projections."""
+    import ctypes as C
+    lib = L.load()
+    rp = RopeParams(n_dims or head_dim, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow)
+    out = torch.empty_like(q)
+    pos = torch.tensor([pos0], dtype=torch.int32, device=q.device)
+    check(lib.pm355_attn_rope_fused(ptr(q), ptr(k), ptr(v), ptr(k_cache), ptr(v_cache), ptr(pos), ptr(freq_factors), ptr(out),
+                                    n_head, n_head_kv, head_dim, n_ctx, float(scale), C.addressof(rp), stream_ptr()),
+          "attn_rope_fused")
+    return out

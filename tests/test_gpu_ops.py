@@ -258,3 +258,29 @@ def test_get_rows_bitexact(P, oracle, t):
     for i, tk in enumerate(toks):
         want = oracle.dequantize_row(t, blocks[tk * rs:(tk + 1) * rs], K)
         assert np.array_equal(got[i].view(np.uint32), want.view(np.uint32)), (t, i)
+
+
+@pytest.mark.parametrize("mode,dh", [(0, 128), (2, 128), (0, 64)])
+@pytest.mark.parametrize("n_past", [0, 1, 7, 8, 9, 63, 300])
+def test_attn_rope_fused_equals_two_kernel_path(P, mode, dh, n_past):
+    """The fused single-token kernel must agree with rope_kv_store + attn_decode (same rounding points) and must
+    leave the caches in exactly the same state."""
+    torch = P.torch
+    rng = np.random.default_rng(44)
+    H, Hkv, n_ctx = 8, 2, 512
+    K0 = rng.normal(0, 1, (n_ctx, Hkv * dh)).astype(np.float16)
+    V0 = rng.normal(0, 1, (Hkv * dh, n_ctx)).astype(np.float16)
+    K0[n_past:] = 0; V0[:, n_past:] = 0
+    q = rng.normal(0, 1, (1, H * dh)).astype(np.float32)
+    k = rng.normal(0, 1, (1, Hkv * dh)).astype(np.float32)
+    v = rng.normal(0, 1, (1, Hkv * dh)).astype(np.float32)
+    ff = (1 + rng.uniform(0, 7, dh // 2)).astype(np.float32)
+    kw = dict(freq_factors=_dev(P, ff), mode=mode, freq_base=500000.0)
+    kc1, vc1 = _f16bits(P, K0), _f16bits(P, V0)
+    qr, _ = P.rope_kv_store(_dev(P, q), _dev(P, k), _dev(P, v), kc1, vc1, n_past, H, Hkv, dh, n_ctx, **kw)
+    want = P.attn_decode(qr, kc1, vc1, n_past, H, Hkv, dh, n_ctx, 1.0 / np.sqrt(dh))
+    kc2, vc2 = _f16bits(P, K0), _f16bits(P, V0)
+    got = P.attn_rope_fused(_dev(P, q), _dev(P, k), _dev(P, v), kc2, vc2, n_past, H, Hkv, dh, n_ctx, 1.0 / np.sqrt(dh), **kw)
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
+    w, g = want.cpu().numpy(), got.cpu().numpy()
+    assert np.abs(w - g).max() <= 2e-6 * max(1.0, np.abs(w).max())      # summation order only
