@@ -97,6 +97,18 @@ PM355_API int pm355_rms_norm(const float * x, const float * w, float * y_f32, vo
 PM355_API int pm355_mul_mat_vec_q(int type, const void * W, const void * W2, int64_t K, int64_t N,
                                   const void * xq, int ncols, float * y, int64_t y_stride,
                                   const float * bias, const float * resid, pm355_stream_t stream);
+/* Single-token fusion used by the engine (and by the plug-in's graph pattern matcher): up to 3 weight matrices of the
+ * same K that share ONE f32 activation row x (e.g. wq/wk/wv; at most two distinct quant types among Q4_K/Q5_K/Q6_K, or
+ * all Q8_0) in ONE launch. The activation is quantized to the reference's vec_dot_type inside the kernel, bit-exactly
+ * (quantize_row_q8_K / quantize_row_q8_0), after an optional fused rms_norm(x, eps) * norm_w
+ * (ggml_compute_forward_rms_norm_f32 + mul). Per job: y = W.x (+bias) (+resid), or silu(W.x) * (W2.x) when W2 != NULL. */
+typedef struct {
+    int32_t type; int32_t pad_; int64_t N;
+    const void * W; const void * W2;
+    float * y; const float * bias; const float * resid;
+} pm355_matvec_job;
+PM355_API int pm355_mul_mat_vec_fused(const pm355_matvec_job * jobs, int njobs, int64_t K, const float * x_f32,
+                                      const float * norm_w, float eps, pm355_stream_t stream);
 /* test hook: additionally writes, per (row, unit), the exact int32 pair {sum scale*q_w*q_a, sum min*bsum} */
 PM355_API int pm355_mul_mat_vec_q_dbg(int type, const void * W, int64_t K, int64_t N, const void * xq, float * y,
                                       int32_t * int_partials, int64_t * units_per_row, pm355_stream_t stream);

@@ -128,6 +128,21 @@ int pm355_mul_mat_vec_q(int type, const void * W, const void * W2, int64_t K, in
     a.y = y; a.y_stride = (size_t) y_stride; a.bias = bias; a.resid = resid; a.dbg_int = nullptr;
     return gemv_rc(pm_launch_gemv(a, S(st)));
 }
+int pm355_mul_mat_vec_fused(const pm355_matvec_job * jobs, int njobs, int64_t K, const float * x_f32, const float * norm_w,
+                            float eps, pm355_stream_t st) {
+    if (njobs < 1 || njobs > 3 || !jobs || !x_f32) return fail(PM355_E_RANGE, "mul_mat_vec_fused: 1..3 jobs and an f32 activation");
+    pm_gemv_fused f = {};
+    f.K = (int) K; f.njobs = njobs; f.xf = x_f32; f.norm_w = norm_w; f.eps = eps;
+    for (int j = 0; j < njobs; ++j) {
+        f.job[j].type = jobs[j].type; f.job[j].N = (int) jobs[j].N; f.job[j].W = jobs[j].W; f.job[j].W2 = jobs[j].W2;
+        f.job[j].y = jobs[j].y; f.job[j].bias = jobs[j].bias; f.job[j].resid = jobs[j].resid;
+    }
+    (void) hipGetLastError();
+    const int rc = gemv_rc(pm_launch_gemv_fused(f, S(st)));
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 int pm355_mul_mat_vec_q_dbg(int type, const void * W, int64_t K, int64_t N, const void * xq, float * y,
                             int32_t * ip, int64_t * upr, pm355_stream_t st) {
     if (upr) *upr = K / (type == PM_Q6_K ? 64 : 32);

@@ -199,13 +199,45 @@ int gemv(const Tensor & w, const Tensor * w2, const ActQ & a, int T, float * y, 
     return pm_launch_gemv(g, st);
 }
 
+// single-token fused GEMV launch helper: jobs share the f32 activation `xf` (rms_norm'ed with norm_w when given)
+int gemv_f32(pm355_model * m, const Tensor * const * ws, const Tensor * const * w2s, float * const * ys,
+             const float * const * biases, const float * const * resids, int nj,
+             const float * xf, const float * norm_w, hipStream_t st) {
+    pm_gemv_fused f = {};
+    f.K = (int) ws[0]->K; f.njobs = nj; f.xf = xf; f.norm_w = norm_w; f.eps = m->hp.rms_eps;
+    for (int j = 0; j < nj; ++j) {
+        f.job[j].type = ws[j]->type; f.job[j].N = (int) ws[j]->N; f.job[j].W = ws[j]->d; f.job[j].W2 = w2s ? (w2s[j] ? w2s[j]->d : nullptr) : nullptr;
+        f.job[j].y = ys[j]; f.job[j].bias = biases ? biases[j] : nullptr; f.job[j].resid = resids ? resids[j] : nullptr;
+    }
+    return pm_launch_gemv_fused(f, st);
+}
+
+// QKV of one layer for a single token: one launch when the type mix allows, else one launch per matrix
+int qkv_fused(pm355_model * m, Layer & L, const float * x, hipStream_t st) {
+    const Tensor * ws[3] = {&L.t[PM355_T_WQ], &L.t[PM355_T_WK], &L.t[PM355_T_WV]};
+    float * ys[3] = {m->q, m->k, m->v};
+    const float * bs[3] = {(const float *) L.t[PM355_T_BQ].d, (const float *) L.t[PM355_T_BK].d, (const float *) L.t[PM355_T_BV].d};
+    const float * nw = (const float *) L.t[PM355_T_ATTN_NORM].d;
+    if (gemv_f32(m, ws, nullptr, ys, bs, nullptr, 3, x, nw, st) == 0) return 0;
+    for (int j = 0; j < 3; ++j) {
+        int rc = gemv_f32(m, ws + j, nullptr, ys + j, bs + j, nullptr, 1, x, nw, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // result_norm + lm_head (+ greedy argmax) on ONE hidden row (build_llama's last sub-graph, src/llama.cpp:11191-11215)
 int run_head(pm355_model * m, const float * x_row, float * d_logits, int32_t * d_argmax, hipStream_t st) {
     if (!m->output.d || !m->out_norm.d) return seterr(m, PM355_E_UNSUPPORTED, "head: output / output_norm missing");
     const Tensor * ow[1] = {&m->output};
-    ActQ a = norm_quantize_for(m, x_row, (const float *) m->out_norm.d, m->hp.n_embd, 1, ow, 1, st);
     float * lg = d_logits ? d_logits : m->logits;
-    if (gemv(m->output, nullptr, a, 1, lg, nullptr, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "head: lm_head gemv");
+    if (!m->no_fuse) {
+        float * y[1] = {lg};
+        if (gemv_f32(m, ow, nullptr, y, nullptr, nullptr, 1, x_row, (const float *) m->out_norm.d, st)) return seterr(m, PM355_E_UNSUPPORTED, "head: fused lm_head gemv");
+    } else {
+        ActQ a = norm_quantize_for(m, x_row, (const float *) m->out_norm.d, m->hp.n_embd, 1, ow, 1, st);
+        if (gemv(m->output, nullptr, a, 1, lg, nullptr, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "head: lm_head gemv");
+    }
     if (d_argmax) pm_launch_argmax(lg, m->hp.n_vocab, d_argmax, nullptr, st);
     return 0;
 }
@@ -229,6 +261,33 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
     for (int il = m->lo; il < m->hi; ++il) {
         Layer & L = m->layers[il - m->lo];
         const Tensor * qkv[3] = {&L.t[PM355_T_WQ], &L.t[PM355_T_WK], &L.t[PM355_T_WV]};
+        if (T == 1 && !m->no_fuse) {
+            // ---- single token: 5 launches per layer, every activation transform fused into a GEMV prologue/epilogue
+            if (qkv_fused(m, L, cur, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused qkv gemv");
+            const long kvs = (long) hp.n_ctx * Hkv * dh;
+            if (pm_launch_attn_rope_fused(m->q, m->k, m->v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d,
+                                          m->att, H, Hkv, dh, hp.n_ctx, kq_scale, m->rope, st))
+                return seterr(m, PM355_E_RANGE, "decode: fused attention unsupported for this head_dim / n_ctx");
+            float * x_mid = (cur == bufs[0]) ? bufs[1] : bufs[0];
+            {
+                const Tensor * w[1] = {&L.t[PM355_T_WO]}; float * y[1] = {x_mid}; const float * r[1] = {cur};
+                if (gemv_f32(m, w, nullptr, y, nullptr, r, 1, m->att, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused wo gemv");
+            }
+            if (L.t[PM355_T_FFN_GATE].type != L.t[PM355_T_FFN_UP].type)
+                return seterr(m, PM355_E_UNSUPPORTED, "decode: ffn_gate and ffn_up of different types");
+            {
+                const Tensor * w[1] = {&L.t[PM355_T_FFN_GATE]}; const Tensor * w2[1] = {&L.t[PM355_T_FFN_UP]}; float * y[1] = {m->h};
+                if (gemv_f32(m, w, w2, y, nullptr, nullptr, 1, x_mid, (const float *) L.t[PM355_T_FFN_NORM].d, st))
+                    return seterr(m, PM355_E_UNSUPPORTED, "decode: fused gate/up gemv");
+            }
+            float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : ((x_mid == bufs[0]) ? bufs[1] : bufs[0]);
+            {
+                const Tensor * w[1] = {&L.t[PM355_T_FFN_DOWN]}; float * y[1] = {x_next}; const float * r[1] = {x_mid};
+                if (gemv_f32(m, w, nullptr, y, nullptr, r, 1, m->h, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused down gemv");
+            }
+            cur = x_next;
+            continue;
+        }
         // attn_norm (+weight), quantized for q/k/v in the same pass when only Q8_K is needed
         ActQ a = norm_quantize_for(m, cur, (const float *) L.t[PM355_T_ATTN_NORM].d, E, T, qkv, 3, st);
         int rc = 0;

@@ -2,68 +2,81 @@
 //
 // Replaces, for tensors in our buffers, the reference's
 //   ggml_compute_forward_mul_mat (ggml/src/ggml.c:12377) -> ggml_vec_dot_q4_K_q8_K (ggml-quants.c:7713),
-//   ggml_vec_dot_q5_K_q8_K (:8281), ggml_vec_dot_q6_K_q8_K (:8918), ggml_vec_dot_q8_0_q8_0 (:5518).
-// Integer arithmetic is identical to the reference (int8 x int4/5/6/8 products, int32 sums, 6-bit
-// scales/mins, Q8_K bsums for the min / -32 terms) and is checked bit-for-bit against the oracle
-// through the dbg_int output; the float scale-and-accumulate uses a fixed, deterministic order.
+//   ggml_vec_dot_q5_K_q8_K (:8281), ggml_vec_dot_q6_K_q8_K (:8918), ggml_vec_dot_q8_0_q8_0 (:5518),
+// and, fused into its prologue, the activation side of that function: quantize_row_q8_K (ggml-quants.c:3785) /
+// quantize_row_q8_0 (:848) preceded, when asked, by ggml_compute_forward_rms_norm_f32 (ggml.c:11950) * weight.
+// Integer arithmetic is identical to the reference (int8 x int4/5/6/8 products, int32 sums, 6-bit scales/mins,
+// group sums of the int8 activations for the min / -32 terms) and is checked bit-for-bit against the oracle through the
+// dbg output; the float scale-and-accumulate uses a fixed, deterministic order.
 //
-// Design ("x-stationary"): HBM-bound, 4.5-8.5 bits per weight, no reuse of W -> no LDS staging of W.
-//  * A row of W is cut into UNITS (16-48 contiguous bytes = 32/64 weights). A workgroup of 256 threads
-//    assigns each thread the SAME unit positions for every row it processes, so the matching slice of
-//    the quantized activation (Q8_K int8 + bsums + d) is loaded ONCE into VGPRs and stays there.
-//  * Per row a thread then issues 2-5 independent 16-byte non-temporal loads (global_load_dwordx4 nt),
-//    R rows deep, before consuming any of them: >= 8 KB in flight per workgroup, several workgroups per CU.
-//  * 64 lanes of a wave cover a contiguous 1-3 KB span of the row -> fully coalesced; all bytes of every
-//    fetched line are used. Alignment: Q4_K/Q5_K blocks are 9/11 x 16 B; Q6_K/Q8_0 are stored row-SoA
-//    (repack.hip) so every field stream is 16-B aligned.
-//  * v_dot4_i32_i8 for the products, DPP row reductions + one LDS word per wave for the row sum.
+// Design: HBM-bound, 4.5-8.5 bits per weight, no reuse of W -> W goes straight from HBM to registers (no LDS staging).
+//  * Two 512-thread workgroups per CU. Each workgroup quantizes the activation row ONCE (from f32, fused rms_norm
+//    optional, bit-exact with the reference quantizers) into LDS: int8 values, 16-group sums, block scales.
+//  * Each WAVE owns whole rows (2 at a time): lanes stride over the row's UNITS (16-48 contiguous weight bytes = 32/64
+//    weights), so a wave instruction covers a contiguous 1-3 KB span of the row -> fully coalesced, every byte of every
+//    fetched line is used. Q4_K/Q5_K blocks are 9/11 x 16 B; Q6_K/Q8_0 are stored row-SoA (repack.hip), so every field
+//    stream is 16-B aligned. 8-20 independent 16-byte non-temporal loads (global_load_dwordx4 nt) are in flight per lane;
+//    16 waves per CU hide the HBM latency. There is NO barrier and NO cross-wave reduction in the row loop.
+//  * All weight loads are unconditional (clamped addresses) and the loop body contains no other VMEM operation (row
+//    results are parked in LDS and written out coalesced afterwards): gfx9 counts loads and stores in ONE vmcnt and a
+//    load in a divergent branch or a store in the stream makes the compiler fall back to s_waitcnt vmcnt(0).
+//  * v_dot4_i32_i8 for the products against the LDS-resident activation, DPP reduction per row.
+//  * Up to 3 weight matrices that share the activation (wq/wk/wv) are served by ONE launch ("jobs"), of at most two
+//    different quant types (Q4_K_M: attn_v is Q6_K/Q5_K next to Q4_K q/k); every workgroup takes an equal slice of
+//    the rows of every job.
 #include "pm355_device.h"
 #include "pm355_kernels.h"
+#include <limits.h>
+
+#define PM_MAX_ROWS_PER_WG 512
 
 namespace {
 
-struct GemvP {
-    const uint8_t * W; const uint8_t * W2; const uint8_t * xq;
-    float * y; const float * bias; const float * resid; int32_t * dbg;
-    int K, N, U /*units per row*/, tpr /*threads per row: 64|128|256*/, rows_per_wg;
-    long row_bytes;
+struct GemvJob {
+    const uint8_t * W; const uint8_t * W2; float * y; const float * bias; const float * resid;
+    long row_stride;
+    int N, is_b /*uses TB*/, U /*units per row*/;
 };
+struct GemvP {
+    GemvJob job[3];
+    const uint8_t * xq;                     // xmode 0: pre-quantized activation row (row-SoA Q8_K / Q8_0)
+    const float * xf; const float * norm_w; // xmode 1: f32 activation; xmode 2: rms_norm(xf) * norm_w first
+    float eps;
+    int xmode, K;
+    int32_t * dbg;
+};
+
+// Per-type traits. A unit's NV values come in NV/16 groups of 16 CONTIGUOUS activations; group_base() gives the
+// activation index of group g. X holds the quantized activation slice of one unit.
+template <int NV> struct XT { uint32_t q[NV / 4]; int gs[NV / 16]; float yd; };
 
 template <int TYPE> struct QT;
 
 // ---------------------------------------------------------------- Q4_K (native 144-B blocks) -------
+// unit u = (block b, chunk c = 2j+h): qs bytes [16c, 16c+16) = low nibbles -> values 64j+16h+i, high -> +32
 template <> struct QT<PM_Q4_K> {
-    static constexpr int VPU = 32;
-    struct X { uint32_t a[4], b[4]; int bs; float yd; };
+    static constexpr int NV = 32, LPB = 8 /*lanes per activation block*/, ABLK = 256;
+    typedef XT<NV> X;
     struct Wr { u32x4 q, h; };
-    static __device__ __forceinline__ void load_x(X & x, const uint8_t * xq, int K, int u) {
-        const int b = u >> 3, c = u & 7, j = c >> 1, h = c & 1;
-        const uint8_t * p = xq + b * 256 + 64 * j + 16 * h;
-        const u32x4 lo = *(const u32x4 *) p, hi = *(const u32x4 *) (p + 32);
-        for (int i = 0; i < 4; ++i) { x.a[i] = lo[i]; x.b[i] = hi[i]; }
-        x.yd = ((const float *) (xq + K))[b];
-        const int16_t * bs = (const int16_t *) (xq + K + (K / 256) * 4) + b * 16 + 2 * c;
-        x.bs = bs[0] + bs[1];
-    }
+    static __device__ __forceinline__ int group_base(int u, int g) { const int c = u & 7; return (u >> 3) * 256 + 64 * (c >> 1) + 16 * (c & 1) + 32 * g; }
     static __device__ __forceinline__ void issue(Wr & w, const uint8_t * row, int, int u) {
         const uint8_t * blk = row + (long) (u >> 3) * PM_BS_Q4_K;
         w.q = ld_nt16(blk + 16 + 16 * (u & 7));
         w.h = ld_nt16(blk);
     }
     static __device__ __forceinline__ float consume(const Wr & w, const X & x, int u, int & isum, int & msum) {
-        const int c = u & 7, j = c >> 1;
+        const int j = (u & 7) >> 1;
         int slo = 0, shi = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            slo = dot4(w.q[i] & 0x0F0F0F0Fu, x.a[i], slo);
-            shi = dot4((w.q[i] >> 4) & 0x0F0F0F0Fu, x.b[i], shi);
+            slo = dot4(w.q[i] & 0x0F0F0F0Fu, x.q[i], slo);
+            shi = dot4((w.q[i] >> 4) & 0x0F0F0F0Fu, x.q[4 + i], shi);
         }
-        int sc0, sc1, m0, mc;
+        int sc0, sc1, m0, m1;
         k4_scale_min(w.h[1], w.h[2], w.h[3], 2 * j, sc0, m0);
-        k4_scale_min(w.h[1], w.h[2], w.h[3], 2 * j + 1, sc1, m0);
-        k4_scale_min(w.h[1], w.h[2], w.h[3], c, m0, mc);
+        k4_scale_min(w.h[1], w.h[2], w.h[3], 2 * j + 1, sc1, m1);
         isum = sc0 * slo + sc1 * shi;
-        msum = mc * x.bs;
+        msum = m0 * x.gs[0] + m1 * x.gs[1];          // this unit's share of sum_s min_s * bsum_s
         const float d = h2f((uint16_t) (w.h[0] & 0xFFFF)), dmin = h2f((uint16_t) (w.h[0] >> 16));
         return x.yd * (d * (float) isum - dmin * (float) msum);
     }
@@ -71,10 +84,10 @@ template <> struct QT<PM_Q4_K> {
 
 // ---------------------------------------------------------------- Q5_K (native 176-B blocks) -------
 template <> struct QT<PM_Q5_K> {
-    static constexpr int VPU = 32;
-    typedef QT<PM_Q4_K>::X X;
+    static constexpr int NV = 32, LPB = 8, ABLK = 256;
+    typedef XT<NV> X;
     struct Wr { u32x4 q, h, qh; };
-    static __device__ __forceinline__ void load_x(X & x, const uint8_t * xq, int K, int u) { QT<PM_Q4_K>::load_x(x, xq, K, u); }
+    static __device__ __forceinline__ int group_base(int u, int g) { return QT<PM_Q4_K>::group_base(u, g); }
     static __device__ __forceinline__ void issue(Wr & w, const uint8_t * row, int, int u) {
         const uint8_t * blk = row + (long) (u >> 3) * PM_BS_Q5_K;
         w.q  = ld_nt16(blk + 48 + 16 * (u & 7));
@@ -82,21 +95,20 @@ template <> struct QT<PM_Q5_K> {
         w.h  = ld_nt16(blk);
     }
     static __device__ __forceinline__ float consume(const Wr & w, const X & x, int u, int & isum, int & msum) {
-        const int c = u & 7, j = c >> 1;
+        const int j = (u & 7) >> 1;
         int slo = 0, shi = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t lo = (w.q[i] & 0x0F0F0F0Fu) | (((w.qh[i] >> (2 * j)) & 0x01010101u) << 4);
             const uint32_t hi = ((w.q[i] >> 4) & 0x0F0F0F0Fu) | (((w.qh[i] >> (2 * j + 1)) & 0x01010101u) << 4);
-            slo = dot4(lo, x.a[i], slo);
-            shi = dot4(hi, x.b[i], shi);
+            slo = dot4(lo, x.q[i], slo);
+            shi = dot4(hi, x.q[4 + i], shi);
         }
-        int sc0, sc1, m0, mc;
+        int sc0, sc1, m0, m1;
         k4_scale_min(w.h[1], w.h[2], w.h[3], 2 * j, sc0, m0);
-        k4_scale_min(w.h[1], w.h[2], w.h[3], 2 * j + 1, sc1, m0);
-        k4_scale_min(w.h[1], w.h[2], w.h[3], c, m0, mc);
+        k4_scale_min(w.h[1], w.h[2], w.h[3], 2 * j + 1, sc1, m1);
         isum = sc0 * slo + sc1 * shi;
-        msum = mc * x.bs;
+        msum = m0 * x.gs[0] + m1 * x.gs[1];
         const float d = h2f((uint16_t) (w.h[0] & 0xFFFF)), dmin = h2f((uint16_t) (w.h[0] >> 16));
         return x.yd * (d * (float) isum - dmin * (float) msum);
     }
@@ -105,20 +117,10 @@ template <> struct QT<PM_Q5_K> {
 // ---------------------------------------------------------------- Q6_K (row-SoA) --------------------
 // row: ql[nb][128] | qh[nb][64] | scales[nb][16] | d[nb]      unit = (block b, half hh, 16-col slice v)
 template <> struct QT<PM_Q6_K> {
-    static constexpr int VPU = 64;
-    struct X { uint32_t q[4][4]; int bs[4]; float yd; };
+    static constexpr int NV = 64, LPB = 4, ABLK = 256;
+    typedef XT<NV> X;
     struct Wr { u32x4 l0, l1, h; u32x2 s; uint16_t d; };
-    static __device__ __forceinline__ void load_x(X & x, const uint8_t * xq, int K, int u) {
-        const int b = u >> 2, hh = (u >> 1) & 1, v = u & 1;
-        const int16_t * bs = (const int16_t *) (xq + K + (K / 256) * 4) + b * 16 + 8 * hh + v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const u32x4 t = *(const u32x4 *) (xq + b * 256 + 128 * hh + 32 * k + 16 * v);
-            for (int i = 0; i < 4; ++i) x.q[k][i] = t[i];
-            x.bs[k] = bs[2 * k];
-        }
-        x.yd = ((const float *) (xq + K))[b];
-    }
+    static __device__ __forceinline__ int group_base(int u, int g) { return (u >> 2) * 256 + 128 * ((u >> 1) & 1) + 32 * g + 16 * (u & 1); }
     static __device__ __forceinline__ void issue(Wr & w, const uint8_t * row, int K, int u) {
         const long nb = K / 256;
         const int b = u >> 2, hh = (u >> 1) & 1, v = u & 1;
@@ -135,17 +137,17 @@ template <> struct QT<PM_Q6_K> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t h = w.h[i];
-            acc[0] = dot4((w.l0[i] & 0x0F0F0F0Fu)        | ((h << 4) & 0x30303030u), x.q[0][i], acc[0]);
-            acc[1] = dot4((w.l1[i] & 0x0F0F0F0Fu)        | ((h << 2) & 0x30303030u), x.q[1][i], acc[1]);
-            acc[2] = dot4(((w.l0[i] >> 4) & 0x0F0F0F0Fu) | (h & 0x30303030u),        x.q[2][i], acc[2]);
-            acc[3] = dot4(((w.l1[i] >> 4) & 0x0F0F0F0Fu) | ((h >> 2) & 0x30303030u), x.q[3][i], acc[3]);
+            acc[0] = dot4((w.l0[i] & 0x0F0F0F0Fu)        | ((h << 4) & 0x30303030u), x.q[i],      acc[0]);
+            acc[1] = dot4((w.l1[i] & 0x0F0F0F0Fu)        | ((h << 2) & 0x30303030u), x.q[4 + i],  acc[1]);
+            acc[2] = dot4(((w.l0[i] >> 4) & 0x0F0F0F0Fu) | (h & 0x30303030u),        x.q[8 + i],  acc[2]);
+            acc[3] = dot4(((w.l1[i] >> 4) & 0x0F0F0F0Fu) | ((h >> 2) & 0x30303030u), x.q[12 + i], acc[3]);
         }
         const uint64_t s8 = ((uint64_t) w.s[1] << 32) | w.s[0];
         isum = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int sc = (int) (int8_t) (s8 >> (8 * (v + 2 * k)));
-            isum += sc * (acc[k] - 32 * x.bs[k]);
+            isum += sc * (acc[k] - 32 * x.gs[k]);            // sum (q-32)*a = sum q*a - 32*sum a
         }
         msum = 0;
         return x.yd * h2f(w.d) * (float) isum;
@@ -153,16 +155,12 @@ template <> struct QT<PM_Q6_K> {
 };
 
 // ---------------------------------------------------------------- Q8_0 (row-SoA) --------------------
-// row: qs[nb32][32] | d[nb32];  activations: Q8_0 row-SoA (qs[K] | half d[K/32]).   unit = one 32-block
+// row: qs[nb32][32] | d[nb32];  activations quantized to Q8_0 (32-blocks, fp16 d).   unit = one 32-block
 template <> struct QT<PM_Q8_0> {
-    static constexpr int VPU = 32;
-    struct X { uint32_t q[8]; float yd; };
+    static constexpr int NV = 32, LPB = 1, ABLK = 32;
+    typedef XT<NV> X;
     struct Wr { u32x4 q0, q1; uint16_t d; };
-    static __device__ __forceinline__ void load_x(X & x, const uint8_t * xq, int K, int u) {
-        const u32x4 a = *(const u32x4 *) (xq + u * 32), b = *(const u32x4 *) (xq + u * 32 + 16);
-        for (int i = 0; i < 4; ++i) { x.q[i] = a[i]; x.q[4 + i] = b[i]; }
-        x.yd = h2f(((const uint16_t *) (xq + K))[u]);
-    }
+    static __device__ __forceinline__ int group_base(int u, int g) { return u * 32 + 16 * g; }
     static __device__ __forceinline__ void issue(Wr & w, const uint8_t * row, int K, int u) {
         w.q0 = ld_nt16(row + (long) u * 32);
         w.q1 = ld_nt16(row + (long) u * 32 + 16);
@@ -179,113 +177,251 @@ template <> struct QT<PM_Q8_0> {
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + expf(-g)); }
 
-// One workgroup: rows [row0, row0 + rows_per_wg) of W (and W2 when PAIR).
-//   tpr threads cooperate on a row; 256/tpr rows are processed side by side ("slots");
-//   R = rows in flight per slot; UPT = units per thread.
-template <int TYPE, int UPT, int R, bool PAIR, bool DBG>
-__global__ __launch_bounds__(256) void gemv_q_kernel(GemvP p) {
-    typedef QT<TYPE> T;
-    constexpr int NM = PAIR ? 2 : 1;
-    __shared__ float red[2][R * NM * 4];
+#define PM_GEMV_BLOCK 512                 // 8 waves per workgroup, 2 workgroups per CU
+#define PM_GEMV_NW (PM_GEMV_BLOCK / 64)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tpr = p.tpr, slots = 256 / tpr, wps = tpr >> 6 /*waves per slot*/;
-    const int slot = tid / tpr, tin = tid - slot * tpr;
+// ---- activation prologue: the workgroup quantizes the WHOLE activation row once into LDS ----------------------------
+//   xs_q  int8  [K]        quantized values
+//   xs_gs int32 [K/16]     sums of each 16 consecutive quantized values (min / -32 terms)
+//   xs_d  float [K/ABLK]   block scales (ABLK = 256: Q8_K, float d;  ABLK = 32: Q8_0, fp16-rounded d)
+struct XLds { const int8_t * q; const int * gs; const float * d; };
 
-    typename T::X x[UPT];
-    bool valid[UPT];
+// one wave, 4 consecutive values per lane = one 256-block (quantize_row_q8_K_ref)
+__device__ __forceinline__ void q8k_block_to_lds(const float v[4], int lane, int8_t * xs_q, int * xs_gs, float * xs_d, int blk) {
+    const float a0 = fabsf(v[0]), a1 = fabsf(v[1]), a2 = fabsf(v[2]), a3 = fabsf(v[3]);
+    float amax = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+    // wave max (identity 0 is fine: |x| >= 0)
+    amax = fmaxf(amax, dpp_f<0xB1>(amax)); amax = fmaxf(amax, dpp_f<0x4E>(amax)); amax = fmaxf(amax, dpp_f<0x141>(amax));
+    amax = fmaxf(amax, dpp_f<0x140>(amax));
 #pragma unroll
-    for (int i = 0; i < UPT; ++i) {
-        const int u = tin + i * tpr;
-        valid[i] = u < p.U;
-        if (valid[i]) T::load_x(x[i], p.xq, p.K, u);
+    for (int off = 16; off <= 32; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    uint32_t packed = 0; int psum = 0;
+    if (amax != 0.0f) {
+        int key = 0x7fffffff;                        // lowest index with |x| == amax; low bit = its sign
+        if (a3 == amax) key = ((4 * lane + 3) << 1) | (v[3] < 0.0f);
+        if (a2 == amax) key = ((4 * lane + 2) << 1) | (v[2] < 0.0f);
+        if (a1 == amax) key = ((4 * lane + 1) << 1) | (v[1] < 0.0f);
+        if (a0 == amax) key = ((4 * lane + 0) << 1) | (v[0] < 0.0f);
+#pragma unroll
+        for (int off = 1; off <= 32; off <<= 1) key = min(key, __shfl_xor(key, off));
+        const float iscale = -127.f / ((key & 1) ? -amax : amax);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int q = nearest_int_rne(iscale * v[i]);
+            q = q > 127 ? 127 : q;
+            psum += q; packed |= (uint32_t) (q & 0xFF) << (8 * i);
+        }
+        if (lane == 0) xs_d[blk] = 1 / iscale;
+    } else if (lane == 0) {
+        xs_d[blk] = 0.0f;
     }
-
-    const int row0 = blockIdx.x * p.rows_per_wg;
-    const int row1 = min(row0 + p.rows_per_wg, p.N);
-    int it = 0;
-    for (int base = row0; base < row1; base += slots * R, ++it) {
-        typename T::Wr w[R][NM][UPT];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int row = base + r * slots + slot;
-            if (row < row1) {
-#pragma unroll
-                for (int i = 0; i < UPT; ++i) if (valid[i]) {
-                    T::issue(w[r][0][i], p.W + (long) row * p.row_bytes, p.K, tin + i * tpr);
-                    if (PAIR) T::issue(w[r][NM - 1][i], p.W2 + (long) row * p.row_bytes, p.K, tin + i * tpr);
-                }
-            }
-        }
-        float * rb = red[it & 1];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int row = base + r * slots + slot;
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                float acc = 0.0f;
-                if (row < row1) {
-#pragma unroll
-                    for (int i = 0; i < UPT; ++i) if (valid[i]) {
-                        int isum, msum;
-                        acc += T::consume(w[r][m][i], x[i], tin + i * tpr, isum, msum);
-                        if (DBG) {
-                            int32_t * o = p.dbg + ((long) (m * p.N + row) * p.U + (tin + i * tpr)) * 2;
-                            o[0] = isum; o[1] = msum;
-                        }
-                    }
-                }
-                acc = wave_sum(acc);
-                if (lane == 0) rb[(r * NM + m) * 4 + wave] = acc;
-            }
-        }
-        __syncthreads();
-        // finalize: thread t < R*slots handles (r = t / slots, slot s = t % slots)
-        if (tid < R * slots) {
-            const int r = tid / slots, s = tid - r * slots;
-            const int row = base + r * slots + s;
-            if (row < row1) {
-                float v[NM];
-#pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    float t = 0.0f;
-                    for (int k = 0; k < wps; ++k) t += rb[(r * NM + m) * 4 + s * wps + k];
-                    v[m] = t;
-                }
-                float out = PAIR ? silu_f(v[0]) * v[NM - 1] : v[0];
-                if (p.bias)  out += p.bias[row];
-                if (p.resid) out += p.resid[row];
-                p.y[row] = out;
-            }
-        }
-    }
+    ((uint32_t *) xs_q)[blk * 64 + lane] = packed;
+    psum += dpp_i<0xB1>(psum); psum += dpp_i<0x4E>(psum);       // 16 values = one quad
+    if ((lane & 3) == 0) xs_gs[blk * 16 + (lane >> 2)] = psum;
 }
 
-template <int TYPE, int UPT, int R, bool PAIR>
-int launch_t(const GemvP & p, int grid, bool dbg, hipStream_t st) {
-    if (dbg) hipLaunchKernelGGL((gemv_q_kernel<TYPE, UPT, R, PAIR, true>), dim3(grid), dim3(256), 0, st, p);
-    else     hipLaunchKernelGGL((gemv_q_kernel<TYPE, UPT, R, PAIR, false>), dim3(grid), dim3(256), 0, st, p);
-    return 0;
+// 8 lanes x 4 values = one 32-block (quantize_row_q8_0_ref)
+__device__ __forceinline__ void q80_block_to_lds(const float v[4], int i4 /*index of this float4 in the row*/,
+                                                 int8_t * xs_q, int * xs_gs, float * xs_d) {
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    amax = group8_max(amax);
+    const float d = amax / 127;
+    const float id = d ? 1.0f / d : 0.0f;
+    uint32_t packed = 0; int psum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int q = (int) roundf(v[i] * id); psum += q; packed |= (uint32_t) (q & 0xFF) << (8 * i); }
+    ((uint32_t *) xs_q)[i4] = packed;
+    psum += dpp_i<0xB1>(psum); psum += dpp_i<0x4E>(psum);
+    if ((i4 & 3) == 0) xs_gs[i4 >> 2] = psum;
+    if ((i4 & 7) == 0) xs_d[i4 >> 3] = h2f(f2h(d));
+}
+
+template <int ABLK>
+__device__ __forceinline__ void stage_activation(const GemvP & p, int8_t * xs_q, int * xs_gs, float * xs_d, double * nred) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K;
+    if (p.xmode == 0) {
+        // pre-quantized row-SoA: int8 qs[K] | scales. Copy + group sums.
+        for (int g = tid; g < K / 16; g += PM_GEMV_BLOCK) {
+            const u32x4 t = *(const u32x4 *) (p.xq + 16 * g);
+            *(u32x4 *) (xs_q + 16 * g) = t;
+            int s_ = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_ = dot4(t[i], 0x01010101u, s_);
+            xs_gs[g] = s_;
+        }
+        for (int b = tid; b < K / ABLK; b += PM_GEMV_BLOCK)
+            xs_d[b] = ABLK == 256 ? ((const float *) (p.xq + K))[b] : h2f(((const uint16_t *) (p.xq + K))[b]);
+        return;
+    }
+    float scale = 1.0f;
+    if (p.xmode == 2) {
+        double ss = 0.0;                             // sum of f32-rounded squares in f64, like the reference
+        for (int i = tid; i < K / 4; i += PM_GEMV_BLOCK) {
+            const float4 f = ((const float4 *) p.xf)[i];
+            ss += (double) (f.x * f.x); ss += (double) (f.y * f.y); ss += (double) (f.z * f.z); ss += (double) (f.w * f.w);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        if (lane == 0) nred[wave] = ss;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < PM_GEMV_NW; ++k) tot += nred[k];
+        const float mean = (float) (tot / K);
+        scale = 1.0f / sqrtf(mean + p.eps);
+    }
+    if (ABLK == 256) {
+        for (int blk = wave; blk < K / 256; blk += PM_GEMV_NW) {       // one wave per 256-block
+            const float4 f = ((const float4 *) (p.xf + (size_t) blk * 256))[lane];
+            float v[4] = {f.x, f.y, f.z, f.w};
+            if (p.xmode == 2) {
+                const float4 g = ((const float4 *) (p.norm_w + (size_t) blk * 256))[lane];
+                v[0] = v[0] * scale * g.x; v[1] = v[1] * scale * g.y; v[2] = v[2] * scale * g.z; v[3] = v[3] * scale * g.w;
+            }
+            q8k_block_to_lds(v, lane, xs_q, xs_gs, xs_d, blk);
+        }
+    } else {
+        const int n4 = K / 4, n4p = (n4 + 7) & ~7;
+        for (int i4 = tid; i4 < n4p; i4 += PM_GEMV_BLOCK) {
+            if (i4 < n4) {                           // K % 32 == 0 -> whole 8-lane groups are in or out together
+                const float4 f = ((const float4 *) p.xf)[i4];
+                float v[4] = {f.x, f.y, f.z, f.w};
+                if (p.xmode == 2) {
+                    const float4 g = ((const float4 *) p.norm_w)[i4];
+                    v[0] = v[0] * scale * g.x; v[1] = v[1] * scale * g.y; v[2] = v[2] * scale * g.z; v[3] = v[3] * scale * g.w;
+                }
+                q80_block_to_lds(v, i4, xs_q, xs_gs, xs_d);
+            }
+        }
+    }
 }
 
 template <int TYPE>
-int launch_type(const GemvP & p, int upt, bool pair, int grid, bool dbg, hipStream_t st) {
-    // rows in flight per slot: keep (R * UPT * NM) around 4 x 16-B load groups per thread
-    if (!pair) {
-        switch (upt) {
-            case 1: return launch_t<TYPE, 1, 4, false>(p, grid, dbg, st);
-            case 2: return launch_t<TYPE, 2, 2, false>(p, grid, dbg, st);
-            case 4: return launch_t<TYPE, 4, 1, false>(p, grid, dbg, st);
+__device__ __forceinline__ void load_x_lds(typename QT<TYPE>::X & x, const XLds & xs, int u) {
+    typedef QT<TYPE> T;
+#pragma unroll
+    for (int g = 0; g < T::NV / 16; ++g) {
+        const int base = T::group_base(u, g);
+        const u32x4 t = *(const u32x4 *) (xs.q + base);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x.q[4 * g + i] = t[i];
+        x.gs[g] = xs.gs[base >> 4];
+    }
+    x.yd = xs.d[T::group_base(u, 0) / T::ABLK];
+}
+
+// rows [r0, r1) of one job; each WAVE owns whole rows (R at a time), lanes stride over the row's units, the
+// activation slice of every unit comes from LDS. No barrier and no cross-wave reduction inside the row loop.
+template <int TYPE, bool PAIR, bool DBG>
+__device__ __forceinline__ void gemv_rows(const GemvP & p, const GemvJob & jb, const XLds & xs, float * outbuf, int r0, int r1) {
+    typedef QT<TYPE> T;
+    constexpr int NM = PAIR ? 2 : 1;
+    constexpr int CH = T::NV == 64 ? 2 : 4;          // units per lane in flight per row
+    constexpr int R  = PAIR ? 1 : 2;                 // rows in flight per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int U = jb.U;
+    const int upl = (U + 63) >> 6;                   // units per lane
+    for (int row = r0 + wave * R; row < r1; row += PM_GEMV_NW * R) {
+        float acc[R][NM];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int m = 0; m < NM; ++m) acc[r][m] = 0.0f;
+        for (int c0 = 0; c0 < upl; c0 += CH) {
+            typename T::Wr w[R][NM][CH];
+            // unconditional loads (row / unit clamped): conditional loads make the compiler drain the VMEM queue
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int rr = min(row + r, r1 - 1);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int u = min(lane + 64 * (c0 + i), U - 1);
+                    T::issue(w[r][0][i], jb.W + (long) rr * jb.row_stride, p.K, u);
+                    if (PAIR) T::issue(w[r][NM - 1][i], jb.W2 + (long) rr * jb.row_stride, p.K, u);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int uu = lane + 64 * (c0 + i);
+                const bool uv = uu < U;
+                const int u = min(uu, U - 1);
+                typename T::X x;
+                load_x_lds<TYPE>(x, xs, u);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        int isum, msum;
+                        const float c = T::consume(w[r][m][i], x, u, isum, msum);
+                        acc[r][m] += uv ? c : 0.0f;
+                        if (DBG) if (uv && row + r < r1) {
+                            int32_t * o = p.dbg + ((long) (m * jb.N + row + r) * U + u) * 2;
+                            o[0] = isum; o[1] = msum;
+                        }
+                    }
+            }
         }
-    } else {
-        switch (upt) {
-            case 1: return launch_t<TYPE, 1, 2, true>(p, grid, dbg, st);
-            case 2: return launch_t<TYPE, 2, 1, true>(p, grid, dbg, st);
-            case 4: return launch_t<TYPE, 4, 1, true>(p, grid, dbg, st);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float o[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) o[m] = wave_sum(acc[r][m]);
+            if (lane == 0 && row + r < r1) outbuf[row + r - r0] = PAIR ? silu_f(o[0]) * o[NM - 1] : o[0];
         }
     }
-    return -1;
 }
+
+template <int TA, int TB, bool PAIR, bool DBG>
+__global__ __launch_bounds__(PM_GEMV_BLOCK, 2) void gemv_q_kernel(GemvP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double nred[PM_GEMV_NW];
+    constexpr int ABLK = QT<TA>::ABLK;
+    int8_t * xs_q  = (int8_t *) smem;                                   // [K] (K % 32 == 0 -> 16-B aligned pieces)
+    int *    xs_gs = (int *) (smem + ((p.K + 15) & ~15));               // [K/16]
+    float *  xs_d  = (float *) (xs_gs + p.K / 16);                      // [K/ABLK]
+    float *  outbuf = xs_d + ((p.K / ABLK + 3) & ~3);                   // [PM_MAX_ROWS_PER_WG]
+    stage_activation<ABLK>(p, xs_q, xs_gs, xs_d, nred);
+    __syncthreads();
+    const XLds xs = {xs_q, xs_gs, xs_d};
+    const int b = blockIdx.x, G = gridDim.x, tid = threadIdx.x;
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {
+        const GemvJob & jb = p.job[j];
+        if (jb.N <= 0) break;
+        const int r0 = (int) ((long) jb.N * b / G), r1 = (int) ((long) jb.N * (b + 1) / G);
+        if (TA != TB && jb.is_b) gemv_rows<TB, PAIR, DBG>(p, jb, xs, outbuf, r0, r1);
+        else                     gemv_rows<TA, PAIR, DBG>(p, jb, xs, outbuf, r0, r1);
+        __syncthreads();
+        for (int t = tid; t < r1 - r0; t += PM_GEMV_BLOCK) {          // coalesced write-out (+bias, +residual)
+            float out = outbuf[t];
+            if (jb.bias)  out += jb.bias[r0 + t];
+            if (jb.resid) out += jb.resid[r0 + t];
+            jb.y[r0 + t] = out;
+        }
+        __syncthreads();
+    }
+}
+
+template <int TA, int TB>
+int launch_types(const GemvP & p, bool pair, int grid, size_t lds, bool dbg, hipStream_t st) {
+    auto go = [&](auto kern) {
+        static bool attr_set = false;                 // one flag per instantiation (lambda is instantiated per kern type)
+        if (lds > 48 * 1024 && !attr_set) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(PM_GEMV_BLOCK), lds, st, p);
+    };
+    if (pair) {
+        if (TA != TB) return -1;
+        if (dbg) go(gemv_q_kernel<TA, TA, true, true>); else go(gemv_q_kernel<TA, TA, true, false>);
+    } else {
+        if (dbg) go(gemv_q_kernel<TA, TB, false, true>); else go(gemv_q_kernel<TA, TB, false, false>);
+    }
+    return 0;
+}
+
+int nv_of(int type) { return type == PM_Q6_K ? 64 : 32; }
+
+bool type_ok(int t) { return t == PM_Q4_K || t == PM_Q5_K || t == PM_Q6_K || t == PM_Q8_0; }
 
 } // namespace
 
@@ -309,41 +445,70 @@ size_t pm_weight_row_stride(int type, int64_t K) {
     return pm_weight_row_bytes(type, K);
 }
 
+static int g_num_cus = 0;
+
+// Fused launch: up to 3 matrices sharing one activation row.
+int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st) {
+    if (a.njobs < 1 || a.njobs > 3) return -4;
+    GemvP p = {};
+    p.K = a.K; p.xq = (const uint8_t *) a.xq; p.xf = a.xf; p.norm_w = a.norm_w; p.eps = a.eps; p.dbg = a.dbg_int;
+    p.xmode = a.xq ? 0 : (a.norm_w ? 2 : 1);
+    int ta = a.job[0].type, tb = ta;
+    const bool pair = a.job[0].W2 != nullptr;
+    long max_rows = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        const int t = a.job[j].type;
+        if (!type_ok(t)) return -1;
+        if (t != ta) { if (tb == ta) tb = t; else if (t != tb) return -1; }
+        if ((a.job[j].W2 != nullptr) != pair) return -1;
+        if (a.job[j].N > max_rows) max_rows = a.job[j].N;
+    }
+    // a Q8_0 job needs Q8_0-quantized activations, the K-quants need Q8_K: one prologue serves only one family
+    if ((ta == PM_Q8_0) != (tb == PM_Q8_0)) return -1;
+    if (ta == PM_Q8_0 ? a.K % 32 : a.K % 256) return -2;
+    if (pair && ta != tb) return -1;
+    if (!g_num_cus) { hipDeviceProp_t pr; int dev = 0; (void) hipGetDevice(&dev); g_num_cus = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
+    // 2 workgroups of 8 waves per CU; every workgroup takes an equal slice of the rows of EVERY job
+    int grid = 2 * g_num_cus;
+    while ((max_rows + grid - 1) / grid > PM_MAX_ROWS_PER_WG) grid *= 2;
+    for (int j = 0; j < 3; ++j) {
+        GemvJob & g = p.job[j];
+        if (j >= a.njobs) { g.N = 0; continue; }
+        const pm_gemv_job & s = a.job[j];
+        g.W = (const uint8_t *) s.W; g.W2 = (const uint8_t *) s.W2; g.y = s.y; g.bias = s.bias; g.resid = s.resid;
+        g.N = s.N; g.is_b = (s.type != ta); g.U = a.K / nv_of(s.type);
+        g.row_stride = (long) pm_weight_row_stride(s.type, a.K);
+    }
+    const int ablk = ta == PM_Q8_0 ? 32 : 256;
+    const size_t lds = (size_t) ((a.K + 15) & ~15) + (size_t) (a.K / 16) * 4 + (size_t) ((a.K / ablk + 3) & ~3) * 4 + PM_MAX_ROWS_PER_WG * 4;
+    if (lds > 150 * 1024) return -4;
+#define PM_L(TA_, TB_) return launch_types<TA_, TB_>(p, pair, grid, lds, a.dbg_int != nullptr, st)
+    if (ta == PM_Q4_K && tb == PM_Q4_K) PM_L(PM_Q4_K, PM_Q4_K);
+    if (ta == PM_Q5_K && tb == PM_Q5_K) PM_L(PM_Q5_K, PM_Q5_K);
+    if (ta == PM_Q6_K && tb == PM_Q6_K) PM_L(PM_Q6_K, PM_Q6_K);
+    if (ta == PM_Q8_0 && tb == PM_Q8_0) PM_L(PM_Q8_0, PM_Q8_0);
+    if ((ta == PM_Q4_K && tb == PM_Q6_K) || (ta == PM_Q6_K && tb == PM_Q4_K)) {
+        if (ta == PM_Q6_K) for (int j = 0; j < a.njobs; ++j) p.job[j].is_b = !p.job[j].is_b;
+        PM_L(PM_Q4_K, PM_Q6_K);
+    }
+    if ((ta == PM_Q4_K && tb == PM_Q5_K) || (ta == PM_Q5_K && tb == PM_Q4_K)) {
+        if (ta == PM_Q5_K) for (int j = 0; j < a.njobs; ++j) p.job[j].is_b = !p.job[j].is_b;
+        PM_L(PM_Q4_K, PM_Q5_K);
+    }
+#undef PM_L
+    return -1;
+}
+
+// Single-matrix entry (ncols pre-quantized activation columns, one launch per column).
 int pm_launch_gemv(const pm_gemv_args & a, hipStream_t st) {
-    const int vpu = a.type == PM_Q6_K ? 64 : 32;
-    if (a.K % 256 != 0 && !(a.type == PM_Q8_0 && a.K % 32 == 0)) return -2;
-    if (a.type == PM_Q8_0 && a.K % 32 != 0) return -3;
-    GemvP p;
-    p.K = a.K; p.N = a.N; p.U = a.K / vpu;
-    p.row_bytes = (long) pm_weight_row_stride(a.type, a.K);
-    p.tpr = p.U >= 256 ? 256 : (p.U > 64 ? 128 : 64);
-    int upt = (p.U + p.tpr - 1) / p.tpr;
-    upt = upt <= 1 ? 1 : (upt <= 2 ? 2 : 4);
-    if ((long) upt * p.tpr < p.U) return -4;                   // K too large for one pass (K <= 32768 for 32-w units)
-    const bool pair = a.W2 != nullptr;
-    const int slots = 256 / p.tpr;
-    const int R = pair ? (upt == 1 ? 2 : 1) : (upt == 1 ? 4 : (upt == 2 ? 2 : 1));
-    const int batch = slots * R;
-    // ~4 workgroups per CU when there is enough work; whole batches per workgroup
-    int rpw = (a.N + 1023) / 1024;
-    rpw = ((rpw + batch - 1) / batch) * batch;
-    p.rows_per_wg = rpw;
-    const int grid = (a.N + rpw - 1) / rpw;
     for (int c = 0; c < a.ncols; ++c) {
         const size_t xrow = a.type == PM_Q8_0 ? pm_q80_row_bytes(a.K) : pm_q8k_row_bytes(a.K);
-        p.W = (const uint8_t *) a.W; p.W2 = (const uint8_t *) a.W2;
-        p.xq = (const uint8_t *) a.xq + (size_t) c * xrow;
-        p.y = a.y + (size_t) c * a.y_stride;
-        p.bias = a.bias; p.resid = a.resid ? a.resid + (size_t) c * a.y_stride : nullptr;
-        p.dbg = a.dbg_int;
-        int rc;
-        switch (a.type) {
-            case PM_Q4_K: rc = launch_type<PM_Q4_K>(p, upt, pair, grid, a.dbg_int != nullptr, st); break;
-            case PM_Q5_K: rc = launch_type<PM_Q5_K>(p, upt, pair, grid, a.dbg_int != nullptr, st); break;
-            case PM_Q6_K: rc = launch_type<PM_Q6_K>(p, upt, pair, grid, a.dbg_int != nullptr, st); break;
-            case PM_Q8_0: rc = launch_type<PM_Q8_0>(p, upt, pair, grid, a.dbg_int != nullptr, st); break;
-            default: return -1;
-        }
+        pm_gemv_fused f = {};
+        f.K = a.K; f.njobs = 1; f.xq = (const uint8_t *) a.xq + (size_t) c * xrow; f.dbg_int = a.dbg_int;
+        f.job[0].type = a.type; f.job[0].N = a.N; f.job[0].W = a.W; f.job[0].W2 = a.W2;
+        f.job[0].y = a.y + (size_t) c * a.y_stride; f.job[0].bias = a.bias;
+        f.job[0].resid = a.resid ? a.resid + (size_t) c * a.y_stride : nullptr;
+        const int rc = pm_launch_gemv_fused(f, st);
         if (rc) return rc;
     }
     return 0;

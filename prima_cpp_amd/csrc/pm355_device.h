@@ -87,8 +87,11 @@ __device__ __forceinline__ int nearest_int_rne(float v) {
 // 6-bit scale / min number `j` (0..7) of a K-quant super-block; s = the 12 scale bytes as 3 dwords
 // (reference: get_scale_min_k4, ggml-quants.c:1898-1906)
 __device__ __forceinline__ void k4_scale_min(uint32_t s0, uint32_t s1, uint32_t s2, int j, int & sc, int & mn) {
+    // branch-free (j differs between lanes: a divergent branch here would split the wave in the hot loop)
     const int sh = 8 * (j & 3);
     const uint32_t b0 = (s0 >> sh) & 0xFF, b1 = (s1 >> sh) & 0xFF, b2 = (s2 >> sh) & 0xFF;
-    if (j < 4) { sc = b0 & 63; mn = b1 & 63; }
-    else       { sc = (b2 & 0x0F) | ((b0 >> 6) << 4); mn = (b2 >> 4) | ((b1 >> 6) << 4); }
+    const int sc_lo = b0 & 63, mn_lo = b1 & 63;
+    const int sc_hi = (b2 & 0x0F) | ((b0 >> 6) << 4), mn_hi = (b2 >> 4) | ((b1 >> 6) << 4);
+    sc = j < 4 ? sc_lo : sc_hi;
+    mn = j < 4 ? mn_lo : mn_hi;
 }

@@ -33,3 +33,19 @@ struct pm_gemv_args {
     int32_t * dbg_int;          // debug: per (row, unit) {isum, msum} pairs, or null
 };
 int pm_launch_gemv(const pm_gemv_args & a, hipStream_t st);
+
+// Fused single-token launch: up to 3 matrices (same K) sharing ONE activation row, which is either pre-quantized
+// (xq) or given in f32 (xf) and quantized in the kernel prologue, optionally after rms_norm(xf, eps) * norm_w.
+struct pm_gemv_job {
+    int type; int N;
+    const void * W; const void * W2;    // W2 != null: y = silu(W.x) * (W2.x) (all jobs of a launch alike)
+    float * y; const float * bias; const float * resid;
+};
+struct pm_gemv_fused {
+    int K; int njobs;
+    pm_gemv_job job[3];
+    const void * xq;                    // pre-quantized activation row, or null
+    const float * xf; const float * norm_w; float eps;
+    int32_t * dbg_int;
+};
+int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st);

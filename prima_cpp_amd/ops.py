@@ -177,3 +177,30 @@ def attn_rope_fused(q, k, v, k_cache, v_cache, pos0, n_head, n_head_kv, head_dim
                                     n_head, n_head_kv, head_dim, n_ctx, float(scale), C.addressof(rp), stream_ptr()),
           "attn_rope_fused")
     return out
+
+
+class MatvecJob(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("type", _C.c_int32), ("pad_", _C.c_int32), ("N", _C.c_int64), ("W", _C.c_void_p), ("W2", _C.c_void_p),
+                ("y", _C.c_void_p), ("bias", _C.c_void_p), ("resid", _C.c_void_p)]
+
+
+def mul_mat_vec_fused(ws, x, norm_w=None, eps=0.0, w2s=None, biases=None, resids=None):
+    """One launch: y_j = W_j . q(x) for up to 3 matrices sharing the f32 row x (optionally rms_norm(x)*norm_w first).
+    Returns the list of f32 outputs [N_j]."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_mul_mat_vec_fused.restype = C.c_int
+    lib.pm355_mul_mat_vec_fused.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    n = len(ws)
+    jobs = (MatvecJob * n)()
+    ys = []
+    for j, w in enumerate(ws):
+        y = torch.empty(w.N, dtype=torch.float32, device=w.data.device)
+        ys.append(y)
+        jobs[j] = MatvecJob(w.type, 0, w.N, ptr(w.data), ptr(w2s[j].data) if w2s else None, ptr(y),
+                            ptr(biases[j]) if biases and biases[j] is not None else None,
+                            ptr(resids[j]) if resids and resids[j] is not None else None)
+    check(lib.pm355_mul_mat_vec_fused(C.addressof(jobs), n, ws[0].K, ptr(x), ptr(norm_w), float(eps), stream_ptr()),
+          "mul_mat_vec_fused")
+    return ys

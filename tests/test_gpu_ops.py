@@ -284,3 +284,43 @@ def test_attn_rope_fused_equals_two_kernel_path(P, mode, dh, n_past):
     assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
     w, g = want.cpu().numpy(), got.cpu().numpy()
     assert np.abs(w - g).max() <= 2e-6 * max(1.0, np.abs(w).max())      # summation order only
+
+
+@pytest.mark.parametrize("t", QUANT_TYPES)
+@pytest.mark.parametrize("K", [256, 4096, 8192, 14336, 28672])
+@pytest.mark.parametrize("norm", [False, True])
+def test_fused_prologue_equals_separate_kernels_bitexact(P, t, K, norm):
+    """f32 -> (rms_norm) -> quantize inside the GEMV prologue must give EXACTLY what the stand-alone rms_norm /
+    quantize kernels + pre-quantized GEMV give (same integers, same float order)."""
+    torch = P.torch
+    rng = np.random.default_rng(51)
+    N = 33
+    w = P.upload_weight(t, rand_blocks(t, N, K, rng), K, N)
+    x = torch.from_numpy(rng.normal(0, 1.5, (1, K)).astype(np.float32)).cuda()
+    x[0, 3] = 7.5; x[0, 5] = -7.5                    # tie on |max| inside the first block
+    nw = torch.from_numpy((1 + rng.normal(0, 0.05, K)).astype(np.float32)).cuda() if norm else None
+    resid = torch.from_numpy(rng.normal(0, 1, N).astype(np.float32)).cuda()
+    xn = P.rms_norm(x, nw, 1e-5) if norm else x
+    want = P.mul_mat_vec(w, x=xn, resid=resid.view(1, -1))[0]
+    got = P.mul_mat_vec_fused([w], x, norm_w=nw, eps=1e-5, resids=[resid])[0]
+    assert torch.equal(got, want), (got - want).abs().max()
+
+
+def test_fused_qkv_mixed_types_one_launch(P, oracle):
+    """wq/wk (Q4_K) + wv (Q6_K or Q5_K) in one launch == three separate mat-vecs, and == the oracle's mul_mat."""
+    torch = P.torch
+    rng = np.random.default_rng(52)
+    K = 4096
+    for tv in (Q6_K, Q5_K, Q4_K):
+        blocks = [rand_blocks(Q4_K, 96, K, rng), rand_blocks(Q4_K, 40, K, rng), rand_blocks(tv, 40, K, rng)]
+        ws = [P.upload_weight(Q4_K, blocks[0], K, 96), P.upload_weight(Q4_K, blocks[1], K, 40), P.upload_weight(tv, blocks[2], K, 40)]
+        x = rng.normal(0, 1, (1, K)).astype(np.float32)
+        nw = (1 + rng.normal(0, 0.05, K)).astype(np.float32)
+        bias = [torch.from_numpy(rng.normal(0, 1, w.N).astype(np.float32)).cuda() for w in ws]
+        ys = P.mul_mat_vec_fused(ws, _dev(P, x), norm_w=_dev(P, nw), eps=1e-6, biases=bias)
+        xn = oracle.rms_norm(x, nw, 1e-6)
+        for w, b, y, bl in zip(ws, bias, ys, blocks):
+            sep = P.mul_mat_vec_fused([w], _dev(P, x), norm_w=_dev(P, nw), eps=1e-6, biases=[b])[0]
+            assert torch.equal(y, sep)
+            want = oracle.mul_mat(w.type, bl, K, w.N, xn)[0] + b.cpu().numpy()
+            assert np.allclose(y.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
