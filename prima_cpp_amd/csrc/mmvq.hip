@@ -254,12 +254,23 @@ __device__ __forceinline__ void stage_activation(const GemvP & p, int8_t * xs_q,
             xs_d[b] = ABLK == 256 ? ((const float *) (p.xq + K))[b] : h2f(((const uint16_t *) (p.xq + K))[b]);
         return;
     }
+    // f32 activation. Thread t owns the float4s t, t+512, t+1024, ...: float4 number i belongs to 256-block i/64, i.e.
+    // wave w owns blocks w, w+8, w+16, ... with lane = position inside the block - the same ownership for the
+    // sum-of-squares pass and for the quantization pass, so the values are loaded ONCE (one exposed L2 latency, all
+    // loads issued back to back) and stay in registers in between. Longer rows (K > 8192) go in groups of 4 float4s per thread.
+    constexpr int NB = 4;                            // float4s per thread in flight at a time (register budget: 128)
+    const int n4 = K / 4;
     float scale = 1.0f;
     if (p.xmode == 2) {
         double ss = 0.0;                             // sum of f32-rounded squares in f64, like the reference
-        for (int i = tid; i < K / 4; i += PM_GEMV_BLOCK) {
-            const float4 f = ((const float4 *) p.xf)[i];
-            ss += (double) (f.x * f.x); ss += (double) (f.y * f.y); ss += (double) (f.z * f.z); ss += (double) (f.w * f.w);
+        for (int i0 = tid; i0 < n4; i0 += NB * PM_GEMV_BLOCK) {
+            float4 f[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) { const int i = i0 + k * PM_GEMV_BLOCK; f[k] = ((const float4 *) p.xf)[i < n4 ? i : 0]; }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) if (i0 + k * PM_GEMV_BLOCK < n4) {
+                ss += (double) (f[k].x * f[k].x); ss += (double) (f[k].y * f[k].y); ss += (double) (f[k].z * f[k].z); ss += (double) (f[k].w * f[k].w);
+            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
@@ -271,27 +282,22 @@ __device__ __forceinline__ void stage_activation(const GemvP & p, int8_t * xs_q,
         const float mean = (float) (tot / K);
         scale = 1.0f / sqrtf(mean + p.eps);
     }
-    if (ABLK == 256) {
-        for (int blk = wave; blk < K / 256; blk += PM_GEMV_NW) {       // one wave per 256-block
-            const float4 f = ((const float4 *) (p.xf + (size_t) blk * 256))[lane];
-            float v[4] = {f.x, f.y, f.z, f.w};
-            if (p.xmode == 2) {
-                const float4 g = ((const float4 *) (p.norm_w + (size_t) blk * 256))[lane];
-                v[0] = v[0] * scale * g.x; v[1] = v[1] * scale * g.y; v[2] = v[2] * scale * g.z; v[3] = v[3] * scale * g.w;
-            }
-            q8k_block_to_lds(v, lane, xs_q, xs_gs, xs_d, blk);
+    for (int i0 = tid; i0 < n4; i0 += NB * PM_GEMV_BLOCK) {
+        float4 f[NB], g[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {               // (x is L1/L2 resident by now when it was read for the norm)
+            const int i = i0 + k * PM_GEMV_BLOCK;
+            f[k] = ((const float4 *) p.xf)[i < n4 ? i : 0];
+            if (p.xmode == 2) g[k] = ((const float4 *) p.norm_w)[i < n4 ? i : 0];
         }
-    } else {
-        const int n4 = K / 4, n4p = (n4 + 7) & ~7;
-        for (int i4 = tid; i4 < n4p; i4 += PM_GEMV_BLOCK) {
-            if (i4 < n4) {                           // K % 32 == 0 -> whole 8-lane groups are in or out together
-                const float4 f = ((const float4 *) p.xf)[i4];
-                float v[4] = {f.x, f.y, f.z, f.w};
-                if (p.xmode == 2) {
-                    const float4 g = ((const float4 *) p.norm_w)[i4];
-                    v[0] = v[0] * scale * g.x; v[1] = v[1] * scale * g.y; v[2] = v[2] * scale * g.z; v[3] = v[3] * scale * g.w;
-                }
-                q80_block_to_lds(v, i4, xs_q, xs_gs, xs_d);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int i = i0 + k * PM_GEMV_BLOCK;
+            if (i - lane < n4) {                     // wave-uniform: whole 256-blocks (and 32-blocks) are in or out
+                float v[4] = {f[k].x, f[k].y, f[k].z, f[k].w};
+                if (p.xmode == 2) { v[0] = v[0] * scale * g[k].x; v[1] = v[1] * scale * g[k].y; v[2] = v[2] * scale * g[k].z; v[3] = v[3] * scale * g[k].w; }
+                if (ABLK == 256) q8k_block_to_lds(v, lane, xs_q, xs_gs, xs_d, i >> 6);
+                else if (i < n4) q80_block_to_lds(v, i, xs_q, xs_gs, xs_d);
             }
         }
     }
@@ -311,96 +317,157 @@ __device__ __forceinline__ void load_x_lds(typename QT<TYPE>::X & x, const XLds 
     x.yd = xs.d[T::group_base(u, 0) / T::ABLK];
 }
 
-// rows [r0, r1) of one job; each WAVE owns whole rows (R at a time), lanes stride over the row's units, the
-// activation slice of every unit comes from LDS. No barrier and no cross-wave reduction inside the row loop.
-template <int TYPE, bool PAIR, bool DBG>
-__device__ __forceinline__ void gemv_rows(const GemvP & p, const GemvJob & jb, const XLds & xs, float * outbuf, int r0, int r1) {
+// A wave processes ITEMS: R consecutive rows of one job. Lanes stride over the row's units in chunks of CH units per
+// lane; the activation slice of every unit comes from LDS. No barrier and no cross-wave reduction inside an item.
+template <int TYPE, bool PAIR> struct Item {
     typedef QT<TYPE> T;
-    constexpr int NM = PAIR ? 2 : 1;
-    constexpr int CH = T::NV == 64 ? 2 : 4;          // units per lane in flight per row
-    constexpr int R  = PAIR ? 1 : 2;                 // rows in flight per wave
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int U = jb.U;
-    const int upl = (U + 63) >> 6;                   // units per lane
-    for (int row = r0 + wave * R; row < r1; row += PM_GEMV_NW * R) {
+    static constexpr int NM = PAIR ? 2 : 1;
+    static constexpr int CH = T::NV == 64 ? 2 : 4;   // units per lane in flight per row
+    static constexpr int R  = PAIR ? 1 : 2;          // rows in flight per wave
+    struct Regs { typename T::Wr w[R][NM][CH]; };
+
+    // unconditional loads (row / unit clamped): conditional loads make the compiler drain the VMEM queue
+    static __device__ __forceinline__ void issue(Regs & g, const GemvP & p, const GemvJob & jb, int row, int r1, int c0, int lane) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int rr = min(row + r, r1 - 1);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int u = min(lane + 64 * (c0 + i), jb.U - 1);
+                T::issue(g.w[r][0][i], jb.W + (long) rr * jb.row_stride, p.K, u);
+                if (PAIR) T::issue(g.w[r][NM - 1][i], jb.W2 + (long) rr * jb.row_stride, p.K, u);
+            }
+        }
+    }
+    template <bool DBG>
+    static __device__ __forceinline__ void consume(const Regs & g, float (&acc)[R][NM], const GemvP & p, const GemvJob & jb,
+                                                   const XLds & xs, int row, int r1, int c0, int lane) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int uu = lane + 64 * (c0 + i);
+            const bool uv = uu < jb.U;
+            const int u = min(uu, jb.U - 1);
+            typename T::X x;
+            load_x_lds<TYPE>(x, xs, u);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    int isum, msum;
+                    const float c = T::consume(g.w[r][m][i], x, u, isum, msum);
+                    acc[r][m] += uv ? c : 0.0f;
+                    if (DBG) if (uv && row + r < r1) {
+                        int32_t * o = p.dbg + ((long) (m * jb.N + row + r) * jb.U + u) * 2;
+                        o[0] = isum; o[1] = msum;
+                    }
+                }
+        }
+    }
+    // whole item; `pre` holds the already-issued loads of chunk 0 when have_pre
+    template <bool DBG>
+    static __device__ __forceinline__ void run(const GemvP & p, const GemvJob & jb, const XLds & xs, float * out /*this job's slice*/,
+                                               int row, int r0, int r1, int lane, Regs & pre, bool have_pre) {
         float acc[R][NM];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int m = 0; m < NM; ++m) acc[r][m] = 0.0f;
-        for (int c0 = 0; c0 < upl; c0 += CH) {
-            typename T::Wr w[R][NM][CH];
-            // unconditional loads (row / unit clamped): conditional loads make the compiler drain the VMEM queue
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int rr = min(row + r, r1 - 1);
-#pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    const int u = min(lane + 64 * (c0 + i), U - 1);
-                    T::issue(w[r][0][i], jb.W + (long) rr * jb.row_stride, p.K, u);
-                    if (PAIR) T::issue(w[r][NM - 1][i], jb.W2 + (long) rr * jb.row_stride, p.K, u);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int uu = lane + 64 * (c0 + i);
-                const bool uv = uu < U;
-                const int u = min(uu, U - 1);
-                typename T::X x;
-                load_x_lds<TYPE>(x, xs, u);
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int m = 0; m < NM; ++m) {
-                        int isum, msum;
-                        const float c = T::consume(w[r][m][i], x, u, isum, msum);
-                        acc[r][m] += uv ? c : 0.0f;
-                        if (DBG) if (uv && row + r < r1) {
-                            int32_t * o = p.dbg + ((long) (m * jb.N + row + r) * U + u) * 2;
-                            o[0] = isum; o[1] = msum;
-                        }
-                    }
-            }
+        const int upl = (jb.U + 63) >> 6;            // units per lane
+        int c0 = 0;
+        if (have_pre) { consume<DBG>(pre, acc, p, jb, xs, row, r1, 0, lane); c0 = CH; }
+        for (; c0 < upl; c0 += CH) {
+            Regs g;
+            issue(g, p, jb, row, r1, c0, lane);
+            consume<DBG>(g, acc, p, jb, xs, row, r1, c0, lane);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float o[NM];
 #pragma unroll
             for (int m = 0; m < NM; ++m) o[m] = wave_sum(acc[r][m]);
-            if (lane == 0 && row + r < r1) outbuf[row + r - r0] = PAIR ? silu_f(o[0]) * o[NM - 1] : o[0];
+            if (lane == 0 && row + r < r1) out[row + r - r0] = PAIR ? silu_f(o[0]) * o[NM - 1] : o[0];
         }
+    }
+};
+
+struct Slices { int r0_0, r1_0, r0_1, r1_1, r0_2, r1_2, it_1, it_2, ob_1, ob_2; };
+
+// (plain functions, no lambdas: a by-reference lambda capture takes the address of the kernel-argument struct and of the
+//  register sets and pushes them into scratch memory)
+template <int TA, int TB, bool PAIR, bool DBG>
+__device__ __forceinline__ void do_item(const GemvP & p, const XLds & xs, float * outbuf, const Slices & sl, int t, int lane,
+                                        typename Item<TA, PAIR>::Regs & pre, bool use_pre) {
+    typedef Item<TA, PAIR> IA;
+    typedef Item<TB, PAIR> IB;
+    constexpr int R = IA::R;
+    const int j = (t >= sl.it_1) + (t >= sl.it_2);
+    const GemvJob & jb = p.job[j];
+    const int r0 = j == 0 ? sl.r0_0 : (j == 1 ? sl.r0_1 : sl.r0_2), r1 = j == 0 ? sl.r1_0 : (j == 1 ? sl.r1_1 : sl.r1_2);
+    const int itb = j == 0 ? 0 : (j == 1 ? sl.it_1 : sl.it_2), ob = j == 0 ? 0 : (j == 1 ? sl.ob_1 : sl.ob_2);
+    const int row = r0 + (t - itb) * R;
+    if (TA != TB && jb.is_b) {
+        typename IB::Regs dummy;
+        IB::template run<DBG>(p, jb, xs, outbuf + ob, row, r0, r1, lane, dummy, false);
+    } else if (use_pre) {
+        IA::template run<DBG>(p, jb, xs, outbuf + ob, row, r0, r1, lane, pre, true);
+    } else {
+        typename IA::Regs dummy;
+        IA::template run<DBG>(p, jb, xs, outbuf + ob, row, r0, r1, lane, dummy, false);
+    }
+}
+
+__device__ __forceinline__ void write_out(const GemvJob & jb, const float * outbuf, int r0, int r1, int ob, int tid) {
+    for (int t = tid; t < r1 - r0; t += PM_GEMV_BLOCK) {
+        float out = outbuf[ob + t];
+        if (jb.bias)  out += jb.bias[r0 + t];
+        if (jb.resid) out += jb.resid[r0 + t];
+        jb.y[r0 + t] = out;
     }
 }
 
 template <int TA, int TB, bool PAIR, bool DBG>
-__global__ __launch_bounds__(PM_GEMV_BLOCK, 2) void gemv_q_kernel(GemvP p) {
+__global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(GemvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double nred[PM_GEMV_NW];
     constexpr int ABLK = QT<TA>::ABLK;
+    typedef Item<TA, PAIR> IA;
+    typedef Item<TB, PAIR> IB;
+    constexpr int R = IA::R;
     int8_t * xs_q  = (int8_t *) smem;                                   // [K] (K % 32 == 0 -> 16-B aligned pieces)
     int *    xs_gs = (int *) (smem + ((p.K + 15) & ~15));               // [K/16]
     float *  xs_d  = (float *) (xs_gs + p.K / 16);                      // [K/ABLK]
-    float *  outbuf = xs_d + ((p.K / ABLK + 3) & ~3);                   // [PM_MAX_ROWS_PER_WG]
+    float *  outbuf = xs_d + ((p.K / ABLK + 3) & ~3);                   // [sum of this workgroup's rows]
+    const int b = blockIdx.x, G = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // this workgroup's slice [r0, r1) of every job, and the ITEM list = concatenation of the jobs' R-row groups
+    // (scalars, not arrays: a runtime-indexed array would live in scratch memory)
+    const int r0_0 = (int) ((long) p.job[0].N * b / G), r1_0 = (int) ((long) p.job[0].N * (b + 1) / G);
+    const int r0_1 = (int) ((long) p.job[1].N * b / G), r1_1 = (int) ((long) p.job[1].N * (b + 1) / G);
+    const int r0_2 = (int) ((long) p.job[2].N * b / G), r1_2 = (int) ((long) p.job[2].N * (b + 1) / G);
+    const int it_1 = (r1_0 - r0_0 + R - 1) / R, it_2 = it_1 + (r1_1 - r0_1 + R - 1) / R;
+    const int n_items = it_2 + (r1_2 - r0_2 + R - 1) / R;
+    const int ob_1 = r1_0 - r0_0, ob_2 = ob_1 + (r1_1 - r0_1);
+
+    // (1) [pre-issuing the first chunk of weight loads across the prologue was tried: the extra live registers spill
+    //      under the 128-VGPR budget that 16 waves/CU need, and it measured slower]
+    typename IA::Regs pre;
+    const bool have_pre = false;
+    // (2) activation row -> LDS (quantized, bit-exact with the reference quantizers)
     stage_activation<ABLK>(p, xs_q, xs_gs, xs_d, nred);
     __syncthreads();
     const XLds xs = {xs_q, xs_gs, xs_d};
-    const int b = blockIdx.x, G = gridDim.x, tid = threadIdx.x;
-#pragma unroll 1
-    for (int j = 0; j < 3; ++j) {
-        const GemvJob & jb = p.job[j];
-        if (jb.N <= 0) break;
-        const int r0 = (int) ((long) jb.N * b / G), r1 = (int) ((long) jb.N * (b + 1) / G);
-        if (TA != TB && jb.is_b) gemv_rows<TB, PAIR, DBG>(p, jb, xs, outbuf, r0, r1);
-        else                     gemv_rows<TA, PAIR, DBG>(p, jb, xs, outbuf, r0, r1);
-        __syncthreads();
-        for (int t = tid; t < r1 - r0; t += PM_GEMV_BLOCK) {          // coalesced write-out (+bias, +residual)
-            float out = outbuf[t];
-            if (jb.bias)  out += jb.bias[r0 + t];
-            if (jb.resid) out += jb.resid[r0 + t];
-            jb.y[r0 + t] = out;
-        }
-        __syncthreads();
+    // (3) items. The first one is peeled so that the pre-issued registers die right after it.
+    const Slices sl = {r0_0, r1_0, r0_1, r1_1, r0_2, r1_2, it_1, it_2, ob_1, ob_2};
+    if (wave < n_items) do_item<TA, TB, PAIR, DBG>(p, xs, outbuf, sl, wave, lane, pre, have_pre);
+    for (int t = wave + PM_GEMV_NW; t < n_items; t += PM_GEMV_NW) {
+        typename IA::Regs none;
+        do_item<TA, TB, PAIR, DBG>(p, xs, outbuf, sl, t, lane, none, false);
     }
+    __syncthreads();
+    // (4) coalesced write-out (+bias, +residual)
+    write_out(p.job[0], outbuf, r0_0, r1_0, 0, tid);
+    write_out(p.job[1], outbuf, r0_1, r1_1, ob_1, tid);
+    write_out(p.job[2], outbuf, r0_2, r1_2, ob_2, tid);
 }
 
 template <int TA, int TB>
@@ -470,7 +537,9 @@ int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st) {
     if (!g_num_cus) { hipDeviceProp_t pr; int dev = 0; (void) hipGetDevice(&dev); g_num_cus = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
     // 2 workgroups of 8 waves per CU; every workgroup takes an equal slice of the rows of EVERY job
     int grid = 2 * g_num_cus;
-    while ((max_rows + grid - 1) / grid > PM_MAX_ROWS_PER_WG) grid *= 2;
+    long tot_rows = 0;
+    for (int j = 0; j < a.njobs; ++j) tot_rows += a.job[j].N;
+    while ((tot_rows + grid - 1) / grid + 3 > PM_MAX_ROWS_PER_WG) grid *= 2;
     for (int j = 0; j < 3; ++j) {
         GemvJob & g = p.job[j];
         if (j >= a.njobs) { g.N = 0; continue; }
