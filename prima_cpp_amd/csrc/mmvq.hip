@@ -322,7 +322,7 @@ __device__ __forceinline__ void load_x_lds(typename QT<TYPE>::X & x, const XLds 
 template <int TYPE, bool PAIR> struct Item {
     typedef QT<TYPE> T;
     static constexpr int NM = PAIR ? 2 : 1;
-    static constexpr int CH = T::NV == 64 ? 2 : 4;   // units per lane in flight per row
+    static constexpr int CH = T::NV == 64 ? 1 : 2;   // units per lane per row and register set (two sets in flight)
     static constexpr int R  = PAIR ? 1 : 2;          // rows in flight per wave
     struct Regs { typename T::Wr w[R][NM][CH]; };
 
@@ -363,58 +363,58 @@ template <int TYPE, bool PAIR> struct Item {
                 }
         }
     }
-    // whole item; `pre` holds the already-issued loads of chunk 0 when have_pre
+    // All items of ONE job that belong to this wave (item ids first, first+NW, ... < n_job_items), flattened into STEPS
+    // (item, chunk) and software-pipelined with two statically named register sets: the loads of step s+1 are in flight
+    // while step s is consumed. The steady-state loop body is straight-line code - every issue() in it is unconditional -
+    // so the compiler can use counted s_waitcnt vmcnt(N); the last one or two steps are peeled off behind the loop.
+    // (All waves start in lock-step after the prologue barrier: without the overlap the whole chip would alternate
+    //  between "only loading" and "only computing".)
     template <bool DBG>
-    static __device__ __forceinline__ void run(const GemvP & p, const GemvJob & jb, const XLds & xs, float * out /*this job's slice*/,
-                                               int row, int r0, int r1, int lane, Regs & pre, bool have_pre) {
+    static __device__ __forceinline__ void run_job(const GemvP & p, const GemvJob & jb, const XLds & xs, float * out /*job slice*/,
+                                                   int first, int n_job_items, int r0, int r1, int lane) {
+        if (first >= n_job_items) return;
+        const int upl = (jb.U + 63) >> 6;            // units per lane
+        const int cpr = (upl + CH - 1) / CH;         // chunks (steps) per item
+        const int n_my = (n_job_items - first + PM_GEMV_NW - 1) / PM_GEMV_NW;
+        const int S = n_my * cpr;
         float acc[R][NM];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int m = 0; m < NM; ++m) acc[r][m] = 0.0f;
-        const int upl = (jb.U + 63) >> 6;            // units per lane
-        int c0 = 0;
-        if (have_pre) { consume<DBG>(pre, acc, p, jb, xs, row, r1, 0, lane); c0 = CH; }
-        for (; c0 < upl; c0 += CH) {
-            Regs g;
-            issue(g, p, jb, row, r1, c0, lane);
-            consume<DBG>(g, acc, p, jb, xs, row, r1, c0, lane);
+        // step cursors: (row, chunk) of the step being ISSUED and of the step being CONSUMED
+        int irow = r0 + first * R, ic = 0, crow = irow, cc = 0;
+        auto next = [&](int & row, int & c) __attribute__((always_inline)) { if (++c == cpr) { c = 0; row += PM_GEMV_NW * R; } };
+        auto finish = [&]() __attribute__((always_inline)) {           // after a step was consumed: end of item?
+            if (cc == cpr - 1) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float o[NM];
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) { o[m] = wave_sum(acc[r][m]); acc[r][m] = 0.0f; }
+                    if (lane == 0 && crow + r < r1) out[crow + r - r0] = PAIR ? silu_f(o[0]) * o[NM - 1] : o[0];
+                }
+            }
+            next(crow, cc);
+        };
+        Regs ga, gb;
+        issue(ga, p, jb, irow, r1, ic * CH, lane); next(irow, ic);
+        int s_ = 0;
+        for (; s_ + 2 < S; s_ += 2) {
+            issue(gb, p, jb, irow, r1, ic * CH, lane); next(irow, ic);
+            consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
+            issue(ga, p, jb, irow, r1, ic * CH, lane); next(irow, ic);
+            consume<DBG>(gb, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float o[NM];
-#pragma unroll
-            for (int m = 0; m < NM; ++m) o[m] = wave_sum(acc[r][m]);
-            if (lane == 0 && row + r < r1) out[row + r - r0] = PAIR ? silu_f(o[0]) * o[NM - 1] : o[0];
+        if (s_ + 1 < S) {
+            issue(gb, p, jb, irow, r1, ic * CH, lane);
+            consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
+            consume<DBG>(gb, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
+        } else {
+            consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
         }
     }
 };
-
-struct Slices { int r0_0, r1_0, r0_1, r1_1, r0_2, r1_2, it_1, it_2, ob_1, ob_2; };
-
-// (plain functions, no lambdas: a by-reference lambda capture takes the address of the kernel-argument struct and of the
-//  register sets and pushes them into scratch memory)
-template <int TA, int TB, bool PAIR, bool DBG>
-__device__ __forceinline__ void do_item(const GemvP & p, const XLds & xs, float * outbuf, const Slices & sl, int t, int lane,
-                                        typename Item<TA, PAIR>::Regs & pre, bool use_pre) {
-    typedef Item<TA, PAIR> IA;
-    typedef Item<TB, PAIR> IB;
-    constexpr int R = IA::R;
-    const int j = (t >= sl.it_1) + (t >= sl.it_2);
-    const GemvJob & jb = p.job[j];
-    const int r0 = j == 0 ? sl.r0_0 : (j == 1 ? sl.r0_1 : sl.r0_2), r1 = j == 0 ? sl.r1_0 : (j == 1 ? sl.r1_1 : sl.r1_2);
-    const int itb = j == 0 ? 0 : (j == 1 ? sl.it_1 : sl.it_2), ob = j == 0 ? 0 : (j == 1 ? sl.ob_1 : sl.ob_2);
-    const int row = r0 + (t - itb) * R;
-    if (TA != TB && jb.is_b) {
-        typename IB::Regs dummy;
-        IB::template run<DBG>(p, jb, xs, outbuf + ob, row, r0, r1, lane, dummy, false);
-    } else if (use_pre) {
-        IA::template run<DBG>(p, jb, xs, outbuf + ob, row, r0, r1, lane, pre, true);
-    } else {
-        typename IA::Regs dummy;
-        IA::template run<DBG>(p, jb, xs, outbuf + ob, row, r0, r1, lane, dummy, false);
-    }
-}
 
 __device__ __forceinline__ void write_out(const GemvJob & jb, const float * outbuf, int r0, int r1, int ob, int tid) {
     for (int t = tid; t < r1 - r0; t += PM_GEMV_BLOCK) {
@@ -440,28 +440,30 @@ __global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(GemvP p) {
     const int b = blockIdx.x, G = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // this workgroup's slice [r0, r1) of every job, and the ITEM list = concatenation of the jobs' R-row groups
-    // (scalars, not arrays: a runtime-indexed array would live in scratch memory)
+    // this workgroup's slice [r0, r1) of every job (scalars, not arrays: a runtime-indexed array would live in scratch)
     const int r0_0 = (int) ((long) p.job[0].N * b / G), r1_0 = (int) ((long) p.job[0].N * (b + 1) / G);
     const int r0_1 = (int) ((long) p.job[1].N * b / G), r1_1 = (int) ((long) p.job[1].N * (b + 1) / G);
     const int r0_2 = (int) ((long) p.job[2].N * b / G), r1_2 = (int) ((long) p.job[2].N * (b + 1) / G);
-    const int it_1 = (r1_0 - r0_0 + R - 1) / R, it_2 = it_1 + (r1_1 - r0_1 + R - 1) / R;
-    const int n_items = it_2 + (r1_2 - r0_2 + R - 1) / R;
+    const int ni_0 = (r1_0 - r0_0 + R - 1) / R, ni_1 = (r1_1 - r0_1 + R - 1) / R, ni_2 = (r1_2 - r0_2 + R - 1) / R;
     const int ob_1 = r1_0 - r0_0, ob_2 = ob_1 + (r1_1 - r0_1);
 
-    // (1) [pre-issuing the first chunk of weight loads across the prologue was tried: the extra live registers spill
-    //      under the 128-VGPR budget that 16 waves/CU need, and it measured slower]
-    typename IA::Regs pre;
-    const bool have_pre = false;
-    // (2) activation row -> LDS (quantized, bit-exact with the reference quantizers)
+    // (1) activation row -> LDS (quantized, bit-exact with the reference quantizers)
     stage_activation<ABLK>(p, xs_q, xs_gs, xs_d, nred);
     __syncthreads();
     const XLds xs = {xs_q, xs_gs, xs_d};
-    // (3) items. The first one is peeled so that the pre-issued registers die right after it.
-    const Slices sl = {r0_0, r1_0, r0_1, r1_1, r0_2, r1_2, it_1, it_2, ob_1, ob_2};
-    if (wave < n_items) do_item<TA, TB, PAIR, DBG>(p, xs, outbuf, sl, wave, lane, pre, have_pre);
-    for (int t = wave + PM_GEMV_NW; t < n_items; t += PM_GEMV_NW) {
-        typename IA::Regs none;
-        do_item<TA, TB, PAIR, DBG>(p, xs, outbuf, sl, t, lane, none, false);
+    // (2) rows. Items of the jobs are dealt to the waves round-robin, continuing across jobs (wave offset rotates) so that
+    //     the small k / v slices do not all land on wave 0.
+    const int w1 = (wave + PM_GEMV_NW - ni_0 % PM_GEMV_NW) % PM_GEMV_NW;            // first item id of this wave in job 1
+    const int w2 = (wave + 2 * PM_GEMV_NW - (ni_0 + ni_1) % PM_GEMV_NW) % PM_GEMV_NW;
+    if (TA != TB && p.job[0].is_b) IB::template run_job<DBG>(p, p.job[0], xs, outbuf, wave, ni_0, r0_0, r1_0, lane);
+    else                           IA::template run_job<DBG>(p, p.job[0], xs, outbuf, wave, ni_0, r0_0, r1_0, lane);
+    if (ni_1 > 0) {
+        if (TA != TB && p.job[1].is_b) IB::template run_job<DBG>(p, p.job[1], xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
+        else                           IA::template run_job<DBG>(p, p.job[1], xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
+    }
+    if (ni_2 > 0) {
+        if (TA != TB && p.job[2].is_b) IB::template run_job<DBG>(p, p.job[2], xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
+        else                           IA::template run_job<DBG>(p, p.job[2], xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
     }
     __syncthreads();
     // (4) coalesced write-out (+bias, +residual)
