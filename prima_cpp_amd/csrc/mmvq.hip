@@ -186,6 +186,15 @@ __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + expf(-g));
 //   xs_d  float [K/ABLK]   block scales (ABLK = 256: Q8_K, float d;  ABLK = 32: Q8_0, fp16-rounded d)
 struct XLds { const int8_t * q; const int * gs; const float * d; };
 
+// wave min, result in every lane (lanes that receive nothing from a DPP step keep their own value)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_keep_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ int wave_min_keep(int v) {
+    v = min(v, dpp_keep_i<0xB1>(v)); v = min(v, dpp_keep_i<0x4E>(v)); v = min(v, dpp_keep_i<0x141>(v)); v = min(v, dpp_keep_i<0x140>(v));
+    v = min(v, dpp_keep_i<0x142, 0xA>(v)); v = min(v, dpp_keep_i<0x143, 0xC>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // one wave, 4 consecutive values per lane = one 256-block (quantize_row_q8_K_ref)
 __device__ __forceinline__ void q8k_block_to_lds(const float v[4], int lane, int8_t * xs_q, int * xs_gs, float * xs_d, int blk) {
     const float a0 = fabsf(v[0]), a1 = fabsf(v[1]), a2 = fabsf(v[2]), a3 = fabsf(v[3]);
@@ -193,8 +202,8 @@ __device__ __forceinline__ void q8k_block_to_lds(const float v[4], int lane, int
     // wave max (identity 0 is fine: |x| >= 0)
     amax = fmaxf(amax, dpp_f<0xB1>(amax)); amax = fmaxf(amax, dpp_f<0x4E>(amax)); amax = fmaxf(amax, dpp_f<0x141>(amax));
     amax = fmaxf(amax, dpp_f<0x140>(amax));
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    amax = fmaxf(amax, dpp_f<0x142, 0xA>(amax)); amax = fmaxf(amax, dpp_f<0x143, 0xC>(amax));      // lane 63 = wave max
+    amax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, amax), 63));
     uint32_t packed = 0; int psum = 0;
     if (amax != 0.0f) {
         int key = 0x7fffffff;                        // lowest index with |x| == amax; low bit = its sign
@@ -202,8 +211,7 @@ __device__ __forceinline__ void q8k_block_to_lds(const float v[4], int lane, int
         if (a2 == amax) key = ((4 * lane + 2) << 1) | (v[2] < 0.0f);
         if (a1 == amax) key = ((4 * lane + 1) << 1) | (v[1] < 0.0f);
         if (a0 == amax) key = ((4 * lane + 0) << 1) | (v[0] < 0.0f);
-#pragma unroll
-        for (int off = 1; off <= 32; off <<= 1) key = min(key, __shfl_xor(key, off));
+        key = wave_min_keep(key);
         const float iscale = -127.f / ((key & 1) ? -amax : amax);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -260,16 +268,35 @@ __device__ __forceinline__ void stage_activation(const GemvP & p, int8_t * xs_q,
     // loads issued back to back) and stay in registers in between. Longer rows (K > 8192) go in groups of 4 float4s per thread.
     constexpr int NB = 4;                            // float4s per thread in flight at a time (register budget: 128)
     const int n4 = K / 4;
+    const bool one_group = n4 <= NB * PM_GEMV_BLOCK; // K <= 8192: everything this thread needs fits in registers
+    float4 f[NB], g[NB];
     float scale = 1.0f;
+    if (one_group) {
+        // ONE exposed load latency for the whole prologue: x and the norm weights are requested together and x stays in
+        // registers across the sum-of-squares barrier.
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int i = tid + k * PM_GEMV_BLOCK;
+            f[k] = ((const float4 *) p.xf)[i < n4 ? i : 0];
+            if (p.xmode == 2) g[k] = ((const float4 *) p.norm_w)[i < n4 ? i : 0];
+        }
+    }
     if (p.xmode == 2) {
         double ss = 0.0;                             // sum of f32-rounded squares in f64, like the reference
-        for (int i0 = tid; i0 < n4; i0 += NB * PM_GEMV_BLOCK) {
-            float4 f[NB];
+        if (one_group) {
 #pragma unroll
-            for (int k = 0; k < NB; ++k) { const int i = i0 + k * PM_GEMV_BLOCK; f[k] = ((const float4 *) p.xf)[i < n4 ? i : 0]; }
-#pragma unroll
-            for (int k = 0; k < NB; ++k) if (i0 + k * PM_GEMV_BLOCK < n4) {
+            for (int k = 0; k < NB; ++k) if (tid + k * PM_GEMV_BLOCK < n4) {
                 ss += (double) (f[k].x * f[k].x); ss += (double) (f[k].y * f[k].y); ss += (double) (f[k].z * f[k].z); ss += (double) (f[k].w * f[k].w);
+            }
+        } else {
+            for (int i0 = tid; i0 < n4; i0 += NB * PM_GEMV_BLOCK) {
+                float4 t[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { const int i = i0 + k * PM_GEMV_BLOCK; t[k] = ((const float4 *) p.xf)[i < n4 ? i : 0]; }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) if (i0 + k * PM_GEMV_BLOCK < n4) {
+                    ss += (double) (t[k].x * t[k].x); ss += (double) (t[k].y * t[k].y); ss += (double) (t[k].z * t[k].z); ss += (double) (t[k].w * t[k].w);
+                }
             }
         }
 #pragma unroll
@@ -283,12 +310,13 @@ __device__ __forceinline__ void stage_activation(const GemvP & p, int8_t * xs_q,
         scale = 1.0f / sqrtf(mean + p.eps);
     }
     for (int i0 = tid; i0 < n4; i0 += NB * PM_GEMV_BLOCK) {
-        float4 f[NB], g[NB];
+        if (!one_group) {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {               // (x is L1/L2 resident by now when it was read for the norm)
-            const int i = i0 + k * PM_GEMV_BLOCK;
-            f[k] = ((const float4 *) p.xf)[i < n4 ? i : 0];
-            if (p.xmode == 2) g[k] = ((const float4 *) p.norm_w)[i < n4 ? i : 0];
+            for (int k = 0; k < NB; ++k) {
+                const int i = i0 + k * PM_GEMV_BLOCK;
+                f[k] = ((const float4 *) p.xf)[i < n4 ? i : 0];
+                if (p.xmode == 2) g[k] = ((const float4 *) p.norm_w)[i < n4 ? i : 0];
+            }
         }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
