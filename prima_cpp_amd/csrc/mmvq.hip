@@ -475,7 +475,10 @@ __global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(GemvP p) {
     const int ni_0 = (r1_0 - r0_0 + R - 1) / R, ni_1 = (r1_1 - r0_1 + R - 1) / R, ni_2 = (r1_2 - r0_2 + R - 1) / R;
     const int ob_1 = r1_0 - r0_0, ob_2 = ob_1 + (r1_1 - r0_1);
 
-    // (1) activation row -> LDS (quantized, bit-exact with the reference quantizers)
+    // (1) activation row -> LDS (quantized, bit-exact with the reference quantizers).
+    //     [Measured and rejected: pre-issuing the first item's 16-byte weight loads across the prologue (spills under the
+    //      128-VGPR budget, -20 %), and an L2 prefetch of that item with one dword per 128-B line (-7 % even when limited to
+    //      the small wq/wo launches: the in-order VMEM return delays the prologue and the lines are fetched twice).]
     stage_activation<ABLK>(p, xs_q, xs_gs, xs_d, nred);
     __syncthreads();
     const XLds xs = {xs_q, xs_gs, xs_d};
