@@ -46,6 +46,15 @@ PM355_API int    pm355_set_device(int device);
 PM355_API int    pm355_device_info(int device, char * name, size_t name_len, size_t * free_bytes, size_t * total_bytes,
                                    int * compute_units);
 PM355_API int    pm355_sync(pm355_stream_t stream);
+/* streams / events for the plug-in's ggml_backend_i (a ggml backend IS a stream) and ggml_backend_event */
+typedef void * pm355_event_t;            /* hipEvent_t */
+PM355_API pm355_stream_t pm355_stream_create(void);
+PM355_API void   pm355_stream_destroy(pm355_stream_t stream);
+PM355_API pm355_event_t  pm355_event_create(void);
+PM355_API void   pm355_event_destroy(pm355_event_t ev);
+PM355_API int    pm355_event_record(pm355_event_t ev, pm355_stream_t stream);
+PM355_API int    pm355_event_wait(pm355_stream_t stream, pm355_event_t ev);      /* stream waits for ev */
+PM355_API int    pm355_event_sync(pm355_event_t ev);                              /* host waits for ev */
 PM355_API const char * pm355_last_error(void);
 
 /* device memory helpers (hipMalloc / hipFree / hipMemcpy[Async]); used by the plug-in's buffer vtable
@@ -151,6 +160,28 @@ PM355_API int pm355_scale(const float * a, float * y, float s, int64_t n, pm355_
 /* synthetic weights generated directly in HBM (bench): random VALID blocks of `type`, |w| ~ scale */
 PM355_API int pm355_fill_random_blocks(int type, void * dst, int64_t K, int64_t nrows, uint64_t seed, float scale,
                                        pm355_stream_t stream);
+
+/* ---- (A') stride-aware node-equivalent ops (prima_cpp_amd/csrc/ggml_ops.hip) ------------------------------------------
+ * What the plug-in falls back to for a graph node that is not covered by a fused fast path: arbitrary views / permutes /
+ * broadcasts exactly as ggml describes them (ne[] elements, nb[] BYTE strides, struct ggml_tensor ggml/include/ggml.h:576). */
+typedef struct { void * data; int32_t type; int32_t pad_; int64_t ne[4]; size_t nb[4]; } pm355_tensor;
+
+/* ggml_compute_forward_dup (ggml.c:8238/:8509): F32/F16 -> F32/F16, same element count, any strides */
+PM355_API int pm355_op_cpy(const pm355_tensor * src, const pm355_tensor * dst, pm355_stream_t stream);
+/* op 0 = add (ggml.c:9002), 1 = mul (ggml.c:10077); b is broadcast over a */
+PM355_API int pm355_op_binary(int op, const pm355_tensor * a, const pm355_tensor * b, const pm355_tensor * dst, pm355_stream_t stream);
+/* op 0 = scale by param (ggml.c:11262), 1 = silu (ggml.c:11581) */
+PM355_API int pm355_op_unary(int op, const pm355_tensor * a, const pm355_tensor * dst, float param, pm355_stream_t stream);
+PM355_API int pm355_op_rms_norm(const pm355_tensor * a, const pm355_tensor * dst, float eps, pm355_stream_t stream);
+/* ggml_compute_forward_soft_max_f32 (ggml.c:13783): mask F32/F16 [ne0, >= ne1] or NULL */
+PM355_API int pm355_op_soft_max(const pm355_tensor * a, const pm355_tensor * mask, const pm355_tensor * dst, float scale,
+                                float max_bias, pm355_stream_t stream);
+PM355_API int pm355_op_rope(const pm355_tensor * a, const int32_t * d_pos, const float * freq_factors, const pm355_tensor * dst,
+                            const pm355_rope_params * rp, pm355_stream_t stream);
+/* MUL_MAT with F16 / F32 src0 (the K.q and V.p products of llm_build_kqv): src1 F32 rounded to F16 when src0 is F16 */
+PM355_API int pm355_op_mul_mat_f(const pm355_tensor * a, const pm355_tensor * b, const pm355_tensor * dst, pm355_stream_t stream);
+PM355_API int pm355_op_get_rows_f32(const pm355_tensor * a, const int32_t * d_idx, int64_t n_idx, const pm355_tensor * dst,
+                                    pm355_stream_t stream);
 
 /* ---- (B) engine: resident decoder for one layer window --------------------------------------------- */
 typedef struct pm355_model pm355_model;

@@ -37,6 +37,14 @@ int pm355_device_info(int d, char * name, size_t name_len, size_t * free_b, size
 }
 int pm355_sync(pm355_stream_t s) { HIP_TRY(s ? hipStreamSynchronize(S(s)) : hipDeviceSynchronize()); return 0; }
 
+pm355_stream_t pm355_stream_create(void) { hipStream_t s = nullptr; return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? (pm355_stream_t) s : nullptr; }
+void pm355_stream_destroy(pm355_stream_t s) { if (s) (void) hipStreamDestroy(S(s)); }
+pm355_event_t pm355_event_create(void) { hipEvent_t e = nullptr; return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? (pm355_event_t) e : nullptr; }
+void pm355_event_destroy(pm355_event_t e) { if (e) (void) hipEventDestroy((hipEvent_t) e); }
+int pm355_event_record(pm355_event_t e, pm355_stream_t s) { HIP_TRY(hipEventRecord((hipEvent_t) e, S(s))); return 0; }
+int pm355_event_wait(pm355_stream_t s, pm355_event_t e) { HIP_TRY(hipStreamWaitEvent(S(s), (hipEvent_t) e, 0)); return 0; }
+int pm355_event_sync(pm355_event_t e) { HIP_TRY(hipEventSynchronize((hipEvent_t) e)); return 0; }
+
 void * pm355_malloc(size_t n) { void * p = nullptr; return hipMalloc(&p, n) == hipSuccess ? p : nullptr; }
 void   pm355_free(void * p) { if (p) (void) hipFree(p); }
 void * pm355_host_malloc(size_t n) { void * p = nullptr; return hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess ? p : nullptr; }

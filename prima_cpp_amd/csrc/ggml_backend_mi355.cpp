@@ -1,0 +1,510 @@
+// ggml_backend_mi355.cpp — the ggml-backend plug-in (libggml-mi355.so): registry / device / buffer-type / buffer /
+// backend(stream) vtables of the reference's plug-in interface (ggml/src/ggml-backend-impl.h:15-216), implemented on
+// the C ABI of libprima_mi355.so. Plain host C++: no HIP in this file. Compiled against the HOST PROJECT's ggml headers
+// (prima_cpp_amd/build_plugin.py passes -I<reference>/ggml/include -I<reference>/ggml/src), never copied.
+//
+// Who calls what (reference call sites): ggml_backend_sched_* (ggml-backend.cpp:1440-2188), ggml_gallocr (alloc sizes),
+// llama.cpp directly (tensor_set/get, buffer_clear, dev_memory ...) and tests/test-backend-ops.cpp (:3801-3852).
+#include "ggml.h"
+#include "ggml-backend.h"
+#include "ggml-backend-impl.h"
+#define GGML_BACKEND_MI355_HAVE_GGML
+#include "../../include/ggml_backend_mi355.h"
+#include "../../include/prima_mi355.h"
+
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+
+#define MI355_CHECK(expr) do { int rc_ = (expr); if (rc_ != 0) { fprintf(stderr, "ggml-mi355: %s failed (rc=%d): %s\n", #expr, rc_, pm355_last_error()); GGML_ABORT("ggml-mi355 error"); } } while (0)
+
+namespace {
+
+bool is_soa_type(enum ggml_type t) { return t == GGML_TYPE_Q6_K || t == GGML_TYPE_Q8_0; }
+bool is_gemv_type(enum ggml_type t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K || t == GGML_TYPE_Q8_0; }
+
+struct dev_ctx { int device; std::string name, desc; };
+struct buft_ctx { int device; std::string name; };
+struct buf_ctx { int device; void * base; size_t size; std::string name; };
+struct backend_ctx {
+    int device; std::string name; pm355_stream_t stream;
+    void * scratch = nullptr; size_t scratch_bytes = 0;
+    int32_t * d_i32 = nullptr;                       // small device scratch (positions)
+};
+
+pm355_tensor to_pm(const struct ggml_tensor * t) {
+    pm355_tensor d;
+    d.data = t->data; d.type = (int32_t) t->type; d.pad_ = 0;
+    for (int i = 0; i < 4; ++i) { d.ne[i] = t->ne[i]; d.nb[i] = t->nb[i]; }
+    return d;
+}
+
+// ------------------------------------------------------------------------------------------------ buffer
+const char * buf_get_name(ggml_backend_buffer_t b) { return ((buf_ctx *) b->context)->name.c_str(); }
+bool buffer_is_mi355(ggml_backend_buffer_t b) { return b && b->iface.get_name == buf_get_name; }
+
+void buf_free(ggml_backend_buffer_t b) {
+    buf_ctx * c = (buf_ctx *) b->context;
+    pm355_set_device(c->device);
+    pm355_free(c->base);
+    delete c;
+}
+void * buf_get_base(ggml_backend_buffer_t b) { return ((buf_ctx *) b->context)->base; }
+void buf_init_tensor(ggml_backend_buffer_t, struct ggml_tensor *) {}
+
+void buf_memset_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, uint8_t v, size_t off, size_t size) {
+    pm355_set_device(((buf_ctx *) b->context)->device);
+    MI355_CHECK(pm355_memset((char *) t->data + off, v, size, nullptr));
+    MI355_CHECK(pm355_sync(nullptr));
+}
+
+// host GGUF-order bytes -> HBM layout (row-local repack for the row-SoA types; see repack.hip)
+void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void * data, size_t off, size_t size) {
+    pm355_set_device(((buf_ctx *) b->context)->device);
+    if (is_soa_type(t->type)) {
+        const size_t rb = ggml_row_size(t->type, t->ne[0]), stride = pm355_row_stride(t->type, t->ne[0]);
+        GGML_ASSERT(off % rb == 0 && size % rb == 0 && "row-granular access to a row-SoA tensor");
+        void * stage = pm355_malloc(size);
+        GGML_ASSERT(stage);
+        MI355_CHECK(pm355_memcpy_h2d(stage, data, size, nullptr));
+        MI355_CHECK(pm355_repack_rows(t->type, stage, (char *) t->data + (off / rb) * stride, t->ne[0], (int64_t) (size / rb), 1, nullptr));
+        MI355_CHECK(pm355_sync(nullptr));
+        pm355_free(stage);
+        return;
+    }
+    MI355_CHECK(pm355_memcpy_h2d((char *) t->data + off, data, size, nullptr));
+    MI355_CHECK(pm355_sync(nullptr));
+}
+void buf_get_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * t, void * data, size_t off, size_t size) {
+    pm355_set_device(((buf_ctx *) b->context)->device);
+    if (is_soa_type(t->type)) {
+        const size_t rb = ggml_row_size(t->type, t->ne[0]), stride = pm355_row_stride(t->type, t->ne[0]);
+        GGML_ASSERT(off % rb == 0 && size % rb == 0 && "row-granular access to a row-SoA tensor");
+        void * stage = pm355_malloc(size);
+        GGML_ASSERT(stage);
+        MI355_CHECK(pm355_repack_rows(t->type, (const char *) t->data + (off / rb) * stride, stage, t->ne[0], (int64_t) (size / rb), 0, nullptr));
+        MI355_CHECK(pm355_memcpy_d2h(data, stage, size, nullptr));
+        MI355_CHECK(pm355_sync(nullptr));
+        pm355_free(stage);
+        return;
+    }
+    MI355_CHECK(pm355_memcpy_d2h(data, (const char *) t->data + off, size, nullptr));
+    MI355_CHECK(pm355_sync(nullptr));
+}
+size_t hbm_bytes(const struct ggml_tensor * t) {
+    if (is_soa_type(t->type)) return pm355_row_stride(t->type, t->ne[0]) * (size_t) (t->ne[1] * t->ne[2] * t->ne[3]);
+    return ggml_nbytes(t);
+}
+bool buf_cpy_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    if (!buffer_is_mi355(src->buffer)) return false;                 // ggml falls back to get + set through the host
+    buf_ctx * sc = (buf_ctx *) src->buffer->context, * dc = (buf_ctx *) b->context;
+    if (sc->device != dc->device || src->type != dst->type || !ggml_is_contiguous(src) || !ggml_is_contiguous(dst)) return false;
+    pm355_set_device(dc->device);
+    MI355_CHECK(pm355_memcpy_d2d(dst->data, src->data, hbm_bytes(src), nullptr));
+    MI355_CHECK(pm355_sync(nullptr));
+    return true;
+}
+void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
+    buf_ctx * c = (buf_ctx *) b->context;
+    pm355_set_device(c->device);
+    MI355_CHECK(pm355_memset(c->base, v, c->size, nullptr));
+    MI355_CHECK(pm355_sync(nullptr));
+}
+const struct ggml_backend_buffer_i buffer_iface = {
+    /* .get_name      = */ buf_get_name,
+    /* .free_buffer   = */ buf_free,
+    /* .get_base      = */ buf_get_base,
+    /* .init_tensor   = */ buf_init_tensor,
+    /* .memset_tensor = */ buf_memset_tensor,
+    /* .set_tensor    = */ buf_set_tensor,
+    /* .get_tensor    = */ buf_get_tensor,
+    /* .cpy_tensor    = */ buf_cpy_tensor,
+    /* .clear         = */ buf_clear,
+    /* .reset         = */ nullptr,
+};
+
+// ------------------------------------------------------------------------------------------------ buffer type
+const char * buft_get_name(ggml_backend_buffer_type_t t) { return ((buft_ctx *) t->context)->name.c_str(); }
+bool buft_is_mi355(ggml_backend_buffer_type_t t) { return t && t->iface.get_name == buft_get_name; }
+
+ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t t, size_t size) {
+    buft_ctx * c = (buft_ctx *) t->context;
+    pm355_set_device(c->device);
+    size = size ? size : 1;
+    void * p = pm355_malloc(size + 256);              // tail slack for 16-byte vector reads
+    if (!p) { fprintf(stderr, "ggml-mi355: allocating %.2f MiB on device %d failed\n", size / 1048576.0, c->device); return nullptr; }
+    return ggml_backend_buffer_init(t, buffer_iface, new buf_ctx{c->device, p, size, c->name}, size);
+}
+size_t buft_alignment(ggml_backend_buffer_type_t) { return 128; }
+size_t buft_alloc_size(ggml_backend_buffer_type_t, const struct ggml_tensor * t) { return hbm_bytes(t); }
+bool buft_is_host(ggml_backend_buffer_type_t) { return false; }
+
+const struct ggml_backend_buffer_type_i buft_iface = {
+    /* .get_name       = */ buft_get_name,
+    /* .alloc_buffer   = */ buft_alloc,
+    /* .get_alignment  = */ buft_alignment,
+    /* .get_max_size   = */ nullptr,
+    /* .get_alloc_size = */ buft_alloc_size,
+    /* .is_host        = */ buft_is_host,
+};
+
+// pinned host buffers: a CPU buffer over hipHostMalloc memory (the scheduler puts CPU-side compute buffers here)
+const char * host_buft_name(ggml_backend_buffer_type_t) { return GGML_MI355_NAME "_Host"; }
+void host_buf_free(ggml_backend_buffer_t b) { pm355_host_free(b->context); }
+ggml_backend_buffer_t host_buft_alloc(ggml_backend_buffer_type_t t, size_t size) {
+    void * p = pm355_host_malloc(size ? size : 1);
+    if (!p) return ggml_backend_buft_alloc_buffer(ggml_backend_cpu_buffer_type(), size);
+    ggml_backend_buffer_t b = ggml_backend_cpu_buffer_from_ptr(p, size);
+    b->buft = t;
+    b->iface.free_buffer = host_buf_free;
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------------ backend (stream)
+const char * backend_name(ggml_backend_t b) { return ((backend_ctx *) b->context)->name.c_str(); }
+void backend_free(ggml_backend_t b) {
+    backend_ctx * c = (backend_ctx *) b->context;
+    pm355_set_device(c->device);
+    pm355_sync(c->stream);
+    pm355_free(c->scratch); pm355_free(c->d_i32);
+    pm355_stream_destroy(c->stream);
+    delete c; delete b;
+}
+void backend_set_async(ggml_backend_t b, struct ggml_tensor * t, const void * data, size_t off, size_t size) {
+    backend_ctx * c = (backend_ctx *) b->context;
+    if (is_soa_type(t->type)) { buf_set_tensor(t->view_src ? t->view_src->buffer : t->buffer, t, data, off, size); return; }
+    pm355_set_device(c->device);
+    MI355_CHECK(pm355_memcpy_h2d((char *) t->data + off, data, size, c->stream));
+}
+void backend_get_async(ggml_backend_t b, const struct ggml_tensor * t, void * data, size_t off, size_t size) {
+    backend_ctx * c = (backend_ctx *) b->context;
+    pm355_set_device(c->device);
+    if (is_soa_type(t->type)) { pm355_sync(c->stream); buf_get_tensor(t->view_src ? t->view_src->buffer : t->buffer, t, data, off, size); return; }
+    MI355_CHECK(pm355_memcpy_d2h(data, (const char *) t->data + off, size, c->stream));
+}
+void backend_sync(ggml_backend_t b) {
+    backend_ctx * c = (backend_ctx *) b->context;
+    pm355_set_device(c->device);
+    MI355_CHECK(pm355_sync(c->stream));
+}
+
+void * scratch(backend_ctx * c, size_t bytes) {
+    if (bytes > c->scratch_bytes) {
+        pm355_sync(c->stream);
+        pm355_free(c->scratch);
+        c->scratch = pm355_malloc(bytes + 256);
+        GGML_ASSERT(c->scratch);
+        c->scratch_bytes = bytes;
+    }
+    return c->scratch;
+}
+
+bool mul_mat_quant_ok(const struct ggml_tensor * op) {
+    const struct ggml_tensor * a = op->src[0], * b = op->src[1];
+    if (!is_gemv_type(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
+    if (!ggml_is_contiguous(a) || !ggml_is_contiguous(b) || !ggml_is_contiguous(op)) return false;
+    if (a->ne[2] != 1 || a->ne[3] != 1 || b->ne[2] != 1 || b->ne[3] != 1) return false;
+    if (a->view_src && is_soa_type(a->type)) return false;           // row-SoA layout is per allocated tensor
+    if (a->ne[0] % (a->type == GGML_TYPE_Q8_0 ? 32 : 256)) return false;
+    return a->ne[0] <= 131072;
+}
+
+bool supports_op_impl(const struct ggml_tensor * op) {
+    const struct ggml_tensor * a = op->src[0], * b = op->src[1];
+    switch (op->op) {
+        case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
+            return true;
+        case GGML_OP_MUL_MAT:
+            if (mul_mat_quant_ok(op)) return true;
+            return (a->type == GGML_TYPE_F16 || a->type == GGML_TYPE_F32) && b->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 &&
+                   a->nb[0] == ggml_type_size(a->type) && b->nb[0] == 4;
+        case GGML_OP_RMS_NORM:
+            return a->type == GGML_TYPE_F32 && a->nb[0] == 4 && op->nb[0] == 4;
+        case GGML_OP_ADD: case GGML_OP_MUL:
+            return a->type == GGML_TYPE_F32 && b->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32;
+        case GGML_OP_SCALE:
+            return a->type == GGML_TYPE_F32;
+        case GGML_OP_UNARY:
+            return ggml_get_unary_op(op) == GGML_UNARY_OP_SILU && a->type == GGML_TYPE_F32;
+        case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
+            const enum ggml_type ts = a->type, td = op->type;
+            return (ts == GGML_TYPE_F32 || ts == GGML_TYPE_F16) && (td == GGML_TYPE_F32 || td == GGML_TYPE_F16);
+        }
+        case GGML_OP_SOFT_MAX:
+            return a->type == GGML_TYPE_F32 && a->nb[0] == 4 && ggml_is_contiguous(a) && a->ne[0] * 4 <= 150 * 1024 &&
+                   (!b || b->type == GGML_TYPE_F32 || b->type == GGML_TYPE_F16);
+        case GGML_OP_ROPE: {
+            const int mode = ((const int32_t *) op->op_params)[2];
+            return a->type == GGML_TYPE_F32 && (mode == 0 || mode == 2) && a->ne[0] % 2 == 0;
+        }
+        case GGML_OP_GET_ROWS:
+            return b->type == GGML_TYPE_I32 && ggml_is_contiguous(b) && b->ne[1] == 1 && b->ne[2] == 1 && b->ne[3] == 1 &&
+                   (a->type == GGML_TYPE_F32 || (is_gemv_type(a->type) && ggml_is_contiguous(a) && a->ne[2] == 1 && a->ne[3] == 1 && !a->view_src));
+        default:
+            return false;
+    }
+}
+
+bool compute_node(backend_ctx * c, struct ggml_tensor * op) {
+    const struct ggml_tensor * a = op->src[0], * b = op->src[1];
+    pm355_stream_t st = c->stream;
+    switch (op->op) {
+        case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
+            return true;
+        case GGML_OP_MUL_MAT: {
+            if (mul_mat_quant_ok(op)) {
+                // one fused launch per activation column: f32 -> vec_dot_type in the kernel prologue, then the mat-vec
+                const int64_t K = a->ne[0], N = a->ne[1], ncols = b->ne[1];
+                for (int64_t col = 0; col < ncols; ++col) {
+                    pm355_matvec_job job = {};
+                    job.type = (int32_t) a->type; job.N = N; job.W = a->data; job.y = (float *) op->data + col * N;
+                    MI355_CHECK(pm355_mul_mat_vec_fused(&job, 1, K, (const float *) b->data + col * K, nullptr, 0.0f, st));
+                }
+                return true;
+            }
+            pm355_tensor ta = to_pm(a), tb = to_pm(b), td = to_pm(op);
+            MI355_CHECK(pm355_op_mul_mat_f(&ta, &tb, &td, st));
+            return true;
+        }
+        case GGML_OP_RMS_NORM: {
+            float eps; memcpy(&eps, op->op_params, sizeof(float));
+            pm355_tensor ta = to_pm(a), td = to_pm(op);
+            MI355_CHECK(pm355_op_rms_norm(&ta, &td, eps, st));
+            return true;
+        }
+        case GGML_OP_ADD: case GGML_OP_MUL: {
+            pm355_tensor ta = to_pm(a), tb = to_pm(b), td = to_pm(op);
+            MI355_CHECK(pm355_op_binary(op->op == GGML_OP_ADD ? 0 : 1, &ta, &tb, &td, st));
+            return true;
+        }
+        case GGML_OP_SCALE: {
+            float s; memcpy(&s, op->op_params, sizeof(float));
+            pm355_tensor ta = to_pm(a), td = to_pm(op);
+            MI355_CHECK(pm355_op_unary(0, &ta, &td, s, st));
+            return true;
+        }
+        case GGML_OP_UNARY: {
+            pm355_tensor ta = to_pm(a), td = to_pm(op);
+            MI355_CHECK(pm355_op_unary(1, &ta, &td, 0.0f, st));
+            return true;
+        }
+        case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
+            // CPY writes into src[1]'s storage (dst is a view of it); DUP/CONT into dst
+            pm355_tensor ta = to_pm(a), td = to_pm(op);
+            MI355_CHECK(pm355_op_cpy(&ta, &td, st));
+            return true;
+        }
+        case GGML_OP_SOFT_MAX: {
+            float scale, max_bias;
+            memcpy(&scale, (const float *) op->op_params + 0, sizeof(float));
+            memcpy(&max_bias, (const float *) op->op_params + 1, sizeof(float));
+            pm355_tensor ta = to_pm(a), td = to_pm(op), tm;
+            if (b) tm = to_pm(b);
+            MI355_CHECK(pm355_op_soft_max(&ta, b ? &tm : nullptr, &td, scale, max_bias, st));
+            return true;
+        }
+        case GGML_OP_ROPE: {
+            const int32_t * prm = (const int32_t *) op->op_params;
+            pm355_rope_params rp;
+            rp.n_dims = prm[1]; rp.mode = prm[2]; rp.n_ctx_orig = prm[4];
+            memcpy(&rp.freq_base, prm + 5, 4); memcpy(&rp.freq_scale, prm + 6, 4); memcpy(&rp.ext_factor, prm + 7, 4);
+            memcpy(&rp.attn_factor, prm + 8, 4); memcpy(&rp.beta_fast, prm + 9, 4); memcpy(&rp.beta_slow, prm + 10, 4);
+            pm355_tensor ta = to_pm(a), td = to_pm(op);
+            const struct ggml_tensor * ff = op->src[2];
+            MI355_CHECK(pm355_op_rope(&ta, (const int32_t *) b->data, ff ? (const float *) ff->data : nullptr, &td, &rp, st));
+            return true;
+        }
+        case GGML_OP_GET_ROWS: {
+            if (a->type == GGML_TYPE_F32) {
+                pm355_tensor ta = to_pm(a), td = to_pm(op);
+                MI355_CHECK(pm355_op_get_rows_f32(&ta, (const int32_t *) b->data, b->ne[0], &td, st));
+            } else {
+                MI355_CHECK(pm355_get_rows((int) a->type, a->data, a->ne[0], (const int32_t *) b->data, (int) b->ne[0], (float *) op->data, st));
+            }
+            return true;
+        }
+        default:
+            return false;
+    }
+}
+
+enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g) {
+    backend_ctx * c = (backend_ctx *) b->context;
+    pm355_set_device(c->device);
+    const int n_nodes = ggml_graph_n_nodes(g);        // public accessors: struct ggml_cgraph is private to ggml (ggml-impl.h:183)
+    for (int i = 0; i < n_nodes; ++i) {
+        struct ggml_tensor * node = ggml_graph_node(g, i);
+        if (ggml_is_empty(node)) continue;
+        if (!compute_node(c, node)) {
+            fprintf(stderr, "ggml-mi355: op %s not supported (supports_op should have rejected it)\n", ggml_op_name(node->op));
+            return GGML_STATUS_FAILED;
+        }
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+bool backend_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    if (!ggml_backend_is_mi355(bs) || !ggml_backend_is_mi355(bd)) return false;
+    if (!buffer_is_mi355(src->view_src ? src->view_src->buffer : src->buffer) || !buffer_is_mi355(dst->view_src ? dst->view_src->buffer : dst->buffer)) return false;
+    backend_ctx * cs = (backend_ctx *) bs->context, * cd = (backend_ctx *) bd->context;
+    if (cs->device != cd->device || src->type != dst->type || !ggml_is_contiguous(src) || !ggml_is_contiguous(dst)) return false;
+    pm355_set_device(cd->device);
+    if (cs != cd) pm355_sync(cs->stream);
+    MI355_CHECK(pm355_memcpy_d2d(dst->data, src->data, hbm_bytes(src), cd->stream));
+    return true;
+}
+void backend_event_record(ggml_backend_t b, ggml_backend_event_t e) { MI355_CHECK(pm355_event_record((pm355_event_t) e->context, ((backend_ctx *) b->context)->stream)); }
+void backend_event_wait(ggml_backend_t b, ggml_backend_event_t e) { MI355_CHECK(pm355_event_wait(((backend_ctx *) b->context)->stream, (pm355_event_t) e->context)); }
+
+const struct ggml_backend_i backend_iface = {
+    /* .get_name                = */ backend_name,
+    /* .free                    = */ backend_free,
+    /* .get_default_buffer_type = */ [](ggml_backend_t b) { return ggml_backend_mi355_buffer_type(((backend_ctx *) b->context)->device); },
+    /* .set_tensor_async        = */ backend_set_async,
+    /* .get_tensor_async        = */ backend_get_async,
+    /* .cpy_tensor_async        = */ backend_cpy_async,
+    /* .synchronize             = */ backend_sync,
+    /* .graph_plan_create       = */ nullptr,
+    /* .graph_plan_free         = */ nullptr,
+    /* .graph_plan_update       = */ nullptr,
+    /* .graph_plan_compute      = */ nullptr,
+    /* .graph_compute           = */ backend_graph_compute,
+    /* .supports_op             = */ nullptr,
+    /* .supports_buft           = */ nullptr,
+    /* .offload_op              = */ nullptr,
+    /* .event_record            = */ backend_event_record,
+    /* .event_wait              = */ backend_event_wait,
+};
+
+ggml_guid_t backend_guid() {
+    static ggml_guid guid = {0x6d, 0x69, 0x33, 0x35, 0x35, 0x78, 0x2d, 0x67, 0x67, 0x6d, 0x6c, 0x2d, 0x70, 0x6d, 0x33, 0x35};
+    return &guid;
+}
+
+// ------------------------------------------------------------------------------------------------ device
+const char * dev_name(ggml_backend_dev_t d) { return ((dev_ctx *) d->context)->name.c_str(); }
+const char * dev_desc(ggml_backend_dev_t d) { return ((dev_ctx *) d->context)->desc.c_str(); }
+void dev_memory(ggml_backend_dev_t d, size_t * f, size_t * t) { ggml_backend_mi355_get_device_memory(((dev_ctx *) d->context)->device, f, t); }
+enum ggml_backend_dev_type dev_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU_FULL; }
+void dev_props(ggml_backend_dev_t d, struct ggml_backend_dev_props * p) {
+    p->name = dev_name(d); p->description = dev_desc(d); p->type = dev_type(d);
+    dev_memory(d, &p->memory_free, &p->memory_total);
+    p->caps = {/* async */ true, /* host_buffer */ true, /* buffer_from_host_ptr */ false, /* events */ true};
+}
+ggml_backend_t dev_init(ggml_backend_dev_t d, const char *) { return ggml_backend_mi355_init(((dev_ctx *) d->context)->device); }
+ggml_backend_buffer_type_t dev_buft(ggml_backend_dev_t d) { return ggml_backend_mi355_buffer_type(((dev_ctx *) d->context)->device); }
+ggml_backend_buffer_type_t dev_host_buft(ggml_backend_dev_t) { return ggml_backend_mi355_host_buffer_type(); }
+bool dev_supports_op(ggml_backend_dev_t, const struct ggml_tensor * op) { return supports_op_impl(op); }
+bool dev_supports_buft(ggml_backend_dev_t d, ggml_backend_buffer_type_t t) {
+    return buft_is_mi355(t) && ((buft_ctx *) t->context)->device == ((dev_ctx *) d->context)->device;
+}
+bool dev_offload_op(ggml_backend_dev_t, const struct ggml_tensor * op) {
+    // weights left in host memory: worth shipping to the GPU only for batched work (cf. ggml-cuda.cu:3201-3208)
+    return op->op != GGML_OP_GET_ROWS && op->ne[1] >= 32;
+}
+ggml_backend_event_t dev_event_new(ggml_backend_dev_t d) {
+    pm355_set_device(((dev_ctx *) d->context)->device);
+    pm355_event_t e = pm355_event_create();
+    if (!e) return nullptr;
+    return new ggml_backend_event{d, e};
+}
+void dev_event_free(ggml_backend_dev_t, ggml_backend_event_t e) { pm355_event_destroy((pm355_event_t) e->context); delete e; }
+void dev_event_sync(ggml_backend_dev_t, ggml_backend_event_t e) { MI355_CHECK(pm355_event_sync((pm355_event_t) e->context)); }
+
+const struct ggml_backend_device_i device_iface = {
+    /* .get_name             = */ dev_name,
+    /* .get_description      = */ dev_desc,
+    /* .get_memory           = */ dev_memory,
+    /* .get_type             = */ dev_type,
+    /* .get_props            = */ dev_props,
+    /* .init_backend         = */ dev_init,
+    /* .get_buffer_type      = */ dev_buft,
+    /* .get_host_buffer_type = */ dev_host_buft,
+    /* .buffer_from_host_ptr = */ nullptr,
+    /* .supports_op          = */ dev_supports_op,
+    /* .supports_buft        = */ dev_supports_buft,
+    /* .offload_op           = */ dev_offload_op,
+    /* .event_new            = */ dev_event_new,
+    /* .event_free           = */ dev_event_free,
+    /* .event_synchronize    = */ dev_event_sync,
+};
+
+// ------------------------------------------------------------------------------------------------ registry
+struct reg_ctx { std::vector<ggml_backend_dev_t> devices; };
+const char * reg_name(ggml_backend_reg_t) { return GGML_MI355_NAME; }
+size_t reg_dev_count(ggml_backend_reg_t r) { return ((reg_ctx *) r->context)->devices.size(); }
+ggml_backend_dev_t reg_dev_get(ggml_backend_reg_t r, size_t i) { reg_ctx * c = (reg_ctx *) r->context; GGML_ASSERT(i < c->devices.size()); return c->devices[i]; }
+void * reg_proc(ggml_backend_reg_t, const char *) { return nullptr; }    // no split buffers, no n_threads (llama.cpp:3772, :21261)
+const struct ggml_backend_reg_i reg_iface = { reg_name, reg_dev_count, reg_dev_get, reg_proc };
+
+} // namespace
+
+extern "C" {
+
+int ggml_backend_mi355_get_device_count(void) { int n = pm355_device_count(); return n > GGML_MI355_MAX_DEVICES ? GGML_MI355_MAX_DEVICES : n; }
+
+void ggml_backend_mi355_get_device_memory(int device, size_t * free, size_t * total) {
+    size_t f = 0, t = 0;
+    pm355_device_info(device, nullptr, 0, &f, &t, nullptr);
+    if (free) *free = f;
+    if (total) *total = t;
+}
+
+ggml_backend_buffer_type_t ggml_backend_mi355_buffer_type(int device) {
+    static std::mutex mu;
+    static struct ggml_backend_buffer_type types[GGML_MI355_MAX_DEVICES];
+    static bool init = false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0 || device >= ggml_backend_mi355_get_device_count()) return nullptr;
+    if (!init) {
+        ggml_backend_reg_t reg = ggml_backend_mi355_reg();
+        for (int i = 0; i < ggml_backend_mi355_get_device_count(); ++i)
+            types[i] = { buft_iface, ggml_backend_reg_dev_get(reg, i), new buft_ctx{i, std::string(GGML_MI355_NAME "X") + std::to_string(i)} };
+        init = true;
+    }
+    return &types[device];                           // stable singleton per device: used as a map key by llama.cpp
+}
+
+ggml_backend_buffer_type_t ggml_backend_mi355_host_buffer_type(void) {
+    static struct ggml_backend_buffer_type t = {
+        { host_buft_name, host_buft_alloc, ggml_backend_cpu_buffer_type()->iface.get_alignment, nullptr,
+          ggml_backend_cpu_buffer_type()->iface.get_alloc_size, ggml_backend_cpu_buffer_type()->iface.is_host },
+        nullptr, nullptr };
+    if (!t.device && ggml_backend_mi355_get_device_count() > 0) t.device = ggml_backend_reg_dev_get(ggml_backend_mi355_reg(), 0);
+    return &t;
+}
+
+ggml_backend_t ggml_backend_mi355_init(int device) {
+    if (device < 0 || device >= ggml_backend_mi355_get_device_count()) { fprintf(stderr, "ggml-mi355: invalid device %d\n", device); return nullptr; }
+    if (pm355_set_device(device)) return nullptr;
+    backend_ctx * c = new backend_ctx{device, std::string(GGML_MI355_NAME "X") + std::to_string(device), pm355_stream_create()};
+    if (!c->stream) { delete c; return nullptr; }
+    return new ggml_backend{ backend_guid(), backend_iface, ggml_backend_reg_dev_get(ggml_backend_mi355_reg(), device), c };
+}
+
+int ggml_backend_is_mi355(ggml_backend_t b) { return b != nullptr && ggml_guid_matches(b->guid, backend_guid()); }
+
+ggml_backend_reg_t ggml_backend_mi355_reg(void) {
+    static struct ggml_backend_reg reg;
+    static bool init = false;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!init) {
+        reg_ctx * rc = new reg_ctx;
+        reg = { reg_iface, rc };
+        const int n = ggml_backend_mi355_get_device_count();
+        for (int i = 0; i < n; ++i) {
+            char nm[256] = "";
+            pm355_device_info(i, nm, sizeof(nm), nullptr, nullptr, nullptr);
+            dev_ctx * dc = new dev_ctx{i, std::string(GGML_MI355_NAME "X") + std::to_string(i), nm};
+            rc->devices.push_back(new ggml_backend_device{ device_iface, &reg, dc });
+        }
+        init = true;
+    }
+    return &reg;
+}
+
+} // extern "C"

@@ -1,0 +1,268 @@
+// ggml_ops.hip — node-equivalent, stride-aware versions of the ggml ops on the hot path, used by the ggml-backend
+// plug-in when a graph node does not match one of the fused fast paths (arbitrary views / permutes / broadcasts as
+// ggml_backend_sched hands them over). Semantics follow the reference CPU ops (paths relative to the reference repo):
+//   cpy / cont      ggml_compute_forward_dup_f32 / _f16            ggml/src/ggml.c:8509, :8238 (F32<->F16 RNE conversion)
+//   add / mul       ggml_compute_forward_add_f32 / mul_f32          ggml.c:9002, :10077   (src1 broadcast over src0)
+//   scale, silu     ggml_compute_forward_scale_f32 :11262, silu_f32 :11581
+//   rms_norm        ggml_compute_forward_rms_norm_f32               ggml.c:11950
+//   soft_max_ext    ggml_compute_forward_soft_max_f32               ggml.c:13783  (mask F32/F16, scale, ALiBi slopes)
+//   rope            ggml_compute_forward_rope_f32                   ggml.c:14143  (NORM / NEOX, freq factors, YaRN)
+//   mul_mat F16xF32 ggml_compute_forward_mul_mat with vec_dot_type F16: src1 rounded to F16, f32 accumulate, broadcast r2/r3
+//   get_rows        ggml_compute_forward_get_rows_f32 / _q          ggml.c:13414, :13288
+// None of these is bandwidth-critical at decode (KBs per call); they exist so that every node the scheduler assigns to
+// the backend has an implementation with the reference's rounding points.
+#include "../../include/prima_mi355.h"
+#include "pm355_device.h"
+#include "pm355_kernels.h"
+#include "pm355_layer_ops.h"
+
+struct TD { char * data; long ne[4]; long nb[4]; };       // byte strides
+
+static TD to_td(const pm355_tensor * t) {
+    TD d; d.data = (char *) t->data;
+    for (int i = 0; i < 4; ++i) { d.ne[i] = t->ne[i]; d.nb[i] = (long) t->nb[i]; }
+    return d;
+}
+static long nelem(const pm355_tensor * t) { return t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3]; }
+
+__device__ __forceinline__ float ld_as_f32(const char * p, int type) { return type == PM_F16 ? h2f(*(const uint16_t *) p) : *(const float *) p; }
+__device__ __forceinline__ void st_from_f32(char * p, int type, float v) { if (type == PM_F16) *(uint16_t *) p = f2h(v); else *(float *) p = v; }
+
+// dst element order = dst's own (i0,i1,i2,i3); the source is addressed by the same LOGICAL flat index (ggml_cpy allows a
+// reshape between src and dst as long as the element counts match)
+__global__ void cpy_kernel(TD s, int st, TD d, int dt, long n) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long r = i;
+    const long d0 = r % d.ne[0]; r /= d.ne[0]; const long d1 = r % d.ne[1]; r /= d.ne[1]; const long d2 = r % d.ne[2]; const long d3 = r / d.ne[2];
+    r = i;
+    const long s0 = r % s.ne[0]; r /= s.ne[0]; const long s1 = r % s.ne[1]; r /= s.ne[1]; const long s2 = r % s.ne[2]; const long s3 = r / s.ne[2];
+    const char * sp = s.data + s0 * s.nb[0] + s1 * s.nb[1] + s2 * s.nb[2] + s3 * s.nb[3];
+    char * dp = d.data + d0 * d.nb[0] + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3];
+    if (st == dt) { if (st == PM_F16) *(uint16_t *) dp = *(const uint16_t *) sp; else *(uint32_t *) dp = *(const uint32_t *) sp; }
+    else st_from_f32(dp, dt, ld_as_f32(sp, st));
+}
+
+// op: 0 add, 1 mul ; b broadcast (ne_b[i] divides ne_a[i])
+__global__ void bin_kernel(TD a, TD b, TD d, int op, long n) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long r = i;
+    const long i0 = r % d.ne[0]; r /= d.ne[0]; const long i1 = r % d.ne[1]; r /= d.ne[1]; const long i2 = r % d.ne[2]; const long i3 = r / d.ne[2];
+    const float x = *(const float *) (a.data + i0 * a.nb[0] + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+    const float y = *(const float *) (b.data + (i0 % b.ne[0]) * b.nb[0] + (i1 % b.ne[1]) * b.nb[1] + (i2 % b.ne[2]) * b.nb[2] + (i3 % b.ne[3]) * b.nb[3]);
+    *(float *) (d.data + i0 * d.nb[0] + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]) = op == 0 ? x + y : x * y;
+}
+
+// op: 0 scale by s, 1 silu
+__global__ void unary_kernel(TD a, TD d, int op, float sc, long n) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long r = i;
+    const long i0 = r % d.ne[0]; r /= d.ne[0]; const long i1 = r % d.ne[1]; r /= d.ne[1]; const long i2 = r % d.ne[2]; const long i3 = r / d.ne[2];
+    const float x = *(const float *) (a.data + i0 * a.nb[0] + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+    *(float *) (d.data + i0 * d.nb[0] + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]) = op == 0 ? x * sc : x / (1.0f + expf(-x));
+}
+
+// one 256-thread workgroup per row; rows may be strided (nb[1..3]), elements contiguous
+__global__ __launch_bounds__(256) void rms_norm_rows_kernel(TD a, TD d, float eps) {
+    __shared__ double red[4];
+    const long row = blockIdx.x;
+    long r = row; const long i1 = r % a.ne[1]; r /= a.ne[1]; const long i2 = r % a.ne[2]; const long i3 = r / a.ne[2];
+    const float * x = (const float *) (a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+    float * y = (float *) (d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s = 0.0;
+    for (long i = tid; i < a.ne[0]; i += 256) s += (double) (x[i] * x[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+    const float mean = (float) (tot / a.ne[0]);
+    const float scale = 1.0f / sqrtf(mean + eps);
+    for (long i = tid; i < a.ne[0]; i += 256) y[i] = x[i] * scale;
+}
+
+// soft_max_ext: x [ne0, ne1, ne2, ne3] contiguous rows; mask [ne0, >=ne1] F32 or F16 or null; one workgroup per row
+__global__ __launch_bounds__(256) void soft_max_kernel(TD a, const char * mask, int mask_type, long mask_nb1, TD d,
+                                                       float scale, float max_bias, float m0, float m1, unsigned n_head_log2) {
+    __shared__ float redf[4];
+    __shared__ double redd[4];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float * wp = (float *) smem;
+    const long row = blockIdx.x;
+    long r = row; const long i1 = r % a.ne[1]; r /= a.ne[1]; const long i2 = r % a.ne[2]; const long i3 = r / a.ne[2];
+    const float * x = (const float *) (a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+    float * y = (float *) (d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned h = (unsigned) i2;
+    const float slope = max_bias > 0.0f ? (h < n_head_log2 ? powf(m0, (float) (h + 1)) : powf(m1, (float) (2 * (h - n_head_log2) + 1))) : 1.0f;
+    const long nc = a.ne[0];
+    float mx = -INFINITY;
+    for (long i = tid; i < nc; i += 256) {
+        float v = x[i] * scale;
+        if (mask) v += slope * ld_as_f32(mask + i1 * mask_nb1 + i * (mask_type == PM_F16 ? 2 : 4), mask_type);
+        wp[i] = v;
+        mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) redf[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    double s = 0.0;
+    for (long i = tid; i < nc; i += 256) { const float e = expf(wp[i] - mx); wp[i] = e; s += (double) e; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) redd[wave] = s;
+    __syncthreads();
+    const float inv = (float) (1.0 / ((redd[0] + redd[1]) + (redd[2] + redd[3])));
+    for (long i = tid; i < nc; i += 256) y[i] = wp[i] * inv;
+}
+
+// rope on x [d, heads, T, ne3] (strided) -> y (strided). pos int32 [T]. One 64-thread workgroup per (head, token, i3).
+struct RopeG { int n_dims, mode; float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1; };
+__global__ __launch_bounds__(64) void rope_generic_kernel(TD a, const int32_t * pos, const float * ff, TD d, RopeG r) {
+    const long h = blockIdx.x, t = blockIdx.y, i3 = blockIdx.z;
+    const char * src = a.data + h * a.nb[1] + t * a.nb[2] + i3 * a.nb[3];
+    char * dst = d.data + h * d.nb[1] + t * d.nb[2] + i3 * d.nb[3];
+    const bool neox = r.mode & 2;
+    const int half = r.n_dims / 2, dh = (int) a.ne[0];
+    for (int pair = threadIdx.x; pair < dh / 2; pair += 64) {
+        int ia, ib; float o0, o1;
+        if (pair < half) {
+            ia = neox ? pair : 2 * pair; ib = neox ? pair + half : 2 * pair + 1;
+            float theta = (float) pos[t];
+            for (int j = 0; j < pair; ++j) theta *= r.theta_scale;
+            const float te = theta / (ff ? ff[pair] : 1.0f);
+            float ti = r.freq_scale * te, th = ti, ms = r.attn_factor;
+            if (r.ext_factor != 0.0f) {
+                const float y = ((float) pair - r.corr0) / fmaxf(0.001f, r.corr1 - r.corr0);
+                const float mix = (1 - fminf(1, fmaxf(0, y))) * r.ext_factor;
+                th = ti * (1 - mix) + te * mix;
+                ms *= 1.0f + 0.1f * logf(1.0f / r.freq_scale);
+            }
+            const float c = cosf(th) * ms, s = sinf(th) * ms;
+            const float x0 = *(const float *) (src + ia * a.nb[0]), x1 = *(const float *) (src + ib * a.nb[0]);
+            o0 = x0 * c - x1 * s; o1 = x0 * s + x1 * c;
+        } else {
+            ia = r.n_dims + 2 * (pair - half); ib = ia + 1;
+            o0 = *(const float *) (src + ia * a.nb[0]); o1 = *(const float *) (src + ib * a.nb[0]);
+        }
+        *(float *) (dst + ia * d.nb[0]) = o0; *(float *) (dst + ib * d.nb[0]) = o1;
+    }
+}
+
+// dst[i0, i1, i2, i3] = sum_k src0[k, i0, i2/r2, i3/r3] * f16(src1[k, i1, i2, i3]); src0 F16 or F32; one wave per element
+__global__ __launch_bounds__(256) void mul_mat_f_kernel(TD a, int at, TD b, TD d, long r2, long r3, long n_out) {
+    const long o = (long) blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (o >= n_out) return;
+    long r = o;
+    const long i0 = r % d.ne[0]; r /= d.ne[0]; const long i1 = r % d.ne[1]; r /= d.ne[1]; const long i2 = r % d.ne[2]; const long i3 = r / d.ne[2];
+    const char * ap = a.data + i0 * a.nb[1] + (i2 / r2) * a.nb[2] + (i3 / r3) * a.nb[3];
+    const char * bp = b.data + i1 * b.nb[1] + i2 * b.nb[2] + i3 * b.nb[3];
+    float acc = 0.0f;
+    for (long k = lane; k < a.ne[0]; k += 64) {
+        const float w = ld_as_f32(ap + k * a.nb[0], at);
+        float x = *(const float *) (bp + k * b.nb[0]);
+        if (at == PM_F16) x = h2f(f2h(x));                    // vec_dot_type F16: the activation is rounded to F16
+        acc += w * x;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) *(float *) (d.data + i0 * d.nb[0] + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]) = acc;
+}
+
+__global__ void get_rows_f32_kernel(TD a, const int32_t * idx, long n_idx, TD d) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.ne[0] * n_idx) return;
+    const long c = i % a.ne[0], r = i / a.ne[0];
+    *(float *) (d.data + c * d.nb[0] + r * d.nb[1]) = *(const float *) (a.data + c * a.nb[0] + (long) idx[r] * a.nb[1]);
+}
+
+#define S(st) ((hipStream_t) (st))
+#define GRID(n) dim3((unsigned) (((n) + 255) / 256)), dim3(256)
+#define OKRET() do { return hipGetLastError() == hipSuccess ? PM355_OK : PM355_E_HIP; } while (0)
+
+extern "C" {
+
+int pm355_op_cpy(const pm355_tensor * src, const pm355_tensor * dst, pm355_stream_t st) {
+    const int ts = src->type, td = dst->type;
+    if ((ts != PM_F32 && ts != PM_F16) || (td != PM_F32 && td != PM_F16) || nelem(src) != nelem(dst)) return PM355_E_UNSUPPORTED;
+    const long n = nelem(dst);
+    (void) hipGetLastError();
+    hipLaunchKernelGGL(cpy_kernel, GRID(n), 0, S(st), to_td(src), ts, to_td(dst), td, n);
+    OKRET();
+}
+int pm355_op_binary(int op, const pm355_tensor * a, const pm355_tensor * b, const pm355_tensor * dst, pm355_stream_t st) {
+    if (a->type != PM_F32 || b->type != PM_F32 || dst->type != PM_F32 || (op != 0 && op != 1)) return PM355_E_UNSUPPORTED;
+    for (int i = 0; i < 4; ++i) if (b->ne[i] <= 0 || a->ne[i] % b->ne[i]) return PM355_E_SHAPE;
+    const long n = nelem(dst);
+    (void) hipGetLastError();
+    hipLaunchKernelGGL(bin_kernel, GRID(n), 0, S(st), to_td(a), to_td(b), to_td(dst), op, n);
+    OKRET();
+}
+int pm355_op_unary(int op, const pm355_tensor * a, const pm355_tensor * dst, float param, pm355_stream_t st) {
+    if (a->type != PM_F32 || dst->type != PM_F32 || (op != 0 && op != 1)) return PM355_E_UNSUPPORTED;
+    const long n = nelem(dst);
+    (void) hipGetLastError();
+    hipLaunchKernelGGL(unary_kernel, GRID(n), 0, S(st), to_td(a), to_td(dst), op, param, n);
+    OKRET();
+}
+int pm355_op_rms_norm(const pm355_tensor * a, const pm355_tensor * dst, float eps, pm355_stream_t st) {
+    if (a->type != PM_F32 || dst->type != PM_F32 || a->nb[0] != 4 || dst->nb[0] != 4) return PM355_E_UNSUPPORTED;
+    const long rows = a->ne[1] * a->ne[2] * a->ne[3];
+    (void) hipGetLastError();
+    hipLaunchKernelGGL(rms_norm_rows_kernel, dim3((unsigned) rows), dim3(256), 0, S(st), to_td(a), to_td(dst), eps);
+    OKRET();
+}
+int pm355_op_soft_max(const pm355_tensor * a, const pm355_tensor * mask, const pm355_tensor * dst, float scale, float max_bias,
+                      pm355_stream_t st) {
+    if (a->type != PM_F32 || dst->type != PM_F32 || a->nb[0] != 4 || dst->nb[0] != 4) return PM355_E_UNSUPPORTED;
+    if (mask && ((mask->type != PM_F32 && mask->type != PM_F16) || mask->ne[0] != a->ne[0] || mask->ne[1] < a->ne[1])) return PM355_E_UNSUPPORTED;
+    const size_t lds = (size_t) a->ne[0] * 4;
+    if (lds > 150 * 1024) return PM355_E_RANGE;
+    const long rows = a->ne[1] * a->ne[2] * a->ne[3];
+    const unsigned n_head = (unsigned) a->ne[2];
+    const unsigned n_head_log2 = 1u << (unsigned) floor(log2((double) n_head));
+    const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    static bool set = false;
+    if (lds > 48 * 1024 && !set) { (void) hipFuncSetAttribute((const void *) soft_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set = true; }
+    (void) hipGetLastError();
+    hipLaunchKernelGGL(soft_max_kernel, dim3((unsigned) rows), dim3(256), lds, S(st), to_td(a), mask ? (const char *) mask->data : nullptr,
+                       mask ? mask->type : 0, mask ? (long) mask->nb[1] : 0, to_td(dst), scale, max_bias, m0, m1, n_head_log2);
+    OKRET();
+}
+int pm355_op_rope(const pm355_tensor * a, const int32_t * d_pos, const float * freq_factors, const pm355_tensor * dst,
+                  const pm355_rope_params * rp, pm355_stream_t st) {
+    if (a->type != PM_F32 || dst->type != PM_F32 || !rp || rp->n_dims % 2 || rp->n_dims > a->ne[0] || a->ne[0] % 2) return PM355_E_UNSUPPORTED;
+    if (rp->mode & ~2) return PM355_E_UNSUPPORTED;                   // only NORM (0) and NEOX (2)
+    pm_rope_cfg c;
+    c.n_dims = rp->n_dims; c.mode = rp->mode; c.n_ctx_orig = rp->n_ctx_orig; c.freq_base = rp->freq_base; c.freq_scale = rp->freq_scale;
+    c.ext_factor = rp->ext_factor; c.attn_factor = rp->attn_factor; c.beta_fast = rp->beta_fast; c.beta_slow = rp->beta_slow;
+    pm_rope_params(c);
+    RopeG r = {c.n_dims, c.mode, c.theta_scale, c.freq_scale, c.ext_factor, c.attn_factor, c.corr0, c.corr1};
+    (void) hipGetLastError();
+    hipLaunchKernelGGL(rope_generic_kernel, dim3((unsigned) a->ne[1], (unsigned) a->ne[2], (unsigned) a->ne[3]), dim3(64), 0, S(st),
+                       to_td(a), d_pos, freq_factors, to_td(dst), r);
+    OKRET();
+}
+int pm355_op_mul_mat_f(const pm355_tensor * a, const pm355_tensor * b, const pm355_tensor * dst, pm355_stream_t st) {
+    if ((a->type != PM_F16 && a->type != PM_F32) || b->type != PM_F32 || dst->type != PM_F32) return PM355_E_UNSUPPORTED;
+    if (a->ne[0] != b->ne[0] || b->ne[2] % a->ne[2] || b->ne[3] % a->ne[3]) return PM355_E_SHAPE;
+    const long n = nelem(dst);
+    (void) hipGetLastError();
+    hipLaunchKernelGGL(mul_mat_f_kernel, dim3((unsigned) ((n + 3) / 4)), dim3(256), 0, S(st), to_td(a), a->type, to_td(b), to_td(dst),
+                       b->ne[2] / a->ne[2], b->ne[3] / a->ne[3], n);
+    OKRET();
+}
+int pm355_op_get_rows_f32(const pm355_tensor * a, const int32_t * d_idx, int64_t n_idx, const pm355_tensor * dst, pm355_stream_t st) {
+    if (a->type != PM_F32 || dst->type != PM_F32) return PM355_E_UNSUPPORTED;
+    const long n = a->ne[0] * n_idx;
+    (void) hipGetLastError();
+    hipLaunchKernelGGL(get_rows_f32_kernel, GRID(n), 0, S(st), to_td(a), d_idx, (long) n_idx, to_td(dst));
+    OKRET();
+}
+
+} // extern "C"

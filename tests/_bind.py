@@ -423,3 +423,69 @@ def _typed(rng, t, k, n, keep, quantize, scale=None):
         data = rand_blocks(t, n, k, rng, scale=None if scale is None else scale)
     keep.append(data)
     return TensorT(t, 0, data.ctypes.data)
+
+
+# --------------------------------------------------------------------------------------------
+# (de)serialisation of a ModelDesc so that golden fixtures are self-contained
+# --------------------------------------------------------------------------------------------
+_LAYER_FIELDS = ["attn_norm", "wq", "wk", "wv", "wo", "ffn_norm", "ffn_gate", "ffn_up", "ffn_down", "bq", "bk", "bv"]
+_HP_FIELDS = ["arch", "n_layer", "n_embd", "n_head", "n_head_kv", "head_dim", "n_ff", "n_vocab", "n_ctx", "n_ctx_orig",
+              "rms_eps", "rope_freq_base", "rope_freq_scale"]
+
+
+def _tensor_shape(d, field):
+    E, Eq, Ekv, F = d.n_embd, d.head_dim * d.n_head, d.head_dim * d.n_head_kv, d.n_ff
+    return {"attn_norm": (E, 1), "wq": (E, Eq), "wk": (E, Ekv), "wv": (E, Ekv), "wo": (Eq, E), "ffn_norm": (E, 1),
+            "ffn_gate": (E, F), "ffn_up": (E, F), "ffn_down": (F, E), "bq": (Eq, 1), "bk": (Ekv, 1), "bv": (Ekv, 1),
+            "tok_embd": (E, d.n_vocab), "out_norm": (E, 1), "output": (E, d.n_vocab)}[field]
+
+
+def _tensor_bytes(t, k, n):
+    return np.ctypeslib.as_array(C.cast(t.data, C.POINTER(C.c_uint8)), shape=(row_size(t.type, k) * n,)).copy()
+
+
+def desc_to_arrays(d):
+    out = {f"hp_{f}": np.array(getattr(d, f)) for f in _HP_FIELDS}
+    for f in _LAYER_FIELDS:
+        arr = getattr(d, f)
+        if not arr:
+            continue
+        for il in range(d.n_layer):
+            k, n = _tensor_shape(d, f)
+            out[f"t_{f}_{il}"] = _tensor_bytes(arr[il], k, n)
+            out[f"y_{f}_{il}"] = np.array(arr[il].type)
+    for f in ("tok_embd", "out_norm", "output"):
+        t = getattr(d, f)
+        k, n = _tensor_shape(d, f)
+        out[f"t_{f}"] = _tensor_bytes(t, k, n)
+        out[f"y_{f}"] = np.array(t.type)
+    if d.rope_freqs:
+        out["t_rope_freqs"] = np.ctypeslib.as_array(C.cast(d.rope_freqs, C.POINTER(C.c_float)), shape=(d.head_dim // 2,)).copy()
+    return out
+
+
+def desc_from_arrays(z):
+    d = ModelDesc()
+    keep = []
+    for f in _HP_FIELDS:
+        v = z[f"hp_{f}"]
+        setattr(d, f, float(v) if f in ("rms_eps", "rope_freq_base", "rope_freq_scale") else int(v))
+
+    def tt(key_t, key_y):
+        data = np.ascontiguousarray(z[key_t])
+        keep.append(data)
+        return TensorT(int(z[key_y]), 0, data.ctypes.data)
+    for f in _LAYER_FIELDS:
+        if f"t_{f}_0" not in z:
+            continue
+        a = (TensorT * d.n_layer)(*[tt(f"t_{f}_{il}", f"y_{f}_{il}") for il in range(d.n_layer)])
+        keep.append(a)
+        setattr(d, f, a)
+    for f in ("tok_embd", "out_norm", "output"):
+        setattr(d, f, tt(f"t_{f}", f"y_{f}"))
+    if "t_rope_freqs" in z:
+        ff = np.ascontiguousarray(z["t_rope_freqs"], dtype=np.float32)
+        keep.append(ff)
+        d.rope_freqs = ff.ctypes.data
+    d._keep = keep
+    return d

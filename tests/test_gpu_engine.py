@@ -137,3 +137,31 @@ def test_step_with_external_activation_buffers(E):
         w.step(x_in=xin, x_out=xout, advance=1, use_graph=True)
         assert torch.equal(xout, ref[i])
     w.close()
+
+
+@pytest.mark.parametrize("name", ["llama", "qwen2"])
+def test_golden_greedy_decode_vs_reference(E, name):
+    """The committed golden run of the REFERENCE CPU backend (tests/golden/tiny_*_decode.npz): same GGUF-order weights,
+    same prompt; logits NMSE < 1e-3 per step (teacher-forced) and greedy-token parity wherever the reference's own
+    top-1/top-2 margin is above the logit noise."""
+    import os
+    from _bind import desc_from_arrays
+    torch = E.torch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"tiny_{name}_decode.npz"))
+    d = desc_from_arrays(z)
+    w = E.Window(_hp(d), n_ctx=int(d.n_ctx))
+    w.load_desc(d)
+    w.finalize(max_tokens=8)
+    prompt, toks, logits = z["prompt"], z["tokens"], z["logits"]
+    _, lg, _ = w.decode(tokens=torch.from_numpy(prompt).cuda(), pos0=0)
+    got, nm = [int(lg.argmax().item())], [_nmse(lg.cpu().numpy(), logits[0])]
+    for i in range(len(toks) - 1):
+        _, lg, am = w.decode(tokens=torch.tensor([int(toks[i])], dtype=torch.int32, device="cuda"), pos0=len(prompt) + i, want_argmax=True)
+        got.append(int(am.item()))
+        nm.append(_nmse(lg.cpu().numpy(), logits[i + 1]))
+    w.close()
+    assert max(nm) < 1e-3, nm
+    for i, (a, b) in enumerate(zip(got, toks)):
+        top2 = np.sort(logits[i])[-2:]
+        if top2[1] - top2[0] > 2e-2 * max(1.0, abs(float(top2[1]))):
+            assert a == int(b), (i, got, toks.tolist())
