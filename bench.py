@@ -174,10 +174,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    local = local % torch.cuda.device_count()      # (PM355_DIST_BACKEND=gloo lets several ranks share one GPU for testing)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = os.environ.get("PM355_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import prima_cpp_amd.engine as E
     from prima_cpp_amd.ring import EngineCompute, RingDriver, partition_layers

@@ -1,0 +1,96 @@
+"""Two ring ranks (two processes, gloo transport, both on the one test GPU) driving real engine windows: the staggered
+multi-sequence piped ring must generate exactly the tokens a single full-model window generates for each sequence."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _hp(d):
+    return dict(arch=d.arch, n_layer=d.n_layer, n_embd=d.n_embd, n_head=d.n_head, n_head_kv=d.n_head_kv,
+                head_dim=d.head_dim, n_ff=d.n_ff, n_vocab=d.n_vocab, rms_eps=d.rms_eps, rope_freq_base=d.rope_freq_base)
+
+
+def _worker(rank, world, port, n_rounds, first, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from _bind import tiny_model
+    import prima_cpp_amd.engine as E
+    from prima_cpp_amd.ring import EngineCompute, RingDriver
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = tiny_model(np.random.default_rng(61), arch=0, n_layer=4, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=320, n_ctx=64, rope_freqs=True)
+    lo, hi = (0, 2) if rank == 0 else (2, 4)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        w = E.Window(_hp(d), lo=lo, hi=hi, flags=(E.HAS_EMBD | E.HAS_HEAD) if rank == 0 else 0, n_ctx=64)
+        w.load_desc(d)
+        w.finalize(max_tokens=1, n_seq=world)
+        comp = EngineCompute(w, world, use_graph=True)
+        drv = RingDriver(comp, rank, world)
+        hist = [[] for _ in range(world)]
+        total = world * (n_rounds + 1)
+        for m in range(total):
+            forced = first[m] if (rank == 0 and m < world) else None
+            seq = drv.micro_step(forced_token=forced)
+            if rank == 0 and m >= world and seq is not None:
+                torch.cuda.synchronize()
+                hist[seq].append(int(comp.cur.item()))          # token that was just generated for `seq` and fed back
+        drv.flush()
+        torch.cuda.synchronize()
+        if rank == 0:
+            q.put(hist)
+        w.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ring_matches_single_window():
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    sys.path.insert(0, ROOT)
+    from _bind import tiny_model
+    import prima_cpp_amd.engine as E
+    world, n_rounds = 2, 6
+    first = [17, 101]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rounds, first, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    # single full window, one sequence at a time, device greedy loop
+    d = tiny_model(np.random.default_rng(61), arch=0, n_layer=4, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=320, n_ctx=64, rope_freqs=True)
+    w = E.Window(_hp(d), n_ctx=64)
+    w.load_desc(d)
+    w.finalize(1)
+    for s in range(world):
+        w.kv_clear()
+        io = torch.zeros(n_rounds + 1, dtype=torch.int32, device="cuda")
+        io[0] = first[s]
+        w.generate(io, 0, n_rounds, use_graph=True)
+        torch.cuda.synchronize()
+        assert got[s][:n_rounds] == io.cpu().numpy()[1:].tolist(), (s, got[s], io.cpu().numpy())
+    w.close()
