@@ -75,6 +75,14 @@ class RingDriver:
         self.m = 0
         self.reqs = []
         self.last_out = None
+        # gloo has no device-memory send/recv: when the transport is gloo and the buffers live on a GPU (single-GPU
+        # tests only), stage through pinned host tensors. With nccl (= RCCL) the device buffers go on the wire directly.
+        dev_is_gpu = torch.device(compute.device).type == "cuda"
+        self.host_stage = world > 1 and dev_is_gpu and dist.get_backend(group) == "gloo"
+        if self.host_stage:
+            self.h_in = [torch.empty((1, compute.n_embd), dtype=torch.float32).pin_memory() for _ in range(2)]
+            self.h_out = [torch.empty((1, compute.n_embd), dtype=torch.float32).pin_memory() for _ in range(2)]
+            self.recv_posted = [False, False]
 
     def _need_recv(self, m):
         if self.world == 1:
@@ -99,14 +107,22 @@ class RingDriver:
                 x_in = self.last_out
             else:
                 x_in = self.x_in[m & 1] if self._need_recv(m) else None
+                if x_in is not None and self.host_stage:
+                    x_in.copy_(self.h_in[m & 1], non_blocking=False)
             out = self.c.first_rank_step(seq, x_in, forced_token) if r == 0 else self.c.rank_step(seq, x_in)
             self.last_out = out
         if W > 1:
             ops = []
             if active:
-                ops.append(dist.P2POp(dist.isend, out, self.nxt, self.group))
+                snd = out
+                if self.host_stage:
+                    self.h_out[m & 1].copy_(out)
+                    torch.cuda.current_stream().synchronize()
+                    snd = self.h_out[m & 1]
+                ops.append(dist.P2POp(dist.isend, snd, self.nxt, self.group))
             if self._need_recv(m + 1):
-                ops.append(dist.P2POp(dist.irecv, self.x_in[(m + 1) & 1], self.prv, self.group))
+                rcv = self.h_in[(m + 1) & 1] if self.host_stage else self.x_in[(m + 1) & 1]
+                ops.append(dist.P2POp(dist.irecv, rcv, self.prv, self.group))
             if ops:
                 self.reqs = dist.batch_isend_irecv(ops)
         return seq
