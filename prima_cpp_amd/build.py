@@ -10,7 +10,8 @@ LIB = os.path.join(HERE, "libprima_mi355.so")
 SOURCES = ["c_api.hip", "quantize.hip", "mmvq.hip", "repack.hip", "layer_ops.hip", "ggml_ops.hip", "engine.hip", "mmq.hip"]
 # -ffp-contract=off: the quantizers must round exactly like the reference (no fused multiply-add where
 # the reference has a separate multiply and add); FMAs we want are written as fmaf().
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+EXTRA = os.environ.get("PM355_EXTRA_FLAGS", "").split()
+FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-const-variable", "-Wno-unused-value", "-Wno-unused-function", "-Wno-unused-result"]
 
 

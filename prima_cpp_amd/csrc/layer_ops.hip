@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void attn_rope_fused_kernel(const float * q, c
     __shared__ float redf[8];
     __shared__ double redd[4];
     constexpr int PARTS = 256 / DH;
+    constexpr int KQ = DH / 8;                   // 16-byte pieces per K row
     float * qs   = (float *) smem;               // [DH]  f16-rounded rotated q
     float * kcur = qs + DH;                      // [DH]  f16-rounded rotated k of this position
     float * vcur = kcur + DH;                    // [DH]  f16-rounded v of this position
@@ -243,15 +244,35 @@ __global__ __launch_bounds__(256) void attn_rope_fused_kernel(const float * q, c
     const int seq = seq_ptr ? *seq_ptr : 0;
     kc += (long) seq * seq_stride; vc += (long) seq * seq_stride;
     const int pos = pos0_ptr[seq];
+    const int n_pad = (pos + 7) & ~7;            // cached keys 0..pos-1, padded to the 16-byte load width
     const bool neox = r.mode & 2;
     const int half = r.n_dims / 2;
+
+    // ---- every global load whose address depends only on `pos` goes out NOW (one exposed latency for the whole
+    //      kernel): this thread's K row of the first sweep and its first two V^T chunks; the rotations below overlap it
+    u32x4 kreg[KQ];
+    const bool have_k = tid < pos;
+    {
+        const uint16_t * kr = kc + (long) (have_k ? tid : 0) * Hkv * DH + (long) hk * DH;
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) kreg[j] = *(const u32x4 *) (kr + 8 * j);
+    }
+    const int ve = tid % DH, vpt = tid / DH;
+    const uint16_t * vrow = vc + (long) (hk * DH + ve) * n_ctx;
+    u32x4 vreg0 = {0, 0, 0, 0}, vreg1 = {0, 0, 0, 0};
+    {
+        const int i0 = vpt * 8, i1 = i0 + PARTS * 8;
+        vreg0 = *(const u32x4 *) (vrow + (i0 < n_pad ? i0 : 0));
+        vreg1 = *(const u32x4 *) (vrow + (i1 < n_pad ? i1 : 0));
+    }
+
     if (tid < DH / 2) {
         float c = 1.0f, s_ = 0.0f;
         if (tid < half) rope_cs(r, (float) pos, tid, freq_factors, c, s_);
         cs[2 * tid] = c; cs[2 * tid + 1] = s_;
     }
     __syncthreads();
-    // rotate q (threads 0..DH/2-1) and k (threads DH/2..DH-1); v copy (threads DH..2DH-1 when available)
+    // rotate q (threads 0..DH/2-1) and k (threads DH/2..DH-1)
     if (tid < DH) {
         const bool is_k = tid >= DH / 2;
         const int pair = is_k ? tid - DH / 2 : tid;
@@ -279,22 +300,27 @@ __global__ __launch_bounds__(256) void attn_rope_fused_kernel(const float * q, c
         if (h % (H / Hkv) == 0) vc[(long) (hk * DH + e) * n_ctx + pos] = hv;
     }
     __syncthreads();
-    // ---- scores: cached keys 0..pos-1 (thread per key), current key from LDS (thread 255 of the first sweep)
+    // ---- scores: cached keys 0..pos-1 (thread per key; first sweep from the pre-loaded registers), current key from LDS
     const int n_kv = pos + 1;
     float lmax = -INFINITY;
-    for (int i = tid; i < pos; i += 256) {
-        const uint16_t * kr = kc + (long) i * Hkv * DH + (long) hk * DH;
+    auto dot_row = [&](const u32x4 (&kk)[KQ]) __attribute__((always_inline)) {
         float acc = 0.0f;
-#pragma unroll 4
-        for (int e = 0; e < DH; e += 8) {
-            const u32x4 kk = *(const u32x4 *) (kr + e);
+#pragma unroll
+        for (int jj = 0; jj < KQ; ++jj)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc += h2f((uint16_t) (kk[j] & 0xFFFF)) * qs[e + 2 * j];
-                acc += h2f((uint16_t) (kk[j] >> 16)) * qs[e + 2 * j + 1];
+                acc += h2f((uint16_t) (kk[jj][j] & 0xFFFF)) * qs[8 * jj + 2 * j];
+                acc += h2f((uint16_t) (kk[jj][j] >> 16)) * qs[8 * jj + 2 * j + 1];
             }
-        }
-        const float s_ = acc * scale;
+        return acc * scale;
+    };
+    if (have_k) { const float s_ = dot_row(kreg); sc[tid] = s_; lmax = s_; }
+    for (int i = tid + 256; i < pos; i += 256) {
+        const uint16_t * kr = kc + (long) i * Hkv * DH + (long) hk * DH;
+        u32x4 kk[KQ];
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) kk[j] = *(const u32x4 *) (kr + 8 * j);
+        const float s_ = dot_row(kk);
         sc[i] = s_;
         lmax = fmaxf(lmax, s_);
     }
@@ -322,30 +348,25 @@ __global__ __launch_bounds__(256) void attn_rope_fused_kernel(const float * q, c
     __syncthreads();
     const double tot = (redd[0] + redd[1]) + (redd[2] + redd[3]);
     const float inv = (float) (1.0 / tot);
-    const int n_pad = (pos + 7) & ~7;                                  // cached part, padded to the 16-B load width
-    float p_cur = 0.0f;
-    for (int i = tid; i < n_pad + 1; i += 256) {
-        if (i < pos) sc[i] = h2f(f2h(sc[i] * inv));
-        else if (i < n_pad) { if (i != pos) sc[i] = 0.0f; }
-    }
+    const float p_cur = h2f(f2h(sc[pos] * inv));                       // every thread reads exp() of the current key
     __syncthreads();
-    p_cur = h2f(f2h(sc[pos] * inv));                                   // sc[pos] still holds exp(): untouched above
+    for (int i = tid; i < n_pad; i += 256) sc[i] = i < pos ? h2f(f2h(sc[i] * inv)) : 0.0f;   // p rounded to F16; pad (incl. `pos`) = 0
     __syncthreads();
-    if (pos < n_pad && tid == 0) sc[pos] = 0.0f;                       // cache column `pos` must not contribute twice
-    __syncthreads();
-    // ---- PV: thread (e, part) streams V^T[hk*DH+e][8*chunk ..] for chunk = part, part+PARTS, ...
+    // ---- PV: thread (e, part) streams V^T[hk*DH+e][8*chunk ..] for chunk = part, part+PARTS, ... (first two pre-loaded)
     {
-        const int e = tid % DH, pt = tid / DH;
-        const uint16_t * vr = vc + (long) (hk * DH + e) * n_ctx;
         float acc = 0.0f;
-        for (int i = pt * 8; i < n_pad; i += PARTS * 8) {
-            const u32x4 vv = *(const u32x4 *) (vr + i);
+        auto fma8 = [&](const u32x4 & vv, int i) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 acc += h2f((uint16_t) (vv[j] & 0xFFFF)) * sc[i + 2 * j];
                 acc += h2f((uint16_t) (vv[j] >> 16)) * sc[i + 2 * j + 1];
             }
-        }
+        };
+        int i = vpt * 8;
+        if (i < n_pad) fma8(vreg0, i);
+        i += PARTS * 8;
+        if (i < n_pad) fma8(vreg1, i);
+        for (i += PARTS * 8; i < n_pad; i += PARTS * 8) { const u32x4 vv = *(const u32x4 *) (vrow + i); fma8(vv, i); }
         part[tid] = acc;
     }
     __syncthreads();

@@ -10,7 +10,7 @@
 // dbg output; the float scale-and-accumulate uses a fixed, deterministic order.
 //
 // Design: HBM-bound, 4.5-8.5 bits per weight, no reuse of W -> W goes straight from HBM to registers (no LDS staging).
-//  * Two 512-thread workgroups per CU. Each workgroup quantizes the activation row ONCE (from f32, fused rms_norm
+//  * One 1024-thread workgroup (16 waves) per CU. Each workgroup quantizes the activation row ONCE (from f32, fused rms_norm
 //    optional, bit-exact with the reference quantizers) into LDS: int8 values, 16-group sums, block scales.
 //  * Each WAVE owns whole rows (2 at a time): lanes stride over the row's UNITS (16-48 contiguous weight bytes = 32/64
 //    weights), so a wave instruction covers a contiguous 1-3 KB span of the row -> fully coalesced, every byte of every
@@ -177,7 +177,9 @@ template <> struct QT<PM_Q8_0> {
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + expf(-g)); }
 
-#define PM_GEMV_BLOCK 512                 // 8 waves per workgroup, 2 workgroups per CU
+#ifndef PM_GEMV_BLOCK
+#define PM_GEMV_BLOCK 1024                // 16 waves: ONE workgroup per CU (measured +2.3 % over 2 x 512: prologue once per CU)
+#endif
 #define PM_GEMV_NW (PM_GEMV_BLOCK / 64)
 
 // ---- activation prologue: the workgroup quantizes the WHOLE activation row once into LDS ----------------------------
@@ -350,8 +352,17 @@ __device__ __forceinline__ void load_x_lds(typename QT<TYPE>::X & x, const XLds 
 template <int TYPE, bool PAIR> struct Item {
     typedef QT<TYPE> T;
     static constexpr int NM = PAIR ? 2 : 1;
-    static constexpr int CH = T::NV == 64 ? 1 : 2;   // units per lane per row and register set (two sets in flight)
-    static constexpr int R  = PAIR ? 1 : 2;          // rows in flight per wave
+#ifndef PM_CH32
+#define PM_CH32 2
+#endif
+#ifndef PM_CH64
+#define PM_CH64 1
+#endif
+#ifndef PM_RSINGLE
+#define PM_RSINGLE 2
+#endif
+    static constexpr int CH = T::NV == 64 ? PM_CH64 : PM_CH32;   // units per lane per row and register set (two sets in flight)
+    static constexpr int R  = PAIR ? 1 : PM_RSINGLE;              // rows in flight per wave
     struct Regs { typename T::Wr w[R][NM][CH]; };
 
     // unconditional loads (row / unit clamped): conditional loads make the compiler drain the VMEM queue
@@ -454,7 +465,7 @@ __device__ __forceinline__ void write_out(const GemvJob & jb, const float * outb
 }
 
 template <int TA, int TB, bool PAIR, bool DBG>
-__global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(GemvP p) {
+__global__ __launch_bounds__(PM_GEMV_BLOCK, PM_GEMV_BLOCK == 256 ? 4 : 4) void gemv_q_kernel(GemvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double nred[PM_GEMV_NW];
     constexpr int ABLK = QT<TA>::ABLK;
@@ -569,7 +580,7 @@ int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st) {
     if (pair && ta != tb) return -1;
     if (!g_num_cus) { hipDeviceProp_t pr; int dev = 0; (void) hipGetDevice(&dev); g_num_cus = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
     // 2 workgroups of 8 waves per CU; every workgroup takes an equal slice of the rows of EVERY job
-    int grid = 2 * g_num_cus;
+    int grid = (1024 / PM_GEMV_BLOCK) * g_num_cus;
     long tot_rows = 0;
     for (int j = 0; j < a.njobs; ++j) tot_rows += a.job[j].N;
     while ((tot_rows + grid - 1) / grid + 3 > PM_MAX_ROWS_PER_WG) grid *= 2;
