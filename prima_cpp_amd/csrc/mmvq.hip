@@ -488,8 +488,9 @@ __global__ __launch_bounds__(PM_GEMV_BLOCK, PM_GEMV_BLOCK == 256 ? 4 : 4) void g
 
     // (1) activation row -> LDS (quantized, bit-exact with the reference quantizers).
     //     [Measured and rejected: pre-issuing the first item's 16-byte weight loads across the prologue (spills under the
-    //      128-VGPR budget, -20 %), and an L2 prefetch of that item with one dword per 128-B line (-7 % even when limited to
-    //      the small wq/wo launches: the in-order VMEM return delays the prologue and the lines are fetched twice).]
+    //      128-VGPR budget, -20 %); an L2 prefetch of that item with one dword per 128-B line (-7 % even when limited to
+    //      the small wq/wo launches: the in-order VMEM return delays the prologue and the lines are fetched twice); and
+    //      splitting the workgroup into 8 prologue waves + 8 waves that pre-issue their first step (-3 %, A/B on one box).]
     stage_activation<ABLK>(p, xs_q, xs_gs, xs_d, nred);
     __syncthreads();
     const XLds xs = {xs_q, xs_gs, xs_d};
