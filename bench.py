@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--prompt", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prefill", type=int, default=512, help="prompt length of the (untimed-for-the-metric) prefill probe, 0 = off")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -167,6 +168,34 @@ def probe_dominant_kernel(win, hp, iters=40):
             "avg_us": us, "gbs": nbytes / us / 1e3}
 
 
+def probe_prefill(hp, mixture, n_tok, n_layers=8):
+    """Prefill probe (reported as an extra, not the metric): n_tok-token prompt through the first n_layers layers of the
+    same model on the MFMA GEMM path, scaled to the full depth. Returns tokens/s and achieved dense TFLOP/s."""
+    import prima_cpp_amd.engine as E
+    win = E.Window(hp, lo=0, hi=n_layers, flags=0, n_ctx=max(1024, ((n_tok + 63) // 64) * 64))
+    win.fill_synthetic(mixture, seed=4321)
+    win.finalize(max_tokens=n_tok, n_seq=1)
+    x = torch.randn(n_tok, hp["n_embd"], device="cuda") * 0.5
+    win.decode(x_in=x, pos0=0, want_hidden=True, want_logits=False)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream()
+    win.kv_clear()
+    e0.record(st)
+    win.decode(x_in=x, pos0=0, want_hidden=True, want_logits=False)
+    e1.record(st)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    Ed, Eq, Ekv, F = hp["n_embd"], hp["head_dim"] * hp["n_head"], hp["head_dim"] * hp["n_head_kv"], hp["n_ff"]
+    params = Ed * Eq * 2 + 2 * Ed * Ekv + 3 * Ed * F
+    flop = 2.0 * params * n_tok * n_layers
+    win.close()
+    full_ms = ms * hp["n_layer"] / n_layers
+    return {"prompt_tokens": n_tok, "layers_timed": n_layers, "tokens_per_s_full_depth": round(n_tok / (full_ms / 1e3), 1),
+            "gemm_tflops": round(flop / (ms / 1e3) / 1e12, 1), "mfma_peak_tflops_f16_dense": 2500.0,
+            "note": "MFMA v_mfma_f32_32x32x16_f16 GEMMs + per-token attention kernel; layers timed x (n_layer / layers_timed)"}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -268,6 +297,11 @@ def main():
                                       "frac": round(pr["gbs"] / HBM_PEAK_GBS, 4), "traffic": None,
                                       "kernel": pr["kernel"], "bytes_per_launch": pr["bytes_per_launch"],
                                       "avg_launch_us": round(pr["avg_us"], 2)}
+            if world == 1 and a.prefill > 0:
+                try:
+                    result["prefill_probe"] = probe_prefill(hp, mixture, a.prefill)
+                except Exception as e:
+                    result["prefill_probe"] = {"error": str(e)}
             if world == 1 and not a.no_cpu_baseline:
                 try:
                     cb = cpu_baseline(hp, mixture, a.cpu_seconds)

@@ -118,6 +118,11 @@ typedef struct {
 } pm355_matvec_job;
 PM355_API int pm355_mul_mat_vec_fused(const pm355_matvec_job * jobs, int njobs, int64_t K, const float * x_f32,
                                       const float * norm_w, float eps, pm355_stream_t stream);
+/* Batched (prefill) path, n_tokens >= 16: Y[t][n] = sum_k W[n][k] x[t][k] (+bias[n]) (+resid[t][n]) on the MFMA matrix cores
+ * (v_mfma_f32_32x32x16_f16, weights dequantized on the fly into LDS, f32 accumulate; prima_cpp_amd/csrc/mmq.hip). Stands
+ * in for the reference CUDA plug-in's mul_mat_q / dequantize+cuBLAS large-batch path (ggml-cuda/mmq.cuh:2583). */
+PM355_API int pm355_mul_mat_q_mfma(int type, const void * W, int64_t K, int64_t N, const float * x, int64_t n_tokens, float * y,
+                                   const float * bias, const float * resid, pm355_stream_t stream);
 /* test hook: additionally writes, per (row, unit), the exact int32 pair {sum scale*q_w*q_a, sum min*bsum} */
 PM355_API int pm355_mul_mat_vec_q_dbg(int type, const void * W, int64_t K, int64_t N, const void * xq, float * y,
                                       int32_t * int_partials, int64_t * units_per_row, pm355_stream_t stream);

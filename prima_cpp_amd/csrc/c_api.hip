@@ -151,6 +151,15 @@ int pm355_mul_mat_vec_fused(const pm355_matvec_job * jobs, int njobs, int64_t K,
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_mul_mat_q_mfma(int type, const void * W, int64_t K, int64_t N, const float * x, int64_t n_tokens, float * y,
+                         const float * bias, const float * resid, pm355_stream_t st) {
+    (void) hipGetLastError();
+    const int rc = pm_launch_gemm_q(type, W, x, y, (int) K, (int) N, (int) n_tokens, bias, resid, S(st));
+    if (rc == -1) return fail(PM355_E_UNSUPPORTED, "mul_mat_q_mfma: weight type");
+    if (rc == -2) return fail(PM355_E_SHAPE, "mul_mat_q_mfma: K % 256 (K % 64 for Q8_0) and N % 4 required");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 int pm355_mul_mat_vec_q_dbg(int type, const void * W, int64_t K, int64_t N, const void * xq, float * y,
                             int32_t * ip, int64_t * upr, pm355_stream_t st) {
     if (upr) *upr = K / (type == PM_Q6_K ? 64 : 32);

@@ -36,7 +36,7 @@ struct pm355_model {
     pm_rope_cfg rope;
     // scratch (device)
     float * x = nullptr, * x1 = nullptr, * q = nullptr, * k = nullptr, * v = nullptr, * att = nullptr, * h = nullptr;
-    float * logits = nullptr, * xn = nullptr;
+    float * logits = nullptr, * xn = nullptr, * h2 = nullptr;
     uint8_t * aq_k = nullptr, * aq_0 = nullptr;     // quantized activation scratch (Q8_K / Q8_0), sized for max(K)
     int32_t * d_pos = nullptr, * d_tok = nullptr, * d_ctl = nullptr;   // d_pos[n_seq]; d_ctl = {current seq, n_seq}
     int n_seq = 1;
@@ -288,6 +288,33 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
             cur = x_next;
             continue;
         }
+        if (T >= 16 && !m->no_fuse) {
+            // ---- prefill: batched GEMMs on the MFMA matrix cores (mmq.hip), f32 activations
+            auto G = [&](const Tensor & w, const float * x, float * y, const float * bias, const float * resid) {
+                return pm_launch_gemm_q(w.type, w.d, x, y, (int) w.K, (int) w.N, T, bias, resid, st);
+            };
+            pm_launch_rmsnorm_q8k(cur, (const float *) L.t[PM355_T_ATTN_NORM].d, m->xn, nullptr, E, T, hp.rms_eps, st);
+            int rc = G(L.t[PM355_T_WQ], m->xn, m->q, (const float *) L.t[PM355_T_BQ].d, nullptr);
+            rc |= G(L.t[PM355_T_WK], m->xn, m->k, (const float *) L.t[PM355_T_BK].d, nullptr);
+            rc |= G(L.t[PM355_T_WV], m->xn, m->v, (const float *) L.t[PM355_T_BV].d, nullptr);
+            if (rc) return seterr(m, PM355_E_UNSUPPORTED, "prefill: qkv gemm");
+            const long kvs = (long) hp.n_ctx * Hkv * dh;
+            pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kvs,
+                                    (const float *) m->rope_freqs.d, T, H, Hkv, dh, hp.n_ctx, m->rope, st);
+            if (pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
+                return seterr(m, PM355_E_RANGE, "prefill: n_ctx too large for the attention kernel");
+            float * x_mid = (cur == bufs[0]) ? bufs[1] : bufs[0];
+            if (G(L.t[PM355_T_WO], m->att, x_mid, nullptr, cur)) return seterr(m, PM355_E_UNSUPPORTED, "prefill: wo gemm");
+            pm_launch_rmsnorm_q8k(x_mid, (const float *) L.t[PM355_T_FFN_NORM].d, m->xn, nullptr, E, T, hp.rms_eps, st);
+            rc = G(L.t[PM355_T_FFN_GATE], m->xn, m->h, nullptr, nullptr);
+            rc |= G(L.t[PM355_T_FFN_UP], m->xn, m->h2, nullptr, nullptr);
+            if (rc) return seterr(m, PM355_E_UNSUPPORTED, "prefill: gate/up gemm");
+            pm_launch_silu_mul(m->h, m->h2, m->h, (long) T * F, st);
+            float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : ((x_mid == bufs[0]) ? bufs[1] : bufs[0]);
+            if (G(L.t[PM355_T_FFN_DOWN], m->h, x_next, nullptr, x_mid)) return seterr(m, PM355_E_UNSUPPORTED, "prefill: down gemm");
+            cur = x_next;
+            continue;
+        }
         // attn_norm (+weight), quantized for q/k/v in the same pass when only Q8_K is needed
         ActQ a = norm_quantize_for(m, cur, (const float *) L.t[PM355_T_ATTN_NORM].d, E, T, qkv, 3, st);
         int rc = 0;
@@ -356,7 +383,7 @@ void pm355_model_free(pm355_model * m) {
     for (auto & L : m->layers) { for (auto & t : L.t) if (t.d) (void) hipFree(t.d); if (L.kc) (void) hipFree(L.kc); if (L.vc) (void) hipFree(L.vc); }
     Tensor * g[4] = {&m->tok_embd, &m->out_norm, &m->output, &m->rope_freqs};
     for (auto t : g) if (t->d) (void) hipFree(t->d);
-    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->dstage};
+    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->h2, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->dstage};
     for (auto p : s) if (p) (void) hipFree(p);
     for (int i = 0; i < 2; ++i) if (m->pin[i]) { (void) hipHostFree(m->pin[i]); (void) hipEventDestroy(m->pin_ev[i]); }
     if (m->up_stream) (void) hipStreamDestroy(m->up_stream);
@@ -449,7 +476,7 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
     auto A = [&](void ** p, size_t n) { return hipMalloc(p, n + 256) == hipSuccess; };
     bool ok = A((void **) &m->x, T * E * 4) && A((void **) &m->x1, T * E * 4) && A((void **) &m->xn, T * E * 4) &&
               A((void **) &m->q, T * Eq * 4) && A((void **) &m->k, T * Ekv * 4) && A((void **) &m->v, T * Ekv * 4) &&
-              A((void **) &m->att, T * Eq * 4) && A((void **) &m->h, T * F * 4) && A((void **) &m->logits, (size_t) hp.n_vocab * 4) &&
+              A((void **) &m->att, T * Eq * 4) && A((void **) &m->h, T * F * 4) && (T < 16 || A((void **) &m->h2, T * F * 4)) && A((void **) &m->logits, (size_t) hp.n_vocab * 4) &&
               A((void **) &m->aq_k, T * pm_q8k_row_bytes((int) ((maxK + 255) / 256 * 256))) &&
               A((void **) &m->aq_0, T * pm_q80_row_bytes((int) ((maxK + 31) / 32 * 32))) &&
               A((void **) &m->d_pos, 64 * 4) && A((void **) &m->d_ctl, 64) && A((void **) &m->d_tok, 64 + T * 4);

@@ -258,6 +258,10 @@ bool compute_node(backend_ctx * c, struct ggml_tensor * op) {
             if (mul_mat_quant_ok(op)) {
                 // one fused launch per activation column: f32 -> vec_dot_type in the kernel prologue, then the mat-vec
                 const int64_t K = a->ne[0], N = a->ne[1], ncols = b->ne[1];
+                if (ncols >= 16 && K % 64 == 0 && N % 4 == 0) {          // prefill: batched GEMM on the MFMA matrix cores
+                    MI355_CHECK(pm355_mul_mat_q_mfma((int) a->type, a->data, K, N, (const float *) b->data, ncols, (float *) op->data, nullptr, nullptr, st));
+                    return true;
+                }
                 for (int64_t col = 0; col < ncols; ++col) {
                     pm355_matvec_job job = {};
                     job.type = (int32_t) a->type; job.N = N; job.W = a->data; job.y = (float *) op->data + col * N;

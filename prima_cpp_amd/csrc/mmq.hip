@@ -1,0 +1,190 @@
+// mmq.hip — batched (prefill) quantized GEMM on the MFMA matrix cores of gfx950.
+//
+// Replaces ggml_compute_forward_mul_mat (ggml/src/ggml.c:12377) for n_tokens >= 16 (what the reference's CUDA plug-in
+// serves with mul_mat_q / dequantize + cuBLAS, ggml-cuda/mmq.cuh:2583, convert.cu:190-279):
+//     Y[t][n] = sum_k W[n][k] * X[t][k]           W: Q4_K / Q5_K / Q6_K / Q8_0 rows in the HBM layout of repack.hip
+// Design: weights are read from HBM exactly once per 128-token tile, dequantized on the fly (f32 math, the exact
+// d*sc*q - dmin*m of dequantize_row_*, then rounded to F16) into an LDS tile, activations are converted F32 -> F16 into a
+// second LDS tile, and 4 waves run v_mfma_f32_32x32x16_f16 with f32 accumulation (each wave a 64x64 output block =
+// 2x2 MFMA tiles). Tile 128 (weight rows) x 128 (tokens) x 64 (k), LDS rows padded to 72 halfs against bank conflicts.
+// This is the compute-bound regime (arithmetic intensity ~ n_tokens FLOP/B >> ridge): the roofline is the dense F16
+// MFMA peak, not HBM. Numerics: like the reference's own GPU large-batch path the activations are NOT re-quantized to
+// Q8_K here; result vs the CPU reference is within the reference's own backend tolerance (NMSE <= 5e-4,
+// tests/test-backend-ops.cpp:1660) - measured ~1e-6, tests/test_gpu_ops.py.
+#include "pm355_device.h"
+#include "pm355_kernels.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 64, LDS_STRIDE = BK + 8;       // halfs per LDS row
+
+// 32 consecutive weights k0..k0+31 (k0 % 32 == 0) of one row, exact dequantize_row_* arithmetic in f32
+template <int TYPE>
+__device__ __forceinline__ void dequant32(const uint8_t * row, int K, int k0, float (&o)[32]) {
+    if (TYPE == PM_Q8_0) {                                             // row-SoA: qs[K] | half d[K/32]
+        const float d = h2f(((const uint16_t *) (row + K))[k0 >> 5]);
+        const u32x4 a = *(const u32x4 *) (row + k0), b = *(const u32x4 *) (row + k0 + 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[4 * i + j]      = (float) (int8_t) (a[i] >> (8 * j)) * d;
+                o[16 + 4 * i + j] = (float) (int8_t) (b[i] >> (8 * j)) * d;
+            }
+        return;
+    }
+    const int b = k0 >> 8, s = (k0 & 255) >> 5;                         // super-block, 32-value sub-block
+    if (TYPE == PM_Q4_K || TYPE == PM_Q5_K) {
+        const uint8_t * blk = row + (long) b * (TYPE == PM_Q4_K ? PM_BS_Q4_K : PM_BS_Q5_K);
+        const u32x4 h = *(const u32x4 *) blk;
+        int sc, mn;
+        k4_scale_min(h[1], h[2], h[3], s, sc, mn);
+        const float ds = h2f((uint16_t) (h[0] & 0xFFFF)) * (float) sc, ms = h2f((uint16_t) (h[0] >> 16)) * (float) mn;
+        const uint8_t * qs = blk + (TYPE == PM_Q4_K ? 16 : 48) + 32 * (s >> 1);
+        const u32x4 q0 = *(const u32x4 *) qs, q1 = *(const u32x4 *) (qs + 16);
+        u32x4 hb0 = {0, 0, 0, 0}, hb1 = {0, 0, 0, 0};
+        if (TYPE == PM_Q5_K) { hb0 = *(const u32x4 *) (blk + 16); hb1 = *(const u32x4 *) (blk + 32); }
+        const int sh = (s & 1) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int v0 = (q0[i] >> (8 * j + sh)) & 0xF, v1 = (q1[i] >> (8 * j + sh)) & 0xF;
+                if (TYPE == PM_Q5_K) { v0 += ((hb0[i] >> (8 * j + s)) & 1) << 4; v1 += ((hb1[i] >> (8 * j + s)) & 1) << 4; }
+                o[4 * i + j] = ds * (float) v0 - ms;
+                o[16 + 4 * i + j] = ds * (float) v1 - ms;
+            }
+        return;
+    }
+    // Q6_K row-SoA: ql[nb][128] | qh[nb][64] | sc[nb][16] | d[nb];  sub-block s -> half hh = s/4, quarter kq = s%4
+    const long nb = K / 256;
+    const int hh = s >> 2, kq = s & 3;
+    const uint8_t * ql = row + (long) b * 128 + 64 * hh + 32 * (kq & 1);
+    const uint8_t * qh = row + nb * 128 + (long) b * 64 + 32 * hh;
+    const int8_t * scl = (const int8_t *) (row + nb * 192 + (long) b * 16 + 8 * hh + 2 * kq);
+    const float d = h2f(((const uint16_t *) (row + nb * 208))[b]);
+    const u32x4 l0 = *(const u32x4 *) ql, l1 = *(const u32x4 *) (ql + 16), h0 = *(const u32x4 *) qh, h1 = *(const u32x4 *) (qh + 16);
+    const float d0 = d * (float) scl[0], d1 = d * (float) scl[1];
+    const int lsh = (kq >> 1) * 4, hsh = 2 * kq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int v0 = (int) (((l0[i] >> (8 * j + lsh)) & 0xF) | (((h0[i] >> (8 * j + hsh)) & 3) << 4)) - 32;
+            const int v1 = (int) (((l1[i] >> (8 * j + lsh)) & 0xF) | (((h1[i] >> (8 * j + hsh)) & 3) << 4)) - 32;
+            o[4 * i + j] = d0 * (float) v0;
+            o[16 + 4 * i + j] = d1 * (float) v1;
+        }
+}
+
+struct GemmP {
+    const uint8_t * W; const float * X; float * Y; const float * bias; const float * resid;
+    long row_stride; int K, N, T;
+};
+
+// grid (ceil(N/128), ceil(T/128)), 256 threads
+template <int TYPE>
+__global__ __launch_bounds__(256) void gemm_q_f16_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) _Float16 As[BM * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[BN * LDS_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * BM, t0 = blockIdx.y * BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;             // this wave's 64x64 block inside the tile
+    float16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int lrow = tid >> 1, lhalf = tid & 1;                        // staging: thread -> (tile row, 32-k half)
+    const int wrow = min(n0 + lrow, p.N - 1), trow = min(t0 + lrow, p.T - 1);
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        // ---- stage A: dequantize 32 weights -> f16
+        {
+            float o[32];
+            dequant32<TYPE>(p.W + (long) wrow * p.row_stride, p.K, k0 + 32 * lhalf, o);
+            _Float16 * dst = As + lrow * LDS_STRIDE + 32 * lhalf;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                half8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (_Float16) o[8 * i + j];
+                *(half8 *) (dst + 8 * i) = v;
+            }
+        }
+        // ---- stage B: 32 activations of one token -> f16
+        {
+            const float * src = p.X + (long) trow * p.K + k0 + 32 * lhalf;
+            _Float16 * dst = Bs + lrow * LDS_STRIDE + 32 * lhalf;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 a = *(const float4 *) (src + 8 * i), b = *(const float4 *) (src + 8 * i + 4);
+                half8 v = {(_Float16) a.x, (_Float16) a.y, (_Float16) a.z, (_Float16) a.w, (_Float16) b.x, (_Float16) b.y, (_Float16) b.z, (_Float16) b.w};
+                *(half8 *) (dst + 8 * i) = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA: A fragment lane l = A[row = l&31][k = 8*(l>>5) .. +8], B fragment = B[k][col = l&31]
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            half8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *(const half8 *) (As + (wm + 32 * i + (lane & 31)) * LDS_STRIDE + kk + 8 * (lane >> 5));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *(const half8 *) (Bs + (wn + 32 * j + (lane & 31)) * LDS_STRIDE + kk + 8 * (lane >> 5));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]; Y[t][n]: 4 consecutive n per float4
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = t0 + wn + 32 * j + (lane & 31);
+            if (t >= p.T) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wm + 32 * i + 8 * g + 4 * (lane >> 5);
+                if (n + 3 < p.N) {
+                    float4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    if (p.bias)  { const float4 bb = *(const float4 *) (p.bias + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+                    if (p.resid) { const float4 rr = *(const float4 *) (p.resid + (long) t * p.N + n); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+                    *(float4 *) (p.Y + (long) t * p.N + n) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < p.N) {
+                        float v = acc[i][j][4 * g + e];
+                        if (p.bias) v += p.bias[n + e];
+                        if (p.resid) v += p.resid[(long) t * p.N + n + e];
+                        p.Y[(long) t * p.N + n + e] = v;
+                    }
+                }
+            }
+        }
+}
+
+} // namespace
+
+int pm_launch_gemm_q(int type, const void * W, const float * X, float * Y, int K, int N, int T, const float * bias,
+                     const float * resid, hipStream_t st) {
+    if (K % 64 || (type != PM_Q8_0 && K % 256) || N % 4) return -2;
+    GemmP p = {(const uint8_t *) W, X, Y, bias, resid, (long) pm_weight_row_stride(type, K), K, N, T};
+    const dim3 grid((N + BM - 1) / BM, (T + BN - 1) / BN);
+    switch (type) {
+        case PM_Q4_K: hipLaunchKernelGGL(gemm_q_f16_kernel<PM_Q4_K>, grid, dim3(256), 0, st, p); break;
+        case PM_Q5_K: hipLaunchKernelGGL(gemm_q_f16_kernel<PM_Q5_K>, grid, dim3(256), 0, st, p); break;
+        case PM_Q6_K: hipLaunchKernelGGL(gemm_q_f16_kernel<PM_Q6_K>, grid, dim3(256), 0, st, p); break;
+        case PM_Q8_0: hipLaunchKernelGGL(gemm_q_f16_kernel<PM_Q8_0>, grid, dim3(256), 0, st, p); break;
+        default: return -1;
+    }
+    return 0;
+}

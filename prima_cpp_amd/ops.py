@@ -204,3 +204,16 @@ def mul_mat_vec_fused(ws, x, norm_w=None, eps=0.0, w2s=None, biases=None, resids
     check(lib.pm355_mul_mat_vec_fused(C.addressof(jobs), n, ws[0].K, ptr(x), ptr(norm_w), float(eps), stream_ptr()),
           "mul_mat_vec_fused")
     return ys
+
+
+def mul_mat_mfma(w, x, bias=None, resid=None):
+    """Batched GEMM on MFMA: x f32 [T, K] -> f32 [T, N]."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_mul_mat_q_mfma.restype = C.c_int
+    lib.pm355_mul_mat_q_mfma.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    x2 = x.contiguous().view(-1, w.K)
+    y = torch.empty((x2.shape[0], w.N), dtype=torch.float32, device=x.device)
+    check(lib.pm355_mul_mat_q_mfma(w.type, ptr(w.data), w.K, w.N, ptr(x2), x2.shape[0], ptr(y), ptr(bias), ptr(resid), stream_ptr()),
+          "mul_mat_q_mfma")
+    return y

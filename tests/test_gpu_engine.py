@@ -165,3 +165,28 @@ def test_golden_greedy_decode_vs_reference(E, name):
         top2 = np.sort(logits[i])[-2:]
         if top2[1] - top2[0] > 2e-2 * max(1.0, abs(float(top2[1]))):
             assert a == int(b), (i, got, toks.tolist())
+
+
+@pytest.mark.parametrize("arch", [0, 1])
+def test_prefill_mfma_path_vs_oracle(E, oracle, arch):
+    """n_tokens >= 16 goes through the MFMA GEMMs (f16 tiles, activations not re-quantized): logits NMSE vs the reference
+    arithmetic stays within the reference's whole-layer backend tolerance (2e-3, tests/test-backend-ops.cpp:3000), and a
+    following single-token decode step continues from the KV cache the prefill wrote."""
+    torch = E.torch
+    rng = np.random.default_rng(81 + arch)
+    d = tiny_model(rng, arch=arch, n_layer=2, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=320, n_ctx=64,
+                   rope_freqs=(arch == 0), quantize=_quantizer())
+    w = E.Window(_hp(d), n_ctx=64)
+    w.load_desc(d)
+    w.finalize(max_tokens=32)
+    ho = oracle.model_new(d)
+    toks = rng.integers(0, d.n_vocab, 25).astype(np.int32)
+    hid, lg, _ = w.decode(tokens=torch.from_numpy(toks[:24]).cuda(), pos0=0)
+    h_ref, l_ref = oracle.model_eval(ho, d, tokens=toks[:24], pos0=0)
+    assert _nmse(hid.cpu().numpy(), h_ref) < 2e-3
+    assert _nmse(lg.cpu().numpy(), l_ref) < 2e-3
+    hid, lg, _ = w.decode(tokens=torch.from_numpy(toks[24:25]).cuda(), pos0=24)
+    h_ref, l_ref = oracle.model_eval(ho, d, tokens=toks[24:25], pos0=24)
+    assert _nmse(lg.cpu().numpy(), l_ref) < 2e-3
+    oracle.model_free(ho)
+    w.close()

@@ -324,3 +324,26 @@ def test_fused_qkv_mixed_types_one_launch(P, oracle):
             assert torch.equal(y, sep)
             want = oracle.mul_mat(w.type, bl, K, w.N, xn)[0] + b.cpu().numpy()
             assert np.allclose(y.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("t", QUANT_TYPES)
+@pytest.mark.parametrize("K,N,T", [(256, 132, 17), (1024, 256, 128), (768, 64, 200)])
+def test_mfma_prefill_gemm_vs_oracle(P, oracle, t, K, N, T):
+    """MFMA batched GEMM (F16 tiles, f32 accumulate, activations not re-quantized) against the reference arithmetic
+    (activations quantized to Q8_K/Q8_0): the reference's own backend tolerance is NMSE <= 5e-4
+    (tests/test-backend-ops.cpp:1660); also against an exact f64 product of the dequantized weights."""
+    rng = np.random.default_rng(71)
+    blocks = rand_blocks(t, N, K, rng, scale=1.0)
+    w = P.upload_weight(t, blocks, K, N)
+    x = rng.normal(0, 1, (T, K)).astype(np.float32)
+    bias = rng.normal(0, 1, N).astype(np.float32)
+    resid = rng.normal(0, 1, (T, N)).astype(np.float32)
+    got = P.mul_mat_mfma(w, _dev(P, x), bias=_dev(P, bias), resid=_dev(P, resid)).cpu().numpy()
+    rs = row_size(t, K)
+    Wf = np.stack([oracle.dequantize_row(t, blocks[r * rs:(r + 1) * rs], K) for r in range(N)]).astype(np.float64)
+    exact = x.astype(np.float64) @ Wf.T + bias + resid
+    nm_exact = ((got - exact) ** 2).sum() / (exact ** 2).sum()
+    assert nm_exact < 1e-6, nm_exact                       # f16 rounding of operands only
+    ref = oracle.mul_mat(t, blocks, K, N, x) + bias + resid
+    nm_ref = ((got - ref) ** 2).sum() / (ref ** 2).sum()
+    assert nm_ref < 5e-4, nm_ref
