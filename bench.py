@@ -125,6 +125,21 @@ def cpu_baseline(hp, mixture, seconds):
                       "attention excluded, which favours the CPU)"}
 
 
+def pmc_traffic(bytes_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r01_c_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE on tools/pmc_probe.py, x1024 B and the gfx950 x2 correction of MI355X_MICROARCH.md).
+    Counters cannot be read from inside the timed process, so this is the recorded measurement for the same kernel and
+    shape; None when the workload's launch does not match the recorded one."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c_pmc_traffic.json")) as f:
+            t = json.load(f)
+        if int(t["algorithmic_bytes_per_launch"]) == int(bytes_per_launch):
+            return int(t["hbm_read_bytes_per_launch"]) + int(t["hbm_write_bytes_per_launch_uncalibrated"])
+    except Exception:
+        pass
+    return None
+
+
 def probe_dominant_kernel(win, hp, iters=40):
     """Average duration of the dominant kernel (Q4_K gate/up mat-vec pair: 2 x [n_ff x n_embd] read once) measured with
     HIP events on the stream it is launched on, rotating over the real layers' weights (no cache reuse)."""
@@ -294,7 +309,8 @@ def main():
             pr = probe_dominant_kernel(win, hp)
             if pr:
                 result["roofline"] = {"bound": "hbm", "achieved": round(pr["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": round(pr["gbs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                                      "frac": round(pr["gbs"] / HBM_PEAK_GBS, 4),
+                                      "traffic": pmc_traffic(pr["bytes_per_launch"]),
                                       "kernel": pr["kernel"], "bytes_per_launch": pr["bytes_per_launch"],
                                       "avg_launch_us": round(pr["avg_us"], 2)}
             if world == 1 and a.prefill > 0:
