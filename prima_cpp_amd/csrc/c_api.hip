@@ -162,7 +162,8 @@ int pm355_mul_mat_q_mfma(int type, const void * W, int64_t K, int64_t N, const f
 }
 int pm355_mul_mat_vec_q_dbg(int type, const void * W, int64_t K, int64_t N, const void * xq, float * y,
                             int32_t * ip, int64_t * upr, pm355_stream_t st) {
-    if (upr) *upr = K / (type == PM_Q6_K ? 64 : 32);
+    if (upr) *upr = pm_gemv_units_per_row(type, K);
+    if (!ip && !y) return 0;                          // query of the unit count only
     pm_gemv_args a = {};
     a.type = type; a.K = (int) K; a.N = (int) N; a.W = W; a.xq = xq; a.ncols = 1; a.y = y; a.y_stride = (size_t) N; a.dbg_int = ip;
     return gemv_rc(pm_launch_gemv(a, S(st)));

@@ -132,8 +132,8 @@ __global__ void fix_scales_kernel(int type, uint8_t * dst, long nb_total, long n
     const long row = b / nb_row, bi = b % nb_row;
     uint8_t * r = dst + row * row_bytes;
     const float u = 0.5f + (float) (pm_hash(seed ^ (0xABCDEF12345ULL + (uint64_t) b)) & 0xFFFF) / 65536.0f;   // [0.5, 1.5)
-    if (type == PM_Q4_K || type == PM_Q5_K) {
-        uint16_t * h = (uint16_t *) (r + bi * (type == PM_Q4_K ? PM_BS_Q4_K : PM_BS_Q5_K));
+    if (type == PM_Q4_K || type == PM_Q5_K) {                         // HBM layout: Q4_K header stream at 128 nb, Q5_K native blocks
+        uint16_t * h = (uint16_t *) (type == PM_Q4_K ? r + nb_row * 128 + bi * 16 : r + bi * PM_BS_Q5_K);
         const float qmax = type == PM_Q4_K ? 15.f : 31.f;
         h[0] = f2h(u * scale / (qmax * 32.f));
         h[1] = f2h(u * scale / 64.f);
@@ -407,7 +407,7 @@ int pm355_model_set_tensor(pm355_model * m, int kind, int layer, int type, const
             (void) hipEventCreateWithFlags(&m->pin_ev[i], hipEventDisableTiming);
         }
     }
-    const bool repack = (type == PM_Q6_K || type == PM_Q8_0) && is_matrix(kind);
+    const bool repack = pm_type_is_repacked(type) && is_matrix(kind);
     const size_t rb = pm_weight_row_bytes(type, t->K);
     const size_t rows_per_chunk = repack ? (CH / rb ? CH / rb : 1) : 0;
     const size_t chunk = repack ? rows_per_chunk * rb : CH;

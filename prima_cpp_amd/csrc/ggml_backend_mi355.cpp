@@ -23,7 +23,7 @@
 
 namespace {
 
-bool is_soa_type(enum ggml_type t) { return t == GGML_TYPE_Q6_K || t == GGML_TYPE_Q8_0; }
+bool is_soa_type(enum ggml_type t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q6_K || t == GGML_TYPE_Q8_0; }   // repack.hip
 bool is_gemv_type(enum ggml_type t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K || t == GGML_TYPE_Q8_0; }
 
 struct dev_ctx { int device; std::string name, desc; };

@@ -22,29 +22,30 @@ __device__ float pm_dequant_elem(int type, const uint8_t * row, int K, int i) {
     switch (type) {
     case PM_F32: return ((const float *) row)[i];
     case PM_F16: return h2f(((const uint16_t *) row)[i]);
-    case PM_Q8_0: {                       // row-SoA: qs[K] | half d[K/32]
+    case PM_Q8_0: {                       // row-SoA: qa[nb][16] | qb[nb][16] | half d[nb]   (repack.hip)
         const float d = h2f(((const uint16_t *) (row + K))[i >> 5]);
-        return (float) ((const int8_t *) row)[i] * d;
+        const int r = i & 31;
+        return (float) ((const int8_t *) row)[(r >> 4) * (K / 2) + 16 * (i >> 5) + (r & 15)] * d;
     }
-    case PM_Q4_K:
-    case PM_Q5_K: {
+    case PM_Q4_K:                         // row-SoA: qa[U][16] | qb[U][16] | hdr[nb][16], unit = (block, j)   (repack.hip)
+    case PM_Q5_K: {                       // native 176-byte blocks
+        const long nb = K / 256;
         const int b = i >> 8, e = i & 255, s = e >> 5, l = e & 31;     // sub-block s, element l
-        const uint8_t * blk = row + (long) b * (type == PM_Q4_K ? PM_BS_Q4_K : PM_BS_Q5_K);
-        const uint32_t * h = (const uint32_t *) blk;
+        const uint8_t * blk = row + (long) b * PM_BS_Q5_K;
+        const uint32_t * h = (const uint32_t *) (type == PM_Q4_K ? row + nb * 128 + (long) b * 16 : blk);
         int sc, mn;
         k4_scale_min(h[1], h[2], h[3], s, sc, mn);
         const float d = h2f((uint16_t) (h[0] & 0xFFFF)), dmin = h2f((uint16_t) (h[0] >> 16));
-        const uint8_t * qs = blk + (type == PM_Q4_K ? 16 : 48);
-        int q = qs[32 * (s >> 1) + l];
+        int q = type == PM_Q4_K ? row[(l >> 4) * nb * 64 + 16 * (4 * (long) b + (s >> 1)) + (l & 15)] : blk[48 + 32 * (s >> 1) + l];
         q = (s & 1) ? (q >> 4) : (q & 0xF);
         if (type == PM_Q5_K) q += ((blk[16 + l] >> s) & 1) << 4;
         const float ds = d * (float) sc, ms = dmin * (float) mn;
         return ds * (float) q - ms;
     }
-    case PM_Q6_K: {                       // row-SoA: ql[nb][128] | qh[nb][64] | sc[nb][16] | d[nb]
+    case PM_Q6_K: {                       // row-SoA: la[U][16] | lb[U][16] | qh[U][16] | sc[nb][16] | d[nb], unit = (block, half, 16-col slice)
         const long nb = K / 256;
         const int b = i >> 8, e = i & 255, hh = e >> 7, r = e & 127, k = r >> 5, l = r & 31;
-        const uint8_t lq = row[(long) b * 128 + 64 * hh + 32 * (k & 1) + l];
+        const uint8_t lq = row[(k & 1) * nb * 64 + 16 * (4 * (long) b + 2 * hh + (l >> 4)) + (l & 15)];
         const uint8_t hq = row[nb * 128 + (long) b * 64 + 32 * hh + l];
         const int q = (int) (((k & 2) ? (lq >> 4) : (lq & 0xF)) | (((hq >> (2 * k)) & 3) << 4)) - 32;
         const int sc = (int) (int8_t) row[nb * 192 + (long) b * 16 + 8 * hh + 2 * k + (l >> 4)];

@@ -24,9 +24,9 @@ constexpr int BM = 128, BN = 128, BK = 64, LDS_STRIDE = BK + 8;       // halfs p
 // 32 consecutive weights k0..k0+31 (k0 % 32 == 0) of one row, exact dequantize_row_* arithmetic in f32
 template <int TYPE>
 __device__ __forceinline__ void dequant32(const uint8_t * row, int K, int k0, float (&o)[32]) {
-    if (TYPE == PM_Q8_0) {                                             // row-SoA: qs[K] | half d[K/32]
+    if (TYPE == PM_Q8_0) {                                             // row-SoA: qa[nb][16] | qb[nb][16] | half d[nb]
         const float d = h2f(((const uint16_t *) (row + K))[k0 >> 5]);
-        const u32x4 a = *(const u32x4 *) (row + k0), b = *(const u32x4 *) (row + k0 + 16);
+        const u32x4 a = *(const u32x4 *) (row + (k0 >> 1)), b = *(const u32x4 *) (row + K / 2 + (k0 >> 1));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -38,13 +38,15 @@ __device__ __forceinline__ void dequant32(const uint8_t * row, int K, int k0, fl
     }
     const int b = k0 >> 8, s = (k0 & 255) >> 5;                         // super-block, 32-value sub-block
     if (TYPE == PM_Q4_K || TYPE == PM_Q5_K) {
-        const uint8_t * blk = row + (long) b * (TYPE == PM_Q4_K ? PM_BS_Q4_K : PM_BS_Q5_K);
-        const u32x4 h = *(const u32x4 *) blk;
+        // Q4_K row-SoA: qa[U][16] | qb[U][16] | hdr[nb][16] (unit = block*4 + s/2);  Q5_K native 176-byte blocks
+        const long nb4 = K / 256;
+        const uint8_t * blk = row + (long) b * PM_BS_Q5_K;
+        const u32x4 h = *(const u32x4 *) (TYPE == PM_Q4_K ? row + nb4 * 128 + (long) b * 16 : blk);
         int sc, mn;
         k4_scale_min(h[1], h[2], h[3], s, sc, mn);
         const float ds = h2f((uint16_t) (h[0] & 0xFFFF)) * (float) sc, ms = h2f((uint16_t) (h[0] >> 16)) * (float) mn;
-        const uint8_t * qs = blk + (TYPE == PM_Q4_K ? 16 : 48) + 32 * (s >> 1);
-        const u32x4 q0 = *(const u32x4 *) qs, q1 = *(const u32x4 *) (qs + 16);
+        const uint8_t * qa = TYPE == PM_Q4_K ? row + 16 * (4 * (long) b + (s >> 1)) : blk + 48 + 32 * (s >> 1);
+        const u32x4 q0 = *(const u32x4 *) qa, q1 = *(const u32x4 *) (qa + (TYPE == PM_Q4_K ? nb4 * 64 : 16));
         u32x4 hb0 = {0, 0, 0, 0}, hb1 = {0, 0, 0, 0};
         if (TYPE == PM_Q5_K) { hb0 = *(const u32x4 *) (blk + 16); hb1 = *(const u32x4 *) (blk + 32); }
         const int sh = (s & 1) * 4;
@@ -59,10 +61,11 @@ __device__ __forceinline__ void dequant32(const uint8_t * row, int K, int k0, fl
             }
         return;
     }
-    // Q6_K row-SoA: ql[nb][128] | qh[nb][64] | sc[nb][16] | d[nb];  sub-block s -> half hh = s/4, quarter kq = s%4
+    // Q6_K row-SoA: la[U][16] | lb[U][16] | qh[U][16] | sc[nb][16] | d[nb], unit = 4 b + 2 hh + v;  sub-block s -> half
+    // hh = s/4, quarter kq = s%4: its 32 ql bytes are the pieces v = 0, 1 of stream (kq & 1)
     const long nb = K / 256;
     const int hh = s >> 2, kq = s & 3;
-    const uint8_t * ql = row + (long) b * 128 + 64 * hh + 32 * (kq & 1);
+    const uint8_t * ql = row + (kq & 1) * nb * 64 + 16 * (4 * (long) b + 2 * hh);
     const uint8_t * qh = row + nb * 128 + (long) b * 64 + 32 * hh;
     const int8_t * scl = (const int8_t *) (row + nb * 192 + (long) b * 16 + 8 * hh + 2 * kq);
     const float d = h2f(((const uint16_t *) (row + nb * 208))[b]);

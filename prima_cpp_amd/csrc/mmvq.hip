@@ -52,33 +52,40 @@ template <int NV> struct XT { uint32_t q[NV / 4]; int gs[NV / 16]; float yd; };
 
 template <int TYPE> struct QT;
 
-// ---------------------------------------------------------------- Q4_K (native 144-B blocks) -------
-// unit u = (block b, chunk c = 2j+h): qs bytes [16c, 16c+16) = low nibbles -> values 64j+16h+i, high -> +32
+// ---------------------------------------------------------------- Q4_K (row-SoA: qa | qb | hdr) -------
+// unit u = (block b = u / 4, j = u % 4): the 32 qs bytes [32j, 32j+32) = sub-blocks 2j (low nibbles, values 64j..64j+31)
+// and 2j+1 (high nibbles, values 64j+32..64j+63) -> 64 CONTIGUOUS activations, one scale decode per 64 weights.
+// HBM row: qa[U][16] (first 16 bytes of every unit) | qb[U][16] (second 16) | hdr[nb][16] (d, dmin, scales[12]): each of
+// the three wave-level loads covers ONE contiguous span (1 KB / 1 KB / 256 B), no cache line is touched by two loads.
 template <> struct QT<PM_Q4_K> {
-    static constexpr int NV = 32, LPB = 8 /*lanes per activation block*/, ABLK = 256;
+    static constexpr int NV = 64, LPB = 4, ABLK = 256;
     typedef XT<NV> X;
-    struct Wr { u32x4 q, h; };
-    static __device__ __forceinline__ int group_base(int u, int g) { const int c = u & 7; return (u >> 3) * 256 + 64 * (c >> 1) + 16 * (c & 1) + 32 * g; }
-    static __device__ __forceinline__ void issue(Wr & w, const uint8_t * row, int, int u) {
-        const uint8_t * blk = row + (long) (u >> 3) * PM_BS_Q4_K;
-        w.q = ld_nt16(blk + 16 + 16 * (u & 7));
-        w.h = ld_nt16(blk);
+    struct Wr { u32x4 q0, q1, h; };
+    static __device__ __forceinline__ int group_base(int u, int g) { return (u >> 2) * 256 + 64 * (u & 3) + 16 * g; }
+    static __device__ __forceinline__ void issue(Wr & w, const uint8_t * row /*wave-uniform*/, int K, int u) {
+        const uint32_t nb = (uint32_t) K / 256;                         // scalar stream bases + 32-bit lane offsets
+        w.q0 = ld_nt16(row + (uint32_t) u * 16u);
+        w.q1 = ld_nt16(row + nb * 64 + (uint32_t) u * 16u);
+        w.h  = ld_nt16(row + nb * 128 + ((uint32_t) u >> 2) * 16u);
     }
-    static __device__ __forceinline__ float consume(const Wr & w, const X & x, int u, int & isum, int & msum) {
-        const int j = (u & 7) >> 1;
+    static __device__ __forceinline__ float consume(const Wr & w, const X & x, int u, float acc, int & isum, int & msum) {
         int slo = 0, shi = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            slo = dot4(w.q[i] & 0x0F0F0F0Fu, x.q[i], slo);
-            shi = dot4((w.q[i] >> 4) & 0x0F0F0F0Fu, x.q[4 + i], shi);
+            slo = dot4(w.q0[i] & 0x0F0F0F0Fu, x.q[i], slo);
+            shi = dot4((w.q0[i] >> 4) & 0x0F0F0F0Fu, x.q[8 + i], shi);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            slo = dot4(w.q1[i] & 0x0F0F0F0Fu, x.q[4 + i], slo);
+            shi = dot4((w.q1[i] >> 4) & 0x0F0F0F0Fu, x.q[12 + i], shi);
         }
         int sc0, sc1, m0, m1;
-        k4_scale_min(w.h[1], w.h[2], w.h[3], 2 * j, sc0, m0);
-        k4_scale_min(w.h[1], w.h[2], w.h[3], 2 * j + 1, sc1, m1);
-        isum = sc0 * slo + sc1 * shi;
-        msum = m0 * x.gs[0] + m1 * x.gs[1];          // this unit's share of sum_s min_s * bsum_s
+        k4_scale_min_pair(w.h[1], w.h[2], w.h[3], u & 3, sc0, sc1, m0, m1);
+        isum = __mul24(sc0, slo) + __mul24(sc1, shi);                  // |slo| <= 32*15*127, scales <= 63: 24-bit safe
+        msum = __mul24(m0, x.gs[0] + x.gs[1]) + __mul24(m1, x.gs[2] + x.gs[3]);
         const float d = h2f((uint16_t) (w.h[0] & 0xFFFF)), dmin = h2f((uint16_t) (w.h[0] >> 16));
-        return x.yd * (d * (float) isum - dmin * (float) msum);
+        return fmaf(x.yd * d, (float) isum, fmaf(-(x.yd * dmin), (float) msum, acc));
     }
 };
 
@@ -87,14 +94,14 @@ template <> struct QT<PM_Q5_K> {
     static constexpr int NV = 32, LPB = 8, ABLK = 256;
     typedef XT<NV> X;
     struct Wr { u32x4 q, h, qh; };
-    static __device__ __forceinline__ int group_base(int u, int g) { return QT<PM_Q4_K>::group_base(u, g); }
+    static __device__ __forceinline__ int group_base(int u, int g) { const int c = u & 7; return (u >> 3) * 256 + 64 * (c >> 1) + 16 * (c & 1) + 32 * g; }
     static __device__ __forceinline__ void issue(Wr & w, const uint8_t * row, int, int u) {
-        const uint8_t * blk = row + (long) (u >> 3) * PM_BS_Q5_K;
-        w.q  = ld_nt16(blk + 48 + 16 * (u & 7));
-        w.qh = ld_nt16(blk + 16 + 16 * (u & 1));
-        w.h  = ld_nt16(blk);
+        const uint32_t hb = (uint32_t) (u >> 3) * PM_BS_Q5_K;
+        w.q  = ld_nt16(row + (hb + 48u + 16u * (uint32_t) (u & 7)));
+        w.qh = ld_nt16(row + (hb + 16u + 16u * (uint32_t) (u & 1)));
+        w.h  = ld_nt16(row + hb);
     }
-    static __device__ __forceinline__ float consume(const Wr & w, const X & x, int u, int & isum, int & msum) {
+    static __device__ __forceinline__ float consume(const Wr & w, const X & x, int u, float acc, int & isum, int & msum) {
         const int j = (u & 7) >> 1;
         int slo = 0, shi = 0;
 #pragma unroll
@@ -105,33 +112,32 @@ template <> struct QT<PM_Q5_K> {
             shi = dot4(hi, x.q[4 + i], shi);
         }
         int sc0, sc1, m0, m1;
-        k4_scale_min(w.h[1], w.h[2], w.h[3], 2 * j, sc0, m0);
-        k4_scale_min(w.h[1], w.h[2], w.h[3], 2 * j + 1, sc1, m1);
-        isum = sc0 * slo + sc1 * shi;
-        msum = m0 * x.gs[0] + m1 * x.gs[1];
+        k4_scale_min_pair(w.h[1], w.h[2], w.h[3], j, sc0, sc1, m0, m1);
+        isum = __mul24(sc0, slo) + __mul24(sc1, shi);
+        msum = __mul24(m0, x.gs[0]) + __mul24(m1, x.gs[1]);
         const float d = h2f((uint16_t) (w.h[0] & 0xFFFF)), dmin = h2f((uint16_t) (w.h[0] >> 16));
-        return x.yd * (d * (float) isum - dmin * (float) msum);
+        return fmaf(x.yd * d, (float) isum, fmaf(-(x.yd * dmin), (float) msum, acc));
     }
 };
 
 // ---------------------------------------------------------------- Q6_K (row-SoA) --------------------
-// row: ql[nb][128] | qh[nb][64] | scales[nb][16] | d[nb]      unit = (block b, half hh, 16-col slice v)
+// row: la[U][16] | lb[U][16] | qh[U][16] | scales[nb][16] | d[nb]      unit u = 4b + 2hh + v = (block b, half hh, 16-col slice v)
+//      la = ql[64hh+16v, +16), lb = ql[64hh+32+16v, +16), qh = qh[32hh+16v, +16): every load is one contiguous span per wave
 template <> struct QT<PM_Q6_K> {
     static constexpr int NV = 64, LPB = 4, ABLK = 256;
     typedef XT<NV> X;
     struct Wr { u32x4 l0, l1, h; u32x2 s; uint16_t d; };
     static __device__ __forceinline__ int group_base(int u, int g) { return (u >> 2) * 256 + 128 * ((u >> 1) & 1) + 32 * g + 16 * (u & 1); }
     static __device__ __forceinline__ void issue(Wr & w, const uint8_t * row, int K, int u) {
-        const long nb = K / 256;
-        const int b = u >> 2, hh = (u >> 1) & 1, v = u & 1;
-        const uint8_t * ql = row + (long) b * 128 + 64 * hh + 16 * v;
-        w.l0 = ld_nt16(ql);
-        w.l1 = ld_nt16(ql + 32);
-        w.h  = ld_nt16(row + nb * 128 + (long) b * 64 + 32 * hh + 16 * v);
-        w.s  = ld_nt8(row + nb * 192 + (long) b * 16 + 8 * hh);
-        w.d  = ld_nt2(row + nb * 208 + (long) b * 2);
+        const uint32_t nb = (uint32_t) K / 256;                         // wave-uniform stream bases, 32-bit lane offsets
+        const uint32_t b = (uint32_t) u >> 2, hh = ((uint32_t) u >> 1) & 1;
+        w.l0 = ld_nt16(row + (uint32_t) u * 16u);
+        w.l1 = ld_nt16(row + nb * 64 + (uint32_t) u * 16u);
+        w.h  = ld_nt16(row + nb * 128 + (uint32_t) u * 16u);
+        w.s  = ld_nt8(row + nb * 192 + (b * 16 + 8 * hh));
+        w.d  = ld_nt2(row + nb * 208 + b * 2);
     }
-    static __device__ __forceinline__ float consume(const Wr & w, const X & x, int u, int & isum, int & msum) {
+    static __device__ __forceinline__ float consume(const Wr & w, const X & x, int u, float facc, int & isum, int & msum) {
         const int v = u & 1;
         int acc[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -147,31 +153,32 @@ template <> struct QT<PM_Q6_K> {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int sc = (int) (int8_t) (s8 >> (8 * (v + 2 * k)));
-            isum += sc * (acc[k] - 32 * x.gs[k]);            // sum (q-32)*a = sum q*a - 32*sum a
+            isum += __mul24(sc, acc[k] - 32 * x.gs[k]);      // sum (q-32)*a = sum q*a - 32*sum a   (|.| <= 16*63*127)
         }
         msum = 0;
-        return x.yd * h2f(w.d) * (float) isum;
+        return fmaf(x.yd * h2f(w.d), (float) isum, facc);
     }
 };
 
 // ---------------------------------------------------------------- Q8_0 (row-SoA) --------------------
-// row: qs[nb32][32] | d[nb32];  activations quantized to Q8_0 (32-blocks, fp16 d).   unit = one 32-block
+// row: qa[nb32][16] | qb[nb32][16] | d[nb32] (first / second 16 int8 of every block); activations quantized to Q8_0
+// (32-blocks, fp16 d).   unit = one 32-block
 template <> struct QT<PM_Q8_0> {
     static constexpr int NV = 32, LPB = 1, ABLK = 32;
     typedef XT<NV> X;
     struct Wr { u32x4 q0, q1; uint16_t d; };
     static __device__ __forceinline__ int group_base(int u, int g) { return u * 32 + 16 * g; }
     static __device__ __forceinline__ void issue(Wr & w, const uint8_t * row, int K, int u) {
-        w.q0 = ld_nt16(row + (long) u * 32);
-        w.q1 = ld_nt16(row + (long) u * 32 + 16);
-        w.d  = ld_nt2(row + (long) K + (long) u * 2);
+        w.q0 = ld_nt16(row + (uint32_t) u * 16u);
+        w.q1 = ld_nt16(row + (uint32_t) K / 2 + (uint32_t) u * 16u);
+        w.d  = ld_nt2(row + (uint32_t) K + (uint32_t) u * 2u);
     }
-    static __device__ __forceinline__ float consume(const Wr & w, const X & x, int, int & isum, int & msum) {
+    static __device__ __forceinline__ float consume(const Wr & w, const X & x, int, float acc, int & isum, int & msum) {
         int s = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s = dot4(w.q0[i], x.q[i], s); s = dot4(w.q1[i], x.q[4 + i], s); }
         isum = s; msum = 0;
-        return (float) s * (h2f(w.d) * x.yd);
+        return fmaf((float) s, h2f(w.d) * x.yd, acc);
     }
 };
 
@@ -359,10 +366,13 @@ template <int TYPE, bool PAIR> struct Item {
 #define PM_CH64 1
 #endif
 #ifndef PM_RSINGLE
-#define PM_RSINGLE 2
+#define PM_RSINGLE 1
+#endif
+#ifndef PM_RPAIR
+#define PM_RPAIR 1
 #endif
     static constexpr int CH = T::NV == 64 ? PM_CH64 : PM_CH32;   // units per lane per row and register set (two sets in flight)
-    static constexpr int R  = PAIR ? 1 : PM_RSINGLE;              // rows in flight per wave
+    static constexpr int R  = PAIR ? PM_RPAIR : PM_RSINGLE;              // rows in flight per wave
     struct Regs { typename T::Wr w[R][NM][CH]; };
 
     // unconditional loads (row / unit clamped): conditional loads make the compiler drain the VMEM queue
@@ -388,13 +398,13 @@ template <int TYPE, bool PAIR> struct Item {
             const int u = min(uu, jb.U - 1);
             typename T::X x;
             load_x_lds<TYPE>(x, xs, u);
+            x.yd = uv ? x.yd : 0.0f;                 // a clamped (out-of-row) unit contributes exactly 0
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
                     int isum, msum;
-                    const float c = T::consume(g.w[r][m][i], x, u, isum, msum);
-                    acc[r][m] += uv ? c : 0.0f;
+                    acc[r][m] = T::consume(g.w[r][m][i], x, u, acc[r][m], isum, msum);
                     if (DBG) if (uv && row + r < r1) {
                         int32_t * o = p.dbg + ((long) (m * jb.N + row + r) * jb.U + u) * 2;
                         o[0] = isum; o[1] = msum;
@@ -476,7 +486,10 @@ __global__ __launch_bounds__(PM_GEMV_BLOCK, PM_GEMV_BLOCK == 256 ? 4 : 4) void g
     int *    xs_gs = (int *) (smem + ((p.K + 15) & ~15));               // [K/16]
     float *  xs_d  = (float *) (xs_gs + p.K / 16);                      // [K/ABLK]
     float *  outbuf = xs_d + ((p.K / ABLK + 3) & ~3);                   // [sum of this workgroup's rows]
-    const int b = blockIdx.x, G = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, G = gridDim.x, tid = threadIdx.x, lane = tid & 63;
+    // wave index as a SCALAR: everything derived from it (row numbers, row base pointers, loop counters) then lives in
+    // SGPRs and the weight loads use the saddr + 32-bit-voffset form instead of 64-bit VALU address arithmetic
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // this workgroup's slice [r0, r1) of every job, and the ITEM list = concatenation of the jobs' R-row groups
     // this workgroup's slice [r0, r1) of every job (scalars, not arrays: a runtime-indexed array would live in scratch)
@@ -531,11 +544,13 @@ int launch_types(const GemvP & p, bool pair, int grid, size_t lds, bool dbg, hip
     return 0;
 }
 
-int nv_of(int type) { return type == PM_Q6_K ? 64 : 32; }
+int nv_of(int type) { return type == PM_Q4_K ? QT<PM_Q4_K>::NV : type == PM_Q6_K ? 64 : 32; }
 
 bool type_ok(int t) { return t == PM_Q4_K || t == PM_Q5_K || t == PM_Q6_K || t == PM_Q8_0; }
 
 } // namespace
+
+int pm_gemv_units_per_row(int type, int64_t K) { return (int) (K / nv_of(type)); }
 
 size_t pm_weight_row_bytes(int type, int64_t K) {
     switch (type) {

@@ -95,3 +95,15 @@ __device__ __forceinline__ void k4_scale_min(uint32_t s0, uint32_t s1, uint32_t 
     sc = j < 4 ? sc_lo : sc_hi;
     mn = j < 4 ? mn_lo : mn_hi;
 }
+
+// Both 6-bit scale/min numbers (2p, 2p+1) of pair p (0..3) at once, branch-free, on 16-bit byte pairs.
+__device__ __forceinline__ void k4_scale_min_pair(uint32_t s0, uint32_t s1, uint32_t s2, int p, int & sc0, int & sc1, int & m0, int & m1) {
+    const int sh = 16 * (p & 1);
+    const uint32_t a = s0 >> sh, b = s1 >> sh, c = s2 >> sh;           // bytes (2p, 2p+1) mod 4 of each scale dword
+    const uint32_t sc_lo = a & 0x3f3fu, m_lo = b & 0x3f3fu;            // numbers 0..3: low 6 bits of bytes 0..3 / 4..7
+    const uint32_t sc_hi = (c & 0x0f0fu) | ((a & 0xc0c0u) >> 2);       // numbers 4..7: nibbles of bytes 8..11 + top 2 bits
+    const uint32_t m_hi  = ((c >> 4) & 0x0f0fu) | ((b & 0xc0c0u) >> 2);
+    const uint32_t sc = p < 2 ? sc_lo : sc_hi, m = p < 2 ? m_lo : m_hi;
+    sc0 = (int) (sc & 0xFF); sc1 = (int) (sc >> 8);
+    m0  = (int) (m & 0xFF);  m1  = (int) (m >> 8);
+}

@@ -13,12 +13,16 @@ size_t pm_weight_row_bytes(int type, int64_t K);
 // row STRIDE in HBM: == row bytes except that the trailing fp16 scale stream of the row-SoA layouts
 // (Q6_K, Q8_0) is padded to 16 B so every row (and every field stream) starts 16-B aligned for any K
 size_t pm_weight_row_stride(int type, int64_t K);
+int pm_gemv_units_per_row(int type, int64_t K);
+  // units of the mat-vec's per-(row, unit) debug partials
+// HBM layout != GGUF block order (repack.hip): Q4_K (12), Q6_K (14), Q8_0 (8)
+static inline bool pm_type_is_repacked(int type) { return type == 12 || type == 14 || type == 8; }
 
 void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStream_t st);
 void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStream_t st);
 void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st);
 
-// weight repack (row-local, bijective):  GGUF block order <-> HBM row-SoA (Q6_K, Q8_0); identity for the rest
+// weight repack (row-local, bijective):  GGUF block order <-> HBM row-SoA (Q4_K, Q6_K, Q8_0); identity for the rest
 void pm_launch_repack(int type, const void * src, void * dst, int64_t K, int64_t nrows, int to_device_layout, hipStream_t st);
 
 // y[N] = W[N,K] . xq (+bias)(+resid);  optional second matrix W2 (same type/shape): y = silu(W.x) * (W2.x)

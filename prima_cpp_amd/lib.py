@@ -19,7 +19,8 @@ class PM355Error(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "libprima_mi355.so")
+    """In-tree library; PM355_LIB selects another build of the same C ABI (A/B kernel experiments)."""
+    return os.environ.get("PM355_LIB") or os.path.join(HERE, "libprima_mi355.so")
 
 
 _lib = None

@@ -34,7 +34,7 @@ def upload_weight(qtype, blocks, K, N):
     blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1)
     assert blocks.size == L.row_size(qtype, K) * N, (blocks.size, L.row_size(qtype, K) * N)
     raw = torch.from_numpy(blocks).to(_dev())
-    if qtype in (Q6_K, Q8_0):
+    if qtype in (Q4_K, Q6_K, Q8_0):
         dst = torch.zeros(N * lib.pm355_row_stride(qtype, K), dtype=torch.uint8, device=raw.device)
         check(lib.pm355_repack_rows(qtype, ptr(raw), ptr(dst), K, N, 1, stream_ptr()), "repack_rows")
         return QWeight(qtype, K, N, dst)
@@ -44,7 +44,7 @@ def upload_weight(qtype, blocks, K, N):
 def download_weight(w):
     """ggml_backend_tensor_get semantics: HBM layout -> host GGUF-order bytes."""
     lib = L.load()
-    if w.type in (Q6_K, Q8_0):
+    if w.type in (Q4_K, Q6_K, Q8_0):
         tmp = torch.empty(w.N * L.row_size(w.type, w.K), dtype=torch.uint8, device=w.data.device)
         check(lib.pm355_repack_rows(w.type, ptr(w.data), ptr(tmp), w.K, w.N, 0, stream_ptr()), "repack_rows")
         return tmp.cpu().numpy()
@@ -106,7 +106,8 @@ def mul_mat_vec_dbg(w, xq):
     import ctypes as C
     lib = L.load()
     upr = C.c_int64(0)
-    units = w.K // (64 if w.type == Q6_K else 32)
+    check(lib.pm355_mul_mat_vec_q_dbg(w.type, None, w.K, w.N, None, None, None, C.addressof(upr), None), "units query")
+    units = int(upr.value)
     y = torch.empty(w.N, dtype=torch.float32, device=w.data.device)
     ip = torch.zeros((w.N, units, 2), dtype=torch.int32, device=w.data.device)
     check(lib.pm355_mul_mat_vec_q_dbg(w.type, ptr(w.data), w.K, w.N, ptr(xq), ptr(y), ptr(ip), C.addressof(upr),

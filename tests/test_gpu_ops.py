@@ -77,7 +77,8 @@ def test_repack_roundtrip_bitexact(P, t, K):
     blocks = rand_blocks(t, N, K, rng)
     w = P.upload_weight(t, blocks, K, N)
     assert np.array_equal(P.download_weight(w), blocks)
-    if t in (Q6_K, Q8_0):      # and the HBM image is the documented row-SoA permutation (rows 16-B aligned)
+    if t in (Q4_K, Q6_K, Q8_0):  # and the HBM image is the documented row-SoA permutation (rows 16-B aligned):
+        # one stream per 16-byte piece a lane loads (repack.hip)
         stride = P.L.load().pm355_row_stride(t, K)
         assert stride % 16 == 0 and 0 <= stride - row_size(t, K) < 16
         img = w.data.cpu().numpy().reshape(N, stride)[:, :row_size(t, K)]
@@ -85,12 +86,22 @@ def test_repack_roundtrip_bitexact(P, t, K):
         if t == Q6_K:
             nb = K // 256
             b = src.reshape(N, nb, 210)
-            want = np.concatenate([b[:, :, :128].reshape(N, -1), b[:, :, 128:192].reshape(N, -1),
+            ql = b[:, :, :128].reshape(N, nb, 2, 2, 2, 16)          # [block][half hh][second][v][16]
+            la = ql[:, :, :, 0].reshape(N, -1)                       # unit order (b, hh, v)
+            lb = ql[:, :, :, 1].reshape(N, -1)
+            want = np.concatenate([la, lb, b[:, :, 128:192].reshape(N, -1),
                                    b[:, :, 192:208].reshape(N, -1), b[:, :, 208:].reshape(N, -1)], axis=1)
+        elif t == Q4_K:
+            nb = K // 256
+            b = src.reshape(N, nb, 144)
+            qs = b[:, :, 16:].reshape(N, nb, 4, 2, 16)               # [block][j][second][16]
+            want = np.concatenate([qs[:, :, :, 0].reshape(N, -1), qs[:, :, :, 1].reshape(N, -1),
+                                   b[:, :, :16].reshape(N, -1)], axis=1)
         else:
             nb = K // 32
             b = src.reshape(N, nb, 34)
-            want = np.concatenate([b[:, :, 2:].reshape(N, -1), b[:, :, :2].reshape(N, -1)], axis=1)
+            qs = b[:, :, 2:].reshape(N, nb, 2, 16)
+            want = np.concatenate([qs[:, :, 0].reshape(N, -1), qs[:, :, 1].reshape(N, -1), b[:, :, :2].reshape(N, -1)], axis=1)
         assert np.array_equal(img, want)
 
 
@@ -106,7 +117,7 @@ def test_gemv_integer_partials_bitexact_and_float_close(P, oracle, t, K, N):
     y, ip = y.cpu().numpy(), ip.cpu().numpy().astype(np.int64)
     a = oracle.quantize_act(t, x)
     rs = row_size(t, K)
-    upb = {Q4_K: 8, Q5_K: 8, Q6_K: 4, Q8_0: 1}[t]
+    upb = ip.shape[1] // (K // (32 if t == Q8_0 else 256))      # units per activation block
     for r in range(N):
         wr = blocks[r * rs:(r + 1) * rs]
         isum, msum = oracle.int_partials(t, K, wr, a)

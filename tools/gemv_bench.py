@@ -30,7 +30,7 @@ def rand_weight(t, K, N):
         v[:, :, 0:2] = h
         v[:, :, 2:4] = h
     w = P.QWeight(t, K, N, raw.view(-1))
-    if t in (Q6_K, Q8_0):
+    if t in (Q4_K, Q6_K, Q8_0):
         dst = torch.empty(N * P.L.load().pm355_row_stride(t, K), dtype=torch.uint8, device="cuda")
         P.check(P.L.load().pm355_repack_rows(t, raw.data_ptr(), dst.data_ptr(), K, N, 1, P.stream_ptr()), "repack")
         w = P.QWeight(t, K, N, dst)
