@@ -162,6 +162,10 @@ PM355_API int pm355_add(const float * a, const float * b, float * y, int64_t n, 
 PM355_API int pm355_mul(const float * a, const float * b, float * y, int64_t n, int64_t nb, pm355_stream_t stream);
 PM355_API int pm355_silu_mul(const float * g, const float * u, float * y, int64_t n, pm355_stream_t stream);
 PM355_API int pm355_scale(const float * a, float * y, float s, int64_t n, pm355_stream_t stream);
+/* measurement helper (bench.py "measured HBM read ceiling"): streams `bytes` from HBM exactly once with the
+ * mat-vec's access pattern (one 1024-thread workgroup per CU x wg_per_cu, every wave reads its own contiguous span with
+ * `unroll` (4 or 8) 16-byte non-temporal loads in flight per lane); `sink` = 4 writable bytes. Not on the product path. */
+PM355_API int pm355_probe_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, pm355_stream_t stream);
 /* synthetic weights generated directly in HBM (bench): random VALID blocks of `type`, |w| ~ scale */
 PM355_API int pm355_fill_random_blocks(int type, void * dst, int64_t K, int64_t nrows, uint64_t seed, float scale,
                                        pm355_stream_t stream);

@@ -218,5 +218,9 @@ int pm355_fill_random_blocks(int type, void * dst, int64_t K, int64_t nrows, uin
     if (!pm_weight_row_bytes(type, K)) return fail(PM355_E_UNSUPPORTED, "fill_random_blocks: type");
     pm_launch_fill_random_blocks(type, dst, K, nrows, seed, scale, S(st)); HIP_TRY(hipGetLastError()); return 0;
 }
+int pm355_probe_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, pm355_stream_t st) {
+    if (pm_launch_stream_read(src, bytes, wg_per_cu, unroll, sink, S(st))) return fail(PM355_E_SHAPE, "probe_stream_read: buffer too small");
+    HIP_TRY(hipGetLastError()); return 0;
+}
 
 } // extern "C"

@@ -204,37 +204,70 @@ __device__ __forceinline__ int wave_min_keep(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-// one wave, 4 consecutive values per lane = one 256-block (quantize_row_q8_K_ref)
-__device__ __forceinline__ void q8k_block_to_lds(const float v[4], int lane, int8_t * xs_q, int * xs_gs, float * xs_d, int blk) {
-    const float a0 = fabsf(v[0]), a1 = fabsf(v[1]), a2 = fabsf(v[2]), a3 = fabsf(v[3]);
-    float amax = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
-    // wave max (identity 0 is fine: |x| >= 0)
-    amax = fmaxf(amax, dpp_f<0xB1>(amax)); amax = fmaxf(amax, dpp_f<0x4E>(amax)); amax = fmaxf(amax, dpp_f<0x141>(amax));
-    amax = fmaxf(amax, dpp_f<0x140>(amax));
-    amax = fmaxf(amax, dpp_f<0x142, 0xA>(amax)); amax = fmaxf(amax, dpp_f<0x143, 0xC>(amax));      // lane 63 = wave max
-    amax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, amax), 63));
-    uint32_t packed = 0; int psum = 0;
-    if (amax != 0.0f) {
-        int key = 0x7fffffff;                        // lowest index with |x| == amax; low bit = its sign
-        if (a3 == amax) key = ((4 * lane + 3) << 1) | (v[3] < 0.0f);
-        if (a2 == amax) key = ((4 * lane + 2) << 1) | (v[2] < 0.0f);
-        if (a1 == amax) key = ((4 * lane + 1) << 1) | (v[1] < 0.0f);
-        if (a0 == amax) key = ((4 * lane + 0) << 1) | (v[0] < 0.0f);
-        key = wave_min_keep(key);
-        const float iscale = -127.f / ((key & 1) ? -amax : amax);
+// Row-of-16-lanes reductions (DPP quad_perm x2, row_half_mirror, row_mirror): every lane of the row gets the result.
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ int row16_min(int v) {
+    v = min(v, dpp_keep_i<0xB1>(v)); v = min(v, dpp_keep_i<0x4E>(v)); v = min(v, dpp_keep_i<0x141>(v)); v = min(v, dpp_keep_i<0x140>(v));
+    return v;
+}
+// f64 wave sum through DPP on the two dword halves (no LDS traffic); total returned in every lane
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_d(double v) {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (uint32_t) u, CTRL, ROW_MASK, 0xF, true);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (uint32_t) (u >> 32), CTRL, ROW_MASK, 0xF, true);
+    return __builtin_bit_cast(double, ((uint64_t) hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_d<0xB1>(v); v += dpp_d<0x4E>(v); v += dpp_d<0x141>(v); v += dpp_d<0x140>(v);
+    v += dpp_d<0x142, 0xA>(v); v += dpp_d<0x143, 0xC>(v);
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) u, 63), hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (u >> 32), 63);
+    return __builtin_bit_cast(double, ((uint64_t) hi << 32) | lo);
+}
+
+// One ROW of 16 lanes = one 256-block (quantize_row_q8_K_ref): lane j holds v[k][i] = x[64k + 4j + i]. Four blocks per
+// wave instruction stream: every workgroup quantizes the whole activation row redundantly, so the per-block instruction
+// count (not bytes) is what the prologue costs - 16 lanes x 16 values needs 4 DPP steps per reduction and a quarter of
+// the instructions of the one-block-per-wave form.
+__device__ __forceinline__ void q8k_rows_to_lds(const float (&v)[4][4], int j, bool valid, int8_t * xs_q, int * xs_gs, float * xs_d, int blk) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fabsf(v[k][i]));
+    amax = row16_max(amax);
+    int key = 0x7fffffff;                            // lowest index with |x| == amax; low bit = its sign
+#pragma unroll
+    for (int k = 3; k >= 0; --k)
+#pragma unroll
+        for (int i = 3; i >= 0; --i)
+            key = fabsf(v[k][i]) == amax ? (((64 * k + 4 * j + i) << 1) | (v[k][i] < 0.0f ? 1 : 0)) : key;
+    key = row16_min(key);
+    const float iscale = amax != 0.0f ? -127.f / ((key & 1) ? -amax : amax) : 0.0f;
+    uint32_t packed[4]; int psum[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        packed[k] = 0; psum[k] = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int q = nearest_int_rne(iscale * v[i]);
+            int q = nearest_int_rne(iscale * v[k][i]);
             q = q > 127 ? 127 : q;
-            psum += q; packed |= (uint32_t) (q & 0xFF) << (8 * i);
+            psum[k] += q; packed[k] |= (uint32_t) (q & 0xFF) << (8 * i);
         }
-        if (lane == 0) xs_d[blk] = 1 / iscale;
-    } else if (lane == 0) {
-        xs_d[blk] = 0.0f;
+        psum[k] += dpp_i<0xB1>(psum[k]); psum[k] += dpp_i<0x4E>(psum[k]);       // 16 consecutive values = one quad of lanes
     }
-    ((uint32_t *) xs_q)[blk * 64 + lane] = packed;
-    psum += dpp_i<0xB1>(psum); psum += dpp_i<0x4E>(psum);       // 16 values = one quad
-    if ((lane & 3) == 0) xs_gs[blk * 16 + (lane >> 2)] = psum;
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ((uint32_t *) xs_q)[blk * 64 + 16 * k + j] = packed[k];
+            if ((j & 3) == 0) xs_gs[blk * 16 + 4 * k + (j >> 2)] = psum[k];
+        }
+        if (j == 0) xs_d[blk] = amax != 0.0f ? 1 / iscale : 0.0f;
+    }
 }
 
 // 8 lanes x 4 values = one 32-block (quantize_row_q8_0_ref)
@@ -253,9 +286,60 @@ __device__ __forceinline__ void q80_block_to_lds(const float v[4], int i4 /*inde
     if ((i4 & 7) == 0) xs_d[i4 >> 3] = h2f(f2h(d));
 }
 
+// The prologue is split in two so that the kernel can put the first steps' WEIGHT loads in flight between them: the
+// activation loads are issued first (they return first: VMEM returns in order), the weight loads queue up behind them
+// and travel from HBM while the workgroup normalizes / quantizes the activation row.
+//   ABLK = 256 (Q8_K): wave w, lane (r = lane / 16, j = lane % 16), pass t handles block 4 (w + 16 t) + r; f[t][k] is the
+//                      float4 at element 64 k + 4 j of that block. Two passes (K <= 32768; K <= 16384 with norm weights)
+//                      are loaded ONCE and stay in registers between the sum-of-squares and the quantization.
+//   ABLK = 32  (Q8_0): thread t owns the float4s t, t + 1024, ... (8 lanes = one 32-block); K <= 16384 held in registers.
+#define PM_PRE2 1     // non-pair launches put their first TWO steps in flight before the activation prologue
+struct ActRegs { float4 f[2][4]; float4 g[4]; };
+
 template <int ABLK>
-__device__ __forceinline__ void stage_activation(const GemvP & p, int8_t * xs_q, int * xs_gs, float * xs_d, double * nred) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ bool act_held(const GemvP & p) {
+    if (p.xmode == 0) return false;
+    if (ABLK == 256) return p.K / 256 <= (p.xmode == 2 ? 64 : 128);
+    return p.K / 4 <= 4 * PM_GEMV_BLOCK;
+}
+
+template <int ABLK>
+__device__ __forceinline__ void stage_issue(const GemvP & p, ActRegs & a, int wave, int lane) {
+    if (!act_held<ABLK>(p)) return;
+    const float4 * xf4 = (const float4 *) p.xf, * nw4 = (const float4 *) p.norm_w;
+    if (ABLK == 256) {
+        const int nblk = p.K / 256, r = lane >> 4, j = lane & 15;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) if (64 * t < nblk) {
+            const int B = min(4 * (wave + PM_GEMV_NW * t) + r, nblk - 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a.f[t][k] = xf4[B * 64 + 16 * k + j];
+        }
+        if (p.xmode == 2) {
+            const int B = min(4 * wave + r, nblk - 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a.g[k] = nw4[B * 64 + 16 * k + j];
+        }
+    } else {
+        const int tid = threadIdx.x, n4 = p.K / 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + k * PM_GEMV_BLOCK;
+            a.f[0][k] = xf4[i < n4 ? i : 0];
+            if (p.xmode == 2) a.g[k] = nw4[i < n4 ? i : 0];
+        }
+    }
+}
+
+__device__ __forceinline__ double sumsq4(const float4 & f) {
+    double s = (double) (f.x * f.x); s += (double) (f.y * f.y); s += (double) (f.z * f.z); s += (double) (f.w * f.w);
+    return s;
+}
+
+template <int ABLK>
+__device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_t * xs_q, int * xs_gs, float * xs_d, double * nred,
+                                             int wave, int lane) {
+    const int tid = threadIdx.x;
     const int K = p.K;
     if (p.xmode == 0) {
         // pre-quantized row-SoA: int8 qs[K] | scales. Copy + group sums.
@@ -271,45 +355,27 @@ __device__ __forceinline__ void stage_activation(const GemvP & p, int8_t * xs_q,
             xs_d[b] = ABLK == 256 ? ((const float *) (p.xq + K))[b] : h2f(((const uint16_t *) (p.xq + K))[b]);
         return;
     }
-    // f32 activation. Thread t owns the float4s t, t+512, t+1024, ...: float4 number i belongs to 256-block i/64, i.e.
-    // wave w owns blocks w, w+8, w+16, ... with lane = position inside the block - the same ownership for the
-    // sum-of-squares pass and for the quantization pass, so the values are loaded ONCE (one exposed L2 latency, all
-    // loads issued back to back) and stay in registers in between. Longer rows (K > 8192) go in groups of 4 float4s per thread.
-    constexpr int NB = 4;                            // float4s per thread in flight at a time (register budget: 128)
+    const float4 * xf4 = (const float4 *) p.xf, * nw4 = (const float4 *) p.norm_w;
     const int n4 = K / 4;
-    const bool one_group = n4 <= NB * PM_GEMV_BLOCK; // K <= 8192: everything this thread needs fits in registers
-    float4 f[NB], g[NB];
+    const bool held = act_held<ABLK>(p);
+    const int nblk = K / 256, r = lane >> 4, j = lane & 15;
     float scale = 1.0f;
-    if (one_group) {
-        // ONE exposed load latency for the whole prologue: x and the norm weights are requested together and x stays in
-        // registers across the sum-of-squares barrier.
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int i = tid + k * PM_GEMV_BLOCK;
-            f[k] = ((const float4 *) p.xf)[i < n4 ? i : 0];
-            if (p.xmode == 2) g[k] = ((const float4 *) p.norm_w)[i < n4 ? i : 0];
-        }
-    }
     if (p.xmode == 2) {
-        double ss = 0.0;                             // sum of f32-rounded squares in f64, like the reference
-        if (one_group) {
+        // sum of the f32-rounded squares in f64 like the reference (ggml.c:11975-11980); any summation order of <= 2^15
+        // f64 terms agrees with the sequential one after the final rounding to f32
+        double ss = 0.0;
+        if (held && ABLK == 256) {
+            if (4 * wave + r < nblk) {
 #pragma unroll
-            for (int k = 0; k < NB; ++k) if (tid + k * PM_GEMV_BLOCK < n4) {
-                ss += (double) (f[k].x * f[k].x); ss += (double) (f[k].y * f[k].y); ss += (double) (f[k].z * f[k].z); ss += (double) (f[k].w * f[k].w);
+                for (int k = 0; k < 4; ++k) ss += sumsq4(a.f[0][k]);
             }
+        } else if (held) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (tid + k * PM_GEMV_BLOCK < n4) ss += sumsq4(a.f[0][k]);
         } else {
-            for (int i0 = tid; i0 < n4; i0 += NB * PM_GEMV_BLOCK) {
-                float4 t[NB];
-#pragma unroll
-                for (int k = 0; k < NB; ++k) { const int i = i0 + k * PM_GEMV_BLOCK; t[k] = ((const float4 *) p.xf)[i < n4 ? i : 0]; }
-#pragma unroll
-                for (int k = 0; k < NB; ++k) if (i0 + k * PM_GEMV_BLOCK < n4) {
-                    ss += (double) (t[k].x * t[k].x); ss += (double) (t[k].y * t[k].y); ss += (double) (t[k].z * t[k].z); ss += (double) (t[k].w * t[k].w);
-                }
-            }
+            for (int i = tid; i < n4; i += PM_GEMV_BLOCK) ss += sumsq4(xf4[i]);
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        ss = wave_sum_f64(ss);
         if (lane == 0) nred[wave] = ss;
         __syncthreads();
         double tot = 0.0;
@@ -318,23 +384,46 @@ __device__ __forceinline__ void stage_activation(const GemvP & p, int8_t * xs_q,
         const float mean = (float) (tot / K);
         scale = 1.0f / sqrtf(mean + p.eps);
     }
-    for (int i0 = tid; i0 < n4; i0 += NB * PM_GEMV_BLOCK) {
-        if (!one_group) {
+    if (ABLK == 256) {
+        auto rows = [&](const float4 (&f)[4], const float4 (&g)[4], int B) __attribute__((always_inline)) {
+            float v[4][4];
 #pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                const int i = i0 + k * PM_GEMV_BLOCK;
-                f[k] = ((const float4 *) p.xf)[i < n4 ? i : 0];
-                if (p.xmode == 2) g[k] = ((const float4 *) p.norm_w)[i < n4 ? i : 0];
+            for (int k = 0; k < 4; ++k) {
+                v[k][0] = f[k].x; v[k][1] = f[k].y; v[k][2] = f[k].z; v[k][3] = f[k].w;
+                if (p.xmode == 2) { v[k][0] = v[k][0] * scale * g[k].x; v[k][1] = v[k][1] * scale * g[k].y; v[k][2] = v[k][2] * scale * g[k].z; v[k][3] = v[k][3] * scale * g[k].w; }
+            }
+            q8k_rows_to_lds(v, j, B < nblk, xs_q, xs_gs, xs_d, B);
+        };
+        if (held) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) if (4 * (wave + PM_GEMV_NW * t) < nblk) rows(a.f[t], a.g, 4 * (wave + PM_GEMV_NW * t) + r);
+        } else {
+            for (int B0 = 4 * wave; B0 < nblk; B0 += 4 * PM_GEMV_NW) {
+                const int Bc = min(B0 + r, nblk - 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a.f[0][k] = xf4[Bc * 64 + 16 * k + j]; if (p.xmode == 2) a.g[k] = nw4[Bc * 64 + 16 * k + j]; }
+                rows(a.f[0], a.g, B0 + r);
             }
         }
+    } else {
+        for (int i0 = tid; i0 < n4; i0 += 4 * PM_GEMV_BLOCK) {
+            if (!held) {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int i = i0 + k * PM_GEMV_BLOCK;
-            if (i - lane < n4) {                     // wave-uniform: whole 256-blocks (and 32-blocks) are in or out
-                float v[4] = {f[k].x, f[k].y, f[k].z, f[k].w};
-                if (p.xmode == 2) { v[0] = v[0] * scale * g[k].x; v[1] = v[1] * scale * g[k].y; v[2] = v[2] * scale * g[k].z; v[3] = v[3] * scale * g[k].w; }
-                if (ABLK == 256) q8k_block_to_lds(v, lane, xs_q, xs_gs, xs_d, i >> 6);
-                else if (i < n4) q80_block_to_lds(v, i, xs_q, xs_gs, xs_d);
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k * PM_GEMV_BLOCK;
+                    a.f[0][k] = xf4[i < n4 ? i : 0];
+                    if (p.xmode == 2) a.g[k] = nw4[i < n4 ? i : 0];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * PM_GEMV_BLOCK;
+                if (i - lane < n4) {                 // wave-uniform (n4 is a multiple of 8 = one 32-block)
+                    const float4 f = a.f[0][k], g = a.g[k];
+                    float v[4] = {f.x, f.y, f.z, f.w};
+                    if (p.xmode == 2) { v[0] = v[0] * scale * g.x; v[1] = v[1] * scale * g.y; v[2] = v[2] * scale * g.z; v[3] = v[3] * scale * g.w; }
+                    if (i < n4) q80_block_to_lds(v, i, xs_q, xs_gs, xs_d);
+                }
             }
         }
     }
@@ -379,7 +468,7 @@ template <int TYPE, bool PAIR> struct Item {
     static __device__ __forceinline__ void issue(Regs & g, const GemvP & p, const GemvJob & jb, int row, int r1, int c0, int lane) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int rr = min(row + r, r1 - 1);
+            const int rr = max(min(row + r, r1 - 1), 0);   // (a workgroup whose slice is empty still pre-issues: row 0 always exists)
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 const int u = min(lane + 64 * (c0 + i), jb.U - 1);
@@ -418,8 +507,9 @@ template <int TYPE, bool PAIR> struct Item {
     // so the compiler can use counted s_waitcnt vmcnt(N); the last one or two steps are peeled off behind the loop.
     // (All waves start in lock-step after the prologue barrier: without the overlap the whole chip would alternate
     //  between "only loading" and "only computing".)
-    template <bool DBG>
-    static __device__ __forceinline__ void run_job(const GemvP & p, const GemvJob & jb, const XLds & xs, float * out /*job slice*/,
+    // PRE: the first step's loads were already issued into `ga` by the kernel (before the activation prologue).
+    template <bool DBG, bool PRE>
+    static __device__ __forceinline__ void run_job(Regs & ga, Regs & gb, const GemvP & p, const GemvJob & jb, const XLds & xs, float * out /*job slice*/,
                                                    int first, int n_job_items, int r0, int r1, int lane) {
         if (first >= n_job_items) return;
         const int upl = (jb.U + 63) >> 6;            // units per lane
@@ -446,9 +536,20 @@ template <int TYPE, bool PAIR> struct Item {
             }
             next(crow, cc);
         };
-        Regs ga, gb;
-        issue(ga, p, jb, irow, r1, ic * CH, lane); next(irow, ic);
+        if (!PRE) issue(ga, p, jb, irow, r1, ic * CH, lane);
+        next(irow, ic);
         int s_ = 0;
+#ifdef PM_PRE2
+        if (PRE && !PAIR) {                          // steps 0 AND 1 are already in flight (gb holds step 1, clamped if S == 1)
+            if (S == 1) { consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish(); return; }
+            next(irow, ic);
+            consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
+            if (S == 2) { consume<DBG>(gb, acc, p, jb, xs, crow, r1, cc * CH, lane); finish(); return; }
+            issue(ga, p, jb, irow, r1, ic * CH, lane); next(irow, ic);
+            consume<DBG>(gb, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
+            s_ = 2;
+        }
+#endif
         for (; s_ + 2 < S; s_ += 2) {
             issue(gb, p, jb, irow, r1, ic * CH, lane); next(irow, ic);
             consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
@@ -504,22 +605,38 @@ __global__ __launch_bounds__(PM_GEMV_BLOCK, PM_GEMV_BLOCK == 256 ? 4 : 4) void g
     //      128-VGPR budget, -20 %); an L2 prefetch of that item with one dword per 128-B line (-7 % even when limited to
     //      the small wq/wo launches: the in-order VMEM return delays the prologue and the lines are fetched twice); and
     //      splitting the workgroup into 8 prologue waves + 8 waves that pre-issue their first step (-3 %, A/B on one box).]
-    stage_activation<ABLK>(p, xs_q, xs_gs, xs_d, nred);
+    ActRegs areg;
+    stage_issue<ABLK>(p, areg, wave, lane);
+    typename IA::Regs g0, g1;                                           // job 0 is always of type TA (host side orders the jobs)
+#ifndef PM_NO_PREISSUE
+    IA::issue(g0, p, p.job[0], r0_0 + wave * R, r1_0, 0, lane);
+#ifdef PM_PRE2
+    if (!PAIR) {   // second step of this wave: next chunk of the same row(s), or the first chunk of its next item
+        const int cpr0 = (((p.job[0].U + 63) >> 6) + IA::CH - 1) / IA::CH;
+        IA::issue(g1, p, p.job[0], cpr0 > 1 ? r0_0 + wave * R : r0_0 + (wave + PM_GEMV_NW) * R, r1_0, cpr0 > 1 ? IA::CH : 0, lane);
+    }
+#endif
+#endif
+    stage_finish<ABLK>(p, areg, xs_q, xs_gs, xs_d, nred, wave, lane);
     __syncthreads();
     const XLds xs = {xs_q, xs_gs, xs_d};
     // (2) rows. Items of the jobs are dealt to the waves round-robin, continuing across jobs (wave offset rotates) so that
     //     the small k / v slices do not all land on wave 0.
     const int w1 = (wave + PM_GEMV_NW - ni_0 % PM_GEMV_NW) % PM_GEMV_NW;            // first item id of this wave in job 1
     const int w2 = (wave + 2 * PM_GEMV_NW - (ni_0 + ni_1) % PM_GEMV_NW) % PM_GEMV_NW;
-    if (TA != TB && p.job[0].is_b) IB::template run_job<DBG>(p, p.job[0], xs, outbuf, wave, ni_0, r0_0, r1_0, lane);
-    else                           IA::template run_job<DBG>(p, p.job[0], xs, outbuf, wave, ni_0, r0_0, r1_0, lane);
+#ifndef PM_NO_PREISSUE
+    IA::template run_job<DBG, true>(g0, g1, p, p.job[0], xs, outbuf, wave, ni_0, r0_0, r1_0, lane);
+#else
+    IA::template run_job<DBG, false>(g0, g1, p, p.job[0], xs, outbuf, wave, ni_0, r0_0, r1_0, lane);
+#endif
+    typename IB::Regs gB, gB1;
     if (ni_1 > 0) {
-        if (TA != TB && p.job[1].is_b) IB::template run_job<DBG>(p, p.job[1], xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
-        else                           IA::template run_job<DBG>(p, p.job[1], xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
+        if (TA != TB && p.job[1].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[1], xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
+        else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[1], xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
     }
     if (ni_2 > 0) {
-        if (TA != TB && p.job[2].is_b) IB::template run_job<DBG>(p, p.job[2], xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
-        else                           IA::template run_job<DBG>(p, p.job[2], xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
+        if (TA != TB && p.job[2].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[2], xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
+        else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[2], xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
     }
     __syncthreads();
     // (4) coalesced write-out (+bias, +residual)
@@ -529,7 +646,10 @@ __global__ __launch_bounds__(PM_GEMV_BLOCK, PM_GEMV_BLOCK == 256 ? 4 : 4) void g
 }
 
 template <int TA, int TB>
-int launch_types(const GemvP & p, bool pair, int grid, size_t lds, bool dbg, hipStream_t st) {
+int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, hipStream_t st) {
+    GemvP p = p_in;
+    if (p.job[0].is_b)                                // the kernel pre-issues job 0 with the TA code path: put a TA job first
+        for (int j = 1; j < 3; ++j) if (p.job[j].N > 0 && !p.job[j].is_b) { const GemvJob t = p.job[0]; p.job[0] = p.job[j]; p.job[j] = t; break; }
     auto go = [&](auto kern) {
         static bool attr_set = false;                 // one flag per instantiation (lambda is instantiated per kern type)
         if (lds > 48 * 1024 && !attr_set) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }

@@ -1,0 +1,42 @@
+// probe.hip — measurement helpers (not on the product path): the HBM read ceiling this chip/box actually delivers for
+// the access pattern of the mat-vec (every wave streams its own contiguous span with 16-byte non-temporal loads, one
+// 1024-thread workgroup per CU), reported next to the 8 TB/s spec peak by bench.py ("confirm on the box").
+#include "pm355_device.h"
+#include "pm355_kernels.h"
+
+namespace {
+
+template <int UNROLL>
+__global__ __launch_bounds__(1024) void stream_read_kernel(const uint8_t * __restrict__ src, long bytes_per_wave, uint32_t * sink) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long) blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint8_t * p = src + wave * bytes_per_wave;
+    u32x4 acc = {0, 0, 0, 0};
+    const long steps = bytes_per_wave / (1024 * UNROLL);
+    for (long s = 0; s < steps; ++s) {
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) v[i] = ld_nt16(p + (uint32_t) (lane * 16 + i * 1024));
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) acc ^= v[i];
+        p += 1024 * UNROLL;
+    }
+    const uint32_t r = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+    if (r == 0x9E3779B9u && sink) sink[0] = r;          // practically never: keeps the loads alive
+}
+
+} // namespace
+
+// reads `bytes` (rounded down to whole wave spans) once; grid = one 1024-thread workgroup per CU x wg_per_cu
+int pm_launch_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, hipStream_t st) {
+    hipDeviceProp_t pr; int dev = 0; (void) hipGetDevice(&dev);
+    const int cus = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256;
+    const int grid = cus * (wg_per_cu > 0 ? wg_per_cu : 1);
+    const long waves = (long) grid * 16;
+    long per_wave = (long) (bytes / waves);
+    per_wave -= per_wave % (1024 * 8);
+    if (per_wave <= 0) return -1;
+    if (unroll == 4) hipLaunchKernelGGL(stream_read_kernel<4>, dim3(grid), dim3(1024), 0, st, (const uint8_t *) src, per_wave, (uint32_t *) sink);
+    else             hipLaunchKernelGGL(stream_read_kernel<8>, dim3(grid), dim3(1024), 0, st, (const uint8_t *) src, per_wave, (uint32_t *) sink);
+    return 0;
+}
