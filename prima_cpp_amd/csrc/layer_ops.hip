@@ -242,15 +242,34 @@ __global__ __launch_bounds__(256) void attn_rope_fused_kernel(const float * q, c
     float * sc   = part + 256;                   // [n_ctx] scores / probabilities
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hk = h / (H / Hkv);
-    const int seq = seq_ptr ? *seq_ptr : 0;
-    kc += (long) seq * seq_stride; vc += (long) seq * seq_stride;
-    const int pos = pos0_ptr[seq];
-    const int n_pad = (pos + 7) & ~7;            // cached keys 0..pos-1, padded to the 16-byte load width
     const bool neox = r.mode & 2;
     const int half = r.n_dims / 2;
+    // ---- (0) loads that depend on nothing but the head go out first: this token's q / k pair and v element
+    const bool is_k = tid >= DH / 2;
+    const int pair = is_k ? tid - DH / 2 : tid;
+    int ia = 0, ib = 0; float x0 = 0.0f, x1 = 0.0f, vnew = 0.0f;
+    if (tid < DH) {
+        const float * src = is_k ? k + (long) hk * DH : q + (long) h * DH;
+        if (pair < half) { ia = neox ? pair : 2 * pair; ib = neox ? pair + half : 2 * pair + 1; }
+        else             { ia = r.n_dims + 2 * (pair - half); ib = ia + 1; }
+        x0 = src[ia]; x1 = src[ib];
+    }
+    if (DH > 128 || tid >= 128) { const int e = DH > 128 ? tid : tid - 128; if (e < DH) vnew = v[(long) hk * DH + e]; }
+    // ---- (1) position: with a sequence selector the selector and all (<= 64) positions are requested TOGETHER
+    //      (the engine's position table has 64 entries) instead of as two dependent loads
+    int seq = 0, pos;
+    if (seq_ptr) {
+        const int pv = pos0_ptr[lane];
+        seq = __builtin_amdgcn_readfirstlane(*seq_ptr);
+        pos = __builtin_amdgcn_readlane(pv, seq);
+    } else {
+        pos = __builtin_amdgcn_readfirstlane(pos0_ptr[0]);
+    }
+    kc += (long) seq * seq_stride; vc += (long) seq * seq_stride;
+    const int n_pad = (pos + 7) & ~7;            // cached keys 0..pos-1, padded to the 16-byte load width
 
-    // ---- every global load whose address depends only on `pos` goes out NOW (one exposed latency for the whole
-    //      kernel): this thread's K row of the first sweep and its first two V^T chunks; the rotations below overlap it
+    // ---- (2) every global load whose address depends only on `pos` goes out NOW (one exposed latency for the rest of
+    //      the kernel): this thread's K row of the first sweep and its first two V^T chunks; the rotations overlap it
     u32x4 kreg[KQ];
     const bool have_k = tid < pos;
     {
@@ -266,39 +285,29 @@ __global__ __launch_bounds__(256) void attn_rope_fused_kernel(const float * q, c
         vreg0 = *(const u32x4 *) (vrow + (i0 < n_pad ? i0 : 0));
         vreg1 = *(const u32x4 *) (vrow + (i1 < n_pad ? i1 : 0));
     }
-
-    if (tid < DH / 2) {
-        float c = 1.0f, s_ = 0.0f;
-        if (tid < half) rope_cs(r, (float) pos, tid, freq_factors, c, s_);
-        cs[2 * tid] = c; cs[2 * tid + 1] = s_;
-    }
-    __syncthreads();
-    // rotate q (threads 0..DH/2-1) and k (threads DH/2..DH-1)
+    // rotate q (threads 0..DH/2-1) and k (threads DH/2..DH-1): each thread builds its own cos/sin
     if (tid < DH) {
-        const bool is_k = tid >= DH / 2;
-        const int pair = is_k ? tid - DH / 2 : tid;
-        const float * src = is_k ? k + (long) hk * DH : q + (long) h * DH;
-        int a, b; float o0, o1;
+        float o0 = x0, o1 = x1;
         if (pair < half) {
-            a = neox ? pair : 2 * pair; b = neox ? pair + half : 2 * pair + 1;
-            const float c = cs[2 * pair], s_ = cs[2 * pair + 1];
-            const float x0 = src[a], x1 = src[b];
+            float c, s_;
+            rope_cs(r, (float) pos, pair, freq_factors, c, s_);
             o0 = x0 * c - x1 * s_; o1 = x0 * s_ + x1 * c;
-        } else {
-            a = r.n_dims + 2 * (pair - half); b = a + 1; o0 = src[a]; o1 = src[b];
         }
         const uint16_t h0 = f2h(o0), h1 = f2h(o1);
         float * dst = is_k ? kcur : qs;
-        dst[a] = h2f(h0); dst[b] = h2f(h1);
+        dst[ia] = h2f(h0); dst[ib] = h2f(h1);
         if (is_k && h % (H / Hkv) == 0) {
             uint16_t * d = kc + (long) pos * Hkv * DH + (long) hk * DH;
-            d[a] = h0; d[b] = h1;
+            d[ia] = h0; d[ib] = h1;
         }
     }
-    for (int e = tid; e < DH; e += 256) {
-        const uint16_t hv = f2h(v[(long) hk * DH + e]);
-        vcur[e] = h2f(hv);
-        if (h % (H / Hkv) == 0) vc[(long) (hk * DH + e) * n_ctx + pos] = hv;
+    if (DH > 128 || tid >= 128) {
+        const int e = DH > 128 ? tid : tid - 128;
+        if (e < DH) {
+            const uint16_t hv = f2h(vnew);
+            vcur[e] = h2f(hv);
+            if (h % (H / Hkv) == 0) vc[(long) (hk * DH + e) * n_ctx + pos] = hv;
+        }
     }
     __syncthreads();
     // ---- scores: cached keys 0..pos-1 (thread per key; first sweep from the pre-loaded registers), current key from LDS
@@ -325,11 +334,12 @@ __global__ __launch_bounds__(256) void attn_rope_fused_kernel(const float * q, c
         sc[i] = s_;
         lmax = fmaxf(lmax, s_);
     }
-    if (tid == 255) {
+    if (wave == 3) {                             // the current key (from LDS): one wave, lanes over the head dimension
         float acc = 0.0f;
-        for (int e = 0; e < DH; ++e) acc += kcur[e] * qs[e];
-        const float s_ = acc * scale;
-        sc[pos] = s_;
+#pragma unroll
+        for (int e = lane; e < DH; e += 64) acc += kcur[e] * qs[e];
+        const float s_ = wave_sum(acc) * scale;
+        if (lane == 0) sc[pos] = s_;
         lmax = fmaxf(lmax, s_);
     }
 #pragma unroll
@@ -381,17 +391,27 @@ __global__ __launch_bounds__(256) void attn_rope_fused_kernel(const float * q, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// argmax over n floats, first maximum wins. Single workgroup of 1024 threads (n ~ 128k: ~2 us).
+// argmax over n floats, first maximum wins. Single workgroup of 1024 threads.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void argmax_kernel(const float * x, int n, int32_t * out_idx, float * out_val) {
     __shared__ float bv[16];
     __shared__ int bi[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float best = -INFINITY; int idx = 0x7fffffff;
-    for (int i = tid; i < n; i += 1024) {
-        const float v = x[i];
-        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+    auto take = [&](float v, int i) __attribute__((always_inline)) { if (v > best || (v == best && i < idx)) { best = v; idx = i; } };
+    // latency-bound (one workgroup, ~0.5 MB): 4 independent 16-byte loads in flight per thread
+    const bool vec = ((uintptr_t) x & 15) == 0;
+    const int n4 = vec ? n / 4 : 0;
+    int i4 = tid;
+    for (; i4 + 3 * 1024 < n4; i4 += 4 * 1024) {
+        float4 t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = ((const float4 *) x)[i4 + k * 1024];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = 4 * (i4 + k * 1024); take(t[k].x, i); take(t[k].y, i + 1); take(t[k].z, i + 2); take(t[k].w, i + 3); }
     }
+    for (; i4 < n4; i4 += 1024) { const float4 t = ((const float4 *) x)[i4]; const int i = 4 * i4; take(t.x, i); take(t.y, i + 1); take(t.z, i + 2); take(t.w, i + 3); }
+    for (int i = 4 * n4 + tid; i < n; i += 1024) take(x[i], i);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float ov = __shfl_xor(best, off); const int oi = __shfl_xor(idx, off);
