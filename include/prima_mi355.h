@@ -166,6 +166,9 @@ PM355_API int pm355_scale(const float * a, float * y, float s, int64_t n, pm355_
  * mat-vec's access pattern (one 1024-thread workgroup per CU x wg_per_cu, every wave reads its own contiguous span with
  * `unroll` (4 or 8) 16-byte non-temporal loads in flight per lane); `sink` = 4 writable bytes. Not on the product path. */
 PM355_API int pm355_probe_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, pm355_stream_t stream);
+/* measurement helper: average cost (microseconds) of one device-wide barrier of the persistent decode kernel
+ * (decode_kernel.hip), measured on a kernel of n_phases empty phases. Not on the product path. */
+PM355_API int pm355_probe_grid_barrier(int n_phases, float * us_per_barrier, pm355_stream_t stream);
 /* synthetic weights generated directly in HBM (bench): random VALID blocks of `type`, |w| ~ scale */
 PM355_API int pm355_fill_random_blocks(int type, void * dst, int64_t K, int64_t nrows, uint64_t seed, float scale,
                                        pm355_stream_t stream);
@@ -239,6 +242,9 @@ PM355_API int pm355_model_decode(pm355_model * m, const int32_t * d_tokens, cons
 /* Device-resident greedy loop (needs HAS_EMBD|HAS_HEAD and the whole model in one window): starting from the token
  * in d_tokens_io[0] at position pos0, generate n_steps tokens; step i reads d_tokens_io[i], writes d_tokens_io[i+1].
  * One captured hipGraph per step, replayed; no host synchronisation inside. */
+/* 0, or an error once a persistent decode kernel's device-wide barrier timed out (results since then are invalid; set
+ * PM355_PERSISTENT=0 to use the 5-launches-per-layer path). Synchronizes the device. */
+PM355_API int pm355_model_check(pm355_model * m);
 PM355_API int pm355_model_generate(pm355_model * m, int32_t * d_tokens_io, int pos0, int n_steps, int use_graph,
                                    pm355_stream_t stream);
 /* single-token step with the position held in device memory (graph-replayable building block of the piped ring):

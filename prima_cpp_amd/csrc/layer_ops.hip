@@ -69,27 +69,7 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(int type, const uint8_t
 // theta is built by the reference's running product (theta *= theta_scale per pair) so that the f32
 // rounding sequence is identical; cosf/sinf are the device libm (<= 2 ulp from glibc).
 // ------------------------------------------------------------------------------------------------
-struct RopeP {
-    int n_dims, mode, n_ctx_orig;
-    float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1;
-};
-
-__device__ __forceinline__ void rope_cs(const RopeP & r, float pos, int pair, const float * ff, float & c, float & s) {
-    float theta = pos;
-    for (int j = 0; j < pair; ++j) theta *= r.theta_scale;
-    const float f = ff ? ff[pair] : 1.0f;
-    const float te = theta / f;
-    float ti = r.freq_scale * te, th = ti, ms = r.attn_factor;
-    if (r.ext_factor != 0.0f) {
-        const float y = ((float) pair - r.corr0) / fmaxf(0.001f, r.corr1 - r.corr0);   // i0/2 == pair
-        const float ramp = 1 - fminf(1, fmaxf(0, y));
-        const float mix = ramp * r.ext_factor;
-        th = ti * (1 - mix) + te * mix;
-        ms *= 1.0f + 0.1f * logf(1.0f / r.freq_scale);
-    }
-    c = cosf(th) * ms;
-    s = sinf(th) * ms;
-}
+#include "attn_device.h"
 
 // q: [n_tok][H*dh] f32 (rotated in place into q_out), k: [n_tok][Hkv*dh], v: [n_tok][Hkv*dh]
 // K cache: f16 [n_ctx][Hkv*dh]; V cache: f16 [Hkv*dh][n_ctx] (transposed, as in the reference without flash-attn)
@@ -224,170 +204,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float * q, const
 // Same rounding points as attn_decode_kernel / the reference (q, p -> F16; K, V F16; f32 accumulate).
 // ------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void attn_rope_fused_kernel(const float * q, const float * k, const float * v,
-                                                              uint16_t * kc, uint16_t * vc,
-                                                              const int32_t * pos0_ptr, const int32_t * seq_ptr, long seq_stride,
-                                                              const float * freq_factors, float * out,
-                                                              int H, int Hkv, int n_ctx, float scale, RopeP r) {
+__global__ __launch_bounds__(256) void attn_rope_fused_kernel(AttnP a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float redf[8];
     __shared__ double redd[4];
-    constexpr int PARTS = 256 / DH;
-    constexpr int KQ = DH / 8;                   // 16-byte pieces per K row
-    float * qs   = (float *) smem;               // [DH]  f16-rounded rotated q
-    float * kcur = qs + DH;                      // [DH]  f16-rounded rotated k of this position
-    float * vcur = kcur + DH;                    // [DH]  f16-rounded v of this position
-    float * cs   = vcur + DH;                    // [DH]  cos/sin per pair
-    float * part = cs + DH;                      // [256] PV partials
-    float * sc   = part + 256;                   // [n_ctx] scores / probabilities
-    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hk = h / (H / Hkv);
-    const bool neox = r.mode & 2;
-    const int half = r.n_dims / 2;
-    // ---- (0) loads that depend on nothing but the head go out first: this token's q / k pair and v element
-    const bool is_k = tid >= DH / 2;
-    const int pair = is_k ? tid - DH / 2 : tid;
-    int ia = 0, ib = 0; float x0 = 0.0f, x1 = 0.0f, vnew = 0.0f;
-    if (tid < DH) {
-        const float * src = is_k ? k + (long) hk * DH : q + (long) h * DH;
-        if (pair < half) { ia = neox ? pair : 2 * pair; ib = neox ? pair + half : 2 * pair + 1; }
-        else             { ia = r.n_dims + 2 * (pair - half); ib = ia + 1; }
-        x0 = src[ia]; x1 = src[ib];
-    }
-    if (DH > 128 || tid >= 128) { const int e = DH > 128 ? tid : tid - 128; if (e < DH) vnew = v[(long) hk * DH + e]; }
-    // ---- (1) position: with a sequence selector the selector and all (<= 64) positions are requested TOGETHER
-    //      (the engine's position table has 64 entries) instead of as two dependent loads
-    int seq = 0, pos;
-    if (seq_ptr) {
-        const int pv = pos0_ptr[lane];
-        seq = __builtin_amdgcn_readfirstlane(*seq_ptr);
-        pos = __builtin_amdgcn_readlane(pv, seq);
-    } else {
-        pos = __builtin_amdgcn_readfirstlane(pos0_ptr[0]);
-    }
-    kc += (long) seq * seq_stride; vc += (long) seq * seq_stride;
-    const int n_pad = (pos + 7) & ~7;            // cached keys 0..pos-1, padded to the 16-byte load width
-
-    // ---- (2) every global load whose address depends only on `pos` goes out NOW (one exposed latency for the rest of
-    //      the kernel): this thread's K row of the first sweep and its first two V^T chunks; the rotations overlap it
-    u32x4 kreg[KQ];
-    const bool have_k = tid < pos;
-    {
-        const uint16_t * kr = kc + (long) (have_k ? tid : 0) * Hkv * DH + (long) hk * DH;
-#pragma unroll
-        for (int j = 0; j < KQ; ++j) kreg[j] = *(const u32x4 *) (kr + 8 * j);
-    }
-    const int ve = tid % DH, vpt = tid / DH;
-    const uint16_t * vrow = vc + (long) (hk * DH + ve) * n_ctx;
-    u32x4 vreg0 = {0, 0, 0, 0}, vreg1 = {0, 0, 0, 0};
-    {
-        const int i0 = vpt * 8, i1 = i0 + PARTS * 8;
-        vreg0 = *(const u32x4 *) (vrow + (i0 < n_pad ? i0 : 0));
-        vreg1 = *(const u32x4 *) (vrow + (i1 < n_pad ? i1 : 0));
-    }
-    // rotate q (threads 0..DH/2-1) and k (threads DH/2..DH-1): each thread builds its own cos/sin
-    if (tid < DH) {
-        float o0 = x0, o1 = x1;
-        if (pair < half) {
-            float c, s_;
-            rope_cs(r, (float) pos, pair, freq_factors, c, s_);
-            o0 = x0 * c - x1 * s_; o1 = x0 * s_ + x1 * c;
-        }
-        const uint16_t h0 = f2h(o0), h1 = f2h(o1);
-        float * dst = is_k ? kcur : qs;
-        dst[ia] = h2f(h0); dst[ib] = h2f(h1);
-        if (is_k && h % (H / Hkv) == 0) {
-            uint16_t * d = kc + (long) pos * Hkv * DH + (long) hk * DH;
-            d[ia] = h0; d[ib] = h1;
-        }
-    }
-    if (DH > 128 || tid >= 128) {
-        const int e = DH > 128 ? tid : tid - 128;
-        if (e < DH) {
-            const uint16_t hv = f2h(vnew);
-            vcur[e] = h2f(hv);
-            if (h % (H / Hkv) == 0) vc[(long) (hk * DH + e) * n_ctx + pos] = hv;
-        }
-    }
-    __syncthreads();
-    // ---- scores: cached keys 0..pos-1 (thread per key; first sweep from the pre-loaded registers), current key from LDS
-    const int n_kv = pos + 1;
-    float lmax = -INFINITY;
-    auto dot_row = [&](const u32x4 (&kk)[KQ]) __attribute__((always_inline)) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int jj = 0; jj < KQ; ++jj)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc += h2f((uint16_t) (kk[jj][j] & 0xFFFF)) * qs[8 * jj + 2 * j];
-                acc += h2f((uint16_t) (kk[jj][j] >> 16)) * qs[8 * jj + 2 * j + 1];
-            }
-        return acc * scale;
-    };
-    if (have_k) { const float s_ = dot_row(kreg); sc[tid] = s_; lmax = s_; }
-    for (int i = tid + 256; i < pos; i += 256) {
-        const uint16_t * kr = kc + (long) i * Hkv * DH + (long) hk * DH;
-        u32x4 kk[KQ];
-#pragma unroll
-        for (int j = 0; j < KQ; ++j) kk[j] = *(const u32x4 *) (kr + 8 * j);
-        const float s_ = dot_row(kk);
-        sc[i] = s_;
-        lmax = fmaxf(lmax, s_);
-    }
-    if (wave == 3) {                             // the current key (from LDS): one wave, lanes over the head dimension
-        float acc = 0.0f;
-#pragma unroll
-        for (int e = lane; e < DH; e += 64) acc += kcur[e] * qs[e];
-        const float s_ = wave_sum(acc) * scale;
-        if (lane == 0) sc[pos] = s_;
-        lmax = fmaxf(lmax, s_);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-    if (lane == 0) redf[wave] = lmax;
-    __syncthreads();
-    const float mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
-    double lsum = 0.0;
-    for (int i = tid; i < n_kv; i += 256) {
-        const float e = expf(sc[i] - mx);
-        sc[i] = e;
-        lsum += (double) e;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
-    if (lane == 0) redd[wave] = lsum;
-    __syncthreads();
-    const double tot = (redd[0] + redd[1]) + (redd[2] + redd[3]);
-    const float inv = (float) (1.0 / tot);
-    const float p_cur = h2f(f2h(sc[pos] * inv));                       // every thread reads exp() of the current key
-    __syncthreads();
-    for (int i = tid; i < n_pad; i += 256) sc[i] = i < pos ? h2f(f2h(sc[i] * inv)) : 0.0f;   // p rounded to F16; pad (incl. `pos`) = 0
-    __syncthreads();
-    // ---- PV: thread (e, part) streams V^T[hk*DH+e][8*chunk ..] for chunk = part, part+PARTS, ... (first two pre-loaded)
-    {
-        float acc = 0.0f;
-        auto fma8 = [&](const u32x4 & vv, int i) __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc += h2f((uint16_t) (vv[j] & 0xFFFF)) * sc[i + 2 * j];
-                acc += h2f((uint16_t) (vv[j] >> 16)) * sc[i + 2 * j + 1];
-            }
-        };
-        int i = vpt * 8;
-        if (i < n_pad) fma8(vreg0, i);
-        i += PARTS * 8;
-        if (i < n_pad) fma8(vreg1, i);
-        for (i += PARTS * 8; i < n_pad; i += PARTS * 8) { const u32x4 vv = *(const u32x4 *) (vrow + i); fma8(vv, i); }
-        part[tid] = acc;
-    }
-    __syncthreads();
-    if (tid < DH) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int pt = 0; pt < PARTS; ++pt) acc += part[pt * DH + tid];
-        acc += vcur[tid] * p_cur;
-        out[(long) h * DH + tid] = acc;
-    }
+    attn_rope_body<DH, false>(a, blockIdx.x, smem, redf, redd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -505,8 +326,8 @@ int pm_launch_attn_rope_fused(const float * q, const float * k, const float * v,
     r.freq_scale = c.freq_scale; r.ext_factor = c.ext_factor; r.attn_factor = c.attn_factor; r.corr0 = c.corr0; r.corr1 = c.corr1;
     auto launch = [&](auto kern) {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipLaunchKernelGGL(kern, dim3(H), dim3(256), lds, st, q, k, v, (uint16_t *) kc, (uint16_t *) vc, pos0, seq, seq_stride,
-                           freq_factors, out, H, Hkv, n_ctx, scale, r);
+        AttnP a = {q, k, v, (uint16_t *) kc, (uint16_t *) vc, pos0, seq, seq_stride, freq_factors, out, H, Hkv, n_ctx, scale, r};
+        hipLaunchKernelGGL(kern, dim3(H), dim3(256), lds, st, a);
     };
     if (dh == 64) launch(attn_rope_fused_kernel<64>);
     else if (dh == 128) launch(attn_rope_fused_kernel<128>);

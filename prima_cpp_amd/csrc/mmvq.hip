@@ -24,632 +24,22 @@
 //  * Up to 3 weight matrices that share the activation (wq/wk/wv) are served by ONE launch ("jobs"), of at most two
 //    different quant types (Q4_K_M: attn_v is Q6_K/Q5_K next to Q4_K q/k); every workgroup takes an equal slice of
 //    the rows of every job.
-#include "pm355_device.h"
-#include "pm355_kernels.h"
-#include <limits.h>
+#include "mmvq_device.h"
 
-#define PM_MAX_ROWS_PER_WG 512
+using namespace pmv;
 
 namespace {
 
-struct GemvJob {
-    const uint8_t * W; const uint8_t * W2; float * y; const float * bias; const float * resid;
-    long row_stride;
-    int N, is_b /*uses TB*/, U /*units per row*/;
-};
-struct GemvP {
-    GemvJob job[3];
-    const uint8_t * xq;                     // xmode 0: pre-quantized activation row (row-SoA Q8_K / Q8_0)
-    const float * xf; const float * norm_w; // xmode 1: f32 activation; xmode 2: rms_norm(xf) * norm_w first
-    float eps;
-    int xmode, K;
-    int32_t * dbg;
-};
-
-// Per-type traits. A unit's NV values come in NV/16 groups of 16 CONTIGUOUS activations; group_base() gives the
-// activation index of group g. X holds the quantized activation slice of one unit.
-template <int NV> struct XT { uint32_t q[NV / 4]; int gs[NV / 16]; float yd; };
-
-template <int TYPE> struct QT;
-
-// ---------------------------------------------------------------- Q4_K (row-SoA: qa | qb | hdr) -------
-// unit u = (block b = u / 4, j = u % 4): the 32 qs bytes [32j, 32j+32) = sub-blocks 2j (low nibbles, values 64j..64j+31)
-// and 2j+1 (high nibbles, values 64j+32..64j+63) -> 64 CONTIGUOUS activations, one scale decode per 64 weights.
-// HBM row: qa[U][16] (first 16 bytes of every unit) | qb[U][16] (second 16) | hdr[nb][16] (d, dmin, scales[12]): each of
-// the three wave-level loads covers ONE contiguous span (1 KB / 1 KB / 256 B), no cache line is touched by two loads.
-template <> struct QT<PM_Q4_K> {
-    static constexpr int NV = 64, LPB = 4, ABLK = 256;
-    typedef XT<NV> X;
-    struct Wr { u32x4 q0, q1, h; };
-    static __device__ __forceinline__ int group_base(int u, int g) { return (u >> 2) * 256 + 64 * (u & 3) + 16 * g; }
-    static __device__ __forceinline__ void issue(Wr & w, const uint8_t * row /*wave-uniform*/, int K, int u) {
-        const uint32_t nb = (uint32_t) K / 256;                         // scalar stream bases + 32-bit lane offsets
-        w.q0 = ld_nt16(row + (uint32_t) u * 16u);
-        w.q1 = ld_nt16(row + nb * 64 + (uint32_t) u * 16u);
-        w.h  = ld_nt16(row + nb * 128 + ((uint32_t) u >> 2) * 16u);
-    }
-    static __device__ __forceinline__ float consume(const Wr & w, const X & x, int u, float acc, int & isum, int & msum) {
-        int slo = 0, shi = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            slo = dot4(w.q0[i] & 0x0F0F0F0Fu, x.q[i], slo);
-            shi = dot4((w.q0[i] >> 4) & 0x0F0F0F0Fu, x.q[8 + i], shi);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            slo = dot4(w.q1[i] & 0x0F0F0F0Fu, x.q[4 + i], slo);
-            shi = dot4((w.q1[i] >> 4) & 0x0F0F0F0Fu, x.q[12 + i], shi);
-        }
-        int sc0, sc1, m0, m1;
-        k4_scale_min_pair(w.h[1], w.h[2], w.h[3], u & 3, sc0, sc1, m0, m1);
-        isum = __mul24(sc0, slo) + __mul24(sc1, shi);                  // |slo| <= 32*15*127, scales <= 63: 24-bit safe
-        msum = __mul24(m0, x.gs[0] + x.gs[1]) + __mul24(m1, x.gs[2] + x.gs[3]);
-        const float d = h2f((uint16_t) (w.h[0] & 0xFFFF)), dmin = h2f((uint16_t) (w.h[0] >> 16));
-        return fmaf(x.yd * d, (float) isum, fmaf(-(x.yd * dmin), (float) msum, acc));
-    }
-};
-
-// ---------------------------------------------------------------- Q5_K (native 176-B blocks) -------
-template <> struct QT<PM_Q5_K> {
-    static constexpr int NV = 32, LPB = 8, ABLK = 256;
-    typedef XT<NV> X;
-    struct Wr { u32x4 q, h, qh; };
-    static __device__ __forceinline__ int group_base(int u, int g) { const int c = u & 7; return (u >> 3) * 256 + 64 * (c >> 1) + 16 * (c & 1) + 32 * g; }
-    static __device__ __forceinline__ void issue(Wr & w, const uint8_t * row, int, int u) {
-        const uint32_t hb = (uint32_t) (u >> 3) * PM_BS_Q5_K;
-        w.q  = ld_nt16(row + (hb + 48u + 16u * (uint32_t) (u & 7)));
-        w.qh = ld_nt16(row + (hb + 16u + 16u * (uint32_t) (u & 1)));
-        w.h  = ld_nt16(row + hb);
-    }
-    static __device__ __forceinline__ float consume(const Wr & w, const X & x, int u, float acc, int & isum, int & msum) {
-        const int j = (u & 7) >> 1;
-        int slo = 0, shi = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t lo = (w.q[i] & 0x0F0F0F0Fu) | (((w.qh[i] >> (2 * j)) & 0x01010101u) << 4);
-            const uint32_t hi = ((w.q[i] >> 4) & 0x0F0F0F0Fu) | (((w.qh[i] >> (2 * j + 1)) & 0x01010101u) << 4);
-            slo = dot4(lo, x.q[i], slo);
-            shi = dot4(hi, x.q[4 + i], shi);
-        }
-        int sc0, sc1, m0, m1;
-        k4_scale_min_pair(w.h[1], w.h[2], w.h[3], j, sc0, sc1, m0, m1);
-        isum = __mul24(sc0, slo) + __mul24(sc1, shi);
-        msum = __mul24(m0, x.gs[0]) + __mul24(m1, x.gs[1]);
-        const float d = h2f((uint16_t) (w.h[0] & 0xFFFF)), dmin = h2f((uint16_t) (w.h[0] >> 16));
-        return fmaf(x.yd * d, (float) isum, fmaf(-(x.yd * dmin), (float) msum, acc));
-    }
-};
-
-// ---------------------------------------------------------------- Q6_K (row-SoA) --------------------
-// row: la[U][16] | lb[U][16] | qh[U][16] | scales[nb][16] | d[nb]      unit u = 4b + 2hh + v = (block b, half hh, 16-col slice v)
-//      la = ql[64hh+16v, +16), lb = ql[64hh+32+16v, +16), qh = qh[32hh+16v, +16): every load is one contiguous span per wave
-template <> struct QT<PM_Q6_K> {
-    static constexpr int NV = 64, LPB = 4, ABLK = 256;
-    typedef XT<NV> X;
-    struct Wr { u32x4 l0, l1, h; u32x2 s; uint16_t d; };
-    static __device__ __forceinline__ int group_base(int u, int g) { return (u >> 2) * 256 + 128 * ((u >> 1) & 1) + 32 * g + 16 * (u & 1); }
-    static __device__ __forceinline__ void issue(Wr & w, const uint8_t * row, int K, int u) {
-        const uint32_t nb = (uint32_t) K / 256;                         // wave-uniform stream bases, 32-bit lane offsets
-        const uint32_t b = (uint32_t) u >> 2, hh = ((uint32_t) u >> 1) & 1;
-        w.l0 = ld_nt16(row + (uint32_t) u * 16u);
-        w.l1 = ld_nt16(row + nb * 64 + (uint32_t) u * 16u);
-        w.h  = ld_nt16(row + nb * 128 + (uint32_t) u * 16u);
-        w.s  = ld_nt8(row + nb * 192 + (b * 16 + 8 * hh));
-        w.d  = ld_nt2(row + nb * 208 + b * 2);
-    }
-    static __device__ __forceinline__ float consume(const Wr & w, const X & x, int u, float facc, int & isum, int & msum) {
-        const int v = u & 1;
-        int acc[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t h = w.h[i];
-            acc[0] = dot4((w.l0[i] & 0x0F0F0F0Fu)        | ((h << 4) & 0x30303030u), x.q[i],      acc[0]);
-            acc[1] = dot4((w.l1[i] & 0x0F0F0F0Fu)        | ((h << 2) & 0x30303030u), x.q[4 + i],  acc[1]);
-            acc[2] = dot4(((w.l0[i] >> 4) & 0x0F0F0F0Fu) | (h & 0x30303030u),        x.q[8 + i],  acc[2]);
-            acc[3] = dot4(((w.l1[i] >> 4) & 0x0F0F0F0Fu) | ((h >> 2) & 0x30303030u), x.q[12 + i], acc[3]);
-        }
-        const uint64_t s8 = ((uint64_t) w.s[1] << 32) | w.s[0];
-        isum = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int sc = (int) (int8_t) (s8 >> (8 * (v + 2 * k)));
-            isum += __mul24(sc, acc[k] - 32 * x.gs[k]);      // sum (q-32)*a = sum q*a - 32*sum a   (|.| <= 16*63*127)
-        }
-        msum = 0;
-        return fmaf(x.yd * h2f(w.d), (float) isum, facc);
-    }
-};
-
-// ---------------------------------------------------------------- Q8_0 (row-SoA) --------------------
-// row: qa[nb32][16] | qb[nb32][16] | d[nb32] (first / second 16 int8 of every block); activations quantized to Q8_0
-// (32-blocks, fp16 d).   unit = one 32-block
-template <> struct QT<PM_Q8_0> {
-    static constexpr int NV = 32, LPB = 1, ABLK = 32;
-    typedef XT<NV> X;
-    struct Wr { u32x4 q0, q1; uint16_t d; };
-    static __device__ __forceinline__ int group_base(int u, int g) { return u * 32 + 16 * g; }
-    static __device__ __forceinline__ void issue(Wr & w, const uint8_t * row, int K, int u) {
-        w.q0 = ld_nt16(row + (uint32_t) u * 16u);
-        w.q1 = ld_nt16(row + (uint32_t) K / 2 + (uint32_t) u * 16u);
-        w.d  = ld_nt2(row + (uint32_t) K + (uint32_t) u * 2u);
-    }
-    static __device__ __forceinline__ float consume(const Wr & w, const X & x, int, float acc, int & isum, int & msum) {
-        int s = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { s = dot4(w.q0[i], x.q[i], s); s = dot4(w.q1[i], x.q[4 + i], s); }
-        isum = s; msum = 0;
-        return fmaf((float) s, h2f(w.d) * x.yd, acc);
-    }
-};
-
-__device__ __forceinline__ float silu_f(float g) { return g / (1.0f + expf(-g)); }
-
-#ifndef PM_GEMV_BLOCK
-#define PM_GEMV_BLOCK 1024                // 16 waves: ONE workgroup per CU (measured +2.3 % over 2 x 512: prologue once per CU)
-#endif
-#define PM_GEMV_NW (PM_GEMV_BLOCK / 64)
-
-// ---- activation prologue: the workgroup quantizes the WHOLE activation row once into LDS ----------------------------
-//   xs_q  int8  [K]        quantized values
-//   xs_gs int32 [K/16]     sums of each 16 consecutive quantized values (min / -32 terms)
-//   xs_d  float [K/ABLK]   block scales (ABLK = 256: Q8_K, float d;  ABLK = 32: Q8_0, fp16-rounded d)
-struct XLds { const int8_t * q; const int * gs; const float * d; };
-
-// wave min, result in every lane (lanes that receive nothing from a DPP step keep their own value)
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ int dpp_keep_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
-__device__ __forceinline__ int wave_min_keep(int v) {
-    v = min(v, dpp_keep_i<0xB1>(v)); v = min(v, dpp_keep_i<0x4E>(v)); v = min(v, dpp_keep_i<0x141>(v)); v = min(v, dpp_keep_i<0x140>(v));
-    v = min(v, dpp_keep_i<0x142, 0xA>(v)); v = min(v, dpp_keep_i<0x143, 0xC>(v));
-    return __builtin_amdgcn_readlane(v, 63);
-}
-
-// Row-of-16-lanes reductions (DPP quad_perm x2, row_half_mirror, row_mirror): every lane of the row gets the result.
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
-    return v;
-}
-__device__ __forceinline__ int row16_min(int v) {
-    v = min(v, dpp_keep_i<0xB1>(v)); v = min(v, dpp_keep_i<0x4E>(v)); v = min(v, dpp_keep_i<0x141>(v)); v = min(v, dpp_keep_i<0x140>(v));
-    return v;
-}
-// f64 wave sum through DPP on the two dword halves (no LDS traffic); total returned in every lane
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ double dpp_d(double v) {
-    const uint64_t u = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (uint32_t) u, CTRL, ROW_MASK, 0xF, true);
-    const uint32_t hi = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (uint32_t) (u >> 32), CTRL, ROW_MASK, 0xF, true);
-    return __builtin_bit_cast(double, ((uint64_t) hi << 32) | lo);
-}
-__device__ __forceinline__ double wave_sum_f64(double v) {
-    v += dpp_d<0xB1>(v); v += dpp_d<0x4E>(v); v += dpp_d<0x141>(v); v += dpp_d<0x140>(v);
-    v += dpp_d<0x142, 0xA>(v); v += dpp_d<0x143, 0xC>(v);
-    const uint64_t u = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) u, 63), hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (u >> 32), 63);
-    return __builtin_bit_cast(double, ((uint64_t) hi << 32) | lo);
-}
-
-// One ROW of 16 lanes = one 256-block (quantize_row_q8_K_ref): lane j holds v[k][i] = x[64k + 4j + i]. Four blocks per
-// wave instruction stream: every workgroup quantizes the whole activation row redundantly, so the per-block instruction
-// count (not bytes) is what the prologue costs - 16 lanes x 16 values needs 4 DPP steps per reduction and a quarter of
-// the instructions of the one-block-per-wave form.
-__device__ __forceinline__ void q8k_rows_to_lds(const float (&v)[4][4], int j, bool valid, int8_t * xs_q, int * xs_gs, float * xs_d, int blk) {
-    float amax = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fabsf(v[k][i]));
-    amax = row16_max(amax);
-    int key = 0x7fffffff;                            // lowest index with |x| == amax; low bit = its sign
-#pragma unroll
-    for (int k = 3; k >= 0; --k)
-#pragma unroll
-        for (int i = 3; i >= 0; --i)
-            key = fabsf(v[k][i]) == amax ? (((64 * k + 4 * j + i) << 1) | (v[k][i] < 0.0f ? 1 : 0)) : key;
-    key = row16_min(key);
-    const float iscale = amax != 0.0f ? -127.f / ((key & 1) ? -amax : amax) : 0.0f;
-    uint32_t packed[4]; int psum[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        packed[k] = 0; psum[k] = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int q = nearest_int_rne(iscale * v[k][i]);
-            q = q > 127 ? 127 : q;
-            psum[k] += q; packed[k] |= (uint32_t) (q & 0xFF) << (8 * i);
-        }
-        psum[k] += dpp_i<0xB1>(psum[k]); psum[k] += dpp_i<0x4E>(psum[k]);       // 16 consecutive values = one quad of lanes
-    }
-    if (valid) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            ((uint32_t *) xs_q)[blk * 64 + 16 * k + j] = packed[k];
-            if ((j & 3) == 0) xs_gs[blk * 16 + 4 * k + (j >> 2)] = psum[k];
-        }
-        if (j == 0) xs_d[blk] = amax != 0.0f ? 1 / iscale : 0.0f;
-    }
-}
-
-// 8 lanes x 4 values = one 32-block (quantize_row_q8_0_ref)
-__device__ __forceinline__ void q80_block_to_lds(const float v[4], int i4 /*index of this float4 in the row*/,
-                                                 int8_t * xs_q, int * xs_gs, float * xs_d) {
-    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    amax = group8_max(amax);
-    const float d = amax / 127;
-    const float id = d ? 1.0f / d : 0.0f;
-    uint32_t packed = 0; int psum = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int q = (int) roundf(v[i] * id); psum += q; packed |= (uint32_t) (q & 0xFF) << (8 * i); }
-    ((uint32_t *) xs_q)[i4] = packed;
-    psum += dpp_i<0xB1>(psum); psum += dpp_i<0x4E>(psum);
-    if ((i4 & 3) == 0) xs_gs[i4 >> 2] = psum;
-    if ((i4 & 7) == 0) xs_d[i4 >> 3] = h2f(f2h(d));
-}
-
-// The prologue is split in two so that the kernel can put the first steps' WEIGHT loads in flight between them: the
-// activation loads are issued first (they return first: VMEM returns in order), the weight loads queue up behind them
-// and travel from HBM while the workgroup normalizes / quantizes the activation row.
-//   ABLK = 256 (Q8_K): wave w, lane (r = lane / 16, j = lane % 16), pass t handles block 4 (w + 16 t) + r; f[t][k] is the
-//                      float4 at element 64 k + 4 j of that block. Two passes (K <= 32768; K <= 16384 with norm weights)
-//                      are loaded ONCE and stay in registers between the sum-of-squares and the quantization.
-//   ABLK = 32  (Q8_0): thread t owns the float4s t, t + 1024, ... (8 lanes = one 32-block); K <= 16384 held in registers.
-#define PM_PRE2 1     // non-pair launches put their first TWO steps in flight before the activation prologue
-struct ActRegs { float4 f[2][4]; float4 g[4]; };
-
-template <int ABLK>
-__device__ __forceinline__ bool act_held(const GemvP & p) {
-    if (p.xmode == 0) return false;
-    if (ABLK == 256) return p.K / 256 <= (p.xmode == 2 ? 64 : 128);
-    return p.K / 4 <= 4 * PM_GEMV_BLOCK;
-}
-
-template <int ABLK>
-__device__ __forceinline__ void stage_issue(const GemvP & p, ActRegs & a, int wave, int lane) {
-    if (!act_held<ABLK>(p)) return;
-    const float4 * xf4 = (const float4 *) p.xf, * nw4 = (const float4 *) p.norm_w;
-    if (ABLK == 256) {
-        const int nblk = p.K / 256, r = lane >> 4, j = lane & 15;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) if (64 * t < nblk) {
-            const int B = min(4 * (wave + PM_GEMV_NW * t) + r, nblk - 1);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a.f[t][k] = xf4[B * 64 + 16 * k + j];
-        }
-        if (p.xmode == 2) {
-            const int B = min(4 * wave + r, nblk - 1);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a.g[k] = nw4[B * 64 + 16 * k + j];
-        }
-    } else {
-        const int tid = threadIdx.x, n4 = p.K / 4;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = tid + k * PM_GEMV_BLOCK;
-            a.f[0][k] = xf4[i < n4 ? i : 0];
-            if (p.xmode == 2) a.g[k] = nw4[i < n4 ? i : 0];
-        }
-    }
-}
-
-__device__ __forceinline__ double sumsq4(const float4 & f) {
-    double s = (double) (f.x * f.x); s += (double) (f.y * f.y); s += (double) (f.z * f.z); s += (double) (f.w * f.w);
-    return s;
-}
-
-template <int ABLK>
-__device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_t * xs_q, int * xs_gs, float * xs_d, double * nred,
-                                             int wave, int lane) {
-    const int tid = threadIdx.x;
-    const int K = p.K;
-    if (p.xmode == 0) {
-        // pre-quantized row-SoA: int8 qs[K] | scales. Copy + group sums.
-        for (int g = tid; g < K / 16; g += PM_GEMV_BLOCK) {
-            const u32x4 t = *(const u32x4 *) (p.xq + 16 * g);
-            *(u32x4 *) (xs_q + 16 * g) = t;
-            int s_ = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s_ = dot4(t[i], 0x01010101u, s_);
-            xs_gs[g] = s_;
-        }
-        for (int b = tid; b < K / ABLK; b += PM_GEMV_BLOCK)
-            xs_d[b] = ABLK == 256 ? ((const float *) (p.xq + K))[b] : h2f(((const uint16_t *) (p.xq + K))[b]);
-        return;
-    }
-    const float4 * xf4 = (const float4 *) p.xf, * nw4 = (const float4 *) p.norm_w;
-    const int n4 = K / 4;
-    const bool held = act_held<ABLK>(p);
-    const int nblk = K / 256, r = lane >> 4, j = lane & 15;
-    float scale = 1.0f;
-    if (p.xmode == 2) {
-        // sum of the f32-rounded squares in f64 like the reference (ggml.c:11975-11980); any summation order of <= 2^15
-        // f64 terms agrees with the sequential one after the final rounding to f32
-        double ss = 0.0;
-        if (held && ABLK == 256) {
-            if (4 * wave + r < nblk) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) ss += sumsq4(a.f[0][k]);
-            }
-        } else if (held) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (tid + k * PM_GEMV_BLOCK < n4) ss += sumsq4(a.f[0][k]);
-        } else {
-            for (int i = tid; i < n4; i += PM_GEMV_BLOCK) ss += sumsq4(xf4[i]);
-        }
-        ss = wave_sum_f64(ss);
-        if (lane == 0) nred[wave] = ss;
-        __syncthreads();
-        double tot = 0.0;
-#pragma unroll
-        for (int k = 0; k < PM_GEMV_NW; ++k) tot += nred[k];
-        const float mean = (float) (tot / K);
-        scale = 1.0f / sqrtf(mean + p.eps);
-    }
-    if (ABLK == 256) {
-        auto rows = [&](const float4 (&f)[4], const float4 (&g)[4], int B) __attribute__((always_inline)) {
-            float v[4][4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[k][0] = f[k].x; v[k][1] = f[k].y; v[k][2] = f[k].z; v[k][3] = f[k].w;
-                if (p.xmode == 2) { v[k][0] = v[k][0] * scale * g[k].x; v[k][1] = v[k][1] * scale * g[k].y; v[k][2] = v[k][2] * scale * g[k].z; v[k][3] = v[k][3] * scale * g[k].w; }
-            }
-            q8k_rows_to_lds(v, j, B < nblk, xs_q, xs_gs, xs_d, B);
-        };
-        if (held) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) if (4 * (wave + PM_GEMV_NW * t) < nblk) rows(a.f[t], a.g, 4 * (wave + PM_GEMV_NW * t) + r);
-        } else {
-            for (int B0 = 4 * wave; B0 < nblk; B0 += 4 * PM_GEMV_NW) {
-                const int Bc = min(B0 + r, nblk - 1);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { a.f[0][k] = xf4[Bc * 64 + 16 * k + j]; if (p.xmode == 2) a.g[k] = nw4[Bc * 64 + 16 * k + j]; }
-                rows(a.f[0], a.g, B0 + r);
-            }
-        }
-    } else {
-        for (int i0 = tid; i0 < n4; i0 += 4 * PM_GEMV_BLOCK) {
-            if (!held) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i = i0 + k * PM_GEMV_BLOCK;
-                    a.f[0][k] = xf4[i < n4 ? i : 0];
-                    if (p.xmode == 2) a.g[k] = nw4[i < n4 ? i : 0];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = i0 + k * PM_GEMV_BLOCK;
-                if (i - lane < n4) {                 // wave-uniform (n4 is a multiple of 8 = one 32-block)
-                    const float4 f = a.f[0][k], g = a.g[k];
-                    float v[4] = {f.x, f.y, f.z, f.w};
-                    if (p.xmode == 2) { v[0] = v[0] * scale * g.x; v[1] = v[1] * scale * g.y; v[2] = v[2] * scale * g.z; v[3] = v[3] * scale * g.w; }
-                    if (i < n4) q80_block_to_lds(v, i, xs_q, xs_gs, xs_d);
-                }
-            }
-        }
-    }
-}
-
-template <int TYPE>
-__device__ __forceinline__ void load_x_lds(typename QT<TYPE>::X & x, const XLds & xs, int u) {
-    typedef QT<TYPE> T;
-#pragma unroll
-    for (int g = 0; g < T::NV / 16; ++g) {
-        const int base = T::group_base(u, g);
-        const u32x4 t = *(const u32x4 *) (xs.q + base);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x.q[4 * g + i] = t[i];
-        x.gs[g] = xs.gs[base >> 4];
-    }
-    x.yd = xs.d[T::group_base(u, 0) / T::ABLK];
-}
-
-// A wave processes ITEMS: R consecutive rows of one job. Lanes stride over the row's units in chunks of CH units per
-// lane; the activation slice of every unit comes from LDS. No barrier and no cross-wave reduction inside an item.
-template <int TYPE, bool PAIR> struct Item {
-    typedef QT<TYPE> T;
-    static constexpr int NM = PAIR ? 2 : 1;
-#ifndef PM_CH32
-#define PM_CH32 2
-#endif
-#ifndef PM_CH64
-#define PM_CH64 1
-#endif
-#ifndef PM_RSINGLE
-#define PM_RSINGLE 1
-#endif
-#ifndef PM_RPAIR
-#define PM_RPAIR 1
-#endif
-    static constexpr int CH = T::NV == 64 ? PM_CH64 : PM_CH32;   // units per lane per row and register set (two sets in flight)
-    static constexpr int R  = PAIR ? PM_RPAIR : PM_RSINGLE;              // rows in flight per wave
-    struct Regs { typename T::Wr w[R][NM][CH]; };
-
-    // unconditional loads (row / unit clamped): conditional loads make the compiler drain the VMEM queue
-    static __device__ __forceinline__ void issue(Regs & g, const GemvP & p, const GemvJob & jb, int row, int r1, int c0, int lane) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int rr = max(min(row + r, r1 - 1), 0);   // (a workgroup whose slice is empty still pre-issues: row 0 always exists)
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int u = min(lane + 64 * (c0 + i), jb.U - 1);
-                T::issue(g.w[r][0][i], jb.W + (long) rr * jb.row_stride, p.K, u);
-                if (PAIR) T::issue(g.w[r][NM - 1][i], jb.W2 + (long) rr * jb.row_stride, p.K, u);
-            }
-        }
-    }
-    template <bool DBG>
-    static __device__ __forceinline__ void consume(const Regs & g, float (&acc)[R][NM], const GemvP & p, const GemvJob & jb,
-                                                   const XLds & xs, int row, int r1, int c0, int lane) {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int uu = lane + 64 * (c0 + i);
-            const bool uv = uu < jb.U;
-            const int u = min(uu, jb.U - 1);
-            typename T::X x;
-            load_x_lds<TYPE>(x, xs, u);
-            x.yd = uv ? x.yd : 0.0f;                 // a clamped (out-of-row) unit contributes exactly 0
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    int isum, msum;
-                    acc[r][m] = T::consume(g.w[r][m][i], x, u, acc[r][m], isum, msum);
-                    if (DBG) if (uv && row + r < r1) {
-                        int32_t * o = p.dbg + ((long) (m * jb.N + row + r) * jb.U + u) * 2;
-                        o[0] = isum; o[1] = msum;
-                    }
-                }
-        }
-    }
-    // All items of ONE job that belong to this wave (item ids first, first+NW, ... < n_job_items), flattened into STEPS
-    // (item, chunk) and software-pipelined with two statically named register sets: the loads of step s+1 are in flight
-    // while step s is consumed. The steady-state loop body is straight-line code - every issue() in it is unconditional -
-    // so the compiler can use counted s_waitcnt vmcnt(N); the last one or two steps are peeled off behind the loop.
-    // (All waves start in lock-step after the prologue barrier: without the overlap the whole chip would alternate
-    //  between "only loading" and "only computing".)
-    // PRE: the first step's loads were already issued into `ga` by the kernel (before the activation prologue).
-    template <bool DBG, bool PRE>
-    static __device__ __forceinline__ void run_job(Regs & ga, Regs & gb, const GemvP & p, const GemvJob & jb, const XLds & xs, float * out /*job slice*/,
-                                                   int first, int n_job_items, int r0, int r1, int lane) {
-        if (first >= n_job_items) return;
-        const int upl = (jb.U + 63) >> 6;            // units per lane
-        const int cpr = (upl + CH - 1) / CH;         // chunks (steps) per item
-        const int n_my = (n_job_items - first + PM_GEMV_NW - 1) / PM_GEMV_NW;
-        const int S = n_my * cpr;
-        float acc[R][NM];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int m = 0; m < NM; ++m) acc[r][m] = 0.0f;
-        // step cursors: (row, chunk) of the step being ISSUED and of the step being CONSUMED
-        int irow = r0 + first * R, ic = 0, crow = irow, cc = 0;
-        auto next = [&](int & row, int & c) __attribute__((always_inline)) { if (++c == cpr) { c = 0; row += PM_GEMV_NW * R; } };
-        auto finish = [&]() __attribute__((always_inline)) {           // after a step was consumed: end of item?
-            if (cc == cpr - 1) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float o[NM];
-#pragma unroll
-                    for (int m = 0; m < NM; ++m) { o[m] = wave_sum(acc[r][m]); acc[r][m] = 0.0f; }
-                    if (lane == 0 && crow + r < r1) out[crow + r - r0] = PAIR ? silu_f(o[0]) * o[NM - 1] : o[0];
-                }
-            }
-            next(crow, cc);
-        };
-        if (!PRE) issue(ga, p, jb, irow, r1, ic * CH, lane);
-        next(irow, ic);
-        int s_ = 0;
-#ifdef PM_PRE2
-        if (PRE && !PAIR) {                          // steps 0 AND 1 are already in flight (gb holds step 1, clamped if S == 1)
-            if (S == 1) { consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish(); return; }
-            next(irow, ic);
-            consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
-            if (S == 2) { consume<DBG>(gb, acc, p, jb, xs, crow, r1, cc * CH, lane); finish(); return; }
-            issue(ga, p, jb, irow, r1, ic * CH, lane); next(irow, ic);
-            consume<DBG>(gb, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
-            s_ = 2;
-        }
-#endif
-        for (; s_ + 2 < S; s_ += 2) {
-            issue(gb, p, jb, irow, r1, ic * CH, lane); next(irow, ic);
-            consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
-            issue(ga, p, jb, irow, r1, ic * CH, lane); next(irow, ic);
-            consume<DBG>(gb, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
-        }
-        if (s_ + 1 < S) {
-            issue(gb, p, jb, irow, r1, ic * CH, lane);
-            consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
-            consume<DBG>(gb, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
-        } else {
-            consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
-        }
-    }
-};
-
-__device__ __forceinline__ void write_out(const GemvJob & jb, const float * outbuf, int r0, int r1, int ob, int tid) {
-    for (int t = tid; t < r1 - r0; t += PM_GEMV_BLOCK) {
-        float out = outbuf[ob + t];
-        if (jb.bias)  out += jb.bias[r0 + t];
-        if (jb.resid) out += jb.resid[r0 + t];
-        jb.y[r0 + t] = out;
-    }
-}
-
 template <int TA, int TB, bool PAIR, bool DBG>
-__global__ __launch_bounds__(PM_GEMV_BLOCK, PM_GEMV_BLOCK == 256 ? 4 : 4) void gemv_q_kernel(GemvP p) {
+__global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(GemvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double nred[PM_GEMV_NW];
-    constexpr int ABLK = QT<TA>::ABLK;
-    typedef Item<TA, PAIR> IA;
-    typedef Item<TB, PAIR> IB;
-    constexpr int R = IA::R;
-    int8_t * xs_q  = (int8_t *) smem;                                   // [K] (K % 32 == 0 -> 16-B aligned pieces)
-    int *    xs_gs = (int *) (smem + ((p.K + 15) & ~15));               // [K/16]
-    float *  xs_d  = (float *) (xs_gs + p.K / 16);                      // [K/ABLK]
-    float *  outbuf = xs_d + ((p.K / ABLK + 3) & ~3);                   // [sum of this workgroup's rows]
-    const int b = blockIdx.x, G = gridDim.x, tid = threadIdx.x, lane = tid & 63;
-    // wave index as a SCALAR: everything derived from it (row numbers, row base pointers, loop counters) then lives in
-    // SGPRs and the weight loads use the saddr + 32-bit-voffset form instead of 64-bit VALU address arithmetic
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    // this workgroup's slice [r0, r1) of every job, and the ITEM list = concatenation of the jobs' R-row groups
-    // this workgroup's slice [r0, r1) of every job (scalars, not arrays: a runtime-indexed array would live in scratch)
-    const int r0_0 = (int) ((long) p.job[0].N * b / G), r1_0 = (int) ((long) p.job[0].N * (b + 1) / G);
-    const int r0_1 = (int) ((long) p.job[1].N * b / G), r1_1 = (int) ((long) p.job[1].N * (b + 1) / G);
-    const int r0_2 = (int) ((long) p.job[2].N * b / G), r1_2 = (int) ((long) p.job[2].N * (b + 1) / G);
-    const int ni_0 = (r1_0 - r0_0 + R - 1) / R, ni_1 = (r1_1 - r0_1 + R - 1) / R, ni_2 = (r1_2 - r0_2 + R - 1) / R;
-    const int ob_1 = r1_0 - r0_0, ob_2 = ob_1 + (r1_1 - r0_1);
-
-    // (1) activation row -> LDS (quantized, bit-exact with the reference quantizers).
-    //     [Measured and rejected: pre-issuing the first item's 16-byte weight loads across the prologue (spills under the
-    //      128-VGPR budget, -20 %); an L2 prefetch of that item with one dword per 128-B line (-7 % even when limited to
-    //      the small wq/wo launches: the in-order VMEM return delays the prologue and the lines are fetched twice); and
-    //      splitting the workgroup into 8 prologue waves + 8 waves that pre-issue their first step (-3 %, A/B on one box).]
-    ActRegs areg;
-    stage_issue<ABLK>(p, areg, wave, lane);
-    typename IA::Regs g0, g1;                                           // job 0 is always of type TA (host side orders the jobs)
-#ifndef PM_NO_PREISSUE
-    IA::issue(g0, p, p.job[0], r0_0 + wave * R, r1_0, 0, lane);
-#ifdef PM_PRE2
-    if (!PAIR) {   // second step of this wave: next chunk of the same row(s), or the first chunk of its next item
-        const int cpr0 = (((p.job[0].U + 63) >> 6) + IA::CH - 1) / IA::CH;
-        IA::issue(g1, p, p.job[0], cpr0 > 1 ? r0_0 + wave * R : r0_0 + (wave + PM_GEMV_NW) * R, r1_0, cpr0 > 1 ? IA::CH : 0, lane);
-    }
-#endif
-#endif
-    stage_finish<ABLK>(p, areg, xs_q, xs_gs, xs_d, nred, wave, lane);
-    __syncthreads();
-    const XLds xs = {xs_q, xs_gs, xs_d};
-    // (2) rows. Items of the jobs are dealt to the waves round-robin, continuing across jobs (wave offset rotates) so that
-    //     the small k / v slices do not all land on wave 0.
-    const int w1 = (wave + PM_GEMV_NW - ni_0 % PM_GEMV_NW) % PM_GEMV_NW;            // first item id of this wave in job 1
-    const int w2 = (wave + 2 * PM_GEMV_NW - (ni_0 + ni_1) % PM_GEMV_NW) % PM_GEMV_NW;
-#ifndef PM_NO_PREISSUE
-    IA::template run_job<DBG, true>(g0, g1, p, p.job[0], xs, outbuf, wave, ni_0, r0_0, r1_0, lane);
-#else
-    IA::template run_job<DBG, false>(g0, g1, p, p.job[0], xs, outbuf, wave, ni_0, r0_0, r1_0, lane);
-#endif
-    typename IB::Regs gB, gB1;
-    if (ni_1 > 0) {
-        if (TA != TB && p.job[1].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[1], xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
-        else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[1], xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
-    }
-    if (ni_2 > 0) {
-        if (TA != TB && p.job[2].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[2], xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
-        else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[2], xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
-    }
-    __syncthreads();
-    // (4) coalesced write-out (+bias, +residual)
-    write_out(p.job[0], outbuf, r0_0, r1_0, 0, tid);
-    write_out(p.job[1], outbuf, r0_1, r1_1, ob_1, tid);
-    write_out(p.job[2], outbuf, r0_2, r1_2, ob_2, tid);
+    gemv_body<TA, TB, PAIR, DBG, false>(p, smem, nred, GridBar{nullptr, nullptr, 0, 1, 1});
 }
 
 template <int TA, int TB>
 int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, hipStream_t st) {
-    GemvP p = p_in;
-    if (p.job[0].is_b)                                // the kernel pre-issues job 0 with the TA code path: put a TA job first
-        for (int j = 1; j < 3; ++j) if (p.job[j].N > 0 && !p.job[j].is_b) { const GemvJob t = p.job[0]; p.job[0] = p.job[j]; p.job[j] = t; break; }
+    const GemvP & p = p_in;
     auto go = [&](auto kern) {
         static bool attr_set = false;                 // one flag per instantiation (lambda is instantiated per kern type)
         if (lds > 48 * 1024 && !attr_set) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
@@ -669,6 +59,8 @@ int nv_of(int type) { return type == PM_Q4_K ? QT<PM_Q4_K>::NV : type == PM_Q6_K
 bool type_ok(int t) { return t == PM_Q4_K || t == PM_Q5_K || t == PM_Q6_K || t == PM_Q8_0; }
 
 } // namespace
+
+static int g_num_cus = 0;
 
 int pm_gemv_units_per_row(int type, int64_t K) { return (int) (K / nv_of(type)); }
 
@@ -692,34 +84,38 @@ size_t pm_weight_row_stride(int type, int64_t K) {
     return pm_weight_row_bytes(type, K);
 }
 
-static int g_num_cus = 0;
-
-// Fused launch: up to 3 matrices sharing one activation row.
-int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st) {
+// Validates a fused job list and fills the kernel argument block. ta <= tb are the (at most two) quant types in the
+// canonical order of the instantiated kernels: (Q4_K,Q4_K) (Q5_K,Q5_K) (Q6_K,Q6_K) (Q8_0,Q8_0) (Q4_K,Q6_K) (Q4_K,Q5_K); job 0 is
+// always a `ta` job (the kernel pre-issues it). grid_fixed > 0: the caller's grid (persistent kernel), else chosen here.
+int pmv::gemv_fill(const pm_gemv_fused & a, int grid_fixed, GemvP & p, int & ta_out, int & tb_out, bool & pair_out, size_t & lds_out, int & grid_out) {
     if (a.njobs < 1 || a.njobs > 3) return -4;
-    GemvP p = {};
+    p = GemvP{};
     p.K = a.K; p.xq = (const uint8_t *) a.xq; p.xf = a.xf; p.norm_w = a.norm_w; p.eps = a.eps; p.dbg = a.dbg_int;
     p.xmode = a.xq ? 0 : (a.norm_w ? 2 : 1);
     int ta = a.job[0].type, tb = ta;
     const bool pair = a.job[0].W2 != nullptr;
-    long max_rows = 0;
     for (int j = 0; j < a.njobs; ++j) {
         const int t = a.job[j].type;
         if (!type_ok(t)) return -1;
         if (t != ta) { if (tb == ta) tb = t; else if (t != tb) return -1; }
         if ((a.job[j].W2 != nullptr) != pair) return -1;
-        if (a.job[j].N > max_rows) max_rows = a.job[j].N;
     }
     // a Q8_0 job needs Q8_0-quantized activations, the K-quants need Q8_K: one prologue serves only one family
     if ((ta == PM_Q8_0) != (tb == PM_Q8_0)) return -1;
     if (ta == PM_Q8_0 ? a.K % 32 : a.K % 256) return -2;
     if (pair && ta != tb) return -1;
+    if (ta != tb) {
+        if (ta != PM_Q4_K) { const int t = ta; ta = tb; tb = t; }     // canonical order: Q4_K first
+        if (ta != PM_Q4_K || (tb != PM_Q6_K && tb != PM_Q5_K)) return -1;
+    }
     if (!g_num_cus) { hipDeviceProp_t pr; int dev = 0; (void) hipGetDevice(&dev); g_num_cus = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
-    // 2 workgroups of 8 waves per CU; every workgroup takes an equal slice of the rows of EVERY job
-    int grid = (1024 / PM_GEMV_BLOCK) * g_num_cus;
+    // one workgroup of 16 waves per CU; every workgroup takes an equal slice of the rows of EVERY job
+    int grid = grid_fixed > 0 ? grid_fixed : (1024 / PM_GEMV_BLOCK) * g_num_cus;
     long tot_rows = 0;
     for (int j = 0; j < a.njobs; ++j) tot_rows += a.job[j].N;
-    while ((tot_rows + grid - 1) / grid + 3 > PM_MAX_ROWS_PER_WG) grid *= 2;
+    int rows_cap = PM_MAX_ROWS_PER_WG;
+    if (grid_fixed > 0) rows_cap = (int) ((tot_rows + grid - 1) / grid + 3 > PM_MAX_ROWS_PER_WG ? (tot_rows + grid - 1) / grid + 4 : PM_MAX_ROWS_PER_WG);
+    else while ((tot_rows + grid - 1) / grid + 3 > PM_MAX_ROWS_PER_WG) grid *= 2;
     for (int j = 0; j < 3; ++j) {
         GemvJob & g = p.job[j];
         if (j >= a.njobs) { g.N = 0; continue; }
@@ -728,22 +124,32 @@ int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st) {
         g.N = s.N; g.is_b = (s.type != ta); g.U = a.K / nv_of(s.type);
         g.row_stride = (long) pm_weight_row_stride(s.type, a.K);
     }
+    if (p.job[0].is_b)                                // the kernel pre-issues job 0 with the TA code path: put a TA job first
+        for (int j = 1; j < 3; ++j) if (p.job[j].N > 0 && !p.job[j].is_b) { const GemvJob t = p.job[0]; p.job[0] = p.job[j]; p.job[j] = t; break; }
     const int ablk = ta == PM_Q8_0 ? 32 : 256;
-    const size_t lds = (size_t) ((a.K + 15) & ~15) + (size_t) (a.K / 16) * 4 + (size_t) ((a.K / ablk + 3) & ~3) * 4 + PM_MAX_ROWS_PER_WG * 4;
+    const size_t lds = (size_t) ((a.K + 15) & ~15) + (size_t) (a.K / 16) * 4 + (size_t) ((a.K / ablk + 3) & ~3) * 4 + (size_t) rows_cap * 4;
     if (lds > 150 * 1024) return -4;
+    ta_out = ta; tb_out = tb; pair_out = pair; lds_out = lds; grid_out = grid;
+    return 0;
+}
+
+int pm_device_cus() {
+    if (!g_num_cus) { hipDeviceProp_t pr; int dev = 0; (void) hipGetDevice(&dev); g_num_cus = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
+    return g_num_cus;
+}
+
+// Fused launch: up to 3 matrices sharing one activation row.
+int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st) {
+    GemvP p; int ta, tb, grid; bool pair; size_t lds;
+    const int rc = gemv_fill(a, 0, p, ta, tb, pair, lds, grid);
+    if (rc) return rc;
 #define PM_L(TA_, TB_) return launch_types<TA_, TB_>(p, pair, grid, lds, a.dbg_int != nullptr, st)
     if (ta == PM_Q4_K && tb == PM_Q4_K) PM_L(PM_Q4_K, PM_Q4_K);
     if (ta == PM_Q5_K && tb == PM_Q5_K) PM_L(PM_Q5_K, PM_Q5_K);
     if (ta == PM_Q6_K && tb == PM_Q6_K) PM_L(PM_Q6_K, PM_Q6_K);
     if (ta == PM_Q8_0 && tb == PM_Q8_0) PM_L(PM_Q8_0, PM_Q8_0);
-    if ((ta == PM_Q4_K && tb == PM_Q6_K) || (ta == PM_Q6_K && tb == PM_Q4_K)) {
-        if (ta == PM_Q6_K) for (int j = 0; j < a.njobs; ++j) p.job[j].is_b = !p.job[j].is_b;
-        PM_L(PM_Q4_K, PM_Q6_K);
-    }
-    if ((ta == PM_Q4_K && tb == PM_Q5_K) || (ta == PM_Q5_K && tb == PM_Q4_K)) {
-        if (ta == PM_Q5_K) for (int j = 0; j < a.njobs; ++j) p.job[j].is_b = !p.job[j].is_b;
-        PM_L(PM_Q4_K, PM_Q5_K);
-    }
+    if (ta == PM_Q4_K && tb == PM_Q6_K) PM_L(PM_Q4_K, PM_Q6_K);
+    if (ta == PM_Q4_K && tb == PM_Q5_K) PM_L(PM_Q4_K, PM_Q5_K);
 #undef PM_L
     return -1;
 }

@@ -28,10 +28,35 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // ---- loads --------------------------------------------------------------------------------------
 // Weights are streamed exactly once per token: non-temporal (global_load ... nt) keeps them from
 // displacing the activation / KV working set in L2 (MI355X_MICROARCH.md "nt-weights").
-__device__ __forceinline__ u32x4 ld_nt16(const void * p) { return __builtin_nontemporal_load((const u32x4 *) p); }
-__device__ __forceinline__ u32x2 ld_nt8(const void * p)  { return __builtin_nontemporal_load((const u32x2 *) p); }
-__device__ __forceinline__ uint32_t ld_nt4(const void * p) { return __builtin_nontemporal_load((const uint32_t *) p); }
-__device__ __forceinline__ uint16_t ld_nt2(const void * p) { return __builtin_nontemporal_load((const uint16_t *) p); }
+// Every pointer these helpers see is device-global memory. The explicit address-space cast makes the backend emit
+// global_load / global_store even where it cannot prove it (pointers read from a descriptor in memory inside the
+// persistent kernel's phase functions would otherwise become FLAT accesses, which count on vmcnt AND lgkmcnt and force
+// s_waitcnt vmcnt(0) lgkmcnt(0) in the row loop).
+#define PM_G __attribute__((address_space(1)))
+__device__ __forceinline__ u32x4 ld_nt16(const void * p) { return __builtin_nontemporal_load((const PM_G u32x4 *) p); }
+__device__ __forceinline__ u32x2 ld_nt8(const void * p)  { return __builtin_nontemporal_load((const PM_G u32x2 *) p); }
+__device__ __forceinline__ uint32_t ld_nt4(const void * p) { return __builtin_nontemporal_load((const PM_G uint32_t *) p); }
+__device__ __forceinline__ uint16_t ld_nt2(const void * p) { return __builtin_nontemporal_load((const PM_G uint16_t *) p); }
+// A pointer that arrives in VGPRs (function argument) but is the same in every lane and points to read-only memory:
+// rebuild it from SGPRs in the constant address space, so that what is read through it is fetched with s_load into SGPRs
+// (and may be hoisted out of loops) instead of with per-lane FLAT loads.
+#define PM_C __attribute__((address_space(4)))
+template <typename T> __device__ __forceinline__ const T * uniform_const_ptr(const T * p) {
+    const uint64_t u = (uint64_t) p;
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) u), hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (u >> 32));
+    return (const T *) (const PM_C T *) (((uint64_t) hi << 32) | lo);
+}
+// same, for a pointer to WRITABLE global memory: only made scalar (the accesses through it cast to PM_G themselves)
+template <typename T> __device__ __forceinline__ T * uniform_ptr(T * p) {
+    const uint64_t u = (uint64_t) p;
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) u), hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (u >> 32));
+    return (T *) (((uint64_t) hi << 32) | lo);
+}
+// plain (cached) global loads / stores
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ T ld_g(const T * p) { return *(const PM_G T *) p; }
+__device__ __forceinline__ float4 ld_g(const float4 * p) { const f32x4 t = *(const PM_G f32x4 *) p; return make_float4(t.x, t.y, t.z, t.w); }
+template <typename T> __device__ __forceinline__ void st_g(T * p, T v) { *(PM_G T *) p = v; }
 
 __device__ __forceinline__ float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
 __device__ __forceinline__ uint16_t f2h(float f) { return __half_as_ushort(__float2half_rn(f)); }   // RNE, == GGML_FP32_TO_FP16
@@ -106,4 +131,29 @@ __device__ __forceinline__ void k4_scale_min_pair(uint32_t s0, uint32_t s1, uint
     const uint32_t sc = p < 2 ? sc_lo : sc_hi, m = p < 2 ? m_lo : m_hi;
     sc0 = (int) (sc & 0xFF); sc1 = (int) (sc >> 8);
     m0  = (int) (m & 0xFF);  m1  = (int) (m >> 8);
+}
+
+// ---- device-coherent activation traffic of the persistent kernel ------------------------------------------------------
+// Activations written by one workgroup and read by another INSIDE one kernel (decode_kernel.hip) go through agent-scope
+// relaxed atomics: global_load / global_store ... sc1, which are coherent across the 8 XCD L2s without any cache
+// write-back / invalidate. COH = false: plain accesses (stand-alone launches: kernel boundaries do the maintenance).
+template <bool COH> __device__ __forceinline__ float ld_act(const float * p) {
+    if (COH) return __hip_atomic_load((const PM_G float *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ld_g(p);
+}
+template <bool COH> __device__ __forceinline__ float4 ld_act4(const float4 * p) {
+    if (COH) {
+        const PM_G float * f = (const PM_G float *) p;
+        float4 r;
+        r.x = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.y = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.z = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.w = __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return r;
+    }
+    return ld_g(p);
+}
+template <bool COH> __device__ __forceinline__ void st_act(float * p, float v) {
+    if (COH) __hip_atomic_store((PM_G float *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else st_g(p, v);
 }

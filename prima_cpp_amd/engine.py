@@ -75,6 +75,7 @@ def _lib():
             "pm355_model_kv_ptr": (_vp, [_vp, _i32, _i32]),
             "pm355_model_decode": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
             "pm355_model_generate": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
+            "pm355_model_check": (_i32, [_vp]),
             "pm355_model_set_pos": (_i32, [_vp, _i32, _vp]),
             "pm355_model_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
         }
@@ -225,6 +226,10 @@ class Window:
 
     def generate(self, tokens_io, pos0, n_steps, use_graph=True):
         self._chk(self.lib.pm355_model_generate(self.h, ptr(tokens_io), pos0, n_steps, int(use_graph), stream_ptr()), "generate")
+
+    def check(self):
+        """0, or non-zero once a persistent decode kernel's barrier watchdog fired (synchronizes the device)."""
+        return int(self.lib.pm355_model_check(self.h))
 
     def set_pos(self, pos):
         self._chk(self.lib.pm355_model_set_pos(self.h, pos, stream_ptr()), "set_pos")
