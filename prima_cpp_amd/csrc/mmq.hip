@@ -21,19 +21,16 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 64, LDS_STRIDE = BK + 8;       // halfs per LDS row
 
-// 32 consecutive weights k0..k0+31 (k0 % 32 == 0) of one row, exact dequantize_row_* arithmetic in f32
+// 32 consecutive weights k0..k0+31 (k0 % 32 == 0) of one row in two halves, so that the global loads of the NEXT k-step
+// can be in flight while the matrix cores work on the current one: fetch() = the raw 16-byte pieces, convert() = the
+// exact dequantize_row_* arithmetic in f32 on them.
+struct RawW { u32x4 r[5]; uint32_t s; };
+
 template <int TYPE>
-__device__ __forceinline__ void dequant32(const uint8_t * row, int K, int k0, float (&o)[32]) {
+__device__ __forceinline__ void fetch_w(const uint8_t * row, int K, int k0, RawW & w) {
     if (TYPE == PM_Q8_0) {                                             // row-SoA: qa[nb][16] | qb[nb][16] | half d[nb]
-        const float d = h2f(((const uint16_t *) (row + K))[k0 >> 5]);
-        const u32x4 a = *(const u32x4 *) (row + (k0 >> 1)), b = *(const u32x4 *) (row + K / 2 + (k0 >> 1));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[4 * i + j]      = (float) (int8_t) (a[i] >> (8 * j)) * d;
-                o[16 + 4 * i + j] = (float) (int8_t) (b[i] >> (8 * j)) * d;
-            }
+        w.s = ((const uint16_t *) (row + K))[k0 >> 5];
+        w.r[0] = *(const u32x4 *) (row + (k0 >> 1)); w.r[1] = *(const u32x4 *) (row + K / 2 + (k0 >> 1));
         return;
     }
     const int b = k0 >> 8, s = (k0 & 255) >> 5;                         // super-block, 32-value sub-block
@@ -41,24 +38,10 @@ __device__ __forceinline__ void dequant32(const uint8_t * row, int K, int k0, fl
         // Q4_K row-SoA: qa[U][16] | qb[U][16] | hdr[nb][16] (unit = block*4 + s/2);  Q5_K native 176-byte blocks
         const long nb4 = K / 256;
         const uint8_t * blk = row + (long) b * PM_BS_Q5_K;
-        const u32x4 h = *(const u32x4 *) (TYPE == PM_Q4_K ? row + nb4 * 128 + (long) b * 16 : blk);
-        int sc, mn;
-        k4_scale_min(h[1], h[2], h[3], s, sc, mn);
-        const float ds = h2f((uint16_t) (h[0] & 0xFFFF)) * (float) sc, ms = h2f((uint16_t) (h[0] >> 16)) * (float) mn;
+        w.r[2] = *(const u32x4 *) (TYPE == PM_Q4_K ? row + nb4 * 128 + (long) b * 16 : blk);
         const uint8_t * qa = TYPE == PM_Q4_K ? row + 16 * (4 * (long) b + (s >> 1)) : blk + 48 + 32 * (s >> 1);
-        const u32x4 q0 = *(const u32x4 *) qa, q1 = *(const u32x4 *) (qa + (TYPE == PM_Q4_K ? nb4 * 64 : 16));
-        u32x4 hb0 = {0, 0, 0, 0}, hb1 = {0, 0, 0, 0};
-        if (TYPE == PM_Q5_K) { hb0 = *(const u32x4 *) (blk + 16); hb1 = *(const u32x4 *) (blk + 32); }
-        const int sh = (s & 1) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int v0 = (q0[i] >> (8 * j + sh)) & 0xF, v1 = (q1[i] >> (8 * j + sh)) & 0xF;
-                if (TYPE == PM_Q5_K) { v0 += ((hb0[i] >> (8 * j + s)) & 1) << 4; v1 += ((hb1[i] >> (8 * j + s)) & 1) << 4; }
-                o[4 * i + j] = ds * (float) v0 - ms;
-                o[16 + 4 * i + j] = ds * (float) v1 - ms;
-            }
+        w.r[0] = *(const u32x4 *) qa; w.r[1] = *(const u32x4 *) (qa + (TYPE == PM_Q4_K ? nb4 * 64 : 16));
+        if (TYPE == PM_Q5_K) { w.r[3] = *(const u32x4 *) (blk + 16); w.r[4] = *(const u32x4 *) (blk + 32); }
         return;
     }
     // Q6_K row-SoA: la[U][16] | lb[U][16] | qh[U][16] | sc[nb][16] | d[nb], unit = 4 b + 2 hh + v;  sub-block s -> half
@@ -67,32 +50,76 @@ __device__ __forceinline__ void dequant32(const uint8_t * row, int K, int k0, fl
     const int hh = s >> 2, kq = s & 3;
     const uint8_t * ql = row + (kq & 1) * nb * 64 + 16 * (4 * (long) b + 2 * hh);
     const uint8_t * qh = row + nb * 128 + (long) b * 64 + 32 * hh;
-    const int8_t * scl = (const int8_t *) (row + nb * 192 + (long) b * 16 + 8 * hh + 2 * kq);
-    const float d = h2f(((const uint16_t *) (row + nb * 208))[b]);
-    const u32x4 l0 = *(const u32x4 *) ql, l1 = *(const u32x4 *) (ql + 16), h0 = *(const u32x4 *) qh, h1 = *(const u32x4 *) (qh + 16);
-    const float d0 = d * (float) scl[0], d1 = d * (float) scl[1];
+    w.r[0] = *(const u32x4 *) ql; w.r[1] = *(const u32x4 *) (ql + 16); w.r[2] = *(const u32x4 *) qh; w.r[3] = *(const u32x4 *) (qh + 16);
+    w.s = (uint32_t) *(const uint16_t *) (row + nb * 192 + (long) b * 16 + 8 * hh + 2 * kq) | ((uint32_t) ((const uint16_t *) (row + nb * 208))[b] << 16);
+}
+
+template <int TYPE>
+__device__ __forceinline__ void convert_w(const RawW & w, int k0, float (&o)[32]) {
+    if (TYPE == PM_Q8_0) {
+        const float d = h2f((uint16_t) w.s);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[4 * i + j]      = (float) (int8_t) (w.r[0][i] >> (8 * j)) * d;
+                o[16 + 4 * i + j] = (float) (int8_t) (w.r[1][i] >> (8 * j)) * d;
+            }
+        return;
+    }
+    const int s = (k0 & 255) >> 5;
+    if (TYPE == PM_Q4_K || TYPE == PM_Q5_K) {
+        const u32x4 h = w.r[2];
+        int sc, mn;
+        k4_scale_min(h[1], h[2], h[3], s, sc, mn);
+        const float ds = h2f((uint16_t) (h[0] & 0xFFFF)) * (float) sc, ms = h2f((uint16_t) (h[0] >> 16)) * (float) mn;
+        const int sh = (s & 1) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int v0 = (w.r[0][i] >> (8 * j + sh)) & 0xF, v1 = (w.r[1][i] >> (8 * j + sh)) & 0xF;
+                if (TYPE == PM_Q5_K) { v0 += ((w.r[3][i] >> (8 * j + s)) & 1) << 4; v1 += ((w.r[4][i] >> (8 * j + s)) & 1) << 4; }
+                o[4 * i + j] = ds * (float) v0 - ms;
+                o[16 + 4 * i + j] = ds * (float) v1 - ms;
+            }
+        return;
+    }
+    const int kq = s & 3;
+    const float d = h2f((uint16_t) (w.s >> 16));
+    const float d0 = d * (float) (int8_t) (w.s & 0xFF), d1 = d * (float) (int8_t) ((w.s >> 8) & 0xFF);
     const int lsh = (kq >> 1) * 4, hsh = 2 * kq;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int v0 = (int) (((l0[i] >> (8 * j + lsh)) & 0xF) | (((h0[i] >> (8 * j + hsh)) & 3) << 4)) - 32;
-            const int v1 = (int) (((l1[i] >> (8 * j + lsh)) & 0xF) | (((h1[i] >> (8 * j + hsh)) & 3) << 4)) - 32;
+            const int v0 = (int) (((w.r[0][i] >> (8 * j + lsh)) & 0xF) | (((w.r[2][i] >> (8 * j + hsh)) & 3) << 4)) - 32;
+            const int v1 = (int) (((w.r[1][i] >> (8 * j + lsh)) & 0xF) | (((w.r[3][i] >> (8 * j + hsh)) & 3) << 4)) - 32;
             o[4 * i + j] = d0 * (float) v0;
             o[16 + 4 * i + j] = d1 * (float) v1;
         }
 }
 
 struct GemmP {
-    const uint8_t * W; const float * X; float * Y; const float * bias; const float * resid;
+    const uint8_t * W; const _Float16 * Xh; float * Y; const float * bias; const float * resid;
     long row_stride; int K, N, T;
 };
 
-// grid (ceil(N/128), ceil(T/128)), 256 threads
+// f32 -> f16 (RNE, == GGML_FP32_TO_FP16) of the activation matrix, once per GEMM call instead of once per weight tile
+__global__ __launch_bounds__(256) void cvt_f16_kernel(const float * __restrict__ x, _Float16 * __restrict__ y, long n8) {
+    const long i = (long) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const float4 a = ((const float4 *) x)[2 * i], b = ((const float4 *) x)[2 * i + 1];
+    half8 v = {(_Float16) a.x, (_Float16) a.y, (_Float16) a.z, (_Float16) a.w, (_Float16) b.x, (_Float16) b.y, (_Float16) b.z, (_Float16) b.w};
+    ((half8 *) y)[i] = v;
+}
+
+// grid (ceil(N/128), ceil(T/128)), 256 threads. Software pipeline over k-steps with two LDS buffers: the raw weight pieces
+// and the f16 activations of step s+1 are loaded into registers before the MFMAs of step s and are dequantized / stored
+// into the other LDS buffer after them; one barrier per step.
 template <int TYPE>
-__global__ __launch_bounds__(256) void gemm_q_f16_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) _Float16 As[BM * LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[BN * LDS_STRIDE];
+__global__ __launch_bounds__(256, 2) void gemm_q_f16_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];      // [2][(BM + BN) * LDS_STRIDE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * BM, t0 = blockIdx.y * BN;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;             // this wave's 64x64 block inside the tile
@@ -106,32 +133,37 @@ __global__ __launch_bounds__(256) void gemm_q_f16_kernel(GemmP p) {
 
     const int lrow = tid >> 1, lhalf = tid & 1;                        // staging: thread -> (tile row, 32-k half)
     const int wrow = min(n0 + lrow, p.N - 1), trow = min(t0 + lrow, p.T - 1);
-    for (int k0 = 0; k0 < p.K; k0 += BK) {
-        // ---- stage A: dequantize 32 weights -> f16
-        {
-            float o[32];
-            dequant32<TYPE>(p.W + (long) wrow * p.row_stride, p.K, k0 + 32 * lhalf, o);
-            _Float16 * dst = As + lrow * LDS_STRIDE + 32 * lhalf;
+    const uint8_t * wptr = p.W + (long) wrow * p.row_stride;
+    const _Float16 * xptr = p.Xh + (long) trow * p.K + 32 * lhalf;
+    constexpr int BUF = (BM + BN) * LDS_STRIDE;
+    RawW rw; half8 rx[4];
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+        fetch_w<TYPE>(wptr, p.K, k0 + 32 * lhalf, rw);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                half8 v;
+        for (int i = 0; i < 4; ++i) rx[i] = *(const half8 *) (xptr + k0 + 8 * i);
+    };
+    auto stage = [&](int k0, _Float16 * buf) __attribute__((always_inline)) {
+        float o[32];
+        convert_w<TYPE>(rw, k0 + 32 * lhalf, o);
+        _Float16 * da = buf + lrow * LDS_STRIDE + 32 * lhalf;
+        _Float16 * db = buf + (BM + lrow) * LDS_STRIDE + 32 * lhalf;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (_Float16) o[8 * i + j];
-                *(half8 *) (dst + 8 * i) = v;
-            }
+        for (int i = 0; i < 4; ++i) {
+            half8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (_Float16) o[8 * i + j];
+            *(half8 *) (da + 8 * i) = v;
+            *(half8 *) (db + 8 * i) = rx[i];
         }
-        // ---- stage B: 32 activations of one token -> f16
-        {
-            const float * src = p.X + (long) trow * p.K + k0 + 32 * lhalf;
-            _Float16 * dst = Bs + lrow * LDS_STRIDE + 32 * lhalf;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 a = *(const float4 *) (src + 8 * i), b = *(const float4 *) (src + 8 * i + 4);
-                half8 v = {(_Float16) a.x, (_Float16) a.y, (_Float16) a.z, (_Float16) a.w, (_Float16) b.x, (_Float16) b.y, (_Float16) b.z, (_Float16) b.w};
-                *(half8 *) (dst + 8 * i) = v;
-            }
-        }
-        __syncthreads();
+    };
+    fetch(0);
+    stage(0, lds);
+    __syncthreads();
+    int it = 0;
+    for (int k0 = 0; k0 < p.K; k0 += BK, ++it) {
+        const _Float16 * As = lds + (it & 1) * BUF, * Bs = As + BM * LDS_STRIDE;
+        const bool more = k0 + BK < p.K;
+        if (more) fetch(k0 + BK);
         // ---- MFMA: A fragment lane l = A[row = l&31][k = 8*(l>>5) .. +8], B fragment = B[k][col = l&31]
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
@@ -145,6 +177,7 @@ __global__ __launch_bounds__(256) void gemm_q_f16_kernel(GemmP p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (more) stage(k0 + BK, lds + ((it + 1) & 1) * BUF);
         __syncthreads();
     }
     // ---- epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]; Y[t][n]: 4 consecutive n per float4
@@ -177,17 +210,34 @@ __global__ __launch_bounds__(256) void gemm_q_f16_kernel(GemmP p) {
 
 } // namespace
 
+// f16 copy of the activations: one scratch buffer per process, grown on demand (single stream of GEMM calls per device)
+static _Float16 * g_xh = nullptr;
+static size_t g_xh_elems = 0;
+
 int pm_launch_gemm_q(int type, const void * W, const float * X, float * Y, int K, int N, int T, const float * bias,
                      const float * resid, hipStream_t st) {
     if (K % 64 || (type != PM_Q8_0 && K % 256) || N % 4) return -2;
-    GemmP p = {(const uint8_t *) W, X, Y, bias, resid, (long) pm_weight_row_stride(type, K), K, N, T};
+    if (type != PM_Q4_K && type != PM_Q5_K && type != PM_Q6_K && type != PM_Q8_0) return -1;
+    const size_t need = (size_t) T * K;
+    if (need > g_xh_elems) {
+        if (g_xh) { (void) hipStreamSynchronize(st); (void) hipFree(g_xh); }
+        if (hipMalloc((void **) &g_xh, need * 2) != hipSuccess) { g_xh = nullptr; g_xh_elems = 0; return -3; }
+        g_xh_elems = need;
+    }
+    hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) ((need / 8 + 255) / 256)), dim3(256), 0, st, X, g_xh, (long) (need / 8));
+    GemmP p = {(const uint8_t *) W, g_xh, Y, bias, resid, (long) pm_weight_row_stride(type, K), K, N, T};
     const dim3 grid((N + BM - 1) / BM, (T + BN - 1) / BN);
+    const size_t lds = (size_t) 2 * (BM + BN) * LDS_STRIDE * sizeof(_Float16);
+    auto go = [&](auto kern) {
+        static bool attr = false;
+        if (!attr) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr = true; }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    };
     switch (type) {
-        case PM_Q4_K: hipLaunchKernelGGL(gemm_q_f16_kernel<PM_Q4_K>, grid, dim3(256), 0, st, p); break;
-        case PM_Q5_K: hipLaunchKernelGGL(gemm_q_f16_kernel<PM_Q5_K>, grid, dim3(256), 0, st, p); break;
-        case PM_Q6_K: hipLaunchKernelGGL(gemm_q_f16_kernel<PM_Q6_K>, grid, dim3(256), 0, st, p); break;
-        case PM_Q8_0: hipLaunchKernelGGL(gemm_q_f16_kernel<PM_Q8_0>, grid, dim3(256), 0, st, p); break;
-        default: return -1;
+        case PM_Q4_K: go(gemm_q_f16_kernel<PM_Q4_K>); break;
+        case PM_Q5_K: go(gemm_q_f16_kernel<PM_Q5_K>); break;
+        case PM_Q6_K: go(gemm_q_f16_kernel<PM_Q6_K>); break;
+        default:      go(gemm_q_f16_kernel<PM_Q8_0>); break;
     }
     return 0;
 }
