@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--prompt", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prefill", type=int, default=512, help="prompt length of the (untimed-for-the-metric) prefill probe, 0 = off")
+    ap.add_argument("--prefill", type=int, default=2048, help="prompt length of the (untimed-for-the-metric) prefill probe, 0 = off")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -252,7 +252,7 @@ def probe_prefill(hp, mixture, n_tok, n_layers=8):
     full_ms = ms * hp["n_layer"] / n_layers
     return {"prompt_tokens": n_tok, "layers_timed": n_layers, "tokens_per_s_full_depth": round(n_tok / (full_ms / 1e3), 1),
             "gemm_tflops": round(flop / (ms / 1e3) / 1e12, 1), "mfma_peak_tflops_f16_dense": 2500.0,
-            "note": "MFMA v_mfma_f32_32x32x16_f16 GEMMs + per-token attention kernel; layers timed x (n_layer / layers_timed)"}
+            "note": "MFMA v_mfma_f32_32x32x16_f16 weight GEMMs (on-the-fly dequantization) + MFMA causal attention; layers timed x (n_layer / layers_timed); gemm_tflops counts the weight GEMMs only over the whole layer time"}
 
 
 def main():

@@ -149,6 +149,12 @@ PM355_API int pm355_rope_kv_store(const float * q, const float * k, const float 
 PM355_API int pm355_attn_decode(const float * q, const void * k_cache, const void * v_cache, const int32_t * d_pos0,
                                 float * out, int n_tokens, int n_head, int n_head_kv, int head_dim, int n_ctx,
                                 float kq_scale, pm355_stream_t stream);
+/* the same chain for a multi-token (prefill) batch on the MFMA matrix cores: causal, two passes over the keys so that p is
+ * rounded to F16 after the division by the full row sum like the reference (prima_cpp_amd/csrc/attn_prefill.hip).
+ * head_dim 64 or 128, n_ctx % 32 == 0. Same arguments and result layout as pm355_attn_decode. */
+PM355_API int pm355_attn_prefill(const float * q, const void * k_cache, const void * v_cache, const int32_t * d_pos0,
+                                 float * out, int n_tokens, int n_head, int n_head_kv, int head_dim, int n_ctx,
+                                 float kq_scale, pm355_stream_t stream);
 /* single-token fusion of the two entries above (rope on q,k + KV store + attention in ONE launch; what the engine
  * uses at decode). q/k/v are the raw projections of ONE token; the caches receive the new K row / V column. */
 PM355_API int pm355_attn_rope_fused(const float * q, const float * k, const float * v, void * k_cache, void * v_cache,

@@ -1,0 +1,172 @@
+// attn_prefill.hip — causal multi-token (prefill) attention on the MFMA matrix cores of gfx950.
+//
+// Replaces, for n_tokens >= 16, the three nodes of llm_build_kqv without flash-attn (src/llama.cpp:10032-10110):
+//   kq  = MUL_MAT(K F16, q)            ggml_compute_forward_mul_mat with vec_dot_type F16: q is converted to F16, f32 accumulate
+//   p   = SOFT_MAX_EXT(kq, mask, scale) ggml_compute_forward_soft_max_f32 (ggml.c:13783): max, expf, sum, scale by 1/sum
+//   kqv = MUL_MAT(V^T F16, p)          p converted to F16, f32 accumulate
+// with the SAME rounding points (q and p rounded to F16, K / V F16, f32 accumulation) - only the f32 summation order
+// differs. The per-token kernel (attn_decode_kernel) needs O(n_tokens^2) scalar work: 9.2 ms per layer for a 2048-token
+// prompt on the 70B shape, more than all GEMMs of the layer together.
+//
+// Design. One workgroup = 128 consecutive query tokens of one head, 4 waves x 32 queries. Everything is computed
+// TRANSPOSED so that a query is a COLUMN of the MFMA result: S^T = K Q^T (keys x queries) and O^T = V^T P^T. In the
+// 32x32 accumulator layout a lane then holds 16 keys of ONE query (column = lane & 31), so the softmax row statistics are
+// in-lane reductions plus one exchange with the partner lane (lane ^ 32), and P^T comes out of the accumulator in exactly
+// the order the next MFMA wants its B operand (again with one partner exchange) - no LDS round trip, no LDS at all.
+// K rows ([key][dh] F16) and V^T rows ([dh][key] F16, the reference's transposed V cache) are both "k-contiguous" MFMA A
+// operands and are read straight from global memory (the 4 waves of a workgroup and the 8 query heads of a KV group share
+// them through L1 / L2). Two passes over the keys, because p must be rounded to F16 AFTER the division by the full row
+// sum, exactly like the reference: pass 1 = row max and sum (online), pass 2 = recompute S, p = exp(s - max) / sum -> F16,
+// accumulate O. FLOPs: 3 x (n_q x n_kv x dh x 2) / 2 per head.
+#include "pm355_device.h"
+#include "pm355_layer_ops.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+struct PfP {
+    const float * q; const uint16_t * kc; const uint16_t * vc; const int32_t * pos0_ptr; const int32_t * seq_ptr; long seq_stride;
+    float * out; int T, H, Hkv, n_ctx; float scale;
+};
+
+// key index (inside a 32-key tile) of accumulator register r in lane-half h: C[row = (r&3) + 8 (r>>2) + 4 h][col]
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
+    constexpr int KK = DH / 16;                  // k-steps of the S^T MFMAs
+    constexpr int DT = DH / 32;                  // 32-row tiles of O^T
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, hf = lane >> 5;
+    const int h = blockIdx.y, hk = h / (p.H / p.Hkv);
+    const int seq = p.seq_ptr ? *p.seq_ptr : 0;
+    const int pos0 = p.pos0_ptr[seq];
+    const uint16_t * kc = p.kc + (long) seq * p.seq_stride + (long) hk * DH;          // K[key][Hkv*DH]
+    const uint16_t * vc = p.vc + (long) seq * p.seq_stride + (long) hk * DH * p.n_ctx; // V^T[hk*DH + e][n_ctx]
+    const int tq0 = blockIdx.x * 128 + wave * 32;                                      // first query token of this wave
+    if (tq0 >= p.T) return;
+    const int tq = min(tq0 + col, p.T - 1);                                            // this lane's query (clamped)
+    const int qpos = pos0 + tq;                                                        // attends keys 0 .. qpos
+    const int last = pos0 + min(tq0 + 31, p.T - 1);                                    // wave-uniform causal limit
+    const int n_tiles = last / 32 + 1;
+    const long krow = (long) p.Hkv * DH;
+
+    // Q^T as B operand: lane (col = query, hf) holds q[query][16 kk + 8 hf .. +8], rounded to F16 like the reference
+    half8 qf[KK];
+    {
+        const float * qr = p.q + ((long) tq * p.H + h) * DH + 8 * hf;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const float4 a = *(const float4 *) (qr + 16 * kk), b = *(const float4 *) (qr + 16 * kk + 4);
+            qf[kk] = half8{(_Float16) a.x, (_Float16) a.y, (_Float16) a.z, (_Float16) a.w, (_Float16) b.x, (_Float16) b.y, (_Float16) b.z, (_Float16) b.w};
+        }
+    }
+    // S^T tile (32 keys x 32 queries) of key tile j: A = K rows (lane: key = j*32 + col', dh slice 16 kk + 8 hf)
+    auto scores = [&](int j, float (&s)[16]) __attribute__((always_inline)) {
+        float16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const int key = min(j * 32 + col, p.n_ctx - 1);
+        const uint16_t * kr = kc + (long) key * krow + 8 * hf;
+        half8 kf[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) kf[kk] = *(const half8 *) (kr + 16 * kk);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = j * 32 + acc_row(r, hf);
+            s[r] = k <= qpos ? acc[r] * p.scale : -INFINITY;        // soft_max_ext: x * scale (+ causal mask = -inf)
+        }
+    };
+
+    // ---- pass 1: row max and sum of exp (online within the lane, merged with the partner lane at the end)
+    float m = -INFINITY, l = 0.0f;
+    for (int j = 0; j < n_tiles; ++j) {
+        float s[16];
+        scores(j, s);
+        float mt = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+        const float mn = fmaxf(m, mt);
+        if (mn != -INFINITY) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc += expf(s[r] - mn);
+            l = l * expf(m - mn) + acc;          // m == -inf: l == 0 and expf(-inf) == 0
+            m = mn;
+        }
+    }
+    {
+        const float mo = __shfl_xor(m, 32), lo = __shfl_xor(l, 32);
+        const float mn = fmaxf(m, mo);           // key 0 is always visible: mn is finite
+        l = (m == -INFINITY ? 0.0f : l * expf(m - mn)) + (mo == -INFINITY ? 0.0f : lo * expf(mo - mn));
+        m = mn;
+    }
+    const float inv = 1.0f / l;
+
+    // ---- pass 2: p = exp(s - m) * inv -> F16;  O^T (dh x queries) += V^T tile (dh x keys) . P^T tile (keys x queries)
+    float16v o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.0f;
+    for (int j = 0; j < n_tiles; ++j) {
+        float s[16];
+        scores(j, s);
+        half4 pk[4];                             // pk[g] = the 4 keys 8 g + 4 hf .. +4 of this query
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pk[g][i] = (_Float16) (expf(s[4 * g + i] - m) * inv);
+        // B operand of k-step kk (keys 16 kk .. +16): lane half hf wants keys 16 kk + 8 hf .. +8 = two groups of 4, one of
+        // which sits in the partner lane (lane ^ 32)
+        half8 pf[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const half4 mine = hf ? pk[2 * kk + 1] : pk[2 * kk];         // keys this lane keeps
+            const half4 send = hf ? pk[2 * kk] : pk[2 * kk + 1];         // keys the partner needs
+            uint32_t s0 = ((const uint32_t *) &send)[0], s1 = ((const uint32_t *) &send)[1];
+            s0 = (uint32_t) __shfl_xor((int) s0, 32); s1 = (uint32_t) __shfl_xor((int) s1, 32);
+            half4 got;
+            ((uint32_t *) &got)[0] = s0; ((uint32_t *) &got)[1] = s1;
+            const half4 lo = hf ? got : mine, hi = hf ? mine : got;      // ascending key order
+            pf[kk] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        const int key0 = j * 32;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            const uint16_t * vr = vc + (long) (32 * d + col) * p.n_ctx + key0 + 8 * hf;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const half8 vf = *(const half8 *) (vr + 16 * kk);
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kk], o[d], 0, 0, 0);
+            }
+        }
+    }
+    // ---- O^T[dh = 32 d + acc_row(r, hf)][query = col] -> out[t][h*DH + dh]
+    if (tq0 + col < p.T) {
+        float * orow = p.out + ((long) tq * p.H + h) * DH;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4 *) (orow + 32 * d + 8 * g + 4 * hf) = float4{o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]};
+    }
+}
+
+} // namespace
+
+// n_ctx % 32 == 0 and head_dim 64 / 128 only (callers fall back to the per-token kernel otherwise)
+int pm_launch_attn_prefill(const float * q, const void * kc, const void * vc, const int32_t * pos0, const int32_t * seq,
+                           long seq_stride, float * out, int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st) {
+    if ((dh != 64 && dh != 128) || n_ctx % 32 || n_tok < 1) return -1;
+    PfP p = {q, (const uint16_t *) kc, (const uint16_t *) vc, pos0, seq, seq_stride, out, n_tok, H, Hkv, n_ctx, scale};
+    const dim3 grid((n_tok + 127) / 128, H);
+    if (dh == 128) hipLaunchKernelGGL(attn_prefill_kernel<128>, grid, dim3(256), 0, st, p);
+    else           hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, dim3(256), 0, st, p);
+    return 0;
+}

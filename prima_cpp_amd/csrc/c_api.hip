@@ -194,6 +194,13 @@ int pm355_attn_decode(const float * q, const void * kc, const void * vc, const i
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_attn_prefill(const float * q, const void * kc, const void * vc, const int32_t * d_pos0, float * out, int n_tokens,
+                       int H, int Hkv, int dh, int n_ctx, float kq_scale, pm355_stream_t st) {
+    if (pm_launch_attn_prefill(q, kc, vc, d_pos0, nullptr, 0, out, n_tokens, H, Hkv, dh, n_ctx, kq_scale, S(st)))
+        return fail(PM355_E_RANGE, "attn_prefill: head_dim must be 64 or 128 and n_ctx a multiple of 32");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 int pm355_attn_rope_fused(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * d_pos0,
                           const float * ff, float * out, int H, int Hkv, int dh, int n_ctx, float kq_scale,
                           const pm355_rope_params * rp, pm355_stream_t st) {

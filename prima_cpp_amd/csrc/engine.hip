@@ -370,7 +370,8 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
             const long kvs = (long) hp.n_ctx * Hkv * dh;
             pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kvs,
                                     (const float *) m->rope_freqs.d, T, H, Hkv, dh, hp.n_ctx, m->rope, st);
-            if (pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
+            if (pm_launch_attn_prefill(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st) &&
+                pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
                 return seterr(m, PM355_E_RANGE, "prefill: n_ctx too large for the attention kernel");
             float * x_mid = (cur == bufs[0]) ? bufs[1] : bufs[0];
             if (G(L.t[PM355_T_WO], m->att, x_mid, nullptr, cur)) return seterr(m, PM355_E_UNSUPPORTED, "prefill: wo gemm");

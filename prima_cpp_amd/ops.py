@@ -151,6 +151,20 @@ def attn_decode(q, k_cache, v_cache, pos0, n_head, n_head_kv, head_dim, n_ctx, s
     return out
 
 
+def attn_prefill(q, k_cache, v_cache, pos0, n_head, n_head_kv, head_dim, n_ctx, scale):
+    """Causal multi-token attention on MFMA (same contract as attn_decode)."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_attn_prefill.restype = C.c_int
+    lib.pm355_attn_prefill.argtypes = [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_float, C.c_void_p]
+    T = q.shape[0]
+    out = torch.empty_like(q)
+    pos = torch.tensor([pos0], dtype=torch.int32, device=q.device)
+    check(lib.pm355_attn_prefill(ptr(q), ptr(k_cache), ptr(v_cache), ptr(pos), ptr(out), T, n_head, n_head_kv, head_dim,
+                                 n_ctx, float(scale), stream_ptr()), "attn_prefill")
+    return out
+
+
 def argmax(x):
     lib = L.load()
     idx = torch.empty(1, dtype=torch.int32, device=x.device)

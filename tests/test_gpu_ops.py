@@ -247,6 +247,35 @@ def test_attn_decode_vs_oracle(P, oracle, n_past, T):
             assert np.abs(out[t, h] - want).max() <= 2e-3 * np.abs(want).max() + 1e-4, (t, h)
 
 
+@pytest.mark.parametrize("dh", [64, 128])
+@pytest.mark.parametrize("n_past,T", [(0, 1), (0, 16), (0, 37), (5, 128), (40, 200), (96, 160)])
+def test_attn_prefill_mfma_vs_exact(P, oracle, n_past, T, dh):
+    """MFMA prefill attention: same rounding points as the reference (q, p -> F16; F16 K/V; f32 accumulate), compared with
+    the float64 restatement of llm_build_kqv on the same f16-rounded inputs AND with the per-token kernel."""
+    torch = P.torch
+    rng = np.random.default_rng(43)
+    H, Hkv, n_ctx = 8, 2, 256
+    n_kv = n_past + T
+    q = rng.normal(0, 1, (T, H, dh)).astype(np.float32)
+    K = rng.normal(0, 1, (n_ctx, Hkv, dh)).astype(np.float16)
+    V = rng.normal(0, 1, (Hkv, dh, n_ctx)).astype(np.float16)
+    K[n_kv:] = 0; V[:, :, n_kv:] = 0
+    args = (_dev(P, q.reshape(T, -1)), _f16bits(P, K), _f16bits(P, V), n_past, H, Hkv, dh, n_ctx, 1.0 / np.sqrt(dh))
+    out = P.attn_prefill(*args).cpu().numpy().reshape(T, H, dh)
+    ref = P.attn_decode(*args).cpu().numpy().reshape(T, H, dh)
+    assert np.abs(out - ref).max() <= 2e-3 * np.abs(ref).max()
+    qh = q.astype(np.float16).astype(np.float64)
+    for t in sorted({0, T // 2, T - 1}):
+        nk = n_past + t + 1
+        for h in range(H):
+            hk = h // (H // Hkv)
+            s = (K[:nk, hk].astype(np.float64) @ qh[t, h]).astype(np.float32) * np.float32(1.0 / np.sqrt(dh))
+            e = np.exp((s - s.max()).astype(np.float32)).astype(np.float32)
+            p = (e * np.float32(1.0 / e.astype(np.float64).sum())).astype(np.float16).astype(np.float64)
+            want = V[hk, :, :nk].astype(np.float64) @ p
+            assert np.abs(out[t, h] - want).max() <= 2e-3 * np.abs(want).max() + 1e-4, (t, h)
+
+
 def test_argmax_first_maximum(P):
     torch = P.torch
     x = torch.randn(128256, device="cuda")
