@@ -3,10 +3,11 @@
 // Replaces ggml_compute_forward_mul_mat (ggml/src/ggml.c:12377) for n_tokens >= 16 (what the reference's CUDA plug-in
 // serves with mul_mat_q / dequantize + cuBLAS, ggml-cuda/mmq.cuh:2583, convert.cu:190-279):
 //     Y[t][n] = sum_k W[n][k] * X[t][k]           W: Q4_K / Q5_K / Q6_K / Q8_0 rows in the HBM layout of repack.hip
-// Design: weights are read from HBM exactly once per 128-token tile, dequantized on the fly (f32 math, the exact
-// d*sc*q - dmin*m of dequantize_row_*, then rounded to F16) into an LDS tile, activations are converted F32 -> F16 into a
-// second LDS tile, and 4 waves run v_mfma_f32_32x32x16_f16 with f32 accumulation (each wave a 64x64 output block =
-// 2x2 MFMA tiles). Tile 128 (weight rows) x 128 (tokens) x 64 (k), LDS rows padded to 72 halfs against bank conflicts.
+// Design: weights are read from HBM exactly once per 256-token tile, dequantized on the fly (f32 math, the exact
+// d*sc*q - dmin*m of dequantize_row_*, then rounded to F16) into an LDS tile; the activations are converted F32 -> F16
+// once per call and copied into a second LDS tile; 8 waves run v_mfma_f32_32x32x16_f16 with f32 accumulation (each wave a
+// 64x64 output block = 2x2 MFMA tiles). Tile 128 (weight rows) x 256 (tokens) x 64 (k), two LDS buffers (software
+// pipeline over k), LDS rows padded to 72 halfs against bank conflicts.
 // This is the compute-bound regime (arithmetic intensity ~ n_tokens FLOP/B >> ridge): the roofline is the dense F16
 // MFMA peak, not HBM. Numerics: like the reference's own GPU large-batch path the activations are NOT re-quantized to
 // Q8_K here; result vs the CPU reference is within the reference's own backend tolerance (NMSE <= 5e-4,
@@ -19,18 +20,18 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 64, LDS_STRIDE = BK + 8;       // halfs per LDS row
+constexpr int BM = 128, BN = 256, BK = 64, LDS_STRIDE = BK + 8;       // weight rows x tokens x k per tile; halfs per LDS row
 
-// 32 consecutive weights k0..k0+31 (k0 % 32 == 0) of one row in two halves, so that the global loads of the NEXT k-step
-// can be in flight while the matrix cores work on the current one: fetch() = the raw 16-byte pieces, convert() = the
-// exact dequantize_row_* arithmetic in f32 on them.
-struct RawW { u32x4 r[5]; uint32_t s; };
+// 16 consecutive weights of one row (part = 0 / 1: first / second half of the 32-weight sub-block starting at k0, k0 % 32
+// == 0) in two steps, so that the global loads of the NEXT k-step can be in flight while the matrix cores work on the
+// current one: fetch() = the raw 16-byte pieces, convert() = the exact dequantize_row_* arithmetic in f32 on them.
+struct RawW { u32x4 r[3]; uint32_t s; };
 
 template <int TYPE>
-__device__ __forceinline__ void fetch_w(const uint8_t * row, int K, int k0, RawW & w) {
+__device__ __forceinline__ void fetch_w(const uint8_t * row, int K, int k0, int part, RawW & w) {
     if (TYPE == PM_Q8_0) {                                             // row-SoA: qa[nb][16] | qb[nb][16] | half d[nb]
         w.s = ((const uint16_t *) (row + K))[k0 >> 5];
-        w.r[0] = *(const u32x4 *) (row + (k0 >> 1)); w.r[1] = *(const u32x4 *) (row + K / 2 + (k0 >> 1));
+        w.r[0] = *(const u32x4 *) (row + part * (K / 2) + (k0 >> 1));
         return;
     }
     const int b = k0 >> 8, s = (k0 & 255) >> 5;                         // super-block, 32-value sub-block
@@ -38,38 +39,33 @@ __device__ __forceinline__ void fetch_w(const uint8_t * row, int K, int k0, RawW
         // Q4_K row-SoA: qa[U][16] | qb[U][16] | hdr[nb][16] (unit = block*4 + s/2);  Q5_K native 176-byte blocks
         const long nb4 = K / 256;
         const uint8_t * blk = row + (long) b * PM_BS_Q5_K;
-        w.r[2] = *(const u32x4 *) (TYPE == PM_Q4_K ? row + nb4 * 128 + (long) b * 16 : blk);
-        const uint8_t * qa = TYPE == PM_Q4_K ? row + 16 * (4 * (long) b + (s >> 1)) : blk + 48 + 32 * (s >> 1);
-        w.r[0] = *(const u32x4 *) qa; w.r[1] = *(const u32x4 *) (qa + (TYPE == PM_Q4_K ? nb4 * 64 : 16));
-        if (TYPE == PM_Q5_K) { w.r[3] = *(const u32x4 *) (blk + 16); w.r[4] = *(const u32x4 *) (blk + 32); }
+        w.r[1] = *(const u32x4 *) (TYPE == PM_Q4_K ? row + nb4 * 128 + (long) b * 16 : blk);
+        w.r[0] = *(const u32x4 *) (TYPE == PM_Q4_K ? row + part * nb4 * 64 + 16 * (4 * (long) b + (s >> 1)) : blk + 48 + 32 * (s >> 1) + 16 * part);
+        if (TYPE == PM_Q5_K) w.r[2] = *(const u32x4 *) (blk + 16 + 16 * part);
         return;
     }
     // Q6_K row-SoA: la[U][16] | lb[U][16] | qh[U][16] | sc[nb][16] | d[nb], unit = 4 b + 2 hh + v;  sub-block s -> half
-    // hh = s/4, quarter kq = s%4: its 32 ql bytes are the pieces v = 0, 1 of stream (kq & 1)
+    // hh = s/4, quarter kq = s%4: its 32 ql bytes are the pieces v = 0, 1 (= part) of stream (kq & 1)
     const long nb = K / 256;
     const int hh = s >> 2, kq = s & 3;
-    const uint8_t * ql = row + (kq & 1) * nb * 64 + 16 * (4 * (long) b + 2 * hh);
-    const uint8_t * qh = row + nb * 128 + (long) b * 64 + 32 * hh;
-    w.r[0] = *(const u32x4 *) ql; w.r[1] = *(const u32x4 *) (ql + 16); w.r[2] = *(const u32x4 *) qh; w.r[3] = *(const u32x4 *) (qh + 16);
-    w.s = (uint32_t) *(const uint16_t *) (row + nb * 192 + (long) b * 16 + 8 * hh + 2 * kq) | ((uint32_t) ((const uint16_t *) (row + nb * 208))[b] << 16);
+    w.r[0] = *(const u32x4 *) (row + (kq & 1) * nb * 64 + 16 * (4 * (long) b + 2 * hh + part));
+    w.r[1] = *(const u32x4 *) (row + nb * 128 + (long) b * 64 + 32 * hh + 16 * part);
+    w.s = (uint32_t) ((const uint8_t *) (row + nb * 192 + (long) b * 16 + 8 * hh + 2 * kq))[part] | ((uint32_t) ((const uint16_t *) (row + nb * 208))[b] << 16);
 }
 
 template <int TYPE>
-__device__ __forceinline__ void convert_w(const RawW & w, int k0, float (&o)[32]) {
+__device__ __forceinline__ void convert_w(const RawW & w, int k0, float (&o)[16]) {
     if (TYPE == PM_Q8_0) {
         const float d = h2f((uint16_t) w.s);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[4 * i + j]      = (float) (int8_t) (w.r[0][i] >> (8 * j)) * d;
-                o[16 + 4 * i + j] = (float) (int8_t) (w.r[1][i] >> (8 * j)) * d;
-            }
+            for (int j = 0; j < 4; ++j) o[4 * i + j] = (float) (int8_t) (w.r[0][i] >> (8 * j)) * d;
         return;
     }
     const int s = (k0 & 255) >> 5;
     if (TYPE == PM_Q4_K || TYPE == PM_Q5_K) {
-        const u32x4 h = w.r[2];
+        const u32x4 h = w.r[1];
         int sc, mn;
         k4_scale_min(h[1], h[2], h[3], s, sc, mn);
         const float ds = h2f((uint16_t) (h[0] & 0xFFFF)) * (float) sc, ms = h2f((uint16_t) (h[0] >> 16)) * (float) mn;
@@ -78,25 +74,21 @@ __device__ __forceinline__ void convert_w(const RawW & w, int k0, float (&o)[32]
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int v0 = (w.r[0][i] >> (8 * j + sh)) & 0xF, v1 = (w.r[1][i] >> (8 * j + sh)) & 0xF;
-                if (TYPE == PM_Q5_K) { v0 += ((w.r[3][i] >> (8 * j + s)) & 1) << 4; v1 += ((w.r[4][i] >> (8 * j + s)) & 1) << 4; }
-                o[4 * i + j] = ds * (float) v0 - ms;
-                o[16 + 4 * i + j] = ds * (float) v1 - ms;
+                int v = (w.r[0][i] >> (8 * j + sh)) & 0xF;
+                if (TYPE == PM_Q5_K) v += ((w.r[2][i] >> (8 * j + s)) & 1) << 4;
+                o[4 * i + j] = ds * (float) v - ms;
             }
         return;
     }
     const int kq = s & 3;
-    const float d = h2f((uint16_t) (w.s >> 16));
-    const float d0 = d * (float) (int8_t) (w.s & 0xFF), d1 = d * (float) (int8_t) ((w.s >> 8) & 0xFF);
+    const float dd = h2f((uint16_t) (w.s >> 16)) * (float) (int8_t) (w.s & 0xFF);
     const int lsh = (kq >> 1) * 4, hsh = 2 * kq;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int v0 = (int) (((w.r[0][i] >> (8 * j + lsh)) & 0xF) | (((w.r[2][i] >> (8 * j + hsh)) & 3) << 4)) - 32;
-            const int v1 = (int) (((w.r[1][i] >> (8 * j + lsh)) & 0xF) | (((w.r[3][i] >> (8 * j + hsh)) & 3) << 4)) - 32;
-            o[4 * i + j] = d0 * (float) v0;
-            o[16 + 4 * i + j] = d1 * (float) v1;
+            const int v = (int) (((w.r[0][i] >> (8 * j + lsh)) & 0xF) | (((w.r[1][i] >> (8 * j + hsh)) & 3) << 4)) - 32;
+            o[4 * i + j] = dd * (float) v;
         }
 }
 
@@ -114,15 +106,18 @@ __global__ __launch_bounds__(256) void cvt_f16_kernel(const float * __restrict__
     ((half8 *) y)[i] = v;
 }
 
-// grid (ceil(N/128), ceil(T/128)), 256 threads. Software pipeline over k-steps with two LDS buffers: the raw weight pieces
-// and the f16 activations of step s+1 are loaded into registers before the MFMAs of step s and are dequantized / stored
-// into the other LDS buffer after them; one barrier per step.
+// grid (ceil(N/128), ceil(T/256)), 512 threads = 8 waves (2 x 4), each a 64x64 output block: a dequantized weight tile
+// serves 256 tokens, so the dequantization VALU work per MFMA is half of what a 128-token tile costs. Software pipeline
+// over k-steps with two LDS buffers: the raw weight pieces and the f16 activations of step s+1 are loaded into registers
+// before the MFMAs of step s and are dequantized / stored into the other LDS buffer after them; one barrier per step.
+// (Measured and rejected: loading three steps ahead - no gain: per step the CU spends ~1000 cycles each on MFMA, on the
+//  dequantization VALU work and on the 128 KB of LDS fragment reads, the global latency is not what limits it.)
 template <int TYPE>
-__global__ __launch_bounds__(256, 2) void gemm_q_f16_kernel(GemmP p) {
+__global__ __launch_bounds__(512) void gemm_q_f16_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];      // [2][(BM + BN) * LDS_STRIDE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * BM, t0 = blockIdx.y * BN;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;             // this wave's 64x64 block inside the tile
+    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 64;             // this wave's 64x64 block inside the tile
     float16v acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -131,30 +126,33 @@ __global__ __launch_bounds__(256, 2) void gemm_q_f16_kernel(GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int lrow = tid >> 1, lhalf = tid & 1;                        // staging: thread -> (tile row, 32-k half)
-    const int wrow = min(n0 + lrow, p.N - 1), trow = min(t0 + lrow, p.T - 1);
-    const uint8_t * wptr = p.W + (long) wrow * p.row_stride;
-    const _Float16 * xptr = p.Xh + (long) trow * p.K + 32 * lhalf;
+    // staging: weights  thread -> (tile row = tid / 4, 32-k half = (tid / 2) % 2, 16-weight part = tid % 2)
+    //          tokens   thread -> (tile row = tid / 2, 32-k half = tid % 2)
+    const int arow = tid >> 2, ahalf = (tid >> 1) & 1, apart = tid & 1;
+    const int brow = tid >> 1, bhalf = tid & 1;
+    const uint8_t * wptr = p.W + (long) min(n0 + arow, p.N - 1) * p.row_stride;
+    const _Float16 * xptr = p.Xh + (long) min(t0 + brow, p.T - 1) * p.K + 32 * bhalf;
     constexpr int BUF = (BM + BN) * LDS_STRIDE;
     RawW rw; half8 rx[4];
     auto fetch = [&](int k0) __attribute__((always_inline)) {
-        fetch_w<TYPE>(wptr, p.K, k0 + 32 * lhalf, rw);
+        fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, apart, rw);
 #pragma unroll
         for (int i = 0; i < 4; ++i) rx[i] = *(const half8 *) (xptr + k0 + 8 * i);
     };
     auto stage = [&](int k0, _Float16 * buf) __attribute__((always_inline)) {
-        float o[32];
-        convert_w<TYPE>(rw, k0 + 32 * lhalf, o);
-        _Float16 * da = buf + lrow * LDS_STRIDE + 32 * lhalf;
-        _Float16 * db = buf + (BM + lrow) * LDS_STRIDE + 32 * lhalf;
+        float o[16];
+        convert_w<TYPE>(rw, k0 + 32 * ahalf, o);
+        _Float16 * da = buf + arow * LDS_STRIDE + 32 * ahalf + 16 * apart;
+        _Float16 * db = buf + (BM + brow) * LDS_STRIDE + 32 * bhalf;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             half8 v;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (_Float16) o[8 * i + j];
             *(half8 *) (da + 8 * i) = v;
-            *(half8 *) (db + 8 * i) = rx[i];
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(half8 *) (db + 8 * i) = rx[i];
     };
     fetch(0);
     stage(0, lds);
@@ -231,7 +229,7 @@ int pm_launch_gemm_q(int type, const void * W, const float * X, float * Y, int K
     auto go = [&](auto kern) {
         static bool attr = false;
         if (!attr) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr = true; }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p);
     };
     switch (type) {
         case PM_Q4_K: go(gemm_q_f16_kernel<PM_Q4_K>); break;
