@@ -133,15 +133,22 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel(GemmP p) {
     const uint8_t * wptr = p.W + (long) min(n0 + arow, p.N - 1) * p.row_stride;
     const _Float16 * xptr = p.Xh + (long) min(t0 + brow, p.T - 1) * p.K + 32 * bhalf;
     constexpr int BUF = (BM + BN) * LDS_STRIDE;
-    RawW rw; half8 rx[4];
-    auto fetch = [&](int k0) __attribute__((always_inline)) {
-        fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, apart, rw);
+    // Two register sets A / B: while the MFMAs of step s run, the SAME straight-line block dequantizes step s+1 (loaded one
+    // iteration earlier) into the other LDS buffer - VALU and matrix pipe of one wave overlap - and issues the loads of step
+    // s+3. No conditionals in the steady state: steps past the end are clamped loads / a redundant store into the idle buffer.
+    struct Regs { RawW w; half8 x[4]; };
+    Regs RA, RB;
+    const int nst = p.K / BK;
+    auto fetch = [&](Regs & R, int st) __attribute__((always_inline)) {
+        const int k0 = min(st, nst - 1) * BK;
+        fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, apart, R.w);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rx[i] = *(const half8 *) (xptr + k0 + 8 * i);
+        for (int i = 0; i < 4; ++i) R.x[i] = *(const half8 *) (xptr + k0 + 8 * i);
     };
-    auto stage = [&](int k0, _Float16 * buf) __attribute__((always_inline)) {
+    auto stage = [&](const Regs & R, int st) __attribute__((always_inline)) {
+        _Float16 * buf = lds + (st & 1) * BUF;
         float o[16];
-        convert_w<TYPE>(rw, k0 + 32 * ahalf, o);
+        convert_w<TYPE>(R.w, min(st, nst - 1) * BK + 32 * ahalf, o);
         _Float16 * da = buf + arow * LDS_STRIDE + 32 * ahalf + 16 * apart;
         _Float16 * db = buf + (BM + brow) * LDS_STRIDE + 32 * bhalf;
 #pragma unroll
@@ -152,17 +159,11 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel(GemmP p) {
             *(half8 *) (da + 8 * i) = v;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(half8 *) (db + 8 * i) = rx[i];
+        for (int i = 0; i < 4; ++i) *(half8 *) (db + 8 * i) = R.x[i];
     };
-    fetch(0);
-    stage(0, lds);
-    __syncthreads();
-    int it = 0;
-    for (int k0 = 0; k0 < p.K; k0 += BK, ++it) {
-        const _Float16 * As = lds + (it & 1) * BUF, * Bs = As + BM * LDS_STRIDE;
-        const bool more = k0 + BK < p.K;
-        if (more) fetch(k0 + BK);
-        // ---- MFMA: A fragment lane l = A[row = l&31][k = 8*(l>>5) .. +8], B fragment = B[k][col = l&31]
+    // MFMA: A fragment lane l = A[row = l&31][k = 8*(l>>5) .. +8], B fragment = B[k][col = l&31]
+    auto mma = [&](int st) __attribute__((always_inline)) {
+        const _Float16 * As = lds + (st & 1) * BUF, * Bs = As + BM * LDS_STRIDE;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             half8 a[2], b[2];
@@ -175,8 +176,30 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel(GemmP p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (more) stage(k0 + BK, lds + ((it + 1) & 1) * BUF);
+    };
+    fetch(RA, 0);
+    stage(RA, 0);
+    fetch(RA, 1); fetch(RB, 2);
+    __syncthreads();
+    // scheduling hint for the block: the 16 MFMAs of a step are issued with ~8 VALU instructions of the dequantization
+    // between them (left alone the compiler emits the MFMAs back to back - the wave then sits in the matrix pipe's issue
+    // queue for 512 cycles - and only afterwards the VALU work)
+    auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // 8 VALU
+        }
+    };
+    for (int st = 0; st < nst; st += 2) {
+        mma(st); stage(RA, st + 1); fetch(RA, st + 3);
+        interleave();
         __syncthreads();
+        if (st + 1 < nst) {
+            mma(st + 1); stage(RB, st + 2); fetch(RB, st + 4);
+            interleave();
+            __syncthreads();
+        }
     }
     // ---- epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]; Y[t][n]: 4 consecutive n per float4
 #pragma unroll
