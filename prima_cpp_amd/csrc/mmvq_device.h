@@ -22,6 +22,8 @@ struct GemvP {
     float eps;
     int xmode, K;
     int32_t * dbg;
+    int ncols;                              // activation columns served by one launch (xmode 0 only when > 1)
+    long xq_stride, y_stride;               // bytes between quantized activation rows; floats between output columns
 };
 
 // Per-type traits. A unit's NV values come in NV/16 groups of 16 CONTIGUOUS activations; group_base() gives the
@@ -171,7 +173,7 @@ __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + expf(-g));
 //   xs_q  int8  [K]        quantized values
 //   xs_gs int32 [K/16]     sums of each 16 consecutive quantized values (min / -32 terms)
 //   xs_d  float [K/ABLK]   block scales (ABLK = 256: Q8_K, float d;  ABLK = 32: Q8_0, fp16-rounded d)
-struct XLds { const int8_t * q; const int * gs; const float * d; };
+struct XLds { const int8_t * q; const int * gs; const float * d; int col_bytes; };   // column c of a multi-column launch: + c * col_bytes
 
 // wave min, result in every lane (lanes that receive nothing from a DPP step keep their own value)
 template <int CTRL, int ROW_MASK = 0xF>
@@ -316,21 +318,25 @@ __device__ __forceinline__ double sumsq4(const float4 & f) {
 
 template <int ABLK, bool COH>
 __device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_t * xs_q, int * xs_gs, float * xs_d, double * nred,
-                                             int wave, int lane) {
+                                             int wave, int lane, int ncols = 1, int col_bytes = 0) {
     const int tid = threadIdx.x;
     const int K = p.K;
     if (p.xmode == 0) {
-        // pre-quantized row-SoA: int8 qs[K] | scales. Copy + group sums.
-        for (int g = tid; g < K / 16; g += PM_GEMV_BLOCK) {
-            const u32x4 t = *(const u32x4 *) (p.xq + 16 * g);
-            *(u32x4 *) (xs_q + 16 * g) = t;
-            int s_ = 0;
+        // pre-quantized row-SoA: int8 qs[K] | scales. Copy + group sums, one LDS region per activation column.
+        for (int c = 0; c < ncols; ++c) {
+            const uint8_t * xq = p.xq + (size_t) c * p.xq_stride;
+            int8_t * cq = xs_q + c * col_bytes; int * cgs = (int *) ((char *) xs_gs + c * col_bytes); float * cd = (float *) ((char *) xs_d + c * col_bytes);
+            for (int g = tid; g < K / 16; g += PM_GEMV_BLOCK) {
+                const u32x4 t = *(const u32x4 *) (xq + 16 * g);
+                *(u32x4 *) (cq + 16 * g) = t;
+                int s_ = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s_ = dot4(t[i], 0x01010101u, s_);
-            xs_gs[g] = s_;
+                for (int i = 0; i < 4; ++i) s_ = dot4(t[i], 0x01010101u, s_);
+                cgs[g] = s_;
+            }
+            for (int b = tid; b < K / ABLK; b += PM_GEMV_BLOCK)
+                cd[b] = ABLK == 256 ? ((const float *) (xq + K))[b] : h2f(((const uint16_t *) (xq + K))[b]);
         }
-        for (int b = tid; b < K / ABLK; b += PM_GEMV_BLOCK)
-            xs_d[b] = ABLK == 256 ? ((const float *) (p.xq + K))[b] : h2f(((const uint16_t *) (p.xq + K))[b]);
         return;
     }
     const float4 * xf4 = (const float4 *) p.xf, * nw4 = (const float4 *) p.norm_w;
@@ -408,22 +414,25 @@ __device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_
 }
 
 template <int TYPE>
-__device__ __forceinline__ void load_x_lds(typename QT<TYPE>::X & x, const XLds & xs, int u) {
+__device__ __forceinline__ void load_x_lds(typename QT<TYPE>::X & x, const XLds & xs, int u, int c = 0) {
     typedef QT<TYPE> T;
+    const int8_t * q = xs.q + c * xs.col_bytes;
+    const int * gs = (const int *) ((const char *) xs.gs + c * xs.col_bytes);
+    const float * d = (const float *) ((const char *) xs.d + c * xs.col_bytes);
 #pragma unroll
     for (int g = 0; g < T::NV / 16; ++g) {
         const int base = T::group_base(u, g);
-        const u32x4 t = *(const u32x4 *) (xs.q + base);
+        const u32x4 t = *(const u32x4 *) (q + base);
 #pragma unroll
         for (int i = 0; i < 4; ++i) x.q[4 * g + i] = t[i];
-        x.gs[g] = xs.gs[base >> 4];
+        x.gs[g] = gs[base >> 4];
     }
-    x.yd = xs.d[T::group_base(u, 0) / T::ABLK];
+    x.yd = d[T::group_base(u, 0) / T::ABLK];
 }
 
 // A wave processes ITEMS: R consecutive rows of one job. Lanes stride over the row's units in chunks of CH units per
 // lane; the activation slice of every unit comes from LDS. No barrier and no cross-wave reduction inside an item.
-template <int TYPE, bool PAIR> struct Item {
+template <int TYPE, bool PAIR, int NC = 1> struct Item {
     typedef QT<TYPE> T;
     static constexpr int NM = PAIR ? 2 : 1;
 #ifndef PM_CH32
@@ -456,27 +465,30 @@ template <int TYPE, bool PAIR> struct Item {
         }
     }
     template <bool DBG>
-    static __device__ __forceinline__ void consume(const Regs & g, float (&acc)[R][NM], const GemvP & p, const GemvJob & jb,
+    static __device__ __forceinline__ void consume(const Regs & g, float (&acc)[R][NM][NC], const GemvP & p, const GemvJob & jb,
                                                    const XLds & xs, int row, int r1, int c0, int lane) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int uu = lane + 64 * (c0 + i);
             const bool uv = uu < jb.U;
             const int u = min(uu, jb.U - 1);
-            typename T::X x;
-            load_x_lds<TYPE>(x, xs, u);
-            x.yd = uv ? x.yd : 0.0f;                 // a clamped (out-of-row) unit contributes exactly 0
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+            for (int c = 0; c < NC; ++c) {           // the nibble / scale decoding of T::consume is common to all columns (CSE)
+                typename T::X x;
+                load_x_lds<TYPE>(x, xs, u, c);
+                x.yd = uv ? x.yd : 0.0f;             // a clamped (out-of-row) unit contributes exactly 0
 #pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    int isum, msum;
-                    acc[r][m] = T::consume(g.w[r][m][i], x, u, acc[r][m], isum, msum);
-                    if (DBG) if (uv && row + r < r1) {
-                        int32_t * o = p.dbg + ((long) (m * jb.N + row + r) * jb.U + u) * 2;
-                        o[0] = isum; o[1] = msum;
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        int isum, msum;
+                        acc[r][m][c] = T::consume(g.w[r][m][i], x, u, acc[r][m][c], isum, msum);
+                        if (DBG) if (uv && row + r < r1) {
+                            int32_t * o = p.dbg + ((long) (m * jb.N + row + r) * jb.U + u) * 2;
+                            o[0] = isum; o[1] = msum;
+                        }
                     }
-                }
+            }
         }
     }
     // All items of ONE job that belong to this wave (item ids first, first+NW, ... < n_job_items), flattened into STEPS
@@ -494,23 +506,27 @@ template <int TYPE, bool PAIR> struct Item {
         const int cpr = (upl + CH - 1) / CH;         // chunks (steps) per item
         const int n_my = (n_job_items - first + PM_GEMV_NW - 1) / PM_GEMV_NW;
         const int S = n_my * cpr;
-        float acc[R][NM];
+        float acc[R][NM][NC];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int m = 0; m < NM; ++m) acc[r][m] = 0.0f;
+            for (int m = 0; m < NM; ++m)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[r][m][c] = 0.0f;
         // step cursors: (row, chunk) of the step being ISSUED and of the step being CONSUMED
         int irow = r0 + first * R, ic = 0, crow = irow, cc = 0;
         auto next = [&](int & row, int & c) __attribute__((always_inline)) { if (++c == cpr) { c = 0; row += PM_GEMV_NW * R; } };
         auto finish = [&]() __attribute__((always_inline)) {           // after a step was consumed: end of item?
             if (cc == cpr - 1) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float o[NM];
+                for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int m = 0; m < NM; ++m) { o[m] = wave_sum(acc[r][m]); acc[r][m] = 0.0f; }
-                    if (lane == 0 && crow + r < r1) out[crow + r - r0] = PAIR ? silu_f(o[0]) * o[NM - 1] : o[0];
-                }
+                    for (int c = 0; c < NC; ++c) {
+                        float o[NM];
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) { o[m] = wave_sum(acc[r][m][c]); acc[r][m][c] = 0.0f; }
+                        if (lane == 0 && crow + r < r1) out[(crow + r - r0) * NC + c] = PAIR ? silu_f(o[0]) * o[NM - 1] : o[0];
+                    }
             }
             next(crow, cc);
         };
@@ -544,13 +560,14 @@ template <int TYPE, bool PAIR> struct Item {
     }
 };
 
-template <bool COH>
-__device__ __forceinline__ void write_out(const GemvJob & jb, const float * outbuf, int r0, int r1, int ob, int tid) {
-    for (int t = tid; t < r1 - r0; t += PM_GEMV_BLOCK) {
-        float out = outbuf[ob + t];
-        if (jb.bias)  out += ld_g(jb.bias + r0 + t);
-        if (jb.resid) out += ld_act<false>(jb.resid + r0 + t);
-        st_act<COH>(jb.y + r0 + t, out);
+template <bool COH, int NC>
+__device__ __forceinline__ void write_out(const GemvJob & jb, const float * outbuf, int r0, int r1, int ob, int tid, long y_stride) {
+    for (int t = tid; t < (r1 - r0) * NC; t += PM_GEMV_BLOCK) {
+        const int c = NC == 1 ? 0 : t / (r1 - r0), row = NC == 1 ? t : t - c * (r1 - r0);     // consecutive threads -> consecutive rows
+        float out = outbuf[(ob + row) * NC + c];
+        if (jb.bias)  out += ld_g(jb.bias + r0 + row);
+        if (jb.resid) out += ld_act<false>(jb.resid + c * y_stride + r0 + row);
+        st_act<COH>(jb.y + c * y_stride + r0 + row, out);
     }
 }
 
@@ -600,16 +617,18 @@ __device__ __forceinline__ void grid_arrive(const GridBar & gb) {
 
 // The whole mat-vec of one workgroup. MEGA: called from the persistent kernel (p lives in global memory, `bar` is the
 // barrier to pass before the activations may be read); otherwise the body of gemv_q_kernel.
-template <int TA, int TB, bool PAIR, bool DBG, bool MEGA>
+template <int TA, int TB, bool PAIR, bool DBG, bool MEGA, int NC = 1>
 __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double * nred, const GridBar & bar) {
     constexpr int ABLK = QT<TA>::ABLK;
-    typedef Item<TA, PAIR> IA;
-    typedef Item<TB, PAIR> IB;
+    typedef Item<TA, PAIR, NC> IA;
+    typedef Item<TB, PAIR, NC> IB;
     constexpr int R = IA::R;
+    // LDS: NC activation columns, each [q int8 K | gs int32 K/16 | d float K/ABLK] (16-byte aligned pieces), then the results
+    const int col_bytes = ((p.K + 15) & ~15) + (p.K / 16) * 4 + ((p.K / ABLK + 3) & ~3) * 4;
     int8_t * xs_q  = (int8_t *) smem;                                   // [K] (K % 32 == 0 -> 16-B aligned pieces)
     int *    xs_gs = (int *) (smem + ((p.K + 15) & ~15));               // [K/16]
     float *  xs_d  = (float *) (xs_gs + p.K / 16);                      // [K/ABLK]
-    float *  outbuf = xs_d + ((p.K / ABLK + 3) & ~3);                   // [sum of this workgroup's rows]
+    float *  outbuf = (float *) (smem + (size_t) NC * col_bytes);       // [sum of this workgroup's rows][NC]
     const int b = blockIdx.x, G = gridDim.x, tid = threadIdx.x, lane = tid & 63;
     // wave index as a SCALAR: everything derived from it (row numbers, row base pointers, loop counters) then lives in
     // SGPRs and the weight loads use the saddr + 32-bit-voffset form instead of 64-bit VALU address arithmetic
@@ -641,9 +660,9 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
 #endif
 #endif
     if (MEGA) { grid_wait(bar); stage_issue<ABLK, MEGA>(p, areg, wave, lane); }   // persistent kernel: the activations exist only now
-    stage_finish<ABLK, MEGA>(p, areg, xs_q, xs_gs, xs_d, nred, wave, lane);
+    stage_finish<ABLK, MEGA>(p, areg, xs_q, xs_gs, xs_d, nred, wave, lane, NC, col_bytes);
     __syncthreads();
-    const XLds xs = {xs_q, xs_gs, xs_d};
+    const XLds xs = {xs_q, xs_gs, xs_d, col_bytes};
     // (2) rows. Items of the jobs are dealt to the waves round-robin, continuing across jobs (wave offset rotates) so that
     //     the small k / v slices do not all land on wave 0.
     const int w1 = (wave + PM_GEMV_NW - ni_0 % PM_GEMV_NW) % PM_GEMV_NW;            // first item id of this wave in job 1
@@ -655,18 +674,18 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
 #endif
     typename IB::Regs gB, gB1;
     if (ni_1 > 0) {
-        if (TA != TB && p.job[1].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[1], xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
-        else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[1], xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
+        if (TA != TB && p.job[1].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[1], xs, outbuf + ob_1 * NC, w1, ni_1, r0_1, r1_1, lane);
+        else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[1], xs, outbuf + ob_1 * NC, w1, ni_1, r0_1, r1_1, lane);
     }
     if (ni_2 > 0) {
-        if (TA != TB && p.job[2].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[2], xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
-        else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[2], xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
+        if (TA != TB && p.job[2].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[2], xs, outbuf + ob_2 * NC, w2, ni_2, r0_2, r1_2, lane);
+        else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[2], xs, outbuf + ob_2 * NC, w2, ni_2, r0_2, r1_2, lane);
     }
     __syncthreads();
     // (4) coalesced write-out (+bias, +residual)
-    write_out<MEGA>(p.job[0], outbuf, r0_0, r1_0, 0, tid);
-    write_out<MEGA>(p.job[1], outbuf, r0_1, r1_1, ob_1, tid);
-    write_out<MEGA>(p.job[2], outbuf, r0_2, r1_2, ob_2, tid);
+    write_out<MEGA, NC>(p.job[0], outbuf, r0_0, r1_0, 0, tid, p.y_stride);
+    write_out<MEGA, NC>(p.job[1], outbuf, r0_1, r1_1, ob_1, tid, p.y_stride);
+    write_out<MEGA, NC>(p.job[2], outbuf, r0_2, r1_2, ob_2, tid, p.y_stride);
 }
 
 

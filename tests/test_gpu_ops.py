@@ -131,10 +131,11 @@ def test_gemv_integer_partials_bitexact_and_float_close(P, oracle, t, K, N):
         assert abs(y[r] - want) <= 4e-6 * mag + 1e-30, (TYPE_NAMES[t], K, r, y[r], want)
 
 
+@pytest.mark.parametrize("C", [3, 4, 7])          # 2+1, 4, 4+2+1 columns per launch group (gemv_q_cols_kernel)
 @pytest.mark.parametrize("t", QUANT_TYPES)
-def test_gemv_epilogues_and_columns(P, oracle, t):
+def test_gemv_epilogues_and_columns(P, oracle, t, C):
     rng = np.random.default_rng(25)
-    K, N, C = 4096 if t != Q6_K else 4096, 70, 3
+    K, N = 4096, 70
     b1, b2 = rand_blocks(t, N, K, rng), rand_blocks(t, N, K, rng)
     x = rng.normal(0, 1, (C, K)).astype(np.float32)
     bias = rng.normal(0, 1, N).astype(np.float32)
