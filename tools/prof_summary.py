@@ -14,7 +14,8 @@ def main(path, tokens):
         if m:
             name = f"gemv<{m.group(1)},{m.group(2)},{'pair' if m.group(3) == 'true' else 'single'}>"
         else:
-            name = re.sub(r"\(.*", "", n)[:40]
+            m2 = re.search(r"(gemm_q_f16_kernel<\d+>|attn_prefill_kernel<\d+>|gemv_q_cols_kernel<\d+, \d+>)", n)
+            name = m2.group(1) if m2 else re.sub(r"\(.*", "", n.replace("void ", "").replace("(anonymous namespace)::", ""))[:40]
         key = (name, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("LDS_Block_Size", ""))
         d[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     tot = sum(sum(v) for v in d.values())
