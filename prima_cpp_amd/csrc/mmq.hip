@@ -231,22 +231,26 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel(GemmP p) {
 
 } // namespace
 
-// f16 copy of the activations: one scratch buffer per process, grown on demand (single stream of GEMM calls per device)
-static _Float16 * g_xh = nullptr;
-static size_t g_xh_elems = 0;
+// f16 copy of the activations: one scratch buffer per DEVICE (a process may drive several GPUs through the plug-in), grown
+// on demand; GEMM calls of one device are issued from one host thread (ggml-backend stream semantics)
+static _Float16 * g_xh[16] = {};
+static size_t g_xh_elems[16] = {};
 
 int pm_launch_gemm_q(int type, const void * W, const float * X, float * Y, int K, int N, int T, const float * bias,
                      const float * resid, hipStream_t st) {
     if (K % 64 || (type != PM_Q8_0 && K % 256) || N % 4) return -2;
     if (type != PM_Q4_K && type != PM_Q5_K && type != PM_Q6_K && type != PM_Q8_0) return -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
     const size_t need = (size_t) T * K;
-    if (need > g_xh_elems) {
-        if (g_xh) { (void) hipStreamSynchronize(st); (void) hipFree(g_xh); }
-        if (hipMalloc((void **) &g_xh, need * 2) != hipSuccess) { g_xh = nullptr; g_xh_elems = 0; return -3; }
-        g_xh_elems = need;
+    if (need > g_xh_elems[dev]) {
+        if (g_xh[dev]) { (void) hipDeviceSynchronize(); (void) hipFree(g_xh[dev]); }
+        if (hipMalloc((void **) &g_xh[dev], need * 2) != hipSuccess) { g_xh[dev] = nullptr; g_xh_elems[dev] = 0; return -3; }
+        g_xh_elems[dev] = need;
     }
-    hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) ((need / 8 + 255) / 256)), dim3(256), 0, st, X, g_xh, (long) (need / 8));
-    GemmP p = {(const uint8_t *) W, g_xh, Y, bias, resid, (long) pm_weight_row_stride(type, K), K, N, T};
+    _Float16 * xh = g_xh[dev];
+    hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) ((need / 8 + 255) / 256)), dim3(256), 0, st, X, xh, (long) (need / 8));
+    GemmP p = {(const uint8_t *) W, xh, Y, bias, resid, (long) pm_weight_row_stride(type, K), K, N, T};
     const dim3 grid((N + BM - 1) / BM, (T + BN - 1) / BN);
     const size_t lds = (size_t) 2 * (BM + BN) * LDS_STRIDE * sizeof(_Float16);
     auto go = [&](auto kern) {
