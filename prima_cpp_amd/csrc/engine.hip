@@ -359,13 +359,14 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         const Tensor * qkv[3] = {&L.t[PM355_T_WQ], &L.t[PM355_T_WK], &L.t[PM355_T_WV]};
         if (T >= 16 && !m->no_fuse) {
             // ---- prefill: batched GEMMs on the MFMA matrix cores (mmq.hip), f32 activations
-            auto G = [&](const Tensor & w, const float * x, float * y, const float * bias, const float * resid) {
-                return pm_launch_gemm_q(w.type, w.d, x, y, (int) w.K, (int) w.N, T, bias, resid, st);
+            auto G = [&](const Tensor & w, const float * x, float * y, const float * bias, const float * resid,
+                         const float * silu_gate = nullptr, int reuse_x = 0) {
+                return pm_launch_gemm_q_ex(w.type, w.d, x, y, (int) w.K, (int) w.N, T, bias, resid, silu_gate, reuse_x, st);
             };
             pm_launch_rmsnorm_q8k(cur, (const float *) L.t[PM355_T_ATTN_NORM].d, m->xn, nullptr, E, T, hp.rms_eps, st);
             int rc = G(L.t[PM355_T_WQ], m->xn, m->q, (const float *) L.t[PM355_T_BQ].d, nullptr);
-            rc |= G(L.t[PM355_T_WK], m->xn, m->k, (const float *) L.t[PM355_T_BK].d, nullptr);
-            rc |= G(L.t[PM355_T_WV], m->xn, m->v, (const float *) L.t[PM355_T_BV].d, nullptr);
+            rc |= G(L.t[PM355_T_WK], m->xn, m->k, (const float *) L.t[PM355_T_BK].d, nullptr, nullptr, 1);      // same activations: f16 copy reused
+            rc |= G(L.t[PM355_T_WV], m->xn, m->v, (const float *) L.t[PM355_T_BV].d, nullptr, nullptr, 1);
             if (rc) return seterr(m, PM355_E_UNSUPPORTED, "prefill: qkv gemm");
             const long kvs = (long) hp.n_ctx * Hkv * dh;
             pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kvs,
@@ -377,9 +378,8 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
             if (G(L.t[PM355_T_WO], m->att, x_mid, nullptr, cur)) return seterr(m, PM355_E_UNSUPPORTED, "prefill: wo gemm");
             pm_launch_rmsnorm_q8k(x_mid, (const float *) L.t[PM355_T_FFN_NORM].d, m->xn, nullptr, E, T, hp.rms_eps, st);
             rc = G(L.t[PM355_T_FFN_GATE], m->xn, m->h, nullptr, nullptr);
-            rc |= G(L.t[PM355_T_FFN_UP], m->xn, m->h2, nullptr, nullptr);
+            rc |= G(L.t[PM355_T_FFN_UP], m->xn, m->h, nullptr, nullptr, m->h, 1);                       // h = silu(gate) * up, in the epilogue
             if (rc) return seterr(m, PM355_E_UNSUPPORTED, "prefill: gate/up gemm");
-            pm_launch_silu_mul(m->h, m->h2, m->h, (long) T * F, st);
             float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : ((x_mid == bufs[0]) ? bufs[1] : bufs[0]);
             if (G(L.t[PM355_T_FFN_DOWN], m->h, x_next, nullptr, x_mid)) return seterr(m, PM355_E_UNSUPPORTED, "prefill: down gemm");
             cur = x_next;

@@ -94,6 +94,7 @@ __device__ __forceinline__ void convert_w(const RawW & w, int k0, float (&o)[16]
 
 struct GemmP {
     const uint8_t * W; const _Float16 * Xh; float * Y; const float * bias; const float * resid;
+    const float * silu_gate;                 // optional [T][N]: Y = silu(gate) * (W.x)   (the SiLU.mul of the FFN fused into the up projection)
     long row_stride; int K, N, T;
 };
 
@@ -215,6 +216,10 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel(GemmP p) {
                     float4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                     if (p.bias)  { const float4 bb = *(const float4 *) (p.bias + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
                     if (p.resid) { const float4 rr = *(const float4 *) (p.resid + (long) t * p.N + n); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+                    if (p.silu_gate) {
+                        const float4 g = *(const float4 *) (p.silu_gate + (long) t * p.N + n);
+                        v.x *= g.x / (1.0f + expf(-g.x)); v.y *= g.y / (1.0f + expf(-g.y)); v.z *= g.z / (1.0f + expf(-g.z)); v.w *= g.w / (1.0f + expf(-g.w));
+                    }
                     *(float4 *) (p.Y + (long) t * p.N + n) = v;
                 } else {
 #pragma unroll
@@ -222,6 +227,7 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel(GemmP p) {
                         float v = acc[i][j][4 * g + e];
                         if (p.bias) v += p.bias[n + e];
                         if (p.resid) v += p.resid[(long) t * p.N + n + e];
+                        if (p.silu_gate) { const float g = p.silu_gate[(long) t * p.N + n + e]; v *= g / (1.0f + expf(-g)); }
                         p.Y[(long) t * p.N + n + e] = v;
                     }
                 }
@@ -238,6 +244,13 @@ static size_t g_xh_elems[16] = {};
 
 int pm_launch_gemm_q(int type, const void * W, const float * X, float * Y, int K, int N, int T, const float * bias,
                      const float * resid, hipStream_t st) {
+    return pm_launch_gemm_q_ex(type, W, X, Y, K, N, T, bias, resid, nullptr, 0, st);
+}
+
+// silu_gate: Y = silu(gate[t][n]) * (W.x + bias) (gate may alias Y). reuse_x != 0: the per-device f16 scratch already holds
+// the f16 copy of THIS X (previous call on this stream with the same X, T, K): skip the conversion.
+int pm_launch_gemm_q_ex(int type, const void * W, const float * X, float * Y, int K, int N, int T, const float * bias,
+                        const float * resid, const float * silu_gate, int reuse_x, hipStream_t st) {
     if (K % 64 || (type != PM_Q8_0 && K % 256) || N % 4) return -2;
     if (type != PM_Q4_K && type != PM_Q5_K && type != PM_Q6_K && type != PM_Q8_0) return -1;
     int dev = 0;
@@ -249,8 +262,8 @@ int pm_launch_gemm_q(int type, const void * W, const float * X, float * Y, int K
         g_xh_elems[dev] = need;
     }
     _Float16 * xh = g_xh[dev];
-    hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) ((need / 8 + 255) / 256)), dim3(256), 0, st, X, xh, (long) (need / 8));
-    GemmP p = {(const uint8_t *) W, xh, Y, bias, resid, (long) pm_weight_row_stride(type, K), K, N, T};
+    if (!reuse_x) hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) ((need / 8 + 255) / 256)), dim3(256), 0, st, X, xh, (long) (need / 8));
+    GemmP p = {(const uint8_t *) W, xh, Y, bias, resid, silu_gate, (long) pm_weight_row_stride(type, K), K, N, T};
     const dim3 grid((N + BM - 1) / BM, (T + BN - 1) / BN);
     const size_t lds = (size_t) 2 * (BM + BN) * LDS_STRIDE * sizeof(_Float16);
     auto go = [&](auto kern) {

@@ -58,6 +58,9 @@ int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st);
 int pm_launch_gemm_q(int type, const void * W, const float * X, float * Y, int K, int N, int T, const float * bias,
                      const float * resid, hipStream_t st);
 
+int pm_launch_gemm_q_ex(int type, const void * W, const float * X, float * Y, int K, int N, int T, const float * bias,
+                        const float * resid, const float * silu_gate, int reuse_x, hipStream_t st);
+
 // measurement helper (probe.hip): stream `bytes` from HBM once with the mat-vec's access pattern
 int pm_launch_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, hipStream_t st);
 int pm_device_cus();
