@@ -92,6 +92,52 @@ __device__ __forceinline__ void convert_w(const RawW & w, int k0, float (&o)[16]
         }
 }
 
+// Packed-F16 dequantization of the same 16 weights straight into the two half8 vectors the LDS tile wants (PM_GEMM_F16_DEQUANT,
+// Q4_K and Q6_K): v_perm_b32 spreads four 4/6-bit values into two dwords of (0x6400 | q) = the F16 numbers 1024 + q, one
+// packed subtract makes them q exactly, one packed fma applies d*sc (and -dmin*m) - 2 VALU instructions per weight instead of
+// ~7 (the dequantization was as expensive as the MFMAs it feeds). d*sc and dmin*m are formed in f32 and rounded to F16, so a
+// weight carries up to 2 F16 roundings instead of 1: far inside the F16-activation noise (NMSE vs the oracle stays ~1e-6).
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+#ifndef PM_GEMM_F16_DEQUANT
+#define PM_GEMM_F16_DEQUANT 1
+#endif
+template <int TYPE>
+__device__ __forceinline__ void convert_w_h(const RawW & w, int k0, half8 (&o)[2]) {
+    const int s = (k0 & 255) >> 5;
+    half2v mul, add;
+    float sub;                                                           // 1024 (+32 for Q6_K)
+    int sh = 0, lsh = 0, hsh = 0;
+    if (TYPE == PM_Q4_K) {
+        const u32x4 h = w.r[1];
+        int sc, mn;
+        k4_scale_min(h[1], h[2], h[3], s, sc, mn);
+        const _Float16 ds = (_Float16) (h2f((uint16_t) (h[0] & 0xFFFF)) * (float) sc), ms = (_Float16) (h2f((uint16_t) (h[0] >> 16)) * (float) mn);
+        mul = half2v{ds, ds}; add = half2v{(_Float16) -ms, (_Float16) -ms};
+        sub = 1024.0f; sh = (s & 1) * 4;
+    } else {
+        const int kq = s & 3;
+        const _Float16 dd = (_Float16) (h2f((uint16_t) (w.s >> 16)) * (float) (int8_t) (w.s & 0xFF));
+        mul = half2v{dd, dd}; add = half2v{(_Float16) 0.0f, (_Float16) 0.0f};
+        sub = 1056.0f; lsh = (kq >> 1) * 4; hsh = 2 * kq;
+    }
+    const half2v bias = half2v{(_Float16) -sub, (_Float16) -sub};
+    uint32_t out[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t v;
+        if (TYPE == PM_Q4_K) v = (w.r[0][i] >> sh) & 0x0F0F0F0Fu;
+        else                 v = ((w.r[0][i] >> lsh) & 0x0F0F0F0Fu) | (((w.r[1][i] >> hsh) & 0x03030303u) << 4);
+        const uint32_t lo = __builtin_amdgcn_perm(0x64646464u, v, 0x05010400u);   // bytes [v0, 0x64, v1, 0x64] = F16 (1024 + v0, 1024 + v1)
+        const uint32_t hi = __builtin_amdgcn_perm(0x64646464u, v, 0x07030602u);
+        half2v a = __builtin_bit_cast(half2v, lo), b = __builtin_bit_cast(half2v, hi);
+        a = (a + bias) * mul + add;                                      // (1024 + q) - 1024 is exact; then one packed multiply-add
+        b = (b + bias) * mul + add;
+        out[2 * i] = __builtin_bit_cast(uint32_t, a); out[2 * i + 1] = __builtin_bit_cast(uint32_t, b);
+    }
+    o[0] = __builtin_bit_cast(half8, u32x4{out[0], out[1], out[2], out[3]});
+    o[1] = __builtin_bit_cast(half8, u32x4{out[4], out[5], out[6], out[7]});
+}
+
 struct GemmP {
     const uint8_t * W; const _Float16 * Xh; float * Y; const float * bias; const float * resid;
     const float * silu_gate;                 // optional [T][N]: Y = silu(gate) * (W.x)   (the SiLU.mul of the FFN fused into the up projection)
@@ -148,16 +194,22 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel(GemmP p) {
     };
     auto stage = [&](const Regs & R, int st) __attribute__((always_inline)) {
         _Float16 * buf = lds + (st & 1) * BUF;
-        float o[16];
-        convert_w<TYPE>(R.w, min(st, nst - 1) * BK + 32 * ahalf, o);
         _Float16 * da = buf + arow * LDS_STRIDE + 32 * ahalf + 16 * apart;
         _Float16 * db = buf + (BM + brow) * LDS_STRIDE + 32 * bhalf;
+        if (PM_GEMM_F16_DEQUANT && (TYPE == PM_Q4_K || TYPE == PM_Q6_K)) {
+            half8 o[2];
+            convert_w_h<TYPE>(R.w, min(st, nst - 1) * BK + 32 * ahalf, o);
+            *(half8 *) da = o[0]; *(half8 *) (da + 8) = o[1];
+        } else {
+            float o[16];
+            convert_w<TYPE>(R.w, min(st, nst - 1) * BK + 32 * ahalf, o);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            half8 v;
+            for (int i = 0; i < 2; ++i) {
+                half8 v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (_Float16) o[8 * i + j];
-            *(half8 *) (da + 8 * i) = v;
+                for (int j = 0; j < 8; ++j) v[j] = (_Float16) o[8 * i + j];
+                *(half8 *) (da + 8 * i) = v;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) *(half8 *) (db + 8 * i) = R.x[i];
@@ -189,7 +241,7 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel(GemmP p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // 8 VALU
+            __builtin_amdgcn_sched_group_barrier(0x002, PM_GEMM_F16_DEQUANT ? 4 : 8, 0);   // VALU
         }
     };
     for (int st = 0; st < nst; st += 2) {
