@@ -3,8 +3,9 @@
 // Replaces ggml_compute_forward_mul_mat (ggml/src/ggml.c:12377) for n_tokens >= 16 (what the reference's CUDA plug-in
 // serves with mul_mat_q / dequantize + cuBLAS, ggml-cuda/mmq.cuh:2583, convert.cu:190-279):
 //     Y[t][n] = sum_k W[n][k] * X[t][k]           W: Q4_K / Q5_K / Q6_K / Q8_0 rows in the HBM layout of repack.hip
-// Design: weights are read from HBM exactly once per 256-token tile, dequantized on the fly (f32 math, the exact
-// d*sc*q - dmin*m of dequantize_row_*, then rounded to F16) into an LDS tile; the activations are converted F32 -> F16
+// Design: weights are read from HBM exactly once per 256-token tile, dequantized on the fly into an F16 LDS tile (packed-F16
+// math for Q4_K / Q6_K, see convert_w_h; f32 math = the exact d*sc*q - dmin*m of dequantize_row_* rounded to F16 for the
+// other types); the activations are converted F32 -> F16
 // once per call and copied into a second LDS tile; 8 waves run v_mfma_f32_32x32x16_f16 with f32 accumulation (each wave a
 // 64x64 output block = 2x2 MFMA tiles). Tile 128 (weight rows) x 256 (tokens) x 64 (k), two LDS buffers (software
 // pipeline over k), LDS rows padded to 72 halfs against bank conflicts.
