@@ -52,6 +52,7 @@ struct pm355_model {
     // staging for set_tensor
     void * pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2]; void * dstage = nullptr; size_t stage_bytes = 0;
     hipStream_t up_stream = nullptr, cap_stream = nullptr;
+    hipStream_t side = nullptr; hipEvent_t side_a = nullptr, side_b = nullptr;   // prefill: wk and wv GEMMs (64 workgroups each) run side by side
     // captured single-token step graphs, keyed on everything that is baked into the kernel arguments
     struct StepGraph { const void * in, * tok; void * out, * logits, * argmax; int adv, rot, head; hipGraphExec_t exec; };
     std::vector<StepGraph> graphs;
@@ -365,8 +366,20 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
             };
             pm_launch_rmsnorm_q8k(cur, (const float *) L.t[PM355_T_ATTN_NORM].d, m->xn, nullptr, E, T, hp.rms_eps, st);
             int rc = G(L.t[PM355_T_WQ], m->xn, m->q, (const float *) L.t[PM355_T_BQ].d, nullptr);
+            // wk and wv (N = n_head_kv * head_dim: a fraction of the CUs each) run concurrently: wv on a side stream that forks
+            // after wq (the f16 copy of the activations exists from there on) and joins before the rope
+            if (!m->side) {
+                if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&m->side_a, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&m->side_b, hipEventDisableTiming) != hipSuccess) return seterr(m, PM355_E_HIP, "prefill: side stream");
+            }
+            (void) hipEventRecord(m->side_a, st);
+            (void) hipStreamWaitEvent(m->side, m->side_a, 0);
             rc |= G(L.t[PM355_T_WK], m->xn, m->k, (const float *) L.t[PM355_T_BK].d, nullptr, nullptr, 1);      // same activations: f16 copy reused
-            rc |= G(L.t[PM355_T_WV], m->xn, m->v, (const float *) L.t[PM355_T_BV].d, nullptr, nullptr, 1);
+            rc |= pm_launch_gemm_q_ex(L.t[PM355_T_WV].type, L.t[PM355_T_WV].d, m->xn, m->v, (int) L.t[PM355_T_WV].K, (int) L.t[PM355_T_WV].N, T,
+                                      (const float *) L.t[PM355_T_BV].d, nullptr, nullptr, 1, m->side);
+            (void) hipEventRecord(m->side_b, m->side);
+            (void) hipStreamWaitEvent(st, m->side_b, 0);
             if (rc) return seterr(m, PM355_E_UNSUPPORTED, "prefill: qkv gemm");
             const long kvs = (long) hp.n_ctx * Hkv * dh;
             pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kvs,
@@ -461,6 +474,7 @@ void pm355_model_free(pm355_model * m) {
     for (int i = 0; i < 2; ++i) if (m->pin[i]) { (void) hipHostFree(m->pin[i]); (void) hipEventDestroy(m->pin_ev[i]); }
     if (m->up_stream) (void) hipStreamDestroy(m->up_stream);
     if (m->cap_stream) (void) hipStreamDestroy(m->cap_stream);
+    if (m->side) { (void) hipStreamDestroy(m->side); (void) hipEventDestroy(m->side_a); (void) hipEventDestroy(m->side_b); }
     delete m;
 }
 
