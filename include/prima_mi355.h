@@ -149,6 +149,15 @@ PM355_API int pm355_rope_kv_store(const float * q, const float * k, const float 
 PM355_API int pm355_attn_decode(const float * q, const void * k_cache, const void * v_cache, const int32_t * d_pos0,
                                 float * out, int n_tokens, int n_head, int n_head_kv, int head_dim, int n_ctx,
                                 float kq_scale, pm355_stream_t stream);
+/* single-token variant of pm355_attn_decode for LONG contexts: the keys are split over n_ctx/256 x n_head_kv workgroups,
+ * each serving the whole group of query heads of its KV head (prima_cpp_amd/csrc/attn_split.hip; the engine uses it beyond
+ * PM355_ATTN_SPLIT_MIN = 1024 positions). q_rot = the token's rotated queries (pm355_rope_kv_store output), the caches
+ * already contain the token. scratch: pm355_attn_split_scratch_floats() floats of device memory. Position d_pos0[0] = index
+ * of the token (it attends keys 0 .. d_pos0[0]). */
+PM355_API size_t pm355_attn_split_scratch_floats(int n_head, int head_dim, int n_ctx);
+PM355_API int pm355_attn_decode_split(const float * q_rot, const void * k_cache, const void * v_cache, const int32_t * d_pos0,
+                                      float * out, float * scratch, int n_head, int n_head_kv, int head_dim, int n_ctx,
+                                      float kq_scale, pm355_stream_t stream);
 /* the same chain for a multi-token (prefill) batch on the MFMA matrix cores: causal, two passes over the keys so that p is
  * rounded to F16 after the division by the full row sum like the reference (prima_cpp_amd/csrc/attn_prefill.hip).
  * head_dim 64 or 128, n_ctx % 32 == 0. Same arguments and result layout as pm355_attn_decode. */

@@ -47,6 +47,11 @@ struct pm355_model {
     bool persistent = false;
     struct Plan { const void * in; void * out, * lg; bool head; pm_decode_plan * pl; };
     std::vector<Plan> plans;
+    // long-context decode attention (attn_split.hip): the host mirrors the device position counters to choose, per step, between
+    // the fused one-workgroup-per-head kernel and the keys-split-over-workgroups path (different launch sequences = different
+    // captured graphs). PM355_ATTN_SPLIT_MIN positions (default 1024: measured crossover on the 70B head shape).
+    float * split_scratch = nullptr;
+    std::vector<int> h_pos; int h_seq = 0; int split_min = 1024; bool long_ctx = false;
     pm_decode_plan * rec = nullptr;       // plan being recorded: the launch helpers append phases instead of launching
     float * slab = nullptr; size_t slab_stride = 0;   // per-layer activation scratch of the persistent kernel (each buffer written once per kernel)
     // staging for set_tensor
@@ -54,7 +59,7 @@ struct pm355_model {
     hipStream_t up_stream = nullptr, cap_stream = nullptr;
     hipStream_t side = nullptr; hipEvent_t side_a = nullptr, side_b = nullptr;   // prefill: wk and wv GEMMs (64 workgroups each) run side by side
     // captured single-token step graphs, keyed on everything that is baked into the kernel arguments
-    struct StepGraph { const void * in, * tok; void * out, * logits, * argmax; int adv, rot, head; hipGraphExec_t exec; };
+    struct StepGraph { const void * in, * tok; void * out, * logits, * argmax; int adv, rot, head, regime; hipGraphExec_t exec; };
     std::vector<StepGraph> graphs;
     char err[256];
 };
@@ -271,6 +276,12 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
         if (m->rec) {
             if (pm_decode_plan_add_attn(m->rec, q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d,
                                         att, H, Hkv, dh, hp.n_ctx, kq_scale, m->rope)) return -1;
+        } else if (m->long_ctx) {
+            // long context: rope + KV store, then the keys split over n_ctx/256 x n_head_kv workgroups (attn_split.hip)
+            pm_launch_rope_kv_store(q, k, v, q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d,
+                                    1, H, Hkv, dh, hp.n_ctx, m->rope, st);
+            if (pm_launch_attn_split(q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, att, m->split_scratch, H, Hkv, dh, hp.n_ctx, kq_scale, st))
+                return seterr(m, PM355_E_RANGE, "decode: split attention unsupported for this shape");
         } else if (pm_launch_attn_rope_fused(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d,
                                              att, H, Hkv, dh, hp.n_ctx, kq_scale, m->rope, st))
             return seterr(m, PM355_E_RANGE, "decode: fused attention unsupported for this head_dim / n_ctx");
@@ -298,7 +309,7 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
 
 // persistent-kernel plan for one (input, output, logits) pointer set: found or recorded now (nullptr: not available)
 pm_decode_plan * get_plan(pm355_model * m, const float * cur, float * d_x_out, float * lg, bool head) {
-    if (!m->persistent || m->no_fuse || m->hi <= m->lo) return nullptr;
+    if (!m->persistent || m->no_fuse || m->hi <= m->lo || m->long_ctx) return nullptr;
     for (auto & p : m->plans) if (p.in == cur && p.out == d_x_out && p.lg == lg && p.head == head) return p.pl;
     if (m->plans.size() >= 16) return nullptr;
     if (!m->slab) {
@@ -340,6 +351,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
     if (!cur) return seterr(m, PM355_E_SHAPE, "decode: neither tokens nor x_in");
     float * bufs[2] = {m->x, m->x1};
     if (T == 1 && !m->no_fuse) {
+        m->long_ctx = m->split_scratch && m->h_pos[m->h_seq] >= m->split_min;
         // ---- single token: every activation transform is fused into a mat-vec prologue / epilogue; one persistent kernel
         //      for the whole window (decode_kernel.hip) or, without a plan, 5 launches per layer
         const bool head = (d_logits || d_argmax) && (m->flags & PM355_HAS_HEAD);
@@ -469,7 +481,7 @@ void pm355_model_free(pm355_model * m) {
     for (auto & L : m->layers) { for (auto & t : L.t) if (t.d) (void) hipFree(t.d); if (L.kc) (void) hipFree(L.kc); if (L.vc) (void) hipFree(L.vc); }
     Tensor * g[4] = {&m->tok_embd, &m->out_norm, &m->output, &m->rope_freqs};
     for (auto t : g) if (t->d) (void) hipFree(t->d);
-    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->h2, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->dstage};
+    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->h2, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->dstage, m->split_scratch};
     for (auto p : s) if (p) (void) hipFree(p);
     for (int i = 0; i < 2; ++i) if (m->pin[i]) { (void) hipHostFree(m->pin[i]); (void) hipEventDestroy(m->pin_ev[i]); }
     if (m->up_stream) (void) hipStreamDestroy(m->up_stream);
@@ -568,6 +580,10 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
               A((void **) &m->aq_0, T * pm_q80_row_bytes((int) ((maxK + 31) / 32 * 32))) &&
               A((void **) &m->d_pos, 64 * 4) && A((void **) &m->d_ctl, 64) && A((void **) &m->d_tok, 64 + T * 4);
     if (!ok) return seterr(m, PM355_E_NOMEM, "finalize: scratch");
+    if (hp.n_head / hp.n_head_kv <= 8 && (hp.head_dim == 64 || hp.head_dim == 128) &&
+        !A((void **) &m->split_scratch, pm_attn_split_scratch_floats(hp.n_head, hp.head_dim, hp.n_ctx) * 4)) return seterr(m, PM355_E_NOMEM, "finalize: attention scratch");
+    m->h_pos.assign(n_seq, 0); m->h_seq = 0;
+    { const char * e = getenv("PM355_ATTN_SPLIT_MIN"); if (e && e[0]) m->split_min = atoi(e); }
     (void) hipMemset(m->d_pos, 0, 64 * 4);
     { const int32_t ctl[2] = {0, n_seq}; (void) hipMemcpy(m->d_ctl, ctl, 8, hipMemcpyHostToDevice); }
     (void) hipDeviceSynchronize();
@@ -611,13 +627,15 @@ int pm355_model_set_seq_pos(pm355_model * m, int seq, int pos, pm355_stream_t st
     if (!m->finalized) return seterr(m, PM355_E_SHAPE, "set_seq_pos: model not finalized");
     if (seq >= m->n_seq) return seterr(m, PM355_E_RANGE, "set_seq_pos: seq >= n_seq");
     // values travel as kernel arguments: capture-safe, no host buffer lifetime to manage
-    if (seq < 0) { pm_launch_set_i32(m->d_ctl, 0, (hipStream_t) st); seq = 0; }
+    if (seq < 0) { pm_launch_set_i32(m->d_ctl, 0, (hipStream_t) st); seq = 0; m->h_seq = 0; }
     pm_launch_set_i32(m->d_pos + seq, pos, (hipStream_t) st);
+    m->h_pos[seq] = pos;
     return 0;
 }
 int pm355_model_set_seq(pm355_model * m, int seq, pm355_stream_t st) {
     if (!m->finalized || seq < 0 || seq >= m->n_seq) return seterr(m, PM355_E_RANGE, "set_seq: bad sequence id");
     pm_launch_set_i32(m->d_ctl, seq, (hipStream_t) st);
+    m->h_seq = seq;
     return 0;
 }
 int pm355_model_head(pm355_model * m, const float * d_x_row, float * d_logits, int32_t * d_argmax, pm355_stream_t st) {
@@ -667,11 +685,15 @@ int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * 
     if (!m->finalized) return seterr(m, PM355_E_SHAPE, "step: model not finalized");
     if (head_first && (!(m->flags & PM355_HAS_HEAD) || !d_token || !d_x_in)) return seterr(m, PM355_E_SHAPE, "step: head_first needs HEAD, d_token and d_x_in");
     hipStream_t st = (hipStream_t) pst;
+    // host mirror of the device-side counters: which attention path this step takes, and the state after it
+    const int regime = (m->split_scratch && m->h_pos[m->h_seq] >= m->split_min) ? 1 : 0;
+    m->long_ctx = regime != 0;
+    struct Mirror { pm355_model * m; int adv, rot; ~Mirror() { m->h_pos[m->h_seq] += adv; if (rot) m->h_seq = (m->h_seq + rot) % m->n_seq; } } mirror{m, advance, rotate};
     if (!use_graph) return step_body(m, d_token, d_x_in, d_x_out, d_logits, d_argmax, advance, rotate, head_first, st);
     hipGraphExec_t exec = nullptr;
     for (auto & g : m->graphs)
         if (g.in == d_x_in && g.tok == d_token && g.out == d_x_out && g.logits == d_logits && g.argmax == d_argmax &&
-            g.adv == advance && g.rot == rotate && g.head == head_first) { exec = g.exec; break; }
+            g.adv == advance && g.rot == rotate && g.head == head_first && g.regime == regime) { exec = g.exec; break; }
     if (!exec) {
         hipGraph_t g = nullptr;
         // persistent-kernel plans are recorded and uploaded BEFORE the capture starts (synchronous copies)
@@ -696,8 +718,8 @@ int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * 
         e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
         (void) hipGraphDestroy(g);
         if (e != hipSuccess) return seterr(m, PM355_E_HIP, "step: graph instantiate");
-        if (m->graphs.size() >= 8) { (void) hipGraphExecDestroy(m->graphs.front().exec); m->graphs.erase(m->graphs.begin()); }
-        m->graphs.push_back({d_x_in, d_token, d_x_out, d_logits, d_argmax, advance, rotate, head_first, exec});
+        if (m->graphs.size() >= 16) { (void) hipGraphExecDestroy(m->graphs.front().exec); m->graphs.erase(m->graphs.begin()); }
+        m->graphs.push_back({d_x_in, d_token, d_x_out, d_logits, d_argmax, advance, rotate, head_first, regime, exec});
     }
     return hipGraphLaunch(exec, st) == hipSuccess ? 0 : seterr(m, PM355_E_HIP, "step: graph launch");
 }

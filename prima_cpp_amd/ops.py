@@ -151,6 +151,22 @@ def attn_decode(q, k_cache, v_cache, pos0, n_head, n_head_kv, head_dim, n_ctx, s
     return out
 
 
+def attn_decode_split(q_rot, k_cache, v_cache, pos, n_head, n_head_kv, head_dim, n_ctx, scale):
+    """Long-context single-token attention (keys split over workgroups). q_rot [1, H*dh]: rotated queries; pos = token index."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_attn_split_scratch_floats.restype = C.c_size_t
+    lib.pm355_attn_split_scratch_floats.argtypes = [C.c_int] * 3
+    lib.pm355_attn_decode_split.restype = C.c_int
+    lib.pm355_attn_decode_split.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float, C.c_void_p]
+    scratch = torch.empty(lib.pm355_attn_split_scratch_floats(n_head, head_dim, n_ctx), dtype=torch.float32, device=q_rot.device)
+    out = torch.empty_like(q_rot)
+    p = torch.tensor([pos], dtype=torch.int32, device=q_rot.device)
+    check(lib.pm355_attn_decode_split(ptr(q_rot), ptr(k_cache), ptr(v_cache), ptr(p), ptr(out), ptr(scratch), n_head, n_head_kv,
+                                      head_dim, n_ctx, float(scale), stream_ptr()), "attn_decode_split")
+    return out
+
+
 def attn_prefill(q, k_cache, v_cache, pos0, n_head, n_head_kv, head_dim, n_ctx, scale):
     """Causal multi-token attention on MFMA (same contract as attn_decode)."""
     import ctypes as C

@@ -277,6 +277,26 @@ def test_attn_prefill_mfma_vs_exact(P, oracle, n_past, T, dh):
             assert np.abs(out[t, h] - want).max() <= 2e-3 * np.abs(want).max() + 1e-4, (t, h)
 
 
+@pytest.mark.parametrize("dh", [64, 128])
+@pytest.mark.parametrize("n_past", [0, 5, 255, 256, 700, 1023])
+def test_attn_decode_split_equals_single_workgroup_kernel(P, n_past, dh):
+    """Long-context path (keys split over workgroups, attn_split.hip) against the per-head kernel: same rounding points,
+    only the summation order differs."""
+    rng = np.random.default_rng(44)
+    H, Hkv, n_ctx = 16, 2, 1024
+    n_kv = n_past + 1
+    q = rng.normal(0, 1, (1, H, dh)).astype(np.float32)
+    K = rng.normal(0, 1, (n_ctx, Hkv, dh)).astype(np.float16)
+    V = rng.normal(0, 1, (Hkv, dh, n_ctx)).astype(np.float16)
+    K[n_kv:] = 0; V[:, :, n_kv:] = 0
+    args = (_dev(P, q.reshape(1, -1)), _f16bits(P, K), _f16bits(P, V), n_past, H, Hkv, dh, n_ctx, 1.0 / np.sqrt(dh))
+    ref = P.attn_decode(*args).cpu().numpy()
+    out = P.attn_decode_split(*args).cpu().numpy()
+    # p is rounded to F16 in both kernels; a sum of exponentials assembled per chunk can move 1/sum by an ulp and with it a
+    # few p values by one F16 ulp (2^-11 relative): bound = a handful of such flips
+    assert np.abs(out - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-6
+
+
 def test_argmax_first_maximum(P):
     torch = P.torch
     x = torch.randn(128256, device="cuda")
