@@ -2,30 +2,34 @@
 //
 // The fused decode kernel (attn_device.h) gives every query head ONE workgroup: perfect while the kernel is latency-bound
 // (7 us at n_kv ~ 50), but a CU pulls ~25 GB/s, so at n_kv = 3800 the 1.9 MB of K/V per head cost 110 us per layer - 8.8 ms
-// per Llama-3-70B token, more than streaming all the weights. Here one workgroup = (KV head, chunk of 256 keys) serves the
+// per Llama-3-70B token, more than streaming all the weights. Here one workgroup = (KV head, chunk of 128 keys) serves the
 // whole group of query heads that shares the KV head (K / V bytes are read once per group, not once per head), over
-// n_ctx/256 x n_head_kv workgroups:
+// n_ctx/128 x n_head_kv workgroups:
 //   1. scores : s[h][key] = scale * K[key] . q_h  for the chunk -> global score buffer; per (head, chunk) max and sum(exp)
 //   2. pv     : global max / sum from the chunk statistics; p = exp(s - max) / sum rounded to F16 (same rounding point as
 //               the reference, ggml.c:13783-13879 + the F16 conversion of mul_mat's src1); partial O = V^T[:, chunk] . p
 //   3. combine: out[h][e] = sum over chunks of the partial O, fixed order (deterministic)
-// preceded by the ordinary rope + KV-store kernel. 4 launches instead of 1, so the engine switches to this path only
-// beyond PM355_ATTN_SPLIT_MIN positions (default 1024 = the measured crossover: the 4 launches cost ~38 us per layer whatever
-// the context, the fused kernel 7 us + 27 ns per position; the host mirrors the device position counters to pick the captured
-// graph). Llama-3-70B decode at 3.8k context: 57.6 -> 85.4 tok/s. Rounding points as in the fused kernel: q and p -> F16, F16 K / V, f32 accumulation; differences to it are
+// RoPE and the KV store of the new token are done by the scores kernel (every workgroup rotates its group's queries; the one
+// whose chunk holds the token's position also rotates k, uses it from LDS and writes the K row / V column). 3 launches
+// instead of 1, so the engine switches to this path only beyond PM355_ATTN_SPLIT_MIN positions (default 640 = the measured
+// crossover: the 3 launches cost ~25 us per layer whatever the context, the fused kernel 7 us + 27 ns per position; the host
+// mirrors the device position counters to pick the captured graph). Llama-3-70B decode at 3.8k context: 57.6 -> 92 tok/s. Rounding points as in the fused kernel: q and p -> F16, F16 K / V, f32 accumulation; differences to it are
 // summation order only (the sum of exponentials is assembled from per-chunk sums).
-#include "pm355_device.h"
+#include "attn_device.h"
 #include "pm355_layer_ops.h"
 
 namespace {
 
-constexpr int CK = 256;                          // keys per workgroup
+constexpr int CK = 128;                          // keys per workgroup (256: half the workgroups, 1.4x the latency chain per workgroup)
 constexpr int RMAX = 8;                          // query heads per KV head (GQA group) handled by one workgroup
 
 struct SplitP {
     const float * q; const uint16_t * kc; const uint16_t * vc; const int32_t * pos0_ptr; const int32_t * seq_ptr; long seq_stride;
     float * out; float * S; float * M; float * L; float * P;     // scratch: S[H][n_ctx], M / L[H][nchunk], P[nchunk][H][dh]
     int H, Hkv, n_ctx, nchunk; float scale;
+    // do_rope: q is the RAW projection; the scores kernel rotates it (every workgroup, its own group's heads), and the
+    // workgroup whose chunk contains the token's position also rotates k, takes it from LDS and stores the K row / V column
+    const float * k; const float * v; const float * ff; uint16_t * kc_w; uint16_t * vc_w; RopeP r; int do_rope;
 };
 
 __device__ __forceinline__ int cur_pos(const SplitP & p, int & seq) {
@@ -53,7 +57,48 @@ __global__ __launch_bounds__(256) void attn_split_scores_kernel(SplitP p) {
     const int k0 = c * CK;
     if (k0 >= n_kv) return;
     const uint16_t * kc = p.kc + (long) seq * p.seq_stride + (long) g * DH;
-    for (int i = tid; i < R * DH; i += 256) { const int h = i / DH, e = i - h * DH; qs[h][e] = h2f(f2h(p.q[(long) (g * R + h) * DH + e])); }
+    __shared__ float kcur[DH];                   // the token's own rotated key (do_rope)
+    const int pos = n_kv - 1;
+    if (!p.do_rope) {
+        for (int i = tid; i < R * DH; i += 256) { const int h = i / DH, e = i - h * DH; qs[h][e] = h2f(f2h(p.q[(long) (g * R + h) * DH + e])); }
+    } else {
+        // same rotation as attn_rope_fused_kernel / rope_kv_store_kernel (ggml_compute_forward_rope_f32, ggml.c:14143). cos / sin
+        // depend on (position, pair) only: ONE rope_cs per thread (its sinf / cosf take the slow large-argument path at long
+        // positions), shared by all heads through LDS
+        __shared__ float cs2[DH / 2][2];
+        const bool neox = p.r.mode & 2;
+        const int half = p.r.n_dims / 2;
+        if (tid < DH / 2) {
+            float cs_ = 1.0f, sn_ = 0.0f;
+            if (tid < half) rope_cs(p.r, (float) pos, tid, p.ff, cs_, sn_);
+            cs2[tid][0] = cs_; cs2[tid][1] = sn_;
+        }
+        __syncthreads();
+        const bool mine = c == pos / CK;         // this workgroup also owns the new K row / V column of its KV head
+        for (int i = tid; i < (R + (mine ? 1 : 0)) * (DH / 2); i += 256) {
+            const int h = i / (DH / 2), pair = i - h * (DH / 2);
+            const bool is_k = h == R;
+            const float * src = is_k ? p.k + (long) g * DH : p.q + (long) (g * R + h) * DH;
+            int ia, ib;
+            if (pair < half) { ia = neox ? pair : 2 * pair; ib = neox ? pair + half : 2 * pair + 1; }
+            else             { ia = p.r.n_dims + 2 * (pair - half); ib = ia + 1; }
+            float o0 = src[ia], o1 = src[ib];
+            if (pair < half) {
+                const float cs_ = cs2[pair][0], sn_ = cs2[pair][1];
+                const float x0 = o0, x1 = o1;
+                o0 = x0 * cs_ - x1 * sn_; o1 = x0 * sn_ + x1 * cs_;
+            }
+            const uint16_t h0 = f2h(o0), h1 = f2h(o1);
+            float * dst = is_k ? kcur : qs[h];
+            dst[ia] = h2f(h0); dst[ib] = h2f(h1);
+            if (is_k) {
+                uint16_t * d = p.kc_w + (long) seq * p.seq_stride + (long) pos * p.Hkv * DH + (long) g * DH;
+                d[ia] = h0; d[ib] = h1;
+            }
+        }
+        if (mine) for (int e = tid; e < DH; e += 256)
+            p.vc_w[(long) seq * p.seq_stride + (long) (g * DH + e) * p.n_ctx + pos] = f2h(p.v[(long) g * DH + e]);
+    }
     __syncthreads();
     const int piece = tid % LPK, kslot = tid / LPK;
     const long krow = (long) p.Hkv * DH;
@@ -76,6 +121,10 @@ __global__ __launch_bounds__(256) void attn_split_scores_kernel(SplitP p) {
         float kf[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { kf[2 * j] = h2f((uint16_t) (kk[j] & 0xFFFF)); kf[2 * j + 1] = h2f((uint16_t) (kk[j] >> 16)); }
+        if (p.do_rope && key == pos) {               // the token's own key: from LDS, the cache row is being written by this kernel
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kf[i] = kcur[8 * piece + i];
+        }
         float acc[RMAX];
 #pragma unroll
         for (int h = 0; h < RMAX; ++h) {
@@ -116,13 +165,18 @@ __global__ __launch_bounds__(256) void attn_split_pv_kernel(SplitP p) {
     const int k0 = c * CK;
     if (k0 >= n_kv) return;
     const int nact = (n_kv + CK - 1) / CK;
-    if (tid < R) {
-        const int hh = g * R + tid;
+    // global max and sum of every head of the group from the chunk statistics: 32 lanes per head, one chunk each (+32, ...)
+    {
+        const int h = tid >> 5, ci = tid & 31;
         float m = -INFINITY;
-        for (int i = 0; i < nact; ++i) m = fmaxf(m, p.M[hh * p.nchunk + i]);
-        double l = 0.0;                          // sum in double like the reference (ggml_float), chunk by chunk
-        for (int i = 0; i < nact; ++i) l += (double) (p.L[hh * p.nchunk + i] * expf(p.M[hh * p.nchunk + i] - m));
-        mx[tid] = m; inv[tid] = (float) (1.0 / l);
+        if (h < R) for (int i = ci; i < nact; i += 32) m = fmaxf(m, p.M[(g * R + h) * p.nchunk + i]);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        double l = 0.0;                          // sum in double like the reference (ggml_float)
+        if (h < R) for (int i = ci; i < nact; i += 32) l += (double) (p.L[(g * R + h) * p.nchunk + i] * expf(p.M[(g * R + h) * p.nchunk + i] - m));
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) l += __shfl_xor(l, off);
+        if (h < R && ci == 0) { mx[h] = m; inv[h] = (float) (1.0 / l); }
     }
     __syncthreads();
     for (int i = tid; i < R * CK; i += 256) {
@@ -185,15 +239,23 @@ size_t pm_attn_split_scratch_floats(int H, int dh, int n_ctx) {
     return (size_t) H * n_ctx + 2 * (size_t) H * nchunk + nchunk * H * dh;
 }
 
-// q: this token's ROTATED queries [H*dh] f32 (rope_kv_store output); the caches already hold the token's K row / V column.
-int pm_launch_attn_split(const float * q, const void * kc, const void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride,
-                         float * out, float * scratch, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st) {
+// rope == nullptr: q = this token's ROTATED queries [H*dh] f32 and the caches already hold its K row / V column (k, v unused).
+// rope != nullptr: q, k, v = the RAW projections; the rotation, the KV store and the attention are done here (3 launches).
+int pm_launch_attn_split(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos0, const int32_t * seq,
+                         long seq_stride, const float * freq_factors, float * out, float * scratch, int H, int Hkv, int dh, int n_ctx,
+                         float scale, const pm_rope_cfg * rope, hipStream_t st) {
     if ((dh != 64 && dh != 128) || H % Hkv || H / Hkv > RMAX || n_ctx % 8 || !scratch) return -1;
     const int nchunk = (n_ctx + CK - 1) / CK;
-    SplitP p;
+    SplitP p = {};
     p.q = q; p.kc = (const uint16_t *) kc; p.vc = (const uint16_t *) vc; p.pos0_ptr = pos0; p.seq_ptr = seq; p.seq_stride = seq_stride;
     p.out = out; p.S = scratch; p.M = p.S + (size_t) H * n_ctx; p.L = p.M + (size_t) H * nchunk; p.P = p.L + (size_t) H * nchunk;
     p.H = H; p.Hkv = Hkv; p.n_ctx = n_ctx; p.nchunk = nchunk; p.scale = scale;
+    if (rope) {
+        const pm_rope_cfg & c = *rope;
+        p.r.n_dims = c.n_dims; p.r.mode = c.mode; p.r.n_ctx_orig = c.n_ctx_orig; p.r.theta_scale = c.theta_scale;
+        p.r.freq_scale = c.freq_scale; p.r.ext_factor = c.ext_factor; p.r.attn_factor = c.attn_factor; p.r.corr0 = c.corr0; p.r.corr1 = c.corr1;
+        p.k = k; p.v = v; p.ff = freq_factors; p.kc_w = (uint16_t *) kc; p.vc_w = (uint16_t *) vc; p.do_rope = 1;
+    }
     const dim3 grid(nchunk, Hkv);
     if (dh == 128) {
         hipLaunchKernelGGL(attn_split_scores_kernel<128>, grid, dim3(256), 0, st, p);

@@ -197,7 +197,7 @@ int pm355_attn_decode(const float * q, const void * kc, const void * vc, const i
 size_t pm355_attn_split_scratch_floats(int H, int dh, int n_ctx) { return pm_attn_split_scratch_floats(H, dh, n_ctx); }
 int pm355_attn_decode_split(const float * q_rot, const void * kc, const void * vc, const int32_t * d_pos0, float * out, float * scratch,
                             int H, int Hkv, int dh, int n_ctx, float kq_scale, pm355_stream_t st) {
-    if (pm_launch_attn_split(q_rot, kc, vc, d_pos0, nullptr, 0, out, scratch, H, Hkv, dh, n_ctx, kq_scale, S(st)))
+    if (pm_launch_attn_split(q_rot, nullptr, nullptr, (void *) kc, (void *) vc, d_pos0, nullptr, 0, nullptr, out, scratch, H, Hkv, dh, n_ctx, kq_scale, nullptr, S(st)))
         return fail(PM355_E_RANGE, "attn_decode_split: head_dim 64/128, at most 8 query heads per KV head, n_ctx % 8 == 0, scratch required");
     HIP_TRY(hipGetLastError());
     return 0;

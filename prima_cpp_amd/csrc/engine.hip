@@ -49,9 +49,9 @@ struct pm355_model {
     std::vector<Plan> plans;
     // long-context decode attention (attn_split.hip): the host mirrors the device position counters to choose, per step, between
     // the fused one-workgroup-per-head kernel and the keys-split-over-workgroups path (different launch sequences = different
-    // captured graphs). PM355_ATTN_SPLIT_MIN positions (default 1024: measured crossover on the 70B head shape).
+    // captured graphs). PM355_ATTN_SPLIT_MIN positions (default 640: measured crossover on the 70B head shape).
     float * split_scratch = nullptr;
-    std::vector<int> h_pos; int h_seq = 0; int split_min = 1024; bool long_ctx = false;
+    std::vector<int> h_pos; int h_seq = 0; int split_min = 640; bool long_ctx = false;
     pm_decode_plan * rec = nullptr;       // plan being recorded: the launch helpers append phases instead of launching
     float * slab = nullptr; size_t slab_stride = 0;   // per-layer activation scratch of the persistent kernel (each buffer written once per kernel)
     // staging for set_tensor
@@ -277,10 +277,9 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
             if (pm_decode_plan_add_attn(m->rec, q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d,
                                         att, H, Hkv, dh, hp.n_ctx, kq_scale, m->rope)) return -1;
         } else if (m->long_ctx) {
-            // long context: rope + KV store, then the keys split over n_ctx/256 x n_head_kv workgroups (attn_split.hip)
-            pm_launch_rope_kv_store(q, k, v, q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d,
-                                    1, H, Hkv, dh, hp.n_ctx, m->rope, st);
-            if (pm_launch_attn_split(q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, att, m->split_scratch, H, Hkv, dh, hp.n_ctx, kq_scale, st))
+            // long context: the keys split over n_ctx/128 x n_head_kv workgroups, rope + KV store in the first kernel (attn_split.hip)
+            if (pm_launch_attn_split(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d, att, m->split_scratch,
+                                     H, Hkv, dh, hp.n_ctx, kq_scale, &m->rope, st))
                 return seterr(m, PM355_E_RANGE, "decode: split attention unsupported for this shape");
         } else if (pm_launch_attn_rope_fused(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d,
                                              att, H, Hkv, dh, hp.n_ctx, kq_scale, m->rope, st))

@@ -18,10 +18,12 @@ void pm_launch_rope_kv_store(const float * q, const float * k, const float * v, 
 int  pm_launch_attn_decode(const float * q, const void * kc, const void * vc, const int32_t * pos0,
                            const int32_t * seq, long seq_stride, float * out,
                            int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st);
-// long-context single-token attention, keys split over workgroups (attn_split.hip); q = ROTATED queries, caches already updated
+// long-context single-token attention, keys split over workgroups (attn_split.hip). rope == nullptr: q = ROTATED queries and the
+// caches are already updated; else q / k / v are the raw projections and rope + KV store happen inside the first kernel
 size_t pm_attn_split_scratch_floats(int H, int dh, int n_ctx);
-int  pm_launch_attn_split(const float * q, const void * kc, const void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride,
-                          float * out, float * scratch, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st);
+int  pm_launch_attn_split(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos0, const int32_t * seq,
+                          long seq_stride, const float * freq_factors, float * out, float * scratch, int H, int Hkv, int dh, int n_ctx,
+                          float scale, const pm_rope_cfg * rope, hipStream_t st);
 // causal multi-token attention on MFMA (attn_prefill.hip); -1: unsupported shape (head_dim 64/128, n_ctx % 32 == 0)
 int  pm_launch_attn_prefill(const float * q, const void * kc, const void * vc, const int32_t * pos0, const int32_t * seq,
                             long seq_stride, float * out, int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st);
