@@ -489,3 +489,71 @@ def desc_from_arrays(z):
         d.rope_freqs = ff.ctypes.data
     d._keep = keep
     return d
+
+
+# --------------------------------------------------------------------------------------------
+# the reference's own driver (oracle/_ref/llama-ref-driver-*, built by oracle/Makefile from /root/reference with the
+# committed gate patch) on GGUF files written by prima_cpp_amd/gguf.py
+# --------------------------------------------------------------------------------------------
+def write_gguf_from_arrays(path, z):
+    """A golden fixture's model arrays (desc_to_arrays) -> GGUF file the reference loader reads."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from prima_cpp_amd import gguf as G
+    hp = {f: z[f"hp_{f}"] for f in _HP_FIELDS}
+    arch, L, E, H, Hkv, F, V, dh = (int(hp[k]) for k in ("arch", "n_layer", "n_embd", "n_head", "n_head_kv", "n_ff", "n_vocab", "head_dim"))
+    Eq, Ekv = dh * H, dh * Hkv
+    kv = G.model_kv(arch, L, E, H, Hkv, F, V, int(hp["n_ctx_orig"]), float(hp["rms_eps"]), float(hp["rope_freq_base"]))
+    shapes = {"attn_norm": (E,), "wq": (E, Eq), "wk": (E, Ekv), "wv": (E, Ekv), "wo": (Eq, E), "ffn_norm": (E,),
+              "ffn_gate": (E, F), "ffn_up": (E, F), "ffn_down": (F, E), "bq": (Eq,), "bk": (Ekv,), "bv": (Ekv,)}
+    keys = set(z.files) if hasattr(z, "files") else set(z.keys())
+    T = [("token_embd.weight", int(z["y_tok_embd"]), (E, V), z["t_tok_embd"])]
+    for il in range(L):
+        for f, nm in G.LAYER_TENSORS.items():
+            if f"t_{f}_{il}" in keys:
+                T.append((f"blk.{il}.{nm}", int(z[f"y_{f}_{il}"]), shapes[f], z[f"t_{f}_{il}"]))
+    T.append(("output_norm.weight", F32, (E,), z["t_out_norm"]))
+    T.append(("output.weight", int(z["y_output"]), (E, V), z["t_output"]))
+    if "t_rope_freqs" in keys:
+        T.append(("rope_freqs.weight", F32, (dh // 2,), z["t_rope_freqs"]))
+    return G.write_gguf(path, kv, T)
+
+
+def llama_driver_path(flavour=None):
+    fl = flavour or best_ref_flavour()
+    for f in ([fl] if fl in ("avx2", "avx512") else []) + ([] if flavour else ["avx2"]):
+        p = os.path.join(ORACLE_DIR, "_ref", f"llama-ref-driver-{f}")
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def run_llama_driver(gguf_path, prompt, n_gen, ngl=0, n_ctx=64, threads=2, extra_args=(), force=None, env=None, timeout=600,
+                     chunk=None, flavour=None):
+    """Greedy decode through the reference's llama_init_from_gpt_params + llama_decode. Returns (tokens, logits, stats)."""
+    import json
+    import tempfile
+    drv = llama_driver_path(flavour)
+    assert drv, "oracle/_ref/llama-ref-driver-* not built"
+    out = tempfile.NamedTemporaryFile(suffix=".refdrv", delete=False).name
+    e = dict(os.environ)
+    e.update({"REFDRV_PROMPT": ",".join(str(int(t)) for t in prompt), "REFDRV_NGEN": str(n_gen), "REFDRV_OUT": out})
+    if force is not None:
+        e["REFDRV_FORCE"] = ",".join(str(int(t)) for t in force)
+    if chunk:
+        e["REFDRV_CHUNK"] = str(chunk)
+    if env:
+        e.update(env)
+    cmd = [drv, "-m", gguf_path, "-c", str(n_ctx), "-t", str(threads), "-ngl", str(ngl)] + list(extra_args)
+    r = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError(f"llama-ref-driver rc={r.returncode}\n{r.stderr[-4000:]}")
+    stats = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"refdrv"')][-1])
+    stats["stderr"] = r.stderr
+    hdr = np.fromfile(out, dtype=np.int32, count=4)
+    assert hdr[0] == 0x52444c4c
+    ng, nv = int(hdr[2]), int(hdr[3])
+    toks = np.fromfile(out, dtype=np.int32, offset=16, count=ng)
+    logits = np.fromfile(out, dtype=np.float32, offset=16 + 4 * ng).reshape(ng, nv)
+    os.unlink(out)
+    return toks, logits, stats
