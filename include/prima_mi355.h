@@ -57,6 +57,15 @@ PM355_API int    pm355_event_wait(pm355_stream_t stream, pm355_event_t ev);     
 PM355_API int    pm355_event_sync(pm355_event_t ev);                              /* host waits for ev */
 PM355_API const char * pm355_last_error(void);
 
+/* hipGraph capture of everything launched on `stream` between begin and end (relaxed mode; nothing executes while capturing):
+ * what the plug-in's graph_compute uses to replay a token's launch sequence (cf. the reference CUDA plug-in's CUDA-graph path,
+ * ggml/src/ggml-cuda.cu:2513-2780). end returns an instantiated executable graph or NULL. */
+typedef void * pm355_graph_t;            /* hipGraphExec_t */
+PM355_API int    pm355_capture_begin(pm355_stream_t stream);
+PM355_API pm355_graph_t pm355_capture_end(pm355_stream_t stream);
+PM355_API int    pm355_graph_launch(pm355_graph_t g, pm355_stream_t stream);
+PM355_API void   pm355_graph_free(pm355_graph_t g);
+
 /* device memory helpers (hipMalloc / hipFree / hipMemcpy[Async]); used by the plug-in's buffer vtable
  * (replaces ggml_backend_cuda_buffer_* of the reference's CUDA plug-in, ggml/src/ggml-cuda.cu:430-560) */
 PM355_API void * pm355_malloc(size_t bytes);
@@ -118,6 +127,8 @@ typedef struct {
 } pm355_matvec_job;
 PM355_API int pm355_mul_mat_vec_fused(const pm355_matvec_job * jobs, int njobs, int64_t K, const float * x_f32,
                                       const float * norm_w, float eps, pm355_stream_t stream);
+/* 0 when pm355_mul_mat_vec_fused can serve this job list in ONE launch (type mix, K, LDS), else the error it would return */
+PM355_API int pm355_mul_mat_vec_fused_check(const pm355_matvec_job * jobs, int njobs, int64_t K);
 /* Batched (prefill) path, n_tokens >= 16: Y[t][n] = sum_k W[n][k] x[t][k] (+bias[n]) (+resid[t][n]) on the MFMA matrix cores
  * (v_mfma_f32_32x32x16_f16, weights dequantized on the fly into LDS, f32 accumulate; prima_cpp_amd/csrc/mmq.hip). Stands
  * in for the reference CUDA plug-in's mul_mat_q / dequantize+cuBLAS large-batch path (ggml-cuda/mmq.cuh:2583). */
@@ -170,6 +181,29 @@ PM355_API int pm355_attn_rope_fused(const float * q, const float * k, const floa
                                     const int32_t * d_pos0, const float * freq_factors, float * out,
                                     int n_head, int n_head_kv, int head_dim, int n_ctx, float kq_scale,
                                     const pm355_rope_params * rp, pm355_stream_t stream);
+/* ggml-graph form of pm355_attn_rope_fused / the split path, what the plug-in's graph_compute lowers the node chain
+ *   ROPE(Qcur) ROPE(Kcur) CPY(K -> k_cache_view) CPY(V^T -> v_cache_view) MUL_MAT(k, q) SOFT_MAX(kq, KQ_mask, scale) MUL_MAT(v, kq) CONT
+ * of llm_build_kv (src/llama.cpp:10167-10205) to for ONE token: the RoPE position comes from the graph's inp_pos tensor
+ * (d_pos[0]); the cache cell the token is stored in and the number of cells attended (kv_self.head / kv_self.n,
+ * src/llama.cpp:18433-18453) are read from DEVICE memory d_cell_nkv[0..1] so that a captured hipGraph can be replayed for the
+ * next token; mask = row 0 of the F32 KQ_mask [n_kv] (0 / -inf, llama_set_inputs src/llama.cpp:17379-17420) or NULL.
+ * split = 0: one workgroup per query head (max_keys bounds the cells attended, LDS); split = 1: keys split over workgroups
+ * (scratch = pm355_attn_split_scratch_floats() floats). */
+typedef struct {
+    const float * q, * k, * v;           /* raw projections of the token: [n_head*head_dim], [n_head_kv*head_dim] x2 */
+    void * k_cache, * v_cache;           /* F16 K rows [n_ctx][n_head_kv*head_dim]; F16 V transposed [n_head_kv*head_dim][n_ctx] */
+    const int32_t * d_pos;               /* device: RoPE position of the token */
+    const int32_t * d_cell_nkv;          /* device int32[2]: {cache cell, cells attended} */
+    const float * mask;                  /* device f32 [cells attended] or NULL */
+    const float * freq_factors;          /* rope_freqs [head_dim/2] or NULL */
+    float * out;                         /* [n_head*head_dim] f32 */
+    float * scratch;                     /* split only */
+    int32_t n_head, n_head_kv, head_dim, n_ctx, split, max_keys;
+    float kq_scale; int32_t pad_;
+} pm355_attn_token_args;
+PM355_API int pm355_attn_token(const pm355_attn_token_args * a, const pm355_rope_params * rp, pm355_stream_t stream);
+/* p[0] = a, p[1] = b on the stream (values travel as kernel arguments: no host buffer lifetime to manage) */
+PM355_API int pm355_set_i32x2(int32_t * d_p, int32_t a, int32_t b, pm355_stream_t stream);
 /* greedy sampler (src/llama-sampling.cpp:390-397): index of the first maximum */
 PM355_API int pm355_argmax(const float * x, int64_t n, int32_t * d_index, float * d_value, pm355_stream_t stream);
 /* ggml_compute_forward_add_f32 / mul_f32 (row-broadcast of b over a), silu(*u), scale */

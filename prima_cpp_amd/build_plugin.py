@@ -17,7 +17,7 @@ def build(force=False):
         print(f"build_plugin: {REF} not present - keeping prebuilt {OUT}" if os.path.exists(OUT) else
               f"build_plugin: {REF} not present and no prebuilt plug-in: skipped")
         return OUT if os.path.exists(OUT) else None
-    deps = [SRC, os.path.join(HERE, "..", "include", "prima_mi355.h"), os.path.join(HERE, "..", "include", "ggml_backend_mi355.h"),
+    deps = [SRC, os.path.join(HERE, "csrc", "ggml_graph_plan.h"), os.path.join(HERE, "..", "include", "prima_mi355.h"), os.path.join(HERE, "..", "include", "ggml_backend_mi355.h"),
             os.path.join(HERE, "libprima_mi355.so")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps if os.path.exists(d)):
         return OUT

@@ -28,6 +28,11 @@ __device__ __forceinline__ void rope_cs(const RopeP & r, float pos, int pair, co
 struct AttnP {
     const float * q, * k, * v; uint16_t * kc, * vc; const int32_t * pos0_ptr, * seq_ptr; long seq_stride;
     const float * freq_factors; float * out; int H, Hkv, n_ctx; float scale; RopeP r;
+    // ggml-graph mode (plug-in, pm355_attn_token): dyn != nullptr -> the RoPE position is pos0_ptr[0] (the graph's inp_pos), the
+    // token's K row / V column go to cache cell dyn[0] (llama_kv_cache head, src/llama.cpp:9688) and cells [0, dyn[1]) are attended
+    // with the additive f32 KQ mask row `mask` (0 / -inf, llama_set_inputs src/llama.cpp:17379-17420). Engine mode (dyn == nullptr):
+    // cell == position, cells [0, pos] attended, no mask.
+    const int32_t * dyn; const float * mask;
 };
 
 // Body of one query head `h`. Written for 256 ACTIVE threads; a larger workgroup (the persistent kernel's 1024) passes
@@ -67,21 +72,28 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
     if (DH > 128 || tid >= 128) { const int e = DH > 128 ? tid : tid - 128; if (e < DH) vnew = v[(long) hk * DH + e]; }
     // ---- (1) position: with a sequence selector the selector and all (<= 64) positions are requested TOGETHER
     //      (the engine's position table has 64 entries) instead of as two dependent loads
-    int seq = 0, pos;
+    int seq = 0, pos, slot, n_kv;                // rope position, cache cell of this token, cells attended = [0, n_kv)
     if (seq_ptr) {
         const int pv = pos0_ptr[lane];
         seq = __builtin_amdgcn_readfirstlane(*seq_ptr);
         pos = __builtin_amdgcn_readlane(pv, seq);
+        slot = pos; n_kv = pos + 1;
     } else {
         pos = __builtin_amdgcn_readfirstlane(pos0_ptr[0]);
+        slot = pos; n_kv = pos + 1;
+        if (a.dyn) {
+            const PM_G int32_t * dyn = (const PM_G int32_t *) a.dyn;
+            slot = __builtin_amdgcn_readfirstlane(dyn[0]); n_kv = __builtin_amdgcn_readfirstlane(dyn[1]);
+        }
     }
+    const PM_G float * mask = (const PM_G float *) a.mask;
     kc += (long) seq * seq_stride; vc += (long) seq * seq_stride;
-    const int n_pad = (pos + 7) & ~7;            // cached keys 0..pos-1, padded to the 16-byte load width
+    const int n_pad = (n_kv + 7) & ~7;           // cached cells [0, n_kv) without `slot`, padded to the 16-byte load width
 
     // ---- (2) every global load whose address depends only on `pos` goes out NOW (one exposed latency for the rest of
     //      the kernel): this thread's K row of the first sweep and its first two V^T chunks; the rotations overlap it
     u32x4 kreg[KQ];
-    const bool have_k = tid < pos;
+    const bool have_k = tid < n_kv && tid != slot;
     {
         const PM_G uint16_t * kr = kc + (long) (have_k ? tid : 0) * Hkv * DH + (long) hk * DH;
 #pragma unroll
@@ -107,7 +119,7 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
         float * dst = is_k ? kcur : qs;
         dst[ia] = h2f(h0); dst[ib] = h2f(h1);
         if (is_k && h % (H / Hkv) == 0) {
-            PM_G uint16_t * d = kc + (long) pos * Hkv * DH + (long) hk * DH;
+            PM_G uint16_t * d = kc + (long) slot * Hkv * DH + (long) hk * DH;
             d[ia] = h0; d[ib] = h1;
         }
     }
@@ -116,12 +128,11 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
         if (e < DH) {
             const uint16_t hv = f2h(vnew);
             vcur[e] = h2f(hv);
-            if (h % (H / Hkv) == 0) vc[(long) (hk * DH + e) * n_ctx + pos] = hv;
+            if (h % (H / Hkv) == 0) vc[(long) (hk * DH + e) * n_ctx + slot] = hv;
         }
     }
     __syncthreads();
-    // ---- scores: cached keys 0..pos-1 (thread per key; first sweep from the pre-loaded registers), current key from LDS
-    const int n_kv = pos + 1;
+    // ---- scores: cached cells (thread per key; first sweep from the pre-loaded registers), current key from LDS
     float lmax = -INFINITY;
     auto dot_row = [&](const u32x4 (&kk)[KQ]) __attribute__((always_inline)) {
         float acc = 0.0f;
@@ -134,13 +145,14 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
             }
         return acc * scale;
     };
-    if (have_k) { const float s_ = dot_row(kreg); sc[tid] = s_; lmax = s_; }
-    for (int i = tid + 256; i < pos; i += 256) {
+    if (have_k) { const float s_ = dot_row(kreg) + (mask ? mask[tid] : 0.0f); sc[tid] = s_; lmax = s_; }
+    for (int i = tid + 256; i < n_kv; i += 256) {
+        if (i == slot) continue;
         const PM_G uint16_t * kr = kc + (long) i * Hkv * DH + (long) hk * DH;
         u32x4 kk[KQ];
 #pragma unroll
         for (int j = 0; j < KQ; ++j) kk[j] = *(const PM_G u32x4 *) (kr + 8 * j);
-        const float s_ = dot_row(kk);
+        const float s_ = dot_row(kk) + (mask ? mask[i] : 0.0f);
         sc[i] = s_;
         lmax = fmaxf(lmax, s_);
     }
@@ -148,8 +160,8 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
         float acc = 0.0f;
 #pragma unroll
         for (int e = lane; e < DH; e += 64) acc += kcur[e] * qs[e];
-        const float s_ = wave_sum(acc) * scale;
-        if (lane == 0) sc[pos] = s_;
+        const float s_ = wave_sum(acc) * scale + (mask ? mask[slot] : 0.0f);
+        if (lane == 0) sc[slot] = s_;
         lmax = fmaxf(lmax, s_);
     }
 #pragma unroll
@@ -169,9 +181,9 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
     __syncthreads();
     const double tot = (redd[0] + redd[1]) + (redd[2] + redd[3]);
     const float inv = (float) (1.0 / tot);
-    const float p_cur = h2f(f2h(sc[pos] * inv));                       // every thread reads exp() of the current key
+    const float p_cur = h2f(f2h(sc[slot] * inv));                      // every thread reads exp() of the current key
     __syncthreads();
-    for (int i = tid; i < n_pad; i += 256) sc[i] = i < pos ? h2f(f2h(sc[i] * inv)) : 0.0f;   // p rounded to F16; pad (incl. `pos`) = 0
+    for (int i = tid; i < n_pad; i += 256) sc[i] = (i < n_kv && i != slot) ? h2f(f2h(sc[i] * inv)) : 0.0f;   // p rounded to F16; pad and `slot` = 0
     __syncthreads();
     // ---- PV: thread (e, part) streams V^T[hk*DH+e][8*chunk ..] for chunk = part, part+PARTS, ... (first two pre-loaded)
     {

@@ -30,11 +30,15 @@ struct SplitP {
     // do_rope: q is the RAW projection; the scores kernel rotates it (every workgroup, its own group's heads), and the
     // workgroup whose chunk contains the token's position also rotates k, takes it from LDS and stores the K row / V column
     const float * k; const float * v; const float * ff; uint16_t * kc_w; uint16_t * vc_w; RopeP r; int do_rope;
+    // ggml-graph mode (see AttnP in attn_device.h): dyn = {cache cell of the token, cells attended}, mask = additive f32 KQ mask row
+    const int32_t * dyn; const float * mask;
 };
 
-__device__ __forceinline__ int cur_pos(const SplitP & p, int & seq) {
+// rope position `pos`, cache cell `slot` the token is stored in, cells attended = [0, n_kv)
+__device__ __forceinline__ void cur_pos(const SplitP & p, int & seq, int & pos, int & slot, int & n_kv) {
     seq = p.seq_ptr ? *p.seq_ptr : 0;
-    return p.pos0_ptr[seq];
+    pos = p.pos0_ptr[seq]; slot = pos; n_kv = pos + 1;
+    if (p.dyn) { slot = p.dyn[0]; n_kv = p.dyn[1]; }
 }
 
 // sum over the LPK (8 or 16) consecutive lanes that share one key; result in every lane of the group
@@ -53,12 +57,11 @@ __global__ __launch_bounds__(256) void attn_split_scores_kernel(SplitP p) {
     __shared__ float sc[RMAX][CK];               // this chunk's scores
     const int c = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int R = p.H / p.Hkv;
-    int seq; const int n_kv = cur_pos(p, seq) + 1;
+    int seq, pos, slot, n_kv; cur_pos(p, seq, pos, slot, n_kv);
     const int k0 = c * CK;
     if (k0 >= n_kv) return;
     const uint16_t * kc = p.kc + (long) seq * p.seq_stride + (long) g * DH;
     __shared__ float kcur[DH];                   // the token's own rotated key (do_rope)
-    const int pos = n_kv - 1;
     if (!p.do_rope) {
         for (int i = tid; i < R * DH; i += 256) { const int h = i / DH, e = i - h * DH; qs[h][e] = h2f(f2h(p.q[(long) (g * R + h) * DH + e])); }
     } else {
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void attn_split_scores_kernel(SplitP p) {
             cs2[tid][0] = cs_; cs2[tid][1] = sn_;
         }
         __syncthreads();
-        const bool mine = c == pos / CK;         // this workgroup also owns the new K row / V column of its KV head
+        const bool mine = c == slot / CK;        // this workgroup also owns the new K row / V column of its KV head
         for (int i = tid; i < (R + (mine ? 1 : 0)) * (DH / 2); i += 256) {
             const int h = i / (DH / 2), pair = i - h * (DH / 2);
             const bool is_k = h == R;
@@ -92,12 +95,12 @@ __global__ __launch_bounds__(256) void attn_split_scores_kernel(SplitP p) {
             float * dst = is_k ? kcur : qs[h];
             dst[ia] = h2f(h0); dst[ib] = h2f(h1);
             if (is_k) {
-                uint16_t * d = p.kc_w + (long) seq * p.seq_stride + (long) pos * p.Hkv * DH + (long) g * DH;
+                uint16_t * d = p.kc_w + (long) seq * p.seq_stride + (long) slot * p.Hkv * DH + (long) g * DH;
                 d[ia] = h0; d[ib] = h1;
             }
         }
         if (mine) for (int e = tid; e < DH; e += 256)
-            p.vc_w[(long) seq * p.seq_stride + (long) (g * DH + e) * p.n_ctx + pos] = f2h(p.v[(long) g * DH + e]);
+            p.vc_w[(long) seq * p.seq_stride + (long) (g * DH + e) * p.n_ctx + slot] = f2h(p.v[(long) g * DH + e]);
     }
     __syncthreads();
     const int piece = tid % LPK, kslot = tid / LPK;
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_split_scores_kernel(SplitP p) {
         float kf[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { kf[2 * j] = h2f((uint16_t) (kk[j] & 0xFFFF)); kf[2 * j + 1] = h2f((uint16_t) (kk[j] >> 16)); }
-        if (p.do_rope && key == pos) {               // the token's own key: from LDS, the cache row is being written by this kernel
+        if (p.do_rope && key == slot) {              // the token's own key: from LDS, the cache row is being written by this kernel
 #pragma unroll
             for (int i = 0; i < 8; ++i) kf[i] = kcur[8 * piece + i];
         }
@@ -134,8 +137,9 @@ __global__ __launch_bounds__(256) void attn_split_scores_kernel(SplitP p) {
         }
 #pragma unroll
         for (int h = 0; h < RMAX; ++h) acc[h] = group_sum<LPK>(acc[h]);
+        const float mk = (p.mask && key < n_kv) ? p.mask[key] : 0.0f;
 #pragma unroll
-        for (int h = 0; h < RMAX; ++h) if (h < R && piece == (h % LPK)) sc[h][kin] = key < n_kv ? acc[h] * p.scale : -INFINITY;
+        for (int h = 0; h < RMAX; ++h) if (h < R && piece == (h % LPK)) sc[h][kin] = key < n_kv ? acc[h] * p.scale + mk : -INFINITY;
     }
     __syncthreads();
     // chunk statistics and the scores themselves: wave w handles heads w, w + 4
@@ -145,7 +149,8 @@ __global__ __launch_bounds__(256) void attn_split_scores_kernel(SplitP p) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
         float l = 0.0f;
-        for (int i = lane; i < CK; i += 64) { const float s = sc[h][i]; l += expf(s - m); if (k0 + i < n_kv) p.S[(long) (g * R + h) * p.n_ctx + k0 + i] = s; }
+        for (int i = lane; i < CK; i += 64) {    // (a fully masked chunk has m = -inf: its sum is 0, not exp(nan))
+            const float s = sc[h][i]; l += s == -INFINITY ? 0.0f : expf(s - m); if (k0 + i < n_kv) p.S[(long) (g * R + h) * p.n_ctx + k0 + i] = s; }
         l = wave_sum(l);
         if (lane == 0) { p.M[(g * R + h) * p.nchunk + c] = m; p.L[(g * R + h) * p.nchunk + c] = l; }
     }
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256) void attn_split_pv_kernel(SplitP p) {
     __shared__ float part[PARTS][RMAX][DH];
     const int c = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const int R = p.H / p.Hkv;
-    int seq; const int n_kv = cur_pos(p, seq) + 1;
+    int seq, pos_, slot_, n_kv; cur_pos(p, seq, pos_, slot_, n_kv);
     const int k0 = c * CK;
     if (k0 >= n_kv) return;
     const int nact = (n_kv + CK - 1) / CK;
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_split_pv_kernel(SplitP p) {
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
         double l = 0.0;                          // sum in double like the reference (ggml_float)
-        if (h < R) for (int i = ci; i < nact; i += 32) l += (double) (p.L[(g * R + h) * p.nchunk + i] * expf(p.M[(g * R + h) * p.nchunk + i] - m));
+        if (h < R) for (int i = ci; i < nact; i += 32) { const float mi = p.M[(g * R + h) * p.nchunk + i]; if (mi != -INFINITY) l += (double) (p.L[(g * R + h) * p.nchunk + i] * expf(mi - m)); }
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) l += __shfl_xor(l, off);
         if (h < R && ci == 0) { mx[h] = m; inv[h] = (float) (1.0 / l); }
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_split_pv_kernel(SplitP p) {
 
 // ---- 3. combine ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_split_combine_kernel(SplitP p, int dh) {
-    int seq; const int n_kv = cur_pos(p, seq) + 1;
+    int seq, pos_, slot_, n_kv; cur_pos(p, seq, pos_, slot_, n_kv);
     const int nact = (n_kv + CK - 1) / CK;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.H * dh) return;
@@ -243,13 +248,13 @@ size_t pm_attn_split_scratch_floats(int H, int dh, int n_ctx) {
 // rope != nullptr: q, k, v = the RAW projections; the rotation, the KV store and the attention are done here (3 launches).
 int pm_launch_attn_split(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos0, const int32_t * seq,
                          long seq_stride, const float * freq_factors, float * out, float * scratch, int H, int Hkv, int dh, int n_ctx,
-                         float scale, const pm_rope_cfg * rope, hipStream_t st) {
+                         float scale, const pm_rope_cfg * rope, hipStream_t st, const int32_t * dyn, const float * mask) {
     if ((dh != 64 && dh != 128) || H % Hkv || H / Hkv > RMAX || n_ctx % 8 || !scratch) return -1;
     const int nchunk = (n_ctx + CK - 1) / CK;
     SplitP p = {};
     p.q = q; p.kc = (const uint16_t *) kc; p.vc = (const uint16_t *) vc; p.pos0_ptr = pos0; p.seq_ptr = seq; p.seq_stride = seq_stride;
     p.out = out; p.S = scratch; p.M = p.S + (size_t) H * n_ctx; p.L = p.M + (size_t) H * nchunk; p.P = p.L + (size_t) H * nchunk;
-    p.H = H; p.Hkv = Hkv; p.n_ctx = n_ctx; p.nchunk = nchunk; p.scale = scale;
+    p.H = H; p.Hkv = Hkv; p.n_ctx = n_ctx; p.nchunk = nchunk; p.scale = scale; p.dyn = dyn; p.mask = mask;
     if (rope) {
         const pm_rope_cfg & c = *rope;
         p.r.n_dims = c.n_dims; p.r.mode = c.mode; p.r.n_ctx_orig = c.n_ctx_orig; p.r.theta_scale = c.theta_scale;

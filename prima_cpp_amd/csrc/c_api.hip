@@ -151,6 +151,13 @@ int pm355_mul_mat_vec_fused(const pm355_matvec_job * jobs, int njobs, int64_t K,
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_mul_mat_vec_fused_check(const pm355_matvec_job * jobs, int njobs, int64_t K) {
+    if (njobs < 1 || njobs > 3 || !jobs) return fail(PM355_E_RANGE, "mul_mat_vec_fused: 1..3 jobs");
+    pm_gemv_fused f = {};
+    f.K = (int) K; f.njobs = njobs; f.xf = (const float *) 16;
+    for (int j = 0; j < njobs; ++j) { f.job[j].type = jobs[j].type; f.job[j].N = (int) jobs[j].N; f.job[j].W = jobs[j].W; f.job[j].W2 = jobs[j].W2; }
+    return gemv_rc(pm_gemv_fused_check(f));
+}
 int pm355_mul_mat_q_mfma(int type, const void * W, int64_t K, int64_t N, const float * x, int64_t n_tokens, float * y,
                          const float * bias, const float * resid, pm355_stream_t st) {
     (void) hipGetLastError();
@@ -222,6 +229,40 @@ int pm355_attn_rope_fused(const float * q, const float * k, const float * v, voi
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_attn_token(const pm355_attn_token_args * a, const pm355_rope_params * rp, pm355_stream_t st) {
+    if (!a || !rp || rp->n_dims % 2 || rp->n_dims > a->head_dim) return fail(PM355_E_SHAPE, "attn_token: n_dims");
+    if (!a->d_pos || !a->d_cell_nkv || !a->q || !a->k || !a->v || !a->k_cache || !a->v_cache || !a->out) return fail(PM355_E_SHAPE, "attn_token: null pointer");
+    pm_rope_cfg c;
+    c.n_dims = rp->n_dims; c.mode = rp->mode; c.n_ctx_orig = rp->n_ctx_orig; c.freq_base = rp->freq_base; c.freq_scale = rp->freq_scale;
+    c.ext_factor = rp->ext_factor; c.attn_factor = rp->attn_factor; c.beta_fast = rp->beta_fast; c.beta_slow = rp->beta_slow;
+    pm_rope_params(c);
+    (void) hipGetLastError();
+    if (a->split) {
+        if (pm_launch_attn_split(a->q, a->k, a->v, a->k_cache, a->v_cache, a->d_pos, nullptr, 0, a->freq_factors, a->out, a->scratch,
+                                 a->n_head, a->n_head_kv, a->head_dim, a->n_ctx, a->kq_scale, &c, S(st), a->d_cell_nkv, a->mask))
+            return fail(PM355_E_UNSUPPORTED, "attn_token(split): head_dim 64/128, at most 8 query heads per KV head, n_ctx % 8 == 0, scratch required");
+    } else if (pm_launch_attn_rope_fused(a->q, a->k, a->v, a->k_cache, a->v_cache, a->d_pos, nullptr, 0, a->freq_factors, a->out,
+                                         a->n_head, a->n_head_kv, a->head_dim, a->n_ctx, a->kq_scale, c, S(st), a->d_cell_nkv, a->mask, a->max_keys))
+        return fail(PM355_E_UNSUPPORTED, "attn_token: head_dim must be 64/128/256, n_ctx % 8 == 0 and max_keys fit LDS");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pm355_set_i32x2(int32_t * d_p, int32_t a, int32_t b, pm355_stream_t st) { pm_launch_set_i32x2(d_p, a, b, S(st)); HIP_TRY(hipGetLastError()); return 0; }
+
+int pm355_capture_begin(pm355_stream_t st) { HIP_TRY(hipStreamBeginCapture(S(st), hipStreamCaptureModeRelaxed)); return 0; }
+pm355_graph_t pm355_capture_end(pm355_stream_t st) {
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(S(st), &g);
+    if (e != hipSuccess || !g) { fail(PM355_E_HIP, "hipStreamEndCapture", e); if (g) (void) hipGraphDestroy(g); return nullptr; }
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    (void) hipGraphDestroy(g);
+    if (e != hipSuccess) { fail(PM355_E_HIP, "hipGraphInstantiate", e); return nullptr; }
+    return (pm355_graph_t) x;
+}
+int pm355_graph_launch(pm355_graph_t g, pm355_stream_t st) { HIP_TRY(hipGraphLaunch((hipGraphExec_t) g, S(st))); return 0; }
+void pm355_graph_free(pm355_graph_t g) { if (g) (void) hipGraphExecDestroy((hipGraphExec_t) g); }
+
 int pm355_argmax(const float * x, int64_t n, int32_t * d_index, float * d_value, pm355_stream_t st) {
     pm_launch_argmax(x, (int) n, d_index, d_value, S(st)); HIP_TRY(hipGetLastError()); return 0;
 }

@@ -11,6 +11,7 @@
 #define GGML_BACKEND_MI355_HAVE_GGML
 #include "../../include/ggml_backend_mi355.h"
 #include "../../include/prima_mi355.h"
+#include "ggml_graph_plan.h"
 
 #include <mutex>
 #include <string>
@@ -18,21 +19,71 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <cstdlib>
 
 #define MI355_CHECK(expr) do { int rc_ = (expr); if (rc_ != 0) { fprintf(stderr, "ggml-mi355: %s failed (rc=%d): %s\n", #expr, rc_, pm355_last_error()); GGML_ABORT("ggml-mi355 error"); } } while (0)
 
 namespace {
+
+// GGML_MI355_PLAN_ONLY=1: a DEBUG / TEST mode for machines without a GPU. One pretend device whose "device memory" is host
+// memory; graph_compute lowers every graph to its launch plan (ggml_graph_plan.h), reports it, and launches NOTHING, so tensors
+// keep whatever bytes they had: results are garbage by design. It exists so that the planner can be exercised under the
+// reference's real llama_decode on the CPU test box (tests/test_plugin_plan.py). It is never a compute path.
+bool plan_only() { static const bool v = [] { const char * e = getenv("GGML_MI355_PLAN_ONLY"); return e && e[0] == '1'; }(); return v; }
+bool env_on(const char * name) { const char * e = getenv(name); return e && e[0] && e[0] != '0'; }
+
+void * dmalloc(size_t n) {
+    if (!plan_only()) return pm355_malloc(n);
+    void * p = aligned_alloc(256, (n + 255) & ~(size_t) 255);       // device allocations are (at least) 256-byte aligned
+    if (p) memset(p, 0, n);
+    return p;
+}
+void   dfree(void * p) { if (plan_only()) free(p); else pm355_free(p); }
+int h2d(void * d, const void * s, size_t n, pm355_stream_t st) { if (plan_only()) { memcpy(d, s, n); return 0; } return pm355_memcpy_h2d(d, s, n, st); }
+int d2h(void * d, const void * s, size_t n, pm355_stream_t st) { if (plan_only()) { memcpy(d, s, n); return 0; } return pm355_memcpy_d2h(d, s, n, st); }
+int d2d(void * d, const void * s, size_t n, pm355_stream_t st) { if (plan_only()) { memmove(d, s, n); return 0; } return pm355_memcpy_d2d(d, s, n, st); }
+int dset(void * d, int v, size_t n, pm355_stream_t st) { if (plan_only()) { memset(d, v, n); return 0; } return pm355_memset(d, v, n, st); }
+int dsync(pm355_stream_t st) { return plan_only() ? 0 : pm355_sync(st); }
+int dsetdev(int d) { return plan_only() ? 0 : pm355_set_device(d); }
+int drepack(int type, const void * src, void * dst, int64_t K, int64_t rows, int to_dev, pm355_stream_t st) {
+    if (plan_only()) { memcpy(dst, src, (size_t) rows * pm355_row_size(type, K)); return 0; }
+    return pm355_repack_rows(type, src, dst, K, rows, to_dev, st);
+}
 
 bool is_soa_type(enum ggml_type t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q6_K || t == GGML_TYPE_Q8_0; }   // repack.hip
 bool is_gemv_type(enum ggml_type t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K || t == GGML_TYPE_Q8_0; }
 
 struct dev_ctx { int device; std::string name, desc; };
 struct buft_ctx { int device; std::string name; };
-struct buf_ctx { int device; void * base; size_t size; std::string name; };
+struct buf_ctx { int device; void * base; size_t size; std::string name; void * stage = nullptr; size_t stage_bytes = 0; };
+// device staging area of a buffer for the row-local repack (kept: the loader calls set_tensor once per weight tensor)
+void * buf_stage(buf_ctx * c, size_t n) {
+    if (n > c->stage_bytes) { dsync(nullptr); dfree(c->stage); c->stage = dmalloc(n); GGML_ASSERT(c->stage); c->stage_bytes = n; }
+    return c->stage;
+}
+// one lowered graph the backend has seen: its per-token fingerprint, its launch plan and (after a warm-up run) the captured hipGraph
+struct graph_entry {
+    std::vector<mi355::graph_fp_node> fp;
+    mi355::plan plan;
+    pm355_graph_t exec = nullptr;
+    int runs = 0;
+    uint64_t last_use = 0;
+};
 struct backend_ctx {
     int device; std::string name; pm355_stream_t stream;
     void * scratch = nullptr; size_t scratch_bytes = 0;
     int32_t * d_i32 = nullptr;                       // small device scratch (positions)
+    // graph lowering (ggml_graph_plan.h)
+    int32_t * d_dyn = nullptr;                       // device int32[2]: {KV cell of the token, cells attended}
+    float * qkv = nullptr; size_t qkv_floats = 0;    // raw q / k / v projections of one token
+    float * split = nullptr; size_t split_floats = 0;
+    std::vector<graph_entry *> graphs;
+    std::vector<mi355::graph_fp_node> fp_tmp;
+    uint64_t tick = 0;
+    bool fuse = true, use_graphs = true, debug_plan = false;
+    int split_min = 640;
+    // counters (GGML_MI355_STATS=1 prints them when the backend is freed; tests read them through the log)
+    uint64_t n_compute = 0, n_replay = 0, n_capture = 0, n_eager = 0, n_plan = 0, n_fp_hit = 0;
 };
 
 pm355_tensor to_pm(const struct ggml_tensor * t) {
@@ -48,51 +99,50 @@ bool buffer_is_mi355(ggml_backend_buffer_t b) { return b && b->iface.get_name ==
 
 void buf_free(ggml_backend_buffer_t b) {
     buf_ctx * c = (buf_ctx *) b->context;
-    pm355_set_device(c->device);
-    pm355_free(c->base);
+    dsetdev(c->device);
+    dfree(c->base);
+    dfree(c->stage);
     delete c;
 }
 void * buf_get_base(ggml_backend_buffer_t b) { return ((buf_ctx *) b->context)->base; }
 void buf_init_tensor(ggml_backend_buffer_t, struct ggml_tensor *) {}
 
 void buf_memset_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, uint8_t v, size_t off, size_t size) {
-    pm355_set_device(((buf_ctx *) b->context)->device);
-    MI355_CHECK(pm355_memset((char *) t->data + off, v, size, nullptr));
-    MI355_CHECK(pm355_sync(nullptr));
+    dsetdev(((buf_ctx *) b->context)->device);
+    MI355_CHECK(dset((char *) t->data + off, v, size, nullptr));
+    MI355_CHECK(dsync(nullptr));
 }
 
 // host GGUF-order bytes -> HBM layout (row-local repack for the row-SoA types; see repack.hip)
 void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void * data, size_t off, size_t size) {
-    pm355_set_device(((buf_ctx *) b->context)->device);
+    dsetdev(((buf_ctx *) b->context)->device);
     if (is_soa_type(t->type)) {
         const size_t rb = ggml_row_size(t->type, t->ne[0]), stride = pm355_row_stride(t->type, t->ne[0]);
         GGML_ASSERT(off % rb == 0 && size % rb == 0 && "row-granular access to a row-SoA tensor");
-        void * stage = pm355_malloc(size);
-        GGML_ASSERT(stage);
-        MI355_CHECK(pm355_memcpy_h2d(stage, data, size, nullptr));
-        MI355_CHECK(pm355_repack_rows(t->type, stage, (char *) t->data + (off / rb) * stride, t->ne[0], (int64_t) (size / rb), 1, nullptr));
-        MI355_CHECK(pm355_sync(nullptr));
-        pm355_free(stage);
+        GGML_ASSERT(!t->view_src && "row-SoA tensors are addressed per allocated tensor, not through views");
+        void * stage = buf_stage((buf_ctx *) b->context, size);
+        MI355_CHECK(h2d(stage, data, size, nullptr));
+        MI355_CHECK(drepack(t->type, stage, (char *) t->data + (off / rb) * stride, t->ne[0], (int64_t) (size / rb), 1, nullptr));
+        MI355_CHECK(dsync(nullptr));
         return;
     }
-    MI355_CHECK(pm355_memcpy_h2d((char *) t->data + off, data, size, nullptr));
-    MI355_CHECK(pm355_sync(nullptr));
+    MI355_CHECK(h2d((char *) t->data + off, data, size, nullptr));
+    MI355_CHECK(dsync(nullptr));
 }
 void buf_get_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * t, void * data, size_t off, size_t size) {
-    pm355_set_device(((buf_ctx *) b->context)->device);
+    dsetdev(((buf_ctx *) b->context)->device);
     if (is_soa_type(t->type)) {
         const size_t rb = ggml_row_size(t->type, t->ne[0]), stride = pm355_row_stride(t->type, t->ne[0]);
         GGML_ASSERT(off % rb == 0 && size % rb == 0 && "row-granular access to a row-SoA tensor");
-        void * stage = pm355_malloc(size);
-        GGML_ASSERT(stage);
-        MI355_CHECK(pm355_repack_rows(t->type, (const char *) t->data + (off / rb) * stride, stage, t->ne[0], (int64_t) (size / rb), 0, nullptr));
-        MI355_CHECK(pm355_memcpy_d2h(data, stage, size, nullptr));
-        MI355_CHECK(pm355_sync(nullptr));
-        pm355_free(stage);
+        GGML_ASSERT(!t->view_src && "row-SoA tensors are addressed per allocated tensor, not through views");
+        void * stage = buf_stage((buf_ctx *) b->context, size);
+        MI355_CHECK(drepack(t->type, (const char *) t->data + (off / rb) * stride, stage, t->ne[0], (int64_t) (size / rb), 0, nullptr));
+        MI355_CHECK(d2h(data, stage, size, nullptr));
+        MI355_CHECK(dsync(nullptr));
         return;
     }
-    MI355_CHECK(pm355_memcpy_d2h(data, (const char *) t->data + off, size, nullptr));
-    MI355_CHECK(pm355_sync(nullptr));
+    MI355_CHECK(d2h(data, (const char *) t->data + off, size, nullptr));
+    MI355_CHECK(dsync(nullptr));
 }
 size_t hbm_bytes(const struct ggml_tensor * t) {
     if (is_soa_type(t->type)) return pm355_row_stride(t->type, t->ne[0]) * (size_t) (t->ne[1] * t->ne[2] * t->ne[3]);
@@ -102,16 +152,16 @@ bool buf_cpy_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * src, str
     if (!buffer_is_mi355(src->buffer)) return false;                 // ggml falls back to get + set through the host
     buf_ctx * sc = (buf_ctx *) src->buffer->context, * dc = (buf_ctx *) b->context;
     if (sc->device != dc->device || src->type != dst->type || !ggml_is_contiguous(src) || !ggml_is_contiguous(dst)) return false;
-    pm355_set_device(dc->device);
-    MI355_CHECK(pm355_memcpy_d2d(dst->data, src->data, hbm_bytes(src), nullptr));
-    MI355_CHECK(pm355_sync(nullptr));
+    dsetdev(dc->device);
+    MI355_CHECK(d2d(dst->data, src->data, hbm_bytes(src), nullptr));
+    MI355_CHECK(dsync(nullptr));
     return true;
 }
 void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
     buf_ctx * c = (buf_ctx *) b->context;
-    pm355_set_device(c->device);
-    MI355_CHECK(pm355_memset(c->base, v, c->size, nullptr));
-    MI355_CHECK(pm355_sync(nullptr));
+    dsetdev(c->device);
+    MI355_CHECK(dset(c->base, v, c->size, nullptr));
+    MI355_CHECK(dsync(nullptr));
 }
 const struct ggml_backend_buffer_i buffer_iface = {
     /* .get_name      = */ buf_get_name,
@@ -132,9 +182,9 @@ bool buft_is_mi355(ggml_backend_buffer_type_t t) { return t && t->iface.get_name
 
 ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t t, size_t size) {
     buft_ctx * c = (buft_ctx *) t->context;
-    pm355_set_device(c->device);
+    dsetdev(c->device);
     size = size ? size : 1;
-    void * p = pm355_malloc(size + 256);              // tail slack for 16-byte vector reads
+    void * p = dmalloc(size + 256);              // tail slack for 16-byte vector reads
     if (!p) { fprintf(stderr, "ggml-mi355: allocating %.2f MiB on device %d failed\n", size / 1048576.0, c->device); return nullptr; }
     return ggml_backend_buffer_init(t, buffer_iface, new buf_ctx{c->device, p, size, c->name}, size);
 }
@@ -153,9 +203,9 @@ const struct ggml_backend_buffer_type_i buft_iface = {
 
 // pinned host buffers: a CPU buffer over hipHostMalloc memory (the scheduler puts CPU-side compute buffers here)
 const char * host_buft_name(ggml_backend_buffer_type_t) { return GGML_MI355_NAME "_Host"; }
-void host_buf_free(ggml_backend_buffer_t b) { pm355_host_free(b->context); }
+void host_buf_free(ggml_backend_buffer_t b) { if (plan_only()) free(b->context); else pm355_host_free(b->context); }
 ggml_backend_buffer_t host_buft_alloc(ggml_backend_buffer_type_t t, size_t size) {
-    void * p = pm355_host_malloc(size ? size : 1);
+    void * p = plan_only() ? aligned_alloc(256, ((size ? size : 1) + 255) & ~(size_t) 255) : pm355_host_malloc(size ? size : 1);
     if (!p) return ggml_backend_buft_alloc_buffer(ggml_backend_cpu_buffer_type(), size);
     ggml_backend_buffer_t b = ggml_backend_cpu_buffer_from_ptr(p, size);
     b->buft = t;
@@ -167,35 +217,40 @@ ggml_backend_buffer_t host_buft_alloc(ggml_backend_buffer_type_t t, size_t size)
 const char * backend_name(ggml_backend_t b) { return ((backend_ctx *) b->context)->name.c_str(); }
 void backend_free(ggml_backend_t b) {
     backend_ctx * c = (backend_ctx *) b->context;
-    pm355_set_device(c->device);
-    pm355_sync(c->stream);
-    pm355_free(c->scratch); pm355_free(c->d_i32);
-    pm355_stream_destroy(c->stream);
+    dsetdev(c->device);
+    dsync(c->stream);
+    if (env_on("GGML_MI355_STATS"))
+        fprintf(stderr, "ggml-mi355 stats: graph_compute %llu, fingerprint hits %llu, plans built %llu, hipGraph replays %llu, captures %llu, eager runs %llu\n",
+                (unsigned long long) c->n_compute, (unsigned long long) c->n_fp_hit, (unsigned long long) c->n_plan, (unsigned long long) c->n_replay,
+                (unsigned long long) c->n_capture, (unsigned long long) c->n_eager);
+    for (graph_entry * e : c->graphs) { if (e->exec) pm355_graph_free(e->exec); delete e; }
+    dfree(c->scratch); dfree(c->d_i32); dfree(c->d_dyn); dfree(c->qkv); dfree(c->split);
+    if (!plan_only()) pm355_stream_destroy(c->stream);
     delete c; delete b;
 }
 void backend_set_async(ggml_backend_t b, struct ggml_tensor * t, const void * data, size_t off, size_t size) {
     backend_ctx * c = (backend_ctx *) b->context;
-    if (is_soa_type(t->type)) { buf_set_tensor(t->view_src ? t->view_src->buffer : t->buffer, t, data, off, size); return; }
-    pm355_set_device(c->device);
-    MI355_CHECK(pm355_memcpy_h2d((char *) t->data + off, data, size, c->stream));
+    dsetdev(c->device);
+    if (is_soa_type(t->type)) { dsync(c->stream); buf_set_tensor(t->view_src ? t->view_src->buffer : t->buffer, t, data, off, size); return; }
+    MI355_CHECK(h2d((char *) t->data + off, data, size, c->stream));
 }
 void backend_get_async(ggml_backend_t b, const struct ggml_tensor * t, void * data, size_t off, size_t size) {
     backend_ctx * c = (backend_ctx *) b->context;
-    pm355_set_device(c->device);
-    if (is_soa_type(t->type)) { pm355_sync(c->stream); buf_get_tensor(t->view_src ? t->view_src->buffer : t->buffer, t, data, off, size); return; }
-    MI355_CHECK(pm355_memcpy_d2h(data, (const char *) t->data + off, size, c->stream));
+    dsetdev(c->device);
+    if (is_soa_type(t->type)) { dsync(c->stream); buf_get_tensor(t->view_src ? t->view_src->buffer : t->buffer, t, data, off, size); return; }
+    MI355_CHECK(d2h(data, (const char *) t->data + off, size, c->stream));
 }
 void backend_sync(ggml_backend_t b) {
     backend_ctx * c = (backend_ctx *) b->context;
-    pm355_set_device(c->device);
-    MI355_CHECK(pm355_sync(c->stream));
+    dsetdev(c->device);
+    MI355_CHECK(dsync(c->stream));
 }
 
 void * scratch(backend_ctx * c, size_t bytes) {
     if (bytes > c->scratch_bytes) {
-        pm355_sync(c->stream);
-        pm355_free(c->scratch);
-        c->scratch = pm355_malloc(bytes + 256);
+        dsync(c->stream);
+        dfree(c->scratch);
+        c->scratch = dmalloc(bytes + 256);
         GGML_ASSERT(c->scratch);
         c->scratch_bytes = bytes;
     }
@@ -335,19 +390,130 @@ bool compute_node(backend_ctx * c, struct ggml_tensor * op) {
     }
 }
 
-enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g) {
-    backend_ctx * c = (backend_ctx *) b->context;
-    pm355_set_device(c->device);
-    const int n_nodes = ggml_graph_n_nodes(g);        // public accessors: struct ggml_cgraph is private to ggml (ggml-impl.h:183)
-    for (int i = 0; i < n_nodes; ++i) {
-        struct ggml_tensor * node = ggml_graph_node(g, i);
-        if (ggml_is_empty(node)) continue;
-        if (!compute_node(c, node)) {
-            fprintf(stderr, "ggml-mi355: op %s not supported (supports_op should have rejected it)\n", ggml_op_name(node->op));
-            return GGML_STATUS_FAILED;
+// scratch callbacks of the planner: stable pointers while large enough (a pointer that moves changes the plan -> new capture)
+float * plan_qkv_scratch(void * user, size_t n_q, size_t n_kv) {
+    backend_ctx * c = (backend_ctx *) user;
+    const size_t need = n_q + 2 * n_kv;
+    if (need > c->qkv_floats) {
+        dsync(c->stream);
+        dfree(c->qkv);
+        c->qkv = (float *) dmalloc(need * 4 + 256);
+        c->qkv_floats = c->qkv ? need : 0;
+    }
+    return c->qkv;
+}
+float * plan_split_scratch(void * user, size_t n) {
+    backend_ctx * c = (backend_ctx *) user;
+    if (n > c->split_floats) {
+        dsync(c->stream);
+        dfree(c->split);
+        c->split = (float *) dmalloc(n * 4 + 256);
+        c->split_floats = c->split ? n : 0;
+    }
+    return c->split;
+}
+
+// the launch sequence of a plan on the backend's stream (also what gets captured into a hipGraph)
+bool run_plan(backend_ctx * c, struct ggml_cgraph * g, const mi355::plan & p) {
+    for (const mi355::step & s : p.steps) {
+        switch (s.kind) {
+            case mi355::STEP_GEMV:
+                MI355_CHECK(pm355_mul_mat_vec_fused(s.job, s.njobs, s.K, s.x, s.norm_w, s.eps, c->stream));
+                break;
+            case mi355::STEP_ATTN:
+                MI355_CHECK(pm355_attn_token(&s.attn, &s.rope, c->stream));
+                break;
+            default: {
+                struct ggml_tensor * node = ggml_graph_node(g, s.node);
+                if (!compute_node(c, node)) {
+                    fprintf(stderr, "ggml-mi355: op %s not supported (supports_op should have rejected it)\n", ggml_op_name(node->op));
+                    return false;
+                }
+            }
         }
     }
-    return GGML_STATUS_SUCCESS;
+    return true;
+}
+
+void print_plan(const backend_ctx * c, struct ggml_cgraph * g, const mi355::plan & p, int32_t cell, int32_t n_kv) {
+    fprintf(stderr, "ggml-mi355 plan: %d nodes -> %zu launches (%d fused mat-vec, %d attention, %d node-equivalent; %d nodes fused) single_token=%d "
+                    "cell=%d n_kv=%d graphable=%d\n", ggml_graph_n_nodes(g), p.steps.size(), p.n_gemv, p.n_attn, p.n_node, p.n_fused_nodes,
+            (int) p.single_token, cell, n_kv, (int) (p.single_token && p.fast_ok));
+    if (!env_on("GGML_MI355_DEBUG_PLAN_STEPS")) return;
+    for (const mi355::step & s : p.steps) {
+        if (s.kind == mi355::STEP_GEMV) {
+            fprintf(stderr, "  [%d,%d) matvec K=%lld norm=%d jobs=%d:", s.node_lo, s.node_hi, (long long) s.K, s.norm_w != nullptr, s.njobs);
+            for (int j = 0; j < s.njobs; ++j) fprintf(stderr, " {%s N=%lld%s%s%s}", ggml_type_name((enum ggml_type) s.job[j].type), (long long) s.job[j].N,
+                                                     s.job[j].W2 ? " pair" : "", s.job[j].bias ? " +bias" : "", s.job[j].resid ? " +resid" : "");
+            fprintf(stderr, "\n");
+        } else if (s.kind == mi355::STEP_ATTN) {
+            fprintf(stderr, "  [%d,%d) attention H=%d Hkv=%d dh=%d n_ctx=%d %s mask=%d ff=%d\n", s.node_lo, s.node_hi, s.attn.n_head, s.attn.n_head_kv, s.attn.head_dim,
+                    s.attn.n_ctx, s.attn.split ? "split" : "fused", s.attn.mask != nullptr, s.attn.freq_factors != nullptr);
+        } else {
+            fprintf(stderr, "  [%d] %s '%s'\n", s.node, ggml_op_name(ggml_graph_node(g, s.node)->op), ggml_graph_node(g, s.node)->name);
+        }
+    }
+    (void) c;
+}
+
+// graph_compute (ggml-backend-impl.h:112; called per split by ggml_backend_sched_compute_splits, ggml-backend.cpp:2139):
+//   1. per-token fingerprint of the split; a hit on a cached entry skips planning
+//   2. else lower the graph to a launch plan (fusion by structural pattern matching); an equal plan of another entry is re-used
+//   3. write the token's KV cell / cells attended to the device, then replay the entry's hipGraph - captured on the entry's second
+//      run, after one eager warm-up run (function attributes, scratch growth) - or run the launches eagerly
+enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g) {
+    backend_ctx * c = (backend_ctx *) b->context;
+    dsetdev(c->device);
+    const int n_nodes = ggml_graph_n_nodes(g);        // public accessors: struct ggml_cgraph is private to ggml (ggml-impl.h:183)
+    ++c->n_compute; ++c->tick;
+    if (n_nodes == 0) return GGML_STATUS_SUCCESS;
+    if (!c->d_dyn) { c->d_dyn = (int32_t *) dmalloc(64); GGML_ASSERT(c->d_dyn); }
+
+    mi355::graph_fingerprint(g, c->fp_tmp);
+    graph_entry * e = nullptr;
+    for (graph_entry * x : c->graphs) if (x->plan.fast_ok && mi355::fingerprint_equal(x->fp, c->fp_tmp)) { e = x; ++c->n_fp_hit; break; }
+    if (!e) {
+        mi355::plan_ctx pc = { c, plan_qkv_scratch, plan_split_scratch, c->d_dyn, c->split_min, c->fuse };
+        mi355::plan p;
+        mi355::planner(g, pc).build(p);
+        ++c->n_plan;
+        for (graph_entry * x : c->graphs) if (mi355::plan_equal(x->plan, p)) { e = x; break; }
+        if (e) { e->fp = c->fp_tmp; e->plan.i_kcell = p.i_kcell; e->plan.i_kview = p.i_kview; e->plan.fast_ok = p.fast_ok; }
+        else {
+            if (c->graphs.size() >= 16) {                        // evict the least recently used entry
+                size_t lru = 0;
+                for (size_t i = 1; i < c->graphs.size(); ++i) if (c->graphs[i]->last_use < c->graphs[lru]->last_use) lru = i;
+                dsync(c->stream);                                // its hipGraph may still be in flight
+                if (c->graphs[lru]->exec) pm355_graph_free(c->graphs[lru]->exec);
+                delete c->graphs[lru];
+                c->graphs.erase(c->graphs.begin() + lru);
+            }
+            e = new graph_entry;
+            e->fp = c->fp_tmp; e->plan = std::move(p);
+            c->graphs.push_back(e);
+        }
+    }
+    e->last_use = c->tick;
+    const mi355::plan & p = e->plan;
+    int32_t cell = 0, n_kv = 0;
+    if (!mi355::plan_dyn(g, p, cell, n_kv)) { fprintf(stderr, "ggml-mi355: cannot locate the KV cell of a planned graph\n"); return GGML_STATUS_FAILED; }
+    if (c->debug_plan) print_plan(c, g, p, cell, n_kv);
+    if (plan_only()) return GGML_STATUS_SUCCESS;
+
+    if (p.has_attn) MI355_CHECK(pm355_set_i32x2(c->d_dyn, cell, n_kv, c->stream));
+    const bool graphable = c->use_graphs && p.single_token && p.n_gemv > 0 && p.steps.size() >= 3;
+    if (graphable && e->exec) { MI355_CHECK(pm355_graph_launch(e->exec, c->stream)); ++e->runs; ++c->n_replay; return GGML_STATUS_SUCCESS; }
+    if (graphable && e->runs >= 1) {
+        MI355_CHECK(pm355_capture_begin(c->stream));
+        const bool ok = run_plan(c, g, p);
+        e->exec = pm355_capture_end(c->stream);
+        if (!ok) return GGML_STATUS_FAILED;
+        if (e->exec) { MI355_CHECK(pm355_graph_launch(e->exec, c->stream)); ++e->runs; ++c->n_capture; return GGML_STATUS_SUCCESS; }
+        fprintf(stderr, "ggml-mi355: hipGraph capture failed (%s) - running eagerly from now on\n", pm355_last_error());
+        c->use_graphs = false;
+    }
+    ++e->runs; ++c->n_eager;
+    return run_plan(c, g, p) ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
 }
 
 bool backend_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const struct ggml_tensor * src, struct ggml_tensor * dst) {
@@ -355,13 +521,13 @@ bool backend_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const struct ggml_t
     if (!buffer_is_mi355(src->view_src ? src->view_src->buffer : src->buffer) || !buffer_is_mi355(dst->view_src ? dst->view_src->buffer : dst->buffer)) return false;
     backend_ctx * cs = (backend_ctx *) bs->context, * cd = (backend_ctx *) bd->context;
     if (cs->device != cd->device || src->type != dst->type || !ggml_is_contiguous(src) || !ggml_is_contiguous(dst)) return false;
-    pm355_set_device(cd->device);
-    if (cs != cd) pm355_sync(cs->stream);
-    MI355_CHECK(pm355_memcpy_d2d(dst->data, src->data, hbm_bytes(src), cd->stream));
+    dsetdev(cd->device);
+    if (cs != cd) dsync(cs->stream);
+    MI355_CHECK(d2d(dst->data, src->data, hbm_bytes(src), cd->stream));
     return true;
 }
-void backend_event_record(ggml_backend_t b, ggml_backend_event_t e) { MI355_CHECK(pm355_event_record((pm355_event_t) e->context, ((backend_ctx *) b->context)->stream)); }
-void backend_event_wait(ggml_backend_t b, ggml_backend_event_t e) { MI355_CHECK(pm355_event_wait(((backend_ctx *) b->context)->stream, (pm355_event_t) e->context)); }
+void backend_event_record(ggml_backend_t b, ggml_backend_event_t e) { if (plan_only()) return; MI355_CHECK(pm355_event_record((pm355_event_t) e->context, ((backend_ctx *) b->context)->stream)); }
+void backend_event_wait(ggml_backend_t b, ggml_backend_event_t e) { if (plan_only()) return; MI355_CHECK(pm355_event_wait(((backend_ctx *) b->context)->stream, (pm355_event_t) e->context)); }
 
 const struct ggml_backend_i backend_iface = {
     /* .get_name                = */ backend_name,
@@ -410,13 +576,13 @@ bool dev_offload_op(ggml_backend_dev_t, const struct ggml_tensor * op) {
     return op->op != GGML_OP_GET_ROWS && op->ne[1] >= 32;
 }
 ggml_backend_event_t dev_event_new(ggml_backend_dev_t d) {
-    pm355_set_device(((dev_ctx *) d->context)->device);
-    pm355_event_t e = pm355_event_create();
+    dsetdev(((dev_ctx *) d->context)->device);
+    pm355_event_t e = plan_only() ? (pm355_event_t) 1 : pm355_event_create();
     if (!e) return nullptr;
     return new ggml_backend_event{d, e};
 }
-void dev_event_free(ggml_backend_dev_t, ggml_backend_event_t e) { pm355_event_destroy((pm355_event_t) e->context); delete e; }
-void dev_event_sync(ggml_backend_dev_t, ggml_backend_event_t e) { MI355_CHECK(pm355_event_sync((pm355_event_t) e->context)); }
+void dev_event_free(ggml_backend_dev_t, ggml_backend_event_t e) { if (!plan_only()) pm355_event_destroy((pm355_event_t) e->context); delete e; }
+void dev_event_sync(ggml_backend_dev_t, ggml_backend_event_t e) { if (plan_only()) return; MI355_CHECK(pm355_event_sync((pm355_event_t) e->context)); }
 
 const struct ggml_backend_device_i device_iface = {
     /* .get_name             = */ dev_name,
@@ -448,11 +614,15 @@ const struct ggml_backend_reg_i reg_iface = { reg_name, reg_dev_count, reg_dev_g
 
 extern "C" {
 
-int ggml_backend_mi355_get_device_count(void) { int n = pm355_device_count(); return n > GGML_MI355_MAX_DEVICES ? GGML_MI355_MAX_DEVICES : n; }
+int ggml_backend_mi355_get_device_count(void) {
+    if (plan_only()) return 1;
+    int n = pm355_device_count(); return n > GGML_MI355_MAX_DEVICES ? GGML_MI355_MAX_DEVICES : n;
+}
 
 void ggml_backend_mi355_get_device_memory(int device, size_t * free, size_t * total) {
     size_t f = 0, t = 0;
-    pm355_device_info(device, nullptr, 0, &f, &t, nullptr);
+    if (plan_only()) f = t = (size_t) 64 << 30;
+    else pm355_device_info(device, nullptr, 0, &f, &t, nullptr);
     if (free) *free = f;
     if (total) *total = t;
 }
@@ -483,9 +653,14 @@ ggml_backend_buffer_type_t ggml_backend_mi355_host_buffer_type(void) {
 
 ggml_backend_t ggml_backend_mi355_init(int device) {
     if (device < 0 || device >= ggml_backend_mi355_get_device_count()) { fprintf(stderr, "ggml-mi355: invalid device %d\n", device); return nullptr; }
-    if (pm355_set_device(device)) return nullptr;
-    backend_ctx * c = new backend_ctx{device, std::string(GGML_MI355_NAME "X") + std::to_string(device), pm355_stream_create()};
+    if (dsetdev(device)) return nullptr;
+    backend_ctx * c = new backend_ctx{device, std::string(GGML_MI355_NAME "X") + std::to_string(device), plan_only() ? (pm355_stream_t) 1 : pm355_stream_create()};
     if (!c->stream) { delete c; return nullptr; }
+    c->fuse = !env_on("GGML_MI355_NO_FUSE");                          // node-by-node kernels only (debug / A-B)
+    c->use_graphs = !env_on("GGML_MI355_NO_GRAPH") && !plan_only();   // no hipGraph capture / replay
+    c->debug_plan = env_on("GGML_MI355_DEBUG_PLAN") || plan_only();
+    if (const char * sm = getenv("GGML_MI355_ATTN_SPLIT_MIN")) if (sm[0]) c->split_min = atoi(sm);
+    if (c->split_min < 32) c->split_min = 32;
     return new ggml_backend{ backend_guid(), backend_iface, ggml_backend_reg_dev_get(ggml_backend_mi355_reg(), device), c };
 }
 
@@ -501,8 +676,8 @@ ggml_backend_reg_t ggml_backend_mi355_reg(void) {
         reg = { reg_iface, rc };
         const int n = ggml_backend_mi355_get_device_count();
         for (int i = 0; i < n; ++i) {
-            char nm[256] = "";
-            pm355_device_info(i, nm, sizeof(nm), nullptr, nullptr, nullptr);
+            char nm[256] = "plan-only pseudo device (no GPU, no compute)";
+            if (!plan_only()) pm355_device_info(i, nm, sizeof(nm), nullptr, nullptr, nullptr);
             dev_ctx * dc = new dev_ctx{i, std::string(GGML_MI355_NAME "X") + std::to_string(i), nm};
             rc->devices.push_back(new ggml_backend_device{ device_iface, &reg, dc });
         }

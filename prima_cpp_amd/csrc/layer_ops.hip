@@ -273,6 +273,7 @@ __global__ void advance_kernel(int32_t * pos, int32_t * ctl, int by, int rotate)
     if (rotate) ctl[0] = (s + rotate) % ctl[1];
 }
 __global__ void set_i32_kernel(int32_t * p, int v) { *p = v; }
+__global__ void set_i32x2_kernel(int32_t * p, int a, int b) { p[0] = a; p[1] = b; }
 
 // ---- launchers -------------------------------------------------------------------------------------
 void pm_launch_embed(int type, const void * table, int K, const int32_t * tokens, int n_tok, float * out, hipStream_t st) {
@@ -317,16 +318,17 @@ int pm_launch_attn_decode(const float * q, const void * kc, const void * vc, con
 
 int pm_launch_attn_rope_fused(const float * q, const float * k, const float * v, void * kc, void * vc,
                                const int32_t * pos0, const int32_t * seq, long seq_stride, const float * freq_factors,
-                               float * out, int H, int Hkv, int dh, int n_ctx, float scale, const pm_rope_cfg & c, hipStream_t st) {
+                               float * out, int H, int Hkv, int dh, int n_ctx, float scale, const pm_rope_cfg & c, hipStream_t st,
+                               const int32_t * dyn, const float * mask, int max_keys) {
     if ((dh != 64 && dh != 128 && dh != 256) || n_ctx % 8) return -1;
-    const size_t lds = (size_t) (4 * dh + 256 + n_ctx + 8) * 4;
+    const size_t lds = (size_t) (4 * dh + 256 + (max_keys > 0 ? ((max_keys + 7) & ~7) : n_ctx) + 8) * 4;
     if (lds > 150 * 1024) return -1;
     RopeP r;
     r.n_dims = c.n_dims; r.mode = c.mode; r.n_ctx_orig = c.n_ctx_orig; r.theta_scale = c.theta_scale;
     r.freq_scale = c.freq_scale; r.ext_factor = c.ext_factor; r.attn_factor = c.attn_factor; r.corr0 = c.corr0; r.corr1 = c.corr1;
     auto launch = [&](auto kern) {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        AttnP a = {q, k, v, (uint16_t *) kc, (uint16_t *) vc, pos0, seq, seq_stride, freq_factors, out, H, Hkv, n_ctx, scale, r};
+        AttnP a = {q, k, v, (uint16_t *) kc, (uint16_t *) vc, pos0, seq, seq_stride, freq_factors, out, H, Hkv, n_ctx, scale, r, dyn, mask};
         hipLaunchKernelGGL(kern, dim3(H), dim3(256), lds, st, a);
     };
     if (dh == 64) launch(attn_rope_fused_kernel<64>);
@@ -352,6 +354,9 @@ void pm_launch_scale(const float * a, float * y, float s, long n, hipStream_t st
 }
 void pm_launch_set_i32(int32_t * p, int v, hipStream_t st) {
     hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, st, p, v);
+}
+void pm_launch_set_i32x2(int32_t * p, int a, int b, hipStream_t st) {
+    hipLaunchKernelGGL(set_i32x2_kernel, dim3(1), dim3(1), 0, st, p, a, b);
 }
 void pm_launch_advance(int32_t * pos, int32_t * ctl, int by, int rotate, hipStream_t st) {
     hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, pos, ctl, by, rotate);

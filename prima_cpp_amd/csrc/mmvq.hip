@@ -147,6 +147,11 @@ int pm_device_cus() {
     return g_num_cus;
 }
 
+int pm_gemv_fused_check(const pm_gemv_fused & a) {
+    GemvP p; int ta, tb, grid; bool pair; size_t lds;
+    return gemv_fill(a, 0, p, ta, tb, pair, lds, grid);
+}
+
 // Fused launch: up to 3 matrices sharing one activation row.
 int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st) {
     GemvP p; int ta, tb, grid; bool pair; size_t lds;

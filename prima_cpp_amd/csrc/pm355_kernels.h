@@ -53,6 +53,7 @@ struct pm_gemv_fused {
     int32_t * dbg_int;
 };
 int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st);
+int pm_gemv_fused_check(const pm_gemv_fused & a);      // the validation part of pm_launch_gemv_fused only
 
 // batched (prefill) GEMM on MFMA: Y[T][N] = X[T][K] . W[N][K]^T (+bias[n]) (+resid[t][n]); W quantized (HBM layout), X f32
 int pm_launch_gemm_q(int type, const void * W, const float * X, float * Y, int K, int N, int T, const float * bias,

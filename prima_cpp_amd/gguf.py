@@ -230,10 +230,14 @@ def random_valid_blocks(t, nrows, k, rng, scale=None):
 
 
 def write_synthetic_model(path, arch, n_layer, n_embd, n_head, n_head_kv, n_ff, n_vocab, n_ctx_train=8192, seed=1234,
-                          rope_freqs=None, is_70b=False, all_type=None, distinct_layers=2):
+                          rope_freqs=None, is_70b=False, all_type=None, distinct_layers=2, branch_scale=1.0):
     """A Llama / Qwen2-shaped GGUF with random valid quant blocks in the Q4_K_M mixture (or every matrix `all_type`).
     To bound generation time for multi-GB shapes only `distinct_layers` different random tensors are drawn per
-    (tensor kind, type); further layers reuse them rolled by a layer-dependent number of rows."""
+    (tensor kind, type); further layers reuse them rolled by a layer-dependent number of rows.
+    branch_scale multiplies the weights of the two projections that write into the residual stream (attn_output, ffn_down).
+    (It does NOT tame the logit-level spread between two float summation orders: that spread comes from the int8 re-quantization
+    of the activations in front of every mat-vec, which turns a perturbation eps into flips of size `step` with probability
+    eps/step, i.e. amplitude ~sqrt(eps*step) per stage, and saturates at ~step after a handful of stages - DESIGN.md, parity.)"""
     rng = np.random.default_rng(seed)
     a = arch
     E, dh = n_embd, n_embd // n_head
@@ -245,21 +249,33 @@ def write_synthetic_model(path, arch, n_layer, n_embd, n_head, n_head_kv, n_ff, 
               "ffn_down": (n_ff, E)}
     pool = {}
 
-    def mat(kind, t, K, N, il):
+    def mat(kind, t, K, N, il, n_out=None):
+        """-> (type, writer(file)): rows of the pooled tensor rolled by a layer-dependent amount (tiled up to n_out rows),
+        written straight to the file so multi-GB models never sit in memory."""
         if t in (Q4_K, Q5_K, Q6_K) and K % 256:
             t = Q8_0                                     # llama_tensor_get_type fallback for K % 256 != 0 (src/llama.cpp:19547)
         key = (kind, t, il % distinct_layers)
         if key not in pool:
-            pool[key] = random_valid_blocks(t, N, K, rng)
-        rs = row_size(t, K)
-        d = pool[key].reshape(N, rs)
+            pool[key] = random_valid_blocks(t, N, K, rng, scale=(branch_scale if kind in ("wo", "ffn_down") else 1.0) / np.sqrt(K))
+        d = pool[key].reshape(N, row_size(t, K))
         r = (il // distinct_layers * 37) % N
-        return t, (np.roll(d, r, axis=0) if r else d)
+        n_out = n_out or N
+
+        def write(f):
+            left, first = n_out, True
+            while left > 0:
+                if first and r:
+                    f.write(memoryview(d[r:r + left]).cast("B")); left -= min(left, N - r)
+                    if left > 0:
+                        f.write(memoryview(d[:min(r, left)]).cast("B")); left -= min(r, left)
+                else:
+                    f.write(memoryview(d[:left]).cast("B")); left -= min(left, N)
+                first = False
+        return t, write
 
     tensors = []
-    t, d = mat("tok_embd", all_type or Q4_K, E, min(n_vocab, 8192), 0)
-    reps = (n_vocab + d.shape[0] - 1) // d.shape[0]
-    tensors.append(("token_embd.weight", t, (E, n_vocab), np.tile(d, (reps, 1))[:n_vocab]))
+    t, d = mat("tok_embd", all_type or Q4_K, E, min(n_vocab, 8192), 0, n_vocab)
+    tensors.append(("token_embd.weight", t, (E, n_vocab), d))
     for il in range(n_layer):
         p = f"blk.{il}."
         tensors.append((p + "attn_norm.weight", F32, (E,), (1 + rng.normal(0, 0.02, E)).astype(np.float32)))
@@ -275,9 +291,8 @@ def write_synthetic_model(path, arch, n_layer, n_embd, n_head, n_head_kv, n_ff, 
             t, d = mat(kind, all_type or q4_k_m_type(kind, il, n_layer, is_70b), K, N, il)
             tensors.append((p + LAYER_TENSORS[kind], t, (K, N), d))
     tensors.append(("output_norm.weight", F32, (E,), (1 + rng.normal(0, 0.02, E)).astype(np.float32)))
-    t, d = mat("output", all_type or Q6_K, E, min(n_vocab, 8192), 1)
-    reps = (n_vocab + d.shape[0] - 1) // d.shape[0]
-    tensors.append(("output.weight", t, (E, n_vocab), np.tile(d, (reps, 1))[:n_vocab]))
+    t, d = mat("output", all_type or Q6_K, E, n_vocab, 1)          # every row distinct: no exactly tied logits
+    tensors.append(("output.weight", t, (E, n_vocab), d))
     if rope_freqs is None:
         rope_freqs = a == 0
     if rope_freqs:

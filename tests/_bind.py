@@ -521,7 +521,7 @@ def write_gguf_from_arrays(path, z):
 
 def llama_driver_path(flavour=None):
     fl = flavour or best_ref_flavour()
-    for f in ([fl] if fl in ("avx2", "avx512") else []) + ([] if flavour else ["avx2"]):
+    for f in ([fl] if fl in ("scalar", "avx2", "avx512") else []) + ([] if flavour else ["avx2"]):
         p = os.path.join(ORACLE_DIR, "_ref", f"llama-ref-driver-{f}")
         if os.path.exists(p):
             return p

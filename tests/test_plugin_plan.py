@@ -1,0 +1,46 @@
+"""The plug-in's graph lowering (prima_cpp_amd/csrc/ggml_graph_plan.h) exercised under the reference's REAL llama_decode on a
+machine without a GPU: GGML_MI355_PLAN_ONLY=1 makes the plug-in register one pretend device backed by host memory whose
+graph_compute plans every split, prints the plan and launches nothing (outputs are garbage by design - this is not a compute
+path). What is checked: the single-token layer graph of build_llama / build_qwen2 lowers to 5 launches per layer
+(QKV, attention, wo+residual, gate/up pair, down+residual; +3 node-equivalent launches in the last layer whose ADD output
+aliases the mat-vec input) and the head to one launch; multi-token batches stay node-equivalent."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from _bind import llama_driver_path, run_llama_driver, write_gguf_from_arrays
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+pytestmark = pytest.mark.skipif(llama_driver_path() is None, reason="oracle/_ref/llama-ref-driver-* not built")
+PLAN = re.compile(r"ggml-mi355 plan: (\d+) nodes -> (\d+) launches \((\d+) fused mat-vec, (\d+) attention, (\d+) node-equivalent; (\d+) nodes fused\) "
+                  r"single_token=(\d) cell=(\d+) n_kv=(\d+) graphable=(\d)")
+
+
+@pytest.mark.parametrize("name,nodes", [("llama", 66), ("qwen2", 72)])
+def test_decode_graph_lowers_to_five_launches_per_layer(name, nodes, tmp_path):
+    z = np.load(os.path.join(HERE, "golden", f"tiny_{name}_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / f"tiny_{name}.gguf"), z)
+    _, _, st = run_llama_driver(path, z["prompt"][:3], 4, ngl=99, n_ctx=64, threads=1, extra_args=["--keep-out-in-cuda"],
+                                env={"GGML_MI355_PLAN_ONLY": "1"}, flavour="avx2", timeout=120)
+    plans = [tuple(int(x) for x in m.groups()) for m in PLAN.finditer(st["stderr"])]
+    assert "plan-only" in st["stderr"] or plans, st["stderr"][-2000:]
+    layer = [p for p in plans if p[0] == nodes]
+    head = [p for p in plans if p[0] == 3]
+    decode = [p for p in layer if p[6] == 1]
+    assert len(decode) >= 3 and len(head) >= 3
+    n_layer = int(z["hp_n_layer"])
+    for p in decode:
+        _, launches, gemv, attn, node_eq, fused, single, cell, n_kv, graphable = p
+        assert attn == n_layer and gemv == 4 * n_layer and node_eq == 3 and launches == 5 * n_layer + 3, p
+        assert fused == nodes - 3 and graphable == 1 and n_kv == 32
+    # the KV cell advances by one per decoded token (the value that is written to the device before the captured graph is replayed)
+    cells = [p[7] for p in decode]
+    assert cells[0] == 0                                       # the warm-up token of llama_init_from_gpt_params (common/common.cpp:1959)
+    assert cells[1:] == list(range(3, 3 + len(cells) - 1)), cells
+    for p in head:
+        assert p[1] == 1 and p[2] == 1, p
+    # the 3-token prompt batch: nothing fused, not a hipGraph candidate
+    prefill = [p for p in layer if p[6] == 0]
+    assert prefill and all(p[2] == 0 and p[3] == 0 and p[9] == 0 for p in prefill), prefill
