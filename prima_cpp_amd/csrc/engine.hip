@@ -282,7 +282,10 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
                                      H, Hkv, dh, hp.n_ctx, kq_scale, &m->rope, st))
                 return seterr(m, PM355_E_RANGE, "decode: split attention unsupported for this shape");
         } else if (pm_launch_attn_rope_fused(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d,
-                                             att, H, Hkv, dh, hp.n_ctx, kq_scale, m->rope, st))
+                                             att, H, Hkv, dh, hp.n_ctx, kq_scale, m->rope, st, nullptr, nullptr,
+                                             // with the split path available this kernel only ever sees < split_min cells: its LDS
+                                             // score buffer is sized for that, not for n_ctx (long contexts stay launchable)
+                                             m->split_scratch ? m->split_min + 8 : 0))
             return seterr(m, PM355_E_RANGE, "decode: fused attention unsupported for this head_dim / n_ctx");
         {
             const Tensor * w[1] = {&L.t[PM355_T_WO]}; float * y[1] = {x_mid}; const float * r[1] = {cur};
@@ -625,6 +628,7 @@ int pm355_model_set_pos(pm355_model * m, int pos, pm355_stream_t st) {
 int pm355_model_set_seq_pos(pm355_model * m, int seq, int pos, pm355_stream_t st) {
     if (!m->finalized) return seterr(m, PM355_E_SHAPE, "set_seq_pos: model not finalized");
     if (seq >= m->n_seq) return seterr(m, PM355_E_RANGE, "set_seq_pos: seq >= n_seq");
+    if (pos < 0 || pos > m->hp.n_ctx) return seterr(m, PM355_E_RANGE, "set_seq_pos: position outside [0, n_ctx]");
     // values travel as kernel arguments: capture-safe, no host buffer lifetime to manage
     if (seq < 0) { pm_launch_set_i32(m->d_ctl, 0, (hipStream_t) st); seq = 0; m->h_seq = 0; }
     pm_launch_set_i32(m->d_pos + seq, pos, (hipStream_t) st);
@@ -652,7 +656,7 @@ int pm355_model_decode(pm355_model * m, const int32_t * d_tokens, const float * 
     if (pos0 < 0 || pos0 + T > m->hp.n_ctx) return seterr(m, PM355_E_RANGE, "decode: position outside n_ctx");
     int rc = pm355_model_set_pos(m, pos0, st);
     if (rc) return rc;
-    return run_window(m, d_tokens, d_x_in, T, d_x_out, d_logits, d_argmax, (hipStream_t) st);
+    return run_window(m, d_tokens, d_x_in, T, d_x_out, d_logits, d_argmax, (hipStream_t) st);   // device counter and mirror stay at pos0
 }
 
 // head_first != 0 (ring rank 0): d_x_in is the LAST rank's activation; apply the head to it (-> d_argmax / d_logits),
@@ -685,10 +689,16 @@ int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * 
     if (head_first && (!(m->flags & PM355_HAS_HEAD) || !d_token || !d_x_in)) return seterr(m, PM355_E_SHAPE, "step: head_first needs HEAD, d_token and d_x_in");
     hipStream_t st = (hipStream_t) pst;
     // host mirror of the device-side counters: which attention path this step takes, and the state after it
+    if (m->hi > m->lo && m->h_pos[m->h_seq] + 1 > m->hp.n_ctx)
+        return seterr(m, PM355_E_RANGE, "step: the sequence is at n_ctx - no KV cell left (llama_decode would fail to find a slot)");
     const int regime = (m->split_scratch && m->h_pos[m->h_seq] >= m->split_min) ? 1 : 0;
     m->long_ctx = regime != 0;
-    struct Mirror { pm355_model * m; int adv, rot; ~Mirror() { m->h_pos[m->h_seq] += adv; if (rot) m->h_seq = (m->h_seq + rot) % m->n_seq; } } mirror{m, advance, rotate};
-    if (!use_graph) return step_body(m, d_token, d_x_in, d_x_out, d_logits, d_argmax, advance, rotate, head_first, st);
+    // the mirror follows the device counters, which only move when the step was really enqueued
+    auto commit = [&]() { m->h_pos[m->h_seq] += advance; if (rotate) m->h_seq = (m->h_seq + rotate) % m->n_seq; return 0; };
+    if (!use_graph) {
+        const int rc = step_body(m, d_token, d_x_in, d_x_out, d_logits, d_argmax, advance, rotate, head_first, st);
+        return rc ? rc : commit();
+    }
     hipGraphExec_t exec = nullptr;
     for (auto & g : m->graphs)
         if (g.in == d_x_in && g.tok == d_token && g.out == d_x_out && g.logits == d_logits && g.argmax == d_argmax &&
@@ -717,10 +727,14 @@ int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * 
         e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
         (void) hipGraphDestroy(g);
         if (e != hipSuccess) return seterr(m, PM355_E_HIP, "step: graph instantiate");
-        if (m->graphs.size() >= 16) { (void) hipGraphExecDestroy(m->graphs.front().exec); m->graphs.erase(m->graphs.begin()); }
+        if (m->graphs.size() >= 16) {
+            (void) hipDeviceSynchronize();                    // the evicted exec may still be in flight on a caller's stream
+            (void) hipGraphExecDestroy(m->graphs.front().exec); m->graphs.erase(m->graphs.begin());
+        }
         m->graphs.push_back({d_x_in, d_token, d_x_out, d_logits, d_argmax, advance, rotate, head_first, regime, exec});
     }
-    return hipGraphLaunch(exec, st) == hipSuccess ? 0 : seterr(m, PM355_E_HIP, "step: graph launch");
+    if (hipGraphLaunch(exec, st) != hipSuccess) return seterr(m, PM355_E_HIP, "step: graph launch");
+    return commit();
 }
 
 // Non-zero when a persistent kernel's barrier watchdog fired (a workgroup was never scheduled): results since then are

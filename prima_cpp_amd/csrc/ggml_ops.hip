@@ -227,8 +227,9 @@ int pm355_op_soft_max(const pm355_tensor * a, const pm355_tensor * mask, const p
     const unsigned n_head = (unsigned) a->ne[2];
     const unsigned n_head_log2 = 1u << (unsigned) floor(log2((double) n_head));
     const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
-    static bool set = false;
-    if (lds > 48 * 1024 && !set) { (void) hipFuncSetAttribute((const void *) soft_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set = true; }
+    static bool set[16] = {};
+    const int dv = lds > 48 * 1024 ? pm_cur_dev() : 0;
+    if (lds > 48 * 1024 && !set[dv]) { (void) hipFuncSetAttribute((const void *) soft_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set[dv] = true; }
     (void) hipGetLastError();
     hipLaunchKernelGGL(soft_max_kernel, dim3((unsigned) rows), dim3(256), lds, S(st), to_td(a), mask ? (const char *) mask->data : nullptr,
                        mask ? mask->type : 0, mask ? (long) mask->nb[1] : 0, to_td(dst), scale, max_bias, m0, m1, n_head_log2);

@@ -308,8 +308,9 @@ int pm_launch_attn_decode(const float * q, const void * kc, const void * vc, con
     const size_t lds = (size_t) (dh + n_ctx) * 4;
     if (lds > 150 * 1024 || dh % 8 || n_ctx % 8) return -1;
     if (lds > 48 * 1024) {
-        static bool set = false;
-        if (!set) { (void) hipFuncSetAttribute((const void *) attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set = true; }
+        static bool set[16] = {};
+        const int dv = pm_cur_dev();
+        if (!set[dv]) { (void) hipFuncSetAttribute((const void *) attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set[dv] = true; }
     }
     hipLaunchKernelGGL(attn_decode_kernel, dim3(H, n_tok), dim3(256), lds, st,
                        q, (const uint16_t *) kc, (const uint16_t *) vc, pos0, seq, seq_stride, out, H, Hkv, dh, n_ctx, scale);

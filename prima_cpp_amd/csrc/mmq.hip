@@ -320,8 +320,8 @@ int pm_launch_gemm_q_ex(int type, const void * W, const float * X, float * Y, in
     const dim3 grid((N + BM - 1) / BM, (T + BN - 1) / BN);
     const size_t lds = (size_t) 2 * (BM + BN) * LDS_STRIDE * sizeof(_Float16);
     auto go = [&](auto kern) {
-        static bool attr = false;
-        if (!attr) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr = true; }
+        static bool attr[16] = {};                    // per instantiation AND per device
+        if (!attr[dev]) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr[dev] = true; }
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p);
     };
     switch (type) {

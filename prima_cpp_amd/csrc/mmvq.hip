@@ -50,8 +50,9 @@ template <int TA, int TB>
 int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, hipStream_t st) {
     const GemvP & p = p_in;
     auto go = [&](auto kern) {
-        static bool attr_set = false;                 // one flag per instantiation (lambda is instantiated per kern type)
-        if (lds > 48 * 1024 && !attr_set) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        static bool attr_set[16] = {};                // one flag per instantiation (lambda is instantiated per kern type) and device
+        const int dv = lds > 48 * 1024 ? pm_cur_dev() : 0;
+        if (lds > 48 * 1024 && !attr_set[dv]) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set[dv] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(PM_GEMV_BLOCK), lds, st, p);
     };
     if (pair) {
@@ -69,7 +70,12 @@ bool type_ok(int t) { return t == PM_Q4_K || t == PM_Q5_K || t == PM_Q6_K || t =
 
 } // namespace
 
-static int g_num_cus = 0;
+static int g_num_cus_dev[16] = {};
+static int num_cus() {
+    const int dv = pm_cur_dev();
+    if (!g_num_cus_dev[dv]) { hipDeviceProp_t pr; g_num_cus_dev[dv] = hipGetDeviceProperties(&pr, dv) == hipSuccess ? pr.multiProcessorCount : 256; }
+    return g_num_cus_dev[dv];
+}
 
 int pm_gemv_units_per_row(int type, int64_t K) { return (int) (K / nv_of(type)); }
 
@@ -117,9 +123,8 @@ int pmv::gemv_fill(const pm_gemv_fused & a, int grid_fixed, GemvP & p, int & ta_
         if (ta != PM_Q4_K) { const int t = ta; ta = tb; tb = t; }     // canonical order: Q4_K first
         if (ta != PM_Q4_K || (tb != PM_Q6_K && tb != PM_Q5_K)) return -1;
     }
-    if (!g_num_cus) { hipDeviceProp_t pr; int dev = 0; (void) hipGetDevice(&dev); g_num_cus = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
     // one workgroup of 16 waves per CU; every workgroup takes an equal slice of the rows of EVERY job
-    int grid = grid_fixed > 0 ? grid_fixed : (1024 / PM_GEMV_BLOCK) * g_num_cus;
+    int grid = grid_fixed > 0 ? grid_fixed : (1024 / PM_GEMV_BLOCK) * num_cus();
     long tot_rows = 0;
     for (int j = 0; j < a.njobs; ++j) tot_rows += a.job[j].N;
     int rows_cap = PM_MAX_ROWS_PER_WG;
@@ -142,10 +147,7 @@ int pmv::gemv_fill(const pm_gemv_fused & a, int grid_fixed, GemvP & p, int & ta_
     return 0;
 }
 
-int pm_device_cus() {
-    if (!g_num_cus) { hipDeviceProp_t pr; int dev = 0; (void) hipGetDevice(&dev); g_num_cus = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
-    return g_num_cus;
-}
+int pm_device_cus() { return num_cus(); }
 
 int pm_gemv_fused_check(const pm_gemv_fused & a) {
     GemvP p; int ta, tb, grid; bool pair; size_t lds;

@@ -4,6 +4,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// index of the current HIP device for the per-device one-time state of the launchers (a process may drive up to 16 GPUs
+// through the plug-in: hipFuncSetAttribute and the CU count are per device, not per process)
+static inline int pm_cur_dev() { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 16) ? d : 0; }
+
 // bytes of one quantized ACTIVATION row in the library's internal row-SoA layout (quantize.hip)
 static inline size_t pm_q8k_row_bytes(int K) { return (size_t) K + (size_t) (K / 256) * 4 + (size_t) (K / 16) * 2; }
 static inline size_t pm_q80_row_bytes(int K) { return (size_t) K + (size_t) (K / 32) * 2; }

@@ -203,12 +203,27 @@ def q4_k_m_type(kind, il, n_layer, is_70b=False):
     return Q4_K
 
 
+_POOL = None
+_POOL_BYTES = (32 << 20) + 8 * 1009          # not a multiple of any block or row size
+
+
 def random_valid_blocks(t, nrows, k, rng, scale=None):
     """Random VALID quant blocks (every bit pattern of the packed fields, finite fp16 scales) with |w| ~ scale
     (default 1/sqrt(k)); mean ~ 0 for Q4_K/Q5_K because dmin/d is chosen so that E[d*sc*q] == E[dmin*m]."""
     nper, bs = BLOCK[t]
     nb = nrows * (k // nper)
-    raw = rng.integers(0, 256, size=(nb, bs), dtype=np.uint8)
+    n = nb * bs
+    if n <= _POOL_BYTES:
+        raw = rng.integers(0, 2 ** 64 - 1, size=(n + 7) // 8, dtype=np.uint64, endpoint=True).view(np.uint8)[:n].reshape(nb, bs).copy()
+    else:
+        # multi-GB shapes: drawing every byte from the generator would take minutes of host time. Bytes come from one random pool,
+        # read cyclically from a random (odd) offset: no two rows hold the same bytes at the same alignment
+        global _POOL
+        if _POOL is None:
+            _POOL = np.random.default_rng(0x9E3779B9).integers(0, 2 ** 64 - 1, size=_POOL_BYTES // 8, dtype=np.uint64, endpoint=True).view(np.uint8)
+        off = int(rng.integers(0, _POOL_BYTES // 2)) | 1
+        reps = (off + n + _POOL_BYTES - 1) // _POOL_BYTES
+        raw = np.tile(_POOL, reps)[off:off + n].reshape(nb, bs)
     if scale is None:
         scale = 1.0 / np.sqrt(k)
 

@@ -327,6 +327,9 @@ class Ref(_Lib):
 # synthetic data
 # --------------------------------------------------------------------------------------------
 
+_POOL = None
+
+
 def rand_blocks(t, nrows, k, rng, scale=None):
     """Random VALID quant blocks (every bit pattern of the packed fields, finite fp16 scales).
 
@@ -334,7 +337,14 @@ def rand_blocks(t, nrows, k, rng, scale=None):
     `scale` sets the magnitude of the fp16 super-block scale d (default gives |w| ~ 1/sqrt(k))."""
     nper, bs = BLOCK[t]
     nb = nrows * (k // nper)
-    raw = rng.integers(0, 256, size=(nb, bs), dtype=np.uint8)
+    if nb * bs >= (1 << 24):      # big tensors (model-shaped tests): bytes from a fixed random pool, read cyclically from a random odd offset
+        global _POOL
+        if _POOL is None:
+            _POOL = np.random.default_rng(0x9E3779B9).integers(0, 2 ** 64 - 1, size=((32 << 20) + 8072) // 8, dtype=np.uint64, endpoint=True).view(np.uint8)
+        n, off = nb * bs, int(rng.integers(0, _POOL.size // 2)) | 1
+        raw = np.tile(_POOL, (off + n + _POOL.size - 1) // _POOL.size)[off:off + n].reshape(nb, bs).copy()
+    else:
+        raw = rng.integers(0, 256, size=(nb, bs), dtype=np.uint8)
     if scale is None:
         scale = 1.0 / np.sqrt(k)
 

@@ -22,7 +22,8 @@ def _hp(d):
 @pytest.fixture(scope="module")
 def E():
     import torch
-    assert torch.cuda.is_available()
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
     import prima_cpp_amd.engine as eng
     eng.torch = torch
     return eng
@@ -253,3 +254,32 @@ def test_long_context_split_attention_path(E, monkeypatch):
         # not bit-identical: a different f32 summation order can flip an F16 / int8 re-quantization downstream, and the KV
         # caches of the two runs then differ by that much for all later tokens (same effect as between the reference's own builds)
         assert _nmse(h1, h0) < 1e-4 and _nmse(l1, l0) < 1e-3        # the whole-stack bound used against the reference itself
+
+
+def test_step_refuses_to_write_past_the_kv_slab(E):
+    """pm355_model_step_ex / set_seq_pos must bound the position by n_ctx (llama_decode returns an error when no KV
+    cell is left, src/llama.cpp:18445); a failed step must not move the host mirror of the device counters."""
+    import prima_cpp_amd.lib as L
+    torch = E.torch
+    rng = np.random.default_rng(3)
+    d = tiny_model(rng, arch=0, n_layer=1, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=320, n_ctx=32, rope_freqs=True)
+    w = E.Window(_hp(d), n_ctx=32)
+    w.load_desc(d)
+    w.finalize(max_tokens=1, n_seq=2)
+    tok = torch.zeros(1, dtype=torch.int32, device="cuda")
+    am = torch.zeros(1, dtype=torch.int32, device="cuda")
+    w.set_pos(31)
+    w.step(token=tok, argmax=am)                       # position 31 = last cell: fine
+    torch.cuda.synchronize()
+    for use_graph in (True, False):
+        with pytest.raises(L.PM355Error):
+            w.step(token=tok, argmax=am, use_graph=use_graph)    # position 32 == n_ctx: refused, nothing launched
+    with pytest.raises(L.PM355Error):
+        w.set_seq_pos(1, 33)
+    with pytest.raises(L.PM355Error):
+        w.set_seq_pos(1, -1)
+    torch.cuda.synchronize()
+    w.set_pos(5)
+    w.step(token=tok, argmax=am)                       # still usable after the refusals
+    torch.cuda.synchronize()
+    w.close()

@@ -65,7 +65,8 @@ def _worker(rank, world, port, n_rounds, first, q):
 def test_two_rank_ring_matches_single_window():
     import torch
     import torch.multiprocessing as mp
-    assert torch.cuda.is_available()
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
     sys.path.insert(0, ROOT)
     from _bind import tiny_model
     import prima_cpp_amd.engine as E
