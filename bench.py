@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefill", type=int, default=2048, help="prompt length of the (untimed-for-the-metric) prefill probe, 0 = off")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip extra_configs / plugin_decode / the llama_decode CPU baseline")
+    ap.add_argument("--tmp", default=os.environ.get("TMPDIR", "/tmp"), help="where the synthetic GGUF files of the plug-in legs go")
     return ap.parse_args()
 
 
@@ -255,6 +257,103 @@ def probe_prefill(hp, mixture, n_tok, n_layers=8):
             "note": "MFMA v_mfma_f32_32x32x16_f16 weight GEMMs (on-the-fly dequantization) + MFMA causal attention; layers timed x (n_layer / layers_timed); gemm_tflops counts the weight GEMMs only over the whole layer time"}
 
 
+def extra_config(name, steps=32, warmup=8, prompt=16, n_ctx=4096):
+    """One more BASELINE.json config on the same engine path as the headline (batch-1 greedy decode, one hipGraph replay per
+    token): tokens/s and fraction of that model's HBM roofline."""
+    import prima_cpp_amd.engine as E
+    from prima_cpp_amd.lib import Q6_K, row_size
+    from prima_cpp_amd.ring import EngineCompute, RingDriver
+    hp, mixture, model_name = model_cfg(name)
+    lb = layer_bytes(hp, mixture)
+    total_w = sum(lb) + row_size(Q6_K, hp["n_embd"]) * hp["n_vocab"] + hp["n_embd"] * 4
+    win = E.Window(hp, lo=0, hi=hp["n_layer"], flags=E.HAS_EMBD | E.HAS_HEAD, n_ctx=n_ctx)
+    win.fill_synthetic(mixture, seed=1234)
+    win.finalize(max_tokens=1, n_seq=1)
+    drv = RingDriver(EngineCompute(win, 1, use_graph=True), 0, 1)
+    rng = np.random.default_rng(1234)
+    toks = rng.integers(0, hp["n_vocab"], size=prompt)
+    for s_ in range(prompt + warmup):
+        drv.micro_step(forced_token=int(toks[s_]) if s_ < prompt else None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        drv.micro_step(forced_token=None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    drv.flush()
+    torch.cuda.synchronize()
+    win.close()
+    roof = HBM_PEAK_GBS * 1e9 / total_w
+    return {"workload": f"{model_name} batch-1 greedy decode, {prompt}-token synthetic prompt, n_ctx {n_ctx}, F16 KV cache, 1 GPU",
+            "tokens_per_s": round(steps / dt, 2), "ms_per_token": round(dt / steps * 1e3, 4), "weights_bytes_per_token": total_w,
+            "hbm_roofline_tokens_per_s": round(roof, 1), "frac_of_hbm_roofline": round(steps / dt / roof, 4)}
+
+
+def _driver(flavour_pref=None):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _bind as B
+    return B, B.llama_driver_path(flavour_pref)
+
+
+def plugin_decode(tmp, n_gen=64, prompt_len=16):
+    """BASELINE.json config 1/2 through the DROP-IN boundary: a Llama-3-8B-shaped Q4_K_M GGUF (random valid blocks) decoded by
+    the reference's unmodified llama_decode (oracle/_ref/llama-ref-driver-*, built from /root/reference with the committed gate
+    patch) with every layer + the output layer in the MI355 buffer type (-ngl 99 --keep-out-in-cuda). The driver binary only
+    orchestrates; all compute runs in libggml-mi355.so / libprima_mi355.so."""
+    from prima_cpp_amd import gguf as G
+    B, drv = _driver()
+    if drv is None:
+        return None, None
+    path = os.path.join(tmp, "pm355_bench_llama3_8b_q4km.gguf")
+    t0 = time.time()
+    G.write_synthetic_model(path, arch=0, n_layer=32, n_embd=4096, n_head=32, n_head_kv=8, n_ff=14336, n_vocab=128256)
+    t_gen = time.time() - t0
+    prompt = np.random.default_rng(1234).integers(0, 128256, prompt_len)
+    prompt[0] = 128000
+    _, _, st = B.run_llama_driver(path, prompt, n_gen, ngl=99, n_ctx=4096, threads=usable_cores(), extra_args=["--keep-out-in-cuda"], timeout=600)
+    total_w = 4617000000.0                       # BASELINE.md section 2: bytes read per decoded token, Llama-3-8B Q4_K_M
+    roof = HBM_PEAK_GBS * 1e9 / total_w
+    out = {"workload": f"Llama-3-8B-shaped Q4_K_M GGUF ({os.path.getsize(path) / 1e9:.2f} GB, random valid blocks, no_vocab) through the reference's "
+                       f"llama_decode + MI355 plug-in: -ngl 99 --keep-out-in-cuda, {prompt_len}-token prompt, {n_gen} greedy tokens, n_ctx 4096",
+           "tokens_per_s": round(st["decode_tok_s"], 2), "ms_per_token": round(st["decode_ms_avg"], 4), "best_ms_per_token": round(st["decode_ms_min"], 4),
+           "prompt_tokens_per_s": round(st["prompt_tok_s"], 1), "load_ms": round(st["load_ms"], 1), "gguf_write_s": round(t_gen, 1),
+           "hbm_roofline_tokens_per_s": round(roof, 1), "frac_of_hbm_roofline": round(st["decode_tok_s"] / roof, 4),
+           "timing": "wall clock around llama_decode + llama_synchronize per token, first 5 tokens dropped (llama_perf convention)"}
+    return out, path
+
+
+def cpu_llama_decode(tmp, path_8b, hp70):
+    """The reference's own llama_decode on this host's cores (-ngl 0): (a) the 8B-shaped GGUF of plugin_decode, (b) the metric's
+    model shape (Llama-3-70B Q4_K_M) at two reduced depths so that a whole-token time for 80 layers follows from the measured
+    per-layer and fixed (embedding + head + graph) costs without writing a 42 GB file."""
+    from prima_cpp_amd import gguf as G
+    B, drv = _driver()
+    if drv is None:
+        return None
+    cores = usable_cores()
+    out = {"cores": cores, "kind": "reference", "binary": os.path.basename(drv),
+           "timing": "wall clock around llama_decode per token (-ngl 0), first tokens dropped"}
+    prompt = np.random.default_rng(1234).integers(0, 128256, 16)
+    if path_8b and os.path.exists(path_8b):
+        _, _, st = B.run_llama_driver(path_8b, prompt, 12, ngl=0, n_ctx=512, threads=cores, timeout=900)
+        out["llama3_8b_q4km"] = {"tokens_per_s": round(st["decode_tok_s"], 3), "prompt_tokens_per_s": round(st["prompt_tok_s"], 2)}
+    ms = {}
+    for L in (2, 6):
+        p = os.path.join(tmp, f"pm355_bench_llama3_70b_shape_{L}l.gguf")
+        G.write_synthetic_model(p, arch=0, n_layer=L, n_embd=hp70["n_embd"], n_head=hp70["n_head"], n_head_kv=hp70["n_head_kv"],
+                                n_ff=hp70["n_ff"], n_vocab=hp70["n_vocab"], is_70b=True)
+        _, _, st = B.run_llama_driver(p, prompt, 10, ngl=0, n_ctx=512, threads=cores, timeout=900)
+        ms[L] = st["decode_ms_avg"]
+        os.unlink(p)
+    per_layer = (ms[6] - ms[2]) / 4.0
+    fixed = ms[2] - 2 * per_layer
+    tok_ms = fixed + hp70["n_layer"] * per_layer
+    out["llama3_70b_q4km"] = {"tokens_per_s": round(1e3 / tok_ms, 3), "ms_per_layer": round(per_layer, 3), "ms_fixed": round(fixed, 3),
+                              "method": f"llama_decode timed on 70B-shaped GGUFs of 2 and 6 layers ({ms[2]:.1f} / {ms[6]:.1f} ms per token); "
+                                        f"token time for {hp70['n_layer']} layers = fixed + n_layer * per-layer (layers alternate the Q4_K_M type mixture with period 2)"}
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -373,6 +472,46 @@ def main():
                     if cb.get("value"):
                         cb["value"] = round(cb["value"], 4)
                     result["cpu_baseline"] = cb
+        win.close()
+        win = None
+        if rank == 0 and world == 1 and not a.no_extras:
+            torch.cuda.empty_cache()
+            extras = []
+            for name in ("llama3-8b", "qwen2.5-72b"):
+                if name == a.model:
+                    continue
+                try:
+                    extras.append(extra_config(name))
+                except Exception as e:
+                    extras.append({"workload": name, "error": str(e)[:300]})
+            result["extra_configs"] = extras
+            path_8b = None
+            try:
+                pd, path_8b = plugin_decode(a.tmp)
+                if pd:
+                    result["plugin_decode"] = pd
+                    result["plugin_decode_tokens_per_s"] = pd["tokens_per_s"]
+            except Exception as e:
+                result["plugin_decode"] = {"error": str(e)[-600:]}
+            if not a.no_cpu_baseline:
+                try:
+                    import prima_cpp_amd.engine as E2
+                    ld = cpu_llama_decode(a.tmp, path_8b, E2.LLAMA3_70B)
+                    if ld and "cpu_baseline" in result:
+                        result["cpu_baseline"]["llama_decode"] = ld
+                        if ld.get("llama3_70b_q4km") and a.model == "llama3-70b":
+                            # the whole-token number through the reference's own driver replaces the mat-vec-only estimate as `value`
+                            result["cpu_baseline"]["matvec_only_tokens_per_s"] = result["cpu_baseline"]["value"]
+                            result["cpu_baseline"]["value"] = ld["llama3_70b_q4km"]["tokens_per_s"]
+                            result["cpu_baseline"]["sample"] = ("reference llama_decode (-ngl 0, unmodified libllama + ggml CPU backend built from /root/reference, "
+                                                                f"{ld['cores']} threads) on Llama-3-70B-shaped Q4_K_M GGUFs of 2 and 6 layers, extrapolated to 80 layers "
+                                                                "(see llama_decode.llama3_70b_q4km.method); matvec_only_tokens_per_s = " + result["cpu_baseline"]["sample"])
+                except Exception as e:
+                    if "cpu_baseline" in result:
+                        result["cpu_baseline"]["llama_decode"] = {"error": str(e)[-600:]}
+            if path_8b and os.path.exists(path_8b):
+                os.unlink(path_8b)
+    if win is not None:
         win.close()
     if world > 1:
         dist.barrier()

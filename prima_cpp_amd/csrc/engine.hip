@@ -285,7 +285,7 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
                                              att, H, Hkv, dh, hp.n_ctx, kq_scale, m->rope, st, nullptr, nullptr,
                                              // with the split path available this kernel only ever sees < split_min cells: its LDS
                                              // score buffer is sized for that, not for n_ctx (long contexts stay launchable)
-                                             m->split_scratch ? m->split_min + 8 : 0))
+                                             (m->split_scratch && m->split_min + 8 < hp.n_ctx) ? m->split_min + 8 : 0))
             return seterr(m, PM355_E_RANGE, "decode: fused attention unsupported for this head_dim / n_ctx");
         {
             const Tensor * w[1] = {&L.t[PM355_T_WO]}; float * y[1] = {x_mid}; const float * r[1] = {cur};

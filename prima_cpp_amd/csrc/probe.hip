@@ -6,7 +6,7 @@
 
 namespace {
 
-template <int UNROLL>
+template <int UNROLL, bool NT = true>
 __global__ __launch_bounds__(1024) void stream_read_kernel(const uint8_t * __restrict__ src, long bytes_per_wave, uint32_t * sink) {
     const int lane = threadIdx.x & 63;
     const long wave = (long) blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -16,7 +16,7 @@ __global__ __launch_bounds__(1024) void stream_read_kernel(const uint8_t * __res
     for (long s = 0; s < steps; ++s) {
         u32x4 v[UNROLL];
 #pragma unroll
-        for (int i = 0; i < UNROLL; ++i) v[i] = ld_nt16(p + (uint32_t) (lane * 16 + i * 1024));
+        for (int i = 0; i < UNROLL; ++i) v[i] = NT ? ld_nt16(p + (uint32_t) (lane * 16 + i * 1024)) : *(const PM_G u32x4 *) (p + (uint32_t) (lane * 16 + i * 1024));
 #pragma unroll
         for (int i = 0; i < UNROLL; ++i) acc ^= v[i];
         p += 1024 * UNROLL;
@@ -31,11 +31,14 @@ __global__ __launch_bounds__(1024) void stream_read_kernel(const uint8_t * __res
 int pm_launch_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, hipStream_t st) {
     hipDeviceProp_t pr; int dev = 0; (void) hipGetDevice(&dev);
     const int cus = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256;
-    const int grid = cus * (wg_per_cu > 0 ? wg_per_cu : 1);
+    const int grid = wg_per_cu < 0 ? -wg_per_cu : cus * (wg_per_cu > 0 ? wg_per_cu : 1);
     const long waves = (long) grid * 16;
     long per_wave = (long) (bytes / waves);
     per_wave -= per_wave % (1024 * 8);
     if (per_wave <= 0) return -1;
+    // unroll < 0: |unroll| = 8 default-policy (cached) loads instead of non-temporal ones (prefetch experiments: does a plain read leave
+    // the lines in the infinity cache for a later nt read?); wg_per_cu < 0: -wg_per_cu workgroups in TOTAL (a partial grid)
+    if (unroll < 0) { hipLaunchKernelGGL((stream_read_kernel<8, false>), dim3(grid), dim3(1024), 0, st, (const uint8_t *) src, per_wave, (uint32_t *) sink); return 0; }
     if (unroll == 4) hipLaunchKernelGGL(stream_read_kernel<4>, dim3(grid), dim3(1024), 0, st, (const uint8_t *) src, per_wave, (uint32_t *) sink);
     else             hipLaunchKernelGGL(stream_read_kernel<8>, dim3(grid), dim3(1024), 0, st, (const uint8_t *) src, per_wave, (uint32_t *) sink);
     return 0;
