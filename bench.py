@@ -387,7 +387,13 @@ def main():
         win.finalize(max_tokens=1, n_seq=world)
         use_graph = not a.no_graph
         comp = EngineCompute(win, world, use_graph=use_graph)
-        drv = RingDriver(comp, rank, world)
+        # N > 1 over RCCL: the transport is the C one (pm355_ring_*: ncclSend / ncclRecv on the library's communication stream, event
+        # hand-off, no host wait per micro-step); PM355_RING_TRANSPORT=torch keeps torch.distributed's batch_isend_irecv instead
+        c_ring = None
+        if world > 1 and os.environ.get("PM355_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("PM355_RING_TRANSPORT", "c") == "c":
+            from prima_cpp_amd.ring import CRing
+            c_ring = CRing(rank, world)
+        drv = RingDriver(comp, rank, world, c_ring=c_ring)
         rng = np.random.default_rng(1234)
         prompt = rng.integers(0, hp["n_vocab"], size=(world, a.prompt))
         prompt[:, 0] = 128000 % hp["n_vocab"]            # BOS first, like llama-bench
@@ -442,7 +448,7 @@ def main():
                 "config": {"workload": f"{model_name} batch-1 greedy decode, {a.prompt}-token synthetic prompt, "
                                        f"{world} sequence(s) in flight, n_ctx {a.n_ctx}, F16 KV cache",
                            "parallelism": "single GPU" if world == 1 else f"piped-ring layer split pp{world} "
-                                          f"(windows {wins}), RCCL send/recv",
+                                          f"(windows {wins}), RCCL send/recv ({'C transport pm355_ring_*: comm stream + events, no host wait' if c_ring else 'torch.distributed'})",
                            "weights_bytes_per_token": total_w, "kv_bytes_per_token_mid_run": kv_b,
                            "hip_graph": use_graph},
                 "hbm_roofline_tokens_per_s": round(HBM_PEAK_GBS * 1e9 / total_w * world, 2),
@@ -513,6 +519,9 @@ def main():
                 os.unlink(path_8b)
     if win is not None:
         win.close()
+    if c_ring is not None:
+        torch.cuda.synchronize()
+        c_ring.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -314,6 +314,30 @@ PM355_API int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, cons
 PM355_API int pm355_model_step(pm355_model * m, const int32_t * d_token, const float * d_x_in, float * d_x_out,
                                float * d_logits, int32_t * d_argmax, int advance, int use_graph, pm355_stream_t stream);
 
+/* ---- (C) piped-ring transport over RCCL (prima_cpp_amd/csrc/ring.hip) ---------------------------------------------------
+ * Replaces llama_send_tensors / llama_recv_tensors (src/llama.cpp:18031-18077, ZeroMQ) and the D2H / H2D bounce of the ring loop
+ * (src/llama.cpp:18503-18564): one rank per GPU, activations handed neighbour to neighbour with ncclSend / ncclRecv on a dedicated
+ * communication stream, event hand-off to the compute stream, no host wait per micro-step. RCCL is dlopen()ed on first use. */
+typedef struct pm355_ring pm355_ring;
+PM355_API const char * pm355_ring_error(void);
+/* rank 0: 128-byte RCCL unique id (ncclGetUniqueId) to be distributed to the other ranks by the launcher */
+PM355_API int pm355_ring_unique_id(void * id128);
+/* ncclCommInitRank on the current device + communication stream + events; NULL on failure (pm355_ring_error) */
+PM355_API pm355_ring * pm355_ring_init(const void * id128, int rank, int world);
+PM355_API void pm355_ring_free(pm355_ring * r);
+PM355_API int pm355_ring_rank(const pm355_ring * r);
+PM355_API int pm355_ring_world(const pm355_ring * r);
+/* ncclGroupStart; ncclSend(send -> next rank); ncclRecv(recv <- previous rank); ncclGroupEnd on the communication stream, after
+ * everything enqueued so far on compute_stream. send / recv: n f32 each, either may be NULL. Asynchronous. */
+PM355_API int pm355_ring_exchange(pm355_ring * r, const float * send, float * recv, int64_t n, pm355_stream_t compute_stream);
+/* compute_stream waits ON THE DEVICE for the last exchange (its input has arrived, the previous send buffer is free again) */
+PM355_API int pm355_ring_wait(pm355_ring * r, pm355_stream_t compute_stream);
+/* one micro-step of a rank = body of the reference's ring loop: pm355_ring_wait -> pm355_model_step_ex -> pm355_ring_exchange
+ * {send x_out to the next rank when do_send, receive the NEXT micro-step's input into recv_next when non-NULL} */
+PM355_API int pm355_ring_step(pm355_ring * r, pm355_model * m, const int32_t * d_token, const float * x_in, float * x_out,
+                              float * d_logits, int32_t * d_argmax, int advance, int rotate, int head_first, int use_graph,
+                              int do_send, float * recv_next, int64_t n_embd, pm355_stream_t compute_stream);
+
 #ifdef __cplusplus
 }
 #endif

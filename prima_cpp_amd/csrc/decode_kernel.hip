@@ -74,7 +74,7 @@ __global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void decode_window_kernel(const P
     const unsigned G = gridDim.x, NG = (G % 16 == 0) ? 16 : 1;
     for (int ph = 0; ph < n_phases; ++ph) {
         const Phase & P = phases[ph];
-        const GridBar bar = {ctr, err, (unsigned) ph, NG, G / NG};
+        const GridBar bar = {ctr, err, (unsigned) ph, NG, G / NG, ph == n_phases - 1 ? 1u : 0u};
         if (P.kind == PH_GEMV) {
             switch (P.combo) {
                 case C_44:  phase_gemv<PM_Q4_K, PM_Q4_K, false>(&P.g, ctr, err, (unsigned) ph, NG); break;
@@ -173,7 +173,7 @@ int pm_decode_plan_finish(pm_decode_plan * pl) {
 
 int pm_decode_plan_launch(pm_decode_plan * pl, hipStream_t st) {
     if (!pl->dev) return -1;
-    if (hipMemsetAsync(pl->ctr, 0, PM_BAR_BYTES, st) != hipSuccess) return -2;     // barrier counters (the watchdog flag behind them is sticky)
+    // (no memset node: the last arriver of the final phase zeroes the barrier state again - grid_arrive; the buffer starts zeroed)
     hipLaunchKernelGGL(decode_window_kernel, dim3(pl->grid), dim3(PM_GEMV_BLOCK), pl->lds, st,
                        (const Phase *) pl->dev, (int) pl->host.size(), pl->ctr, (int *) (pl->ctr + PM_BAR_BYTES / 4));
     return 0;

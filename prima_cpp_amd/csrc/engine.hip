@@ -45,6 +45,11 @@ struct pm355_model {
     // 8.6 ms per 70B token for the 5-launch path): one plan per distinct (input, output, logits) pointer set; plans live as
     // long as the model (captured graphs reference their device tables).
     bool persistent = false;
+    // EXPERIMENT (PM355_ATTN_WO=1, attn_wo.hip): attention + wo as ONE two-phase launch per layer - every workgroup first puts its wo
+    // weight loads in flight, the 64 head workgroups run the latency-bound attention meanwhile, one device-wide barrier, then the wo
+    // mat-vec: 4 launches per layer instead of 5. Bit-identical, but the barrier + first-touch fetch of the heads' outputs costs what
+    // the launch boundary cost: 8.74 vs 8.60 ms per Llama-3-70B token, 1.72 vs 1.66 ms per 8B token
+    bool attn_wo = false; void * aw_ctr = nullptr;       // barrier state of that kernel (zero between launches) + watchdog flag
     struct Plan { const void * in; void * out, * lg; bool head; pm_decode_plan * pl; };
     std::vector<Plan> plans;
     // long-context decode attention (attn_split.hip): the host mirrors the device position counters to choose, per step, between
@@ -273,7 +278,17 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
             }
         }
         const long kvs = (long) hp.n_ctx * Hkv * dh;
-        if (m->rec) {
+        bool aw_done = false;
+        if (!m->rec && m->attn_wo && m->aw_ctr && !m->long_ctx) {
+            const Tensor & wo = L.t[PM355_T_WO];
+            pm_gemv_fused f = {};
+            f.K = (int) wo.K; f.njobs = 1; f.xf = att; f.eps = hp.rms_eps;
+            f.job[0].type = wo.type; f.job[0].N = (int) wo.N; f.job[0].W = wo.d; f.job[0].y = x_mid; f.job[0].resid = cur;
+            aw_done = pm_launch_attn_wo(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d, att, H, Hkv, dh,
+                                        hp.n_ctx, kq_scale, m->rope, f, m->aw_ctr, st) == 0;
+        }
+        if (aw_done) {
+        } else if (m->rec) {
             if (pm_decode_plan_add_attn(m->rec, q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d,
                                         att, H, Hkv, dh, hp.n_ctx, kq_scale, m->rope)) return -1;
         } else if (m->long_ctx) {
@@ -287,7 +302,7 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
                                              // score buffer is sized for that, not for n_ctx (long contexts stay launchable)
                                              (m->split_scratch && m->split_min + 8 < hp.n_ctx) ? m->split_min + 8 : 0))
             return seterr(m, PM355_E_RANGE, "decode: fused attention unsupported for this head_dim / n_ctx");
-        {
+        if (!aw_done) {
             const Tensor * w[1] = {&L.t[PM355_T_WO]}; float * y[1] = {x_mid}; const float * r[1] = {cur};
             if (gemv_f32(m, w, nullptr, y, nullptr, r, 1, att, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused wo gemv");
         }
@@ -471,6 +486,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     pm_rope_params(m->rope);
     { const char * e = getenv("PM355_NO_FUSE"); m->no_fuse = e && e[0] == '1'; }
     { const char * e = getenv("PM355_PERSISTENT"); m->persistent = e && e[0] == '1'; }
+    { const char * e = getenv("PM355_ATTN_WO"); m->attn_wo = e && e[0] == '1'; }       // measured: 8.74 vs 8.60 ms per 70B token -> opt-in experiment
     return m;
 }
 
@@ -479,6 +495,7 @@ void pm355_model_free(pm355_model * m) {
     (void) hipDeviceSynchronize();
     for (auto & g : m->graphs) (void) hipGraphExecDestroy(g.exec);
     for (auto & pl : m->plans) pm_decode_plan_free(pl.pl);
+    if (m->aw_ctr) (void) hipFree(m->aw_ctr);
     if (m->slab) (void) hipFree(m->slab);
     for (auto & L : m->layers) { for (auto & t : L.t) if (t.d) (void) hipFree(t.d); if (L.kc) (void) hipFree(L.kc); if (L.vc) (void) hipFree(L.vc); }
     Tensor * g[4] = {&m->tok_embd, &m->out_norm, &m->output, &m->rope_freqs};
@@ -584,6 +601,10 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
     if (!ok) return seterr(m, PM355_E_NOMEM, "finalize: scratch");
     if (hp.n_head / hp.n_head_kv <= 8 && (hp.head_dim == 64 || hp.head_dim == 128) &&
         !A((void **) &m->split_scratch, pm_attn_split_scratch_floats(hp.n_head, hp.head_dim, hp.n_ctx) * 4)) return seterr(m, PM355_E_NOMEM, "finalize: attention scratch");
+    if (m->attn_wo && !m->aw_ctr) {
+        if (hipMalloc(&m->aw_ctr, pm_attn_wo_bar_bytes()) != hipSuccess) m->aw_ctr = nullptr;
+        else (void) hipMemset(m->aw_ctr, 0, pm_attn_wo_bar_bytes());
+    }
     m->h_pos.assign(n_seq, 0); m->h_seq = 0;
     { const char * e = getenv("PM355_ATTN_SPLIT_MIN"); if (e && e[0]) m->split_min = atoi(e); }
     (void) hipMemset(m->d_pos, 0, 64 * 4);
@@ -743,6 +764,11 @@ int pm355_model_check(pm355_model * m) {
     if (!m) return PM355_E_SHAPE;
     (void) hipDeviceSynchronize();
     for (auto & p : m->plans) if (pm_decode_plan_error(p.pl)) return seterr(m, PM355_E_HIP, "persistent decode kernel: device-wide barrier timed out");
+    if (m->aw_ctr) {
+        int e = 0;
+        if (hipMemcpy(&e, (char *) m->aw_ctr + pm_attn_wo_bar_bytes() - 64, 4, hipMemcpyDeviceToHost) == hipSuccess && e)
+            return seterr(m, PM355_E_HIP, "attention + wo kernel: device-wide barrier timed out");
+    }
     return 0;
 }
 

@@ -584,7 +584,7 @@ __device__ __forceinline__ void write_out(const GemvJob & jb, const float * outb
 // publishes the phase number in every group's release flag; a workgroup polls only its own group's flag (16 pollers per
 // line - 256 pollers on the counter line starved the arriving atomics: 10 us per barrier, measured). All values are
 // monotonic within a launch (reset by a memset node before the kernel).
-struct GridBar { unsigned * ctr; int * err; unsigned phase, ngroups, gsize; };
+struct GridBar { unsigned * ctr; int * err; unsigned phase, ngroups, gsize; unsigned last = 0; };   // last: final phase of the launch
 __device__ __forceinline__ void grid_wait(const GridBar & gb) {
 #ifdef PM_EXP_NOBAR
     if (false) {
@@ -608,9 +608,20 @@ __device__ __forceinline__ void grid_arrive(const GridBar & gb) {
         const unsigned old = __hip_atomic_fetch_add((PM_G unsigned *) g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((old + 1) % gb.gsize == 0) {                               // last workgroup of this group for this phase
             const unsigned t = __hip_atomic_fetch_add((PM_G unsigned *) gb.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t + 1 == gb.ngroups * (gb.phase + 1))                  // last group: release everybody
-                for (unsigned k = 0; k < gb.ngroups; ++k)
-                    __hip_atomic_store((PM_G unsigned *) (gb.ctr + 32 * (17 + k)), gb.phase + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t + 1 == gb.ngroups * (gb.phase + 1)) {                // last group
+                if (gb.last) {
+                    // final phase: nobody waits any more and every workgroup has arrived -> put the barrier state back to zero, so
+                    // the next launch of this plan needs no memset node in front of it (a graph node costs ~1.7 us)
+                    __hip_atomic_store((PM_G unsigned *) gb.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (unsigned k = 0; k < gb.ngroups; ++k) {
+                        __hip_atomic_store((PM_G unsigned *) (gb.ctr + 32 * (1 + k)), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store((PM_G unsigned *) (gb.ctr + 32 * (17 + k)), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else {                                               // release everybody
+                    for (unsigned k = 0; k < gb.ngroups; ++k)
+                        __hip_atomic_store((PM_G unsigned *) (gb.ctr + 32 * (17 + k)), gb.phase + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
 }

@@ -83,3 +83,8 @@ int  pm_decode_plan_finish(pm_decode_plan * pl);                                
 int  pm_decode_plan_launch(pm_decode_plan * pl, hipStream_t st);                     // counter reset + one kernel
 int  pm_decode_plan_error(pm_decode_plan * pl);                                      // watchdog flag (synchronizes)
 int  pm_decode_plan_add_nop(pm_decode_plan * pl, int n);                             // measurement: n empty phases (barriers only)
+// attention + wo mat-vec (+ residual) of one layer as ONE two-phase launch (decode_kernel.hip); -1: no kernel for this shape / type
+int  pm_launch_attn_wo(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos0, const int32_t * seq,
+                       long seq_stride, const float * freq_factors, float * att, int H, int Hkv, int dh, int n_ctx, float scale,
+                       const pm_rope_cfg & c, const pm_gemv_fused & f, void * ctr, hipStream_t st);
+size_t pm_attn_wo_bar_bytes();

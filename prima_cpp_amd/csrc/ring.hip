@@ -1,0 +1,165 @@
+// ring.hip — the piped-ring transport in C over RCCL (C ABI part (C) of include/prima_mi355.h).
+//
+// Replaces llama_send_tensors / llama_recv_tensors (src/llama.cpp:18031-18077: ZeroMQ multipart messages carrying the window's
+// output activation + positions) and the D2H / H2D bounce around them in llama_decode_internal's ring loop
+// (src/llama.cpp:18503-18564, :17306-17310). One rank per MI355X; the activation row(s) stay in HBM and travel neighbour to
+// neighbour with ncclSend / ncclRecv over xGMI. Per micro-step ONE grouped exchange (ncclGroupStart ... ncclGroupEnd: send this
+// step's output to the next rank, receive the next step's input from the previous rank) is enqueued on a dedicated communication
+// stream; compute stream and communication stream hand over with HIP events, so the host never waits inside the token loop.
+//
+// RCCL is resolved at run time (dlopen("librccl.so.1")): the library keeps loading on machines without RCCL, and inside a PyTorch
+// process the loader hands back the copy torch already mapped (same SONAME), never a second one.
+#include "../../include/prima_mi355.h"
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+
+// the slice of rccl.h this file needs (rccl/rccl.h:40-43, :187, :220, :260, :339, :700, :722, :923, :933)
+typedef struct ncclComm * ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+enum { ncclSuccess = 0 };
+enum { ncclFloat32 = 7 };
+struct Rccl {
+    void * h = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    const char * (*GetErrorString)(int) = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    bool ok = false;
+};
+Rccl & rccl() {
+    static Rccl r;
+    if (r.h) return r;
+    for (const char * name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.h) break;
+    }
+    if (!r.h) return r;
+    r.GetUniqueId = (decltype(r.GetUniqueId)) dlsym(r.h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank)) dlsym(r.h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy)) dlsym(r.h, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString)) dlsym(r.h, "ncclGetErrorString");
+    r.Send = (decltype(r.Send)) dlsym(r.h, "ncclSend");
+    r.Recv = (decltype(r.Recv)) dlsym(r.h, "ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart)) dlsym(r.h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd)) dlsym(r.h, "ncclGroupEnd");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Send && r.Recv && r.GroupStart && r.GroupEnd;
+    return r;
+}
+
+thread_local char g_ring_err[256] = "";
+int rfail(int code, const char * what, int nccl_rc = 0) {
+    Rccl & R = rccl();
+    snprintf(g_ring_err, sizeof(g_ring_err), "%s%s%s", what, nccl_rc ? ": " : "", nccl_rc && R.GetErrorString ? R.GetErrorString(nccl_rc) : "");
+    return code;
+}
+
+} // namespace
+
+struct pm355_ring {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, next = 0, prev = 0;
+    hipStream_t cs = nullptr;                 // communication stream
+    hipEvent_t ready = nullptr;               // compute -> comm: the buffer to send is complete
+    hipEvent_t done = nullptr;                // comm -> compute: the exchange (send left, input arrived) is complete
+    bool pending = false;                     // an exchange was enqueued since the last wait
+};
+
+extern "C" {
+
+const char * pm355_ring_error(void) { return g_ring_err; }
+
+int pm355_ring_unique_id(void * id128) {
+    Rccl & R = rccl();
+    if (!R.ok) return rfail(PM355_E_UNSUPPORTED, "ring: librccl.so.1 not found or incomplete");
+    ncclUniqueId id;
+    const int rc = R.GetUniqueId(&id);
+    if (rc != ncclSuccess) return rfail(PM355_E_HIP, "ncclGetUniqueId", rc);
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+pm355_ring * pm355_ring_init(const void * id128, int rank, int world) {
+    Rccl & R = rccl();
+    if (!R.ok) { rfail(PM355_E_UNSUPPORTED, "ring: librccl.so.1 not found or incomplete"); return nullptr; }
+    if (!id128 || world < 1 || rank < 0 || rank >= world) { rfail(PM355_E_RANGE, "ring_init: rank / world"); return nullptr; }
+    pm355_ring * r = new pm355_ring();
+    r->rank = rank; r->world = world; r->next = (rank + 1) % world; r->prev = (rank + world - 1) % world;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    const int rc = R.CommInitRank(&r->comm, world, id, rank);
+    if (rc != ncclSuccess) { rfail(PM355_E_HIP, "ncclCommInitRank", rc); delete r; return nullptr; }
+    if (hipStreamCreateWithFlags(&r->cs, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->done, hipEventDisableTiming) != hipSuccess) {
+        rfail(PM355_E_HIP, "ring_init: stream / events");
+        pm355_ring_free(r);
+        return nullptr;
+    }
+    return r;
+}
+
+void pm355_ring_free(pm355_ring * r) {
+    if (!r) return;
+    if (r->cs) { (void) hipStreamSynchronize(r->cs); }
+    if (r->comm) (void) rccl().CommDestroy(r->comm);
+    if (r->cs) (void) hipStreamDestroy(r->cs);
+    if (r->ready) (void) hipEventDestroy(r->ready);
+    if (r->done) (void) hipEventDestroy(r->done);
+    delete r;
+}
+
+// One grouped exchange on the communication stream: send `send` (n floats, may be NULL) to the next rank and receive `recv`
+// (n floats, may be NULL) from the previous rank. The communication stream first waits for everything enqueued so far on
+// `compute_stream` (the producer of `send`); the completion is published through an event that pm355_ring_wait hands to the
+// compute stream. Nothing here blocks the host.
+int pm355_ring_exchange(pm355_ring * r, const float * send, float * recv, int64_t n, pm355_stream_t compute_stream) {
+    Rccl & R = rccl();
+    if (!r || !R.ok) return rfail(PM355_E_SHAPE, "ring_exchange: no ring");
+    if (!send && !recv) return 0;
+    hipStream_t st = (hipStream_t) compute_stream;
+    if (hipEventRecord(r->ready, st) != hipSuccess || hipStreamWaitEvent(r->cs, r->ready, 0) != hipSuccess) return rfail(PM355_E_HIP, "ring_exchange: event hand-off");
+    int rc = R.GroupStart();
+    if (rc == ncclSuccess && send) rc = R.Send(send, (size_t) n, ncclFloat32, r->next, r->comm, r->cs);
+    if (rc == ncclSuccess && recv) rc = R.Recv(recv, (size_t) n, ncclFloat32, r->prev, r->comm, r->cs);
+    const int rc2 = R.GroupEnd();
+    if (rc != ncclSuccess || rc2 != ncclSuccess) return rfail(PM355_E_HIP, "ring_exchange: ncclSend / ncclRecv", rc != ncclSuccess ? rc : rc2);
+    if (hipEventRecord(r->done, r->cs) != hipSuccess) return rfail(PM355_E_HIP, "ring_exchange: event record");
+    r->pending = true;
+    return 0;
+}
+
+// The compute stream waits (on the device) for the last exchange: the previous send has left its buffer, the input has arrived.
+int pm355_ring_wait(pm355_ring * r, pm355_stream_t compute_stream) {
+    if (!r) return rfail(PM355_E_SHAPE, "ring_wait: no ring");
+    if (!r->pending) return 0;
+    if (hipStreamWaitEvent((hipStream_t) compute_stream, r->done, 0) != hipSuccess) return rfail(PM355_E_HIP, "ring_wait");
+    r->pending = false;
+    return 0;
+}
+
+// One micro-step of a rank in the body of the reference's ring loop (src/llama.cpp:18503-18564), all enqueued, no host wait:
+//   wait for the previous exchange (this step's input) -> window step (pm355_model_step_ex: [head on x_in] -> embed -> layers) ->
+//   grouped exchange {send x_out to the next rank, receive the NEXT step's input into recv_next}.
+// x_in may be NULL (rank 0 while the pipeline fills / forced tokens); send / recv_next NULL = nothing to send / receive.
+int pm355_ring_step(pm355_ring * r, pm355_model * m, const int32_t * d_token, const float * x_in, float * x_out, float * d_logits,
+                    int32_t * d_argmax, int advance, int rotate, int head_first, int use_graph, int do_send, float * recv_next,
+                    int64_t n_embd, pm355_stream_t compute_stream) {
+    int rc = pm355_ring_wait(r, compute_stream);
+    if (rc) return rc;
+    rc = pm355_model_step_ex(m, d_token, x_in, x_out, d_logits, d_argmax, advance, rotate, head_first, use_graph, compute_stream);
+    if (rc) return rfail(rc, pm355_model_error(m));
+    return pm355_ring_exchange(r, do_send ? x_out : nullptr, recv_next, n_embd, compute_stream);
+}
+
+int pm355_ring_rank(const pm355_ring * r) { return r ? r->rank : -1; }
+int pm355_ring_world(const pm355_ring * r) { return r ? r->world : 0; }
+
+} // extern "C"

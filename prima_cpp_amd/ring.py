@@ -67,8 +67,12 @@ class RingDriver:
     next == previous) and the NCCL per-communicator ordering deadlock-free; a rank sends at micro-step m iff
     it is active (m >= rank) and its successor receives for m+1 under exactly the same condition."""
 
-    def __init__(self, compute, rank, world, group=None):
+    def __init__(self, compute, rank, world, group=None, c_ring=None):
+        """c_ring: a prima_cpp_amd.ring.CRing (RCCL transport in C, pm355_ring_* of include/prima_mi355.h): the exchange is enqueued
+        on the library's communication stream with event hand-off and the host never waits; without it the exchange goes through
+        torch.distributed (gloo in the CPU tests) and the host waits for the requests at the start of the next micro-step."""
         self.c, self.rank, self.world, self.group = compute, rank, world, group
+        self.c_ring = c_ring if world > 1 else None
         self.nxt, self.prv = (rank + 1) % world, (rank - 1) % world
         # receive buffers alternate so the receive for m+1 never targets the buffer micro-step m reads
         self.x_in = [torch.empty((1, compute.n_embd), dtype=torch.float32, device=compute.device) for _ in range(2)]
@@ -78,7 +82,7 @@ class RingDriver:
         # gloo has no device-memory send/recv: when the transport is gloo and the buffers live on a GPU (single-GPU
         # tests only), stage through pinned host tensors. With nccl (= RCCL) the device buffers go on the wire directly.
         dev_is_gpu = torch.device(compute.device).type == "cuda"
-        self.host_stage = world > 1 and dev_is_gpu and dist.get_backend(group) == "gloo"
+        self.host_stage = world > 1 and dev_is_gpu and self.c_ring is None and dist.get_backend(group) == "gloo"
         if self.host_stage:
             self.h_in = [torch.empty((1, compute.n_embd), dtype=torch.float32).pin_memory() for _ in range(2)]
             self.h_out = [torch.empty((1, compute.n_embd), dtype=torch.float32).pin_memory() for _ in range(2)]
@@ -90,6 +94,9 @@ class RingDriver:
         return m >= self.world if self.rank == 0 else m >= self.rank
 
     def _wait(self):
+        if self.c_ring is not None:
+            self.c_ring.wait()                        # device-side: the compute stream waits for the exchange's event
+            return
         for q in self.reqs:
             q.wait()
         self.reqs = []
@@ -111,7 +118,10 @@ class RingDriver:
                     x_in.copy_(self.h_in[m & 1], non_blocking=False)
             out = self.c.first_rank_step(seq, x_in, forced_token) if r == 0 else self.c.rank_step(seq, x_in)
             self.last_out = out
-        if W > 1:
+        if W > 1 and self.c_ring is not None:
+            rcv = self.x_in[(m + 1) & 1] if self._need_recv(m + 1) else None
+            self.c_ring.exchange(out if active else None, rcv)       # ncclGroupStart; ncclSend; ncclRecv; ncclGroupEnd on the comm stream
+        elif W > 1:
             ops = []
             if active:
                 snd = out
@@ -131,6 +141,54 @@ class RingDriver:
         """After the last micro-step: the receive posted for the never-executed next micro-step absorbs the
         predecessor's final send, so every send has been matched; wait for both."""
         self._wait()
+
+
+class CRing:
+    """RCCL transport in C (prima_cpp_amd/csrc/ring.hip). The 128-byte unique id is created on rank 0 and handed to the other
+    ranks by the launcher - here through the already initialised torch.distributed group (process launch is all Python keeps)."""
+
+    def __init__(self, rank, world, group=None):
+        import ctypes as C
+        from . import lib as L
+        self.lib = L.load()
+        self.lib.pm355_ring_init.restype = C.c_void_p
+        self.lib.pm355_ring_init.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self.lib.pm355_ring_free.argtypes = [C.c_void_p]
+        self.lib.pm355_ring_error.restype = C.c_char_p
+        self.lib.pm355_ring_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        self.lib.pm355_ring_wait.argtypes = [C.c_void_p, C.c_void_p]
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            rc = self.lib.pm355_ring_unique_id(buf)
+            if rc:
+                raise L.PM355Error(f"pm355_ring_unique_id rc={rc}: {self.lib.pm355_ring_error().decode()}")
+            ident[0] = bytes(buf.raw)
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0, group=group)
+        self.h = self.lib.pm355_ring_init(ident[0], rank, world)
+        if not self.h:
+            raise L.PM355Error(f"pm355_ring_init failed: {self.lib.pm355_ring_error().decode()}")
+        self.rank, self.world = rank, world
+
+    def _chk(self, rc, what):
+        if rc:
+            from . import lib as L
+            raise L.PM355Error(f"{what} rc={rc}: {self.lib.pm355_ring_error().decode()}")
+
+    def exchange(self, send, recv):
+        n = (send if send is not None else recv).numel() if (send is not None or recv is not None) else 0
+        st = torch.cuda.current_stream().cuda_stream
+        self._chk(self.lib.pm355_ring_exchange(self.h, send.data_ptr() if send is not None else None,
+                                               recv.data_ptr() if recv is not None else None, n, st), "pm355_ring_exchange")
+
+    def wait(self):
+        self._chk(self.lib.pm355_ring_wait(self.h, torch.cuda.current_stream().cuda_stream), "pm355_ring_wait")
+
+    def close(self):
+        if self.h:
+            self.lib.pm355_ring_free(self.h)
+            self.h = None
 
 
 class EngineCompute(RankCompute):

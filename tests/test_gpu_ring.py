@@ -95,3 +95,64 @@ def test_two_rank_ring_matches_single_window():
         torch.cuda.synchronize()
         assert got[s][:n_rounds] == io.cpu().numpy()[1:].tolist(), (s, got[s], io.cpu().numpy())
     w.close()
+
+
+def test_c_ring_transport_world1_self_send():
+    """The RCCL transport in C (pm355_ring_*, prima_cpp_amd/csrc/ring.hip) with world size 1: rank 0's next and previous rank are
+    itself, so one grouped ncclSend + ncclRecv moves a buffer through the communicator; then whole micro-steps through
+    pm355_ring_step (wait -> window step -> exchange) against plain engine steps. Multi-rank RCCL needs one GPU per rank (the
+    driver's --gpus N run); the staggered schedule itself is covered by the gloo tests."""
+    import ctypes as C
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    sys.path.insert(0, ROOT)
+    from _bind import tiny_model
+    import prima_cpp_amd.engine as E
+    from prima_cpp_amd.ring import CRing
+    E.torch = torch
+    ring = CRing(0, 1)
+    a = torch.randn(1, 4096, device="cuda")
+    b = torch.zeros_like(a)
+    ring.exchange(a, b)
+    ring.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    # micro-steps: x_out of step i is sent to "the next rank" (= this rank) and arrives as the input buffer of step i + 1
+    rng = np.random.default_rng(11)
+    d = tiny_model(rng, arch=0, n_layer=2, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=320, n_ctx=64, rope_freqs=True)
+    hp = dict(arch=d.arch, n_layer=d.n_layer, n_embd=d.n_embd, n_head=d.n_head, n_head_kv=d.n_head_kv, head_dim=d.head_dim,
+              n_ff=d.n_ff, n_vocab=d.n_vocab, rms_eps=d.rms_eps, rope_freq_base=d.rope_freq_base)
+    outs = []
+    for use_ring in (False, True):
+        w = E.Window(hp, n_ctx=64)
+        w.load_desc(d)
+        w.finalize(max_tokens=1)
+        w.set_pos(0)
+        tok = torch.tensor([5], dtype=torch.int32, device="cuda")
+        x_out = [torch.zeros(1, d.n_embd, device="cuda") for _ in range(2)]
+        x_in = [torch.zeros(1, d.n_embd, device="cuda") for _ in range(2)]
+        am = torch.zeros(1, dtype=torch.int32, device="cuda")
+        lib = w.lib
+        lib.pm355_ring_step.restype = C.c_int
+        lib.pm355_ring_step.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p, C.c_int64, C.c_void_p]
+        res = []
+        for i in range(6):
+            st = torch.cuda.current_stream().cuda_stream
+            if use_ring:
+                rc = lib.pm355_ring_step(ring.h, w.h, tok.data_ptr(), None, x_out[i & 1].data_ptr(), None, am.data_ptr(), 1, 0, 0, 1,
+                                         1, x_in[(i + 1) & 1].data_ptr(), d.n_embd, st)
+                assert rc == 0, lib.pm355_ring_error()
+                ring.wait()
+                torch.cuda.synchronize()
+                assert torch.equal(x_in[(i + 1) & 1], x_out[i & 1])          # what was sent is what arrived
+            else:
+                w.step(token=tok, x_out=x_out[i & 1], argmax=am, advance=1)
+                torch.cuda.synchronize()
+            res.append((x_out[i & 1].cpu().numpy().copy(), int(am.item())))
+            tok.copy_(am)
+        outs.append(res)
+        w.close()
+    for (h0, t0), (h1, t1) in zip(*outs):
+        assert t0 == t1 and np.array_equal(h0, h1)
+    ring.close()
