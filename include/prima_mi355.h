@@ -237,6 +237,10 @@ PM355_API int pm355_op_rms_norm(const pm355_tensor * a, const pm355_tensor * dst
 /* ggml_compute_forward_soft_max_f32 (ggml.c:13783): mask F32/F16 [ne0, >= ne1] or NULL */
 PM355_API int pm355_op_soft_max(const pm355_tensor * a, const pm355_tensor * mask, const pm355_tensor * dst, float scale,
                                 float max_bias, pm355_stream_t stream);
+/* ggml_compute_forward_flash_attn_ext_f16 (ggml.c:15538): q F32 [D, N, H], k / v F16 [D, n_kv, Hkv] (V not transposed), mask F16
+ * [n_kv, >= N] or NULL, dst F32 [D, H, N]; scale, ALiBi max_bias, logit softcap as in ggml_flash_attn_ext (ggml.h:1757) */
+PM355_API int pm355_op_flash_attn_ext(const pm355_tensor * q, const pm355_tensor * k, const pm355_tensor * v, const pm355_tensor * mask,
+                                      const pm355_tensor * dst, float scale, float max_bias, float logit_softcap, pm355_stream_t stream);
 PM355_API int pm355_op_rope(const pm355_tensor * a, const int32_t * d_pos, const float * freq_factors, const pm355_tensor * dst,
                             const pm355_rope_params * rp, pm355_stream_t stream);
 /* MUL_MAT with F16 / F32 src0 (the K.q and V.p products of llm_build_kqv): src1 F32 rounded to F16 when src0 is F16 */

@@ -295,6 +295,15 @@ bool supports_op_impl(const struct ggml_tensor * op) {
             const int mode = ((const int32_t *) op->op_params)[2];
             return a->type == GGML_TYPE_F32 && (mode == 0 || mode == 2) && a->ne[0] % 2 == 0;
         }
+        case GGML_OP_FLASH_ATTN_EXT: {
+            // F16 K / V (the default KV cache type); quantized KV caches stay on the CPU backend
+            const struct ggml_tensor * k = op->src[1], * v = op->src[2], * m = op->src[3];
+            const int64_t D = a->ne[0];
+            if (a->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16 || op->type != GGML_TYPE_F32) return false;
+            if (D < 8 || D > 256 || a->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || (m && m->type != GGML_TYPE_F16)) return false;
+            const int64_t Dp = (D + 7) & ~7;
+            return (size_t) (Dp + ((k->ne[1] + 3) & ~3) + (256 / (Dp / 8)) * Dp) * 4 <= 150 * 1024;     // scores of one query live in LDS
+        }
         case GGML_OP_GET_ROWS:
             return b->type == GGML_TYPE_I32 && ggml_is_contiguous(b) && b->ne[1] == 1 && b->ne[2] == 1 && b->ne[3] == 1 &&
                    (a->type == GGML_TYPE_F32 || (is_gemv_type(a->type) && ggml_is_contiguous(a) && a->ne[2] == 1 && a->ne[3] == 1 && !a->view_src));
@@ -374,6 +383,15 @@ bool compute_node(backend_ctx * c, struct ggml_tensor * op) {
             pm355_tensor ta = to_pm(a), td = to_pm(op);
             const struct ggml_tensor * ff = op->src[2];
             MI355_CHECK(pm355_op_rope(&ta, (const int32_t *) b->data, ff ? (const float *) ff->data : nullptr, &td, &rp, st));
+            return true;
+        }
+        case GGML_OP_FLASH_ATTN_EXT: {
+            float scale, max_bias, softcap;
+            memcpy(&scale, (const float *) op->op_params + 0, 4); memcpy(&max_bias, (const float *) op->op_params + 1, 4);
+            memcpy(&softcap, (const float *) op->op_params + 2, 4);
+            pm355_tensor tq = to_pm(a), tk = to_pm(op->src[1]), tv = to_pm(op->src[2]), td = to_pm(op), tm;
+            if (op->src[3]) tm = to_pm(op->src[3]);
+            MI355_CHECK(pm355_op_flash_attn_ext(&tq, &tk, &tv, op->src[3] ? &tm : nullptr, &td, scale, max_bias, softcap, st));
             return true;
         }
         case GGML_OP_GET_ROWS: {

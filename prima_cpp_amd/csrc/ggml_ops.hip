@@ -185,6 +185,87 @@ __global__ void get_rows_f32_kernel(TD a, const int32_t * idx, long n_idx, TD d)
 #define GRID(n) dim3((unsigned) (((n) + 255) / 256)), dim3(256)
 #define OKRET() do { return hipGetLastError() == hipSuccess ? PM355_OK : PM355_E_HIP; } while (0)
 
+
+// ---- GGML_OP_FLASH_ATTN_EXT (ggml_compute_forward_flash_attn_ext_f16, ggml.c:15538-15760; llm_build_kqv flash path
+//      src/llama.cpp:10075-10095): q F32 [D, N, H, B], k / v F16 [D, n_kv, Hkv, B] (V NOT transposed), mask F16 [n_kv, >= N] or null,
+//      dst F32 [D, H, N, B]. One 256-thread workgroup per (query, head, batch): scores over all keys into LDS (q rounded to F16
+//      like the reference's q_to_vec_dot, f32 accumulate), softcap / ALiBi slope / mask, max, exp, f32 sum, then P.V with the keys
+//      dealt to 256 / (D/8) slots of 8 channels each. The reference runs an online softmax that re-scales an F16 accumulator;
+//      here the accumulation is f32 (differences far below the reference's own backend tolerance, NMSE 5e-4).
+__global__ __launch_bounds__(256) void flash_attn_ext_kernel(TD q, TD k, TD v, const char * mask, long mask_nb1, TD d, float scale,
+                                                           float max_bias, float softcap, float m0, float m1, unsigned n_head_log2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float redf[8];
+    const int D = (int) q.ne[0];
+    const int n_kv = (int) k.ne[1];
+    float * qs = (float *) smem;                              // [Dp]
+    const int Dp = (D + 7) & ~7;
+    float * sc = qs + Dp;                                     // [n_kv]
+    float * part = sc + ((n_kv + 3) & ~3);                    // [nslot][Dp]
+    const int iq1 = blockIdx.x, h = blockIdx.y, b3 = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hk = h / (int) (q.ne[2] / k.ne[2]), hv = h / (int) (q.ne[2] / v.ne[2]);
+    const int bk = b3 / (int) (q.ne[3] / k.ne[3]), bv = b3 / (int) (q.ne[3] / v.ne[3]);
+    const char * qp = q.data + (long) iq1 * q.nb[1] + (long) h * q.nb[2] + (long) b3 * q.nb[3];
+    for (int e = tid; e < Dp; e += 256) qs[e] = e < D ? h2f(f2h(*(const float *) (qp + (long) e * 4))) : 0.0f;
+    const float slope = max_bias > 0.0f ? ((unsigned) h < n_head_log2 ? powf(m0, (float) (h + 1)) : powf(m1, (float) (2 * (h - (int) n_head_log2) + 1))) : 1.0f;
+    const uint16_t * mp = mask ? (const uint16_t *) (mask + (long) iq1 * mask_nb1) : nullptr;
+    __syncthreads();
+    float lmax = -INFINITY;
+    for (int i = tid; i < n_kv; i += 256) {
+        const float mv = mp ? slope * h2f(mp[i]) : 0.0f;
+        float s = -INFINITY;
+        if (mv != -INFINITY) {
+            const uint16_t * kr = (const uint16_t *) (k.data + (long) i * k.nb[1] + (long) hk * k.nb[2] + (long) bk * k.nb[3]);
+            float acc = 0.0f;
+            for (int e = 0; e < D; ++e) acc += h2f(kr[e]) * qs[e];
+            s = acc * scale;
+            if (softcap != 0.0f) s = softcap * tanhf(s);
+            s += mv;
+        }
+        sc[i] = s;
+        lmax = fmaxf(lmax, s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    if (lane == 0) redf[wave] = lmax;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    float lsum = 0.0f;
+    for (int i = tid; i < n_kv; i += 256) {
+        const float p = (sc[i] == -INFINITY || mx == -INFINITY) ? 0.0f : expf(sc[i] - mx);
+        sc[i] = p;
+        lsum += p;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+    __syncthreads();
+    if (lane == 0) redf[4 + wave] = lsum;
+    __syncthreads();
+    const float S = (redf[4] + redf[5]) + (redf[6] + redf[7]);
+    // P.V: thread = (8-channel chunk c, key slot)
+    const int nchunk = Dp / 8, nslot = 256 / nchunk;
+    const int c = tid % nchunk, slot = tid / nchunk;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (slot < nslot) {
+        for (int i = slot; i < n_kv; i += nslot) {
+            const float p = sc[i];
+            if (p == 0.0f) continue;
+            const uint16_t * vr = (const uint16_t *) (v.data + (long) i * v.nb[1] + (long) hv * v.nb[2] + (long) bv * v.nb[3]) + 8 * c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (8 * c + j < D) acc[j] += h2f(vr[j]) * p;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[slot * Dp + 8 * c + j] = acc[j];
+    }
+    __syncthreads();
+    char * dp = d.data + (long) h * d.nb[1] + (long) iq1 * d.nb[2] + (long) b3 * d.nb[3];
+    for (int e = tid; e < D; e += 256) {
+        float o = 0.0f;
+        for (int sl = 0; sl < nslot; ++sl) o += part[sl * Dp + e];
+        *(float *) (dp + (long) e * 4) = S > 0.0f ? o / S : 0.0f;
+    }
+}
+
 extern "C" {
 
 int pm355_op_cpy(const pm355_tensor * src, const pm355_tensor * dst, pm355_stream_t st) {
@@ -233,6 +314,30 @@ int pm355_op_soft_max(const pm355_tensor * a, const pm355_tensor * mask, const p
     (void) hipGetLastError();
     hipLaunchKernelGGL(soft_max_kernel, dim3((unsigned) rows), dim3(256), lds, S(st), to_td(a), mask ? (const char *) mask->data : nullptr,
                        mask ? mask->type : 0, mask ? (long) mask->nb[1] : 0, to_td(dst), scale, max_bias, m0, m1, n_head_log2);
+    OKRET();
+}
+int pm355_op_flash_attn_ext(const pm355_tensor * q, const pm355_tensor * k, const pm355_tensor * v, const pm355_tensor * mask,
+                            const pm355_tensor * dst, float scale, float max_bias, float logit_softcap, pm355_stream_t st) {
+    if (q->type != PM_F32 || k->type != PM_F16 || v->type != PM_F16 || dst->type != PM_F32) return PM355_E_UNSUPPORTED;
+    if (q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || dst->nb[0] != 4) return PM355_E_UNSUPPORTED;
+    if (k->ne[0] != q->ne[0] || v->ne[0] != q->ne[0] || v->ne[1] != k->ne[1] || q->ne[0] > 256 || q->ne[0] < 8) return PM355_E_SHAPE;
+    if (q->ne[2] % k->ne[2] || q->ne[2] % v->ne[2] || q->ne[3] % k->ne[3] || q->ne[3] % v->ne[3]) return PM355_E_SHAPE;
+    if (mask && (mask->type != PM_F16 || mask->ne[0] != k->ne[1] || mask->ne[1] < q->ne[1] || mask->nb[0] != 2)) return PM355_E_UNSUPPORTED;
+    if (dst->ne[0] != q->ne[0] || dst->ne[1] != q->ne[2] || dst->ne[2] != q->ne[1]) return PM355_E_SHAPE;
+    const int Dp = ((int) q->ne[0] + 7) & ~7, nslot = 256 / (Dp / 8);
+    const size_t lds = ((size_t) Dp + (((size_t) k->ne[1] + 3) & ~(size_t) 3) + (size_t) nslot * Dp) * 4;
+    if (lds > 150 * 1024) return PM355_E_RANGE;
+    if (logit_softcap != 0.0f) scale /= logit_softcap;
+    const unsigned n_head = (unsigned) q->ne[2];
+    const unsigned n_head_log2 = 1u << (unsigned) floor(log2((double) n_head));
+    const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    static bool set[16] = {};
+    const int dv = lds > 48 * 1024 ? pm_cur_dev() : 0;
+    if (lds > 48 * 1024 && !set[dv]) { (void) hipFuncSetAttribute((const void *) flash_attn_ext_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set[dv] = true; }
+    (void) hipGetLastError();
+    hipLaunchKernelGGL(flash_attn_ext_kernel, dim3((unsigned) q->ne[1], (unsigned) q->ne[2], (unsigned) q->ne[3]), dim3(256), lds, S(st),
+                       to_td(q), to_td(k), to_td(v), mask ? (const char *) mask->data : nullptr, mask ? (long) mask->nb[1] : 0, to_td(dst),
+                       scale, max_bias, logit_softcap, m0, m1, n_head_log2);
     OKRET();
 }
 int pm355_op_rope(const pm355_tensor * a, const int32_t * d_pos, const float * freq_factors, const pm355_tensor * dst,
