@@ -129,12 +129,14 @@ def cpu_baseline(hp, mixture, seconds):
 
 
 def pmc_traffic(bytes_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r01_c_pmc_traffic.json:
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r02_pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE on tools/pmc_probe.py, x1024 B and the gfx950 x2 correction of MI355X_MICROARCH.md).
     Counters cannot be read from inside the timed process, so this is the recorded measurement for the same kernel and
     shape; None when the workload's launch does not match the recorded one."""
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c_pmc_traffic.json")) as f:
+        prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        name = "r02_pmc_traffic.json" if os.path.exists(os.path.join(prof, "r02_pmc_traffic.json")) else "r01_c_pmc_traffic.json"
+        with open(os.path.join(prof, name)) as f:
             t = json.load(f)
         if int(t["algorithmic_bytes_per_launch"]) == int(bytes_per_launch):
             return int(t["hbm_read_bytes_per_launch"]) + int(t["hbm_write_bytes_per_launch_uncalibrated"])
@@ -229,32 +231,79 @@ def probe_dominant_kernel(win, hp, iters=40):
     return out
 
 
-def probe_prefill(hp, mixture, n_tok, n_layers=8):
-    """Prefill probe (reported as an extra, not the metric): n_tok-token prompt through the first n_layers layers of the
-    same model on the MFMA GEMM path, scaled to the full depth. Returns tokens/s and achieved dense TFLOP/s."""
+def probe_prefill(hp, mixture, n_tok):
+    """Prefill probe (reported as an extra, not the metric): an n_tok-token prompt through the WHOLE model (token embedding, every
+    layer on the MFMA GEMM + MFMA attention path, result_norm + lm_head on the last token), plus `roofline` for its dominant kernel
+    - the ffn gate / up GEMM - timed with HIP events on its launch stream."""
+    import ctypes as C
     import prima_cpp_amd.engine as E
-    win = E.Window(hp, lo=0, hi=n_layers, flags=0, n_ctx=max(1024, ((n_tok + 63) // 64) * 64))
+    import prima_cpp_amd.ops as P
+    from prima_cpp_amd.lib import Q4_K, Q6_K
+    win = E.Window(hp, lo=0, hi=hp["n_layer"], flags=E.HAS_EMBD | E.HAS_HEAD, n_ctx=max(1024, ((n_tok + 63) // 64) * 64))
     win.fill_synthetic(mixture, seed=4321)
     win.finalize(max_tokens=n_tok, n_seq=1)
-    x = torch.randn(n_tok, hp["n_embd"], device="cuda") * 0.5
-    win.decode(x_in=x, pos0=0, want_hidden=True, want_logits=False)
+    toks = torch.randint(0, hp["n_vocab"], (n_tok,), dtype=torch.int32, device="cuda")
+    win.decode(tokens=toks, pos0=0, want_hidden=False, want_logits=True)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st = torch.cuda.current_stream()
     win.kv_clear()
     e0.record(st)
-    win.decode(x_in=x, pos0=0, want_hidden=True, want_logits=False)
+    win.decode(tokens=toks, pos0=0, want_hidden=False, want_logits=True)
     e1.record(st)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     Ed, Eq, Ekv, F = hp["n_embd"], hp["head_dim"] * hp["n_head"], hp["head_dim"] * hp["n_head_kv"], hp["n_ff"]
     params = Ed * Eq * 2 + 2 * Ed * Ekv + 3 * Ed * F
-    flop = 2.0 * params * n_tok * n_layers
+    flop = 2.0 * params * n_tok * hp["n_layer"]
+    out = {"prompt_tokens": n_tok, "layers_timed": hp["n_layer"], "tokens_per_s": round(n_tok / (ms / 1e3), 1), "ms": round(ms, 2),
+           "gemm_tflops_whole_prompt": round(flop / (ms / 1e3) / 1e12, 1), "mfma_peak_tflops_f16_dense": 2500.0,
+           "note": "token embedding + all layers (MFMA v_mfma_f32_32x32x16_f16 weight GEMMs with on-the-fly dequantization, MFMA causal "
+                   "attention) + result_norm + lm_head on the last token; gemm_tflops_whole_prompt counts the weight-GEMM FLOPs over the whole time"}
+    # dominant kernel: ffn_gate GEMM [n_tok x n_embd] x [n_ff x n_embd]^T of layer 0 (its type decides the instantiation)
+    try:
+        lib = P.L.load()
+        lib.pm355_model_tensor_ptr.restype = C.c_void_p
+        lib.pm355_model_tensor_ptr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        ty = C.c_int(0)
+        wp = lib.pm355_model_tensor_ptr(win.h, E.T_FFN_GATE, 0, C.byref(ty))
+        x = torch.randn(n_tok, Ed, device="cuda") * 0.5
+        y = torch.empty(n_tok, F, device="cuda")
+        lib.pm355_mul_mat_q_mfma.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        run = lambda: P.check(lib.pm355_mul_mat_q_mfma(ty.value, wp, Ed, F, x.data_ptr(), n_tok, y.data_ptr(), None, None, st.cuda_stream), "gemm probe")
+        run(); torch.cuda.synchronize()
+        iters = 10
+        e0.record(st)
+        for _ in range(iters):
+            run()
+        e1.record(st)
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        tf = 2.0 * n_tok * Ed * F / us / 1e6
+        # what the vendor's plain F16 GEMM (no dequantization) reaches for the same shape on this box: the practical ceiling, measured
+        a16, b16 = x.half(), torch.randn(F, Ed, device="cuda", dtype=torch.float16)
+        for _ in range(2):
+            (a16 @ b16.t())
+        torch.cuda.synchronize()
+        e0.record(st)
+        for _ in range(iters):
+            (a16 @ b16.t())
+        e1.record(st)
+        torch.cuda.synchronize()
+        lib_tf = 2.0 * n_tok * Ed * F / (e0.elapsed_time(e1) * 1e3 / iters) / 1e6
+        out["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                           "kernel": f"gemm_q_f16_kernel2<{'Q4_K' if ty.value == Q4_K else 'Q6_K' if ty.value == Q6_K else ty.value}> ffn_gate "
+                                     f"[{n_tok} x {Ed}] x [{F} x {Ed}]^T incl. the f32->f16 conversion of the activations",
+                           "flops_per_launch": 2.0 * n_tok * Ed * F, "avg_launch_us": round(us, 1),
+                           "library_f16_gemm_same_shape_tflops": round(lib_tf, 1), "frac_of_library_f16_gemm": round(tf / lib_tf, 4),
+                           "traffic": None,
+                           "note": "peak = dense F16 MFMA at the nominal 2.4 GHz; under this load the chip runs at ~1.6 GHz (GRBM_GUI_ACTIVE / duration, "
+                                   "profiles/r02_prefill_pmc.txt), where rocprofv3 reports MfmaUtil 46 %; library_f16_gemm = torch.matmul (hipBLASLt) F16 x F16 "
+                                   "of the same shape on this box, measured here only as the practical ceiling"}
+    except Exception as e:
+        out["roofline"] = {"error": str(e)[:300]}
     win.close()
-    full_ms = ms * hp["n_layer"] / n_layers
-    return {"prompt_tokens": n_tok, "layers_timed": n_layers, "tokens_per_s_full_depth": round(n_tok / (full_ms / 1e3), 1),
-            "gemm_tflops": round(flop / (ms / 1e3) / 1e12, 1), "mfma_peak_tflops_f16_dense": 2500.0,
-            "note": "MFMA v_mfma_f32_32x32x16_f16 weight GEMMs (on-the-fly dequantization) + MFMA causal attention; layers timed x (n_layer / layers_timed); gemm_tflops counts the weight GEMMs only over the whole layer time"}
+    return out
 
 
 def extra_config(name, steps=32, warmup=8, prompt=16, n_ctx=4096):
@@ -466,9 +515,9 @@ def main():
                                       "frac_of_measured_peak": round(pr["gbs"] / pr["stream_read_gbs"], 4) if pr.get("stream_read_gbs") else None}
             if world == 1 and a.prefill > 0:
                 try:
-                    result["prefill_probe"] = probe_prefill(hp, mixture, a.prefill)
+                    result["prefill"] = probe_prefill(hp, mixture, a.prefill)
                 except Exception as e:
-                    result["prefill_probe"] = {"error": str(e)}
+                    result["prefill"] = {"error": str(e)}
             if world == 1 and not a.no_cpu_baseline:
                 try:
                     cb = cpu_baseline(hp, mixture, a.cpu_seconds)

@@ -15,6 +15,7 @@
 // tests/test-backend-ops.cpp:1660) - measured ~1e-6, tests/test_gpu_ops.py.
 #include "pm355_device.h"
 #include "pm355_kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -137,6 +138,34 @@ __device__ __forceinline__ void convert_w_h(const RawW & w, int k0, half8 (&o)[2
     }
     o[0] = __builtin_bit_cast(half8, u32x4{out[0], out[1], out[2], out[3]});
     o[1] = __builtin_bit_cast(half8, u32x4{out[4], out[5], out[6], out[7]});
+}
+
+// Q4_K: both 16-weight parts of one 32-weight sub-block share its 6-bit scale / min - decode them once (gemm_q_f16_kernel2 stages
+// the two parts from the same thread)
+__device__ __forceinline__ void convert_q4k_pair_h(const RawW & w0, const RawW & w1, int k0, half8 (&o)[4]) {
+    const int s = (k0 & 255) >> 5;
+    const u32x4 h = w0.r[1];
+    int sc, mn;
+    k4_scale_min(h[1], h[2], h[3], s, sc, mn);
+    const _Float16 ds = (_Float16) (h2f((uint16_t) (h[0] & 0xFFFF)) * (float) sc), ms = (_Float16) (h2f((uint16_t) (h[0] >> 16)) * (float) mn);
+    const half2v mul = half2v{ds, ds}, add = half2v{(_Float16) -ms, (_Float16) -ms};
+    const half2v bias = half2v{(_Float16) -1024.0f, (_Float16) -1024.0f};
+    const int sh = (s & 1) * 4;
+    uint32_t out[16];
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t v = ((part ? w1.r[0][i] : w0.r[0][i]) >> sh) & 0x0F0F0F0Fu;
+            const uint32_t lo = __builtin_amdgcn_perm(0x64646464u, v, 0x05010400u);
+            const uint32_t hi = __builtin_amdgcn_perm(0x64646464u, v, 0x07030602u);
+            half2v a = __builtin_bit_cast(half2v, lo), b = __builtin_bit_cast(half2v, hi);
+            a = (a + bias) * mul + add;
+            b = (b + bias) * mul + add;
+            out[8 * part + 2 * i] = __builtin_bit_cast(uint32_t, a); out[8 * part + 2 * i + 1] = __builtin_bit_cast(uint32_t, b);
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = __builtin_bit_cast(half8, u32x4{out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]});
 }
 
 struct GemmP {
@@ -288,6 +317,160 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel(GemmP p) {
         }
 }
 
+
+// ---- second generation: 256 x 256 x 64 tile, 8 waves (4 x 2) of 64 (weight rows) x 128 (tokens) each ---------------------------
+// What the first kernel above loses (rocprofv3 --pmc on the ffn_gate shape, profiles/r02_prefill_pmc.txt: MfmaUtil 41 %, VALUBusy 28 %,
+// LdsUtil 36 %, no bank conflicts, memory unit never stalled): nothing is saturated - the waves WAIT. Its ISA shows why: the compiler
+// kept three fragment registers and emitted ds_read_b128 -> s_waitcnt lgkmcnt(0) -> v_mfma chains, i.e. one exposed LDS latency
+// (~130 cycles) in front of most 32-cycle MFMAs. Here
+//   * the A / B fragments of k-slice kk+1 are loaded into a SECOND register set while the MFMAs of slice kk run (explicit double
+//     buffering; counted lgkmcnt waits), 
+//   * a wave owns 2 x 4 MFMA tiles: 6 fragment reads feed 8 MFMAs (was 4 for 4), and a k-step is 32 MFMAs (1024 matrix-pipe
+//     cycles) per barrier instead of 16,
+//   * the weight tile is 256 rows: every dequantized weight still serves 256 tokens, the activation tile is read by twice as many rows.
+// LDS: 2 buffers x (256 + 256) rows x 72 halfs = 147 KB (one workgroup per CU, 2 waves per SIMD); staging registers: one set, the
+// loads of step s+2 are issued right after step s+1 was written to LDS (a step is ~1 us: enough for an HBM round trip).
+constexpr int BM2 = 256, BN2 = 256;
+#ifndef PM_GEMM2_VALU_PER_MFMA
+#define PM_GEMM2_VALU_PER_MFMA 3
+#endif
+
+template <int TYPE>
+__global__ __launch_bounds__(512) void gemm_q_f16_kernel2(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];      // [2][(BM2 + BN2) * LDS_STRIDE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * BM2, t0 = blockIdx.y * BN2;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;             // this wave's 64 x 128 block inside the tile
+    float16v acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // staging: weights  thread -> (tile row = tid / 2, 32-k half = tid % 2), both 16-weight parts of that half
+    //          tokens   thread -> (tile row = tid / 2, 32-k half = tid % 2)
+    const int arow = tid >> 1, ahalf = tid & 1;
+    const uint8_t * wptr = p.W + (long) min(n0 + arow, p.N - 1) * p.row_stride;
+    const _Float16 * xptr = p.Xh + (long) min(t0 + arow, p.T - 1) * p.K + 32 * ahalf;
+    constexpr int BUF = (BM2 + BN2) * LDS_STRIDE;
+    struct Regs { RawW w[2]; half8 x[4]; };
+    Regs R;
+    const int nst = p.K / BK;
+    auto fetch = [&](int st) __attribute__((always_inline)) {
+        const int k0 = min(st, nst - 1) * BK;
+        fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, 0, R.w[0]);
+        fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, 1, R.w[1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) R.x[i] = *(const half8 *) (xptr + k0 + 8 * i);
+    };
+    auto stage = [&](int st) __attribute__((always_inline)) {
+        _Float16 * buf = lds + (st & 1) * BUF;
+        _Float16 * da = buf + arow * LDS_STRIDE + 32 * ahalf;
+        _Float16 * db = buf + (BM2 + arow) * LDS_STRIDE + 32 * ahalf;
+        const int k0 = min(st, nst - 1) * BK + 32 * ahalf;
+        if (PM_GEMM_F16_DEQUANT && TYPE == PM_Q4_K) {
+            half8 o[4];
+            convert_q4k_pair_h(R.w[0], R.w[1], k0, o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(half8 *) (da + 8 * q) = o[q];
+        } else
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            if (PM_GEMM_F16_DEQUANT && (TYPE == PM_Q4_K || TYPE == PM_Q6_K)) {
+                half8 o[2];
+                convert_w_h<TYPE>(R.w[part], k0, o);
+                *(half8 *) (da + 16 * part) = o[0]; *(half8 *) (da + 16 * part + 8) = o[1];
+            } else {
+                float o[16];
+                convert_w<TYPE>(R.w[part], k0, o);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    half8 v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (_Float16) o[8 * i + j];
+                    *(half8 *) (da + 16 * part + 8 * i) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(half8 *) (db + 8 * i) = R.x[i];
+    };
+    struct Frag { half8 a[2], b[4]; };
+    auto load_frag = [&](Frag & f, const _Float16 * As, const _Float16 * Bs, int kk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) f.a[i] = *(const half8 *) (As + (wm + 32 * i + (lane & 31)) * LDS_STRIDE + kk + 8 * (lane >> 5));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.b[j] = *(const half8 *) (Bs + (wn + 32 * j + (lane & 31)) * LDS_STRIDE + kk + 8 * (lane >> 5));
+    };
+    auto mma8 = [&](const Frag & f) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+    };
+    fetch(0);
+    stage(0);
+    fetch(1);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const _Float16 * As = lds + (st & 1) * BUF, * Bs = As + BM2 * LDS_STRIDE;
+        Frag f0, f1;
+        load_frag(f0, As, Bs, 0);
+        load_frag(f1, As, Bs, 16);
+        mma8(f0);
+        load_frag(f0, As, Bs, 32);
+        mma8(f1);
+        load_frag(f1, As, Bs, 48);
+        mma8(f0);
+        stage(st + 1);                                    // dequantize step st+1 (registers) into the other buffer ...
+        mma8(f1);
+        fetch(st + 2);                                    // ... and put the loads of step st+2 in flight
+        // schedule: fragment reads of the next slice first, then MFMAs with a few VALU instructions of the dequantization between them
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);    // 6 DS reads
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, PM_GEMM2_VALU_PER_MFMA, 0);    // VALU in its shadow
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]; Y[t][n]: 4 consecutive n per float4
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + wn + 32 * j + (lane & 31);
+            if (t >= p.T) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wm + 32 * i + 8 * g + 4 * (lane >> 5);
+                if (n + 3 < p.N) {
+                    float4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    if (p.bias)  { const float4 bb = *(const float4 *) (p.bias + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+                    if (p.resid) { const float4 rr = *(const float4 *) (p.resid + (long) t * p.N + n); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+                    if (p.silu_gate) {
+                        const float4 gg = *(const float4 *) (p.silu_gate + (long) t * p.N + n);
+                        v.x *= gg.x / (1.0f + expf(-gg.x)); v.y *= gg.y / (1.0f + expf(-gg.y)); v.z *= gg.z / (1.0f + expf(-gg.z)); v.w *= gg.w / (1.0f + expf(-gg.w));
+                    }
+                    *(float4 *) (p.Y + (long) t * p.N + n) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < p.N) {
+                        float v = acc[i][j][4 * g + e];
+                        if (p.bias) v += p.bias[n + e];
+                        if (p.resid) v += p.resid[(long) t * p.N + n + e];
+                        if (p.silu_gate) { const float gg = p.silu_gate[(long) t * p.N + n + e]; v *= gg / (1.0f + expf(-gg)); }
+                        p.Y[(long) t * p.N + n + e] = v;
+                    }
+                }
+            }
+        }
+}
+
 } // namespace
 
 // f16 copy of the activations: one scratch buffer per DEVICE (a process may drive several GPUs through the plug-in), grown
@@ -317,6 +500,26 @@ int pm_launch_gemm_q_ex(int type, const void * W, const float * X, float * Y, in
     _Float16 * xh = g_xh[dev];
     if (!reuse_x) hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) ((need / 8 + 255) / 256)), dim3(256), 0, st, X, xh, (long) (need / 8));
     GemmP p = {(const uint8_t *) W, xh, Y, bias, resid, silu_gate, (long) pm_weight_row_stride(type, K), K, N, T};
+    // 256 x 256 tiles (gemm_q_f16_kernel2) when they still fill the chip; else the 128 x 256 kernel (more workgroups for small N)
+    static const int force = [] { const char * e = getenv("PM355_GEMM_KERNEL"); return e ? atoi(e) : 0; }();
+    const long wg2 = (long) ((N + BM2 - 1) / BM2) * ((T + BN2 - 1) / BN2);
+    const bool use2 = force == 2 || (force != 1 && 2 * wg2 >= pm_device_cus());     // at least half the CUs get a 256 x 256 tile
+    if (use2) {
+        const dim3 grid2((N + BM2 - 1) / BM2, (T + BN2 - 1) / BN2);
+        const size_t lds2 = (size_t) 2 * (BM2 + BN2) * LDS_STRIDE * sizeof(_Float16);
+        auto go2 = [&](auto kern) {
+            static bool attr[16] = {};                // per instantiation AND per device
+            if (!attr[dev]) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds2); attr[dev] = true; }
+            hipLaunchKernelGGL(kern, grid2, dim3(512), lds2, st, p);
+        };
+        switch (type) {
+            case PM_Q4_K: go2(gemm_q_f16_kernel2<PM_Q4_K>); break;
+            case PM_Q5_K: go2(gemm_q_f16_kernel2<PM_Q5_K>); break;
+            case PM_Q6_K: go2(gemm_q_f16_kernel2<PM_Q6_K>); break;
+            default:      go2(gemm_q_f16_kernel2<PM_Q8_0>); break;
+        }
+        return 0;
+    }
     const dim3 grid((N + BM - 1) / BM, (T + BN - 1) / BN);
     const size_t lds = (size_t) 2 * (BM + BN) * LDS_STRIDE * sizeof(_Float16);
     auto go = [&](auto kern) {

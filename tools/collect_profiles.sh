@@ -1,0 +1,54 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of a round into gpurun_out/$1 (copy what should be judged into profiles/). Run ON THE GPU BOX from the
+# repo root:  bash tools/collect_profiles.sh r02
+# kernel-trace / stats passes and PMC passes are SEPARATE runs (never --pmc together with trace domains other than --kernel-trace).
+set -u
+R=${1:-r02}
+OUT=$PWD/gpurun_out/$R
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+# (1) decode: kernel trace of the default bench workload (Llama-3-70B Q4_K_M) -> per-kernel table + one-token timeline
+rm -rf /tmp/prof_dec && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dec -- python $OLDPWD/bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-extras --prefill 0 > $OUT/${R}_bench_under_profiler.json 2>/dev/null
+f=$(find /tmp/prof_dec -name "*kernel_trace.csv" | head -1)
+{ echo "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-extras --prefill 0"; echo "(Llama-3-70B Q4_K_M decode: 52 tokens; tools/prof_summary.py <trace> 53, tools/timeline.py <trace>)"; echo;
+  python $OLDPWD/tools/prof_summary.py $f 53; echo; python $OLDPWD/tools/timeline.py $f 3; } > $OUT/${R}_decode_summary.txt
+cp $(find /tmp/prof_dec -name "*kernel_stats.csv" | head -1) $OUT/${R}_decode_kernel_stats.csv 2>/dev/null
+# (2) HBM traffic of the dominant decode kernel: FETCH_SIZE / WRITE_SIZE, one pass each
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c && rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python $OLDPWD/tools/pmc_probe.py > /tmp/pmc_$c.log 2>&1
+  cp $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $OUT/${R}_pmc_$c.csv
+done
+python - <<PY
+import csv, json
+def vals(path):
+    return [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if "gemv_q_kernel" in r["Kernel_Name"]]
+f, w = vals("$OUT/${R}_pmc_FETCH_SIZE.csv"), vals("$OUT/${R}_pmc_WRITE_SIZE.csv")
+alg = 2 * 28672 * 4608
+fr = sorted(f)[len(f) // 2] * 1024 * 2          # KB -> bytes, gfx950 correction x2 (MI355X_MICROARCH.md, HBM section)
+wr = sorted(w)[len(w) // 2] * 1024
+json.dump({"source": "rocprofv3 --pmc <counter> --kernel-trace --output-format csv -- python tools/pmc_probe.py (separate passes)",
+           "kernel": "gemv_q_kernel<12,12,true> Q4_K gate/up pair, K=8192, N=28672 (Llama-3-70B ffn), row-SoA layout",
+           "algorithmic_bytes_per_launch": alg, "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
+           "hbm_read_bytes_per_launch": int(fr), "hbm_write_bytes_per_launch_uncalibrated": int(wr),
+           "traffic_over_algorithmic": fr / alg}, open("$OUT/${R}_pmc_traffic.json", "w"), indent=1)
+print("traffic/algorithmic", fr / alg)
+PY
+# (3) prefill GEMM: achieved TFLOP/s + MFMA / VALU / LDS utilisation counters, one pass per counter
+{ echo "prefill GEMM (ffn_gate shape, T = 2048), tools/gemm_probe.py; counters: separate rocprofv3 --pmc <counter> --kernel-trace passes, 4 launches each";
+  for k in 1 2; do echo "== PM355_GEMM_KERNEL=$k (1 = 128x256 tile, first generation; 2 = 256x256 tile, fragment double buffering)";
+    for s in gate wo down wk; do PM355_GEMM_KERNEL=$k python $OLDPWD/tools/gemm_probe.py 2048 $s 2>/dev/null; done; done
+  echo "== default kernel selection"; for s in gate wo down wk; do python $OLDPWD/tools/gemm_probe.py 2048 $s 2>/dev/null; done
+  python $OLDPWD/tools/torch_gemm_ref.py 2>/dev/null
+  for k in 1 2; do echo "== counters, PM355_GEMM_KERNEL=$k, gate shape";
+    for c in MfmaUtil VALUBusy LdsUtil LdsBankConflict MemUnitStalled GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_LDS; do
+      rm -rf /tmp/pg_$c && PM355_GEMM_KERNEL=$k PMC_ITERS=3 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pg_$c -- python $OLDPWD/tools/gemm_probe.py 2048 gate > /dev/null 2>&1
+      python - <<PY
+import csv, glob
+f = glob.glob("/tmp/pg_$c/**/*counter_collection.csv", recursive=True)[0]; k = glob.glob("/tmp/pg_$c/**/*kernel_trace.csv", recursive=True)[0]
+v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "gemm_q_f16" in r["Kernel_Name"]]
+t = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(k)) if "gemm_q_f16" in r["Kernel_Name"]]
+print(f"  $c: avg {sum(v) / len(v):.5g} over {len(v)} launches; kernel duration {sum(t) / len(t):.1f} us")
+PY
+    done; done; } > $OUT/${R}_prefill_pmc.txt 2>&1
+ls -la $OUT
