@@ -272,6 +272,13 @@ PM355_API const char * pm355_model_error(pm355_model * m);
  * pinned double buffers (hipMemcpyAsync) and re-ordered into the HBM layout on the device
  * (replaces load_all_data's synchronous upload, src/llama.cpp:5418-5640). layer = -1 for per-model tensors. */
 PM355_API int pm355_model_set_tensor(pm355_model * m, int kind, int layer, int type, const void * host_data, size_t nbytes);
+/* WINDOW STREAMING for windows larger than HBM (call before the first layer tensor is set): the layer tensors are kept in pinned
+ * host memory (already in the HBM layout) and cycled through n_slots device-side layer slots by a copy stream (hipMemcpyAsync),
+ * one layer ahead per free slot, while the compute stream works on the current layer - replaces prima.cpp's mmap prefetch /
+ * release of the next layer window (manage_graph_tensors + posix_madvise, src/llama.cpp:18152-18218, :18566-18575).
+ * n_slots = 0: everything resident (default). Token embedding, head and KV caches always stay resident. */
+PM355_API int pm355_model_set_streaming(pm355_model * m, int n_slots);
+PM355_API uint64_t pm355_model_streamed_bytes(const pm355_model * m);   /* host -> device bytes streamed so far */
 /* synthetic tensor generated in HBM (no host traffic) */
 PM355_API int pm355_model_fill_tensor(pm355_model * m, int kind, int layer, int type, uint64_t seed, float scale);
 /* allocate KV cache (F16, zero-cleared: llama_kv_cache_init src/llama.cpp:3889-3992) + scratch for max_tokens per call */

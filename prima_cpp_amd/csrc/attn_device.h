@@ -70,43 +70,43 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
         x0 = src[ia]; x1 = src[ib];
     }
     if (DH > 128 || tid >= 128) { const int e = DH > 128 ? tid : tid - 128; if (e < DH) vnew = v[(long) hk * DH + e]; }
-    // ---- (1) position: with a sequence selector the selector and all (<= 64) positions are requested TOGETHER
-    //      (the engine's position table has 64 entries) instead of as two dependent loads
+    // ---- (1) + (2) position and the first K / V^T loads. The ADDRESSES of this thread's K row of the first sweep (cell = tid) and of its
+    //      first two V^T chunks do not depend on the position, only on the sequence's slab - so with a single slab (seq_stride == 0)
+    //      they are issued together with the position / q / k / v loads: ONE exposed memory latency instead of two (which cells are
+    //      valid is decided later; rows beyond n_kv are loaded and ignored). With several slabs the sequence id has to arrive first.
+    u32x4 kreg[KQ];
+    const int ve = tid % DH, vpt = tid / DH;
+    u32x4 vreg0 = {0, 0, 0, 0}, vreg1 = {0, 0, 0, 0};
+    auto first_loads = [&](const PM_G uint16_t * kcb, const PM_G uint16_t * vcb) __attribute__((always_inline)) {
+        const PM_G uint16_t * kr = kcb + (long) (tid < n_ctx ? tid : 0) * Hkv * DH + (long) hk * DH;
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) kreg[j] = *(const PM_G u32x4 *) (kr + 8 * j);
+        const PM_G uint16_t * vr = vcb + (long) (hk * DH + ve) * n_ctx;
+        const int i0 = vpt * 8, i1 = i0 + PARTS * 8;
+        vreg0 = *(const PM_G u32x4 *) (vr + (i0 + 8 <= n_ctx ? i0 : 0));
+        vreg1 = *(const PM_G u32x4 *) (vr + (i1 + 8 <= n_ctx ? i1 : 0));
+    };
     int seq = 0, pos, slot, n_kv;                // rope position, cache cell of this token, cells attended = [0, n_kv)
+    int pv = 0, sv = 0;
+    if (seq_ptr) { pv = pos0_ptr[lane]; sv = *seq_ptr; } else pv = pos0_ptr[0];     // (the engine's position table has 64 entries)
+    int dyn0 = 0, dyn1 = 0;
+    if (a.dyn) { const PM_G int32_t * dyn = (const PM_G int32_t *) a.dyn; dyn0 = dyn[0]; dyn1 = dyn[1]; }
+    if (seq_stride == 0 || !seq_ptr) first_loads(kc, vc);
     if (seq_ptr) {
-        const int pv = pos0_ptr[lane];
-        seq = __builtin_amdgcn_readfirstlane(*seq_ptr);
+        seq = __builtin_amdgcn_readfirstlane(sv);
         pos = __builtin_amdgcn_readlane(pv, seq);
         slot = pos; n_kv = pos + 1;
     } else {
-        pos = __builtin_amdgcn_readfirstlane(pos0_ptr[0]);
+        pos = __builtin_amdgcn_readfirstlane(pv);
         slot = pos; n_kv = pos + 1;
-        if (a.dyn) {
-            const PM_G int32_t * dyn = (const PM_G int32_t *) a.dyn;
-            slot = __builtin_amdgcn_readfirstlane(dyn[0]); n_kv = __builtin_amdgcn_readfirstlane(dyn[1]);
-        }
+        if (a.dyn) { slot = __builtin_amdgcn_readfirstlane(dyn0); n_kv = __builtin_amdgcn_readfirstlane(dyn1); }
     }
     const PM_G float * mask = (const PM_G float *) a.mask;
     kc += (long) seq * seq_stride; vc += (long) seq * seq_stride;
+    if (seq_stride != 0 && seq_ptr) first_loads(kc, vc);
     const int n_pad = (n_kv + 7) & ~7;           // cached cells [0, n_kv) without `slot`, padded to the 16-byte load width
-
-    // ---- (2) every global load whose address depends only on `pos` goes out NOW (one exposed latency for the rest of
-    //      the kernel): this thread's K row of the first sweep and its first two V^T chunks; the rotations overlap it
-    u32x4 kreg[KQ];
     const bool have_k = tid < n_kv && tid != slot;
-    {
-        const PM_G uint16_t * kr = kc + (long) (have_k ? tid : 0) * Hkv * DH + (long) hk * DH;
-#pragma unroll
-        for (int j = 0; j < KQ; ++j) kreg[j] = *(const PM_G u32x4 *) (kr + 8 * j);
-    }
-    const int ve = tid % DH, vpt = tid / DH;
     const PM_G uint16_t * vrow = vc + (long) (hk * DH + ve) * n_ctx;
-    u32x4 vreg0 = {0, 0, 0, 0}, vreg1 = {0, 0, 0, 0};
-    {
-        const int i0 = vpt * 8, i1 = i0 + PARTS * 8;
-        vreg0 = *(const PM_G u32x4 *) (vrow + (i0 < n_pad ? i0 : 0));
-        vreg1 = *(const PM_G u32x4 *) (vrow + (i1 < n_pad ? i1 : 0));
-    }
     // rotate q (threads 0..DH/2-1) and k (threads DH/2..DH-1): each thread builds its own cos/sin
     if (tid < DH) {
         float o0 = x0, o1 = x1;

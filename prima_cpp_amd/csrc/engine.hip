@@ -22,7 +22,9 @@ namespace {
 
 struct Tensor { void * d = nullptr; int type = -1; int64_t K = 0, N = 0; size_t bytes = 0; };
 
-struct Layer { Tensor t[12]; void * kc = nullptr; void * vc = nullptr; };
+struct Layer { Tensor t[12]; void * kc = nullptr; void * vc = nullptr; void * host[12] = {}; size_t hbm[12] = {}; };
+// weight streaming (models larger than HBM): a device slot holds the tensors of ONE layer; layers are cycled through n slots
+struct Slot { void * d[12] = {}; hipEvent_t ready = nullptr, free_ = nullptr; int layer = -1; };
 
 } // namespace
 
@@ -49,7 +51,17 @@ struct pm355_model {
     // weight loads in flight, the 64 head workgroups run the latency-bound attention meanwhile, one device-wide barrier, then the wo
     // mat-vec: 4 launches per layer instead of 5. Bit-identical, but the barrier + first-touch fetch of the heads' outputs costs what
     // the launch boundary cost: 8.74 vs 8.60 ms per Llama-3-70B token, 1.72 vs 1.66 ms per 8B token
-    bool attn_wo = false; void * aw_ctr = nullptr;       // barrier state of that kernel (zero between launches) + watchdog flag
+    bool attn_wo = false;
+    // WINDOW STREAMING (pm355_model_set_streaming): the layer tensors live in pinned HOST memory (in the HBM layout) and are streamed
+    // through `slots` device-side layer slots by a copy stream, slot (l - lo) % n_slots for layer l, one layer ahead of the compute
+    // stream per free slot - the GPU-side form of prima.cpp's "prefetch the next layer window while this one computes"
+    // (manage_graph_tensors + posix_madvise, src/llama.cpp:18152-18218, :18566-18575) with hipMemcpyAsync from pinned memory in place of
+    // mmap page faults. KV caches, embedding and head stay resident.
+    int n_slots = 0;
+    std::vector<Slot> slots;
+    hipStream_t copy_stream = nullptr;
+    size_t slot_bytes[12] = {};
+    uint64_t streamed_bytes = 0; void * aw_ctr = nullptr;       // barrier state of that kernel (zero between launches) + watchdog flag
     struct Plan { const void * in; void * out, * lg; bool head; pm_decode_plan * pl; };
     std::vector<Plan> plans;
     // long-context decode attention (attn_split.hip): the host mirrors the device position counters to choose, per step, between
@@ -112,6 +124,7 @@ int seterr(pm355_model * m, int code, const char * msg) {
 // hipGetLastError() is sticky across unrelated earlier calls: test-and-clear around OUR launches only
 bool hip_ok() { return hipGetLastError() == hipSuccess; }
 
+size_t g_last_hbm = 0;        // HBM bytes of the tensor alloc_tensor allocated last (single-threaded loader)
 int alloc_tensor(pm355_model * m, Tensor * t, int kind, int type) {
     int64_t K, N;
     if (tensor_shape(m, kind, K, N)) return PM355_E_UNSUPPORTED;
@@ -123,6 +136,7 @@ int alloc_tensor(pm355_model * m, Tensor * t, int kind, int type) {
                      kind == PM355_T_TOK_EMBD || kind == PM355_T_OUTPUT;
     const size_t hbm = (mat ? pm_weight_row_stride(type, K) : rb) * (size_t) N;
     if (hipMalloc(&t->d, hbm + 256) != hipSuccess) return PM355_E_NOMEM;        // +256: tail slack for 16-B vector reads
+    g_last_hbm = hbm + 256;
     return 0;
 }
 
@@ -190,6 +204,41 @@ void pm_launch_fill_random_f32(float * dst, int64_t n, uint64_t seed, float mean
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// ---- window streaming ------------------------------------------------------------------------------------------------------------
+// enqueue the H2D copies of layer `il` into its slot on the copy stream (after the slot was released by its previous user)
+void stream_prefetch(pm355_model * m, int il) {
+    const int n = m->hi - m->lo;
+    Slot & S = m->slots[(il - m->lo) % m->n_slots];
+    Layer & L = m->layers[il - m->lo];
+    (void) hipStreamWaitEvent(m->copy_stream, S.free_, 0);
+    for (int k = 0; k < 12; ++k) if (L.host[k]) {
+        (void) hipMemcpyAsync(S.d[k], L.host[k], L.hbm[k], hipMemcpyHostToDevice, m->copy_stream);
+        m->streamed_bytes += L.hbm[k];
+    }
+    (void) hipEventRecord(S.ready, m->copy_stream);
+    S.layer = il;
+    (void) n;
+}
+// the layer as the kernels see it: resident tensors, or (streaming) the slot's copies once the copy stream has delivered them
+Layer layer_acquire(pm355_model * m, int il, hipStream_t st) {
+    Layer L = m->layers[il - m->lo];
+    if (!m->n_slots) return L;
+    Slot & S = m->slots[(il - m->lo) % m->n_slots];
+    if (S.layer != il) stream_prefetch(m, il);                          // (only after an interrupted pass; normally already in flight)
+    (void) hipStreamWaitEvent(st, S.ready, 0);
+    for (int k = 0; k < 12; ++k) if (L.host[k]) L.t[k].d = S.d[k];
+    return L;
+}
+// the layer's last kernel has been enqueued: release its slot and start fetching the layer that uses the slot next (wrapping around
+// to the first layers of the next token)
+void layer_release(pm355_model * m, int il, hipStream_t st) {
+    if (!m->n_slots) return;
+    const int n = m->hi - m->lo;
+    Slot & S = m->slots[(il - m->lo) % m->n_slots];
+    (void) hipEventRecord(S.free_, st);
+    if (n > m->n_slots) stream_prefetch(m, m->lo + (il - m->lo + m->n_slots) % n);
+}
+
 // quantize `src` [T][K] into the activation format(s) the given weights need; returns pointers
 struct ActQ { const void * k = nullptr; const void * z = nullptr; };
 ActQ quantize_for(pm355_model * m, const float * src, int K, int T, const Tensor * const * ws, int nw, hipStream_t st) {
@@ -256,7 +305,7 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
     const float kq_scale = 1.0f / sqrtf((float) dh);
     float * bufs[2] = {m->x, m->x1};
     for (int il = m->lo; il < m->hi; ++il) {
-        Layer & L = m->layers[il - m->lo];
+        Layer Lv = layer_acquire(m, il, st); Layer & L = Lv;
         // scratch: shared by all layers for the launch path; one private set per layer for the persistent kernel, where no
         // buffer may be written twice within the kernel (readers use plain cached loads, see mmvq_device.h grid_wait)
         float * q = m->q, * k = m->k, * v = m->v, * att = m->att, * hbuf = m->h;
@@ -277,7 +326,7 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
                     if (gemv_f32(m, ws + j, nullptr, ys + j, bs + j, nullptr, 1, cur, nw, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused qkv gemv");
             }
         }
-        const long kvs = (long) hp.n_ctx * Hkv * dh;
+        const long kvs = m->n_seq > 1 ? (long) hp.n_ctx * Hkv * dh : 0;     // one slab: the kernels may address the cache before the sequence id arrives
         bool aw_done = false;
         if (!m->rec && m->attn_wo && m->aw_ctr && !m->long_ctx) {
             const Tensor & wo = L.t[PM355_T_WO];
@@ -318,6 +367,7 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
             const Tensor * w[1] = {&L.t[PM355_T_FFN_DOWN]}; float * y[1] = {x_next}; const float * r[1] = {x_mid};
             if (gemv_f32(m, w, nullptr, y, nullptr, r, 1, hbuf, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused down gemv");
         }
+        layer_release(m, il, st);
         cur = x_next;
     }
     *cur_out = cur;
@@ -385,7 +435,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         cur = end;
     } else
     for (int il = m->lo; il < m->hi; ++il) {
-        Layer & L = m->layers[il - m->lo];
+        Layer Lv = layer_acquire(m, il, st); Layer & L = Lv;
         const Tensor * qkv[3] = {&L.t[PM355_T_WQ], &L.t[PM355_T_WK], &L.t[PM355_T_WV]};
         if (T >= 16 && !m->no_fuse) {
             // ---- prefill: batched GEMMs on the MFMA matrix cores (mmq.hip), f32 activations
@@ -424,6 +474,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
             if (rc) return seterr(m, PM355_E_UNSUPPORTED, "prefill: gate/up gemm");
             float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : ((x_mid == bufs[0]) ? bufs[1] : bufs[0]);
             if (G(L.t[PM355_T_FFN_DOWN], m->h, x_next, nullptr, x_mid)) return seterr(m, PM355_E_UNSUPPORTED, "prefill: down gemm");
+            layer_release(m, il, st);
             cur = x_next;
             continue;
         }
@@ -459,6 +510,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         // `cur` is dead after the wo GEMV consumed it as residual, so the other scratch buffer can be reused
         float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : ((x_mid == bufs[0]) ? bufs[1] : bufs[0]);
         if (gemv(L.t[PM355_T_FFN_DOWN], nullptr, a, T, x_next, nullptr, x_mid, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: down gemv");
+        layer_release(m, il, st);
         cur = x_next;
     }
     if (d_x_out && cur != d_x_out) (void) hipMemcpyAsync(d_x_out, cur, (size_t) T * E * 4, hipMemcpyDeviceToDevice, st);
@@ -496,6 +548,9 @@ void pm355_model_free(pm355_model * m) {
     for (auto & g : m->graphs) (void) hipGraphExecDestroy(g.exec);
     for (auto & pl : m->plans) pm_decode_plan_free(pl.pl);
     if (m->aw_ctr) (void) hipFree(m->aw_ctr);
+    if (m->copy_stream) { (void) hipStreamSynchronize(m->copy_stream); (void) hipStreamDestroy(m->copy_stream); }
+    for (auto & S : m->slots) { for (auto p : S.d) if (p) (void) hipFree(p); if (S.ready) (void) hipEventDestroy(S.ready); if (S.free_) (void) hipEventDestroy(S.free_); }
+    for (auto & L : m->layers) for (auto p : L.host) if (p) (void) hipHostFree(p);
     if (m->slab) (void) hipFree(m->slab);
     for (auto & L : m->layers) { for (auto & t : L.t) if (t.d) (void) hipFree(t.d); if (L.kc) (void) hipFree(L.kc); if (L.vc) (void) hipFree(L.vc); }
     Tensor * g[4] = {&m->tok_embd, &m->out_norm, &m->output, &m->rope_freqs};
@@ -508,6 +563,33 @@ void pm355_model_free(pm355_model * m) {
     if (m->side) { (void) hipStreamDestroy(m->side); (void) hipEventDestroy(m->side_a); (void) hipEventDestroy(m->side_b); }
     delete m;
 }
+
+// streaming mode: a freshly uploaded (and repacked) layer tensor is moved to pinned host memory; its device copy is released
+static int stream_park(pm355_model * m, int kind, int layer) {
+    if (!m->n_slots || kind >= 12) return 0;
+    Layer & L = m->layers[layer - m->lo];
+    Tensor & t = L.t[kind];
+    if (m->up_stream) (void) hipStreamSynchronize(m->up_stream);
+    (void) hipDeviceSynchronize();
+    if (L.host[kind]) { (void) hipHostFree(L.host[kind]); L.host[kind] = nullptr; }
+    const size_t n = g_last_hbm;
+    if (hipHostMalloc(&L.host[kind], n, hipHostMallocDefault) != hipSuccess) return seterr(m, PM355_E_NOMEM, "streaming: pinned host memory");
+    if (hipMemcpy(L.host[kind], t.d, n, hipMemcpyDeviceToHost) != hipSuccess) return seterr(m, PM355_E_HIP, "streaming: park tensor");
+    (void) hipFree(t.d);
+    t.d = nullptr;
+    L.hbm[kind] = n;
+    if (n > m->slot_bytes[kind]) m->slot_bytes[kind] = n;
+    return 0;
+}
+
+int pm355_model_set_streaming(pm355_model * m, int n_slots) {
+    if (!m || m->finalized) return m ? seterr(m, PM355_E_SHAPE, "set_streaming: call before finalize") : PM355_E_SHAPE;
+    for (auto & L : m->layers) for (auto & t : L.t) if (t.d) return seterr(m, PM355_E_SHAPE, "set_streaming: call before the first layer tensor is set");
+    if (n_slots < 0 || n_slots > 1024) return seterr(m, PM355_E_RANGE, "set_streaming: n_slots");
+    m->n_slots = n_slots;
+    return 0;
+}
+uint64_t pm355_model_streamed_bytes(const pm355_model * m) { return m ? m->streamed_bytes : 0; }
 
 int pm355_model_set_tensor(pm355_model * m, int kind, int layer, int type, const void * host, size_t nbytes) {
     (void) hipGetLastError();
@@ -550,7 +632,8 @@ int pm355_model_set_tensor(pm355_model * m, int kind, int layer, int type, const
         (void) hipEventRecord(m->pin_ev[b], m->up_stream);
         off += n; b ^= 1;
     }
-    return hip_ok() ? 0 : seterr(m, PM355_E_HIP, "set_tensor: upload failed");
+    if (!hip_ok()) return seterr(m, PM355_E_HIP, "set_tensor: upload failed");
+    return stream_park(m, kind, layer);
 }
 
 int pm355_model_fill_tensor(pm355_model * m, int kind, int layer, int type, uint64_t seed, float scale) {
@@ -567,7 +650,8 @@ int pm355_model_fill_tensor(pm355_model * m, int kind, int layer, int type, uint
     } else {
         pm_launch_fill_random_blocks(type, t->d, t->K, t->N, seed, scale, nullptr);
     }
-    return hip_ok() ? 0 : seterr(m, PM355_E_HIP, "fill_tensor");
+    if (!hip_ok()) return seterr(m, PM355_E_HIP, "fill_tensor");
+    return stream_park(m, kind, layer);
 }
 
 int pm355_model_finalize(pm355_model * m, int max_tokens) { return pm355_model_finalize_seqs(m, max_tokens, 1); }
@@ -585,7 +669,7 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
     for (int il = m->lo; il < m->hi; ++il) {
         Layer & L = m->layers[il - m->lo];
         for (int kd : {PM355_T_ATTN_NORM, PM355_T_WQ, PM355_T_WK, PM355_T_WV, PM355_T_WO, PM355_T_FFN_NORM, PM355_T_FFN_GATE, PM355_T_FFN_UP, PM355_T_FFN_DOWN})
-            if (!L.t[kd].d) return seterr(m, PM355_E_SHAPE, "finalize: a layer tensor is missing");
+            if (!L.t[kd].d && !L.host[kd]) return seterr(m, PM355_E_SHAPE, "finalize: a layer tensor is missing");
         const size_t kvb = Ekv * (size_t) hp.n_ctx * 2 * (size_t) n_seq;
         if (hipMalloc(&L.kc, kvb + 256) != hipSuccess || hipMalloc(&L.vc, kvb + 256) != hipSuccess) return seterr(m, PM355_E_NOMEM, "finalize: kv cache");
         (void) hipMemset(L.kc, 0, kvb + 256); (void) hipMemset(L.vc, 0, kvb + 256);
@@ -601,6 +685,20 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
     if (!ok) return seterr(m, PM355_E_NOMEM, "finalize: scratch");
     if (hp.n_head / hp.n_head_kv <= 8 && (hp.head_dim == 64 || hp.head_dim == 128) &&
         !A((void **) &m->split_scratch, pm_attn_split_scratch_floats(hp.n_head, hp.head_dim, hp.n_ctx) * 4)) return seterr(m, PM355_E_NOMEM, "finalize: attention scratch");
+    if (m->n_slots) {
+        if (m->n_slots > m->hi - m->lo) m->n_slots = m->hi - m->lo;
+        if (hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking) != hipSuccess) return seterr(m, PM355_E_HIP, "finalize: copy stream");
+        m->slots.resize(m->n_slots);
+        for (auto & S : m->slots) {
+            for (int k = 0; k < 12; ++k) if (m->slot_bytes[k] && hipMalloc(&S.d[k], m->slot_bytes[k]) != hipSuccess) return seterr(m, PM355_E_NOMEM, "finalize: layer slot");
+            if (hipEventCreateWithFlags(&S.ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&S.free_, hipEventDisableTiming) != hipSuccess)
+                return seterr(m, PM355_E_HIP, "finalize: slot events");
+            (void) hipEventRecord(S.free_, nullptr);
+        }
+        (void) hipDeviceSynchronize();
+        for (int i = 0; i < m->n_slots; ++i) stream_prefetch(m, m->lo + i);
+        m->attn_wo = false;
+    }
     if (m->attn_wo && !m->aw_ctr) {
         if (hipMalloc(&m->aw_ctr, pm_attn_wo_bar_bytes()) != hipSuccess) m->aw_ctr = nullptr;
         else (void) hipMemset(m->aw_ctr, 0, pm_attn_wo_bar_bytes());
@@ -716,7 +814,7 @@ int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * 
     m->long_ctx = regime != 0;
     // the mirror follows the device counters, which only move when the step was really enqueued
     auto commit = [&]() { m->h_pos[m->h_seq] += advance; if (rotate) m->h_seq = (m->h_seq + rotate) % m->n_seq; return 0; };
-    if (!use_graph) {
+    if (!use_graph || m->n_slots) {              // (streaming: copies and kernels are ordered with events across two streams, not captured)
         const int rc = step_body(m, d_token, d_x_in, d_x_out, d_logits, d_argmax, advance, rotate, head_first, st);
         return rc ? rc : commit();
     }

@@ -78,6 +78,8 @@ def _lib():
             "pm355_model_check": (_i32, [_vp]),
             "pm355_model_set_pos": (_i32, [_vp, _i32, _vp]),
             "pm355_model_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+            "pm355_model_set_streaming": (_i32, [_vp, _i32]),
+            "pm355_model_streamed_bytes": (C.c_uint64, [_vp]),
         }
         for name, (res, args) in S.items():
             f = getattr(lib, name)
@@ -184,6 +186,13 @@ class Window:
             self.fill_tensor(T_OUTPUT, -1, out_t, seed + 9, 1.0 / np.sqrt(hp["n_embd"]) * 2.0)
         if rope_freqs and hp["arch"] == 0:
             self.fill_tensor(T_ROPE_FREQS, -1, F32, seed + 11, 0.0)
+
+    def set_streaming(self, n_slots):
+        """Layer tensors in pinned host memory, streamed through n_slots device-side layer slots (before any layer tensor is set)."""
+        self._chk(self.lib.pm355_model_set_streaming(self.h, int(n_slots)), "set_streaming")
+
+    def streamed_bytes(self):
+        return int(self.lib.pm355_model_streamed_bytes(self.h))
 
     def finalize(self, max_tokens=1, n_seq=1):
         self.n_seq = n_seq

@@ -283,3 +283,41 @@ def test_step_refuses_to_write_past_the_kv_slab(E):
     w.step(token=tok, argmax=am)                       # still usable after the refusals
     torch.cuda.synchronize()
     w.close()
+
+
+@pytest.mark.parametrize("n_slots", [1, 2, 3, 4])
+def test_window_streaming_matches_resident(E, n_slots):
+    """pm355_model_set_streaming: layer tensors parked in pinned host memory and cycled through n_slots device slots by the copy
+    stream (the GPU-side form of prima.cpp's layer-window prefetch, src/llama.cpp:18152-18218) must give bit-identical results to the
+    fully resident window: 20-token MFMA prefill, a short multi-token batch, and single-token steps wrapping around the slot ring."""
+    torch = E.torch
+    rng = np.random.default_rng(99)
+    d = tiny_model(rng, arch=0, n_layer=4, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=320, n_ctx=64, rope_freqs=True)
+    toks = rng.integers(0, d.n_vocab, 30).astype(np.int32)
+    outs = []
+    for slots in (0, n_slots):
+        w = E.Window(_hp(d), n_ctx=64)
+        if slots:
+            w.set_streaming(slots)
+        w.load_desc(d)
+        w.finalize(max_tokens=20)
+        res = []
+        h, lg, _ = w.decode(tokens=torch.from_numpy(toks[:20]).cuda(), pos0=0)
+        res.append((h.cpu().numpy(), lg.cpu().numpy()))
+        h, lg, _ = w.decode(tokens=torch.from_numpy(toks[20:23]).cuda(), pos0=20)
+        res.append((h.cpu().numpy(), lg.cpu().numpy()))
+        w.set_pos(23)
+        x_out = torch.empty((1, d.n_embd), dtype=torch.float32, device="cuda")
+        lgt = torch.empty(d.n_vocab, dtype=torch.float32, device="cuda")
+        tok = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for t in toks[23:]:
+            tok[0] = int(t)
+            w.step(token=tok, x_out=x_out, logits=lgt, advance=1)
+            torch.cuda.synchronize()
+            res.append((x_out.cpu().numpy().copy(), lgt.cpu().numpy().copy()))
+        if slots:
+            assert w.streamed_bytes() > 0
+        outs.append(res)
+        w.close()
+    for (h0, l0), (h1, l1) in zip(*outs):
+        assert np.array_equal(h0, h1) and np.array_equal(l0, l1)
