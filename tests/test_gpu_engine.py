@@ -321,3 +321,34 @@ def test_window_streaming_matches_resident(E, n_slots):
         w.close()
     for (h0, l0), (h1, l1) in zip(*outs):
         assert np.array_equal(h0, h1) and np.array_equal(l0, l1)
+
+
+def test_attn_wo_two_phase_kernel_is_bit_identical(E, monkeypatch):
+    """PM355_ATTN_WO=1 (csrc/attn_wo.hip: attention + wo mat-vec of a layer as one two-phase launch with a device-wide barrier) must
+    reproduce the two-launch path bit for bit - same device functions, same reduction orders - through graph replay."""
+    torch = E.torch
+    rng = np.random.default_rng(123)
+    d = tiny_model(rng, arch=0, n_layer=2, n_embd=512, n_head=4, n_head_kv=2, n_ff=1024, n_vocab=320, n_ctx=64, rope_freqs=True)
+    assert d.head_dim == 128
+    toks = rng.integers(0, d.n_vocab, 12).astype(np.int32)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("PM355_ATTN_WO", flag)
+        w = E.Window(_hp(d), n_ctx=64)
+        w.load_desc(d)
+        w.finalize(max_tokens=1)
+        w.set_pos(0)
+        x_out = torch.empty((1, d.n_embd), dtype=torch.float32, device="cuda")
+        lg = torch.empty(d.n_vocab, dtype=torch.float32, device="cuda")
+        tok = torch.zeros(1, dtype=torch.int32, device="cuda")
+        res = []
+        for t in toks:
+            tok[0] = int(t)
+            w.step(token=tok, x_out=x_out, logits=lg, advance=1, use_graph=True)
+            torch.cuda.synchronize()
+            res.append((x_out.cpu().numpy().copy(), lg.cpu().numpy().copy()))
+        assert w.check() == 0
+        outs.append(res)
+        w.close()
+    for (h0, l0), (h1, l1) in zip(*outs):
+        assert np.array_equal(h0, h1) and np.array_equal(l0, l1)
