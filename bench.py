@@ -474,7 +474,17 @@ def main():
         c_ring = None
         if world > 1 and os.environ.get("PM355_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("PM355_RING_TRANSPORT", "c") == "c":
             from prima_cpp_amd.ring import CRing
-            c_ring = CRing(rank, world)
+            ok = torch.ones(1, device="cuda")
+            try:
+                c_ring = CRing(rank, world)
+            except Exception as e:                       # every rank must take the same path: agree on it below
+                print(f"[rank {rank}] C ring transport unavailable ({e}); falling back to torch.distributed", file=sys.stderr, flush=True)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() < 1:
+                if c_ring is not None:
+                    c_ring.close()
+                c_ring = None
         drv = RingDriver(comp, rank, world, c_ring=c_ring)
         rng = np.random.default_rng(1234)
         prompt = rng.integers(0, hp["n_vocab"], size=(world, a.prompt))

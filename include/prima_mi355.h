@@ -175,6 +175,13 @@ PM355_API int pm355_attn_decode_split(const float * q_rot, const void * k_cache,
 PM355_API int pm355_attn_prefill(const float * q, const void * k_cache, const void * v_cache, const int32_t * d_pos0,
                                  float * out, int n_tokens, int n_head, int n_head_kv, int head_dim, int n_ctx,
                                  float kq_scale, pm355_stream_t stream);
+/* ggml-graph form of pm355_attn_prefill: the node chain MUL_MAT(k, q) SOFT_MAX(kq, KQ_mask, scale) MUL_MAT(v, kq) PERMUTE CONT of
+ * llm_build_kqv (src/llama.cpp:10062-10148) for a multi-token batch. q = the ROTATED queries [n_tokens][n_head*head_dim] f32, the caches
+ * already hold the batch; every query attends cells [0, n_kv) with its row of the additive F32 KQ_mask [n_kv per row, mask_stride floats
+ * apart] (any mask the reference builds, not just causal). */
+PM355_API int pm355_attn_prefill_masked(const float * q, const void * k_cache, const void * v_cache, const float * mask, int64_t mask_stride,
+                                        float * out, int n_tokens, int n_head, int n_head_kv, int head_dim, int n_ctx, int n_kv,
+                                        float kq_scale, pm355_stream_t stream);
 /* single-token fusion of the two entries above (rope on q,k + KV store + attention in ONE launch; what the engine
  * uses at decode). q/k/v are the raw projections of ONE token; the caches receive the new K row / V column. */
 PM355_API int pm355_attn_rope_fused(const float * q, const float * k, const float * v, void * k_cache, void * v_cache,

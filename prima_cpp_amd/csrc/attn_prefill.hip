@@ -30,6 +30,9 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 struct PfP {
     const float * q; const uint16_t * kc; const uint16_t * vc; const int32_t * pos0_ptr; const int32_t * seq_ptr; long seq_stride;
     float * out; int T, H, Hkv, n_ctx; float scale;
+    // ggml-graph mode (mask != nullptr; pm355_attn_prefill_masked): every query attends cells [0, n_kv) with the additive F32 KQ_mask
+    // row of its token (0 / -inf; llama_set_inputs src/llama.cpp:17379-17420) instead of the causal rule "cell <= position"
+    const float * mask; long mask_stride; int n_kv;
 };
 
 // key index (inside a 32-key tile) of accumulator register r in lane-half h: C[row = (r&3) + 8 (r>>2) + 4 h][col]
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
     const int col = lane & 31, hf = lane >> 5;
     const int h = blockIdx.y, hk = h / (p.H / p.Hkv);
     const int seq = p.seq_ptr ? *p.seq_ptr : 0;
-    const int pos0 = p.pos0_ptr[seq];
+    const int pos0 = p.mask ? 0 : p.pos0_ptr[seq];
     const uint16_t * kc = p.kc + (long) seq * p.seq_stride + (long) hk * DH;          // K[key][Hkv*DH]
     const uint16_t * vc = p.vc + (long) seq * p.seq_stride + (long) hk * DH * p.n_ctx; // V^T[hk*DH + e][n_ctx]
     const int tq0 = blockIdx.x * 128 + wave * 32;                                      // first query token of this wave
@@ -51,8 +54,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
     const int tq = min(tq0 + col, p.T - 1);                                            // this lane's query (clamped)
     const int qpos = pos0 + tq;                                                        // attends keys 0 .. qpos
     const int last = pos0 + min(tq0 + 31, p.T - 1);                                    // wave-uniform causal limit
-    const int n_tiles = last / 32 + 1;
+    const int n_tiles = p.mask ? (p.n_kv + 31) / 32 : last / 32 + 1;
     const long krow = (long) p.Hkv * DH;
+    const float * mrow = p.mask ? p.mask + (long) tq * p.mask_stride : nullptr;
 
     // Q^T as B operand: lane (col = query, hf) holds q[query][16 kk + 8 hf .. +8], rounded to F16 like the reference
     half8 qf[KK];
@@ -76,6 +80,16 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
         for (int kk = 0; kk < KK; ++kk) kf[kk] = *(const half8 *) (kr + 16 * kk);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[kk], acc, 0, 0, 0);
+        if (mrow) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                            // registers 4g .. 4g+3 = keys j*32 + 8g + 4hf .. +4: one float4 of the mask row
+                const int k0 = j * 32 + 8 * g + 4 * hf;
+                const float4 mv = k0 + 3 < p.n_kv ? *(const float4 *) (mrow + k0) : float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                s[4 * g + 0] = acc[4 * g + 0] * p.scale + mv.x; s[4 * g + 1] = acc[4 * g + 1] * p.scale + mv.y;
+                s[4 * g + 2] = acc[4 * g + 2] * p.scale + mv.z; s[4 * g + 3] = acc[4 * g + 3] * p.scale + mv.w;
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = j * 32 + acc_row(r, hf);
@@ -162,9 +176,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
 
 // n_ctx % 32 == 0 and head_dim 64 / 128 only (callers fall back to the per-token kernel otherwise)
 int pm_launch_attn_prefill(const float * q, const void * kc, const void * vc, const int32_t * pos0, const int32_t * seq,
-                           long seq_stride, float * out, int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st) {
+                           long seq_stride, float * out, int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st,
+                           const float * mask, long mask_stride, int n_kv) {
     if ((dh != 64 && dh != 128) || n_ctx % 32 || n_tok < 1) return -1;
-    PfP p = {q, (const uint16_t *) kc, (const uint16_t *) vc, pos0, seq, seq_stride, out, n_tok, H, Hkv, n_ctx, scale};
+    if (mask && (n_kv < 1 || n_kv > n_ctx || n_kv % 4 || mask_stride % 4)) return -1;
+    PfP p = {q, (const uint16_t *) kc, (const uint16_t *) vc, pos0, seq, seq_stride, out, n_tok, H, Hkv, n_ctx, scale, mask, mask_stride, n_kv};
     const dim3 grid((n_tok + 127) / 128, H);
     if (dh == 128) hipLaunchKernelGGL(attn_prefill_kernel<128>, grid, dim3(256), 0, st, p);
     else           hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, dim3(256), 0, st, p);

@@ -216,6 +216,14 @@ int pm355_attn_prefill(const float * q, const void * kc, const void * vc, const 
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_attn_prefill_masked(const float * q, const void * kc, const void * vc, const float * mask, int64_t mask_stride, float * out,
+                              int n_tokens, int H, int Hkv, int dh, int n_ctx, int n_kv, float kq_scale, pm355_stream_t st) {
+    if (!mask) return fail(PM355_E_SHAPE, "attn_prefill_masked: mask required");
+    if (pm_launch_attn_prefill(q, kc, vc, nullptr, nullptr, 0, out, n_tokens, H, Hkv, dh, n_ctx, kq_scale, S(st), mask, (long) mask_stride, n_kv))
+        return fail(PM355_E_RANGE, "attn_prefill_masked: head_dim 64/128, n_ctx % 32 == 0, n_kv % 4 == 0 <= n_ctx required");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 int pm355_attn_rope_fused(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * d_pos0,
                           const float * ff, float * out, int H, int Hkv, int dh, int n_ctx, float kq_scale,
                           const pm355_rope_params * rp, pm355_stream_t st) {

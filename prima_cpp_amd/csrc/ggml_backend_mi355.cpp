@@ -441,6 +441,10 @@ bool run_plan(backend_ctx * c, struct ggml_cgraph * g, const mi355::plan & p) {
             case mi355::STEP_ATTN:
                 MI355_CHECK(pm355_attn_token(&s.attn, &s.rope, c->stream));
                 break;
+            case mi355::STEP_ATTN_BATCH:
+                MI355_CHECK(pm355_attn_prefill_masked(s.ab.q, s.ab.kc, s.ab.vc, s.ab.mask, s.ab.mask_stride, s.ab.out, s.ab.n_tokens, s.ab.n_head,
+                                                      s.ab.n_head_kv, s.ab.head_dim, s.ab.n_ctx, s.ab.n_kv, s.ab.scale, c->stream));
+                break;
             default: {
                 struct ggml_tensor * node = ggml_graph_node(g, s.node);
                 if (!compute_node(c, node)) {
@@ -454,6 +458,7 @@ bool run_plan(backend_ctx * c, struct ggml_cgraph * g, const mi355::plan & p) {
 }
 
 void print_plan(const backend_ctx * c, struct ggml_cgraph * g, const mi355::plan & p, int32_t cell, int32_t n_kv) {
+    if (p.n_attn_batch) fprintf(stderr, "ggml-mi355 plan: %d multi-token attention chain(s) -> MFMA masked attention\n", p.n_attn_batch);
     fprintf(stderr, "ggml-mi355 plan: %d nodes -> %zu launches (%d fused mat-vec, %d attention, %d node-equivalent; %d nodes fused) single_token=%d "
                     "cell=%d n_kv=%d graphable=%d\n", ggml_graph_n_nodes(g), p.steps.size(), p.n_gemv, p.n_attn, p.n_node, p.n_fused_nodes,
             (int) p.single_token, cell, n_kv, (int) (p.single_token && p.fast_ok));
@@ -464,6 +469,9 @@ void print_plan(const backend_ctx * c, struct ggml_cgraph * g, const mi355::plan
             for (int j = 0; j < s.njobs; ++j) fprintf(stderr, " {%s N=%lld%s%s%s}", ggml_type_name((enum ggml_type) s.job[j].type), (long long) s.job[j].N,
                                                      s.job[j].W2 ? " pair" : "", s.job[j].bias ? " +bias" : "", s.job[j].resid ? " +resid" : "");
             fprintf(stderr, "\n");
+        } else if (s.kind == mi355::STEP_ATTN_BATCH) {
+            fprintf(stderr, "  [%d,%d) batch attention T=%d H=%d Hkv=%d dh=%d n_kv=%d (MFMA, masked)\n", s.node_lo, s.node_hi, s.ab.n_tokens, s.ab.n_head,
+                    s.ab.n_head_kv, s.ab.head_dim, s.ab.n_kv);
         } else if (s.kind == mi355::STEP_ATTN) {
             fprintf(stderr, "  [%d,%d) attention H=%d Hkv=%d dh=%d n_ctx=%d %s mask=%d ff=%d\n", s.node_lo, s.node_hi, s.attn.n_head, s.attn.n_head_kv, s.attn.head_dim,
                     s.attn.n_ctx, s.attn.split ? "split" : "fused", s.attn.mask != nullptr, s.attn.freq_factors != nullptr);

@@ -33,7 +33,7 @@
 
 namespace mi355 {
 
-enum step_kind : int32_t { STEP_NODE = 0, STEP_GEMV = 1, STEP_ATTN = 2 };
+enum step_kind : int32_t { STEP_NODE = 0, STEP_GEMV = 1, STEP_ATTN = 2, STEP_ATTN_BATCH = 3 };
 
 struct tensor_fp {                                   // everything a node-equivalent kernel reads from a tensor
     const void * data; int32_t type; int32_t pad_; int64_t ne[4]; size_t nb[4];
@@ -49,6 +49,9 @@ struct step {
     int64_t K; int32_t njobs; float eps; const float * x; const float * norm_w; pm355_matvec_job job[3];
     // STEP_ATTN
     pm355_attn_token_args attn; pm355_rope_params rope;
+    // STEP_ATTN_BATCH (multi-token): pm355_attn_prefill_masked
+    struct { const float * q; const void * kc, * vc; const float * mask; int64_t mask_stride; float * out;
+             int32_t n_tokens, n_head, n_head_kv, head_dim, n_ctx, n_kv; float scale; int32_t pad_; } ab;
     // STEP_NODE
     node_fp fp;
 };
@@ -60,7 +63,7 @@ struct plan {
     bool fast_ok = true;                             // no view with a non-zero offset other than the KV cell views handled via `dyn`
     int  i_kcell = -1, i_kview = -1;                 // graph indices: CPY into the K cell view (-> cell), VIEW k (ne[1] = cells attended)
     int  n_fused_nodes = 0;
-    int  n_gemv = 0, n_attn = 0, n_node = 0;
+    int  n_gemv = 0, n_attn = 0, n_node = 0, n_attn_batch = 0;
 };
 
 struct plan_ctx {                                    // what the backend provides to the planner
@@ -149,6 +152,7 @@ public:
                 if (!adv) adv = try_norm_matvec(p, i);
                 if (!adv) adv = try_matvec_resid(p, i);
             }
+            if (!adv && c_.fuse && !p.single_token) adv = try_batch_attention(p, i);
             if (adv) { p.n_fused_nodes += adv; i += adv; continue; }
             emit_node(p, i);
             ++i;
@@ -439,6 +443,61 @@ private:
             }
         }
         return 0;
+    }
+
+    // ---- multi-token batches (prompt processing): VIEW(v) VIEW(k) PERMUTE(q) | MUL_MAT(k,q) SOFT_MAX(mask) MUL_MAT(v,kq) PERMUTE CONT of
+    //      llm_build_kqv -> ONE launch of the MFMA attention with the additive mask (pm355_attn_prefill_masked). The rotations and the
+    //      KV-store copies in front of it stay node-equivalent (the graph's Qcur / Kcur / Vcur buffers alias each other, so the chain can
+    //      only be entered after ROPE materialised q and the cache holds the batch).
+    int try_batch_attention(plan & p, int i0) {
+        const ggml_tensor * vv = nullptr, * kv = nullptr, * qp = nullptr;
+        int i = i0;
+        for (int r = 0; r < 3; ++r) {
+            const ggml_tensor * t = N(i);
+            if (!t) return 0;
+            if (t->op == GGML_OP_VIEW && t->view_src && t->type == GGML_TYPE_F16 && !kv && t->nb[1] > t->nb[2] && t->ne[3] == 1) kv = t;   // k [dh, n_kv, Hkv]: nb1 = cache row > nb2 = dh*2 (v: nb1 = n_ctx*2 < nb2)
+            else if (t->op == GGML_OP_VIEW && t->view_src && t->type == GGML_TYPE_F16 && !vv) vv = t;
+            else if (t->op == GGML_OP_PERMUTE && !qp) qp = t;
+            else return 0;
+            ++i;
+        }
+        if (!vv || !kv || !qp) return 0;
+        const ggml_tensor * kq = N(i), * sm = N(i + 1), * kqv = N(i + 2), * pm = N(i + 3), * ct = N(i + 4);
+        if (!kq || !sm || !kqv || !pm || !ct) return 0;
+        if (kq->op != GGML_OP_MUL_MAT || sm->op != GGML_OP_SOFT_MAX || kqv->op != GGML_OP_MUL_MAT || pm->op != GGML_OP_PERMUTE || ct->op != GGML_OP_CONT) return 0;
+        const ggml_tensor * kcache = kv->view_src, * vcache = vv->view_src;
+        if (kcache->view_src || vcache->view_src || kcache->op != GGML_OP_NONE || vcache->op != GGML_OP_NONE || !ggml_is_contiguous(kcache) || !ggml_is_contiguous(vcache)) return 0;
+        if (kv->data != kcache->data || vv->data != vcache->data) return 0;
+        const int64_t dh = kv->ne[0], n_kv = kv->ne[1], Hkv = kv->ne[2];
+        const ggml_tensor * qr = qp->src[0];                            // the rotated queries [dh, H, T] f32 contiguous
+        if (!qr || qr->type != GGML_TYPE_F32 || !ggml_is_contiguous(qr) || qr->ne[0] != dh || qr->ne[3] != 1) return 0;
+        const int64_t H = qr->ne[1], T = qr->ne[2];
+        if (T < 2 || (dh != 64 && dh != 128) || Hkv < 1 || H % Hkv) return 0;
+        if (kv->nb[0] != 2 || kv->nb[1] != (size_t) (Hkv * dh * 2) || kv->nb[2] != (size_t) (dh * 2)) return 0;
+        const int64_t n_ctx = (int64_t) (vv->nb[1] / 2);
+        if (vv->ne[0] != n_kv || vv->ne[1] != dh || vv->ne[2] != Hkv || vv->ne[3] != 1 || vv->nb[0] != 2 || vv->nb[2] != (size_t) (n_ctx * dh * 2)) return 0;
+        if (n_ctx <= 0 || n_ctx % 32 || n_kv > n_ctx || n_kv % 4 || (int64_t) ggml_nelements(kcache) < n_ctx * Hkv * dh || (int64_t) ggml_nelements(vcache) < n_ctx * Hkv * dh) return 0;
+        if (qp->data != qr->data || qp->ne[0] != dh || qp->ne[1] != T || qp->ne[2] != H || qp->nb[0] != 4 || qp->nb[1] != (size_t) (H * dh * 4) || qp->nb[2] != (size_t) (dh * 4)) return 0;
+        if (kq->src[0] != kv || kq->src[1] != qp || kq->type != GGML_TYPE_F32 || kq->ne[0] != n_kv || kq->ne[1] != T || kq->ne[2] != H) return 0;
+        const ggml_tensor * mask = sm->src[1];
+        float scale, max_bias; memcpy(&scale, sm->op_params, 4); memcpy(&max_bias, (const float *) sm->op_params + 1, 4);
+        if (sm->src[0] != kq || max_bias != 0.0f || !mask || mask->type != GGML_TYPE_F32 || mask->ne[0] != n_kv || mask->ne[1] < T || mask->nb[0] != 4 ||
+            mask->nb[1] % 16 || mask->ne[2] != 1 || mask->ne[3] != 1) return 0;
+        if (kqv->src[0] != vv || kqv->src[1] != sm || kqv->ne[0] != dh || kqv->ne[1] != T || kqv->ne[2] != H) return 0;
+        if (pm->src[0] != kqv || ct->src[0] != pm || ct->type != GGML_TYPE_F32 || !ggml_is_contiguous(ct) || ct->ne[0] != H * dh || ct->ne[1] != T ||
+            pm->ne[0] != dh || pm->ne[1] != H || pm->ne[2] != T) return 0;
+        const int hi = i + 5, out_idx = hi - 1;
+        if (!range_private(i0, hi, &out_idx, 1)) return 0;
+        if (overlap(ct->data, ggml_nbytes(ct), qr->data, ggml_nbytes(qr))) return 0;       // every query row is read by 1 workgroup, written by it last
+        step s; memset(&s, 0, sizeof(s));
+        s.kind = STEP_ATTN_BATCH; s.node = -1; s.node_lo = i0; s.node_hi = hi;
+        s.ab.q = (const float *) qr->data; s.ab.kc = kcache->data; s.ab.vc = vcache->data; s.ab.mask = (const float *) mask->data;
+        s.ab.mask_stride = (int64_t) (mask->nb[1] / 4); s.ab.out = (float *) ct->data;
+        s.ab.n_tokens = (int32_t) T; s.ab.n_head = (int32_t) H; s.ab.n_head_kv = (int32_t) Hkv; s.ab.head_dim = (int32_t) dh;
+        s.ab.n_ctx = (int32_t) n_ctx; s.ab.n_kv = (int32_t) n_kv; s.ab.scale = scale;
+        p.steps.push_back(s);
+        ++p.n_attn_batch;
+        return hi - i0;
     }
 
     // ---- launches 3 and 5: MUL_MAT(W, x) [ADD(mm, residual)] with the f32 row quantized in the kernel prologue -----------------

@@ -44,3 +44,5 @@ def test_decode_graph_lowers_to_five_launches_per_layer(name, nodes, tmp_path):
     # the 3-token prompt batch: nothing fused, not a hipGraph candidate
     prefill = [p for p in layer if p[6] == 0]
     assert prefill and all(p[2] == 0 and p[3] == 0 and p[9] == 0 for p in prefill), prefill
+    # ... except the attention chain of every layer, which becomes one launch of the masked MFMA attention
+    assert f"{n_layer} multi-token attention chain(s) -> MFMA masked attention" in st["stderr"]
