@@ -222,8 +222,8 @@ PM355_API int pm355_scale(const float * a, float * y, float s, int64_t n, pm355_
  * mat-vec's access pattern (one 1024-thread workgroup per CU x wg_per_cu, every wave reads its own contiguous span with
  * `unroll` (4 or 8) 16-byte non-temporal loads in flight per lane); `sink` = 4 writable bytes. Not on the product path. */
 PM355_API int pm355_probe_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, pm355_stream_t stream);
-/* measurement helper: average cost (microseconds) of one device-wide barrier of the persistent decode kernel
- * (decode_kernel.hip), measured on a kernel of n_phases empty phases. Not on the product path. */
+/* measurement helper: average cost (microseconds) of one split device-wide barrier (the one inside the opt-in two-phase
+ * attention + wo kernel, attn_wo.hip), measured on a kernel of n_phases empty phases. Not on the product path. */
 PM355_API int pm355_probe_grid_barrier(int n_phases, float * us_per_barrier, pm355_stream_t stream);
 /* synthetic weights generated directly in HBM (bench): random VALID blocks of `type`, |w| ~ scale */
 PM355_API int pm355_fill_random_blocks(int type, void * dst, int64_t K, int64_t nrows, uint64_t seed, float scale,

@@ -1,5 +1,5 @@
 // attn_device.h — device code of the fused single-token attention (RoPE + KV store + K.q + softmax + V.p), shared by
-// layer_ops.hip's stand-alone launch and the persistent per-token kernel (decode_kernel.hip). Design notes: layer_ops.hip.
+// layer_ops.hip's stand-alone launch and the two-phase attention + wo kernel (attn_wo.hip). Design notes: layer_ops.hip.
 #pragma once
 #include "pm355_device.h"
 
@@ -35,12 +35,12 @@ struct AttnP {
     const int32_t * dyn; const float * mask;
 };
 
-// Body of one query head `h`. Written for 256 ACTIVE threads; a larger workgroup (the persistent kernel's 1024) passes
+// Body of one query head `h`. Written for 256 ACTIVE threads; a larger workgroup (attn_wo.hip) passes
 // its extra threads through: they only take part in the barriers.
 template <int DH, bool COH>
 __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * smem, float * redf /*[8]*/, double * redd /*[4]*/) {
     // all of these are device-global memory: the explicit address space keeps the accesses global_* (not FLAT) when the
-    // pointers come out of a descriptor in memory (persistent kernel)
+    // pointers may come out of a descriptor in memory
     const PM_G float * q = (const PM_G float *) a.q, * k = (const PM_G float *) a.k, * v = (const PM_G float *) a.v;
     PM_G uint16_t * kc = (PM_G uint16_t *) a.kc, * vc = (PM_G uint16_t *) a.vc;
     const PM_G int32_t * pos0_ptr = (const PM_G int32_t *) a.pos0_ptr, * seq_ptr = (const PM_G int32_t *) a.seq_ptr; const long seq_stride = a.seq_stride;

@@ -5,7 +5,7 @@
 //   phase 0: workgroups 0 .. H-1 run the attention of their head (attn_device.h, same code as the stand-alone kernel) and publish
 //            the head's output write-through; all others fall through
 //   phase 1: the wo mat-vec (+ residual) of mmvq_device.h in its persistent-kernel form: weight loads are put in flight FIRST, then
-//            the workgroup waits for all heads (split device-wide barrier of decode_kernel.hip: two-level arrival, release flags,
+//            the workgroup waits for all heads (split device-wide barrier of mmvq_device.h: two-level arrival, release flags,
 //            bounded spin), quantizes the attention output and runs its rows
 // so the wo weights travel from HBM while the attention latency chain runs, and one launch boundary disappears.
 // 512-thread workgroups (PM_GEMV_BLOCK below): the attention body keeps a K row per thread in registers and does not fit the
@@ -36,7 +36,22 @@ __global__ __launch_bounds__(PM_GEMV_BLOCK, 2) void attn_wo_kernel(AttnP a, Gemv
     grid_arrive(GridBar{ctr, err, 1u, NG, G / NG, 1u});
 }
 
+// measurement: n empty phases = n device-wide barriers (pm355_probe_grid_barrier)
+__global__ __launch_bounds__(PM_GEMV_BLOCK, 2) void barrier_probe_kernel(int n, unsigned * ctr, int * err) {
+    const unsigned G = gridDim.x, NG = (G % 16 == 0) ? 16 : 1;
+    for (int ph = 0; ph < n; ++ph) {
+        const GridBar bar = {ctr, err, (unsigned) ph, NG, G / NG, ph == n - 1 ? 1u : 0u};
+        grid_wait(bar);
+        grid_arrive(bar);
+    }
+}
+
 } // namespace
+
+// n device-wide barriers in one launch on `ctr` (pm_attn_wo_bar_bytes() of zeroed device memory; left zeroed)
+void pm_launch_barrier_probe(int n, void * ctr, hipStream_t st) {
+    hipLaunchKernelGGL(barrier_probe_kernel, dim3(pm_device_cus()), dim3(PM_GEMV_BLOCK), 0, st, n, (unsigned *) ctr, (int *) ((char *) ctr + PM_BAR_BYTES));
+}
 
 // Launches attention + wo of one layer as one kernel; -1 when this shape / type has no such kernel (caller keeps the two launches).
 // `ctr` = PM_ATTN_WO_BAR_BYTES of zero-initialised device memory (the kernel leaves it zeroed), err = watchdog flag (int).

@@ -286,25 +286,28 @@ int pm355_probe_stream_read(const void * src, size_t bytes, int wg_per_cu, int u
     if (pm_launch_stream_read(src, bytes, wg_per_cu, unroll, sink, S(st))) return fail(PM355_E_SHAPE, "probe_stream_read: buffer too small");
     HIP_TRY(hipGetLastError()); return 0;
 }
-/* measurement helper: one persistent kernel of n_phases empty phases; returns the average microseconds per device-wide
- * barrier in *us_per_barrier */
+/* measurement helper: one kernel of n_phases empty phases separated by the split device-wide barrier of mmvq_device.h;
+ * returns the average microseconds per barrier in *us_per_barrier */
 int pm355_probe_grid_barrier(int n_phases, float * us_per_barrier, pm355_stream_t st) {
-    pm_decode_plan * pl = pm_decode_plan_new();
-    pm_decode_plan_add_nop(pl, n_phases);
-    if (pm_decode_plan_finish(pl)) { pm_decode_plan_free(pl); return fail(PM355_E_HIP, "probe_grid_barrier: plan"); }
+    void * ctr = nullptr;
+    const size_t nb = pm_attn_wo_bar_bytes();
+    if (n_phases < 1) return fail(PM355_E_RANGE, "probe_grid_barrier: n_phases");
+    HIP_TRY(hipMalloc(&ctr, nb));
+    (void) hipMemset(ctr, 0, nb);
     hipEvent_t e0, e1;
     (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
-    (void) pm_decode_plan_launch(pl, S(st));
+    pm_launch_barrier_probe(n_phases, ctr, S(st));
     (void) hipStreamSynchronize(S(st));
     (void) hipEventRecord(e0, S(st));
-    (void) pm_decode_plan_launch(pl, S(st));
+    pm_launch_barrier_probe(n_phases, ctr, S(st));
     (void) hipEventRecord(e1, S(st));
     (void) hipStreamSynchronize(S(st));
     float ms = 0.0f;
     (void) hipEventElapsedTime(&ms, e0, e1);
-    const int err = pm_decode_plan_error(pl);
+    int err = 0;
+    (void) hipMemcpy(&err, (char *) ctr + nb - 64, 4, hipMemcpyDeviceToHost);
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
-    pm_decode_plan_free(pl);
+    (void) hipFree(ctr);
     if (us_per_barrier) *us_per_barrier = ms * 1e3f / (float) n_phases;
     return err ? fail(PM355_E_HIP, "probe_grid_barrier: watchdog fired") : 0;
 }

@@ -43,10 +43,6 @@ struct pm355_model {
     int32_t * d_pos = nullptr, * d_tok = nullptr, * d_ctl = nullptr;   // d_pos[n_seq]; d_ctl = {current seq, n_seq}
     int n_seq = 1;
     bool no_fuse = false;                 // PM355_NO_FUSE=1: node-by-node kernels (debug / A-B)
-    // EXPERIMENTAL persistent per-token kernel (decode_kernel.hip, PM355_PERSISTENT=1; default off: measured 9.5 ms vs
-    // 8.6 ms per 70B token for the 5-launch path): one plan per distinct (input, output, logits) pointer set; plans live as
-    // long as the model (captured graphs reference their device tables).
-    bool persistent = false;
     // EXPERIMENT (PM355_ATTN_WO=1, attn_wo.hip): attention + wo as ONE two-phase launch per layer - every workgroup first puts its wo
     // weight loads in flight, the 64 head workgroups run the latency-bound attention meanwhile, one device-wide barrier, then the wo
     // mat-vec: 4 launches per layer instead of 5. Bit-identical, but the barrier + first-touch fetch of the heads' outputs costs what
@@ -62,15 +58,11 @@ struct pm355_model {
     hipStream_t copy_stream = nullptr;
     size_t slot_bytes[12] = {};
     uint64_t streamed_bytes = 0; void * aw_ctr = nullptr;       // barrier state of that kernel (zero between launches) + watchdog flag
-    struct Plan { const void * in; void * out, * lg; bool head; pm_decode_plan * pl; };
-    std::vector<Plan> plans;
     // long-context decode attention (attn_split.hip): the host mirrors the device position counters to choose, per step, between
     // the fused one-workgroup-per-head kernel and the keys-split-over-workgroups path (different launch sequences = different
     // captured graphs). PM355_ATTN_SPLIT_MIN positions (default 640: measured crossover on the 70B head shape).
     float * split_scratch = nullptr;
     std::vector<int> h_pos; int h_seq = 0; int split_min = 640; bool long_ctx = false;
-    pm_decode_plan * rec = nullptr;       // plan being recorded: the launch helpers append phases instead of launching
-    float * slab = nullptr; size_t slab_stride = 0;   // per-layer activation scratch of the persistent kernel (each buffer written once per kernel)
     // staging for set_tensor
     void * pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2]; void * dstage = nullptr; size_t stage_bytes = 0;
     hipStream_t up_stream = nullptr, cap_stream = nullptr;
@@ -277,7 +269,6 @@ int gemv_f32(pm355_model * m, const Tensor * const * ws, const Tensor * const * 
         f.job[j].type = ws[j]->type; f.job[j].N = (int) ws[j]->N; f.job[j].W = ws[j]->d; f.job[j].W2 = w2s ? (w2s[j] ? w2s[j]->d : nullptr) : nullptr;
         f.job[j].y = ys[j]; f.job[j].bias = biases ? biases[j] : nullptr; f.job[j].resid = resids ? resids[j] : nullptr;
     }
-    if (m->rec) return pm_decode_plan_add_gemv(m->rec, f);
     return pm_launch_gemv_fused(f, st);
 }
 
@@ -293,42 +284,34 @@ int run_head(pm355_model * m, const float * x_row, float * d_logits, int32_t * d
         ActQ a = norm_quantize_for(m, x_row, (const float *) m->out_norm.d, m->hp.n_embd, 1, ow, 1, st);
         if (gemv(m->output, nullptr, a, 1, lg, nullptr, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "head: lm_head gemv");
     }
-    if (d_argmax && !m->rec) pm_launch_argmax(lg, m->hp.n_vocab, d_argmax, nullptr, st);
+    if (d_argmax) pm_launch_argmax(lg, m->hp.n_vocab, d_argmax, nullptr, st);
     return 0;
 }
 
-// the single-token layer sequence (5 launches per layer, or 5 phases when a plan is being recorded)
+// the single-token layer sequence (5 launches per layer)
 int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const float ** cur_out, hipStream_t st) {
     const pm355_hparams & hp = m->hp;
-    const int E = hp.n_embd, H = hp.n_head, Hkv = hp.n_head_kv, dh = hp.head_dim;
-    const int Eq = H * dh, Ekv = Hkv * dh;
+    const int H = hp.n_head, Hkv = hp.n_head_kv, dh = hp.head_dim;
     const float kq_scale = 1.0f / sqrtf((float) dh);
     float * bufs[2] = {m->x, m->x1};
     for (int il = m->lo; il < m->hi; ++il) {
         Layer Lv = layer_acquire(m, il, st); Layer & L = Lv;
-        // scratch: shared by all layers for the launch path; one private set per layer for the persistent kernel, where no
-        // buffer may be written twice within the kernel (readers use plain cached loads, see mmvq_device.h grid_wait)
         float * q = m->q, * k = m->k, * v = m->v, * att = m->att, * hbuf = m->h;
         float * x_mid = (cur == bufs[0]) ? bufs[1] : bufs[0];
         float * x_nxt = (x_mid == bufs[0]) ? bufs[1] : bufs[0];
-        if (m->rec) {
-            float * b = m->slab + (size_t) (il - m->lo) * m->slab_stride;
-            x_mid = b; x_nxt = b + E; q = b + 2 * E; k = q + Eq; v = k + Ekv; att = v + Ekv; hbuf = att + Eq;
-        }
         {
             const Tensor * ws[3] = {&L.t[PM355_T_WQ], &L.t[PM355_T_WK], &L.t[PM355_T_WV]};
             float * ys[3] = {q, k, v};
             const float * bs[3] = {(const float *) L.t[PM355_T_BQ].d, (const float *) L.t[PM355_T_BK].d, (const float *) L.t[PM355_T_BV].d};
             const float * nw = (const float *) L.t[PM355_T_ATTN_NORM].d;
             if (gemv_f32(m, ws, nullptr, ys, bs, nullptr, 3, cur, nw, st)) {
-                if (m->rec) return -1;
                 for (int j = 0; j < 3; ++j)               // type mix without a 3-job kernel: one launch per matrix
                     if (gemv_f32(m, ws + j, nullptr, ys + j, bs + j, nullptr, 1, cur, nw, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused qkv gemv");
             }
         }
         const long kvs = m->n_seq > 1 ? (long) hp.n_ctx * Hkv * dh : 0;     // one slab: the kernels may address the cache before the sequence id arrives
         bool aw_done = false;
-        if (!m->rec && m->attn_wo && m->aw_ctr && !m->long_ctx) {
+        if (m->attn_wo && m->aw_ctr && !m->long_ctx) {
             const Tensor & wo = L.t[PM355_T_WO];
             pm_gemv_fused f = {};
             f.K = (int) wo.K; f.njobs = 1; f.xf = att; f.eps = hp.rms_eps;
@@ -337,9 +320,6 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
                                         hp.n_ctx, kq_scale, m->rope, f, m->aw_ctr, st) == 0;
         }
         if (aw_done) {
-        } else if (m->rec) {
-            if (pm_decode_plan_add_attn(m->rec, q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d,
-                                        att, H, Hkv, dh, hp.n_ctx, kq_scale, m->rope)) return -1;
         } else if (m->long_ctx) {
             // long context: the keys split over n_ctx/128 x n_head_kv workgroups, rope + KV store in the first kernel (attn_split.hip)
             if (pm_launch_attn_split(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d, att, m->split_scratch,
@@ -374,33 +354,6 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
     return 0;
 }
 
-// persistent-kernel plan for one (input, output, logits) pointer set: found or recorded now (nullptr: not available)
-pm_decode_plan * get_plan(pm355_model * m, const float * cur, float * d_x_out, float * lg, bool head) {
-    if (!m->persistent || m->no_fuse || m->hi <= m->lo || m->long_ctx) return nullptr;
-    for (auto & p : m->plans) if (p.in == cur && p.out == d_x_out && p.lg == lg && p.head == head) return p.pl;
-    if (m->plans.size() >= 16) return nullptr;
-    if (!m->slab) {
-        const pm355_hparams & hp = m->hp;
-        const size_t per = (size_t) 2 * hp.n_embd + 2 * (size_t) hp.n_head * hp.head_dim + 2 * (size_t) hp.n_head_kv * hp.head_dim + hp.n_ff;
-        m->slab_stride = (per + 63) & ~(size_t) 63;                     // 256-byte aligned sets: no cache line is shared
-        if (hipMalloc((void **) &m->slab, m->slab_stride * 4 * (size_t) (m->hi - m->lo)) != hipSuccess) { m->slab = nullptr; m->persistent = false; return nullptr; }
-    }
-    pm_decode_plan * pl = pm_decode_plan_new();
-    m->rec = pl;
-    const float * end = nullptr;
-    int rc = run_layers_fused(m, cur, d_x_out, &end, nullptr);
-    if (!rc && head) rc = run_head(m, end, lg, nullptr, nullptr);
-    m->rec = nullptr;
-    if (!rc) rc = pm_decode_plan_finish(pl);
-    if (rc) {                                         // a type mix without phase code, or no memory: keep the 5-launch path
-        pm_decode_plan_free(pl);
-        m->persistent = false; m->err[0] = 0;
-        return nullptr;
-    }
-    m->plans.push_back({cur, d_x_out, lg, head, pl});
-    return pl;
-}
-
 // x_in -> x_out for layers [lo, hi); positions from device memory d_pos (pos of token 0)
 int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, int T, float * d_x_out,
                float * d_logits, int32_t * d_argmax, hipStream_t st) {
@@ -419,16 +372,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
     float * bufs[2] = {m->x, m->x1};
     if (T == 1 && !m->no_fuse) {
         m->long_ctx = m->split_scratch && m->h_pos[m->h_seq] >= m->split_min;
-        // ---- single token: every activation transform is fused into a mat-vec prologue / epilogue; one persistent kernel
-        //      for the whole window (decode_kernel.hip) or, without a plan, 5 launches per layer
-        const bool head = (d_logits || d_argmax) && (m->flags & PM355_HAS_HEAD);
-        float * lg = d_logits ? d_logits : m->logits;
-        if (pm_decode_plan * pl = get_plan(m, cur, d_x_out, head ? lg : nullptr, head)) {
-            if (pm_decode_plan_launch(pl, st)) return seterr(m, PM355_E_HIP, "decode: persistent kernel launch");
-            if (head && d_argmax) pm_launch_argmax(lg, m->hp.n_vocab, d_argmax, nullptr, st);
-            if (d_x_out && m->hi == m->lo) (void) hipMemcpyAsync(d_x_out, cur, (size_t) E * 4, hipMemcpyDeviceToDevice, st);
-            return hip_ok() ? 0 : seterr(m, PM355_E_HIP, "decode: kernel launch failed");
-        }
+        // ---- single token: every activation transform is fused into a mat-vec prologue / epilogue, 5 launches per layer
         const float * end = nullptr;
         int rc = run_layers_fused(m, cur, d_x_out, &end, st);
         if (rc) return rc;
@@ -537,7 +481,6 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     m->rope.ext_factor = 0.0f; m->rope.attn_factor = 1.0f; m->rope.beta_fast = 32.0f; m->rope.beta_slow = 1.0f;
     pm_rope_params(m->rope);
     { const char * e = getenv("PM355_NO_FUSE"); m->no_fuse = e && e[0] == '1'; }
-    { const char * e = getenv("PM355_PERSISTENT"); m->persistent = e && e[0] == '1'; }
     { const char * e = getenv("PM355_ATTN_WO"); m->attn_wo = e && e[0] == '1'; }       // measured: 8.74 vs 8.60 ms per 70B token -> opt-in experiment
     return m;
 }
@@ -546,12 +489,10 @@ void pm355_model_free(pm355_model * m) {
     if (!m) return;
     (void) hipDeviceSynchronize();
     for (auto & g : m->graphs) (void) hipGraphExecDestroy(g.exec);
-    for (auto & pl : m->plans) pm_decode_plan_free(pl.pl);
     if (m->aw_ctr) (void) hipFree(m->aw_ctr);
     if (m->copy_stream) { (void) hipStreamSynchronize(m->copy_stream); (void) hipStreamDestroy(m->copy_stream); }
     for (auto & S : m->slots) { for (auto p : S.d) if (p) (void) hipFree(p); if (S.ready) (void) hipEventDestroy(S.ready); if (S.free_) (void) hipEventDestroy(S.free_); }
     for (auto & L : m->layers) for (auto p : L.host) if (p) (void) hipHostFree(p);
-    if (m->slab) (void) hipFree(m->slab);
     for (auto & L : m->layers) { for (auto & t : L.t) if (t.d) (void) hipFree(t.d); if (L.kc) (void) hipFree(L.kc); if (L.vc) (void) hipFree(L.vc); }
     Tensor * g[4] = {&m->tok_embd, &m->out_norm, &m->output, &m->rope_freqs};
     for (auto t : g) if (t->d) (void) hipFree(t->d);
@@ -824,16 +765,6 @@ int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * 
             g.adv == advance && g.rot == rotate && g.head == head_first && g.regime == regime) { exec = g.exec; break; }
     if (!exec) {
         hipGraph_t g = nullptr;
-        // persistent-kernel plans are recorded and uploaded BEFORE the capture starts (synchronous copies)
-        {
-            const bool toks = d_token != nullptr;
-            const float * cur = toks ? m->x : d_x_in;
-            if (head_first) (void) get_plan(m, m->x, d_x_out, nullptr, false);
-            else {
-                const bool head = (d_logits || d_argmax) && (m->flags & PM355_HAS_HEAD);
-                (void) get_plan(m, cur, d_x_out, head ? (d_logits ? d_logits : m->logits) : nullptr, head);
-            }
-        }
         // capture on a private stream (the legacy default stream cannot capture); nothing executes during capture,
         // the instantiated graph is then launched on the caller's stream
         if (!m->cap_stream && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess)
@@ -856,12 +787,11 @@ int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * 
     return commit();
 }
 
-// Non-zero when a persistent kernel's barrier watchdog fired (a workgroup was never scheduled): results since then are
-// invalid. Synchronizes the device.
+// Non-zero when the barrier watchdog of the two-phase attention + wo kernel (PM355_ATTN_WO=1) fired (a workgroup was never
+// scheduled): results since then are invalid. Synchronizes the device.
 int pm355_model_check(pm355_model * m) {
     if (!m) return PM355_E_SHAPE;
     (void) hipDeviceSynchronize();
-    for (auto & p : m->plans) if (pm_decode_plan_error(p.pl)) return seterr(m, PM355_E_HIP, "persistent decode kernel: device-wide barrier timed out");
     if (m->aw_ctr) {
         int e = 0;
         if (hipMemcpy(&e, (char *) m->aw_ctr + pm_attn_wo_bar_bytes() - 64, 4, hipMemcpyDeviceToHost) == hipSuccess && e)

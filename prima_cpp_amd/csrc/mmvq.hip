@@ -101,7 +101,7 @@ size_t pm_weight_row_stride(int type, int64_t K) {
 
 // Validates a fused job list and fills the kernel argument block. ta <= tb are the (at most two) quant types in the
 // canonical order of the instantiated kernels: (Q4_K,Q4_K) (Q5_K,Q5_K) (Q6_K,Q6_K) (Q8_0,Q8_0) (Q4_K,Q6_K) (Q4_K,Q5_K); job 0 is
-// always a `ta` job (the kernel pre-issues it). grid_fixed > 0: the caller's grid (persistent kernel), else chosen here.
+// always a `ta` job (the kernel pre-issues it). grid_fixed > 0: the caller's grid (attn_wo.hip), else chosen here.
 int pmv::gemv_fill(const pm_gemv_fused & a, int grid_fixed, GemvP & p, int & ta_out, int & tb_out, bool & pair_out, size_t & lds_out, int & grid_out) {
     if (a.njobs < 1 || a.njobs > 3) return -4;
     p = GemvP{};

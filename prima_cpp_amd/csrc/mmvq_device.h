@@ -1,5 +1,5 @@
 // mmvq_device.h — device code of the batch-1 quantized mat-vec (shared by mmvq.hip's stand-alone launches and the
-// persistent per-token kernel of decode_kernel.hip). See mmvq.hip for the design notes.
+// two-phase attention + wo kernel of attn_wo.hip). See mmvq.hip for the design notes.
 #pragma once
 #include "pm355_device.h"
 #include "pm355_kernels.h"
@@ -571,7 +571,7 @@ __device__ __forceinline__ void write_out(const GemvJob & jb, const float * outb
     }
 }
 
-// Split-phase grid barrier of the persistent kernel (decode_kernel.hip): a phase first puts its weight loads in flight,
+// Split-phase grid barrier (used inside one launch by attn_wo.hip): a phase first puts its weight loads in flight,
 // THEN waits for the previous phase of all workgroups (whose outputs are its activations).
 // No cache maintenance inside the kernel: activations are WRITTEN with write-through device-scope stores (st_act) and
 // every activation buffer is written exactly once per kernel (the engine gives each layer its own scratch set), so a
@@ -626,7 +626,7 @@ __device__ __forceinline__ void grid_arrive(const GridBar & gb) {
     }
 }
 
-// The whole mat-vec of one workgroup. MEGA: called from the persistent kernel (p lives in global memory, `bar` is the
+// The whole mat-vec of one workgroup. MEGA: called as a later phase of a multi-phase launch (attn_wo.hip; p lives in global memory, `bar` is the
 // barrier to pass before the activations may be read); otherwise the body of gemv_q_kernel.
 template <int TA, int TB, bool PAIR, bool DBG, bool MEGA, int NC = 1>
 __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double * nred, const GridBar & bar) {
@@ -670,7 +670,7 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
     }
 #endif
 #endif
-    if (MEGA) { grid_wait(bar); stage_issue<ABLK, MEGA>(p, areg, wave, lane); }   // persistent kernel: the activations exist only now
+    if (MEGA) { grid_wait(bar); stage_issue<ABLK, MEGA>(p, areg, wave, lane); }   // multi-phase launch: the activations exist only now
     stage_finish<ABLK, MEGA>(p, areg, xs_q, xs_gs, xs_d, nred, wave, lane, NC, col_bytes);
     __syncthreads();
     const XLds xs = {xs_q, xs_gs, xs_d, col_bytes};

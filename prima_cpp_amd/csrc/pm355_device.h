@@ -29,8 +29,8 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // Weights are streamed exactly once per token: non-temporal (global_load ... nt) keeps them from
 // displacing the activation / KV working set in L2 (MI355X_MICROARCH.md "nt-weights").
 // Every pointer these helpers see is device-global memory. The explicit address-space cast makes the backend emit
-// global_load / global_store even where it cannot prove it (pointers read from a descriptor in memory inside the
-// persistent kernel's phase functions would otherwise become FLAT accesses, which count on vmcnt AND lgkmcnt and force
+// global_load / global_store even where it cannot prove it (pointers read from a descriptor in memory
+// would otherwise become FLAT accesses, which count on vmcnt AND lgkmcnt and force
 // s_waitcnt vmcnt(0) lgkmcnt(0) in the row loop).
 #define PM_G __attribute__((address_space(1)))
 __device__ __forceinline__ u32x4 ld_nt16(const void * p) { return __builtin_nontemporal_load((const PM_G u32x4 *) p); }
@@ -133,8 +133,8 @@ __device__ __forceinline__ void k4_scale_min_pair(uint32_t s0, uint32_t s1, uint
     m0  = (int) (m & 0xFF);  m1  = (int) (m >> 8);
 }
 
-// ---- device-coherent activation traffic of the persistent kernel ------------------------------------------------------
-// Activations written by one workgroup and read by another INSIDE one kernel (decode_kernel.hip) go through agent-scope
+// ---- device-coherent activation traffic inside one launch ------------------------------------------------------
+// Activations written by one workgroup and read by another INSIDE one kernel (attn_wo.hip) go through agent-scope
 // relaxed atomics: global_load / global_store ... sc1, which are coherent across the 8 XCD L2s without any cache
 // write-back / invalidate. COH = false: plain accesses (stand-alone launches: kernel boundaries do the maintenance).
 template <bool COH> __device__ __forceinline__ float ld_act(const float * p) {

@@ -70,21 +70,10 @@ int pm_launch_gemm_q_ex(int type, const void * W, const float * X, float * Y, in
 int pm_launch_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, hipStream_t st);
 int pm_device_cus();
 
-// ---- persistent per-token decode kernel (decode_kernel.hip): the 5 per-layer launches become PHASES of one kernel
-struct pm_decode_plan;
 struct pm_rope_cfg;
-pm_decode_plan * pm_decode_plan_new();
-void pm_decode_plan_free(pm_decode_plan * pl);
-int  pm_decode_plan_add_gemv(pm_decode_plan * pl, const pm_gemv_fused & f);          // 0, or < 0 when this type mix has no phase code
-int  pm_decode_plan_add_attn(pm_decode_plan * pl, const float * q, const float * k, const float * v, void * kc, void * vc,
-                             const int32_t * pos0, const int32_t * seq, long seq_stride, const float * freq_factors, float * out,
-                             int H, int Hkv, int dh, int n_ctx, float scale, const pm_rope_cfg & c);
-int  pm_decode_plan_finish(pm_decode_plan * pl);                                     // upload the phase table (synchronous)
-int  pm_decode_plan_launch(pm_decode_plan * pl, hipStream_t st);                     // counter reset + one kernel
-int  pm_decode_plan_error(pm_decode_plan * pl);                                      // watchdog flag (synchronizes)
-int  pm_decode_plan_add_nop(pm_decode_plan * pl, int n);                             // measurement: n empty phases (barriers only)
-// attention + wo mat-vec (+ residual) of one layer as ONE two-phase launch (decode_kernel.hip); -1: no kernel for this shape / type
+// attention + wo mat-vec (+ residual) of one layer as ONE two-phase launch (attn_wo.hip); -1: no kernel for this shape / type
 int  pm_launch_attn_wo(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos0, const int32_t * seq,
                        long seq_stride, const float * freq_factors, float * att, int H, int Hkv, int dh, int n_ctx, float scale,
                        const pm_rope_cfg & c, const pm_gemv_fused & f, void * ctr, hipStream_t st);
 size_t pm_attn_wo_bar_bytes();
+void pm_launch_barrier_probe(int n, void * ctr, hipStream_t st);       // measurement: n device-wide barriers in one launch

@@ -237,7 +237,7 @@ class Window:
         self._chk(self.lib.pm355_model_generate(self.h, ptr(tokens_io), pos0, n_steps, int(use_graph), stream_ptr()), "generate")
 
     def check(self):
-        """0, or non-zero once a persistent decode kernel's barrier watchdog fired (synchronizes the device)."""
+        """0, or non-zero once the barrier watchdog of the opt-in attention + wo kernel fired (synchronizes the device)."""
         return int(self.lib.pm355_model_check(self.h))
 
     def set_pos(self, pos):

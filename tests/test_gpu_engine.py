@@ -193,32 +193,6 @@ def test_prefill_mfma_path_vs_oracle(E, oracle, arch):
     w.close()
 
 
-def test_persistent_kernel_matches_launch_path(E, monkeypatch):
-    """The experimental persistent per-token kernel (PM355_PERSISTENT=1, decode_kernel.hip) runs the same device code as
-    the 5-launches-per-layer path behind device-wide barriers: greedy tokens, hidden state and logits are bit-identical."""
-    torch = E.torch
-    rng = np.random.default_rng(77)
-    d = tiny_model(rng, arch=0, n_layer=3, n_embd=512, n_head=4, n_head_kv=2, n_ff=1024, n_vocab=512, n_ctx=64, rope_freqs=True)
-    assert d.head_dim == 128
-    n, first = 12, 5
-    outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("PM355_PERSISTENT", flag)
-        w = E.Window(_hp(d), n_ctx=64)
-        w.load_desc(d); w.finalize(4)
-        io = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
-        io[0] = first
-        w.generate(io, 0, n, use_graph=True)
-        hid, lg, _ = w.decode(tokens=io[n:n + 1].clone(), pos0=n)
-        torch.cuda.synchronize()
-        assert w.check() == 0                             # the barrier watchdog never fired
-        outs.append((io.cpu().numpy(), hid.cpu().numpy(), lg.cpu().numpy()))
-        w.close()
-    assert np.array_equal(outs[0][0], outs[1][0])
-    assert np.array_equal(outs[0][1], outs[1][1])
-    assert np.array_equal(outs[0][2], outs[1][2])
-
-
 def test_long_context_split_attention_path(E, monkeypatch):
     """Beyond PM355_ATTN_SPLIT_MIN positions the engine switches from the one-workgroup-per-head attention kernel to the
     keys-split-over-workgroups path (attn_split.hip, 4 launches, other captured graph): same rounding points, so hidden state
