@@ -225,6 +225,11 @@ PM355_API int pm355_probe_stream_read(const void * src, size_t bytes, int wg_per
 /* measurement helper: average cost (microseconds) of one split device-wide barrier (the one inside the opt-in two-phase
  * attention + wo kernel, attn_wo.hip), measured on a kernel of n_phases empty phases. Not on the product path. */
 PM355_API int pm355_probe_grid_barrier(int n_phases, float * us_per_barrier, pm355_stream_t stream);
+/* measurement skeleton of a persistent decode layer on a run-ahead LDS-DMA weight loader (engine_probe.hip, tools/engine_probe.py):
+ * real byte counts and seams, stand-in consumer arithmetic. Not on the product path. */
+PM355_API int pm355_probe_engine(const void * w, int64_t region_stride, int n_regions, int n_layers, int nph, const int * chunks,
+                                 const int * act_n, const int * out_n, int attn_ph, float attn_us, float * act, int64_t act_stride,
+                                 void * ctr, int nw, int ns, int nt, int thin, float * us, int * err_out, pm355_stream_t stream);
 /* synthetic weights generated directly in HBM (bench): random VALID blocks of `type`, |w| ~ scale */
 PM355_API int pm355_fill_random_blocks(int type, void * dst, int64_t K, int64_t nrows, uint64_t seed, float scale,
                                        pm355_stream_t stream);

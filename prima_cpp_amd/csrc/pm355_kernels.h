@@ -69,6 +69,10 @@ int pm_launch_gemm_q_ex(int type, const void * W, const float * X, float * Y, in
 // measurement helper (probe.hip): stream `bytes` from HBM once with the mat-vec's access pattern
 int pm_launch_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, hipStream_t st);
 int pm_device_cus();
+// measurement skeleton of a persistent LDS-DMA loader / consumer decode layer (engine_probe.hip)
+int pm_launch_engine_probe(const void * w, long region_stride, int n_regions, int n_layers, int nph, const int * chunks, const int * act_n,
+                           const int * out_n, int attn_ph, float attn_us, float * act, long act_stride, void * ctr, int nw, int ns, int nt,
+                           int thin, hipStream_t st);
 
 struct pm_rope_cfg;
 // attention + wo mat-vec (+ residual) of one layer as ONE two-phase launch (attn_wo.hip); -1: no kernel for this shape / type
