@@ -77,6 +77,20 @@ PM355_API int    pm355_memcpy_d2h(void * dst, const void * src, size_t bytes, pm
 PM355_API int    pm355_memcpy_d2d(void * dst, const void * src, size_t bytes, pm355_stream_t stream);
 PM355_API int    pm355_memset(void * dst, int value, size_t bytes, pm355_stream_t stream);
 
+/* Asynchronous weight staging from host DRAM (upload.hip): pageable / mmap'd GGUF bytes -> ring of pinned chunks (filled by
+ * `copy_threads` copier threads; -1 = PM355_UPLOAD_THREADS or 4) -> hipMemcpyAsync on a private stream -> (row-SoA types) repack into
+ * the HBM layout, the three stages overlapped. Replaces the synchronous per-tensor ggml_backend_tensor_set(cur, mmap pointer, ...)
+ * upload of the reference's loader (src/llama.cpp:5580-5600 -> ggml-cuda.cu:503-511); its own pinned async path (:5432-5520) is
+ * disabled in this fork. pm355_upload returns once the last chunk is enqueued (the host bytes have been copied out);
+ * pm355_uploader_sync waits for the device side. repack=1: `type` matrices of K-weight rows, nbytes = whole rows, dev = first
+ * destination row in the HBM layout (pm355_row_stride apart); repack=0 or a type without re-ordering: plain bytes. */
+typedef struct pm355_uploader pm355_uploader;
+PM355_API pm355_uploader * pm355_uploader_new(size_t chunk_bytes /* 0 = 32 MiB */, int copy_threads);
+PM355_API void   pm355_uploader_free(pm355_uploader * u);
+PM355_API int    pm355_upload(pm355_uploader * u, int type, int64_t K, const void * host, void * dev, size_t nbytes, int repack);
+PM355_API int    pm355_uploader_sync(pm355_uploader * u);
+PM355_API uint64_t pm355_uploader_bytes(const pm355_uploader * u);
+
 /* ---- weight layout ------------------------------------------------------------------------------ */
 /* bytes of one row of K weights == ggml_row_size(type, K) (ggml/src/ggml.c:3579) */
 PM355_API size_t pm355_row_size(int type, int64_t K);

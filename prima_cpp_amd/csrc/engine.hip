@@ -64,8 +64,8 @@ struct pm355_model {
     float * split_scratch = nullptr;
     std::vector<int> h_pos; int h_seq = 0; int split_min = 640; bool long_ctx = false;
     // staging for set_tensor
-    void * pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2]; void * dstage = nullptr; size_t stage_bytes = 0;
-    hipStream_t up_stream = nullptr, cap_stream = nullptr;
+    pm355_uploader * up = nullptr;        // pinned ring + copier threads + private stream (upload.hip)
+    hipStream_t cap_stream = nullptr;
     hipStream_t side = nullptr; hipEvent_t side_a = nullptr, side_b = nullptr;   // prefill: wk and wv GEMMs (64 workgroups each) run side by side
     // captured single-token step graphs, keyed on everything that is baked into the kernel arguments
     struct StepGraph { const void * in, * tok; void * out, * logits, * argmax; int adv, rot, head, regime; hipGraphExec_t exec; };
@@ -496,10 +496,9 @@ void pm355_model_free(pm355_model * m) {
     for (auto & L : m->layers) { for (auto & t : L.t) if (t.d) (void) hipFree(t.d); if (L.kc) (void) hipFree(L.kc); if (L.vc) (void) hipFree(L.vc); }
     Tensor * g[4] = {&m->tok_embd, &m->out_norm, &m->output, &m->rope_freqs};
     for (auto t : g) if (t->d) (void) hipFree(t->d);
-    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->h2, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->dstage, m->split_scratch};
+    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->h2, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->split_scratch};
     for (auto p : s) if (p) (void) hipFree(p);
-    for (int i = 0; i < 2; ++i) if (m->pin[i]) { (void) hipHostFree(m->pin[i]); (void) hipEventDestroy(m->pin_ev[i]); }
-    if (m->up_stream) (void) hipStreamDestroy(m->up_stream);
+    pm355_uploader_free(m->up);
     if (m->cap_stream) (void) hipStreamDestroy(m->cap_stream);
     if (m->side) { (void) hipStreamDestroy(m->side); (void) hipEventDestroy(m->side_a); (void) hipEventDestroy(m->side_b); }
     delete m;
@@ -510,7 +509,7 @@ static int stream_park(pm355_model * m, int kind, int layer) {
     if (!m->n_slots || kind >= 12) return 0;
     Layer & L = m->layers[layer - m->lo];
     Tensor & t = L.t[kind];
-    if (m->up_stream) (void) hipStreamSynchronize(m->up_stream);
+    (void) pm355_uploader_sync(m->up);
     (void) hipDeviceSynchronize();
     if (L.host[kind]) { (void) hipHostFree(L.host[kind]); L.host[kind] = nullptr; }
     const size_t n = g_last_hbm;
@@ -539,40 +538,10 @@ int pm355_model_set_tensor(pm355_model * m, int kind, int layer, int type, const
     int rc = alloc_tensor(m, t, kind, type);
     if (rc) return seterr(m, rc, "set_tensor: alloc");
     if (nbytes != t->bytes) return seterr(m, PM355_E_SHAPE, "set_tensor: byte size does not match type/shape");
-    // pinned double-buffered staging: host -> pinned (CPU memcpy) -> device (hipMemcpyAsync) -> repack kernel
-    const size_t CH = 32u << 20;
-    if (!m->up_stream) {
-        if (hipStreamCreateWithFlags(&m->up_stream, hipStreamNonBlocking) != hipSuccess) return seterr(m, PM355_E_HIP, "set_tensor: stream");
-        for (int i = 0; i < 2; ++i) {
-            if (hipHostMalloc(&m->pin[i], CH, hipHostMallocDefault) != hipSuccess) return seterr(m, PM355_E_NOMEM, "set_tensor: pinned");
-            (void) hipEventCreateWithFlags(&m->pin_ev[i], hipEventDisableTiming);
-        }
-    }
-    const bool repack = pm_type_is_repacked(type) && is_matrix(kind);
-    const size_t rb = pm_weight_row_bytes(type, t->K);
-    const size_t rows_per_chunk = repack ? (CH / rb ? CH / rb : 1) : 0;
-    const size_t chunk = repack ? rows_per_chunk * rb : CH;
-    if (repack && chunk > CH) return seterr(m, PM355_E_RANGE, "set_tensor: row larger than staging chunk");
-    if (repack && m->stage_bytes < CH) {
-        if (m->dstage) (void) hipFree(m->dstage);
-        if (hipMalloc(&m->dstage, 2 * CH) != hipSuccess) return seterr(m, PM355_E_NOMEM, "set_tensor: device staging");
-        m->stage_bytes = CH;
-    }
-    size_t off = 0; int b = 0;
-    while (off < nbytes) {
-        const size_t n = nbytes - off < chunk ? nbytes - off : chunk;
-        (void) hipEventSynchronize(m->pin_ev[b]);                       // previous use of this pinned buffer done
-        memcpy(m->pin[b], (const char *) host + off, n);
-        if (repack) {
-            char * ds = (char *) m->dstage + (size_t) b * CH;
-            (void) hipMemcpyAsync(ds, m->pin[b], n, hipMemcpyHostToDevice, m->up_stream);
-            pm_launch_repack(type, ds, (char *) t->d + (off / rb) * pm_weight_row_stride(type, t->K), t->K, (int64_t) (n / rb), 1, m->up_stream);
-        } else {
-            (void) hipMemcpyAsync((char *) t->d + off, m->pin[b], n, hipMemcpyHostToDevice, m->up_stream);
-        }
-        (void) hipEventRecord(m->pin_ev[b], m->up_stream);
-        off += n; b ^= 1;
-    }
+    // pinned ring staging: host -> pinned (copier threads) -> device (hipMemcpyAsync) -> repack kernel, all overlapped (upload.hip)
+    if (!m->up && !(m->up = pm355_uploader_new(0, -1))) return seterr(m, PM355_E_NOMEM, "set_tensor: uploader (stream / pinned memory)");
+    rc = pm355_upload(m->up, type, t->K, host, t->d, nbytes, is_matrix(kind) ? 1 : 0);
+    if (rc) return seterr(m, rc, "set_tensor: upload failed");
     if (!hip_ok()) return seterr(m, PM355_E_HIP, "set_tensor: upload failed");
     return stream_park(m, kind, layer);
 }
@@ -601,7 +570,7 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
     (void) hipGetLastError();
     if (n_seq < 1 || n_seq > 64) return seterr(m, PM355_E_RANGE, "finalize: n_seq must be 1..64");
     m->n_seq = n_seq;
-    if (m->up_stream) (void) hipStreamSynchronize(m->up_stream);
+    (void) pm355_uploader_sync(m->up);
     (void) hipDeviceSynchronize();
     const pm355_hparams & hp = m->hp;
     const size_t E = hp.n_embd, Eq = (size_t) hp.head_dim * hp.n_head, Ekv = (size_t) hp.head_dim * hp.n_head_kv, F = hp.n_ff;

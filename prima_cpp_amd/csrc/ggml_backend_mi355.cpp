@@ -13,6 +13,7 @@
 #include "../../include/prima_mi355.h"
 #include "ggml_graph_plan.h"
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -55,7 +56,24 @@ bool is_gemv_type(enum ggml_type t) { return t == GGML_TYPE_Q4_K || t == GGML_TY
 
 struct dev_ctx { int device; std::string name, desc; };
 struct buft_ctx { int device; std::string name; };
-struct buf_ctx { int device; void * base; size_t size; std::string name; void * stage = nullptr; size_t stage_bytes = 0; };
+struct buf_ctx { int device; void * base; size_t size; std::string name; void * stage = nullptr; size_t stage_bytes = 0;
+                 pm355_uploader * up = nullptr; bool up_pending = false; };
+// Asynchronous weight staging (upload.hip): set_tensor of a large tensor returns when its bytes sit in the pinned ring; the DMA and
+// the repack run on the uploader's private stream. Everything that must observe the data drains the pending uploaders first:
+// every other buffer operation on that buffer, and graph_compute (all buffers). g_up_pending keeps that check to one load.
+std::mutex g_up_mu;
+std::vector<buf_ctx *> g_up_bufs;
+std::atomic<int> g_up_pending{0};
+constexpr size_t UPLOAD_ASYNC_MIN = (size_t) 4 << 20;
+void buf_drain(buf_ctx * c) {
+    if (c->up_pending) { pm355_uploader_sync(c->up); c->up_pending = false; }
+}
+void drain_all_uploads() {
+    if (!g_up_pending.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> lk(g_up_mu);
+    for (buf_ctx * c : g_up_bufs) buf_drain(c);
+    g_up_pending.store(0, std::memory_order_release);
+}
 // device staging area of a buffer for the row-local repack (kept: the loader calls set_tensor once per weight tensor)
 void * buf_stage(buf_ctx * c, size_t n) {
     if (n > c->stage_bytes) { dsync(nullptr); dfree(c->stage); c->stage = dmalloc(n); GGML_ASSERT(c->stage); c->stage_bytes = n; }
@@ -100,6 +118,12 @@ bool buffer_is_mi355(ggml_backend_buffer_t b) { return b && b->iface.get_name ==
 void buf_free(ggml_backend_buffer_t b) {
     buf_ctx * c = (buf_ctx *) b->context;
     dsetdev(c->device);
+    if (c->up) {
+        std::lock_guard<std::mutex> lk(g_up_mu);
+        buf_drain(c);
+        for (size_t i = 0; i < g_up_bufs.size(); ++i) if (g_up_bufs[i] == c) { g_up_bufs.erase(g_up_bufs.begin() + i); break; }
+        pm355_uploader_free(c->up);
+    }
     dfree(c->base);
     dfree(c->stage);
     delete c;
@@ -109,17 +133,37 @@ void buf_init_tensor(ggml_backend_buffer_t, struct ggml_tensor *) {}
 
 void buf_memset_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, uint8_t v, size_t off, size_t size) {
     dsetdev(((buf_ctx *) b->context)->device);
+    buf_drain((buf_ctx *) b->context);
     MI355_CHECK(dset((char *) t->data + off, v, size, nullptr));
     MI355_CHECK(dsync(nullptr));
 }
 
 // host GGUF-order bytes -> HBM layout (row-local repack for the row-SoA types; see repack.hip)
 void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void * data, size_t off, size_t size) {
-    dsetdev(((buf_ctx *) b->context)->device);
-    if (is_soa_type(t->type)) {
-        const size_t rb = ggml_row_size(t->type, t->ne[0]), stride = pm355_row_stride(t->type, t->ne[0]);
+    buf_ctx * c = (buf_ctx *) b->context;
+    dsetdev(c->device);
+    const bool soa = is_soa_type(t->type);
+    const size_t rb = ggml_row_size(t->type, t->ne[0]), stride = soa ? pm355_row_stride(t->type, t->ne[0]) : rb;
+    if (soa) {
         GGML_ASSERT(off % rb == 0 && size % rb == 0 && "row-granular access to a row-SoA tensor");
         GGML_ASSERT(!t->view_src && "row-SoA tensors are addressed per allocated tensor, not through views");
+    }
+    if (size >= UPLOAD_ASYNC_MIN && !plan_only() && !env_on("GGML_MI355_SYNC_UPLOAD")) {
+        // weights: pinned ring + copier threads + private stream, returns once the bytes have left `data`
+        if (!c->up) {
+            c->up = pm355_uploader_new(0, -1);
+            GGML_ASSERT(c->up && "uploader: pinned memory / stream");
+            std::lock_guard<std::mutex> lk(g_up_mu);
+            g_up_bufs.push_back(c);
+        }
+        MI355_CHECK(dsync(nullptr));                                   // order after earlier synchronous writes to this range
+        MI355_CHECK(pm355_upload(c->up, (int) t->type, t->ne[0], data, (char *) t->data + (soa ? (off / rb) * stride : off), size, soa ? 1 : 0));
+        c->up_pending = true;
+        g_up_pending.store(1, std::memory_order_release);
+        return;
+    }
+    buf_drain(c);
+    if (soa) {
         void * stage = buf_stage((buf_ctx *) b->context, size);
         MI355_CHECK(h2d(stage, data, size, nullptr));
         MI355_CHECK(drepack(t->type, stage, (char *) t->data + (off / rb) * stride, t->ne[0], (int64_t) (size / rb), 1, nullptr));
@@ -131,6 +175,7 @@ void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void 
 }
 void buf_get_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * t, void * data, size_t off, size_t size) {
     dsetdev(((buf_ctx *) b->context)->device);
+    buf_drain((buf_ctx *) b->context);
     if (is_soa_type(t->type)) {
         const size_t rb = ggml_row_size(t->type, t->ne[0]), stride = pm355_row_stride(t->type, t->ne[0]);
         GGML_ASSERT(off % rb == 0 && size % rb == 0 && "row-granular access to a row-SoA tensor");
@@ -153,6 +198,7 @@ bool buf_cpy_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * src, str
     buf_ctx * sc = (buf_ctx *) src->buffer->context, * dc = (buf_ctx *) b->context;
     if (sc->device != dc->device || src->type != dst->type || !ggml_is_contiguous(src) || !ggml_is_contiguous(dst)) return false;
     dsetdev(dc->device);
+    buf_drain(sc); buf_drain(dc);
     MI355_CHECK(d2d(dst->data, src->data, hbm_bytes(src), nullptr));
     MI355_CHECK(dsync(nullptr));
     return true;
@@ -160,6 +206,7 @@ bool buf_cpy_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * src, str
 void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
     buf_ctx * c = (buf_ctx *) b->context;
     dsetdev(c->device);
+    buf_drain(c);
     MI355_CHECK(dset(c->base, v, c->size, nullptr));
     MI355_CHECK(dsync(nullptr));
 }
@@ -231,18 +278,21 @@ void backend_free(ggml_backend_t b) {
 void backend_set_async(ggml_backend_t b, struct ggml_tensor * t, const void * data, size_t off, size_t size) {
     backend_ctx * c = (backend_ctx *) b->context;
     dsetdev(c->device);
+    drain_all_uploads();
     if (is_soa_type(t->type)) { dsync(c->stream); buf_set_tensor(t->view_src ? t->view_src->buffer : t->buffer, t, data, off, size); return; }
     MI355_CHECK(h2d((char *) t->data + off, data, size, c->stream));
 }
 void backend_get_async(ggml_backend_t b, const struct ggml_tensor * t, void * data, size_t off, size_t size) {
     backend_ctx * c = (backend_ctx *) b->context;
     dsetdev(c->device);
+    drain_all_uploads();
     if (is_soa_type(t->type)) { dsync(c->stream); buf_get_tensor(t->view_src ? t->view_src->buffer : t->buffer, t, data, off, size); return; }
     MI355_CHECK(d2h(data, (const char *) t->data + off, size, c->stream));
 }
 void backend_sync(ggml_backend_t b) {
     backend_ctx * c = (backend_ctx *) b->context;
     dsetdev(c->device);
+    drain_all_uploads();
     MI355_CHECK(dsync(c->stream));
 }
 
@@ -490,6 +540,7 @@ void print_plan(const backend_ctx * c, struct ggml_cgraph * g, const mi355::plan
 enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g) {
     backend_ctx * c = (backend_ctx *) b->context;
     dsetdev(c->device);
+    drain_all_uploads();                               // weights staged asynchronously by set_tensor (one atomic load when none are pending)
     const int n_nodes = ggml_graph_n_nodes(g);        // public accessors: struct ggml_cgraph is private to ggml (ggml-impl.h:183)
     ++c->n_compute; ++c->tick;
     if (n_nodes == 0) return GGML_STATUS_SUCCESS;
@@ -548,6 +599,7 @@ bool backend_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const struct ggml_t
     backend_ctx * cs = (backend_ctx *) bs->context, * cd = (backend_ctx *) bd->context;
     if (cs->device != cd->device || src->type != dst->type || !ggml_is_contiguous(src) || !ggml_is_contiguous(dst)) return false;
     dsetdev(cd->device);
+    drain_all_uploads();
     if (cs != cd) dsync(cs->stream);
     MI355_CHECK(d2d(dst->data, src->data, hbm_bytes(src), cd->stream));
     return true;

@@ -40,6 +40,11 @@ _SIGS = {
     "pm355_q8_K_row_size": (_sz, [_i64]),
     "pm355_q8_0_row_size": (_sz, [_i64]),
     "pm355_repack_rows": (_i32, [_i32, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "pm355_uploader_new": (_vp, [_sz, _i32]),
+    "pm355_uploader_free": (None, [_vp]),
+    "pm355_upload": (_i32, [_vp, _i32, _i64, _vp, _vp, _sz, _i32]),
+    "pm355_uploader_sync": (_i32, [_vp]),
+    "pm355_uploader_bytes": (C.c_uint64, [_vp]),
     "pm355_quantize_q8_K": (_i32, [_vp, _vp, _i64, _i64, _vp]),
     "pm355_quantize_q8_0": (_i32, [_vp, _vp, _i64, _i64, _vp]),
     "pm355_act_to_ggml_blocks": (_i32, [_i32, _vp, _vp, _i64, _i64, _vp]),

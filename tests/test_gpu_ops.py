@@ -106,6 +106,42 @@ def test_repack_roundtrip_bitexact(P, t, K):
         assert np.array_equal(img, want)
 
 
+@pytest.mark.parametrize("threads", [0, 3])
+def test_async_uploader_matches_synchronous_set_tensor(P, threads):
+    """upload.hip (pinned ring + copier threads + private stream + repack per chunk) leaves exactly the HBM image of the synchronous
+    H2D + repack path, for chunks smaller than a tensor (rows split over many chunks), ragged tails, and plain byte tensors."""
+    import ctypes as C
+    import torch
+    lib = P.L.load()
+    rng = np.random.default_rng(231)
+    up = lib.pm355_uploader_new(1 << 20, threads)                      # 1-MiB chunks: every tensor below spans several
+    assert up
+    try:
+        total = 0
+        for t, K, N in ((Q4_K, 4096, 1500), (Q6_K, 2304, 1111), (Q8_0, 1056, 4099), (Q5_K, 2048, 999)):
+            blocks = rand_blocks(t, N, K, rng)
+            want = P.upload_weight(t, blocks, K, N)
+            host = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1)
+            dst = torch.zeros_like(want.data)
+            assert lib.pm355_upload(up, t, K, host.ctypes.data, dst.data_ptr(), host.size, 1) == 0
+            host[:] = 0                                               # the source may be reused as soon as the call returns
+            assert lib.pm355_uploader_sync(up) == 0
+            assert torch.equal(dst, want.data)
+            total += host.size
+        raw = rng.integers(0, 256, (3 << 20) + 12345, dtype=np.uint8)
+        dst = torch.zeros(raw.size, dtype=torch.uint8, device="cuda")
+        assert lib.pm355_upload(up, -1, 0, raw.ctypes.data, dst.data_ptr(), raw.size, 0) == 0
+        assert lib.pm355_uploader_sync(up) == 0
+        assert np.array_equal(dst.cpu().numpy(), raw)
+        assert lib.pm355_uploader_bytes(up) == total + raw.size
+        # a row that does not fit a chunk is refused, never truncated
+        big = rand_blocks(Q4_K, 1, 2 << 20, rng).reshape(-1)
+        d2 = torch.zeros(big.size, dtype=torch.uint8, device="cuda")
+        assert lib.pm355_upload(up, Q4_K, 2 << 20, big.ctypes.data, d2.data_ptr(), big.size, 1) != 0
+    finally:
+        lib.pm355_uploader_free(up)
+
+
 @pytest.mark.parametrize("t", QUANT_TYPES)
 @pytest.mark.parametrize("K,N", [(256, 3), (768, 5), (2048, 5), (4096, 37), (5120, 4), (8192, 64), (14336, 9), (28672, 6)])
 def test_gemv_integer_partials_bitexact_and_float_close(P, oracle, t, K, N):
