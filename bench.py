@@ -401,6 +401,12 @@ def plugin_decode(tmp, n_gen=64, prompt_len=16):
            "prompt_tokens_per_s": round(st["prompt_tok_s"], 1), "load_ms": round(st["load_ms"], 1), "gguf_write_s": round(t_gen, 1),
            "hbm_roofline_tokens_per_s": round(roof, 1), "frac_of_hbm_roofline": round(st["decode_tok_s"] / roof, 4),
            "timing": "wall clock around llama_decode + llama_synchronize per token, first 5 tokens dropped (llama_perf convention)"}
+    # the same model with --flash-attn (FLASH_ATTN_EXT graphs: row-major V cache, F16 mask) - lowered to the same five launches
+    try:
+        _, _, sf = B.run_llama_driver(path, prompt, 32, ngl=99, n_ctx=4096, threads=usable_cores(), extra_args=["--keep-out-in-cuda", "-fa"], timeout=600)
+        out["flash_attn"] = {"tokens_per_s": round(sf["decode_tok_s"], 2), "ms_per_token": round(sf["decode_ms_avg"], 4), "prompt_tokens_per_s": round(sf["prompt_tok_s"], 1)}
+    except Exception as e:                       # noqa: BLE001 - a bench leg, never fatal
+        out["flash_attn"] = {"error": str(e)[:200]}
     return out, path
 
 

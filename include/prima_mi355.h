@@ -212,16 +212,22 @@ PM355_API int pm355_attn_rope_fused(const float * q, const float * k, const floa
  * (scratch = pm355_attn_split_scratch_floats() floats). */
 typedef struct {
     const float * q, * k, * v;           /* raw projections of the token: [n_head*head_dim], [n_head_kv*head_dim] x2 */
-    void * k_cache, * v_cache;           /* F16 K rows [n_ctx][n_head_kv*head_dim]; F16 V transposed [n_head_kv*head_dim][n_ctx] */
+    void * k_cache, * v_cache;           /* F16 K rows [n_ctx][n_head_kv*head_dim]; F16 V transposed [n_head_kv*head_dim][n_ctx], or
+                                          * (PM355_ATTN_V_ROWMAJOR) rows like K */
     const int32_t * d_pos;               /* device: RoPE position of the token */
     const int32_t * d_cell_nkv;          /* device int32[2]: {cache cell, cells attended} */
-    const float * mask;                  /* device f32 [cells attended] or NULL */
+    const void * mask;                   /* device f32 (F16 with PM355_ATTN_MASK_F16) [cells attended] or NULL */
     const float * freq_factors;          /* rope_freqs [head_dim/2] or NULL */
     float * out;                         /* [n_head*head_dim] f32 */
     float * scratch;                     /* split only */
     int32_t n_head, n_head_kv, head_dim, n_ctx, split, max_keys;
-    float kq_scale; int32_t pad_;
+    float kq_scale; int32_t flags;       /* PM355_ATTN_* */
 } pm355_attn_token_args;
+/* flash-attention graphs (llm_build_kv with cparams.flash_attn, src/llama.cpp:9705, :10075-10095: CPY(V -> row of v_cache),
+ * FLASH_ATTN_EXT(q, k, v, F16 mask)): the V cache is row-major and the mask is F16; the kernel then uses the rounding points of
+ * ggml_compute_forward_flash_attn_ext_f16 (q -> F16, probabilities stay f32) with an f32 accumulator. */
+#define PM355_ATTN_V_ROWMAJOR 1
+#define PM355_ATTN_MASK_F16   2
 PM355_API int pm355_attn_token(const pm355_attn_token_args * a, const pm355_rope_params * rp, pm355_stream_t stream);
 /* p[0] = a, p[1] = b on the stream (values travel as kernel arguments: no host buffer lifetime to manage) */
 PM355_API int pm355_set_i32x2(int32_t * d_p, int32_t a, int32_t b, pm355_stream_t stream);

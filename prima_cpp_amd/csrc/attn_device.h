@@ -33,11 +33,20 @@ struct AttnP {
     // with the additive f32 KQ mask row `mask` (0 / -inf, llama_set_inputs src/llama.cpp:17379-17420). Engine mode (dyn == nullptr):
     // cell == position, cells [0, pos] attended, no mask.
     const int32_t * dyn; const float * mask;
+    // mask_f16 != 0: `mask` points to F16 values (the flash-attention graphs cast the KQ mask, build_inp_KQ_mask src/llama.cpp:10466)
+    int mask_f16;
 };
+__device__ __forceinline__ float attn_mask_at(const void * mask, int f16, int i) {
+    if (!mask) return 0.0f;
+    return f16 ? h2f(((const PM_G uint16_t *) mask)[i]) : ((const PM_G float *) mask)[i];
+}
 
 // Body of one query head `h`. Written for 256 ACTIVE threads; a larger workgroup (attn_wo.hip) passes
 // its extra threads through: they only take part in the barriers.
-template <int DH, bool COH>
+// VM = layout of the V cache: 0 = transposed [n_embd_v_gqa][n_ctx] (llm_build_kv_store without flash attention, src/llama.cpp:9712),
+// 1 = row-major [n_ctx][n_embd_v_gqa] like K (flash-attention graphs, :9705) - with the reference's flash-attention rounding points
+// (ggml_compute_forward_flash_attn_ext_f16, ggml.c:15870-16050): q -> F16, probabilities stay f32 (no F16 rounding of P).
+template <int DH, bool COH, int VM = 0>
 __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * smem, float * redf /*[8]*/, double * redd /*[4]*/) {
     // all of these are device-global memory: the explicit address space keeps the accesses global_* (not FLAT) when the
     // pointers may come out of a descriptor in memory
@@ -53,8 +62,10 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
     float * kcur = qs + DH;                      // [DH]  f16-rounded rotated k of this position
     float * vcur = kcur + DH;                    // [DH]  f16-rounded v of this position
     float * cs   = vcur + DH;                    // [DH]  cos/sin per pair
-    float * part = cs + DH;                      // [256] PV partials
-    float * sc   = part + 256;                   // [n_ctx] scores / probabilities
+    constexpr int C8 = DH / 8, NSL = 256 / C8;   // VM 1: 16-byte chunks per V row, key slots per workgroup
+    constexpr int PART_FLOATS = VM == 0 ? 256 : 2048;
+    float * part = cs + DH;                      // PV partials: [256] (VM 0) / [NSL][DH] (VM 1)
+    float * sc   = part + PART_FLOATS;           // [n_ctx] scores / probabilities
     const int tid = active ? (int) threadIdx.x : (1 << 28), lane = tid & 63, wave = tid >> 6;   // passengers: every range test fails
     const int hk = h / (H / Hkv);
     const bool neox = r.mode & 2;
@@ -81,10 +92,17 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
         const PM_G uint16_t * kr = kcb + (long) (tid < n_ctx ? tid : 0) * Hkv * DH + (long) hk * DH;
 #pragma unroll
         for (int j = 0; j < KQ; ++j) kreg[j] = *(const PM_G u32x4 *) (kr + 8 * j);
-        const PM_G uint16_t * vr = vcb + (long) (hk * DH + ve) * n_ctx;
-        const int i0 = vpt * 8, i1 = i0 + PARTS * 8;
-        vreg0 = *(const PM_G u32x4 *) (vr + (i0 + 8 <= n_ctx ? i0 : 0));
-        vreg1 = *(const PM_G u32x4 *) (vr + (i1 + 8 <= n_ctx ? i1 : 0));
+        if (VM == 0) {
+            const PM_G uint16_t * vr = vcb + (long) (hk * DH + ve) * n_ctx;
+            const int i0 = vpt * 8, i1 = i0 + PARTS * 8;
+            vreg0 = *(const PM_G u32x4 *) (vr + (i0 + 8 <= n_ctx ? i0 : 0));
+            vreg1 = *(const PM_G u32x4 *) (vr + (i1 + 8 <= n_ctx ? i1 : 0));
+        } else {                                 // rows (tid / C8) and (tid / C8 + NSL), 16-byte chunk tid % C8 of this KV head
+            const int c8 = tid % C8, ks = tid / C8;
+            const PM_G uint16_t * vr = vcb + (long) hk * DH + 8 * c8;
+            vreg0 = *(const PM_G u32x4 *) (vr + (long) (ks < n_ctx ? ks : 0) * Hkv * DH);
+            vreg1 = *(const PM_G u32x4 *) (vr + (long) (ks + NSL < n_ctx ? ks + NSL : 0) * Hkv * DH);
+        }
     };
     int seq = 0, pos, slot, n_kv;                // rope position, cache cell of this token, cells attended = [0, n_kv)
     int pv = 0, sv = 0;
@@ -101,7 +119,7 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
         slot = pos; n_kv = pos + 1;
         if (a.dyn) { slot = __builtin_amdgcn_readfirstlane(dyn0); n_kv = __builtin_amdgcn_readfirstlane(dyn1); }
     }
-    const PM_G float * mask = (const PM_G float *) a.mask;
+    const void * mask = a.mask; const int mf16 = a.mask_f16;
     kc += (long) seq * seq_stride; vc += (long) seq * seq_stride;
     if (seq_stride != 0 && seq_ptr) first_loads(kc, vc);
     const int n_pad = (n_kv + 7) & ~7;           // cached cells [0, n_kv) without `slot`, padded to the 16-byte load width
@@ -128,7 +146,10 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
         if (e < DH) {
             const uint16_t hv = f2h(vnew);
             vcur[e] = h2f(hv);
-            if (h % (H / Hkv) == 0) vc[(long) (hk * DH + e) * n_ctx + slot] = hv;
+            if (h % (H / Hkv) == 0) {
+                if (VM == 0) vc[(long) (hk * DH + e) * n_ctx + slot] = hv;
+                else         vc[(long) slot * Hkv * DH + hk * DH + e] = hv;
+            }
         }
     }
     __syncthreads();
@@ -145,14 +166,14 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
             }
         return acc * scale;
     };
-    if (have_k) { const float s_ = dot_row(kreg) + (mask ? mask[tid] : 0.0f); sc[tid] = s_; lmax = s_; }
+    if (have_k) { const float s_ = dot_row(kreg) + attn_mask_at(mask, mf16, tid); sc[tid] = s_; lmax = s_; }
     for (int i = tid + 256; i < n_kv; i += 256) {
         if (i == slot) continue;
         const PM_G uint16_t * kr = kc + (long) i * Hkv * DH + (long) hk * DH;
         u32x4 kk[KQ];
 #pragma unroll
         for (int j = 0; j < KQ; ++j) kk[j] = *(const PM_G u32x4 *) (kr + 8 * j);
-        const float s_ = dot_row(kk) + (mask ? mask[i] : 0.0f);
+        const float s_ = dot_row(kk) + attn_mask_at(mask, mf16, i);
         sc[i] = s_;
         lmax = fmaxf(lmax, s_);
     }
@@ -160,7 +181,7 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
         float acc = 0.0f;
 #pragma unroll
         for (int e = lane; e < DH; e += 64) acc += kcur[e] * qs[e];
-        const float s_ = wave_sum(acc) * scale + (mask ? mask[slot] : 0.0f);
+        const float s_ = wave_sum(acc) * scale + attn_mask_at(mask, mf16, slot);
         if (lane == 0) sc[slot] = s_;
         lmax = fmaxf(lmax, s_);
     }
@@ -181,10 +202,46 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
     __syncthreads();
     const double tot = (redd[0] + redd[1]) + (redd[2] + redd[3]);
     const float inv = (float) (1.0 / tot);
-    const float p_cur = h2f(f2h(sc[slot] * inv));                      // every thread reads exp() of the current key
+    const float p_cur = VM == 0 ? h2f(f2h(sc[slot] * inv)) : sc[slot] * inv;   // every thread reads exp() of the current key
     __syncthreads();
-    for (int i = tid; i < n_pad; i += 256) sc[i] = (i < n_kv && i != slot) ? h2f(f2h(sc[i] * inv)) : 0.0f;   // p rounded to F16; pad and `slot` = 0
+    for (int i = tid; i < n_pad; i += 256)                             // VM 0: p rounded to F16; pad and `slot` = 0
+        sc[i] = (i < n_kv && i != slot) ? (VM == 0 ? h2f(f2h(sc[i] * inv)) : sc[i] * inv) : 0.0f;
     __syncthreads();
+    if (VM == 1) {
+        // ---- PV, row-major V: thread (16-byte chunk c8, key slot ks) takes rows ks, ks + NSL, ... (first two pre-loaded)
+        const int c8 = tid % C8, ks = tid / C8;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto fma_row = [&](const u32x4 & vv, float pr) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * j]     += h2f((uint16_t) (vv[j] & 0xFFFF)) * pr;
+                acc[2 * j + 1] += h2f((uint16_t) (vv[j] >> 16)) * pr;
+            }
+        };
+        const PM_G uint16_t * vr = vc + (long) hk * DH + 8 * c8;
+        int i = ks;
+        if (i < n_kv && i != slot) fma_row(vreg0, sc[i]);
+        i += NSL;
+        if (i < n_kv && i != slot) fma_row(vreg1, sc[i]);
+        for (i += NSL; i < n_kv; i += NSL) {
+            if (i == slot) continue;                                    // (that row is being written by this launch)
+            const u32x4 vv = *(const PM_G u32x4 *) (vr + (long) i * Hkv * DH);
+            fma_row(vv, sc[i]);
+        }
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[ks * DH + 8 * c8 + j] = acc[j];
+        }
+        __syncthreads();
+        if (tid < DH) {
+            float o = 0.0f;
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) o += part[sl * DH + tid];
+            o += vcur[tid] * p_cur;
+            st_act<COH>(out + (long) h * DH + tid, o);
+        }
+        return;
+    }
     // ---- PV: thread (e, part) streams V^T[hk*DH+e][8*chunk ..] for chunk = part, part+PARTS, ... (first two pre-loaded)
     {
         float acc = 0.0f;

@@ -31,7 +31,8 @@ struct SplitP {
     // workgroup whose chunk contains the token's position also rotates k, takes it from LDS and stores the K row / V column
     const float * k; const float * v; const float * ff; uint16_t * kc_w; uint16_t * vc_w; RopeP r; int do_rope;
     // ggml-graph mode (see AttnP in attn_device.h): dyn = {cache cell of the token, cells attended}, mask = additive f32 KQ mask row
-    const int32_t * dyn; const float * mask;
+    const int32_t * dyn; const void * mask; int mask_f16;
+    int vm;                                      // V cache layout: 0 transposed, 1 row-major (flash-attention graphs; P stays f32) - attn_device.h
 };
 
 // rope position `pos`, cache cell `slot` the token is stored in, cells attended = [0, n_kv)
@@ -99,8 +100,11 @@ __global__ __launch_bounds__(256) void attn_split_scores_kernel(SplitP p) {
                 d[ia] = h0; d[ib] = h1;
             }
         }
-        if (mine) for (int e = tid; e < DH; e += 256)
-            p.vc_w[(long) seq * p.seq_stride + (long) (g * DH + e) * p.n_ctx + slot] = f2h(p.v[(long) g * DH + e]);
+        if (mine) for (int e = tid; e < DH; e += 256) {
+            const uint16_t hv = f2h(p.v[(long) g * DH + e]);
+            if (p.vm == 0) p.vc_w[(long) seq * p.seq_stride + (long) (g * DH + e) * p.n_ctx + slot] = hv;
+            else           p.vc_w[(long) seq * p.seq_stride + (long) slot * p.Hkv * DH + (long) g * DH + e] = hv;
+        }
     }
     __syncthreads();
     const int piece = tid % LPK, kslot = tid / LPK;
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void attn_split_scores_kernel(SplitP p) {
         }
 #pragma unroll
         for (int h = 0; h < RMAX; ++h) acc[h] = group_sum<LPK>(acc[h]);
-        const float mk = (p.mask && key < n_kv) ? p.mask[key] : 0.0f;
+        const float mk = (p.mask && key < n_kv) ? attn_mask_at(p.mask, p.mask_f16, key) : 0.0f;
 #pragma unroll
         for (int h = 0; h < RMAX; ++h) if (h < R && piece == (h % LPK)) sc[h][kin] = key < n_kv ? acc[h] * p.scale + mk : -INFINITY;
     }
@@ -157,13 +161,13 @@ __global__ __launch_bounds__(256) void attn_split_scores_kernel(SplitP p) {
 }
 
 // ---- 2. probabilities and partial P.V ---------------------------------------------------------------------------------
-template <int DH>
+template <int DH, int VM>
 __global__ __launch_bounds__(256) void attn_split_pv_kernel(SplitP p) {
     constexpr int PARTS = 256 / DH;              // key sub-ranges per workgroup (2 for dh 128, 4 for dh 64)
     constexpr int KP = CK / PARTS;               // keys per sub-range
     __shared__ float pl[RMAX][CK];               // F16-rounded probabilities of this chunk
     __shared__ float mx[RMAX], inv[RMAX];
-    __shared__ float part[PARTS][RMAX][DH];
+    __shared__ float part[VM == 1 ? 4 : PARTS][RMAX][DH];
     const int c = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const int R = p.H / p.Hkv;
     int seq, pos_, slot_, n_kv; cur_pos(p, seq, pos_, slot_, n_kv);
@@ -187,9 +191,59 @@ __global__ __launch_bounds__(256) void attn_split_pv_kernel(SplitP p) {
     for (int i = tid; i < R * CK; i += 256) {
         const int h = i / CK, kin = i - h * CK;
         const int key = k0 + kin;
-        pl[h][kin] = key < n_kv ? h2f(f2h(expf(p.S[(long) (g * R + h) * p.n_ctx + key] - mx[h]) * inv[h])) : 0.0f;
+        const float pr = key < n_kv ? expf(p.S[(long) (g * R + h) * p.n_ctx + key] - mx[h]) * inv[h] : 0.0f;
+        pl[h][kin] = VM == 0 ? h2f(f2h(pr)) : pr;
     }
     __syncthreads();
+    if (VM == 1) {
+        // row-major V: thread (16-byte chunk c8, key slot ks) takes rows k0 + ks, + NSL, ... of this chunk for all R heads; the key slots
+        // are folded with lane shuffles inside a wave and through LDS across the 4 waves
+        constexpr int C8 = DH / 8, NSL = 256 / C8, NR = CK / NSL;
+        const int c8 = tid % C8, ks = tid / C8, wave = tid >> 6;
+        const uint16_t * vr = p.vc + (long) seq * p.seq_stride + (long) g * DH + 8 * c8;
+        const long vrow = (long) p.Hkv * DH;
+        u32x4 vall[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) vall[j] = *(const u32x4 *) (vr + (long) min(k0 + ks + j * NSL, p.n_ctx - 1) * vrow);
+        float acc[RMAX][8];
+#pragma unroll
+        for (int h = 0; h < RMAX; ++h)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[h][i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int kin = ks + j * NSL;
+            if (k0 + kin >= n_kv) continue;
+            const u32x4 vv = vall[j];
+            float vf[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { vf[2 * i] = h2f((uint16_t) (vv[i] & 0xFFFF)); vf[2 * i + 1] = h2f((uint16_t) (vv[i] >> 16)); }
+#pragma unroll
+            for (int h = 0; h < RMAX; ++h) if (h < R) {
+                const float pr = pl[h][kin];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[h][i] = fmaf(vf[i], pr, acc[h][i]);
+            }
+        }
+        float * red = &part[0][0][0];                                    // [4 waves][RMAX][DH]
+#pragma unroll
+        for (int h = 0; h < RMAX; ++h) if (h < R) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v_ = acc[h][i];
+#pragma unroll
+                for (int off = C8; off < 64; off <<= 1) v_ += __shfl_xor(v_, off);
+                if ((tid & 63) < C8) red[(wave * RMAX + h) * DH + 8 * c8 + i] = v_;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < R * DH; i += 256) {
+            const int h = i / DH, ee = i - h * DH;
+            const float o = (red[(0 * RMAX + h) * DH + ee] + red[(1 * RMAX + h) * DH + ee]) + (red[(2 * RMAX + h) * DH + ee] + red[(3 * RMAX + h) * DH + ee]);
+            p.P[((long) c * p.H + g * R + h) * DH + ee] = o;
+        }
+        return;
+    }
     // thread (e, part): V^T row e of this KV head, keys [part * KP, +KP) of the chunk, all R heads at once
     const int e = tid % DH, pt = tid / DH;
     const uint16_t * vr = p.vc + (long) seq * p.seq_stride + (long) (g * DH + e) * p.n_ctx;
@@ -248,13 +302,13 @@ size_t pm_attn_split_scratch_floats(int H, int dh, int n_ctx) {
 // rope != nullptr: q, k, v = the RAW projections; the rotation, the KV store and the attention are done here (3 launches).
 int pm_launch_attn_split(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos0, const int32_t * seq,
                          long seq_stride, const float * freq_factors, float * out, float * scratch, int H, int Hkv, int dh, int n_ctx,
-                         float scale, const pm_rope_cfg * rope, hipStream_t st, const int32_t * dyn, const float * mask) {
+                         float scale, const pm_rope_cfg * rope, hipStream_t st, const int32_t * dyn, const void * mask, int v_rowmajor, int mask_f16) {
     if ((dh != 64 && dh != 128) || H % Hkv || H / Hkv > RMAX || n_ctx % 8 || !scratch) return -1;
     const int nchunk = (n_ctx + CK - 1) / CK;
     SplitP p = {};
     p.q = q; p.kc = (const uint16_t *) kc; p.vc = (const uint16_t *) vc; p.pos0_ptr = pos0; p.seq_ptr = seq; p.seq_stride = seq_stride;
     p.out = out; p.S = scratch; p.M = p.S + (size_t) H * n_ctx; p.L = p.M + (size_t) H * nchunk; p.P = p.L + (size_t) H * nchunk;
-    p.H = H; p.Hkv = Hkv; p.n_ctx = n_ctx; p.nchunk = nchunk; p.scale = scale; p.dyn = dyn; p.mask = mask;
+    p.H = H; p.Hkv = Hkv; p.n_ctx = n_ctx; p.nchunk = nchunk; p.scale = scale; p.dyn = dyn; p.mask = mask; p.mask_f16 = mask_f16; p.vm = v_rowmajor ? 1 : 0;
     if (rope) {
         const pm_rope_cfg & c = *rope;
         p.r.n_dims = c.n_dims; p.r.mode = c.mode; p.r.n_ctx_orig = c.n_ctx_orig; p.r.theta_scale = c.theta_scale;
@@ -264,10 +318,12 @@ int pm_launch_attn_split(const float * q, const float * k, const float * v, void
     const dim3 grid(nchunk, Hkv);
     if (dh == 128) {
         hipLaunchKernelGGL(attn_split_scores_kernel<128>, grid, dim3(256), 0, st, p);
-        hipLaunchKernelGGL(attn_split_pv_kernel<128>, grid, dim3(256), 0, st, p);
+        if (p.vm) hipLaunchKernelGGL((attn_split_pv_kernel<128, 1>), grid, dim3(256), 0, st, p);
+        else      hipLaunchKernelGGL((attn_split_pv_kernel<128, 0>), grid, dim3(256), 0, st, p);
     } else {
         hipLaunchKernelGGL(attn_split_scores_kernel<64>, grid, dim3(256), 0, st, p);
-        hipLaunchKernelGGL(attn_split_pv_kernel<64>, grid, dim3(256), 0, st, p);
+        if (p.vm) hipLaunchKernelGGL((attn_split_pv_kernel<64, 1>), grid, dim3(256), 0, st, p);
+        else      hipLaunchKernelGGL((attn_split_pv_kernel<64, 0>), grid, dim3(256), 0, st, p);
     }
     hipLaunchKernelGGL(attn_split_combine_kernel, dim3((H * dh + 255) / 256), dim3(256), 0, st, p, dh);
     return 0;

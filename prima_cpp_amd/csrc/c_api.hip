@@ -247,10 +247,12 @@ int pm355_attn_token(const pm355_attn_token_args * a, const pm355_rope_params * 
     (void) hipGetLastError();
     if (a->split) {
         if (pm_launch_attn_split(a->q, a->k, a->v, a->k_cache, a->v_cache, a->d_pos, nullptr, 0, a->freq_factors, a->out, a->scratch,
-                                 a->n_head, a->n_head_kv, a->head_dim, a->n_ctx, a->kq_scale, &c, S(st), a->d_cell_nkv, a->mask))
+                                 a->n_head, a->n_head_kv, a->head_dim, a->n_ctx, a->kq_scale, &c, S(st), a->d_cell_nkv, a->mask,
+                                 a->flags & PM355_ATTN_V_ROWMAJOR, a->flags & PM355_ATTN_MASK_F16))
             return fail(PM355_E_UNSUPPORTED, "attn_token(split): head_dim 64/128, at most 8 query heads per KV head, n_ctx % 8 == 0, scratch required");
     } else if (pm_launch_attn_rope_fused(a->q, a->k, a->v, a->k_cache, a->v_cache, a->d_pos, nullptr, 0, a->freq_factors, a->out,
-                                         a->n_head, a->n_head_kv, a->head_dim, a->n_ctx, a->kq_scale, c, S(st), a->d_cell_nkv, a->mask, a->max_keys))
+                                         a->n_head, a->n_head_kv, a->head_dim, a->n_ctx, a->kq_scale, c, S(st), a->d_cell_nkv, a->mask, a->max_keys,
+                                         a->flags & PM355_ATTN_V_ROWMAJOR, a->flags & PM355_ATTN_MASK_F16))
         return fail(PM355_E_UNSUPPORTED, "attn_token: head_dim must be 64/128/256, n_ctx % 8 == 0 and max_keys fit LDS");
     HIP_TRY(hipGetLastError());
     return 0;

@@ -311,54 +311,93 @@ private:
         // both rotations: same parameters, same position tensor, same frequency factors
         if (memcmp(rq->op_params, rk->op_params, sizeof(rq->op_params)) || rq->src[1] != rk->src[1] || rq->src[2] != rk->src[2]) return 0;
         if (rq->op_params[1] > dh || rq->op_params[1] % 2) return 0;
-        // KV store: VIEW(k cell) CPY(Krot -> cell) ; TRANSPOSE(V) VIEW(v cell) CPY(V^T -> cell)
-        const ggml_tensor * kcv = N(i), * kcp = N(i + 1), * vt = N(i + 2), * vcv = N(i + 3), * vcp = N(i + 4);
-        if (!kcv || !kcp || !vt || !vcv || !vcp) return 0;
-        if (kcv->op != GGML_OP_VIEW || kcp->op != GGML_OP_CPY || vt->op != GGML_OP_TRANSPOSE || vcv->op != GGML_OP_VIEW || vcp->op != GGML_OP_CPY) return 0;
+        // KV store: VIEW(k cell) CPY(Krot -> cell) ; then either TRANSPOSE(V) VIEW(v cell) CPY(V^T -> cell) (llm_build_kv_store,
+        // src/llama.cpp:9712-9722) or, in flash-attention graphs, VIEW(v row) CPY(V -> row) (:9705-9707)
+        const ggml_tensor * kcv = N(i), * kcp = N(i + 1);
+        if (!kcv || !kcp || !N(i + 2) || !N(i + 3)) return 0;
+        const bool fa = N(i + 2)->op != GGML_OP_TRANSPOSE;
+        const ggml_tensor * vt = fa ? nullptr : N(i + 2), * vcv = fa ? N(i + 2) : N(i + 3), * vcp = fa ? N(i + 3) : N(i + 4);
+        if (!vcv || !vcp) return 0;
+        if (kcv->op != GGML_OP_VIEW || kcp->op != GGML_OP_CPY || vcv->op != GGML_OP_VIEW || vcp->op != GGML_OP_CPY) return 0;
         const ggml_tensor * kcache = kcv->view_src, * vcache = vcv->view_src;
         if (!kcache || !vcache || kcache->type != GGML_TYPE_F16 || vcache->type != GGML_TYPE_F16 || kcache->view_src || vcache->view_src ||
             kcache->op != GGML_OP_NONE || vcache->op != GGML_OP_NONE || !ggml_is_contiguous(kcache) || !ggml_is_contiguous(vcache)) return 0;
         if (kcp->src[0] != rk || kcp->src[1] != kcv || kcv->type != GGML_TYPE_F16 || kcv->ne[0] != Ekv || kcv->ne[1] != 1 || kcv->nb[0] != 2) return 0;
-        if (vt->src[0] != v || vcp->src[0] != vt || vcp->src[1] != vcv || vcv->type != GGML_TYPE_F16 || vcv->ne[0] != 1 || vcv->ne[1] != Ekv || vcv->nb[0] != 2) return 0;
         const size_t k_row = (size_t) Ekv * 2;
         const size_t k_off = (const char *) kcv->data - (const char *) kcache->data, v_off = (const char *) vcv->data - (const char *) vcache->data;
-        if (k_off % k_row || v_off % 2 || k_off / k_row != v_off / 2) return 0;
-        const int64_t n_ctx = (int64_t) (vcv->nb[1] / 2);
+        int64_t n_ctx;
+        if (!fa) {
+            if (vt->src[0] != v || vcp->src[0] != vt || vcp->src[1] != vcv || vcv->type != GGML_TYPE_F16 || vcv->ne[0] != 1 || vcv->ne[1] != Ekv || vcv->nb[0] != 2) return 0;
+            if (k_off % k_row || v_off % 2 || k_off / k_row != v_off / 2) return 0;
+            n_ctx = (int64_t) (vcv->nb[1] / 2);
+        } else {
+            if (vcp->src[0] != v || vcp->src[1] != vcv || vcv->type != GGML_TYPE_F16 || vcv->ne[0] != Ekv || vcv->ne[1] != 1 || vcv->nb[0] != 2) return 0;
+            if (k_off % k_row || v_off != k_off) return 0;
+            n_ctx = (int64_t) ggml_nelements(kcache) / Ekv;
+        }
         if (n_ctx <= 0 || n_ctx % 8 || (int64_t) ggml_nelements(kcache) < n_ctx * Ekv || (int64_t) ggml_nelements(vcache) < n_ctx * Ekv) return 0;
         const int64_t cell = (int64_t) (k_off / k_row);
         if (cell >= n_ctx) return 0;
-        i += 5;
-        // VIEW(v) VIEW(k) PERMUTE(q) in any order
+        i += fa ? 4 : 5;
+        // VIEW(v) VIEW(k) PERMUTE(q) in any order; flash-attention graphs may also hold the F32 -> F16 cast of the KQ mask here
+        // (build_inp_KQ_mask, src/llama.cpp:10466: once per graph, in front of its first use)
         const ggml_tensor * vv = nullptr, * kv = nullptr, * qp = nullptr;
-        for (int r = 0; r < 3; ++r) {
+        int mask_cast = -1;
+        for (int r = 0; r < 4; ++r) {
             const ggml_tensor * t = N(i);
             if (!t) return 0;
             if (t->op == GGML_OP_VIEW && t->view_src == vcache && !vv) vv = t;
             else if (t->op == GGML_OP_VIEW && t->view_src == kcache && !kv) kv = t;
             else if (t->op == GGML_OP_PERMUTE && t->src[0] == rq && !qp) qp = t;
-            else return 0;
+            else if (fa && t->op == GGML_OP_CPY && t->type == GGML_TYPE_F16 && t->src[0] && t->src[0]->type == GGML_TYPE_F32 && mask_cast < 0) mask_cast = i;
+            else break;
             ++i;
         }
-        const ggml_tensor * kq = N(i), * sm = N(i + 1), * kqv = N(i + 2), * pm = N(i + 3), * ct = N(i + 4);
-        if (!kq || !sm || !kqv || !pm || !ct) return 0;
-        if (kq->op != GGML_OP_MUL_MAT || sm->op != GGML_OP_SOFT_MAX || kqv->op != GGML_OP_MUL_MAT || pm->op != GGML_OP_PERMUTE || ct->op != GGML_OP_CONT) return 0;
+        if (!vv || !kv || !qp) return 0;
         const int64_t n_kv = kv->ne[1];
-        // k view [dh, n_kv, Hkv] rows of the K cache from cell 0; v view [n_kv, dh, Hkv] of the transposed V cache; q [dh, 1, H]
+        // k view [dh, n_kv, Hkv] rows of the K cache from cell 0; q [dh, 1, H]
         if (kv->data != kcache->data || kv->ne[0] != dh || kv->ne[2] != Hkv || kv->ne[3] != 1 || kv->nb[0] != 2 || kv->nb[1] != k_row || kv->nb[2] != (size_t) dh * 2) return 0;
-        if (vv->data != vcache->data || vv->ne[0] != n_kv || vv->ne[1] != dh || vv->ne[2] != Hkv || vv->ne[3] != 1 || vv->nb[0] != 2 ||
-            vv->nb[1] != (size_t) n_ctx * 2 || vv->nb[2] != (size_t) n_ctx * dh * 2) return 0;
         if (qp->ne[0] != dh || qp->ne[1] != 1 || qp->ne[2] != H || qp->nb[0] != 4 || qp->nb[2] != (size_t) dh * 4 || qp->data != rq->data) return 0;
-        if (kq->src[0] != kv || kq->src[1] != qp || kq->type != GGML_TYPE_F32 || kq->ne[0] != n_kv || kq->ne[1] != 1 || kq->ne[2] != H) return 0;
-        const ggml_tensor * mask = sm->src[1];
-        float scale, max_bias; memcpy(&scale, sm->op_params, 4); memcpy(&max_bias, (const float *) sm->op_params + 1, 4);
-        if (sm->src[0] != kq || max_bias != 0.0f || sm->ne[0] != n_kv) return 0;
-        if (mask && (mask->type != GGML_TYPE_F32 || mask->ne[0] != n_kv || mask->nb[0] != 4 || mask->ne[2] != 1 || mask->ne[3] != 1)) return 0;
-        if (kqv->src[0] != vv || kqv->src[1] != sm || kqv->ne[0] != dh || kqv->ne[1] != 1 || kqv->ne[2] != H) return 0;
-        if (pm->src[0] != kqv || ct->src[0] != pm || !f32_vec(ct, Eq) || pm->ne[0] != dh || pm->ne[1] != H || pm->ne[2] != 1) return 0;
         if (n_kv > n_ctx || cell >= n_kv) return 0;
-        i += 5;
+        const ggml_tensor * mask = nullptr, * out_t = nullptr;
+        float scale;
+        if (!fa) {
+            const ggml_tensor * kq = N(i), * sm = N(i + 1), * kqv = N(i + 2), * pm = N(i + 3), * ct = N(i + 4);
+            if (!kq || !sm || !kqv || !pm || !ct) return 0;
+            if (kq->op != GGML_OP_MUL_MAT || sm->op != GGML_OP_SOFT_MAX || kqv->op != GGML_OP_MUL_MAT || pm->op != GGML_OP_PERMUTE || ct->op != GGML_OP_CONT) return 0;
+            // v view [n_kv, dh, Hkv] of the transposed V cache
+            if (vv->data != vcache->data || vv->ne[0] != n_kv || vv->ne[1] != dh || vv->ne[2] != Hkv || vv->ne[3] != 1 || vv->nb[0] != 2 ||
+                vv->nb[1] != (size_t) n_ctx * 2 || vv->nb[2] != (size_t) n_ctx * dh * 2) return 0;
+            if (kq->src[0] != kv || kq->src[1] != qp || kq->type != GGML_TYPE_F32 || kq->ne[0] != n_kv || kq->ne[1] != 1 || kq->ne[2] != H) return 0;
+            mask = sm->src[1];
+            float max_bias; memcpy(&scale, sm->op_params, 4); memcpy(&max_bias, (const float *) sm->op_params + 1, 4);
+            if (sm->src[0] != kq || max_bias != 0.0f || sm->ne[0] != n_kv) return 0;
+            if (mask && (mask->type != GGML_TYPE_F32 || mask->ne[0] != n_kv || mask->nb[0] != 4 || mask->ne[2] != 1 || mask->ne[3] != 1)) return 0;
+            if (kqv->src[0] != vv || kqv->src[1] != sm || kqv->ne[0] != dh || kqv->ne[1] != 1 || kqv->ne[2] != H) return 0;
+            if (pm->src[0] != kqv || ct->src[0] != pm || !f32_vec(ct, Eq) || pm->ne[0] != dh || pm->ne[1] != H || pm->ne[2] != 1) return 0;
+            out_t = ct;
+            i += 5;
+        } else {
+            // FLASH_ATTN_EXT(q, k, v, mask F16) RESHAPE(-> [Eq, 1])  (llm_build_kqv, src/llama.cpp:10075-10095)
+            const ggml_tensor * fe = N(i), * rs2 = N(i + 1);
+            if (!fe || !rs2 || fe->op != GGML_OP_FLASH_ATTN_EXT || rs2->op != GGML_OP_RESHAPE || rs2->src[0] != fe) return 0;
+            // v view [dh, n_kv, Hkv]: rows of the V cache from cell 0
+            if (vv->data != vcache->data || vv->ne[0] != dh || vv->ne[1] != n_kv || vv->ne[2] != Hkv || vv->ne[3] != 1 || vv->nb[0] != 2 ||
+                vv->nb[1] != k_row || vv->nb[2] != (size_t) dh * 2) return 0;
+            if (fe->src[0] != qp || fe->src[1] != kv || fe->src[2] != vv || fe->type != GGML_TYPE_F32 || fe->ne[0] != dh || fe->ne[1] != H || fe->ne[2] != 1 || fe->ne[3] != 1 ||
+                !ggml_is_contiguous(fe)) return 0;
+            float max_bias, softcap;
+            memcpy(&scale, fe->op_params, 4); memcpy(&max_bias, (const float *) fe->op_params + 1, 4); memcpy(&softcap, (const float *) fe->op_params + 2, 4);
+            if (max_bias != 0.0f || softcap != 0.0f) return 0;
+            mask = fe->src[3];
+            if (mask && (mask->type != GGML_TYPE_F16 || mask->ne[0] != n_kv || mask->nb[0] != 2 || mask->ne[2] != 1 || mask->ne[3] != 1)) return 0;
+            if (mask_cast >= 0 && nodes_[mask_cast] != mask) return 0;  // some other cast sitting here: not ours to reorder
+            if (!f32_vec(rs2, Eq) || rs2->data != fe->data) return 0;
+            out_t = rs2;
+            i += 2;
+        }
         const int hi = i;
-        const int out_idx = hi - 1;                                  // the CONT node
+        const int out_idx = hi - 1;                                  // the CONT node / the RESHAPE of the flash-attention result
         // supported by the kernels?
         const bool can_split = (dh == 64 || dh == 128) && H / Hkv <= 8;
         const bool can_fused = dh == 64 || dh == 128 || dh == 256;
@@ -371,13 +410,15 @@ private:
         // one workgroup per head: the score buffer lives in LDS, sized for split_min (+ one padding step of the cache) or, when the
         // split kernels cannot serve this shape, for the whole cache
         const int64_t max_keys = can_split ? c_.split_min + 32 : n_ctx;
-        if (!split && !(can_fused && n_kv <= max_keys && (size_t) (4 * dh + 256 + max_keys + 16) * 4 <= 150 * 1024)) return 0;
+        if (!split && !(can_fused && n_kv <= max_keys && (size_t) (4 * dh + (fa ? 2048 : 256) + max_keys + 16) * 4 <= 150 * 1024)) return 0;
         float * sq = c_.qkv_scratch ? c_.qkv_scratch(c_.user, (size_t) Eq, (size_t) Ekv) : nullptr;
         if (!sq) return 0;
         float * sk = sq + Eq, * sv = sk + Ekv;
         // one cell / cells-attended pair per graph
         if (p.has_attn && (cell_ != cell || n_kv_ != n_kv)) return 0;
-        if (!range_private(i0, hi, &out_idx, 1)) return 0;
+        const int outs[2] = {out_idx, mask_cast};
+        if (!range_private(i0, hi, outs, mask_cast >= 0 ? 2 : 1)) return 0;
+        if (mask_cast >= 0) emit_node(p, mask_cast);                 // the F16 mask is produced first: later layers' graphs-in-graph read it too
         // launch 1: norm + QKV
         pm355_matvec_job jobs[3] = { job_of(mq, sq, bq, nullptr), job_of(mk, sk, bk, nullptr), job_of(mv, sv, bv, nullptr) };
         const bool one_launch = pm355_mul_mat_vec_fused_check(jobs, 3, E) == 0;
@@ -389,9 +430,10 @@ private:
         s.kind = STEP_ATTN; s.node = -1; s.node_lo = i0; s.node_hi = hi;
         s.attn.q = sq; s.attn.k = sk; s.attn.v = sv; s.attn.k_cache = kcache->data; s.attn.v_cache = vcache->data;
         s.attn.d_pos = (const int32_t *) rq->src[1]->data; s.attn.d_cell_nkv = c_.d_dyn;
-        s.attn.mask = mask ? (const float *) mask->data : nullptr;
+        s.attn.mask = mask ? mask->data : nullptr;
+        s.attn.flags = fa ? (PM355_ATTN_V_ROWMAJOR | PM355_ATTN_MASK_F16) : 0;
         s.attn.freq_factors = rq->src[2] ? (const float *) rq->src[2]->data : nullptr;
-        s.attn.out = (float *) ct->data; s.attn.scratch = split ? split_mem : nullptr;
+        s.attn.out = (float *) out_t->data; s.attn.scratch = split ? split_mem : nullptr;
         s.attn.n_head = (int32_t) H; s.attn.n_head_kv = (int32_t) Hkv; s.attn.head_dim = (int32_t) dh; s.attn.n_ctx = (int32_t) n_ctx;
         s.attn.split = split ? 1 : 0; s.attn.max_keys = split ? 0 : (int32_t) max_keys; s.attn.kq_scale = scale;
         rope_params_of(rq, s.rope);

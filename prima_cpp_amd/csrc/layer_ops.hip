@@ -203,12 +203,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float * q, const
 //   PV: thread = (channel e, part); each thread streams its own V^T row with 16-B loads - no cross-lane reduction.
 // Same rounding points as attn_decode_kernel / the reference (q, p -> F16; K, V F16; f32 accumulate).
 // ------------------------------------------------------------------------------------------------
-template <int DH>
+template <int DH, int VM = 0>
 __global__ __launch_bounds__(256) void attn_rope_fused_kernel(AttnP a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float redf[8];
     __shared__ double redd[4];
-    attn_rope_body<DH, false>(a, blockIdx.x, smem, redf, redd);
+    attn_rope_body<DH, false, VM>(a, blockIdx.x, smem, redf, redd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -320,19 +320,24 @@ int pm_launch_attn_decode(const float * q, const void * kc, const void * vc, con
 int pm_launch_attn_rope_fused(const float * q, const float * k, const float * v, void * kc, void * vc,
                                const int32_t * pos0, const int32_t * seq, long seq_stride, const float * freq_factors,
                                float * out, int H, int Hkv, int dh, int n_ctx, float scale, const pm_rope_cfg & c, hipStream_t st,
-                               const int32_t * dyn, const float * mask, int max_keys) {
+                               const int32_t * dyn, const void * mask, int max_keys, int v_rowmajor, int mask_f16) {
     if ((dh != 64 && dh != 128 && dh != 256) || n_ctx % 8) return -1;
-    const size_t lds = (size_t) (4 * dh + 256 + (max_keys > 0 ? ((max_keys + 7) & ~7) : n_ctx) + 8) * 4;
+    const size_t lds = (size_t) (4 * dh + (v_rowmajor ? 2048 : 256) + (max_keys > 0 ? ((max_keys + 7) & ~7) : n_ctx) + 8) * 4;
     if (lds > 150 * 1024) return -1;
     RopeP r;
     r.n_dims = c.n_dims; r.mode = c.mode; r.n_ctx_orig = c.n_ctx_orig; r.theta_scale = c.theta_scale;
     r.freq_scale = c.freq_scale; r.ext_factor = c.ext_factor; r.attn_factor = c.attn_factor; r.corr0 = c.corr0; r.corr1 = c.corr1;
     auto launch = [&](auto kern) {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        AttnP a = {q, k, v, (uint16_t *) kc, (uint16_t *) vc, pos0, seq, seq_stride, freq_factors, out, H, Hkv, n_ctx, scale, r, dyn, mask};
+        AttnP a = {q, k, v, (uint16_t *) kc, (uint16_t *) vc, pos0, seq, seq_stride, freq_factors, out, H, Hkv, n_ctx, scale, r, dyn,
+                   (const float *) mask, mask_f16};
         hipLaunchKernelGGL(kern, dim3(H), dim3(256), lds, st, a);
     };
-    if (dh == 64) launch(attn_rope_fused_kernel<64>);
+    if (v_rowmajor) {
+        if (dh == 64) launch(attn_rope_fused_kernel<64, 1>);
+        else if (dh == 128) launch(attn_rope_fused_kernel<128, 1>);
+        else launch(attn_rope_fused_kernel<256, 1>);
+    } else if (dh == 64) launch(attn_rope_fused_kernel<64>);
     else if (dh == 128) launch(attn_rope_fused_kernel<128>);
     else launch(attn_rope_fused_kernel<256>);
     return 0;

@@ -23,7 +23,8 @@ int  pm_launch_attn_decode(const float * q, const void * kc, const void * vc, co
 size_t pm_attn_split_scratch_floats(int H, int dh, int n_ctx);
 int  pm_launch_attn_split(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos0, const int32_t * seq,
                           long seq_stride, const float * freq_factors, float * out, float * scratch, int H, int Hkv, int dh, int n_ctx,
-                          float scale, const pm_rope_cfg * rope, hipStream_t st, const int32_t * dyn = nullptr, const float * mask = nullptr);
+                          float scale, const pm_rope_cfg * rope, hipStream_t st, const int32_t * dyn = nullptr, const void * mask = nullptr,
+                          int v_rowmajor = 0, int mask_f16 = 0);
 // causal multi-token attention on MFMA (attn_prefill.hip); -1: unsupported shape (head_dim 64/128, n_ctx % 32 == 0)
 int  pm_launch_attn_prefill(const float * q, const void * kc, const void * vc, const int32_t * pos0, const int32_t * seq,
                             long seq_stride, float * out, int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st,
@@ -31,9 +32,10 @@ int  pm_launch_attn_prefill(const float * q, const void * kc, const void * vc, c
 int  pm_launch_attn_rope_fused(const float * q, const float * k, const float * v, void * kc, void * vc,
                                 const int32_t * pos0, const int32_t * seq, long seq_stride, const float * freq_factors,
                                 float * out, int H, int Hkv, int dh, int n_ctx, float scale, const pm_rope_cfg & c, hipStream_t st,
-                                const int32_t * dyn = nullptr, const float * mask = nullptr, int max_keys = 0);
+                                const int32_t * dyn = nullptr, const void * mask = nullptr, int max_keys = 0, int v_rowmajor = 0, int mask_f16 = 0);
 // ggml-graph mode of the two launchers above: dyn = device int32[2] {cache cell the token is stored in, cells attended}, the RoPE
-// position is pos0[0], mask = additive f32 KQ-mask row [cells attended] or null; max_keys (> 0) sizes the fused kernel's LDS score
+// position is pos0[0], mask = additive KQ-mask row [cells attended] (f32, or F16 with mask_f16) or null; v_rowmajor = the V cache is
+// [n_ctx][n_embd_v_gqa] (flash-attention graphs) instead of transposed, with flash-attention rounding points; max_keys (> 0) sizes the fused kernel's LDS score
 // buffer instead of n_ctx (the caller guarantees cells attended <= max_keys)
 void pm_launch_set_i32x2(int32_t * p, int a, int b, hipStream_t st);
 void pm_launch_argmax(const float * x, int n, int32_t * idx, float * val, hipStream_t st);
