@@ -228,6 +228,12 @@ typedef struct {
  * ggml_compute_forward_flash_attn_ext_f16 (q -> F16, probabilities stay f32) with an f32 accumulator. */
 #define PM355_ATTN_V_ROWMAJOR 1
 #define PM355_ATTN_MASK_F16   2
+/* quantized KV cache (`-ctk q8_0` / `-ctv q8_0`, with flash attention): k_cache / v_cache hold native Q8_0 blocks (34 bytes per 32
+ * values), rows like K; the token's K / V are quantized on store (quantize_row_q8_0_ref) and the query is quantized to Q8_0 for the
+ * K.q products (ggml_vec_dot_q8_0_q8_0) as the reference CPU path does. One workgroup per head (no split path): max_keys bounds the
+ * cells attended. Requires PM355_ATTN_V_ROWMAJOR. */
+#define PM355_ATTN_K_Q8_0     4
+#define PM355_ATTN_V_Q8_0     8
 PM355_API int pm355_attn_token(const pm355_attn_token_args * a, const pm355_rope_params * rp, pm355_stream_t stream);
 /* p[0] = a, p[1] = b on the stream (values travel as kernel arguments: no host buffer lifetime to manage) */
 PM355_API int pm355_set_i32x2(int32_t * d_p, int32_t a, int32_t b, pm355_stream_t stream);

@@ -245,6 +245,15 @@ int pm355_attn_token(const pm355_attn_token_args * a, const pm355_rope_params * 
     c.ext_factor = rp->ext_factor; c.attn_factor = rp->attn_factor; c.beta_fast = rp->beta_fast; c.beta_slow = rp->beta_slow;
     pm_rope_params(c);
     (void) hipGetLastError();
+    if (a->flags & (PM355_ATTN_K_Q8_0 | PM355_ATTN_V_Q8_0)) {
+        if (!(a->flags & PM355_ATTN_V_ROWMAJOR) || a->split) return fail(PM355_E_UNSUPPORTED, "attn_token: a quantized KV cache needs row-major V and the one-workgroup-per-head path");
+        if (pm_launch_attn_q8_token(a->q, a->k, a->v, a->k_cache, a->v_cache, a->d_pos, a->d_cell_nkv, a->mask, a->flags & PM355_ATTN_MASK_F16,
+                                    a->freq_factors, a->out, a->n_head, a->n_head_kv, a->head_dim, a->n_ctx, a->kq_scale, c,
+                                    a->flags & PM355_ATTN_K_Q8_0, a->flags & PM355_ATTN_V_Q8_0, a->max_keys, S(st)))
+            return fail(PM355_E_UNSUPPORTED, "attn_token(q8_0): head_dim 64/128 and max_keys must fit LDS");
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (a->split) {
         if (pm_launch_attn_split(a->q, a->k, a->v, a->k_cache, a->v_cache, a->d_pos, nullptr, 0, a->freq_factors, a->out, a->scratch,
                                  a->n_head, a->n_head_kv, a->head_dim, a->n_ctx, a->kq_scale, &c, S(st), a->d_cell_nkv, a->mask,

@@ -52,6 +52,13 @@ int drepack(int type, const void * src, void * dst, int64_t K, int64_t rows, int
 }
 
 bool is_soa_type(enum ggml_type t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q6_K || t == GGML_TYPE_Q8_0; }   // repack.hip
+// ... of weight MATRICES. A 1-D quantized tensor - the quantized KV caches (ggml_new_tensor_1d(type_k, n_embd_k_gqa * kv_size),
+// llama_kv_cache_init src/llama.cpp:3548-3551) - keeps ggml's native block order, so the byte offsets of the reference's cache views
+// and of state save / restore stay valid (attn_q8.hip)
+bool is_soa_tensor(const struct ggml_tensor * t) {
+    const struct ggml_tensor * r = t->view_src ? t->view_src : t;
+    return is_soa_type(r->type) && r->ne[1] > 1;
+}
 bool is_gemv_type(enum ggml_type t) { return t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K || t == GGML_TYPE_Q8_0; }
 
 struct dev_ctx { int device; std::string name, desc; };
@@ -142,7 +149,7 @@ void buf_memset_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, uint8_t 
 void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void * data, size_t off, size_t size) {
     buf_ctx * c = (buf_ctx *) b->context;
     dsetdev(c->device);
-    const bool soa = is_soa_type(t->type);
+    const bool soa = is_soa_tensor(t);
     const size_t rb = ggml_row_size(t->type, t->ne[0]), stride = soa ? pm355_row_stride(t->type, t->ne[0]) : rb;
     if (soa) {
         GGML_ASSERT(off % rb == 0 && size % rb == 0 && "row-granular access to a row-SoA tensor");
@@ -176,7 +183,7 @@ void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void 
 void buf_get_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * t, void * data, size_t off, size_t size) {
     dsetdev(((buf_ctx *) b->context)->device);
     buf_drain((buf_ctx *) b->context);
-    if (is_soa_type(t->type)) {
+    if (is_soa_tensor(t)) {
         const size_t rb = ggml_row_size(t->type, t->ne[0]), stride = pm355_row_stride(t->type, t->ne[0]);
         GGML_ASSERT(off % rb == 0 && size % rb == 0 && "row-granular access to a row-SoA tensor");
         GGML_ASSERT(!t->view_src && "row-SoA tensors are addressed per allocated tensor, not through views");
@@ -190,7 +197,7 @@ void buf_get_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * t, void 
     MI355_CHECK(dsync(nullptr));
 }
 size_t hbm_bytes(const struct ggml_tensor * t) {
-    if (is_soa_type(t->type)) return pm355_row_stride(t->type, t->ne[0]) * (size_t) (t->ne[1] * t->ne[2] * t->ne[3]);
+    if (is_soa_tensor(t)) return pm355_row_stride(t->type, t->ne[0]) * (size_t) (t->ne[1] * t->ne[2] * t->ne[3]);
     return ggml_nbytes(t);
 }
 bool buf_cpy_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * src, struct ggml_tensor * dst) {
@@ -279,14 +286,14 @@ void backend_set_async(ggml_backend_t b, struct ggml_tensor * t, const void * da
     backend_ctx * c = (backend_ctx *) b->context;
     dsetdev(c->device);
     drain_all_uploads();
-    if (is_soa_type(t->type)) { dsync(c->stream); buf_set_tensor(t->view_src ? t->view_src->buffer : t->buffer, t, data, off, size); return; }
+    if (is_soa_tensor(t)) { dsync(c->stream); buf_set_tensor(t->view_src ? t->view_src->buffer : t->buffer, t, data, off, size); return; }
     MI355_CHECK(h2d((char *) t->data + off, data, size, c->stream));
 }
 void backend_get_async(ggml_backend_t b, const struct ggml_tensor * t, void * data, size_t off, size_t size) {
     backend_ctx * c = (backend_ctx *) b->context;
     dsetdev(c->device);
     drain_all_uploads();
-    if (is_soa_type(t->type)) { dsync(c->stream); buf_get_tensor(t->view_src ? t->view_src->buffer : t->buffer, t, data, off, size); return; }
+    if (is_soa_tensor(t)) { dsync(c->stream); buf_get_tensor(t->view_src ? t->view_src->buffer : t->buffer, t, data, off, size); return; }
     MI355_CHECK(d2h(data, (const char *) t->data + off, size, c->stream));
 }
 void backend_sync(ggml_backend_t b) {
@@ -312,7 +319,7 @@ bool mul_mat_quant_ok(const struct ggml_tensor * op) {
     if (!is_gemv_type(a->type) || b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32) return false;
     if (!ggml_is_contiguous(a) || !ggml_is_contiguous(b) || !ggml_is_contiguous(op)) return false;
     if (a->ne[2] != 1 || a->ne[3] != 1 || b->ne[2] != 1 || b->ne[3] != 1) return false;
-    if (a->view_src && is_soa_type(a->type)) return false;           // row-SoA layout is per allocated tensor
+    if (is_soa_type(a->type) && (a->view_src || !is_soa_tensor(a))) return false;   // row-SoA layout is per allocated weight matrix (not views, not the 1-D quantized KV caches)
     if (a->ne[0] % (a->type == GGML_TYPE_Q8_0 ? 32 : 256)) return false;
     return a->ne[0] <= 131072;
 }
@@ -336,6 +343,9 @@ bool supports_op_impl(const struct ggml_tensor * op) {
             return ggml_get_unary_op(op) == GGML_UNARY_OP_SILU && a->type == GGML_TYPE_F32;
         case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
             const enum ggml_type ts = a->type, td = op->type;
+            // KV store into a quantized cache: f32 rows -> contiguous native Q8_0 blocks of a 1-D cache tensor (attn_q8.hip)
+            if (op->op == GGML_OP_CPY && ts == GGML_TYPE_F32 && td == GGML_TYPE_Q8_0)
+                return a->nb[0] == 4 && a->ne[0] % 32 == 0 && ggml_is_contiguous(op) && op->view_src && !is_soa_tensor(op);
             return (ts == GGML_TYPE_F32 || ts == GGML_TYPE_F16) && (td == GGML_TYPE_F32 || td == GGML_TYPE_F16);
         }
         case GGML_OP_SOFT_MAX:
@@ -346,9 +356,16 @@ bool supports_op_impl(const struct ggml_tensor * op) {
             return a->type == GGML_TYPE_F32 && (mode == 0 || mode == 2) && a->ne[0] % 2 == 0;
         }
         case GGML_OP_FLASH_ATTN_EXT: {
-            // F16 K / V (the default KV cache type); quantized KV caches stay on the CPU backend
+            // F16 K / V (the default KV cache type), or Q8_0 K and / or V (-ctk / -ctv q8_0: native blocks, attn_q8.hip)
             const struct ggml_tensor * k = op->src[1], * v = op->src[2], * m = op->src[3];
             const int64_t D = a->ne[0];
+            if (a->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && (k->type == GGML_TYPE_Q8_0 || v->type == GGML_TYPE_Q8_0)) {
+                float max_bias; memcpy(&max_bias, (const float *) op->op_params + 1, 4);
+                if ((k->type != GGML_TYPE_Q8_0 && k->type != GGML_TYPE_F16) || (v->type != GGML_TYPE_Q8_0 && v->type != GGML_TYPE_F16)) return false;
+                if ((k->type == GGML_TYPE_Q8_0 && is_soa_tensor(k)) || (v->type == GGML_TYPE_Q8_0 && is_soa_tensor(v))) return false;
+                if ((D != 64 && D != 128 && D != 256) || a->nb[0] != 4 || max_bias != 0.0f || (m && m->type != GGML_TYPE_F16)) return false;
+                return (size_t) (D + ((k->ne[1] + 3) & ~3) + (256 / (D / 8)) * D) * 4 <= 150 * 1024;
+            }
             if (a->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16 || op->type != GGML_TYPE_F32) return false;
             if (D < 8 || D > 256 || a->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || (m && m->type != GGML_TYPE_F16)) return false;
             const int64_t Dp = (D + 7) & ~7;
@@ -356,7 +373,7 @@ bool supports_op_impl(const struct ggml_tensor * op) {
         }
         case GGML_OP_GET_ROWS:
             return b->type == GGML_TYPE_I32 && ggml_is_contiguous(b) && b->ne[1] == 1 && b->ne[2] == 1 && b->ne[3] == 1 &&
-                   (a->type == GGML_TYPE_F32 || (is_gemv_type(a->type) && ggml_is_contiguous(a) && a->ne[2] == 1 && a->ne[3] == 1 && !a->view_src));
+                   (a->type == GGML_TYPE_F32 || (is_gemv_type(a->type) && ggml_is_contiguous(a) && a->ne[2] == 1 && a->ne[3] == 1 && !a->view_src && (!is_soa_type(a->type) || is_soa_tensor(a))));
         default:
             return false;
     }

@@ -109,7 +109,8 @@ inline void fill_tensor_fp(tensor_fp & f, const ggml_tensor * t) {
 struct graph_fp_node { int32_t op, type, flags; uint32_t params; const void * base; int64_t ne[4]; size_t nb[4]; const void * src[3]; };
 
 inline const void * fp_base(const ggml_tensor * t) {
-    if (t->view_src && t->view_src->type == GGML_TYPE_F16 && t->view_src->op == GGML_OP_NONE && !t->view_src->view_src) return t->view_src->data;
+    const ggml_tensor * r = t->view_src;           // F16 leaf, or a 1-D Q8_0 leaf (quantized KV cache)
+    if (r && (r->type == GGML_TYPE_F16 || (r->type == GGML_TYPE_Q8_0 && r->ne[1] == 1)) && r->op == GGML_OP_NONE && !r->view_src) return r->data;
     return t->data;
 }
 inline void graph_fingerprint(struct ggml_cgraph * g, std::vector<graph_fp_node> & out) {
@@ -320,10 +321,16 @@ private:
         if (!vcv || !vcp) return 0;
         if (kcv->op != GGML_OP_VIEW || kcp->op != GGML_OP_CPY || vcv->op != GGML_OP_VIEW || vcp->op != GGML_OP_CPY) return 0;
         const ggml_tensor * kcache = kcv->view_src, * vcache = vcv->view_src;
-        if (!kcache || !vcache || kcache->type != GGML_TYPE_F16 || vcache->type != GGML_TYPE_F16 || kcache->view_src || vcache->view_src ||
+        if (!kcache || !vcache || kcache->view_src || vcache->view_src ||
             kcache->op != GGML_OP_NONE || vcache->op != GGML_OP_NONE || !ggml_is_contiguous(kcache) || !ggml_is_contiguous(vcache)) return 0;
-        if (kcp->src[0] != rk || kcp->src[1] != kcv || kcv->type != GGML_TYPE_F16 || kcv->ne[0] != Ekv || kcv->ne[1] != 1 || kcv->nb[0] != 2) return 0;
-        const size_t k_row = (size_t) Ekv * 2;
+        // F16 caches; with flash attention also Q8_0 (1-D tensors of native 34-byte blocks, attn_q8.hip)
+        const bool kq8 = kcache->type == GGML_TYPE_Q8_0, vq8 = vcache->type == GGML_TYPE_Q8_0;
+        if ((!kq8 && kcache->type != GGML_TYPE_F16) || (!vq8 && vcache->type != GGML_TYPE_F16) || ((kq8 || vq8) && !fa)) return 0;
+        if ((kq8 && (kcache->ne[1] != 1 || dh % 32)) || (vq8 && (vcache->ne[1] != 1 || dh % 32))) return 0;
+        const size_t k_ts = kq8 ? 34 : 2, v_ts = vq8 ? 34 : 2;
+        const size_t k_row = kq8 ? (size_t) Ekv / 32 * 34 : (size_t) Ekv * 2, v_rowb = vq8 ? (size_t) Ekv / 32 * 34 : (size_t) Ekv * 2;
+        const size_t k_hd = kq8 ? (size_t) dh / 32 * 34 : (size_t) dh * 2, v_hd = vq8 ? (size_t) dh / 32 * 34 : (size_t) dh * 2;
+        if (kcp->src[0] != rk || kcp->src[1] != kcv || kcv->type != kcache->type || kcv->ne[0] != Ekv || kcv->ne[1] != 1 || kcv->nb[0] != k_ts) return 0;
         const size_t k_off = (const char *) kcv->data - (const char *) kcache->data, v_off = (const char *) vcv->data - (const char *) vcache->data;
         int64_t n_ctx;
         if (!fa) {
@@ -331,8 +338,8 @@ private:
             if (k_off % k_row || v_off % 2 || k_off / k_row != v_off / 2) return 0;
             n_ctx = (int64_t) (vcv->nb[1] / 2);
         } else {
-            if (vcp->src[0] != v || vcp->src[1] != vcv || vcv->type != GGML_TYPE_F16 || vcv->ne[0] != Ekv || vcv->ne[1] != 1 || vcv->nb[0] != 2) return 0;
-            if (k_off % k_row || v_off != k_off) return 0;
+            if (vcp->src[0] != v || vcp->src[1] != vcv || vcv->type != vcache->type || vcv->ne[0] != Ekv || vcv->ne[1] != 1 || vcv->nb[0] != v_ts) return 0;
+            if (k_off % k_row || v_off % v_rowb || v_off / v_rowb != k_off / k_row) return 0;
             n_ctx = (int64_t) ggml_nelements(kcache) / Ekv;
         }
         if (n_ctx <= 0 || n_ctx % 8 || (int64_t) ggml_nelements(kcache) < n_ctx * Ekv || (int64_t) ggml_nelements(vcache) < n_ctx * Ekv) return 0;
@@ -356,7 +363,7 @@ private:
         if (!vv || !kv || !qp) return 0;
         const int64_t n_kv = kv->ne[1];
         // k view [dh, n_kv, Hkv] rows of the K cache from cell 0; q [dh, 1, H]
-        if (kv->data != kcache->data || kv->ne[0] != dh || kv->ne[2] != Hkv || kv->ne[3] != 1 || kv->nb[0] != 2 || kv->nb[1] != k_row || kv->nb[2] != (size_t) dh * 2) return 0;
+        if (kv->data != kcache->data || kv->ne[0] != dh || kv->ne[2] != Hkv || kv->ne[3] != 1 || kv->nb[0] != k_ts || kv->nb[1] != k_row || kv->nb[2] != k_hd) return 0;
         if (qp->ne[0] != dh || qp->ne[1] != 1 || qp->ne[2] != H || qp->nb[0] != 4 || qp->nb[2] != (size_t) dh * 4 || qp->data != rq->data) return 0;
         if (n_kv > n_ctx || cell >= n_kv) return 0;
         const ggml_tensor * mask = nullptr, * out_t = nullptr;
@@ -382,8 +389,8 @@ private:
             const ggml_tensor * fe = N(i), * rs2 = N(i + 1);
             if (!fe || !rs2 || fe->op != GGML_OP_FLASH_ATTN_EXT || rs2->op != GGML_OP_RESHAPE || rs2->src[0] != fe) return 0;
             // v view [dh, n_kv, Hkv]: rows of the V cache from cell 0
-            if (vv->data != vcache->data || vv->ne[0] != dh || vv->ne[1] != n_kv || vv->ne[2] != Hkv || vv->ne[3] != 1 || vv->nb[0] != 2 ||
-                vv->nb[1] != k_row || vv->nb[2] != (size_t) dh * 2) return 0;
+            if (vv->data != vcache->data || vv->ne[0] != dh || vv->ne[1] != n_kv || vv->ne[2] != Hkv || vv->ne[3] != 1 || vv->nb[0] != v_ts ||
+                vv->nb[1] != v_rowb || vv->nb[2] != v_hd) return 0;
             if (fe->src[0] != qp || fe->src[1] != kv || fe->src[2] != vv || fe->type != GGML_TYPE_F32 || fe->ne[0] != dh || fe->ne[1] != H || fe->ne[2] != 1 || fe->ne[3] != 1 ||
                 !ggml_is_contiguous(fe)) return 0;
             float max_bias, softcap;
@@ -399,8 +406,9 @@ private:
         const int hi = i;
         const int out_idx = hi - 1;                                  // the CONT node / the RESHAPE of the flash-attention result
         // supported by the kernels?
-        const bool can_split = (dh == 64 || dh == 128) && H / Hkv <= 8;
-        const bool can_fused = dh == 64 || dh == 128 || dh == 256;
+        const bool q8 = kq8 || vq8;                                   // quantized cache: one workgroup per head only, head_dim 64 / 128
+        const bool can_split = (dh == 64 || dh == 128) && H / Hkv <= 8 && !q8;
+        const bool can_fused = dh == 64 || dh == 128 || (dh == 256 && !q8);
         bool split = n_kv >= c_.split_min && can_split;
         float * split_mem = nullptr;
         if (split) {
@@ -409,7 +417,7 @@ private:
         }
         // one workgroup per head: the score buffer lives in LDS, sized for split_min (+ one padding step of the cache) or, when the
         // split kernels cannot serve this shape, for the whole cache
-        const int64_t max_keys = can_split ? c_.split_min + 32 : n_ctx;
+        const int64_t max_keys = can_split ? c_.split_min + 32 : (q8 && n_ctx > 32768 ? 32768 : n_ctx);
         if (!split && !(can_fused && n_kv <= max_keys && (size_t) (4 * dh + (fa ? 2048 : 256) + max_keys + 16) * 4 <= 150 * 1024)) return 0;
         float * sq = c_.qkv_scratch ? c_.qkv_scratch(c_.user, (size_t) Eq, (size_t) Ekv) : nullptr;
         if (!sq) return 0;
@@ -431,7 +439,7 @@ private:
         s.attn.q = sq; s.attn.k = sk; s.attn.v = sv; s.attn.k_cache = kcache->data; s.attn.v_cache = vcache->data;
         s.attn.d_pos = (const int32_t *) rq->src[1]->data; s.attn.d_cell_nkv = c_.d_dyn;
         s.attn.mask = mask ? mask->data : nullptr;
-        s.attn.flags = fa ? (PM355_ATTN_V_ROWMAJOR | PM355_ATTN_MASK_F16) : 0;
+        s.attn.flags = (fa ? (PM355_ATTN_V_ROWMAJOR | PM355_ATTN_MASK_F16) : 0) | (kq8 ? PM355_ATTN_K_Q8_0 : 0) | (vq8 ? PM355_ATTN_V_Q8_0 : 0);
         s.attn.freq_factors = rq->src[2] ? (const float *) rq->src[2]->data : nullptr;
         s.attn.out = (float *) out_t->data; s.attn.scratch = split ? split_mem : nullptr;
         s.attn.n_head = (int32_t) H; s.attn.n_head_kv = (int32_t) Hkv; s.attn.head_dim = (int32_t) dh; s.attn.n_ctx = (int32_t) n_ctx;
@@ -602,7 +610,7 @@ inline bool plan_dyn(struct ggml_cgraph * g, const plan & p, int32_t & cell, int
     if (p.i_kcell < 0 || p.i_kview < 0 || p.i_kcell >= ggml_graph_n_nodes(g) || p.i_kview >= ggml_graph_n_nodes(g)) return false;
     const ggml_tensor * cp = ggml_graph_node(g, p.i_kcell), * kv = ggml_graph_node(g, p.i_kview);
     if (cp->op != GGML_OP_CPY || !cp->view_src || kv->op != GGML_OP_VIEW) return false;
-    const size_t row = (size_t) cp->ne[0] * 2;
+    const size_t row = ggml_row_size(cp->type, cp->ne[0]);
     cell = (int32_t) (((const char *) cp->data - (const char *) cp->view_src->data) / row);
     n_kv = (int32_t) kv->ne[1];
     return true;

@@ -270,6 +270,12 @@ extern "C" {
 
 int pm355_op_cpy(const pm355_tensor * src, const pm355_tensor * dst, pm355_stream_t st) {
     const int ts = src->type, td = dst->type;
+    if (td == PM_Q8_0) {                             // KV store into a quantized cache (attn_q8.hip); dst = contiguous native blocks
+        if (nelem(src) != nelem(dst)) return PM355_E_SHAPE;
+        (void) hipGetLastError();
+        if (pm_launch_cpy_f32_q8_0(src, dst->data, S(st))) return PM355_E_UNSUPPORTED;
+        OKRET();
+    }
     if ((ts != PM_F32 && ts != PM_F16) || (td != PM_F32 && td != PM_F16) || nelem(src) != nelem(dst)) return PM355_E_UNSUPPORTED;
     const long n = nelem(dst);
     (void) hipGetLastError();
@@ -318,6 +324,18 @@ int pm355_op_soft_max(const pm355_tensor * a, const pm355_tensor * mask, const p
 }
 int pm355_op_flash_attn_ext(const pm355_tensor * q, const pm355_tensor * k, const pm355_tensor * v, const pm355_tensor * mask,
                             const pm355_tensor * dst, float scale, float max_bias, float logit_softcap, pm355_stream_t st) {
+    if (q->type == PM_F32 && dst->type == PM_F32 && (k->type == PM_Q8_0 || v->type == PM_Q8_0)) {      // quantized KV cache (attn_q8.hip)
+        if ((k->type != PM_Q8_0 && k->type != PM_F16) || (v->type != PM_Q8_0 && v->type != PM_F16) || q->nb[0] != 4 || dst->nb[0] != 4 || max_bias != 0.0f)
+            return PM355_E_UNSUPPORTED;
+        if (k->ne[0] != q->ne[0] || v->ne[0] != q->ne[0] || v->ne[1] != k->ne[1]) return PM355_E_SHAPE;
+        if (q->ne[2] % k->ne[2] || q->ne[2] % v->ne[2] || q->ne[3] % k->ne[3] || q->ne[3] % v->ne[3]) return PM355_E_SHAPE;
+        if (mask && (mask->type != PM_F16 || mask->ne[0] != k->ne[1] || mask->ne[1] < q->ne[1] || mask->nb[0] != 2)) return PM355_E_UNSUPPORTED;
+        if (dst->ne[0] != q->ne[0] || dst->ne[1] != q->ne[2] || dst->ne[2] != q->ne[1]) return PM355_E_SHAPE;
+        (void) hipGetLastError();
+        const int rc = pm_launch_flash_attn_ext_q8(q, k, v, mask, dst, scale, logit_softcap, S(st));
+        if (rc) return rc == -2 ? PM355_E_RANGE : PM355_E_UNSUPPORTED;
+        OKRET();
+    }
     if (q->type != PM_F32 || k->type != PM_F16 || v->type != PM_F16 || dst->type != PM_F32) return PM355_E_UNSUPPORTED;
     if (q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || dst->nb[0] != 4) return PM355_E_UNSUPPORTED;
     if (k->ne[0] != q->ne[0] || v->ne[0] != q->ne[0] || v->ne[1] != k->ne[1] || q->ne[0] > 256 || q->ne[0] < 8) return PM355_E_SHAPE;

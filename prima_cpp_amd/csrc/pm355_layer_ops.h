@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/prima_mi355.h"
 
 struct pm_rope_cfg {
     int n_dims, mode /*0 = NORM, 2 = NEOX*/, n_ctx_orig;
@@ -38,6 +39,13 @@ int  pm_launch_attn_rope_fused(const float * q, const float * k, const float * v
 // [n_ctx][n_embd_v_gqa] (flash-attention graphs) instead of transposed, with flash-attention rounding points; max_keys (> 0) sizes the fused kernel's LDS score
 // buffer instead of n_ctx (the caller guarantees cells attended <= max_keys)
 void pm_launch_set_i32x2(int32_t * p, int a, int b, hipStream_t st);
+// quantized (Q8_0) KV cache, native 34-byte blocks (attn_q8.hip)
+int  pm_launch_cpy_f32_q8_0(const pm355_tensor * src, void * dst, hipStream_t st);
+int  pm_launch_flash_attn_ext_q8(const pm355_tensor * q, const pm355_tensor * k, const pm355_tensor * v, const pm355_tensor * mask,
+                                 const pm355_tensor * dst, float scale, float softcap, hipStream_t st);
+int  pm_launch_attn_q8_token(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos, const int32_t * dyn,
+                             const void * mask, int mask_f16, const float * ff, float * out, int H, int Hkv, int dh, int n_ctx, float scale,
+                             const pm_rope_cfg & c, int k_q8, int v_q8, int max_keys, hipStream_t st);
 void pm_launch_argmax(const float * x, int n, int32_t * idx, float * val, hipStream_t st);
 void pm_launch_add(const float * a, const float * b, float * y, long n, long nb, hipStream_t st);
 void pm_launch_mul(const float * a, const float * b, float * y, long n, long nb, hipStream_t st);

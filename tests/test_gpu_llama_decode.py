@@ -113,6 +113,26 @@ def test_llama_decode_plugin_flash_attn(gpu, name, tmp_path):
     _check(f"tiny_{name} -fa", toks, logits, path, z["prompt"], n, 64, cpu_args=["-fa"], nmse_floor=1e-3, err_floor=5e-2)
 
 
+@pytest.mark.parametrize("name", ["llama", "qwen2"])
+@pytest.mark.parametrize("ctk,ctv", [("q8_0", "q8_0"), ("q8_0", "f16"), ("f16", "q8_0")])
+def test_llama_decode_plugin_quantized_kv_cache(gpu, name, ctk, ctv, tmp_path):
+    """-ctk / -ctv q8_0 with --flash-attn: the KV store quantizes (CPY f32 -> Q8_0 view), the prompt batch runs FLASH_ATTN_EXT on the
+    native Q8_0 blocks and single tokens run the fused rope + quantized store + attention launch (attn_q8.hip) - against the same
+    options on the reference CPU backend (which quantizes the query to Q8_0 for a Q8_0 K cache), and lowered vs node by node."""
+    z = np.load(os.path.join(HERE, "golden", f"tiny_{name}_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / f"tiny_{name}.gguf"), z)
+    n = len(z["tokens"])
+    kv = ["-fa", "-ctk", ctk, "-ctv", ctv]
+    toks, logits, stats = run_llama_driver(path, z["prompt"], n, ngl=99, n_ctx=64, extra_args=GPU_ARGS + kv, env={"GGML_MI355_STATS": "1"})
+    assert f"K ({ctk})" in stats["stderr"] and f"V ({ctv})" in stats["stderr"] and "MI355X0 KV buffer" in stats["stderr"], stats["stderr"][-1500:]
+    m = re.search(r"hipGraph replays (\d+)", stats["stderr"])
+    assert m and int(m.group(1)) >= n - 4, stats["stderr"][-600:]
+    t2, l2, _ = run_llama_driver(path, z["prompt"], n, ngl=99, n_ctx=64, extra_args=GPU_ARGS + kv, env={"GGML_MI355_NO_FUSE": "1"}, force=toks[:-1])
+    print(f"\n[{name} K {ctk} V {ctv}] lowered vs node-by-node NMSE {_nmse(logits, l2):.3e}")
+    assert _nmse(logits, l2) < 1e-5
+    _check(f"tiny_{name} -fa -ctk {ctk} -ctv {ctv}", toks, logits, path, z["prompt"], n, 64, cpu_args=kv, nmse_floor=1e-3, err_floor=5e-2)
+
+
 @pytest.mark.parametrize("fa", [False, True])
 def test_llama_decode_plugin_long_context_split_attention(gpu, fa, tmp_path):
     """Beyond GGML_MI355_ATTN_SPLIT_MIN cells (640) the single-token attention runs on the keys-split-over-workgroups kernels

@@ -46,3 +46,24 @@ def test_decode_graph_lowers_to_five_launches_per_layer(name, nodes, tmp_path):
     assert prefill and all(p[2] == 0 and p[3] == 0 and p[9] == 0 for p in prefill), prefill
     # ... except the attention chain of every layer, which becomes one launch of the masked MFMA attention
     assert f"{n_layer} multi-token attention chain(s) -> MFMA masked attention" in st["stderr"]
+
+
+def test_flash_attn_decode_graph_lowers_to_five_launches_per_layer(tmp_path):
+    """--flash-attn: CPY(V -> row of the row-major V cache), FLASH_ATTN_EXT(q, k, v, F16 mask) (llm_build_kv, src/llama.cpp:9705,
+    :10075-10095) lower to the same five launches per layer; the once-per-graph F32 -> F16 cast of the KQ mask stays a node."""
+    z = np.load(os.path.join(HERE, "golden", "tiny_llama_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / "tiny_llama.gguf"), z)
+    _, _, st = run_llama_driver(path, z["prompt"][:3], 4, ngl=99, n_ctx=64, threads=1, extra_args=["--keep-out-in-cuda", "-fa"],
+                                env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1"}, flavour="avx2", timeout=120)
+    assert "flash_attn   = 1" in st["stderr"]
+    plans = [tuple(int(x) for x in m.groups()) for m in PLAN.finditer(st["stderr"])]
+    n_layer = int(z["hp_n_layer"])
+    decode = [p for p in plans if p[0] > 3 and p[6] == 1]
+    assert len(decode) >= 3, st["stderr"][-2000:]
+    for p in decode:
+        nodes, launches, gemv, attn, node_eq, fused, single, cell, n_kv, graphable = p
+        assert attn == n_layer and gemv == 4 * n_layer and node_eq == 1 and launches == 5 * n_layer + 1, p
+        assert graphable == 1 and n_kv == 256                     # (flash attention pads the cells attended to 256, src/llama.cpp:18425)
+    assert "KQ_mask (copy)" in st["stderr"] and "FLASH_ATTN_EXT" not in st["stderr"].split("single_token=1")[1].split("ggml-mi355 plan")[0]
+    cells = [p[7] for p in decode]
+    assert cells[0] == 0 and cells[1:] == list(range(3, 3 + len(cells) - 1)), cells
