@@ -196,6 +196,11 @@ PM355_API int pm355_attn_prefill(const float * q, const void * k_cache, const vo
 PM355_API int pm355_attn_prefill_masked(const float * q, const void * k_cache, const void * v_cache, const float * mask, int64_t mask_stride,
                                         float * out, int n_tokens, int n_head, int n_head_kv, int head_dim, int n_ctx, int n_kv,
                                         float kq_scale, pm355_stream_t stream);
+/* the same for flash-attention graphs (FLASH_ATTN_EXT over a multi-token batch, llm_build_kqv src/llama.cpp:10075-10095):
+ * flags = PM355_ATTN_V_ROWMAJOR (V cache [n_ctx][n_head_kv*head_dim]) | PM355_ATTN_MASK_F16 (mask rows are F16, mask_stride in elements) */
+PM355_API int pm355_attn_prefill_masked_ex(const float * q, const void * k_cache, const void * v_cache, const void * mask, int64_t mask_stride,
+                                           float * out, int n_tokens, int n_head, int n_head_kv, int head_dim, int n_ctx, int n_kv,
+                                           float kq_scale, int flags, pm355_stream_t stream);
 /* single-token fusion of the two entries above (rope on q,k + KV store + attention in ONE launch; what the engine
  * uses at decode). q/k/v are the raw projections of ONE token; the caches receive the new K row / V column. */
 PM355_API int pm355_attn_rope_fused(const float * q, const float * k, const float * v, void * k_cache, void * v_cache,

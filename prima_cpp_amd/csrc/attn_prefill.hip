@@ -33,6 +33,10 @@ struct PfP {
     // ggml-graph mode (mask != nullptr; pm355_attn_prefill_masked): every query attends cells [0, n_kv) with the additive F32 KQ_mask
     // row of its token (0 / -inf; llama_set_inputs src/llama.cpp:17379-17420) instead of the causal rule "cell <= position"
     const float * mask; long mask_stride; int n_kv;
+    // flash-attention graphs (FLASH_ATTN_EXT, llm_build_kqv src/llama.cpp:10075-10095): v_rowmajor = the V cache is [n_ctx][Hkv*DH] like K
+    // (the V^T operand is then gathered with 2-byte loads: a lane needs 8 consecutive keys of ONE channel); mask_f16 = the mask rows are
+    // F16. P is rounded to F16 here as well (it is an MFMA operand; the reference keeps it f32 and rounds its F16 accumulator instead).
+    int v_rowmajor, mask_f16;
 };
 
 // key index (inside a 32-key tile) of accumulator register r in lane-half h: C[row = (r&3) + 8 (r>>2) + 4 h][col]
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
     const int seq = p.seq_ptr ? *p.seq_ptr : 0;
     const int pos0 = p.mask ? 0 : p.pos0_ptr[seq];
     const uint16_t * kc = p.kc + (long) seq * p.seq_stride + (long) hk * DH;          // K[key][Hkv*DH]
-    const uint16_t * vc = p.vc + (long) seq * p.seq_stride + (long) hk * DH * p.n_ctx; // V^T[hk*DH + e][n_ctx]
+    const uint16_t * vc = p.vc + (long) seq * p.seq_stride + (p.v_rowmajor ? (long) hk * DH : (long) hk * DH * p.n_ctx); // V^T[hk*DH + e][n_ctx] / V[key][Hkv*DH]
     const int tq0 = blockIdx.x * 128 + wave * 32;                                      // first query token of this wave
     if (tq0 >= p.T) return;
     const int tq = min(tq0 + col, p.T - 1);                                            // this lane's query (clamped)
@@ -56,7 +60,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
     const int last = pos0 + min(tq0 + 31, p.T - 1);                                    // wave-uniform causal limit
     const int n_tiles = p.mask ? (p.n_kv + 31) / 32 : last / 32 + 1;
     const long krow = (long) p.Hkv * DH;
-    const float * mrow = p.mask ? p.mask + (long) tq * p.mask_stride : nullptr;
+    const float * mrow = (p.mask && !p.mask_f16) ? p.mask + (long) tq * p.mask_stride : nullptr;
+    const uint16_t * mrow16 = (p.mask && p.mask_f16) ? (const uint16_t *) p.mask + (long) tq * p.mask_stride : nullptr;
 
     // Q^T as B operand: lane (col = query, hf) holds q[query][16 kk + 8 hf .. +8], rounded to F16 like the reference
     half8 qf[KK];
@@ -80,11 +85,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
         for (int kk = 0; kk < KK; ++kk) kf[kk] = *(const half8 *) (kr + 16 * kk);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[kk], acc, 0, 0, 0);
-        if (mrow) {
+        if (mrow || mrow16) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {                            // registers 4g .. 4g+3 = keys j*32 + 8g + 4hf .. +4: one float4 of the mask row
                 const int k0 = j * 32 + 8 * g + 4 * hf;
-                const float4 mv = k0 + 3 < p.n_kv ? *(const float4 *) (mrow + k0) : float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                float4 mv = float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                if (k0 + 3 < p.n_kv) {
+                    if (mrow) mv = *(const float4 *) (mrow + k0);
+                    else { const u32x2 mh = *(const u32x2 *) (mrow16 + k0); mv = float4{h2f((uint16_t) (mh[0] & 0xFFFF)), h2f((uint16_t) (mh[0] >> 16)), h2f((uint16_t) (mh[1] & 0xFFFF)), h2f((uint16_t) (mh[1] >> 16))}; }
+                }
                 s[4 * g + 0] = acc[4 * g + 0] * p.scale + mv.x; s[4 * g + 1] = acc[4 * g + 1] * p.scale + mv.y;
                 s[4 * g + 2] = acc[4 * g + 2] * p.scale + mv.z; s[4 * g + 3] = acc[4 * g + 3] * p.scale + mv.w;
             }
@@ -153,11 +162,25 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
         const int key0 = j * 32;
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
-            const uint16_t * vr = vc + (long) (32 * d + col) * p.n_ctx + key0 + 8 * hf;
+            if (!p.v_rowmajor) {
+                const uint16_t * vr = vc + (long) (32 * d + col) * p.n_ctx + key0 + 8 * hf;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const half8 vf = *(const half8 *) (vr + 16 * kk);
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kk], o[d], 0, 0, 0);
+                for (int kk = 0; kk < 2; ++kk) {
+                    const half8 vf = *(const half8 *) (vr + 16 * kk);
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kk], o[d], 0, 0, 0);
+                }
+            } else {
+                const uint16_t * vr = vc + (long) (key0 + 8 * hf) * krow + 32 * d + col;       // channel 32 d + col of keys key0 + 8 hf ..
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    uint16_t e[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) e[t] = vr[(long) (16 * kk + t) * krow];
+                    half8 vf;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) vf[t] = __builtin_bit_cast(_Float16, e[t]);
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kk], o[d], 0, 0, 0);
+                }
             }
         }
     }
@@ -177,10 +200,12 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
 // n_ctx % 32 == 0 and head_dim 64 / 128 only (callers fall back to the per-token kernel otherwise)
 int pm_launch_attn_prefill(const float * q, const void * kc, const void * vc, const int32_t * pos0, const int32_t * seq,
                            long seq_stride, float * out, int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st,
-                           const float * mask, long mask_stride, int n_kv) {
+                           const float * mask, long mask_stride, int n_kv, int v_rowmajor, int mask_f16) {
     if ((dh != 64 && dh != 128) || n_ctx % 32 || n_tok < 1) return -1;
     if (mask && (n_kv < 1 || n_kv > n_ctx || n_kv % 4 || mask_stride % 4)) return -1;
-    PfP p = {q, (const uint16_t *) kc, (const uint16_t *) vc, pos0, seq, seq_stride, out, n_tok, H, Hkv, n_ctx, scale, mask, mask_stride, n_kv};
+    if ((v_rowmajor || mask_f16) && !mask) return -1;                 // the flash-attention form exists in ggml-graph mode only
+    PfP p = {q, (const uint16_t *) kc, (const uint16_t *) vc, pos0, seq, seq_stride, out, n_tok, H, Hkv, n_ctx, scale, mask, mask_stride, n_kv,
+             v_rowmajor ? 1 : 0, mask_f16 ? 1 : 0};
     const dim3 grid((n_tok + 127) / 128, H);
     if (dh == 128) hipLaunchKernelGGL(attn_prefill_kernel<128>, grid, dim3(256), 0, st, p);
     else           hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, dim3(256), 0, st, p);

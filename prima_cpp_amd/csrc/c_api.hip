@@ -216,13 +216,18 @@ int pm355_attn_prefill(const float * q, const void * kc, const void * vc, const 
     HIP_TRY(hipGetLastError());
     return 0;
 }
-int pm355_attn_prefill_masked(const float * q, const void * kc, const void * vc, const float * mask, int64_t mask_stride, float * out,
-                              int n_tokens, int H, int Hkv, int dh, int n_ctx, int n_kv, float kq_scale, pm355_stream_t st) {
+int pm355_attn_prefill_masked_ex(const float * q, const void * kc, const void * vc, const void * mask, int64_t mask_stride, float * out,
+                                 int n_tokens, int H, int Hkv, int dh, int n_ctx, int n_kv, float kq_scale, int flags, pm355_stream_t st) {
     if (!mask) return fail(PM355_E_SHAPE, "attn_prefill_masked: mask required");
-    if (pm_launch_attn_prefill(q, kc, vc, nullptr, nullptr, 0, out, n_tokens, H, Hkv, dh, n_ctx, kq_scale, S(st), mask, (long) mask_stride, n_kv))
+    if (pm_launch_attn_prefill(q, kc, vc, nullptr, nullptr, 0, out, n_tokens, H, Hkv, dh, n_ctx, kq_scale, S(st), (const float *) mask, (long) mask_stride, n_kv,
+                               flags & PM355_ATTN_V_ROWMAJOR, flags & PM355_ATTN_MASK_F16))
         return fail(PM355_E_RANGE, "attn_prefill_masked: head_dim 64/128, n_ctx % 32 == 0, n_kv % 4 == 0 <= n_ctx required");
     HIP_TRY(hipGetLastError());
     return 0;
+}
+int pm355_attn_prefill_masked(const float * q, const void * kc, const void * vc, const float * mask, int64_t mask_stride, float * out,
+                              int n_tokens, int H, int Hkv, int dh, int n_ctx, int n_kv, float kq_scale, pm355_stream_t st) {
+    return pm355_attn_prefill_masked_ex(q, kc, vc, mask, mask_stride, out, n_tokens, H, Hkv, dh, n_ctx, n_kv, kq_scale, 0, st);
 }
 int pm355_attn_rope_fused(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * d_pos0,
                           const float * ff, float * out, int H, int Hkv, int dh, int n_ctx, float kq_scale,

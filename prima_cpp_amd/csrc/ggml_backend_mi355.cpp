@@ -509,8 +509,8 @@ bool run_plan(backend_ctx * c, struct ggml_cgraph * g, const mi355::plan & p) {
                 MI355_CHECK(pm355_attn_token(&s.attn, &s.rope, c->stream));
                 break;
             case mi355::STEP_ATTN_BATCH:
-                MI355_CHECK(pm355_attn_prefill_masked(s.ab.q, s.ab.kc, s.ab.vc, s.ab.mask, s.ab.mask_stride, s.ab.out, s.ab.n_tokens, s.ab.n_head,
-                                                      s.ab.n_head_kv, s.ab.head_dim, s.ab.n_ctx, s.ab.n_kv, s.ab.scale, c->stream));
+                MI355_CHECK(pm355_attn_prefill_masked_ex(s.ab.q, s.ab.kc, s.ab.vc, s.ab.mask, s.ab.mask_stride, s.ab.out, s.ab.n_tokens, s.ab.n_head,
+                                                         s.ab.n_head_kv, s.ab.head_dim, s.ab.n_ctx, s.ab.n_kv, s.ab.scale, s.ab.flags, c->stream));
                 break;
             default: {
                 struct ggml_tensor * node = ggml_graph_node(g, s.node);

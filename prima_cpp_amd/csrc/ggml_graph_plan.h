@@ -50,8 +50,8 @@ struct step {
     // STEP_ATTN
     pm355_attn_token_args attn; pm355_rope_params rope;
     // STEP_ATTN_BATCH (multi-token): pm355_attn_prefill_masked
-    struct { const float * q; const void * kc, * vc; const float * mask; int64_t mask_stride; float * out;
-             int32_t n_tokens, n_head, n_head_kv, head_dim, n_ctx, n_kv; float scale; int32_t pad_; } ab;
+    struct { const float * q; const void * kc, * vc; const void * mask; int64_t mask_stride; float * out;
+             int32_t n_tokens, n_head, n_head_kv, head_dim, n_ctx, n_kv; float scale; int32_t flags; } ab;
     // STEP_NODE
     node_fp fp;
 };
@@ -154,6 +154,7 @@ public:
                 if (!adv) adv = try_matvec_resid(p, i);
             }
             if (!adv && c_.fuse && !p.single_token) adv = try_batch_attention(p, i);
+            if (!adv && c_.fuse && !p.single_token) adv = try_batch_flash_attention(p, i);
             if (adv) { p.n_fused_nodes += adv; i += adv; continue; }
             emit_node(p, i);
             ++i;
@@ -541,10 +542,65 @@ private:
         if (overlap(ct->data, ggml_nbytes(ct), qr->data, ggml_nbytes(qr))) return 0;       // every query row is read by 1 workgroup, written by it last
         step s; memset(&s, 0, sizeof(s));
         s.kind = STEP_ATTN_BATCH; s.node = -1; s.node_lo = i0; s.node_hi = hi;
-        s.ab.q = (const float *) qr->data; s.ab.kc = kcache->data; s.ab.vc = vcache->data; s.ab.mask = (const float *) mask->data;
+        s.ab.q = (const float *) qr->data; s.ab.kc = kcache->data; s.ab.vc = vcache->data; s.ab.mask = mask->data;
         s.ab.mask_stride = (int64_t) (mask->nb[1] / 4); s.ab.out = (float *) ct->data;
         s.ab.n_tokens = (int32_t) T; s.ab.n_head = (int32_t) H; s.ab.n_head_kv = (int32_t) Hkv; s.ab.head_dim = (int32_t) dh;
         s.ab.n_ctx = (int32_t) n_ctx; s.ab.n_kv = (int32_t) n_kv; s.ab.scale = scale;
+        p.steps.push_back(s);
+        ++p.n_attn_batch;
+        return hi - i0;
+    }
+
+    // ---- the same for flash-attention graphs: PERMUTE(q) VIEW(k) VIEW(v) [CPY(mask F32 -> F16)] FLASH_ATTN_EXT RESHAPE over a multi-token
+    //      batch (llm_build_kqv, src/llama.cpp:10075-10095) -> one launch of the MFMA attention on the row-major F16 V cache
+    int try_batch_flash_attention(plan & p, int i0) {
+        int i = i0, mask_cast = -1, n_pre = 0;
+        for (; n_pre < 4; ++n_pre, ++i) {
+            const ggml_tensor * t = N(i);
+            if (!t) return 0;
+            if (t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE) continue;
+            if (t->op == GGML_OP_CPY && t->type == GGML_TYPE_F16 && t->src[0] && t->src[0]->type == GGML_TYPE_F32 && mask_cast < 0) { mask_cast = i; continue; }
+            break;
+        }
+        const ggml_tensor * fe = N(i), * rs2 = N(i + 1);
+        if (n_pre < 3 || !fe || !rs2 || fe->op != GGML_OP_FLASH_ATTN_EXT || rs2->op != GGML_OP_RESHAPE || rs2->src[0] != fe || rs2->data != fe->data) return 0;
+        const ggml_tensor * qp = fe->src[0], * kv = fe->src[1], * vv = fe->src[2], * mask = fe->src[3];
+        // the three operands are the nodes in front of the op
+        int found = 0;
+        for (int j = i0; j < i; ++j) if (nodes_[j] == qp || nodes_[j] == kv || nodes_[j] == vv) ++found;
+        if (found != 3 || qp->op != GGML_OP_PERMUTE || kv->op != GGML_OP_VIEW || vv->op != GGML_OP_VIEW) return 0;
+        const ggml_tensor * kcache = kv->view_src, * vcache = vv->view_src;
+        if (!kcache || !vcache || kcache->type != GGML_TYPE_F16 || vcache->type != GGML_TYPE_F16 || kcache->view_src || vcache->view_src ||
+            kcache->op != GGML_OP_NONE || vcache->op != GGML_OP_NONE || !ggml_is_contiguous(kcache) || !ggml_is_contiguous(vcache)) return 0;
+        if (kv->data != kcache->data || vv->data != vcache->data) return 0;
+        const int64_t dh = kv->ne[0], n_kv = kv->ne[1], Hkv = kv->ne[2];
+        const ggml_tensor * qr = qp->src[0];                            // the rotated queries [dh, H, T] f32 contiguous
+        if (!qr || qr->type != GGML_TYPE_F32 || !ggml_is_contiguous(qr) || qr->ne[0] != dh || qr->ne[3] != 1) return 0;
+        const int64_t H = qr->ne[1], T = qr->ne[2];
+        if (T < 2 || (dh != 64 && dh != 128) || Hkv < 1 || H % Hkv) return 0;
+        const size_t row = (size_t) (Hkv * dh * 2);
+        if (kv->type != GGML_TYPE_F16 || kv->nb[0] != 2 || kv->nb[1] != row || kv->nb[2] != (size_t) (dh * 2) || kv->ne[3] != 1) return 0;
+        if (vv->type != GGML_TYPE_F16 || vv->ne[0] != dh || vv->ne[1] != n_kv || vv->ne[2] != Hkv || vv->ne[3] != 1 || vv->nb[0] != 2 || vv->nb[1] != row || vv->nb[2] != (size_t) (dh * 2)) return 0;
+        const int64_t n_ctx = (int64_t) ggml_nelements(kcache) / (Hkv * dh);
+        if (n_ctx <= 0 || n_ctx % 32 || n_kv > n_ctx || n_kv % 4 || (int64_t) ggml_nelements(vcache) < n_ctx * Hkv * dh) return 0;
+        if (qp->data != qr->data || qp->ne[0] != dh || qp->ne[1] != T || qp->ne[2] != H || qp->nb[0] != 4 || qp->nb[1] != (size_t) (H * dh * 4) || qp->nb[2] != (size_t) (dh * 4)) return 0;
+        float scale, max_bias, softcap;
+        memcpy(&scale, fe->op_params, 4); memcpy(&max_bias, (const float *) fe->op_params + 1, 4); memcpy(&softcap, (const float *) fe->op_params + 2, 4);
+        if (max_bias != 0.0f || softcap != 0.0f) return 0;
+        if (!mask || mask->type != GGML_TYPE_F16 || mask->ne[0] != n_kv || mask->ne[1] < T || mask->nb[0] != 2 || mask->nb[1] % 8 || mask->ne[2] != 1 || mask->ne[3] != 1) return 0;
+        if (mask_cast >= 0 && nodes_[mask_cast] != mask) return 0;
+        if (fe->type != GGML_TYPE_F32 || !ggml_is_contiguous(fe) || fe->ne[0] != dh || fe->ne[1] != H || fe->ne[2] != T || fe->ne[3] != 1) return 0;
+        const int hi = i + 2, out_idx = hi - 1;
+        const int outs[2] = {out_idx, mask_cast};
+        if (!range_private(i0, hi, outs, mask_cast >= 0 ? 2 : 1)) return 0;
+        if (overlap(fe->data, ggml_nbytes(fe), qr->data, ggml_nbytes(qr))) return 0;
+        if (mask_cast >= 0) emit_node(p, mask_cast);
+        step s; memset(&s, 0, sizeof(s));
+        s.kind = STEP_ATTN_BATCH; s.node = -1; s.node_lo = i0; s.node_hi = hi;
+        s.ab.q = (const float *) qr->data; s.ab.kc = kcache->data; s.ab.vc = vcache->data; s.ab.mask = mask->data;
+        s.ab.mask_stride = (int64_t) (mask->nb[1] / 2); s.ab.out = (float *) fe->data;
+        s.ab.n_tokens = (int32_t) T; s.ab.n_head = (int32_t) H; s.ab.n_head_kv = (int32_t) Hkv; s.ab.head_dim = (int32_t) dh;
+        s.ab.n_ctx = (int32_t) n_ctx; s.ab.n_kv = (int32_t) n_kv; s.ab.scale = scale; s.ab.flags = PM355_ATTN_V_ROWMAJOR | PM355_ATTN_MASK_F16;
         p.steps.push_back(s);
         ++p.n_attn_batch;
         return hi - i0;

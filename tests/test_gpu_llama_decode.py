@@ -104,9 +104,11 @@ def test_llama_decode_plugin_flash_attn(gpu, name, tmp_path):
     # the single-token flash-attention graph is lowered to the fused launches and replayed as a hipGraph like the default graph
     m = re.search(r"hipGraph replays (\d+)", stats["stderr"])
     assert m and int(m.group(1)) >= n - 4, stats["stderr"][-600:]
-    # ... and the fused lowering agrees with the node-by-node execution of the same graph (both accumulate in f32: summation order only)
+    # ... and the lowering agrees with the node-by-node execution of the same graphs: the prompt batch runs the MFMA attention
+    # (P rounded to F16 as an MFMA operand) in one run and the f32-P node kernel in the other, single tokens differ in summation order
     t2, l2, _ = run_llama_driver(path, z["prompt"], n, ngl=99, n_ctx=64, extra_args=GPU_ARGS + ["-fa"], env={"GGML_MI355_NO_FUSE": "1"}, force=toks[:-1])
-    assert _nmse(logits, l2) < 1e-5, _nmse(logits, l2)     # (an int8 re-quantization flip downstream costs ~1e-7)
+    print(f"\n[{name} -fa] lowered vs node-by-node NMSE {_nmse(logits, l2):.3e}")
+    assert _nmse(logits, l2) < 1e-3, _nmse(logits, l2)
     # the reference's flash-attention accumulates V.p in an F16 accumulator that is re-scaled at every new running maximum
     # (ggml.c:15690-15704); the kernel here accumulates in f32 - the difference is the reference's own F16 rounding, bounded by its
     # backend tolerance for this op (NMSE 5e-4 per node, tests/test-backend-ops.cpp:2710), 1e-3 for the whole stack
