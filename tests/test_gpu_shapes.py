@@ -5,6 +5,7 @@ against the reference CPU backend itself (oracle/_ref, AVX2 build, multi-threade
 of a 70B layer) - and the two dominant decode launches (gate/up PAIR kernel, 3-job mixed-type QKV) at K = 8192 with the real
 row counts against oracle.mul_mat."""
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -57,7 +58,7 @@ SHAPES = {
 def test_model_shaped_layer_decode_and_prefill(E, oracle, name):
     torch = E.torch
     arch, n_ff, tv, td, tout = SHAPES[name]
-    rng = np.random.default_rng(hash(name) % 1000)
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000)     # (str hash() is salted per process: a different model every run)
     types = {"attn_v": tv, "ffn_down": td, "output": tout}
     if name.startswith("qwen"):
         types.update({k: Q6_K for k in ("attn_q", "attn_k", "attn_output", "ffn_gate", "ffn_up", "token_embd")})
