@@ -172,7 +172,14 @@ struct GemmP {
     const uint8_t * W; const _Float16 * Xh; float * Y; const float * bias; const float * resid;
     const float * silu_gate;                 // optional [T][N]: Y = silu(gate) * (W.x)   (the SiLU.mul of the FFN fused into the up projection)
     long row_stride; int K, N, T;
+    int exp;                                 // ablation switches (measurements only, compiled in with -DPM_GEMM_ABLATE=1; results are wrong when set)
 };
+// Ablations of gemm_q_f16_kernel2 (PM355_EXTRA_FLAGS=-DPM_GEMM_ABLATE=1 build, PM355_GEMM_EXP=<bits>, tools/gemm_probe.py; numbers in
+// DESIGN.md section 6 / profiles/r02_gemm_ablation.txt): 1 no dequantization arithmetic, 2 no global loads in the loop, 4 no barrier,
+// 8 half of the fragment reads, 16 no staging writes, 32 no weight loads, 64 no activation loads.
+#ifndef PM_GEMM_ABLATE
+#define PM_GEMM_ABLATE 0
+#endif
 
 // f32 -> f16 (RNE, == GGML_FP32_TO_FP16) of the activation matrix, once per GEMM call instead of once per weight tile
 __global__ __launch_bounds__(256) void cvt_f16_kernel(const float * __restrict__ x, _Float16 * __restrict__ y, long n8) {
@@ -357,18 +364,29 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel2(GemmP p) {
     struct Regs { RawW w[2]; half8 x[4]; };
     Regs R;
     const int nst = p.K / BK;
+    const int exp = PM_GEMM_ABLATE ? p.exp : 0;
     auto fetch = [&](int st) __attribute__((always_inline)) {
         const int k0 = min(st, nst - 1) * BK;
-        fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, 0, R.w[0]);
-        fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, 1, R.w[1]);
+        if (exp & 2) return;
+        if (!(exp & 32)) {
+            fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, 0, R.w[0]);
+            fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, 1, R.w[1]);
+        }
+        if (!(exp & 64)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) R.x[i] = *(const half8 *) (xptr + k0 + 8 * i);
+            for (int i = 0; i < 4; ++i) R.x[i] = *(const half8 *) (xptr + k0 + 8 * i);
+        }
     };
     auto stage = [&](int st) __attribute__((always_inline)) {
         _Float16 * buf = lds + (st & 1) * BUF;
         _Float16 * da = buf + arow * LDS_STRIDE + 32 * ahalf;
         _Float16 * db = buf + (BM2 + arow) * LDS_STRIDE + 32 * ahalf;
         const int k0 = min(st, nst - 1) * BK + 32 * ahalf;
+        if (exp & 16) return;
+        if (exp & 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(half8 *) (da + 8 * q) = __builtin_bit_cast(half8, R.w[0].r[q % 3]);
+        } else
         if (PM_GEMM_F16_DEQUANT && TYPE == PM_Q4_K) {
             half8 o[4];
             convert_q4k_pair_h(R.w[0], R.w[1], k0, o);
@@ -419,9 +437,9 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel2(GemmP p) {
         load_frag(f0, As, Bs, 0);
         load_frag(f1, As, Bs, 16);
         mma8(f0);
-        load_frag(f0, As, Bs, 32);
+        if (!(exp & 8)) load_frag(f0, As, Bs, 32);
         mma8(f1);
-        load_frag(f1, As, Bs, 48);
+        if (!(exp & 8)) load_frag(f1, As, Bs, 48);
         mma8(f0);
         stage(st + 1);                                    // dequantize step st+1 (registers) into the other buffer ...
         mma8(f1);
@@ -436,7 +454,7 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel2(GemmP p) {
                 __builtin_amdgcn_sched_group_barrier(0x002, PM_GEMM2_VALU_PER_MFMA, 0);    // VALU in its shadow
             }
         }
-        __syncthreads();
+        if (!(exp & 4)) __syncthreads();
     }
     // ---- epilogue: C[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]; Y[t][n]: 4 consecutive n per float4
 #pragma unroll
@@ -499,7 +517,8 @@ int pm_launch_gemm_q_ex(int type, const void * W, const float * X, float * Y, in
     }
     _Float16 * xh = g_xh[dev];
     if (!reuse_x) hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) ((need / 8 + 255) / 256)), dim3(256), 0, st, X, xh, (long) (need / 8));
-    GemmP p = {(const uint8_t *) W, xh, Y, bias, resid, silu_gate, (long) pm_weight_row_stride(type, K), K, N, T};
+    static const int exp_sw = [] { const char * e = getenv("PM355_GEMM_EXP"); return e ? atoi(e) : 0; }();
+    GemmP p = {(const uint8_t *) W, xh, Y, bias, resid, silu_gate, (long) pm_weight_row_stride(type, K), K, N, T, exp_sw};
     // 256 x 256 tiles (gemm_q_f16_kernel2) when they still fill the chip; else the 128 x 256 kernel (more workgroups for small N)
     static const int force = [] { const char * e = getenv("PM355_GEMM_KERNEL"); return e ? atoi(e) : 0; }();
     const long wg2 = (long) ((N + BM2 - 1) / BM2) * ((T + BN2 - 1) / BN2);
