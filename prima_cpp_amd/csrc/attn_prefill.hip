@@ -42,26 +42,77 @@ struct PfP {
 // key index (inside a 32-key tile) of accumulator register r in lane-half h: C[row = (r&3) + 8 (r>>2) + 4 h][col]
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// K and V tiles (32 keys) travel global -> registers -> LDS once per WORKGROUP and are double-buffered: the loads of tile j+1 are in
+// flight while the four waves multiply tile j out of LDS (round 2; before, every wave loaded its own copy straight into MFMA operands,
+// 213 + 80 registers = one wave per SIMD and nothing to hide the L2 latency behind: 8.3 us per key tile, 1.14 ms per layer for a
+// 2048-token prompt of the 70B shape). Row strides are padded so that the fragment reads (lane = key / channel, 16 bytes) are
+// conflict-free: K rows DH + 8 halves (68 dwords: lane i -> bank 4 i), V^T rows 40 halves (20 dwords: 16 lanes cover the 64 banks once).
+// A row-major V cache (flash-attention graphs) is transposed on its way into LDS.
 template <int DH>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PfP p) {
     constexpr int KK = DH / 16;                  // k-steps of the S^T MFMAs
     constexpr int DT = DH / 32;                  // 32-row tiles of O^T
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int KS = DH + 8, VS = 40;          // LDS row strides (halves)
+    constexpr int UPR = DH / 8;                  // 16-byte units per K row
+    constexpr int NU = DH / 64;                  // units per thread and tile (K: 32 * UPR / 256; V^T: 4 * DH / 256)
+    __shared__ __attribute__((aligned(16))) _Float16 ks[2][32 * KS];
+    __shared__ __attribute__((aligned(16))) _Float16 vs[2][DH * VS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, hf = lane >> 5;
     const int h = blockIdx.y, hk = h / (p.H / p.Hkv);
     const int seq = p.seq_ptr ? *p.seq_ptr : 0;
     const int pos0 = p.mask ? 0 : p.pos0_ptr[seq];
+    const long krow = (long) p.Hkv * DH;
     const uint16_t * kc = p.kc + (long) seq * p.seq_stride + (long) hk * DH;          // K[key][Hkv*DH]
     const uint16_t * vc = p.vc + (long) seq * p.seq_stride + (p.v_rowmajor ? (long) hk * DH : (long) hk * DH * p.n_ctx); // V^T[hk*DH + e][n_ctx] / V[key][Hkv*DH]
-    const int tq0 = blockIdx.x * 128 + wave * 32;                                      // first query token of this wave
-    if (tq0 >= p.T) return;
+    // causal mode: the LAST query blocks attend the most keys - they are dispatched first (longest-processing-time order) so that the
+    // short ones fill the tail
+    const int qb = p.mask ? (int) blockIdx.x : (int) (gridDim.x - 1 - blockIdx.x);
+    const int tq0 = qb * 128 + wave * 32;                                              // first query token of this wave
+    const bool wave_live = tq0 < p.T;
     const int tq = min(tq0 + col, p.T - 1);                                            // this lane's query (clamped)
     const int qpos = pos0 + tq;                                                        // attends keys 0 .. qpos
     const int last = pos0 + min(tq0 + 31, p.T - 1);                                    // wave-uniform causal limit
-    const int n_tiles = p.mask ? (p.n_kv + 31) / 32 : last / 32 + 1;
-    const long krow = (long) p.Hkv * DH;
+    const int n_tiles = !wave_live ? 0 : (p.mask ? (p.n_kv + 31) / 32 : last / 32 + 1);
+    // the workgroup walks the tiles its LAST live wave needs (every wave takes part in the staging and the barriers)
+    const int n_wg = p.mask ? (p.n_kv + 31) / 32 : (pos0 + min(qb * 128 + 127, p.T - 1)) / 32 + 1;
     const float * mrow = (p.mask && !p.mask_f16) ? p.mask + (long) tq * p.mask_stride : nullptr;
     const uint16_t * mrow16 = (p.mask && p.mask_f16) ? (const uint16_t *) p.mask + (long) tq * p.mask_stride : nullptr;
+
+    // ---- staging: global -> registers (fetch) -> LDS (put)
+    u32x4 kg[NU], vg[NU];
+    auto fetch_k = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + 256 * i, key = min(j * 32 + u / UPR, p.n_ctx - 1), piece = u % UPR;
+            kg[i] = *(const u32x4 *) (kc + (long) key * krow + 8 * piece);
+        }
+    };
+    auto fetch_v = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + 256 * i;
+            if (!p.v_rowmajor) { const int row = u >> 2, unit = u & 3; vg[i] = *(const u32x4 *) (vc + (long) row * p.n_ctx + j * 32 + 8 * unit); }
+            else { const int key = min(j * 32 + u / UPR, p.n_ctx - 1), piece = u % UPR; vg[i] = *(const u32x4 *) (vc + (long) key * krow + 8 * piece); }
+        }
+    };
+    auto put_k = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { const int u = tid + 256 * i; *(u32x4 *) (ks[b] + (u / UPR) * KS + 8 * (u % UPR)) = kg[i]; }
+    };
+    auto put_v = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + 256 * i;
+            if (!p.v_rowmajor) *(u32x4 *) (vs[b] + (u >> 2) * VS + 8 * (u & 3)) = vg[i];
+            else {                                                       // V[key][8 piece .. +8] -> V^T rows 8 piece .. +8, column key
+                const int key = u / UPR, piece = u % UPR;
+                uint16_t * d = (uint16_t *) vs[b] + (8 * piece) * VS + key;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { d[(2 * e) * VS] = (uint16_t) (vg[i][e] & 0xFFFF); d[(2 * e + 1) * VS] = (uint16_t) (vg[i][e] >> 16); }
+            }
+        }
+    };
 
     // Q^T as B operand: lane (col = query, hf) holds q[query][16 kk + 8 hf .. +8], rounded to F16 like the reference
     half8 qf[KK];
@@ -73,18 +124,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
             qf[kk] = half8{(_Float16) a.x, (_Float16) a.y, (_Float16) a.z, (_Float16) a.w, (_Float16) b.x, (_Float16) b.y, (_Float16) b.z, (_Float16) b.w};
         }
     }
-    // S^T tile (32 keys x 32 queries) of key tile j: A = K rows (lane: key = j*32 + col', dh slice 16 kk + 8 hf)
-    auto scores = [&](int j, float (&s)[16]) __attribute__((always_inline)) {
+    // S^T tile (32 keys x 32 queries) of key tile j out of LDS buffer b: A = K rows (lane: key = col, dh slice 16 kk + 8 hf)
+    auto scores = [&](int j, int b, float (&s)[16]) __attribute__((always_inline)) {
         float16v acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        const int key = min(j * 32 + col, p.n_ctx - 1);
-        const uint16_t * kr = kc + (long) key * krow + 8 * hf;
-        half8 kf[KK];
+        const _Float16 * kr = ks[b] + col * KS + 8 * hf;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) kf[kk] = *(const half8 *) (kr + 16 * kk);
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[kk], acc, 0, 0, 0);
+        for (int kk = 0; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8 *) (kr + 16 * kk), qf[kk], acc, 0, 0, 0);
         if (mrow || mrow16) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {                            // registers 4g .. 4g+3 = keys j*32 + 8g + 4hf .. +4: one float4 of the mask row
@@ -107,21 +154,32 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
     };
 
     // ---- pass 1: row max and sum of exp (online within the lane, merged with the partner lane at the end)
+    // exp = v_exp_f32 (__expf, ~1 ulp): the probabilities are rounded to F16 right after, and the reference's own SIMD builds use a
+    // polynomial expf (ggml_v_expf, ggml.c:2370); libm's expf was ~30 VALU instructions x 33 per lane and key tile - most of the kernel
     float m = -INFINITY, l = 0.0f;
-    for (int j = 0; j < n_tiles; ++j) {
-        float s[16];
-        scores(j, s);
-        float mt = s[0];
+    fetch_k(0);
+    put_k(0);
+    __syncthreads();
+    for (int j = 0; j < n_wg; ++j) {
+        const bool more = j + 1 < n_wg;
+        if (more) fetch_k(j + 1);
+        if (j < n_tiles) {
+            float s[16];
+            scores(j, j & 1, s);
+            float mt = s[0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
-        const float mn = fmaxf(m, mt);
-        if (mn != -INFINITY) {
-            float acc = 0.0f;
+            for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+            const float mn = fmaxf(m, mt);
+            if (mn != -INFINITY) {
+                float acc = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc += expf(s[r] - mn);
-            l = l * expf(m - mn) + acc;          // m == -inf: l == 0 and expf(-inf) == 0
-            m = mn;
+                for (int r = 0; r < 16; ++r) acc += __expf(s[r] - mn);
+                l = l * __expf(m - mn) + acc;     // m == -inf: l == 0 and expf(-inf) == 0
+                m = mn;
+            }
         }
+        if (more) put_k((j + 1) & 1);
+        __syncthreads();
     }
     {
         const float mo = __shfl_xor(m, 32), lo = __shfl_xor(l, 32);
@@ -137,55 +195,46 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PfP p) {
     for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.0f;
-    for (int j = 0; j < n_tiles; ++j) {
-        float s[16];
-        scores(j, s);
-        half4 pk[4];                             // pk[g] = the 4 keys 8 g + 4 hf .. +4 of this query
+    fetch_k(0); fetch_v(0);
+    put_k(0); put_v(0);
+    __syncthreads();
+    for (int j = 0; j < n_wg; ++j) {
+        const bool more = j + 1 < n_wg;
+        if (more) { fetch_k(j + 1); fetch_v(j + 1); }
+        if (j < n_tiles) {
+            float s[16];
+            scores(j, j & 1, s);
+            half4 pk[4];                         // pk[g] = the 4 keys 8 g + 4 hf .. +4 of this query
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pk[g][i] = (_Float16) (expf(s[4 * g + i] - m) * inv);
-        // B operand of k-step kk (keys 16 kk .. +16): lane half hf wants keys 16 kk + 8 hf .. +8 = two groups of 4, one of
-        // which sits in the partner lane (lane ^ 32)
-        half8 pf[2];
+                for (int i = 0; i < 4; ++i) pk[g][i] = (_Float16) (__expf(s[4 * g + i] - m) * inv);
+            // B operand of k-step kk (keys 16 kk .. +16): lane half hf wants keys 16 kk + 8 hf .. +8 = two groups of 4, one of
+            // which sits in the partner lane (lane ^ 32)
+            half8 pf[2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const half4 mine = hf ? pk[2 * kk + 1] : pk[2 * kk];         // keys this lane keeps
-            const half4 send = hf ? pk[2 * kk] : pk[2 * kk + 1];         // keys the partner needs
-            uint32_t s0 = ((const uint32_t *) &send)[0], s1 = ((const uint32_t *) &send)[1];
-            s0 = (uint32_t) __shfl_xor((int) s0, 32); s1 = (uint32_t) __shfl_xor((int) s1, 32);
-            half4 got;
-            ((uint32_t *) &got)[0] = s0; ((uint32_t *) &got)[1] = s1;
-            const half4 lo = hf ? got : mine, hi = hf ? mine : got;      // ascending key order
-            pf[kk] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-        const int key0 = j * 32;
-#pragma unroll
-        for (int d = 0; d < DT; ++d) {
-            if (!p.v_rowmajor) {
-                const uint16_t * vr = vc + (long) (32 * d + col) * p.n_ctx + key0 + 8 * hf;
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const half8 vf = *(const half8 *) (vr + 16 * kk);
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kk], o[d], 0, 0, 0);
-                }
-            } else {
-                const uint16_t * vr = vc + (long) (key0 + 8 * hf) * krow + 32 * d + col;       // channel 32 d + col of keys key0 + 8 hf ..
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    uint16_t e[8];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) e[t] = vr[(long) (16 * kk + t) * krow];
-                    half8 vf;
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) vf[t] = __builtin_bit_cast(_Float16, e[t]);
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kk], o[d], 0, 0, 0);
-                }
+            for (int kk = 0; kk < 2; ++kk) {
+                const half4 mine = hf ? pk[2 * kk + 1] : pk[2 * kk];         // keys this lane keeps
+                const half4 send = hf ? pk[2 * kk] : pk[2 * kk + 1];         // keys the partner needs
+                uint32_t s0 = ((const uint32_t *) &send)[0], s1 = ((const uint32_t *) &send)[1];
+                s0 = (uint32_t) __shfl_xor((int) s0, 32); s1 = (uint32_t) __shfl_xor((int) s1, 32);
+                half4 got;
+                ((uint32_t *) &got)[0] = s0; ((uint32_t *) &got)[1] = s1;
+                const half4 lo = hf ? got : mine, hi = hf ? mine : got;      // ascending key order
+                pf[kk] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
+            const _Float16 * vb = vs[j & 1] + col * VS + 8 * hf;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8 *) (vb + (32 * d) * VS + 16 * kk), pf[kk], o[d], 0, 0, 0);
         }
+        if (more) { put_k((j + 1) & 1); put_v((j + 1) & 1); }
+        __syncthreads();
     }
     // ---- O^T[dh = 32 d + acc_row(r, hf)][query = col] -> out[t][h*DH + dh]
-    if (tq0 + col < p.T) {
+    if (wave_live && tq0 + col < p.T) {
         float * orow = p.out + ((long) tq * p.H + h) * DH;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
