@@ -37,6 +37,7 @@ struct PfP {
     // (the V^T operand is then gathered with 2-byte loads: a lane needs 8 consecutive keys of ONE channel); mask_f16 = the mask rows are
     // F16. P is rounded to F16 here as well (it is an MFMA operand; the reference keeps it f32 and rounds its F16 accumulator instead).
     int v_rowmajor, mask_f16;
+    _Float16 * out_h;                            // optional: the result as F16 [T][H*DH] (activations of the wo GEMM) instead of `out`
 };
 
 // key index (inside a 32-key tile) of accumulator register r in lane-half h: C[row = (r&3) + 8 (r>>2) + 4 h][col]
@@ -235,12 +236,21 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PfP p) {
     }
     // ---- O^T[dh = 32 d + acc_row(r, hf)][query = col] -> out[t][h*DH + dh]
     if (wave_live && tq0 + col < p.T) {
+        if (p.out_h) {
+            _Float16 * orow = p.out_h + ((long) tq * p.H + h) * DH;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(half4 *) (orow + 32 * d + 8 * g + 4 * hf) = half4{(_Float16) o[d][4 * g], (_Float16) o[d][4 * g + 1], (_Float16) o[d][4 * g + 2], (_Float16) o[d][4 * g + 3]};
+        } else {
         float * orow = p.out + ((long) tq * p.H + h) * DH;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *(float4 *) (orow + 32 * d + 8 * g + 4 * hf) = float4{o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]};
+        }
     }
 }
 
@@ -249,12 +259,12 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PfP p) {
 // n_ctx % 32 == 0 and head_dim 64 / 128 only (callers fall back to the per-token kernel otherwise)
 int pm_launch_attn_prefill(const float * q, const void * kc, const void * vc, const int32_t * pos0, const int32_t * seq,
                            long seq_stride, float * out, int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st,
-                           const float * mask, long mask_stride, int n_kv, int v_rowmajor, int mask_f16) {
+                           const float * mask, long mask_stride, int n_kv, int v_rowmajor, int mask_f16, void * out_f16) {
     if ((dh != 64 && dh != 128) || n_ctx % 32 || n_tok < 1) return -1;
     if (mask && (n_kv < 1 || n_kv > n_ctx || n_kv % 4 || mask_stride % 4)) return -1;
     if ((v_rowmajor || mask_f16) && !mask) return -1;                 // the flash-attention form exists in ggml-graph mode only
     PfP p = {q, (const uint16_t *) kc, (const uint16_t *) vc, pos0, seq, seq_stride, out, n_tok, H, Hkv, n_ctx, scale, mask, mask_stride, n_kv,
-             v_rowmajor ? 1 : 0, mask_f16 ? 1 : 0};
+             v_rowmajor ? 1 : 0, mask_f16 ? 1 : 0, (_Float16 *) out_f16};
     const dim3 grid((n_tok + 127) / 128, H);
     if (dh == 128) hipLaunchKernelGGL(attn_prefill_kernel<128>, grid, dim3(256), 0, st, p);
     else           hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, dim3(256), 0, st, p);

@@ -383,41 +383,46 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         const Tensor * qkv[3] = {&L.t[PM355_T_WQ], &L.t[PM355_T_WK], &L.t[PM355_T_WV]};
         if (T >= 16 && !m->no_fuse) {
             // ---- prefill: batched GEMMs on the MFMA matrix cores (mmq.hip), f32 activations
-            auto G = [&](const Tensor & w, const float * x, float * y, const float * bias, const float * resid,
-                         const float * silu_gate = nullptr, int reuse_x = 0) {
-                return pm_launch_gemm_q_ex(w.type, w.d, x, y, (int) w.K, (int) w.N, T, bias, resid, silu_gate, reuse_x, st);
+            // F16 plumbing: the producers of GEMM activations write them as F16 (the rounding the GEMM's own conversion pass would apply) into
+            // the engine's scratch - xn / att in place of their f32 forms, h = silu(gate) * up into h2: no conversion launches, half the bytes
+            auto G = [&](const Tensor & w, const void * xh, float * y, void * yh, const float * bias, const float * resid,
+                         const float * silu_gate = nullptr, hipStream_t s2 = nullptr) {
+                return pm_launch_gemm_q_h(w.type, w.d, nullptr, xh, y, yh, (int) w.K, (int) w.N, T, bias, resid, silu_gate, 0, s2 ? s2 : st);
             };
-            pm_launch_rmsnorm_q8k(cur, (const float *) L.t[PM355_T_ATTN_NORM].d, m->xn, nullptr, E, T, hp.rms_eps, st);
-            int rc = G(L.t[PM355_T_WQ], m->xn, m->q, (const float *) L.t[PM355_T_BQ].d, nullptr);
+            pm_launch_rmsnorm_q8k(cur, (const float *) L.t[PM355_T_ATTN_NORM].d, nullptr, nullptr, E, T, hp.rms_eps, st, m->xn);
+            int rc = G(L.t[PM355_T_WQ], m->xn, m->q, nullptr, (const float *) L.t[PM355_T_BQ].d, nullptr);
             // wk and wv (N = n_head_kv * head_dim: a fraction of the CUs each) run concurrently: wv on a side stream that forks
-            // after wq (the f16 copy of the activations exists from there on) and joins before the rope
+            // after wq and joins before the rope
             if (!m->side) {
-                if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
-                    hipEventCreateWithFlags(&m->side_a, hipEventDisableTiming) != hipSuccess ||
+                if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->side_a, hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&m->side_b, hipEventDisableTiming) != hipSuccess) return seterr(m, PM355_E_HIP, "prefill: side stream");
             }
             (void) hipEventRecord(m->side_a, st);
             (void) hipStreamWaitEvent(m->side, m->side_a, 0);
-            rc |= G(L.t[PM355_T_WK], m->xn, m->k, (const float *) L.t[PM355_T_BK].d, nullptr, nullptr, 1);      // same activations: f16 copy reused
-            rc |= pm_launch_gemm_q_ex(L.t[PM355_T_WV].type, L.t[PM355_T_WV].d, m->xn, m->v, (int) L.t[PM355_T_WV].K, (int) L.t[PM355_T_WV].N, T,
-                                      (const float *) L.t[PM355_T_BV].d, nullptr, nullptr, 1, m->side);
+            rc |= G(L.t[PM355_T_WK], m->xn, m->k, nullptr, (const float *) L.t[PM355_T_BK].d, nullptr);
+            rc |= G(L.t[PM355_T_WV], m->xn, m->v, nullptr, (const float *) L.t[PM355_T_BV].d, nullptr, nullptr, m->side);
             (void) hipEventRecord(m->side_b, m->side);
             (void) hipStreamWaitEvent(st, m->side_b, 0);
             if (rc) return seterr(m, PM355_E_UNSUPPORTED, "prefill: qkv gemm");
             const long kvs = (long) hp.n_ctx * Hkv * dh;
             pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kvs,
                                     (const float *) m->rope_freqs.d, T, H, Hkv, dh, hp.n_ctx, m->rope, st);
-            if (pm_launch_attn_prefill(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st) &&
-                pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
-                return seterr(m, PM355_E_RANGE, "prefill: n_ctx too large for the attention kernel");
+            bool att_h = true;
+            if (pm_launch_attn_prefill(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, nullptr, T, H, Hkv, dh, hp.n_ctx, kq_scale, st, nullptr, 0, 0, 0, 0, m->att)) {
+                att_h = false;
+                if (pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
+                    return seterr(m, PM355_E_RANGE, "prefill: n_ctx too large for the attention kernel");
+            }
             float * x_mid = (cur == bufs[0]) ? bufs[1] : bufs[0];
-            if (G(L.t[PM355_T_WO], m->att, x_mid, nullptr, cur)) return seterr(m, PM355_E_UNSUPPORTED, "prefill: wo gemm");
-            pm_launch_rmsnorm_q8k(x_mid, (const float *) L.t[PM355_T_FFN_NORM].d, m->xn, nullptr, E, T, hp.rms_eps, st);
-            rc = G(L.t[PM355_T_FFN_GATE], m->xn, m->h, nullptr, nullptr);
-            rc |= G(L.t[PM355_T_FFN_UP], m->xn, m->h, nullptr, nullptr, m->h, 1);                       // h = silu(gate) * up, in the epilogue
+            if (att_h ? G(L.t[PM355_T_WO], m->att, x_mid, nullptr, nullptr, cur)
+                      : pm_launch_gemm_q_ex(L.t[PM355_T_WO].type, L.t[PM355_T_WO].d, m->att, x_mid, (int) L.t[PM355_T_WO].K, (int) L.t[PM355_T_WO].N, T, nullptr, cur, nullptr, 0, st))
+                return seterr(m, PM355_E_UNSUPPORTED, "prefill: wo gemm");
+            pm_launch_rmsnorm_q8k(x_mid, (const float *) L.t[PM355_T_FFN_NORM].d, nullptr, nullptr, E, T, hp.rms_eps, st, m->xn);
+            rc = G(L.t[PM355_T_FFN_GATE], m->xn, m->h, nullptr, nullptr, nullptr);
+            rc |= G(L.t[PM355_T_FFN_UP], m->xn, nullptr, m->h2, nullptr, nullptr, m->h);                // h2 = F16(silu(gate) * up), in the epilogue
             if (rc) return seterr(m, PM355_E_UNSUPPORTED, "prefill: gate/up gemm");
             float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : ((x_mid == bufs[0]) ? bufs[1] : bufs[0]);
-            if (G(L.t[PM355_T_FFN_DOWN], m->h, x_next, nullptr, x_mid)) return seterr(m, PM355_E_UNSUPPORTED, "prefill: down gemm");
+            if (G(L.t[PM355_T_FFN_DOWN], m->h2, x_next, nullptr, nullptr, x_mid)) return seterr(m, PM355_E_UNSUPPORTED, "prefill: down gemm");
             layer_release(m, il, st);
             cur = x_next;
             continue;

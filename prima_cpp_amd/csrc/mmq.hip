@@ -100,6 +100,7 @@ __device__ __forceinline__ void convert_w(const RawW & w, int k0, float (&o)[16]
 // ~7 (the dequantization was as expensive as the MFMAs it feeds). d*sc and dmin*m are formed in f32 and rounded to F16, so a
 // weight carries up to 2 F16 roundings instead of 1: far inside the F16-activation noise (NMSE vs the oracle stays ~1e-6).
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 #ifndef PM_GEMM_F16_DEQUANT
 #define PM_GEMM_F16_DEQUANT 1
 #endif
@@ -172,6 +173,7 @@ struct GemmP {
     const uint8_t * W; const _Float16 * Xh; float * Y; const float * bias; const float * resid;
     const float * silu_gate;                 // optional [T][N]: Y = silu(gate) * (W.x)   (the SiLU.mul of the FFN fused into the up projection)
     long row_stride; int K, N, T;
+    _Float16 * Yh;                           // optional: the result goes here as F16 [T][N] (the next GEMM's activations) instead of Y
     int exp;                                 // ablation switches (measurements only, compiled in with -DPM_GEMM_ABLATE=1; results are wrong when set)
 };
 // Ablations of gemm_q_f16_kernel2 (PM355_EXTRA_FLAGS=-DPM_GEMM_ABLATE=1 build, PM355_GEMM_EXP=<bits>, tools/gemm_probe.py; numbers in
@@ -309,7 +311,8 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel(GemmP p) {
                         const float4 g = *(const float4 *) (p.silu_gate + (long) t * p.N + n);
                         v.x *= g.x / (1.0f + expf(-g.x)); v.y *= g.y / (1.0f + expf(-g.y)); v.z *= g.z / (1.0f + expf(-g.z)); v.w *= g.w / (1.0f + expf(-g.w));
                     }
-                    *(float4 *) (p.Y + (long) t * p.N + n) = v;
+                    if (p.Yh) *(half4v *) (p.Yh + (long) t * p.N + n) = half4v{(_Float16) v.x, (_Float16) v.y, (_Float16) v.z, (_Float16) v.w};
+                    else *(float4 *) (p.Y + (long) t * p.N + n) = v;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (n + e < p.N) {
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel(GemmP p) {
                         if (p.bias) v += p.bias[n + e];
                         if (p.resid) v += p.resid[(long) t * p.N + n + e];
                         if (p.silu_gate) { const float g = p.silu_gate[(long) t * p.N + n + e]; v *= g / (1.0f + expf(-g)); }
-                        p.Y[(long) t * p.N + n + e] = v;
+                        if (p.Yh) p.Yh[(long) t * p.N + n + e] = (_Float16) v; else p.Y[(long) t * p.N + n + e] = v;
                     }
                 }
             }
@@ -474,7 +477,8 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel2(GemmP p) {
                         const float4 gg = *(const float4 *) (p.silu_gate + (long) t * p.N + n);
                         v.x *= gg.x / (1.0f + expf(-gg.x)); v.y *= gg.y / (1.0f + expf(-gg.y)); v.z *= gg.z / (1.0f + expf(-gg.z)); v.w *= gg.w / (1.0f + expf(-gg.w));
                     }
-                    *(float4 *) (p.Y + (long) t * p.N + n) = v;
+                    if (p.Yh) *(half4v *) (p.Yh + (long) t * p.N + n) = half4v{(_Float16) v.x, (_Float16) v.y, (_Float16) v.z, (_Float16) v.w};
+                    else *(float4 *) (p.Y + (long) t * p.N + n) = v;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (n + e < p.N) {
@@ -482,7 +486,7 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel2(GemmP p) {
                         if (p.bias) v += p.bias[n + e];
                         if (p.resid) v += p.resid[(long) t * p.N + n + e];
                         if (p.silu_gate) { const float gg = p.silu_gate[(long) t * p.N + n + e]; v *= gg / (1.0f + expf(-gg)); }
-                        p.Y[(long) t * p.N + n + e] = v;
+                        if (p.Yh) p.Yh[(long) t * p.N + n + e] = (_Float16) v; else p.Y[(long) t * p.N + n + e] = v;
                     }
                 }
             }
@@ -505,20 +509,28 @@ int pm_launch_gemm_q(int type, const void * W, const float * X, float * Y, int K
 // the f16 copy of THIS X (previous call on this stream with the same X, T, K): skip the conversion.
 int pm_launch_gemm_q_ex(int type, const void * W, const float * X, float * Y, int K, int N, int T, const float * bias,
                         const float * resid, const float * silu_gate, int reuse_x, hipStream_t st) {
+    return pm_launch_gemm_q_h(type, W, X, nullptr, Y, nullptr, K, N, T, bias, resid, silu_gate, reuse_x, st);
+}
+
+// F16 plumbing between the prefill kernels: x_f16 != null = the activations are already F16 [T][K] (written by the producing kernel:
+// rms-norm, attention, the previous GEMM's epilogue) - no conversion pass, no scratch; y_f16 != null = the result is stored as F16 [T][N]
+// (the rounding the next GEMM's conversion pass would apply) and Y is not written.
+int pm_launch_gemm_q_h(int type, const void * W, const float * X, const void * x_f16, float * Y, void * y_f16, int K, int N, int T,
+                       const float * bias, const float * resid, const float * silu_gate, int reuse_x, hipStream_t st) {
     if (K % 64 || (type != PM_Q8_0 && K % 256) || N % 4) return -2;
     if (type != PM_Q4_K && type != PM_Q5_K && type != PM_Q6_K && type != PM_Q8_0) return -1;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
     const size_t need = (size_t) T * K;
-    if (need > g_xh_elems[dev]) {
+    if (!x_f16 && need > g_xh_elems[dev]) {
         if (g_xh[dev]) { (void) hipDeviceSynchronize(); (void) hipFree(g_xh[dev]); }
         if (hipMalloc((void **) &g_xh[dev], need * 2) != hipSuccess) { g_xh[dev] = nullptr; g_xh_elems[dev] = 0; return -3; }
         g_xh_elems[dev] = need;
     }
-    _Float16 * xh = g_xh[dev];
-    if (!reuse_x) hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) ((need / 8 + 255) / 256)), dim3(256), 0, st, X, xh, (long) (need / 8));
+    _Float16 * xh = x_f16 ? (_Float16 *) x_f16 : g_xh[dev];
+    if (!reuse_x && !x_f16) hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) ((need / 8 + 255) / 256)), dim3(256), 0, st, X, xh, (long) (need / 8));
     static const int exp_sw = [] { const char * e = getenv("PM355_GEMM_EXP"); return e ? atoi(e) : 0; }();
-    GemmP p = {(const uint8_t *) W, xh, Y, bias, resid, silu_gate, (long) pm_weight_row_stride(type, K), K, N, T, exp_sw};
+    GemmP p = {(const uint8_t *) W, xh, Y, bias, resid, silu_gate, (long) pm_weight_row_stride(type, K), K, N, T, (_Float16 *) y_f16, exp_sw};
     // 256 x 256 tiles (gemm_q_f16_kernel2) when they still fill the chip; else the 128 x 256 kernel (more workgroups for small N)
     static const int force = [] { const char * e = getenv("PM355_GEMM_KERNEL"); return e ? atoi(e) : 0; }();
     const long wg2 = (long) ((N + BM2 - 1) / BM2) * ((T + BN2 - 1) / BN2);

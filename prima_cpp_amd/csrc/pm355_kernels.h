@@ -24,7 +24,7 @@ static inline bool pm_type_is_repacked(int type) { return type == 12 || type == 
 
 void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStream_t st);
 void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStream_t st);
-void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st);
+void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st, void * ynorm_f16 = nullptr);
 
 // weight repack (row-local, bijective):  GGUF block order <-> HBM row-SoA (Q4_K, Q6_K, Q8_0); identity for the rest
 void pm_launch_repack(int type, const void * src, void * dst, int64_t K, int64_t nrows, int to_device_layout, hipStream_t st);
@@ -65,6 +65,8 @@ int pm_launch_gemm_q(int type, const void * W, const float * X, float * Y, int K
 
 int pm_launch_gemm_q_ex(int type, const void * W, const float * X, float * Y, int K, int N, int T, const float * bias,
                         const float * resid, const float * silu_gate, int reuse_x, hipStream_t st);
+int pm_launch_gemm_q_h(int type, const void * W, const float * X, const void * x_f16, float * Y, void * y_f16, int K, int N, int T,
+                       const float * bias, const float * resid, const float * silu_gate, int reuse_x, hipStream_t st);
 
 // measurement helper (probe.hip): stream `bytes` from HBM once with the mat-vec's access pattern
 int pm_launch_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, hipStream_t st);

@@ -30,7 +30,8 @@ int  pm_launch_attn_split(const float * q, const float * k, const float * v, voi
 int  pm_launch_attn_prefill(const float * q, const void * kc, const void * vc, const int32_t * pos0, const int32_t * seq,
                             long seq_stride, float * out, int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st,
                             const float * mask = nullptr, long mask_stride = 0, int n_kv = 0,   // mask != null: ggml-graph mode (cells [0, n_kv) + additive mask row per token)
-                            int v_rowmajor = 0, int mask_f16 = 0);                             // flash-attention graphs: row-major V cache, F16 mask rows
+                            int v_rowmajor = 0, int mask_f16 = 0,                              // flash-attention graphs: row-major V cache, F16 mask rows
+                            void * out_f16 = nullptr);                                         // result as F16 (activations of the wo GEMM) instead of `out`
 int  pm_launch_attn_rope_fused(const float * q, const float * k, const float * v, void * kc, void * vc,
                                 const int32_t * pos0, const int32_t * seq, long seq_stride, const float * freq_factors,
                                 float * out, int H, int Hkv, int dh, int n_ctx, float scale, const pm_rope_cfg & c, hipStream_t st,

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void quantize_q80_kernel(const float * __restr
 // Optionally also writes the normalised f32 row (ynorm != nullptr).
 __global__ __launch_bounds__(256) void rmsnorm_q8k_kernel(const float * __restrict__ x, const float * __restrict__ w,
                                                           float * __restrict__ ynorm, uint8_t * __restrict__ yq,
-                                                          int K, float eps, size_t yq_row_bytes) {
+                                                          int K, float eps, size_t yq_row_bytes, _Float16 * __restrict__ yh) {
     __shared__ double red[4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nblk = K / PM_QK_K;
@@ -144,6 +144,10 @@ __global__ __launch_bounds__(256) void rmsnorm_q8k_kernel(const float * __restri
             v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
         }
         if (ynorm) ((float4 *) (ynorm + (size_t) row * K + (size_t) blk * PM_QK_K))[lane] = make_float4(v[0], v[1], v[2], v[3]);
+        if (yh) {                                // F16 copy for the MFMA GEMMs (RNE, the rounding their conversion pass applies)
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            ((h4 *) (yh + (size_t) row * K + (size_t) blk * PM_QK_K))[lane] = h4{(_Float16) v[0], (_Float16) v[1], (_Float16) v[2], (_Float16) v[3]};
+        }
         if (yq) q8k_block_from_regs(v, lane, yq + (size_t) row * yq_row_bytes, K, blk);
     }
 }
@@ -159,6 +163,6 @@ void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStrea
     hipLaunchKernelGGL(quantize_q80_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st,
                        x, (uint8_t *) y, K, rows, pm_q80_row_bytes(K));
 }
-void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st) {
-    hipLaunchKernelGGL(rmsnorm_q8k_kernel, dim3(rows), dim3(256), 0, st, x, w, ynorm, (uint8_t *) yq, K, eps, pm_q8k_row_bytes(K));
+void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st, void * ynorm_f16) {
+    hipLaunchKernelGGL(rmsnorm_q8k_kernel, dim3(rows), dim3(256), 0, st, x, w, ynorm, (uint8_t *) yq, K, eps, pm_q8k_row_bytes(K), (_Float16 *) ynorm_f16);
 }
