@@ -172,7 +172,8 @@ __device__ __forceinline__ void convert_q4k_pair_h(const RawW & w0, const RawW &
 struct GemmP {
     const uint8_t * W; const _Float16 * Xh; float * Y; const float * bias; const float * resid;
     const float * silu_gate;                 // optional [T][N]: Y = silu(gate) * (W.x)   (the SiLU.mul of the FFN fused into the up projection)
-    long row_stride; int K, N, T;
+    long row_stride; int K, N, T;             // N = weight rows of THIS launch (a launch may cover a row range of the matrix)
+    long ldy;                                // elements between consecutive tokens of Y / Yh / resid / silu_gate
     _Float16 * Yh;                           // optional: the result goes here as F16 [T][N] (the next GEMM's activations) instead of Y
     int exp;                                 // ablation switches (measurements only, compiled in with -DPM_GEMM_ABLATE=1; results are wrong when set)
 };
@@ -306,21 +307,21 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel(GemmP p) {
                 if (n + 3 < p.N) {
                     float4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                     if (p.bias)  { const float4 bb = *(const float4 *) (p.bias + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
-                    if (p.resid) { const float4 rr = *(const float4 *) (p.resid + (long) t * p.N + n); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+                    if (p.resid) { const float4 rr = *(const float4 *) (p.resid + (long) t * p.ldy + n); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
                     if (p.silu_gate) {
-                        const float4 g = *(const float4 *) (p.silu_gate + (long) t * p.N + n);
+                        const float4 g = *(const float4 *) (p.silu_gate + (long) t * p.ldy + n);
                         v.x *= g.x / (1.0f + expf(-g.x)); v.y *= g.y / (1.0f + expf(-g.y)); v.z *= g.z / (1.0f + expf(-g.z)); v.w *= g.w / (1.0f + expf(-g.w));
                     }
-                    if (p.Yh) *(half4v *) (p.Yh + (long) t * p.N + n) = half4v{(_Float16) v.x, (_Float16) v.y, (_Float16) v.z, (_Float16) v.w};
-                    else *(float4 *) (p.Y + (long) t * p.N + n) = v;
+                    if (p.Yh) *(half4v *) (p.Yh + (long) t * p.ldy + n) = half4v{(_Float16) v.x, (_Float16) v.y, (_Float16) v.z, (_Float16) v.w};
+                    else *(float4 *) (p.Y + (long) t * p.ldy + n) = v;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (n + e < p.N) {
                         float v = acc[i][j][4 * g + e];
                         if (p.bias) v += p.bias[n + e];
-                        if (p.resid) v += p.resid[(long) t * p.N + n + e];
-                        if (p.silu_gate) { const float g = p.silu_gate[(long) t * p.N + n + e]; v *= g / (1.0f + expf(-g)); }
-                        if (p.Yh) p.Yh[(long) t * p.N + n + e] = (_Float16) v; else p.Y[(long) t * p.N + n + e] = v;
+                        if (p.resid) v += p.resid[(long) t * p.ldy + n + e];
+                        if (p.silu_gate) { const float g = p.silu_gate[(long) t * p.ldy + n + e]; v *= g / (1.0f + expf(-g)); }
+                        if (p.Yh) p.Yh[(long) t * p.ldy + n + e] = (_Float16) v; else p.Y[(long) t * p.ldy + n + e] = v;
                     }
                 }
             }
@@ -472,21 +473,21 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel2(GemmP p) {
                 if (n + 3 < p.N) {
                     float4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                     if (p.bias)  { const float4 bb = *(const float4 *) (p.bias + n); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
-                    if (p.resid) { const float4 rr = *(const float4 *) (p.resid + (long) t * p.N + n); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+                    if (p.resid) { const float4 rr = *(const float4 *) (p.resid + (long) t * p.ldy + n); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
                     if (p.silu_gate) {
-                        const float4 gg = *(const float4 *) (p.silu_gate + (long) t * p.N + n);
+                        const float4 gg = *(const float4 *) (p.silu_gate + (long) t * p.ldy + n);
                         v.x *= gg.x / (1.0f + expf(-gg.x)); v.y *= gg.y / (1.0f + expf(-gg.y)); v.z *= gg.z / (1.0f + expf(-gg.z)); v.w *= gg.w / (1.0f + expf(-gg.w));
                     }
-                    if (p.Yh) *(half4v *) (p.Yh + (long) t * p.N + n) = half4v{(_Float16) v.x, (_Float16) v.y, (_Float16) v.z, (_Float16) v.w};
-                    else *(float4 *) (p.Y + (long) t * p.N + n) = v;
+                    if (p.Yh) *(half4v *) (p.Yh + (long) t * p.ldy + n) = half4v{(_Float16) v.x, (_Float16) v.y, (_Float16) v.z, (_Float16) v.w};
+                    else *(float4 *) (p.Y + (long) t * p.ldy + n) = v;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (n + e < p.N) {
                         float v = acc[i][j][4 * g + e];
                         if (p.bias) v += p.bias[n + e];
-                        if (p.resid) v += p.resid[(long) t * p.N + n + e];
-                        if (p.silu_gate) { const float gg = p.silu_gate[(long) t * p.N + n + e]; v *= gg / (1.0f + expf(-gg)); }
-                        if (p.Yh) p.Yh[(long) t * p.N + n + e] = (_Float16) v; else p.Y[(long) t * p.N + n + e] = v;
+                        if (p.resid) v += p.resid[(long) t * p.ldy + n + e];
+                        if (p.silu_gate) { const float gg = p.silu_gate[(long) t * p.ldy + n + e]; v *= gg / (1.0f + expf(-gg)); }
+                        if (p.Yh) p.Yh[(long) t * p.ldy + n + e] = (_Float16) v; else p.Y[(long) t * p.ldy + n + e] = v;
                     }
                 }
             }
@@ -530,13 +531,16 @@ int pm_launch_gemm_q_h(int type, const void * W, const float * X, const void * x
     _Float16 * xh = x_f16 ? (_Float16 *) x_f16 : g_xh[dev];
     if (!reuse_x && !x_f16) hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) ((need / 8 + 255) / 256)), dim3(256), 0, st, X, xh, (long) (need / 8));
     static const int exp_sw = [] { const char * e = getenv("PM355_GEMM_EXP"); return e ? atoi(e) : 0; }();
-    GemmP p = {(const uint8_t *) W, xh, Y, bias, resid, silu_gate, (long) pm_weight_row_stride(type, K), K, N, T, (_Float16 *) y_f16, exp_sw};
-    // 256 x 256 tiles (gemm_q_f16_kernel2) when they still fill the chip; else the 128 x 256 kernel (more workgroups for small N)
-    static const int force = [] { const char * e = getenv("PM355_GEMM_KERNEL"); return e ? atoi(e) : 0; }();
-    const long wg2 = (long) ((N + BM2 - 1) / BM2) * ((T + BN2 - 1) / BN2);
-    const bool use2 = force == 2 || (force != 1 && 2 * wg2 >= pm_device_cus());     // at least half the CUs get a 256 x 256 tile
-    if (use2) {
-        const dim3 grid2((N + BM2 - 1) / BM2, (T + BN2 - 1) / BN2);
+    const long rs = (long) pm_weight_row_stride(type, K);
+    // a launch over weight rows [r0, r0 + n): every per-column pointer is advanced, the token stride stays N
+    auto params = [&](int r0, int n) {
+        GemmP p = {(const uint8_t *) W + (long) r0 * rs, xh, Y ? Y + r0 : nullptr, bias ? bias + r0 : nullptr, resid ? resid + r0 : nullptr,
+                   silu_gate ? silu_gate + r0 : nullptr, rs, K, n, T, (long) N, y_f16 ? (_Float16 *) y_f16 + r0 : nullptr, exp_sw};
+        return p;
+    };
+    auto launch2 = [&](int r0, int n) {               // 256 x 256 tiles
+        const GemmP p = params(r0, n);
+        const dim3 grid2((n + BM2 - 1) / BM2, (T + BN2 - 1) / BN2);
         const size_t lds2 = (size_t) 2 * (BM2 + BN2) * LDS_STRIDE * sizeof(_Float16);
         auto go2 = [&](auto kern) {
             static bool attr[16] = {};                // per instantiation AND per device
@@ -549,20 +553,46 @@ int pm_launch_gemm_q_h(int type, const void * W, const float * X, const void * x
             case PM_Q6_K: go2(gemm_q_f16_kernel2<PM_Q6_K>); break;
             default:      go2(gemm_q_f16_kernel2<PM_Q8_0>); break;
         }
-        return 0;
-    }
-    const dim3 grid((N + BM - 1) / BM, (T + BN - 1) / BN);
-    const size_t lds = (size_t) 2 * (BM + BN) * LDS_STRIDE * sizeof(_Float16);
-    auto go = [&](auto kern) {
-        static bool attr[16] = {};                    // per instantiation AND per device
-        if (!attr[dev]) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr[dev] = true; }
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p);
     };
-    switch (type) {
-        case PM_Q4_K: go(gemm_q_f16_kernel<PM_Q4_K>); break;
-        case PM_Q5_K: go(gemm_q_f16_kernel<PM_Q5_K>); break;
-        case PM_Q6_K: go(gemm_q_f16_kernel<PM_Q6_K>); break;
-        default:      go(gemm_q_f16_kernel<PM_Q8_0>); break;
+    auto launch1 = [&](int r0, int n) {               // 128 x 256 tiles
+        const GemmP p = params(r0, n);
+        const dim3 grid((n + BM - 1) / BM, (T + BN - 1) / BN);
+        const size_t lds = (size_t) 2 * (BM + BN) * LDS_STRIDE * sizeof(_Float16);
+        auto go = [&](auto kern) {
+            static bool attr[16] = {};                // per instantiation AND per device
+            if (!attr[dev]) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr[dev] = true; }
+            hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p);
+        };
+        switch (type) {
+            case PM_Q4_K: go(gemm_q_f16_kernel<PM_Q4_K>); break;
+            case PM_Q5_K: go(gemm_q_f16_kernel<PM_Q5_K>); break;
+            case PM_Q6_K: go(gemm_q_f16_kernel<PM_Q6_K>); break;
+            default:      go(gemm_q_f16_kernel<PM_Q8_0>); break;
+        }
+    };
+    // 256 x 256 tiles (gemm_q_f16_kernel2) when they still fill the chip; else the 128 x 256 kernel (more workgroups for small N)
+    static const int force = [] { const char * e = getenv("PM355_GEMM_KERNEL"); return e ? atoi(e) : 0; }();
+    static const bool no_tail_split = [] { const char * e = getenv("PM355_GEMM_TAIL_SPLIT"); return e && e[0] == '0'; }();
+    const int cus = pm_device_cus();
+    const int tn = (N + BM2 - 1) / BM2, tt = (T + BN2 - 1) / BN2;
+    const long wg2 = (long) tn * tt;
+    const bool use2 = force == 2 || (force != 1 && 2 * wg2 >= cus);     // at least half the CUs get a 256 x 256 tile
+    if (!use2) { launch1(0, N); return 0; }
+    // Tail: one 256 x 256 workgroup occupies a CU, so tn * tt tiles take ceil(tiles / CUs) rounds and the last one may be mostly empty
+    // (ffn_gate of the 70B shape at 2048 tokens: 896 tiles = 3.5 rounds, 12.5 % of the launch idle). The weight rows of the last partial
+    // round go to the 128 x 256 kernel instead (twice the workgroups, ~0.62 of a big tile's time each): [0, N1) = whole rounds of big
+    // tiles, [N1, N) = small tiles - when that is estimated to be shorter.
+    const long full = wg2 / cus, rem = wg2 % cus;
+    if (!no_tail_split && force != 2 && full >= 1 && rem != 0) {
+        const int tn_full = (int) (full * cus / tt);                   // big-tile rows that fill `full` rounds (or slightly less)
+        const int N1 = tn_full * BM2;
+        if (tn_full >= 1 && N1 < N) {
+            const long small = (long) ((N - N1 + BM - 1) / BM) * ((T + BN - 1) / BN);
+            const double t_old = (double) (full + 1);
+            const double t_new = (double) ((long) tn_full * tt + cus - 1) / cus + 0.62 * (double) ((small + cus - 1) / cus);
+            if (t_new < t_old - 0.05) { launch2(0, N1); launch1(N1, N - N1); return 0; }
+        }
     }
+    launch2(0, N);
     return 0;
 }
