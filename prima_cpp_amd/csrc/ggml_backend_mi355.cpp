@@ -14,6 +14,7 @@
 #include "ggml_graph_plan.h"
 
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -68,6 +69,14 @@ struct buf_ctx { int device; void * base; size_t size; std::string name; void * 
 // Asynchronous weight staging (upload.hip): set_tensor of a large tensor returns when its bytes sit in the pinned ring; the DMA and
 // the repack run on the uploader's private stream. Everything that must observe the data drains the pending uploaders first:
 // every other buffer operation on that buffer, and graph_compute (all buffers). g_up_pending keeps that check to one load.
+// host-side time spent inside the plug-in (GGML_MI355_STATS=1 prints it): where a token's wall time goes besides the kernels
+struct host_timers { std::atomic<uint64_t> ns_compute{0}, ns_set{0}, ns_get{0}, ns_sync{0}, n_set{0}, n_get{0}, n_sync{0}; };
+host_timers g_ht;
+struct scoped_ns {
+    std::atomic<uint64_t> & acc; std::chrono::steady_clock::time_point t0;
+    explicit scoped_ns(std::atomic<uint64_t> & a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~scoped_ns() { acc += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
 std::mutex g_up_mu;
 std::vector<buf_ctx *> g_up_bufs;
 std::atomic<int> g_up_pending{0};
@@ -147,6 +156,7 @@ void buf_memset_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, uint8_t 
 
 // host GGUF-order bytes -> HBM layout (row-local repack for the row-SoA types; see repack.hip)
 void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void * data, size_t off, size_t size) {
+    scoped_ns tm(g_ht.ns_set); ++g_ht.n_set;
     buf_ctx * c = (buf_ctx *) b->context;
     dsetdev(c->device);
     const bool soa = is_soa_tensor(t);
@@ -181,6 +191,7 @@ void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void 
     MI355_CHECK(dsync(nullptr));
 }
 void buf_get_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * t, void * data, size_t off, size_t size) {
+    scoped_ns tm(g_ht.ns_get); ++g_ht.n_get;
     dsetdev(((buf_ctx *) b->context)->device);
     buf_drain((buf_ctx *) b->context);
     if (is_soa_tensor(t)) {
@@ -277,6 +288,11 @@ void backend_free(ggml_backend_t b) {
         fprintf(stderr, "ggml-mi355 stats: graph_compute %llu, fingerprint hits %llu, plans built %llu, hipGraph replays %llu, captures %llu, eager runs %llu\n",
                 (unsigned long long) c->n_compute, (unsigned long long) c->n_fp_hit, (unsigned long long) c->n_plan, (unsigned long long) c->n_replay,
                 (unsigned long long) c->n_capture, (unsigned long long) c->n_eager);
+    if (env_on("GGML_MI355_STATS"))
+        fprintf(stderr, "ggml-mi355 host time: graph_compute %.3f ms total (%.1f us per call), set_tensor %.3f ms in %llu calls, get_tensor %.3f ms in %llu calls, "
+                        "synchronize %.3f ms in %llu calls\n", g_ht.ns_compute / 1e6, c->n_compute ? g_ht.ns_compute / 1e3 / (double) c->n_compute : 0.0,
+                g_ht.ns_set / 1e6, (unsigned long long) g_ht.n_set.load(), g_ht.ns_get / 1e6, (unsigned long long) g_ht.n_get.load(),
+                g_ht.ns_sync / 1e6, (unsigned long long) g_ht.n_sync.load());
     for (graph_entry * e : c->graphs) { if (e->exec) pm355_graph_free(e->exec); delete e; }
     dfree(c->scratch); dfree(c->d_i32); dfree(c->d_dyn); dfree(c->qkv); dfree(c->split);
     if (!plan_only()) pm355_stream_destroy(c->stream);
@@ -297,6 +313,7 @@ void backend_get_async(ggml_backend_t b, const struct ggml_tensor * t, void * da
     MI355_CHECK(d2h(data, (const char *) t->data + off, size, c->stream));
 }
 void backend_sync(ggml_backend_t b) {
+    scoped_ns tm(g_ht.ns_sync); ++g_ht.n_sync;
     backend_ctx * c = (backend_ctx *) b->context;
     dsetdev(c->device);
     drain_all_uploads();
@@ -555,6 +572,7 @@ void print_plan(const backend_ctx * c, struct ggml_cgraph * g, const mi355::plan
 //   3. write the token's KV cell / cells attended to the device, then replay the entry's hipGraph - captured on the entry's second
 //      run, after one eager warm-up run (function attributes, scratch growth) - or run the launches eagerly
 enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g) {
+    scoped_ns tm(g_ht.ns_compute);
     backend_ctx * c = (backend_ctx *) b->context;
     dsetdev(c->device);
     drain_all_uploads();                               // weights staged asynchronously by set_tensor (one atomic load when none are pending)

@@ -122,7 +122,10 @@ inline void graph_fingerprint(struct ggml_cgraph * g, std::vector<graph_fp_node>
         memset(&f, 0, sizeof(f));
         f.op = (int32_t) t->op; f.type = (int32_t) t->type; f.flags = t->flags; f.base = fp_base(t);
         uint32_t h = 2166136261u;
-        for (int k = 0; k < 16; ++k) { h ^= (uint32_t) t->op_params[k]; h *= 16777619u; }
+        // (a VIEW keeps its byte offset in op_params, ggml_view_impl ggml.c:6490: for the KV cell views that offset is the per-token value the
+        // fingerprint leaves out - hashing it made every token miss and re-plan the whole split, ~80 us of host time per graph_compute)
+        const bool cell_view = t->op == GGML_OP_VIEW && fp_base(t) != t->data;
+        if (!cell_view) for (int k = 0; k < 16; ++k) { h ^= (uint32_t) t->op_params[k]; h *= 16777619u; }
         f.params = h;
         for (int k = 0; k < 4; ++k) { f.ne[k] = t->ne[k]; f.nb[k] = t->nb[k]; }
         for (int k = 0; k < 3; ++k) f.src[k] = t->src[k] ? fp_base(t->src[k]) : nullptr;
