@@ -213,8 +213,9 @@ PM355_API int pm355_attn_rope_fused(const float * q, const float * k, const floa
  * (d_pos[0]); the cache cell the token is stored in and the number of cells attended (kv_self.head / kv_self.n,
  * src/llama.cpp:18433-18453) are read from DEVICE memory d_cell_nkv[0..1] so that a captured hipGraph can be replayed for the
  * next token; mask = row 0 of the F32 KQ_mask [n_kv] (0 / -inf, llama_set_inputs src/llama.cpp:17379-17420) or NULL.
- * split = 0: one workgroup per query head (max_keys bounds the cells attended, LDS); split = 1: keys split over workgroups
- * (scratch = pm355_attn_split_scratch_floats() floats). */
+ * split = 0: one workgroup per query head (max_keys bounds the cells attended, LDS); split = 1: keys split over workgroups, one launch
+ * (flash-decoding with an in-launch merge, attn_flash.hip; max_keys = cells the grid covers, 0 = n_ctx; scratch =
+ * pm355_attn_split_scratch_floats() floats, ZEROED once after allocation; PM355_ATTN_FLASH=0 selects the three-launch form). */
 typedef struct {
     const float * q, * k, * v;           /* raw projections of the token: [n_head*head_dim], [n_head_kv*head_dim] x2 */
     void * k_cache, * v_cache;           /* F16 K rows [n_ctx][n_head_kv*head_dim]; F16 V transposed [n_head_kv*head_dim][n_ctx], or

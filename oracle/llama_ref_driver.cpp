@@ -10,7 +10,7 @@
 //   REFDRV_OUT     binary dump: int32 {magic 0x52444c4c, n_prompt, n_gen, n_vocab}, int32 tokens[n_gen],
 //                  float logits[n_gen][n_vocab] (logits that produced each generated token)
 //   REFDRV_FORCE   comma-separated token ids fed instead of the argmax (teacher forcing; logits are still dumped)
-//   REFDRV_CHUNK   prompt tokens per llama_decode call (default: all = one prefill batch)
+//   REFDRV_CHUNK   prompt tokens per llama_decode call (default: all = one prefill batch; clamped to n_batch)
 // Timing is wall-clock around llama_decode + llama_synchronize and the reference's llama_perf_context
 // (src/llama.cpp:23832-23862), printed as one JSON line on stdout.
 #include "arg.h"
@@ -61,6 +61,7 @@ int main(int argc, char ** argv) {
     const int n_vocab = llama_n_vocab(model);
     int chunk = getenv("REFDRV_CHUNK") ? atoi(getenv("REFDRV_CHUNK")) : (int) prompt.size();
     if (chunk < 1) chunk = 1;
+    if (chunk > (int) llama_n_batch(ctx)) chunk = (int) llama_n_batch(ctx);      // llama_decode asserts n_tokens <= n_batch (and ggml_abort's gdb fork can hang)
 
     std::vector<llama_token> toks(prompt.begin(), prompt.end());
     std::vector<int32_t> gen;

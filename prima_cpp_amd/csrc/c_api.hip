@@ -201,7 +201,10 @@ int pm355_attn_decode(const float * q, const void * kc, const void * vc, const i
     HIP_TRY(hipGetLastError());
     return 0;
 }
-size_t pm355_attn_split_scratch_floats(int H, int dh, int n_ctx) { return pm_attn_split_scratch_floats(H, dh, n_ctx); }
+size_t pm355_attn_split_scratch_floats(int H, int dh, int n_ctx) {       // (covers both long-context forms: attn_split.hip and attn_flash.hip)
+    const size_t a = pm_attn_split_scratch_floats(H, dh, n_ctx), b = pm_attn_flash_scratch_floats(H, H, dh, n_ctx);
+    return a > b ? a : b;
+}
 int pm355_attn_decode_split(const float * q_rot, const void * kc, const void * vc, const int32_t * d_pos0, float * out, float * scratch,
                             int H, int Hkv, int dh, int n_ctx, float kq_scale, pm355_stream_t st) {
     if (pm_launch_attn_split(q_rot, nullptr, nullptr, (void *) kc, (void *) vc, d_pos0, nullptr, 0, nullptr, out, scratch, H, Hkv, dh, n_ctx, kq_scale, nullptr, S(st)))
@@ -259,7 +262,15 @@ int pm355_attn_token(const pm355_attn_token_args * a, const pm355_rope_params * 
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    if (a->split) {
+    static const bool three_launch = [] { const char * e = getenv("PM355_ATTN_FLASH"); return e && e[0] == '0'; }();
+    if (a->split && !three_launch) {
+        // long context, ONE launch: flash-decoding with an in-launch merge (attn_flash.hip); max_keys (> 0) = cells the grid is sized for.
+        // The scratch must have been zeroed once after its allocation (ticket words).
+        if (pm_launch_attn_flash(a->q, a->k, a->v, a->k_cache, a->v_cache, a->d_pos, nullptr, 0, a->freq_factors, a->out, a->scratch,
+                                 a->n_head, a->n_head_kv, a->head_dim, a->n_ctx, a->kq_scale, c, S(st), a->d_cell_nkv, a->mask,
+                                 a->flags & PM355_ATTN_V_ROWMAJOR, a->flags & PM355_ATTN_MASK_F16, a->max_keys))
+            return fail(PM355_E_UNSUPPORTED, "attn_token(flash): head_dim 64/128, at most 8 query heads per KV head, n_ctx % 8 == 0, scratch required");
+    } else if (a->split) {
         if (pm_launch_attn_split(a->q, a->k, a->v, a->k_cache, a->v_cache, a->d_pos, nullptr, 0, a->freq_factors, a->out, a->scratch,
                                  a->n_head, a->n_head_kv, a->head_dim, a->n_ctx, a->kq_scale, &c, S(st), a->d_cell_nkv, a->mask,
                                  a->flags & PM355_ATTN_V_ROWMAJOR, a->flags & PM355_ATTN_MASK_F16))

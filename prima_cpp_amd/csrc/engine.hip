@@ -17,6 +17,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
 
 namespace {
 
@@ -63,6 +64,7 @@ struct pm355_model {
     // captured graphs). PM355_ATTN_SPLIT_MIN positions (default 640: measured crossover on the 70B head shape).
     float * split_scratch = nullptr;
     std::vector<int> h_pos; int h_seq = 0; int split_min = 640; bool long_ctx = false;
+    int flash_cells = 0; bool use_flash = true;   // long contexts: one-launch flash-decoding (attn_flash.hip), grid sized for `flash_cells` (a power-of-two bucket of the position)
     // staging for set_tensor
     pm355_uploader * up = nullptr;        // pinned ring + copier threads + private stream (upload.hip)
     hipStream_t cap_stream = nullptr;
@@ -288,6 +290,16 @@ int run_head(pm355_model * m, const float * x_row, float * d_logits, int32_t * d
     return 0;
 }
 
+// which single-token attention path the current sequence takes: 0 = one workgroup per head; else the cells the long-context grid is
+// sized for (power-of-two bucket >= position + 1, capped at n_ctx) - also the key of the captured step graph
+int attn_regime(const pm355_model * m) {
+    const int pos = m->h_pos[m->h_seq];
+    if (!m->split_scratch || pos < m->split_min) return 0;
+    long b = 1024;
+    while (b < (long) pos + 2) b *= 2;
+    return (int) (b > m->hp.n_ctx ? m->hp.n_ctx : b);
+}
+
 // the single-token layer sequence (5 launches per layer)
 int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const float ** cur_out, hipStream_t st) {
     const pm355_hparams & hp = m->hp;
@@ -320,8 +332,13 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
                                         hp.n_ctx, kq_scale, m->rope, f, m->aw_ctr, st) == 0;
         }
         if (aw_done) {
+        } else if (m->long_ctx && m->use_flash) {
+            // long context: keys split over workgroups, rope + KV store + online softmax + in-launch merge in ONE launch (attn_flash.hip)
+            if (pm_launch_attn_flash(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d, att, m->split_scratch,
+                                     H, Hkv, dh, hp.n_ctx, kq_scale, m->rope, st, nullptr, nullptr, 0, 0, m->flash_cells))
+                return seterr(m, PM355_E_RANGE, "decode: flash-decoding attention unsupported for this shape");
         } else if (m->long_ctx) {
-            // long context: the keys split over n_ctx/128 x n_head_kv workgroups, rope + KV store in the first kernel (attn_split.hip)
+            // (PM355_ATTN_FLASH=0) the three-launch form: scores, probabilities + partial P.V, combine (attn_split.hip)
             if (pm_launch_attn_split(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d, att, m->split_scratch,
                                      H, Hkv, dh, hp.n_ctx, kq_scale, &m->rope, st))
                 return seterr(m, PM355_E_RANGE, "decode: split attention unsupported for this shape");
@@ -371,7 +388,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
     if (!cur) return seterr(m, PM355_E_SHAPE, "decode: neither tokens nor x_in");
     float * bufs[2] = {m->x, m->x1};
     if (T == 1 && !m->no_fuse) {
-        m->long_ctx = m->split_scratch && m->h_pos[m->h_seq] >= m->split_min;
+        m->flash_cells = attn_regime(m); m->long_ctx = m->flash_cells != 0;
         // ---- single token: every activation transform is fused into a mat-vec prologue / epilogue, 5 launches per layer
         const float * end = nullptr;
         int rc = run_layers_fused(m, cur, d_x_out, &end, st);
@@ -599,7 +616,10 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
               A((void **) &m->d_pos, 64 * 4) && A((void **) &m->d_ctl, 64) && A((void **) &m->d_tok, 64 + T * 4);
     if (!ok) return seterr(m, PM355_E_NOMEM, "finalize: scratch");
     if (hp.n_head / hp.n_head_kv <= 8 && (hp.head_dim == 64 || hp.head_dim == 128) &&
-        !A((void **) &m->split_scratch, pm_attn_split_scratch_floats(hp.n_head, hp.head_dim, hp.n_ctx) * 4)) return seterr(m, PM355_E_NOMEM, "finalize: attention scratch");
+        !A((void **) &m->split_scratch, std::max(pm_attn_split_scratch_floats(hp.n_head, hp.head_dim, hp.n_ctx),
+                                                 pm_attn_flash_scratch_floats(hp.n_head, hp.n_head_kv, hp.head_dim, hp.n_ctx)) * 4)) return seterr(m, PM355_E_NOMEM, "finalize: attention scratch");
+    if (m->split_scratch) (void) hipMemset(m->split_scratch, 0, std::max(pm_attn_split_scratch_floats(hp.n_head, hp.head_dim, hp.n_ctx),
+                                                                         pm_attn_flash_scratch_floats(hp.n_head, hp.n_head_kv, hp.head_dim, hp.n_ctx)) * 4);   // (the flash kernel's tickets start at 0)
     if (m->n_slots) {
         if (m->n_slots > m->hi - m->lo) m->n_slots = m->hi - m->lo;
         if (hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking) != hipSuccess) return seterr(m, PM355_E_HIP, "finalize: copy stream");
@@ -620,6 +640,7 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
     }
     m->h_pos.assign(n_seq, 0); m->h_seq = 0;
     { const char * e = getenv("PM355_ATTN_SPLIT_MIN"); if (e && e[0]) m->split_min = atoi(e); }
+    { const char * e = getenv("PM355_ATTN_FLASH"); m->use_flash = !(e && e[0] == '0'); }
     (void) hipMemset(m->d_pos, 0, 64 * 4);
     { const int32_t ctl[2] = {0, n_seq}; (void) hipMemcpy(m->d_ctl, ctl, 8, hipMemcpyHostToDevice); }
     (void) hipDeviceSynchronize();
@@ -725,8 +746,8 @@ int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * 
     // host mirror of the device-side counters: which attention path this step takes, and the state after it
     if (m->hi > m->lo && m->h_pos[m->h_seq] + 1 > m->hp.n_ctx)
         return seterr(m, PM355_E_RANGE, "step: the sequence is at n_ctx - no KV cell left (llama_decode would fail to find a slot)");
-    const int regime = (m->split_scratch && m->h_pos[m->h_seq] >= m->split_min) ? 1 : 0;
-    m->long_ctx = regime != 0;
+    const int regime = attn_regime(m);
+    m->flash_cells = regime; m->long_ctx = regime != 0;
     // the mirror follows the device counters, which only move when the step was really enqueued
     auto commit = [&]() { m->h_pos[m->h_seq] += advance; if (rotate) m->h_seq = (m->h_seq + rotate) % m->n_seq; return 0; };
     if (!use_graph || m->n_slots) {              // (streaming: copies and kernels are ordered with events across two streams, not captured)

@@ -537,6 +537,7 @@ float * plan_split_scratch(void * user, size_t n) {
         dfree(c->split);
         c->split = (float *) dmalloc(n * 4 + 256);
         c->split_floats = c->split ? n : 0;
+        if (c->split) { dset(c->split, 0, n * 4 + 256, nullptr); dsync(nullptr); }      // the flash-decoding tickets start at zero
     }
     return c->split;
 }

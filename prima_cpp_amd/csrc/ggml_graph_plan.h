@@ -447,7 +447,10 @@ private:
         s.attn.freq_factors = rq->src[2] ? (const float *) rq->src[2]->data : nullptr;
         s.attn.out = (float *) out_t->data; s.attn.scratch = split ? split_mem : nullptr;
         s.attn.n_head = (int32_t) H; s.attn.n_head_kv = (int32_t) Hkv; s.attn.head_dim = (int32_t) dh; s.attn.n_ctx = (int32_t) n_ctx;
-        s.attn.split = split ? 1 : 0; s.attn.max_keys = split ? 0 : (int32_t) max_keys; s.attn.kq_scale = scale;
+        int64_t grid_cells = 1024;                                    // long-context grid: power-of-two bucket of the cells attended, so that the plan
+        while (grid_cells < n_kv) grid_cells *= 2;                    // (and its captured hipGraph) survives the steps of n_kv inside a bucket
+        if (grid_cells > n_ctx) grid_cells = n_ctx;
+        s.attn.split = split ? 1 : 0; s.attn.max_keys = split ? (int32_t) grid_cells : (int32_t) max_keys; s.attn.kq_scale = scale;
         rope_params_of(rq, s.rope);
         p.steps.push_back(s);
         ++p.n_attn;

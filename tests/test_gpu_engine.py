@@ -193,13 +193,16 @@ def test_prefill_mfma_path_vs_oracle(E, oracle, arch):
     w.close()
 
 
-def test_long_context_split_attention_path(E, monkeypatch):
+@pytest.mark.parametrize("flash,n_head", [("1", 8), ("1", 4), ("0", 8)])
+def test_long_context_split_attention_path(E, monkeypatch, flash, n_head):
     """Beyond PM355_ATTN_SPLIT_MIN positions the engine switches from the one-workgroup-per-head attention kernel to the
-    keys-split-over-workgroups path (attn_split.hip, 4 launches, other captured graph): same rounding points, so hidden state
-    and logits agree to summation-order accuracy at every position, through graph replay and through plain decode()."""
+    keys-split-over-workgroups path - one launch of flash-decoding with an in-launch merge (attn_flash.hip; head_dim 64 and 128, up to
+    three spans merged here), or with PM355_ATTN_FLASH=0 the three-launch form (attn_split.hip) - in another captured graph: hidden
+    state and logits agree at every position, through graph replay and through plain decode()."""
     torch = E.torch
     rng = np.random.default_rng(78)
-    d = tiny_model(rng, arch=0, n_layer=2, n_embd=512, n_head=8, n_head_kv=2, n_ff=1024, n_vocab=320, n_ctx=320, rope_freqs=True)
+    monkeypatch.setenv("PM355_ATTN_FLASH", flash)
+    d = tiny_model(rng, arch=0, n_layer=2, n_embd=512, n_head=n_head, n_head_kv=2, n_ff=1024, n_vocab=320, n_ctx=320, rope_freqs=True)
     toks = rng.integers(0, d.n_vocab, 300).astype(np.int32)
     res = []
     for split_min in ("100000", "40"):
