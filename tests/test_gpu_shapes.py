@@ -54,9 +54,13 @@ SHAPES = {
 }
 
 
-@pytest.mark.parametrize("name", list(SHAPES))
-def test_model_shaped_layer_decode_and_prefill(E, oracle, name):
+@pytest.mark.parametrize("name", list(SHAPES) + ["llama3_70b+flash"])
+def test_model_shaped_layer_decode_and_prefill(E, oracle, name, monkeypatch):
     torch = E.torch
+    if name.endswith("+flash"):
+        # the decode step at position 32 then runs the long-context kernel (attn_flash.hip) at the model's GQA shape (8 query heads per KV head)
+        monkeypatch.setenv("PM355_ATTN_SPLIT_MIN", "16")
+        name = name[:-6]
     arch, n_ff, tv, td, tout = SHAPES[name]
     rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000)     # (str hash() is salted per process: a different model every run)
     types = {"attn_v": tv, "ffn_down": td, "output": tout}
