@@ -67,3 +67,33 @@ def test_flash_attn_decode_graph_lowers_to_five_launches_per_layer(tmp_path):
     assert "KQ_mask (copy)" in st["stderr"] and "FLASH_ATTN_EXT" not in st["stderr"].split("single_token=1")[1].split("ggml-mi355 plan")[0]
     cells = [p[7] for p in decode]
     assert cells[0] == 0 and cells[1:] == list(range(3, 3 + len(cells) - 1)), cells
+
+
+@pytest.mark.parametrize("kv", [["-ctk", "q8_0", "-ctv", "q8_0"], ["-ctk", "q8_0"], ["-ctv", "q8_0"]])
+def test_quantized_kv_graphs_stay_on_the_plugin_and_lower(kv, tmp_path):
+    """-ctk / -ctv q8_0 (with --flash-attn): the KV buffer lives in the MI355 buffer type, every node of the split is accepted by
+    supports_op (one graph per layer window, nothing bounced to the CPU backend) and single tokens lower to five launches per layer."""
+    z = np.load(os.path.join(HERE, "golden", "tiny_llama_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / "tiny_llama.gguf"), z)
+    _, _, st = run_llama_driver(path, z["prompt"][:3], 4, ngl=99, n_ctx=64, threads=1, extra_args=["--keep-out-in-cuda", "-fa"] + kv,
+                                env={"GGML_MI355_PLAN_ONLY": "1"}, flavour="avx2", timeout=120)
+    assert "MI355X0 KV buffer size" in st["stderr"] and "q8_0" in st["stderr"]
+    plans = [tuple(int(x) for x in m.groups()) for m in PLAN.finditer(st["stderr"])]
+    n_layer = int(z["hp_n_layer"])
+    decode = [p for p in plans if p[0] > 3 and p[6] == 1]
+    assert len(decode) >= 3, st["stderr"][-2000:]
+    for p in decode:
+        nodes, launches, gemv, attn, node_eq, fused, single, cell, n_kv, graphable = p
+        assert nodes == 59 and attn == n_layer and gemv == 4 * n_layer and launches == 5 * n_layer + 1 and graphable == 1, p
+    # the 3-token prompt batch: one graph of all 59 nodes as well (CPY f32 -> Q8_0 and FLASH_ATTN_EXT on Q8_0 blocks are served)
+    assert any(p[0] == 59 and p[6] == 0 for p in plans)
+
+
+def test_flash_attn_prompt_batches_use_the_mfma_attention(tmp_path):
+    z = np.load(os.path.join(HERE, "golden", "tiny_llama_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / "tiny_llama.gguf"), z)
+    _, _, st = run_llama_driver(path, z["prompt"][:3], 2, ngl=99, n_ctx=64, threads=1, extra_args=["--keep-out-in-cuda", "-fa"],
+                                env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1"}, flavour="avx2", timeout=120)
+    n_layer = int(z["hp_n_layer"])
+    assert f"{n_layer} multi-token attention chain(s) -> MFMA masked attention" in st["stderr"]
+    assert "batch attention T=3" in st["stderr"]
