@@ -392,7 +392,7 @@ def plugin_decode(tmp, n_gen=64, prompt_len=16):
     t_gen = time.time() - t0
     prompt = np.random.default_rng(1234).integers(0, 128256, prompt_len)
     prompt[0] = 128000
-    _, _, st = B.run_llama_driver(path, prompt, n_gen, ngl=99, n_ctx=4096, threads=usable_cores(), extra_args=["--keep-out-in-cuda"], timeout=600)
+    _, _, st = B.run_llama_driver(path, prompt, n_gen, ngl=99, n_ctx=4096, threads=usable_cores(), extra_args=["--keep-out-in-cuda"], timeout=150)
     total_w = 4617000000.0                       # bytes read per decoded token, Llama-3-8B Q4_K_M
     roof = HBM_PEAK_GBS * 1e9 / total_w
     out = {"workload": f"Llama-3-8B-shaped Q4_K_M GGUF ({os.path.getsize(path) / 1e9:.2f} GB, random valid blocks, no_vocab) through the reference's "
@@ -403,7 +403,7 @@ def plugin_decode(tmp, n_gen=64, prompt_len=16):
            "timing": "wall clock around llama_decode + llama_synchronize per token, first 5 tokens dropped (llama_perf convention)"}
     # the same model with --flash-attn (FLASH_ATTN_EXT graphs: row-major V cache, F16 mask) - lowered to the same five launches
     try:
-        _, _, sf = B.run_llama_driver(path, prompt, 32, ngl=99, n_ctx=4096, threads=usable_cores(), extra_args=["--keep-out-in-cuda", "-fa"], timeout=600)
+        _, _, sf = B.run_llama_driver(path, prompt, 32, ngl=99, n_ctx=4096, threads=usable_cores(), extra_args=["--keep-out-in-cuda", "-fa"], timeout=150)
         out["flash_attn"] = {"tokens_per_s": round(sf["decode_tok_s"], 2), "ms_per_token": round(sf["decode_ms_avg"], 4), "prompt_tokens_per_s": round(sf["prompt_tok_s"], 1)}
     except Exception as e:                       # noqa: BLE001 - a bench leg, never fatal
         out["flash_attn"] = {"error": str(e)[:200]}
@@ -423,14 +423,14 @@ def cpu_llama_decode(tmp, path_8b, hp70):
            "timing": "wall clock around llama_decode per token (-ngl 0), first tokens dropped"}
     prompt = np.random.default_rng(1234).integers(0, 128256, 16)
     if path_8b and os.path.exists(path_8b):
-        _, _, st = B.run_llama_driver(path_8b, prompt, 12, ngl=0, n_ctx=512, threads=cores, timeout=900)
+        _, _, st = B.run_llama_driver(path_8b, prompt, 12, ngl=0, n_ctx=512, threads=cores, timeout=240)
         out["llama3_8b_q4km"] = {"tokens_per_s": round(st["decode_tok_s"], 3), "prompt_tokens_per_s": round(st["prompt_tok_s"], 2)}
     ms = {}
     for L in (2, 6):
         p = os.path.join(tmp, f"pm355_bench_llama3_70b_shape_{L}l.gguf")
         G.write_synthetic_model(p, arch=0, n_layer=L, n_embd=hp70["n_embd"], n_head=hp70["n_head"], n_head_kv=hp70["n_head_kv"],
                                 n_ff=hp70["n_ff"], n_vocab=hp70["n_vocab"], is_70b=True)
-        _, _, st = B.run_llama_driver(p, prompt, 10, ngl=0, n_ctx=512, threads=cores, timeout=900)
+        _, _, st = B.run_llama_driver(p, prompt, 10, ngl=0, n_ctx=512, threads=cores, timeout=240)
         ms[L] = st["decode_ms_avg"]
         os.unlink(p)
     per_layer = (ms[6] - ms[2]) / 4.0
