@@ -68,6 +68,29 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(FlashP p) {
     const long krow = (long) p.Hkv * DH;
     uint16_t * kcw = p.kc + (long) seq * p.seq_stride, * vcw = p.vc + (long) seq * p.seq_stride;
     const uint16_t * kc = kcw + (long) g * DH;
+    const int piece = tid % LPK, kslot = tid / LPK;
+    // memory pipeline: the V pieces of a chunk are requested at its top (they are not needed before the probabilities exist), the K pieces
+    // of the NEXT chunk as soon as this chunk's scores have consumed the registers: one exposed round trip per span instead of two per chunk
+    constexpr int NVR = VM == 0 ? KP / 8 : NR;
+    u32x4 kall[NPS], vall[NVR];
+    auto load_k = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) kall[ps] = *(const u32x4 *) (kc + (long) min(k0 + ps * KPP + kslot, p.n_ctx - 1) * krow + 8 * piece);
+    };
+    auto load_v = [&](int k0) __attribute__((always_inline)) {
+        if (VM == 0) {
+            const uint16_t * vr = vcw + (long) (g * DH + tid % DH) * p.n_ctx;
+#pragma unroll
+            for (int j = 0; j < NVR; ++j) vall[j] = *(const u32x4 *) (vr + min(k0 + (tid / DH) * KP + 8 * j, p.n_ctx - 8));
+        } else {
+            const uint16_t * vr = vcw + (long) g * DH + 8 * (tid % C8);
+#pragma unroll
+            for (int j = 0; j < NVR; ++j) vall[j] = *(const u32x4 *) (vr + (long) min(k0 + tid / C8 + j * NSL, p.n_ctx - 1) * krow);
+        }
+    };
+    // the first chunk's K and V pieces do not depend on the queries: they are requested before the RoPE (one exposed latency less)
+    load_k(k_begin);
+    load_v(k_begin);
     // ---- RoPE of the group's queries (+ the token's key / value store in the span that owns its cell): as attn_split_scores_kernel
     const bool neox = p.r.mode & 2;
     const int half = p.r.n_dims / 2;
@@ -111,7 +134,6 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(FlashP p) {
         }
     }
     __syncthreads();
-    const int piece = tid % LPK, kslot = tid / LPK;
     float qr[RMAX][8];
 #pragma unroll
     for (int h = 0; h < RMAX; ++h)
@@ -124,28 +146,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(FlashP p) {
 #pragma unroll
         for (int i = 0; i < (VM == 0 ? 1 : 8); ++i) oacc[h][i] = 0.0f;
 
-    // memory pipeline: the V pieces of a chunk are requested at its top (they are not needed before the probabilities exist), the K pieces
-    // of the NEXT chunk as soon as this chunk's scores have consumed the registers: one exposed round trip per span instead of two per chunk
-    constexpr int NVR = VM == 0 ? KP / 8 : NR;
-    u32x4 kall[NPS], vall[NVR];
-    auto load_k = [&](int k0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int ps = 0; ps < NPS; ++ps) kall[ps] = *(const u32x4 *) (kc + (long) min(k0 + ps * KPP + kslot, p.n_ctx - 1) * krow + 8 * piece);
-    };
-    auto load_v = [&](int k0) __attribute__((always_inline)) {
-        if (VM == 0) {
-            const uint16_t * vr = vcw + (long) (g * DH + tid % DH) * p.n_ctx;
-#pragma unroll
-            for (int j = 0; j < NVR; ++j) vall[j] = *(const u32x4 *) (vr + min(k0 + (tid / DH) * KP + 8 * j, p.n_ctx - 8));
-        } else {
-            const uint16_t * vr = vcw + (long) g * DH + 8 * (tid % C8);
-#pragma unroll
-            for (int j = 0; j < NVR; ++j) vall[j] = *(const u32x4 *) (vr + (long) min(k0 + tid / C8 + j * NSL, p.n_ctx - 1) * krow);
-        }
-    };
-    load_k(k_begin);
     for (int k0 = k_begin; k0 < k_end; k0 += CK) {
-        load_v(k0);
+        if (k0 != k_begin) load_v(k0);
         // ---- scores of this chunk
 #pragma unroll
         for (int ps = 0; ps < NPS; ++ps) {
