@@ -373,8 +373,19 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel2(GemmP p) {
         const int k0 = min(st, nst - 1) * BK;
         if (exp & 2) return;
         if (!(exp & 32)) {
-            fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, 0, R.w[0]);
-            fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, 1, R.w[1]);
+            if (TYPE == PM_Q4_K) {
+                // Q4_K: the two threads of a row (lanes 2r, 2r+1 = 32-k halves = sub-blocks 2u, 2u+1) need the SAME two 16-byte pieces
+                // (stream a / stream b of unit u, low / high nibbles) and the same block header: each lane loads ONE of them (its own
+                // stream; lane 2r also the header) and the pair swaps through DPP at staging time - 1.5 weight-load instructions per
+                // thread and k-step instead of 4
+                const int b = k0 >> 8, u = (k0 & 255) >> 6;
+                const long nb4 = p.K / 256;
+                R.w[0].r[0] = *(const u32x4 *) (wptr + (long) ahalf * nb4 * 64 + 16 * (4 * (long) b + u));
+                if (ahalf == 0) R.w[0].r[1] = *(const u32x4 *) (wptr + nb4 * 128 + (long) b * 16);
+            } else {
+                fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, 0, R.w[0]);
+                fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, 1, R.w[1]);
+            }
         }
         if (!(exp & 64)) {
 #pragma unroll
@@ -393,7 +404,19 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel2(GemmP p) {
         } else
         if (PM_GEMM_F16_DEQUANT && TYPE == PM_Q4_K) {
             half8 o[4];
-            convert_q4k_pair_h(R.w[0], R.w[1], k0, o);
+            // pair exchange (quad_perm [1,0,3,2]): the neighbour's stream piece and, for the odd lane, the header
+            RawW wa, wb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t own = R.w[0].r[0][q];
+                const uint32_t oth = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) own, 0xB1, 0xF, 0xF, true);
+                wa.r[0][q] = ahalf ? oth : own;              // stream a piece (16-weight part 0 of the sub-block)
+                wb.r[0][q] = ahalf ? own : oth;              // stream b piece (part 1)
+                const uint32_t hown = R.w[0].r[1][q];
+                const uint32_t hoth = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) hown, 0xB1, 0xF, 0xF, true);
+                wa.r[1][q] = ahalf ? hoth : hown;
+            }
+            convert_q4k_pair_h(wa, wb, k0, o);
 #pragma unroll
             for (int q = 0; q < 4; ++q) *(half8 *) (da + 8 * q) = o[q];
         } else
