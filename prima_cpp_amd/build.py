@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libprima_mi355.so")
-SOURCES = ["c_api.hip", "quantize.hip", "mmvq.hip", "repack.hip", "layer_ops.hip", "ggml_ops.hip", "engine.hip", "mmq.hip", "probe.hip", "engine_probe.hip", "attn_prefill.hip", "attn_split.hip", "attn_flash.hip", "attn_q8.hip", "attn_wo.hip", "ring.hip", "upload.hip"]
+SOURCES = ["c_api.hip", "quantize.hip", "mmvq.hip", "mmvq_cols.hip", "repack.hip", "layer_ops.hip", "ggml_ops.hip", "engine.hip", "mmq.hip", "mmq_i8.hip", "probe.hip", "engine_probe.hip", "attn_prefill.hip", "attn_split.hip", "attn_flash.hip", "attn_q8.hip", "attn_wo.hip", "ring.hip", "upload.hip"]
 # -ffp-contract=off: the quantizers must round exactly like the reference (no fused multiply-add where
 # the reference has a separate multiply and add); FMAs we want are written as fmaf().
 EXTRA = os.environ.get("PM355_EXTRA_FLAGS", "").split()

@@ -167,6 +167,21 @@ int pm355_mul_mat_q_mfma(int type, const void * W, int64_t K, int64_t N, const f
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_mul_mat_q_small(int type, const void * W, int64_t K, int64_t N, const void * xq, const float * x, int64_t n_tokens, float * y,
+                          const float * bias, const float * resid, pm355_stream_t st) {
+    (void) hipGetLastError();
+    if (!xq && !x) return fail(PM355_E_RANGE, "mul_mat_q_small: neither xq nor x given");
+    const int rc = pm_launch_mmq_i8(type, W, xq, x, y, (int) K, (int) N, (int) n_tokens, bias, resid, 0, S(st));
+    if (rc == -1) return fail(PM355_E_UNSUPPORTED, "mul_mat_q_small: weight type (Q4_K / Q6_K)");
+    if (rc == -2) return fail(PM355_E_SHAPE, "mul_mat_q_small: 1 <= n_tokens <= 32, K % 256 == 0, K >= 512 required");
+    if (rc == -4) return fail(PM355_E_RANGE, "mul_mat_q_small: K too large for the LDS tiles");
+    if (rc) return fail(PM355_E_HIP, "mul_mat_q_small: scratch allocation");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pm355_mul_mat_q_small_check(int type, int64_t K, int64_t N, int64_t n_tokens) {
+    return pm_mmq_i8_check(type, (int) K, (int) N, (int) n_tokens) == 0 ? 0 : PM355_E_UNSUPPORTED;
+}
 int pm355_mul_mat_vec_q_dbg(int type, const void * W, int64_t K, int64_t N, const void * xq, float * y,
                             int32_t * ip, int64_t * upr, pm355_stream_t st) {
     if (upr) *upr = pm_gemv_units_per_row(type, K);

@@ -44,6 +44,7 @@ struct pm355_model {
     int32_t * d_pos = nullptr, * d_tok = nullptr, * d_ctl = nullptr;   // d_pos[n_seq]; d_ctl = {current seq, n_seq}
     int n_seq = 1;
     bool no_fuse = false;                 // PM355_NO_FUSE=1: node-by-node kernels (debug / A-B)
+    bool no_mmq = false;                  // PM355_NO_MMQ_I8=1: 4..32-token batches on the round-1 paths (mat-vec columns, F16 GEMM from 16 tokens)
     // EXPERIMENT (PM355_ATTN_WO=1, attn_wo.hip): attention + wo as ONE two-phase launch per layer - every workgroup first puts its wo
     // weight loads in flight, the 64 head workgroups run the latency-bound attention meanwhile, one device-wide barrier, then the wo
     // mat-vec: 4 launches per layer instead of 5. Bit-identical, but the barrier + first-touch fetch of the heads' outputs costs what
@@ -261,6 +262,18 @@ int gemv(const Tensor & w, const Tensor * w2, const ActQ & a, int T, float * y, 
     return pm_launch_gemv(g, st);
 }
 
+// 4..32 tokens: one pass over the weights on the integer matrix cores (mmq_i8.hip) where the type / shape is served, else the mat-vec
+// (one to three passes per 8 columns). `prepped`: the kernel's activation tables already describe THIS activation set (set by the first
+// served call, cleared by the caller whenever the activations change)
+const int MMQ_MIN_TOKENS = 4, MMQ_MAX_TOKENS = 32;
+int matmul_small(pm355_model * m, const Tensor & w, const ActQ & a, int T, float * y, const float * bias, const float * resid, bool & prepped, hipStream_t st) {
+    if (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && a.k && pm_mmq_i8_check(w.type, (int) w.K, (int) w.N, T) == 0) {
+        const int rc = pm_launch_mmq_i8(w.type, w.d, a.k, nullptr, y, (int) w.K, (int) w.N, T, bias, resid, prepped ? 1 : 0, st);
+        if (rc == 0) { prepped = true; return 0; }
+    }
+    return gemv(w, nullptr, a, T, y, bias, resid, st);
+}
+
 // single-token fused GEMV launch helper: jobs share the f32 activation `xf` (rms_norm'ed with norm_w when given)
 int gemv_f32(pm355_model * m, const Tensor * const * ws, const Tensor * const * w2s, float * const * ys,
              const float * const * biases, const float * const * resids, int nj,
@@ -398,7 +411,9 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
     for (int il = m->lo; il < m->hi; ++il) {
         Layer Lv = layer_acquire(m, il, st); Layer & L = Lv;
         const Tensor * qkv[3] = {&L.t[PM355_T_WQ], &L.t[PM355_T_WK], &L.t[PM355_T_WV]};
-        if (T >= 16 && !m->no_fuse) {
+        // 16..32 tokens take the small-batch path below unless its per-token attention kernel cannot hold n_ctx scores in LDS
+        const bool small_attn_ok = (size_t) (dh + hp.n_ctx) * 4 <= 150 * 1024;
+        if (T > ((m->no_mmq || !small_attn_ok) ? 15 : MMQ_MAX_TOKENS) && !m->no_fuse) {
             // ---- prefill: batched GEMMs on the MFMA matrix cores (mmq.hip), f32 activations
             // F16 plumbing: the producers of GEMM activations write them as F16 (the rounding the GEMM's own conversion pass would apply) into
             // the engine's scratch - xn / att in place of their f32 forms, h = silu(gate) * up into h2: no conversion launches, half the bytes
@@ -447,9 +462,10 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         // attn_norm (+weight), quantized for q/k/v in the same pass when only Q8_K is needed
         ActQ a = norm_quantize_for(m, cur, (const float *) L.t[PM355_T_ATTN_NORM].d, E, T, qkv, 3, st);
         int rc = 0;
-        rc |= gemv(L.t[PM355_T_WQ], nullptr, a, T, m->q, (const float *) L.t[PM355_T_BQ].d, nullptr, st);
-        rc |= gemv(L.t[PM355_T_WK], nullptr, a, T, m->k, (const float *) L.t[PM355_T_BK].d, nullptr, st);
-        rc |= gemv(L.t[PM355_T_WV], nullptr, a, T, m->v, (const float *) L.t[PM355_T_BV].d, nullptr, st);
+        bool prepped = false;
+        rc |= matmul_small(m, L.t[PM355_T_WQ], a, T, m->q, (const float *) L.t[PM355_T_BQ].d, nullptr, prepped, st);
+        rc |= matmul_small(m, L.t[PM355_T_WK], a, T, m->k, (const float *) L.t[PM355_T_BK].d, nullptr, prepped, st);
+        rc |= matmul_small(m, L.t[PM355_T_WV], a, T, m->v, (const float *) L.t[PM355_T_BV].d, nullptr, prepped, st);
         if (rc) return seterr(m, rc, "decode: qkv gemv");
         const long kv_stride = (long) hp.n_ctx * Hkv * dh;
         bool fused_attn = false;
@@ -465,17 +481,27 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         const Tensor * wo[1] = {&L.t[PM355_T_WO]};
         a = quantize_for(m, m->att, Eq, T, wo, 1, st);
         float * x_mid = (cur == bufs[0]) ? bufs[1] : bufs[0];                 // ffn_inp = wo.att + inpSA
-        if (gemv(L.t[PM355_T_WO], nullptr, a, T, x_mid, nullptr, cur, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: wo gemv");
+        prepped = false;
+        if (matmul_small(m, L.t[PM355_T_WO], a, T, x_mid, nullptr, cur, prepped, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: wo gemv");
         const Tensor * gu[2] = {&L.t[PM355_T_FFN_GATE], &L.t[PM355_T_FFN_UP]};
         a = norm_quantize_for(m, x_mid, (const float *) L.t[PM355_T_FFN_NORM].d, E, T, gu, 2, st);
         if (L.t[PM355_T_FFN_GATE].type != L.t[PM355_T_FFN_UP].type)
             return seterr(m, PM355_E_UNSUPPORTED, "decode: ffn_gate and ffn_up of different types");
+        const Tensor & wg = L.t[PM355_T_FFN_GATE], & wu = L.t[PM355_T_FFN_UP];
+        if (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && m->h2 && a.k && pm_mmq_i8_check(wg.type, (int) wg.K, (int) wg.N, T) == 0) {
+            // gate and up: one weight pass each for all tokens, then silu(gate) * up (the pair mat-vec would take one launch per token)
+            prepped = false;
+            if (matmul_small(m, wg, a, T, m->h, nullptr, nullptr, prepped, st) || matmul_small(m, wu, a, T, m->h2, nullptr, nullptr, prepped, st))
+                return seterr(m, PM355_E_UNSUPPORTED, "decode: gate/up small-batch mat-mul");
+            pm_launch_silu_mul(m->h, m->h2, m->h, (long) T * F, st);
+        } else
         if (gemv(L.t[PM355_T_FFN_GATE], &L.t[PM355_T_FFN_UP], a, T, m->h, nullptr, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: gate/up gemv");
         const Tensor * dn[1] = {&L.t[PM355_T_FFN_DOWN]};
         a = quantize_for(m, m->h, F, T, dn, 1, st);
         // `cur` is dead after the wo GEMV consumed it as residual, so the other scratch buffer can be reused
         float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : ((x_mid == bufs[0]) ? bufs[1] : bufs[0]);
-        if (gemv(L.t[PM355_T_FFN_DOWN], nullptr, a, T, x_next, nullptr, x_mid, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: down gemv");
+        prepped = false;
+        if (matmul_small(m, L.t[PM355_T_FFN_DOWN], a, T, x_next, nullptr, x_mid, prepped, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: down gemv");
         layer_release(m, il, st);
         cur = x_next;
     }
@@ -503,6 +529,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     m->rope.ext_factor = 0.0f; m->rope.attn_factor = 1.0f; m->rope.beta_fast = 32.0f; m->rope.beta_slow = 1.0f;
     pm_rope_params(m->rope);
     { const char * e = getenv("PM355_NO_FUSE"); m->no_fuse = e && e[0] == '1'; }
+    { const char * e = getenv("PM355_NO_MMQ_I8"); m->no_mmq = e && e[0] == '1'; }     // 2..32-token batches: mat-vec columns / F16 GEMM from 16 (the round-1 paths)
     { const char * e = getenv("PM355_ATTN_WO"); m->attn_wo = e && e[0] == '1'; }       // measured: 8.74 vs 8.60 ms per 70B token -> opt-in experiment
     return m;
 }
@@ -610,7 +637,7 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
     auto A = [&](void ** p, size_t n) { return hipMalloc(p, n + 256) == hipSuccess; };
     bool ok = A((void **) &m->x, T * E * 4) && A((void **) &m->x1, T * E * 4) && A((void **) &m->xn, T * E * 4) &&
               A((void **) &m->q, T * Eq * 4) && A((void **) &m->k, T * Ekv * 4) && A((void **) &m->v, T * Ekv * 4) &&
-              A((void **) &m->att, T * Eq * 4) && A((void **) &m->h, T * F * 4) && (T < 16 || A((void **) &m->h2, T * F * 4)) && A((void **) &m->logits, (size_t) hp.n_vocab * 4) &&
+              A((void **) &m->att, T * Eq * 4) && A((void **) &m->h, T * F * 4) && (T < MMQ_MIN_TOKENS || A((void **) &m->h2, T * F * 4)) && A((void **) &m->logits, (size_t) hp.n_vocab * 4) &&
               A((void **) &m->aq_k, T * pm_q8k_row_bytes((int) ((maxK + 255) / 256 * 256))) &&
               A((void **) &m->aq_0, T * pm_q80_row_bytes((int) ((maxK + 31) / 32 * 32))) &&
               A((void **) &m->d_pos, 64 * 4) && A((void **) &m->d_ctl, 64) && A((void **) &m->d_tok, 64 + T * 4);

@@ -1,0 +1,374 @@
+// mmq_i8.hip — small-batch (2..32 tokens) quantized mat-mul on the INTEGER matrix cores (v_mfma_i32_32x32x16_i8).
+//
+// What it replaces: for 2..32 activation rows the reference runs ggml_compute_forward_mul_mat's vec_dot loop once per (row, token)
+// (ggml/src/ggml.c ggml_compute_forward_mul_mat -> ggml_vec_dot_q4_K_q8_K / ggml_vec_dot_q6_K_q8_K, ggml-quants.c), its CUDA plug-in
+// the integer mmq tiles (ggml-cuda/mmq.cuh:2583). The arithmetic here is the reference's own: activations quantized to Q8_K, exact
+// int32 sums  sum_s scale_s * (q_w . q_a)  and  sum_s min_s * bsum_s  per 256-weight super-block, then ONE f32 multiply-add per
+// super-block with d_w * d_a - only the order in which the super-block terms are added in f32 differs (K split over waves).
+//
+// Why a third mat-mul kernel: between the mat-vec (1 token: weight-stream bound) and the F16 MFMA GEMM (256-token tiles: a 16-token
+// batch pays for 256) sits the regime of speculative decoding, parallel sequences and prompt tails. The multi-column mat-vec
+// (mmvq_cols.hip) re-reads its activations from LDS for every decoded weight and costs ~10 us per extra column on the ffn_gate shape
+// (profiles/r02_cols_probe.txt); this kernel streams the weights ONCE for up to 32 tokens and does the products on the matrix cores.
+//
+// Mapping (one v_mfma_i32_32x32x16_i8 = 32 tokens x 32 weight rows x 16 k):
+//   A operand = activations: lane (t = lane % 32, g = lane / 32) holds 8 consecutive int8 of token t
+//   B operand = weights    : lane (r = lane % 32, g)            holds 8 int8 of weight row r  (same k as A)
+//   result                 : lane (r, g) holds, for ITS OWN row r, tokens 8 (v / 4) + 4 g + v % 4, v = 0..15
+// so the per-row sub-block scale / min / d of a K-quant are lane-local scalars when the i32 tile is scaled. A 16-k MFMA never
+// crosses a scale group (Q4_K: 32, Q6_K: 16 weights per scale). The min / -32 terms are one more MFMA per super-block in F16
+// (v_mfma_f32_32x32x16_f16: 6-bit mins or int8 scales x 16-value activation sums <= 2032, all exact in F16, f32 accumulate exact).
+//
+// Data movement: weights keep the mat-vec's row-SoA HBM layout (repack.hip). A wave owns 32 rows x 512 k per step: it loads them
+// with FULL 128-byte lines per row and stream (8 lanes per line, non-temporal), parks them in its private LDS tile and reads them
+// back in MFMA operand order - no barrier, a wave's LDS accesses execute in order. The next step's loads are in flight while the
+// current one is computed (VMEM returns in order: the activation loads a step waits for are always issued BEFORE the weight
+// prefetch that overlaps it). Activations come straight from L2 in operand order; two small tables made by a prologue launch hold
+// the activation scales (transposed, -> LDS) and the F16 group sums in A-operand order.
+// Work split: workgroup = 8 waves, a balanced slice of rows = up to 8 groups of 32; K is split over the waves that share a row
+// group and their f32 partial tiles are added in a fixed order through LDS (bitwise reproducible).
+#include "pm355_device.h"
+#include "pm355_kernels.h"
+
+namespace {
+
+typedef int      i32x16 __attribute__((ext_vector_type(16)));
+typedef float    f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8  __attribute__((ext_vector_type(8)));
+
+constexpr int BLOCK = 512, NWAVE = 8;
+constexpr int PITCH = 144;            // LDS bytes per row of a 128-byte stream tile: 16 consecutive rows -> 16 distinct 16-byte bank slots
+constexpr int PITCH_H = 48;           // same for the 2 x 16-byte per-row header / scale tile
+
+struct MmqP {
+    const uint8_t * W; long row_stride; int N, K, T, rgb_log2;     // 1 << rgb_log2 row groups per batch (1, 2, 4, 8)
+    const uint8_t * xq; long xq_stride;                            // row-SoA Q8_K activations [T]
+    const uint8_t * bsT; const float * dT;                         // prologue tables: [nsb][64 lanes][8 f16], [nsb][32]
+    float * y; long y_stride; const float * bias; const float * resid;
+};
+
+__device__ __forceinline__ long pk(uint32_t a, uint32_t b) { return (long) (((uint64_t) b << 32) | a); }
+__device__ __forceinline__ u32x4 ld_c16(const void * p) { return *(const PM_G u32x4 *) p; }
+__device__ __forceinline__ u32x2 ld_c8(const void * p)  { return *(const PM_G u32x2 *) p; }
+__device__ __forceinline__ i32x16 mfma_i8(long a, long b, i32x16 c) { return __builtin_amdgcn_mfma_i32_32x32x16_i8(a, b, c, 0, 0, 0); }
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// gfx950's 2 x K form: lane (i, g) holds 16 consecutive int8 (k = 16 g .. 16 g + 15)
+__device__ __forceinline__ i32x16 mfma_i8x32(u32x4 a, u32x4 b, i32x16 c) {
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
+}
+
+// where the loader lanes of a wave point: lane (rr = lane / 8, c = lane % 8) fetches 16-byte chunk c of rows rr, rr + 8, rr + 16, rr + 24
+struct Rows {
+    const uint8_t * base; uint32_t stride; int lim /*last valid row of the group, relative*/, rr, rh;
+    __device__ __forceinline__ uint32_t off(int n) const { return (uint32_t) min(rr + 8 * n, lim) * stride; }
+    __device__ __forceinline__ uint32_t off_h() const { return (uint32_t) min(rh, lim) * stride; }
+};
+
+template <int TYPE> struct MT;
+
+// ---------------------------------------------------------------- Q4_K: row = qa[U][16] | qb[U][16] | hdr[nb][16] ------------
+template <> struct MT<PM_Q4_K> {
+    static constexpr int QA = 0, QB = 32 * PITCH, HD = 64 * PITCH, WAVE_LDS = 64 * PITCH + 32 * PITCH_H;
+    struct B { u32x4 qa[4], qb[4], h; };
+    struct A { u32x4 q[8]; f16x8 bs; };
+    static __device__ __forceinline__ void issue_b(B & b, const Rows & rw, int nb, int pr, int lane) {
+        const uint32_t u = (uint32_t) min(8 * pr + (lane & 7), 4 * nb - 1), sb = (uint32_t) min(2 * pr + (lane & 1), nb - 1);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            b.qa[n] = ld_nt16(rw.base + (rw.off(n) + u * 16u));
+            b.qb[n] = ld_nt16(rw.base + (rw.off(n) + (uint32_t) nb * 64u + u * 16u));
+        }
+        b.h = ld_nt16(rw.base + (rw.off_h() + (uint32_t) nb * 128u + sb * 16u));
+    }
+    static __device__ __forceinline__ void stash(const B & b, uint8_t * L, int lane) {
+        const int rr = lane >> 3, c = lane & 7;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            *(u32x4 *) (L + QA + (rr + 8 * n) * PITCH + c * 16) = b.qa[n];
+            *(u32x4 *) (L + QB + (rr + 8 * n) * PITCH + c * 16) = b.qb[n];
+        }
+        *(u32x4 *) (L + HD + (lane >> 1) * PITCH_H + (lane & 1) * 16) = b.h;
+    }
+    // sub-block s (32 weights) = the 16 bytes at 32 s + 16 g of the super-block
+    static __device__ __forceinline__ void issue_a(A & a, const uint8_t * xa /*token row + 16 g*/, const uint8_t * bs_lane, int sb) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) a.q[s] = ld_c16(xa + sb * 256 + 32 * s);
+        a.bs = *(const PM_G f16x8 *) (bs_lane + (size_t) sb * 1024);
+    }
+    template <bool HALF>
+    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out) {
+        constexpr int NV = HALF ? 8 : 16;
+        const u32x4 hd = *(const u32x4 *) (L + HD + r * PITCH_H + sbi * 16);
+        const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        i32x16 isum = zero;
+        f16x8 bm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 w = *(const u32x4 *) (L + (g ? QB : QA) + r * PITCH + (4 * sbi + j) * 16);
+            int sc0, sc1, m0, m1;
+            k4_scale_min_pair(hd[1], hd[2], hd[3], j, sc0, sc1, m0, m1);
+            const u32x4 alo = a.q[2 * j], ahi = a.q[2 * j + 1];
+            i32x16 acc = mfma_i8x32(alo, w & 0x0F0F0F0Fu, zero);                          // one 32-k MFMA = one 32-weight sub-block
+#pragma unroll
+            for (int v = 0; v < NV; ++v) isum[v] += __mul24(sc0, acc[v]);               // |acc| <= 32*15*127, scales <= 63
+            acc = mfma_i8x32(ahi, (w >> 4) & 0x0F0F0F0Fu, zero);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) isum[v] += __mul24(sc1, acc[v]);
+            bm[2 * j] = (_Float16) (float) m0; bm[2 * j + 1] = (_Float16) (float) m1;
+        }
+        const f32x16 fz = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const f32x16 ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.bs, bm, fz, 0, 0, 0);   // sum_s min_s * (bsum[2s] + bsum[2s+1]), exact
+        const float d = h2f((uint16_t) (hd[0] & 0xFFFF)), dmin = h2f((uint16_t) (hd[0] >> 16));
+#pragma unroll
+        for (int q = 0; q < NV / 4; ++q) {
+            const f32x4 yd = *(const f32x4 *) (yd_lds + 8 * q + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = 4 * q + i;
+                out[v] = fmaf(yd[i] * d, (float) isum[v], fmaf(-(yd[i] * dmin), ms[v], out[v]));
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------- Q6_K: row = la[U][16] | lb[U][16] | qh[U][16] | scales[nb][16] | d[nb] ------
+template <> struct MT<PM_Q6_K> {
+    static constexpr int LA = 0, LB = 32 * PITCH, QH = 64 * PITCH, SC = 96 * PITCH, DD = SC + 32 * PITCH_H, WAVE_LDS = DD + 128;
+    struct B { u32x4 la[4], lb[4], qh[4], s; uint16_t d; };
+    struct A { u32x2 q[16]; f16x8 bs; };
+    static __device__ __forceinline__ void issue_b(B & b, const Rows & rw, int nb, int pr, int lane) {
+        const uint32_t u = (uint32_t) min(8 * pr + (lane & 7), 4 * nb - 1), sb = (uint32_t) min(2 * pr + (lane & 1), nb - 1);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            b.la[n] = ld_nt16(rw.base + (rw.off(n) + u * 16u));
+            b.lb[n] = ld_nt16(rw.base + (rw.off(n) + (uint32_t) nb * 64u + u * 16u));
+            b.qh[n] = ld_nt16(rw.base + (rw.off(n) + (uint32_t) nb * 128u + u * 16u));
+        }
+        b.s = ld_nt16(rw.base + (rw.off_h() + (uint32_t) nb * 192u + sb * 16u));
+        // (d: one 2-byte load per lane (row lane % 32, super-block 2 pr + lane / 32), issued by the kernel with its own row offset)
+    }
+    static __device__ __forceinline__ void stash(const B & b, uint8_t * L, int lane) {
+        const int rr = lane >> 3, c = lane & 7;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            *(u32x4 *) (L + LA + (rr + 8 * n) * PITCH + c * 16) = b.la[n];
+            *(u32x4 *) (L + LB + (rr + 8 * n) * PITCH + c * 16) = b.lb[n];
+            *(u32x4 *) (L + QH + (rr + 8 * n) * PITCH + c * 16) = b.qh[n];
+        }
+        *(u32x4 *) (L + SC + (lane >> 1) * PITCH_H + (lane & 1) * 16) = b.s;
+        *(uint16_t *) (L + DD + lane * 2) = b.d;                     // [c = lane / 32][r = lane % 32]
+    }
+    // 16-weight group G = the 8 bytes at 16 G + 8 g of the super-block
+    static __device__ __forceinline__ void issue_a(A & a, const uint8_t * xa /*token row + 8 g*/, const uint8_t * bs_lane, int sb) {
+#pragma unroll
+        for (int G = 0; G < 16; ++G) a.q[G] = ld_c8(xa + sb * 256 + 16 * G);
+        a.bs = *(const PM_G f16x8 *) (bs_lane + (size_t) sb * 1024);
+    }
+    template <bool HALF>
+    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out) {
+        constexpr int NV = HALF ? 8 : 16;
+        const u32x4 s16 = *(const u32x4 *) (L + SC + r * PITCH_H + sbi * 16);
+        const float d = h2f(*(const uint16_t *) (L + DD + (sbi * 32 + r) * 2));
+        const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        i32x16 isum = zero;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int v2 = 0; v2 < 2; ++v2) {
+                const int uo = (4 * sbi + 2 * hh + v2) * 16 + 8 * g;
+                const u32x2 la = *(const u32x2 *) (L + LA + r * PITCH + uo), lb = *(const u32x2 *) (L + LB + r * PITCH + uo),
+                            qh = *(const u32x2 *) (L + QH + r * PITCH + uo);
+                u32x2 qv[4];
+                qv[0] = (la & 0x0F0F0F0Fu)        | ((qh << 4) & 0x30303030u);
+                qv[1] = (lb & 0x0F0F0F0Fu)        | ((qh << 2) & 0x30303030u);
+                qv[2] = ((la >> 4) & 0x0F0F0F0Fu) | (qh & 0x30303030u);
+                qv[3] = ((lb >> 4) & 0x0F0F0F0Fu) | ((qh >> 2) & 0x30303030u);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int G = 8 * hh + 2 * c + v2;                                   // group index inside the super-block = scale index
+                    const int sc = (int) (int8_t) (s16[G >> 2] >> (8 * (G & 3)));
+                    const i32x16 acc = mfma_i8(pk(a.q[G][0], a.q[G][1]), pk(qv[c][0], qv[c][1]), zero);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) isum[v] += __mul24(sc, acc[v]);         // |acc| <= 16*63*127
+                }
+            }
+        // sum_G scale_G * bsum_G (the -32 offset of every weight): B slot s of lane group g = scale[2 s + g]
+        f16x8 bm;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { const int G = 2 * s + g; bm[s] = (_Float16) (float) (int) (int8_t) (s16[G >> 2] >> (8 * (G & 3))); }
+        const f32x16 fz = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const f32x16 ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.bs, bm, fz, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NV / 4; ++q) {
+            const f32x4 yd = *(const f32x4 *) (yd_lds + 8 * q + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = 4 * q + i;
+                out[v] = fmaf(yd[i] * d, (float) (isum[v] - 32 * (int) ms[v]), out[v]);   // the reference's integer sum, then one rounding
+            }
+        }
+    }
+};
+
+template <int TYPE, bool HALF>
+__global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
+    typedef MT<TYPE> M;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nsb = p.K / 256, npairs = (nsb + 1) >> 1;
+    float * dTl = (float *) smem;                                 // activation scales [nsb + 1][32] (0 for token slots >= T; last row all 0)
+    uint8_t * stage = smem + (size_t) (nsb + 1) * 128;            // NWAVE x WAVE_LDS; afterwards the 32 KB reduction buffer
+    for (int i = tid; i < nsb * 8; i += BLOCK) ((f32x4 *) dTl)[i] = *((const PM_G f32x4 *) p.dT + i);
+    if (tid < 32) dTl[nsb * 32 + tid] = 0.0f;
+    const int G = (int) gridDim.x, w = (int) blockIdx.x;
+    const int r0 = (int) ((long) p.N * w / G), r1 = (int) ((long) p.N * (w + 1) / G);
+    const int nrg = (r1 - r0 + 31) >> 5;
+    const int RGB = 1 << p.rgb_log2, KS = NWAVE >> p.rgb_log2;
+    const int rgi = wave & (RGB - 1), ks = wave >> p.rgb_log2;
+    const int pb = npairs * ks / KS, pe = npairs * (ks + 1) / KS;
+    uint8_t * L = stage + wave * M::WAVE_LDS;
+    const int r = lane & 31, g = lane >> 5;
+    const uint8_t * xa = p.xq + (long) min(r, p.T - 1) * p.xq_stride + (TYPE == PM_Q4_K ? 16 : 8) * g;
+    const uint8_t * bs_lane = p.bsT + lane * 16;
+    __syncthreads();
+    for (int rg0 = 0; rg0 < nrg; rg0 += RGB) {
+        const int rg = rg0 + rgi;
+        f32x16 out = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (rg < nrg && pb < pe) {
+            const int rbase = r0 + 32 * rg;
+            Rows rw;
+            rw.base = p.W + (long) rbase * p.row_stride;
+            rw.stride = (uint32_t) p.row_stride; rw.lim = r1 - 1 - rbase; rw.rr = lane >> 3; rw.rh = lane >> 1;
+            const uint32_t off_d = (uint32_t) min(r, rw.lim) * rw.stride + (uint32_t) nsb * 208u;
+            typename M::B R;
+            typename M::A A0, A1;
+            auto issue_b = [&](int pr) __attribute__((always_inline)) {
+                M::issue_b(R, rw, nsb, pr, lane);
+                if constexpr (TYPE == PM_Q6_K) R.d = ld_nt2(rw.base + (off_d + (uint32_t) min(2 * pr + g, nsb - 1) * 2u));
+            };
+            issue_b(pb);
+            M::issue_a(A0, xa, bs_lane, 2 * pb);
+            for (int pr = pb; pr < pe; ++pr) {
+                M::stash(R, L, lane);                                  // waits for this step's weights only
+                const int sb0 = 2 * pr, sb1 = min(2 * pr + 1, nsb - 1);
+                // Issue order is the design (VMEM returns in order): the compiler's schedulers must not sink the prefetches towards
+                // their uses - no conditional code in the step (an odd tail super-block is computed on clamped data with the all-zero
+                // scale row) and scheduling barriers around the issue points.
+                M::issue_a(A1, xa, bs_lane, sb1);
+                issue_b(min(pr + 1, pe - 1));                          // unconditional (clamped): in flight during the whole step
+                __builtin_amdgcn_sched_barrier(0);
+                M::template compute<HALF>(A0, L, 0, r, g, dTl + sb0 * 32, out);
+                __builtin_amdgcn_sched_barrier(0);
+                M::issue_a(A0, xa, bs_lane, min(2 * pr + 2, nsb - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                M::template compute<HALF>(A1, L, 1, r, g, dTl + (2 * pr + 1 < nsb ? sb1 : nsb) * 32, out);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // fixed-order sum of the K slices through LDS, epilogue, store
+        __syncthreads();
+        float * red = (float *) stage;
+        constexpr int NV = HALF ? 8 : 16;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) red[(wave * 16 + v) * 64 + lane] = out[v];
+        __syncthreads();
+        for (int o = tid; o < RGB * 1024; o += BLOCK) {
+            const int gi = o >> 10, v = (o >> 6) & 15, l = o & 63;
+            if (HALF && v >= 8) continue;
+            float s = 0.0f;
+            for (int k = 0; k < KS; ++k) s += red[(((k << p.rgb_log2) + gi) * 16 + v) * 64 + l];
+            const int t = 8 * (v >> 2) + 4 * (l >> 5) + (v & 3), row = r0 + 32 * (rg0 + gi) + (l & 31);
+            if (t < p.T && row < r1) {
+                if (p.bias)  s += ld_g(p.bias + row);
+                if (p.resid) s += ld_g(p.resid + (long) t * p.y_stride + row);
+                st_g(p.y + (long) t * p.y_stride + row, s);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// prologue: per super-block, the activation group sums as F16 in A-operand order and the transposed activation scales
+__global__ __launch_bounds__(64) void mmq_prep_kernel(const uint8_t * xq, long xq_stride, int K, int T, uint8_t * bsT, float * dT) {
+    const int sb = (int) blockIdx.x, l = (int) threadIdx.x, t = l & 31, g = l >> 5;
+    const uint8_t * row = xq + (long) min(t, T - 1) * xq_stride;
+    const int16_t * bsums = (const int16_t *) (row + K + (K / 256) * 4);
+    f16x8 h;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) h[s] = t < T ? (_Float16) (float) (int) bsums[sb * 16 + 2 * s + g] : (_Float16) 0.0f;
+    *(f16x8 *) (bsT + ((size_t) sb * 64 + l) * 16) = h;
+    if (g == 0) dT[sb * 32 + t] = t < T ? ((const float *) (row + K))[sb] : 0.0f;
+}
+
+// per-device scratch (grown on demand, like mmq.hip's f16 activation copy): quantized activations of an f32 call + the two tables
+uint8_t * g_scr[16] = {};
+size_t g_scr_bytes[16] = {};
+
+}  // namespace
+
+size_t pm_mmq_i8_lds_bytes(int type, int K) {
+    const size_t w = type == PM_Q4_K ? MT<PM_Q4_K>::WAVE_LDS : MT<PM_Q6_K>::WAVE_LDS;
+    return (size_t) (K / 256 + 1) * 128 + NWAVE * w;
+}
+
+// 0 when pm_launch_mmq_i8 serves this shape
+int pm_mmq_i8_check(int type, int K, int N, int T) {
+    if (type != PM_Q4_K && type != PM_Q6_K) return -1;
+    if (T < 1 || T > 32 || K % 256 || K < 512 || N < 1) return -2;
+    if (pm_mmq_i8_lds_bytes(type, K) > 150 * 1024) return -4;
+    return 0;
+}
+
+// Y[t][n] = W[n,:] . x[t,:] (+bias[n]) (+resid[t][n]) for 1 <= T <= 32 tokens. xq: activations already in the library's row-SoA Q8_K
+// form (quantize.hip), or null and x_f32 [T][K] is quantized first. Y / resid token stride = N.
+// Tokens per launch: 32 for Q6_K; 16 for Q4_K (its 32-token instantiation needs 8 live 16-register MFMA tiles on top of the prefetch
+// registers and spills 420 B / lane - two 16-token passes are faster).
+// reuse_prep != 0: the previous pm_launch_mmq_i8 on this device and stream had the SAME activations (xq / x_f32 contents, T, K): its
+// quantized copy and tables are still valid, skip the prologue launches (q/k/v and gate/up share one activation set).
+int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_f32, float * Y, int K, int N, int T,
+                     const float * bias, const float * resid, int reuse_prep, hipStream_t st) {
+    const int rc = pm_mmq_i8_check(type, K, N, T);
+    if (rc) return rc;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
+    const int nsb = K / 256;
+    const size_t xrow = pm_q8k_row_bytes(K), tab = (size_t) nsb * (1024 + 128);
+    const size_t need = 2 * tab + (xq ? 0 : ((size_t) T * xrow + 255) / 256 * 256);
+    if (need > g_scr_bytes[dev]) {
+        if (reuse_prep) return -3;                                 // (cannot happen: the previous call sized the scratch for this K)
+        if (g_scr[dev]) { (void) hipDeviceSynchronize(); (void) hipFree(g_scr[dev]); }
+        const size_t cap = 2 * tab + (size_t) 32 * xrow + 256;     // any later call with this K fits
+        if (hipMalloc((void **) &g_scr[dev], cap) != hipSuccess) { g_scr[dev] = nullptr; g_scr_bytes[dev] = 0; return -3; }
+        g_scr_bytes[dev] = cap;
+    }
+    if (!xq) {
+        uint8_t * q = g_scr[dev] + 2 * tab;
+        if (!reuse_prep) pm_launch_quantize_q8k(x_f32, q, K, T, st);
+        xq = q;
+    }
+    const int cus = pm_device_cus();
+    const int grid = N / 32 >= cus ? cus : (N + 31) / 32;
+    const int rows = (N + grid - 1) / grid, nrg = (rows + 31) / 32;
+    const size_t lds = pm_mmq_i8_lds_bytes(type, K);
+    const int tmax = type == PM_Q4_K ? 16 : 32;
+    for (int t0 = 0, c = 0; t0 < T; t0 += tmax, ++c) {
+        const int tn = T - t0 < tmax ? T - t0 : tmax;
+        uint8_t * bsT = g_scr[dev] + c * tab; float * dT = (float *) (bsT + (size_t) nsb * 1024);
+        const uint8_t * xc = (const uint8_t *) xq + (size_t) t0 * xrow;
+        if (!reuse_prep) hipLaunchKernelGGL(mmq_prep_kernel, dim3(nsb), dim3(64), 0, st, xc, (long) xrow, K, tn, bsT, dT);
+        MmqP p = {};
+        p.W = (const uint8_t *) W; p.row_stride = (long) pm_weight_row_stride(type, K); p.N = N; p.K = K; p.T = tn;
+        p.xq = xc; p.xq_stride = (long) xrow; p.bsT = bsT; p.dT = dT;
+        p.y = Y + (size_t) t0 * N; p.y_stride = N; p.bias = bias; p.resid = resid ? resid + (size_t) t0 * N : nullptr;
+        p.rgb_log2 = nrg >= 8 ? 3 : nrg >= 3 ? 2 : nrg == 2 ? 1 : 0;
+        auto go = [&](auto kern) {
+            static bool attr[16] = {};
+            if (!attr[dev]) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr[dev] = true; }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, st, p);
+        };
+        if (type == PM_Q4_K) go(mmq_i8_kernel<PM_Q4_K, true>);
+        else if (tn <= 16)   go(mmq_i8_kernel<PM_Q6_K, true>);
+        else                 go(mmq_i8_kernel<PM_Q6_K, false>);
+    }
+    return 0;
+}

@@ -37,15 +37,6 @@ __global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(GemvP p) {
     gemv_body<TA, TB, PAIR, DBG, false>(p, smem, nred, GridBar{nullptr, nullptr, 0, 1, 1});
 }
 
-// NC activation columns per launch (2 or 4 tokens: speculative / short batches): the weights are streamed ONCE, every
-// decoded unit is dotted with NC activation slices from LDS. Single quant type, no pair, pre-quantized activations.
-template <int T, int NC>
-__global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_cols_kernel(GemvP p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ double nred[PM_GEMV_NW];
-    gemv_body<T, T, false, false, false, NC>(p, smem, nred, GridBar{nullptr, nullptr, 0, 1, 1});
-}
-
 template <int TA, int TB>
 int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, hipStream_t st) {
     const GemvP & p = p_in;
@@ -170,19 +161,7 @@ int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st) {
     return -1;
 }
 
-// Single-matrix entry (ncols pre-quantized activation columns, one launch per column).
-// one launch for nc (2 or 4) pre-quantized activation columns; -1 when this shape has no multi-column kernel
-template <int T>
-static int launch_cols(GemvP & p, int nc, int grid, size_t lds, hipStream_t st) {
-    auto go = [&](auto kern) {
-        (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(PM_GEMV_BLOCK), lds, st, p);
-    };
-    if (nc == 4) go(gemv_q_cols_kernel<T, 4>); else if (nc == 2) go(gemv_q_cols_kernel<T, 2>); else return -1;
-    return 0;
-}
-
-// Single-matrix entry with ncols pre-quantized activation columns: groups of 4 / 2 columns share one pass over the
+// Single-matrix entry with ncols pre-quantized activation columns: groups of 8 / 4 / 2 columns share one pass over the
 // weights (gemv_q_cols_kernel), a remaining single column - and pair / debug launches - go one launch per column.
 int pm_launch_gemv(const pm_gemv_args & a, hipStream_t st) {
     const size_t xrow = a.type == PM_Q8_0 ? pm_q80_row_bytes(a.K) : pm_q8k_row_bytes(a.K);
@@ -194,7 +173,7 @@ int pm_launch_gemv(const pm_gemv_args & a, hipStream_t st) {
         f.job[0].y = a.y + (size_t) c * a.y_stride; f.job[0].bias = a.bias;
         f.job[0].resid = a.resid ? a.resid + (size_t) c * a.y_stride : nullptr;
         const int left = a.ncols - c;
-        int nc = (a.W2 || a.dbg_int || left < 2) ? 1 : (left >= 4 ? 4 : 2);     // (8 columns per launch spill under the 128-VGPR budget)
+        int nc = (a.W2 || a.dbg_int || left < 2) ? 1 : (left >= 8 && a.type != PM_Q5_K ? 8 : left >= 4 ? 4 : 2);   // (8 Q5_K columns spill even at 256 VGPRs)
         if (nc > 1) {
             GemvP p; int ta, tb, grid; bool pair; size_t lds1;
             int rc = gemv_fill(f, 0, p, ta, tb, pair, lds1, grid);
@@ -207,12 +186,7 @@ int pm_launch_gemv(const pm_gemv_args & a, hipStream_t st) {
             if (nc > 1) {
                 p.ncols = nc; p.xq_stride = (long) xrow; p.y_stride = (long) a.y_stride;
                 const size_t lds = nc * col + rows * nc * 4;
-                switch (ta) {
-                    case PM_Q4_K: rc = launch_cols<PM_Q4_K>(p, nc, grid, lds, st); break;
-                    case PM_Q5_K: rc = launch_cols<PM_Q5_K>(p, nc, grid, lds, st); break;
-                    case PM_Q6_K: rc = launch_cols<PM_Q6_K>(p, nc, grid, lds, st); break;
-                    default:      rc = launch_cols<PM_Q8_0>(p, nc, grid, lds, st); break;
-                }
+                rc = pm_launch_gemv_cols(ta, p, nc, grid, lds, st);      // mmvq_cols.hip (512-thread workgroups, 256-VGPR budget)
                 if (rc) return rc;
                 c += nc;
                 continue;

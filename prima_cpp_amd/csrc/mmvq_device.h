@@ -704,3 +704,6 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
 int gemv_fill(const pm_gemv_fused & a, int grid_fixed, GemvP & p, int & ta, int & tb, bool & pair, size_t & lds, int & grid);
 
 } // namespace pmv
+
+// multi-column launch (mmvq_cols.hip): nc = 2 / 4 / 8 activation columns per pass over the weights
+int pm_launch_gemv_cols(int type, const pmv::GemvP & p, int nc, int grid, size_t lds, hipStream_t st);

@@ -83,3 +83,9 @@ int  pm_launch_attn_wo(const float * q, const float * k, const float * v, void *
                        const pm_rope_cfg & c, const pm_gemv_fused & f, void * ctr, hipStream_t st);
 size_t pm_attn_wo_bar_bytes();
 void pm_launch_barrier_probe(int n, void * ctr, hipStream_t st);       // measurement: n device-wide barriers in one launch
+
+// small-batch (1..32 tokens) quantized mat-mul on the integer matrix cores (mmq_i8.hip): Q4_K / Q6_K weights, Q8_K activations
+// (xq row-SoA, or x_f32 quantized first into a per-device scratch). 0, or -1 type / -2 shape / -3 device / -4 LDS
+int pm_mmq_i8_check(int type, int K, int N, int T);
+int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_f32, float * Y, int K, int N, int T,
+                     const float * bias, const float * resid, int reuse_prep, hipStream_t st);

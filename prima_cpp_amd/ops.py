@@ -237,6 +237,21 @@ def mul_mat_vec_fused(ws, x, norm_w=None, eps=0.0, w2s=None, biases=None, resids
     return ys
 
 
+def mul_mat_small(w, x=None, xq=None, n_tokens=None, bias=None, resid=None):
+    """1..32 tokens on the integer matrix cores (mmq_i8.hip): x f32 [T, K] (quantized to Q8_K on device) or pre-quantized xq -> f32 [T, N]."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_mul_mat_q_small.restype = C.c_int
+    lib.pm355_mul_mat_q_small.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    if xq is None:
+        x = x.contiguous().view(-1, w.K)
+        n_tokens = x.shape[0]
+    y = torch.empty((n_tokens, w.N), dtype=torch.float32, device=w.data.device)
+    check(lib.pm355_mul_mat_q_small(w.type, ptr(w.data), w.K, w.N, ptr(xq), ptr(x) if xq is None else None, n_tokens, ptr(y), ptr(bias), ptr(resid),
+                                    stream_ptr()), "mul_mat_q_small")
+    return y
+
+
 def mul_mat_mfma(w, x, bias=None, resid=None):
     """Batched GEMM on MFMA: x f32 [T, K] -> f32 [T, N]."""
     import ctypes as C

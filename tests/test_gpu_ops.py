@@ -168,7 +168,7 @@ def test_gemv_integer_partials_bitexact_and_float_close(P, oracle, t, K, N):
         assert abs(y[r] - want) <= 4e-6 * mag + 1e-30, (TYPE_NAMES[t], K, r, y[r], want)
 
 
-@pytest.mark.parametrize("C", [3, 4, 7])          # 2+1, 4, 4+2+1 columns per launch group (gemv_q_cols_kernel)
+@pytest.mark.parametrize("C", [3, 4, 7, 8])       # 2+1, 4, 4+2+1, 8 columns per launch group (mmvq_cols.hip)
 @pytest.mark.parametrize("t", QUANT_TYPES)
 def test_gemv_epilogues_and_columns(P, oracle, t, C):
     rng = np.random.default_rng(25)
@@ -187,6 +187,33 @@ def test_gemv_epilogues_and_columns(P, oracle, t, C):
     assert np.allclose(y, want1 + bias[None] + resid, **tol)
     y = P.mul_mat_vec(w1, x=_dev(P, x), w2=w2).cpu().numpy()
     assert np.allclose(y, oracle.silu_mul(want1, want2), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("T", [1, 2, 5, 8, 16, 17, 32])
+@pytest.mark.parametrize("t", [Q4_K, Q6_K])
+def test_small_batch_matmul_on_integer_matrix_cores(P, oracle, t, T):
+    """mmq_i8.hip: same integer block sums as the mat-vec (vec_dot_q4_K_q8_K / vec_dot_q6_K_q8_K), f32 super-block terms added in a
+    different order -> oracle.mul_mat within the mat-vec's tolerance. Shapes: ragged row slices (N = 70: clamped rows), several row
+    groups per workgroup (N = 600 on <= 256 workgroups is 1 group; N = 20000 gives 3), odd super-block count (K = 768)."""
+    rng = np.random.default_rng(100 * t + T)
+    for K, N in ((4096, 70), (768, 600), (1024, 20000)):
+        if N == 20000 and T not in (5, 32): continue
+        b = rand_blocks(t, N, K, rng)
+        x = rng.normal(0, 1, (T, K)).astype(np.float32)
+        bias = rng.normal(0, 1, N).astype(np.float32)
+        resid = rng.normal(0, 1, (T, N)).astype(np.float32)
+        w = P.upload_weight(t, b, K, N)
+        want = oracle.mul_mat(t, b, K, N, x)
+        tol = dict(rtol=2e-5, atol=2e-5 * np.sqrt(K / 4096))
+        y = P.mul_mat_small(w, x=_dev(P, x)).cpu().numpy()
+        assert np.allclose(y, want, **tol), (K, N, np.abs(y - want).max())
+        xq = P.quantize_act(_dev(P, x), P.vec_dot_act_type(t))
+        y2 = P.mul_mat_small(w, xq=xq, n_tokens=T, bias=_dev(P, bias), resid=_dev(P, resid)).cpu().numpy()
+        assert np.allclose(y2, want + bias[None] + resid, **tol)
+        # against the mat-vec itself: identical integers, f32 sums of <= K/256 terms in another order
+        if T <= 8:
+            y1 = P.mul_mat_vec(w, xq=xq, ncols=T).cpu().numpy()
+            assert np.allclose(y, y1, rtol=1e-5, atol=1e-5)
 
 
 def test_rms_norm_matches_oracle(P, oracle):
