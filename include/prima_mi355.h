@@ -148,7 +148,7 @@ PM355_API int pm355_mul_mat_vec_fused_check(const pm355_matvec_job * jobs, int n
  * in for the reference CUDA plug-in's mul_mat_q / dequantize+cuBLAS large-batch path (ggml-cuda/mmq.cuh:2583). */
 PM355_API int pm355_mul_mat_q_mfma(int type, const void * W, int64_t K, int64_t N, const float * x, int64_t n_tokens, float * y,
                                    const float * bias, const float * resid, pm355_stream_t stream);
-/* Small batches, 1 <= n_tokens <= 32 (speculative decoding, parallel sequences, prompt tails): the weights are streamed ONCE for all
+/* Small batches, 1 <= n_tokens <= 64 (speculative decoding, parallel sequences, short prompts): the weights are streamed ONCE per 32
  * tokens and the products run on the integer matrix cores (v_mfma_i32_32x32x16_i8, prima_cpp_amd/csrc/mmq_i8.hip) with the
  * reference's own integer arithmetic - activations quantized to Q8_K, exact int32 block sums, one f32 multiply-add per 256-weight
  * super-block (ggml_vec_dot_q4_K_q8_K / ggml_vec_dot_q6_K_q8_K, ggml/src/ggml-quants.c; CUDA plug-in: ggml-cuda/mmq.cuh:2583).

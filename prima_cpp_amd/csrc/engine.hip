@@ -44,7 +44,7 @@ struct pm355_model {
     int32_t * d_pos = nullptr, * d_tok = nullptr, * d_ctl = nullptr;   // d_pos[n_seq]; d_ctl = {current seq, n_seq}
     int n_seq = 1;
     bool no_fuse = false;                 // PM355_NO_FUSE=1: node-by-node kernels (debug / A-B)
-    bool no_mmq = false;                  // PM355_NO_MMQ_I8=1: 4..32-token batches on the round-1 paths (mat-vec columns, F16 GEMM from 16 tokens)
+    bool no_mmq = false;                  // PM355_NO_MMQ_I8=1: 4..64-token batches on the round-1 paths (mat-vec columns, F16 GEMM from 16 tokens)
     // EXPERIMENT (PM355_ATTN_WO=1, attn_wo.hip): attention + wo as ONE two-phase launch per layer - every workgroup first puts its wo
     // weight loads in flight, the 64 head workgroups run the latency-bound attention meanwhile, one device-wide barrier, then the wo
     // mat-vec: 4 launches per layer instead of 5. Bit-identical, but the barrier + first-touch fetch of the heads' outputs costs what
@@ -262,10 +262,10 @@ int gemv(const Tensor & w, const Tensor * w2, const ActQ & a, int T, float * y, 
     return pm_launch_gemv(g, st);
 }
 
-// 4..32 tokens: one pass over the weights on the integer matrix cores (mmq_i8.hip) where the type / shape is served, else the mat-vec
+// 4..64 tokens: one pass over the weights per 32 tokens on the integer matrix cores (mmq_i8.hip) where the type / shape is served, else the mat-vec
 // (one to three passes per 8 columns). `prepped`: the kernel's activation tables already describe THIS activation set (set by the first
 // served call, cleared by the caller whenever the activations change)
-const int MMQ_MIN_TOKENS = 4, MMQ_MAX_TOKENS = 32;
+const int MMQ_MIN_TOKENS = 4, MMQ_MAX_TOKENS = 64;
 int matmul_small(pm355_model * m, const Tensor & w, const ActQ & a, int T, float * y, const float * bias, const float * resid, bool & prepped, hipStream_t st) {
     if (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && a.k && pm_mmq_i8_check(w.type, (int) w.K, (int) w.N, T) == 0) {
         const int rc = pm_launch_mmq_i8(w.type, w.d, a.k, nullptr, y, (int) w.K, (int) w.N, T, bias, resid, prepped ? 1 : 0, st);
@@ -411,9 +411,12 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
     for (int il = m->lo; il < m->hi; ++il) {
         Layer Lv = layer_acquire(m, il, st); Layer & L = Lv;
         const Tensor * qkv[3] = {&L.t[PM355_T_WQ], &L.t[PM355_T_WK], &L.t[PM355_T_WV]};
-        // 16..32 tokens take the small-batch path below unless its per-token attention kernel cannot hold n_ctx scores in LDS
+        // 16..64 tokens take the small-batch path below unless its per-token attention kernel cannot hold n_ctx scores in LDS
         const bool small_attn_ok = (size_t) (dh + hp.n_ctx) * 4 <= 150 * 1024;
-        if (T > ((m->no_mmq || !small_attn_ok) ? 15 : MMQ_MAX_TOKENS) && !m->no_fuse) {
+        bool small_ok = !m->no_mmq && small_attn_ok;              // ... and unless one of the layer's large matrices has a type mmq_i8.hip does not serve
+        for (int k : {PM355_T_WQ, PM355_T_WO, PM355_T_FFN_GATE, PM355_T_FFN_UP, PM355_T_FFN_DOWN})
+            small_ok = small_ok && pm_mmq_i8_check(L.t[k].type, (int) L.t[k].K, (int) L.t[k].N, T < 1 ? 1 : (T > MMQ_MAX_TOKENS ? MMQ_MAX_TOKENS : T)) == 0;
+        if (T > (small_ok ? MMQ_MAX_TOKENS : 15) && !m->no_fuse) {
             // ---- prefill: batched GEMMs on the MFMA matrix cores (mmq.hip), f32 activations
             // F16 plumbing: the producers of GEMM activations write them as F16 (the rounding the GEMM's own conversion pass would apply) into
             // the engine's scratch - xn / att in place of their f32 forms, h = silu(gate) * up into h2: no conversion launches, half the bytes
@@ -529,7 +532,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     m->rope.ext_factor = 0.0f; m->rope.attn_factor = 1.0f; m->rope.beta_fast = 32.0f; m->rope.beta_slow = 1.0f;
     pm_rope_params(m->rope);
     { const char * e = getenv("PM355_NO_FUSE"); m->no_fuse = e && e[0] == '1'; }
-    { const char * e = getenv("PM355_NO_MMQ_I8"); m->no_mmq = e && e[0] == '1'; }     // 2..32-token batches: mat-vec columns / F16 GEMM from 16 (the round-1 paths)
+    { const char * e = getenv("PM355_NO_MMQ_I8"); m->no_mmq = e && e[0] == '1'; }     // 4..64-token batches: mat-vec columns / F16 GEMM from 16 (the round-1 paths)
     { const char * e = getenv("PM355_ATTN_WO"); m->attn_wo = e && e[0] == '1'; }       // measured: 8.74 vs 8.60 ms per 70B token -> opt-in experiment
     return m;
 }

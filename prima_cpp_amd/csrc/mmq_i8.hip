@@ -1,4 +1,4 @@
-// mmq_i8.hip — small-batch (2..32 tokens) quantized mat-mul on the INTEGER matrix cores (v_mfma_i32_32x32x16_i8).
+// mmq_i8.hip — small-batch (up to 32 tokens per pass, 64 per call) quantized mat-mul on the INTEGER matrix cores (v_mfma_i32_32x32x16_i8).
 //
 // What it replaces: for 2..32 activation rows the reference runs ggml_compute_forward_mul_mat's vec_dot loop once per (row, token)
 // (ggml/src/ggml.c ggml_compute_forward_mul_mat -> ggml_vec_dot_q4_K_q8_K / ggml_vec_dot_q6_K_q8_K, ggml-quants.c), its CUDA plug-in
@@ -90,31 +90,34 @@ template <> struct MT<PM_Q4_K> {
         *(u32x4 *) (L + HD + (lane >> 1) * PITCH_H + (lane & 1) * 16) = b.h;
     }
     // sub-block s (32 weights) = the 16 bytes at 32 s + 16 g of the super-block
-    static __device__ __forceinline__ void issue_a(A & a, const uint8_t * xa /*token row + 16 g*/, const uint8_t * bs_lane, int sb) {
+    static __device__ __forceinline__ void issue_a(A & a, const uint8_t * xa /*token row + 16 g*/, const uint8_t * bs_lane, int sb, bool act) {
+        if (act) {                                   // exec-masked: the texture path is paid per ACTIVE lane (tools/small_batch_probe.py ablation)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) a.q[s] = ld_c16(xa + sb * 256 + 32 * s);
-        a.bs = *(const PM_G f16x8 *) (bs_lane + (size_t) sb * 1024);
+            for (int s = 0; s < 8; ++s) a.q[s] = ld_c16(xa + sb * 256 + 32 * s);
+            a.bs = *(const PM_G f16x8 *) (bs_lane + (size_t) sb * 1024);
+        }
     }
-    template <bool HALF>
+    template <int NV>
     static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out) {
-        constexpr int NV = HALF ? 8 : 16;
         const u32x4 hd = *(const u32x4 *) (L + HD + r * PITCH_H + sbi * 16);
         const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         i32x16 isum = zero;
+        // the 8 six-bit scales / mins of the super-block, four per dword (get_scale_min_k4, ggml-quants.c:1898-1906, on whole dwords)
+        const uint32_t sc4[2] = {hd[1] & 0x3f3f3f3fu, (hd[3] & 0x0f0f0f0fu) | ((hd[1] >> 2) & 0x30303030u)};
+        const uint32_t mn4[2] = {hd[2] & 0x3f3f3f3fu, ((hd[3] >> 4) & 0x0f0f0f0fu) | ((hd[2] >> 2) & 0x30303030u)};
         f16x8 bm;
+#pragma unroll
+        for (int sb = 0; sb < 8; ++sb) bm[sb] = (_Float16) (float) ((mn4[sb >> 2] >> (8 * (sb & 3))) & 0xFFu);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const u32x4 w = *(const u32x4 *) (L + (g ? QB : QA) + r * PITCH + (4 * sbi + j) * 16);
-            int sc0, sc1, m0, m1;
-            k4_scale_min_pair(hd[1], hd[2], hd[3], j, sc0, sc1, m0, m1);
-            const u32x4 alo = a.q[2 * j], ahi = a.q[2 * j + 1];
-            i32x16 acc = mfma_i8x32(alo, w & 0x0F0F0F0Fu, zero);                          // one 32-k MFMA = one 32-weight sub-block
+            const int sc0 = (int) ((sc4[(2 * j) >> 2] >> (8 * ((2 * j) & 3))) & 0xFFu), sc1 = (int) ((sc4[(2 * j + 1) >> 2] >> (8 * ((2 * j + 1) & 3))) & 0xFFu);
+            i32x16 acc = mfma_i8x32(a.q[2 * j], w & 0x0F0F0F0Fu, zero);                    // one 32-k MFMA = one 32-weight sub-block
 #pragma unroll
-            for (int v = 0; v < NV; ++v) isum[v] += __mul24(sc0, acc[v]);               // |acc| <= 32*15*127, scales <= 63
-            acc = mfma_i8x32(ahi, (w >> 4) & 0x0F0F0F0Fu, zero);
+            for (int v = 0; v < NV; ++v) { isum[v] = __mul24(sc0, acc[v]) + isum[v]; asm volatile("" : "+v"(isum[v])); }   // (keeps it ONE v_mad_i32_i24:
+            acc = mfma_i8x32(a.q[2 * j + 1], (w >> 4) & 0x0F0F0F0Fu, zero);                //  the re-associated mul, mul, add3 form is 1.5 instructions per term)
 #pragma unroll
-            for (int v = 0; v < NV; ++v) isum[v] += __mul24(sc1, acc[v]);
-            bm[2 * j] = (_Float16) (float) m0; bm[2 * j + 1] = (_Float16) (float) m1;
+            for (int v = 0; v < NV; ++v) { isum[v] = __mul24(sc1, acc[v]) + isum[v]; asm volatile("" : "+v"(isum[v])); }
         }
         const f32x16 fz = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const f32x16 ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.bs, bm, fz, 0, 0, 0);   // sum_s min_s * (bsum[2s] + bsum[2s+1]), exact
@@ -159,14 +162,15 @@ template <> struct MT<PM_Q6_K> {
         *(uint16_t *) (L + DD + lane * 2) = b.d;                     // [c = lane / 32][r = lane % 32]
     }
     // 16-weight group G = the 8 bytes at 16 G + 8 g of the super-block
-    static __device__ __forceinline__ void issue_a(A & a, const uint8_t * xa /*token row + 8 g*/, const uint8_t * bs_lane, int sb) {
+    static __device__ __forceinline__ void issue_a(A & a, const uint8_t * xa /*token row + 8 g*/, const uint8_t * bs_lane, int sb, bool act) {
+        if (act) {
 #pragma unroll
-        for (int G = 0; G < 16; ++G) a.q[G] = ld_c8(xa + sb * 256 + 16 * G);
-        a.bs = *(const PM_G f16x8 *) (bs_lane + (size_t) sb * 1024);
+            for (int G = 0; G < 16; ++G) a.q[G] = ld_c8(xa + sb * 256 + 16 * G);
+            a.bs = *(const PM_G f16x8 *) (bs_lane + (size_t) sb * 1024);
+        }
     }
-    template <bool HALF>
+    template <int NV>
     static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out) {
-        constexpr int NV = HALF ? 8 : 16;
         const u32x4 s16 = *(const u32x4 *) (L + SC + r * PITCH_H + sbi * 16);
         const float d = h2f(*(const uint16_t *) (L + DD + (sbi * 32 + r) * 2));
         const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -189,7 +193,7 @@ template <> struct MT<PM_Q6_K> {
                     const int sc = (int) (int8_t) (s16[G >> 2] >> (8 * (G & 3)));
                     const i32x16 acc = mfma_i8(pk(a.q[G][0], a.q[G][1]), pk(qv[c][0], qv[c][1]), zero);
 #pragma unroll
-                    for (int v = 0; v < NV; ++v) isum[v] += __mul24(sc, acc[v]);         // |acc| <= 16*63*127
+                    for (int v = 0; v < NV; ++v) { isum[v] = __mul24(sc, acc[v]) + isum[v]; if constexpr (NV < 16) asm volatile("" : "+v"(isum[v])); }   // |acc| <= 16*63*127 (NV = 16: the barrier costs 100 B of spills)
                 }
             }
         // sum_G scale_G * bsum_G (the -32 offset of every weight): B slot s of lane group g = scale[2 s + g]
@@ -210,7 +214,8 @@ template <> struct MT<PM_Q6_K> {
     }
 };
 
-template <int TYPE, bool HALF>
+// ABL (measurement only, PM355_MMQ_ABL): 1 = no activation loads in the loop, 2 = no weight loads in the loop, 4 = no MFMA / VALU work
+template <int TYPE, int NV, int ABL = 0>      // NV result registers per lane in use: 4 (<= 8 tokens), 8 (<= 16), 16 (<= 32)
 __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     typedef MT<TYPE> M;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -218,8 +223,6 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     const int nsb = p.K / 256, npairs = (nsb + 1) >> 1;
     float * dTl = (float *) smem;                                 // activation scales [nsb + 1][32] (0 for token slots >= T; last row all 0)
     uint8_t * stage = smem + (size_t) (nsb + 1) * 128;            // NWAVE x WAVE_LDS; afterwards the 32 KB reduction buffer
-    for (int i = tid; i < nsb * 8; i += BLOCK) ((f32x4 *) dTl)[i] = *((const PM_G f32x4 *) p.dT + i);
-    if (tid < 32) dTl[nsb * 32 + tid] = 0.0f;
     const int G = (int) gridDim.x, w = (int) blockIdx.x;
     const int r0 = (int) ((long) p.N * w / G), r1 = (int) ((long) p.N * (w + 1) / G);
     const int nrg = (r1 - r0 + 31) >> 5;
@@ -230,51 +233,62 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     const int r = lane & 31, g = lane >> 5;
     const uint8_t * xa = p.xq + (long) min(r, p.T - 1) * p.xq_stride + (TYPE == PM_Q4_K ? 16 : 8) * g;
     const uint8_t * bs_lane = p.bsT + lane * 16;
+    const bool act = NV == 16 ? true : r < p.T;                                     // token slots >= T: operand bytes are don't-care (scale row 0, never stored)
+    Rows rw;
+    uint32_t off_d = 0;
+    typename M::B R;
+    typename M::A A0 = {}, A1 = {};                              // (inactive token lanes keep these zeros)
+    auto issue_b = [&](int pr) __attribute__((always_inline)) {
+        M::issue_b(R, rw, nsb, pr, lane);
+        if constexpr (TYPE == PM_Q6_K) R.d = ld_nt2(rw.base + (off_d + (uint32_t) min(2 * pr + g, nsb - 1) * 2u));
+    };
+    // the first weight tile and activation slice of a row group (in flight before anything waits)
+    auto first = [&](int rg) __attribute__((always_inline)) {
+        const int rbase = r0 + 32 * rg;
+        rw.base = p.W + (long) rbase * p.row_stride;
+        rw.stride = (uint32_t) p.row_stride; rw.lim = r1 - 1 - rbase; rw.rr = lane >> 3; rw.rh = lane >> 1;
+        off_d = (uint32_t) min(r, rw.lim) * rw.stride + (uint32_t) nsb * 208u;
+        issue_b(pb);
+        M::issue_a(A0, xa, bs_lane, 2 * pb, act);
+        if constexpr (ABL & 1) M::issue_a(A1, xa, bs_lane, 2 * pb, act);
+    };
+    if (rgi < nrg && pb < pe) first(rgi);                         // ... including the staging of the scale table:
+    for (int i = tid; i < nsb * 8; i += BLOCK) ((f32x4 *) dTl)[i] = *((const PM_G f32x4 *) p.dT + i);
+    if (tid < 32) dTl[nsb * 32 + tid] = 0.0f;
     __syncthreads();
     for (int rg0 = 0; rg0 < nrg; rg0 += RGB) {
         const int rg = rg0 + rgi;
         f32x16 out = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (rg < nrg && pb < pe) {
-            const int rbase = r0 + 32 * rg;
-            Rows rw;
-            rw.base = p.W + (long) rbase * p.row_stride;
-            rw.stride = (uint32_t) p.row_stride; rw.lim = r1 - 1 - rbase; rw.rr = lane >> 3; rw.rh = lane >> 1;
-            const uint32_t off_d = (uint32_t) min(r, rw.lim) * rw.stride + (uint32_t) nsb * 208u;
-            typename M::B R;
-            typename M::A A0, A1;
-            auto issue_b = [&](int pr) __attribute__((always_inline)) {
-                M::issue_b(R, rw, nsb, pr, lane);
-                if constexpr (TYPE == PM_Q6_K) R.d = ld_nt2(rw.base + (off_d + (uint32_t) min(2 * pr + g, nsb - 1) * 2u));
-            };
-            issue_b(pb);
-            M::issue_a(A0, xa, bs_lane, 2 * pb);
+            if (rg0 > 0) first(rg);
             for (int pr = pb; pr < pe; ++pr) {
                 M::stash(R, L, lane);                                  // waits for this step's weights only
                 const int sb0 = 2 * pr, sb1 = min(2 * pr + 1, nsb - 1);
                 // Issue order is the design (VMEM returns in order): the compiler's schedulers must not sink the prefetches towards
                 // their uses - no conditional code in the step (an odd tail super-block is computed on clamped data with the all-zero
                 // scale row) and scheduling barriers around the issue points.
-                M::issue_a(A1, xa, bs_lane, sb1);
-                issue_b(min(pr + 1, pe - 1));                          // unconditional (clamped): in flight during the whole step
+                if constexpr (!(ABL & 1)) M::issue_a(A1, xa, bs_lane, sb1, act);
+                if constexpr (!(ABL & 2)) issue_b(min(pr + 1, pe - 1));  // unconditional (clamped): in flight during the whole step
                 __builtin_amdgcn_sched_barrier(0);
-                M::template compute<HALF>(A0, L, 0, r, g, dTl + sb0 * 32, out);
+                if constexpr (!(ABL & 4)) M::template compute<NV>(A0, L, 0, r, g, dTl + sb0 * 32, out);
+                else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A0.q[s_])); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane))); }
                 __builtin_amdgcn_sched_barrier(0);
-                M::issue_a(A0, xa, bs_lane, min(2 * pr + 2, nsb - 1));
+                if constexpr (!(ABL & 1)) M::issue_a(A0, xa, bs_lane, min(2 * pr + 2, nsb - 1), act);
                 __builtin_amdgcn_sched_barrier(0);
-                M::template compute<HALF>(A1, L, 1, r, g, dTl + (2 * pr + 1 < nsb ? sb1 : nsb) * 32, out);
+                if constexpr (!(ABL & 4)) M::template compute<NV>(A1, L, 1, r, g, dTl + (2 * pr + 1 < nsb ? sb1 : nsb) * 32, out);
+                else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A1.q[s_])); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane + 1024))); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         // fixed-order sum of the K slices through LDS, epilogue, store
         __syncthreads();
         float * red = (float *) stage;
-        constexpr int NV = HALF ? 8 : 16;
 #pragma unroll
         for (int v = 0; v < NV; ++v) red[(wave * 16 + v) * 64 + lane] = out[v];
         __syncthreads();
         for (int o = tid; o < RGB * 1024; o += BLOCK) {
             const int gi = o >> 10, v = (o >> 6) & 15, l = o & 63;
-            if (HALF && v >= 8) continue;
+            if (v >= NV) continue;
             float s = 0.0f;
             for (int k = 0; k < KS; ++k) s += red[(((k << p.rgb_log2) + gi) * 16 + v) * 64 + l];
             const int t = 8 * (v >> 2) + 4 * (l >> 5) + (v & 3), row = r0 + 32 * (rg0 + gi) + (l & 31);
@@ -314,12 +328,12 @@ size_t pm_mmq_i8_lds_bytes(int type, int K) {
 // 0 when pm_launch_mmq_i8 serves this shape
 int pm_mmq_i8_check(int type, int K, int N, int T) {
     if (type != PM_Q4_K && type != PM_Q6_K) return -1;
-    if (T < 1 || T > 32 || K % 256 || K < 512 || N < 1) return -2;
+    if (T < 1 || T > 64 || K % 256 || K < 512 || N < 1) return -2;
     if (pm_mmq_i8_lds_bytes(type, K) > 150 * 1024) return -4;
     return 0;
 }
 
-// Y[t][n] = W[n,:] . x[t,:] (+bias[n]) (+resid[t][n]) for 1 <= T <= 32 tokens. xq: activations already in the library's row-SoA Q8_K
+// Y[t][n] = W[n,:] . x[t,:] (+bias[n]) (+resid[t][n]) for 1 <= T <= 64 tokens (passes of up to 32). xq: activations already in the library's row-SoA Q8_K
 // form (quantize.hip), or null and x_f32 [T][K] is quantized first. Y / resid token stride = N.
 // Tokens per launch: 32 for Q6_K; 16 for Q4_K (its 32-token instantiation needs 8 live 16-register MFMA tiles on top of the prefetch
 // registers and spills 420 B / lane - two 16-token passes are faster).
@@ -337,7 +351,7 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
     if (need > g_scr_bytes[dev]) {
         if (reuse_prep) return -3;                                 // (cannot happen: the previous call sized the scratch for this K)
         if (g_scr[dev]) { (void) hipDeviceSynchronize(); (void) hipFree(g_scr[dev]); }
-        const size_t cap = 2 * tab + (size_t) 32 * xrow + 256;     // any later call with this K fits
+        const size_t cap = 2 * tab + (size_t) 64 * xrow + 256;     // any later call with this K fits
         if (hipMalloc((void **) &g_scr[dev], cap) != hipSuccess) { g_scr[dev] = nullptr; g_scr_bytes[dev] = 0; return -3; }
         g_scr_bytes[dev] = cap;
     }
@@ -350,7 +364,7 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
     const int grid = N / 32 >= cus ? cus : (N + 31) / 32;
     const int rows = (N + grid - 1) / grid, nrg = (rows + 31) / 32;
     const size_t lds = pm_mmq_i8_lds_bytes(type, K);
-    const int tmax = type == PM_Q4_K ? 16 : 32;
+    const int tmax = 32;
     for (int t0 = 0, c = 0; t0 < T; t0 += tmax, ++c) {
         const int tn = T - t0 < tmax ? T - t0 : tmax;
         uint8_t * bsT = g_scr[dev] + c * tab; float * dT = (float *) (bsT + (size_t) nsb * 1024);
@@ -366,9 +380,24 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
             if (!attr[dev]) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr[dev] = true; }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, st, p);
         };
-        if (type == PM_Q4_K) go(mmq_i8_kernel<PM_Q4_K, true>);
-        else if (tn <= 16)   go(mmq_i8_kernel<PM_Q6_K, true>);
-        else                 go(mmq_i8_kernel<PM_Q6_K, false>);
+#ifdef PM_MMQ_ABLATE      // measurement build (profiles/r02_small_batch_probe.txt): PM355_MMQ_ABL = 1 no activation loads | 2 no weight loads | 4 no compute
+        static const int abl = [] { const char * e = getenv("PM355_MMQ_ABL"); return e ? atoi(e) : 0; }();
+        if (abl && type == PM_Q4_K && tn <= 8) {
+            switch (abl) {
+                case 1: go(mmq_i8_kernel<PM_Q4_K, 4, 1>); break;
+                case 2: go(mmq_i8_kernel<PM_Q4_K, 4, 2>); break;
+                case 3: go(mmq_i8_kernel<PM_Q4_K, 4, 3>); break;
+                case 4: go(mmq_i8_kernel<PM_Q4_K, 4, 4>); break;
+                case 5: go(mmq_i8_kernel<PM_Q4_K, 4, 5>); break;
+                case 6: go(mmq_i8_kernel<PM_Q4_K, 4, 6>); break;
+                default: go(mmq_i8_kernel<PM_Q4_K, 4, 7>); break;
+            }
+        } else
+#endif
+        if (type == PM_Q4_K) { if (tn <= 8) go(mmq_i8_kernel<PM_Q4_K, 4>); else if (tn <= 16) go(mmq_i8_kernel<PM_Q4_K, 8>); else go(mmq_i8_kernel<PM_Q4_K, 16>); }
+        else if (tn <= 8)    go(mmq_i8_kernel<PM_Q6_K, 4>);
+        else if (tn <= 16)   go(mmq_i8_kernel<PM_Q6_K, 8>);
+        else                 go(mmq_i8_kernel<PM_Q6_K, 16>);
     }
     return 0;
 }

@@ -189,7 +189,7 @@ def test_gemv_epilogues_and_columns(P, oracle, t, C):
     assert np.allclose(y, oracle.silu_mul(want1, want2), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("T", [1, 2, 5, 8, 16, 17, 32])
+@pytest.mark.parametrize("T", [1, 2, 5, 8, 16, 17, 32, 33, 64])
 @pytest.mark.parametrize("t", [Q4_K, Q6_K])
 def test_small_batch_matmul_on_integer_matrix_cores(P, oracle, t, T):
     """mmq_i8.hip: same integer block sums as the mat-vec (vec_dot_q4_K_q8_K / vec_dot_q6_K_q8_K), f32 super-block terms added in a
@@ -197,7 +197,7 @@ def test_small_batch_matmul_on_integer_matrix_cores(P, oracle, t, T):
     groups per workgroup (N = 600 on <= 256 workgroups is 1 group; N = 20000 gives 3), odd super-block count (K = 768)."""
     rng = np.random.default_rng(100 * t + T)
     for K, N in ((4096, 70), (768, 600), (1024, 20000)):
-        if N == 20000 and T not in (5, 32): continue
+        if N == 20000 and T not in (5, 32, 64): continue
         b = rand_blocks(t, N, K, rng)
         x = rng.normal(0, 1, (T, K)).astype(np.float32)
         bias = rng.normal(0, 1, N).astype(np.float32)

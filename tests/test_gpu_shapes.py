@@ -1,6 +1,6 @@
 """Parity at BASELINE.json shapes: one Llama-3-70B-shaped and one Qwen2.5-72B-shaped LAYER
 (E 8192, 64 heads / 8 KV heads, head_dim 128, F 28672 / 29568 with the Q8_0 ffn_down the reference falls back to for
-K % 256 != 0, Q5_K / Q6_K attn_v) through the engine - single-token decode against the oracle, 48-token MFMA prefill + decode, 12-token small-batch step (integer matrix cores)
+K % 256 != 0, Q5_K / Q6_K attn_v) through the engine - single-token decode against the oracle, 80-token MFMA prefill + decode, 40-token small-batch step (integer matrix cores, two passes)
 against the reference CPU backend itself (oracle/_ref, AVX2 build, multi-threaded: the scalar oracle needs ~50 s for 32 tokens
 of a 70B layer) - and the two dominant decode launches (gate/up PAIR kernel, 3-job mixed-type QKV) at K = 8192 with the real
 row counts against oracle.mul_mat."""
@@ -70,8 +70,8 @@ def test_model_shaped_layer_decode_and_prefill(E, oracle, name, monkeypatch):
                    rope_freqs=(arch == 0), types=types)
     w = E.Window(_hp(d), n_ctx=128)
     w.load_desc(d)
-    w.finalize(max_tokens=48)
-    toks = rng.integers(0, d.n_vocab, 49).astype(np.int32)
+    w.finalize(max_tokens=80)
+    toks = rng.integers(0, d.n_vocab, 81).astype(np.int32)
 
     # (1) single-token decode (fused 5-launch path: 3-job QKV, fused attention, wo, PAIR gate/up, down) vs the ORACLE
     ho = oracle.model_new(d)
@@ -82,7 +82,7 @@ def test_model_shaped_layer_decode_and_prefill(E, oracle, name, monkeypatch):
     print(f"\n[{name}] decode vs oracle: hidden NMSE {n1:.2e}, logits NMSE {n2:.2e}")
     assert n1 < 1e-6 and n2 < 1e-4
 
-    # (2) 48-token prefill (MFMA GEMMs + MFMA attention, GQA 8:1) then a decode step at position 48 (fused attention over 49
+    # (2) 80-token prefill (MFMA GEMMs + MFMA attention, GQA 8:1) then a decode step at position 80 (fused attention over 81
     #     cached keys) vs the REFERENCE CPU backend (unmodified ggml, AVX2 build) on the same weights
     if not have_ref("avx2"):
         pytest.skip("oracle/_ref/libggml_ref_avx2.so not built")
@@ -90,31 +90,36 @@ def test_model_shaped_layer_decode_and_prefill(E, oracle, name, monkeypatch):
     hr = ref.model_new(d)
     thr = max(1, min(16, len(os.sched_getaffinity(0))))
     w.kv_clear()
-    hid_p, lg_p, _ = w.decode(tokens=torch.from_numpy(toks[:48]).cuda(), pos0=0, want_argmax=True)
-    hp_ref, lp_ref = ref.model_eval(hr, d, tokens=toks[:48], pos0=0, n_threads=thr)
-    hid_d, lg_d, _ = w.decode(tokens=torch.from_numpy(toks[48:]).cuda(), pos0=48, want_argmax=True)
-    hd_ref, ld_ref = ref.model_eval(hr, d, tokens=toks[48:], pos0=48, n_threads=thr)
+    hid_p, lg_p, _ = w.decode(tokens=torch.from_numpy(toks[:80]).cuda(), pos0=0, want_argmax=True)
+    hp_ref, lp_ref = ref.model_eval(hr, d, tokens=toks[:80], pos0=0, n_threads=thr)
+    hid_d, lg_d, _ = w.decode(tokens=torch.from_numpy(toks[80:]).cuda(), pos0=80, want_argmax=True)
+    hd_ref, ld_ref = ref.model_eval(hr, d, tokens=toks[80:], pos0=80, n_threads=thr)
     ref.model_free(hr)
     a, b = _nmse(hid_p.cpu().numpy(), hp_ref), _nmse(lg_p.cpu().numpy(), lp_ref)
     c, e = _nmse(hid_d.cpu().numpy(), hd_ref), _nmse(lg_d.cpu().numpy(), ld_ref)
-    print(f"[{name}] prefill(48) vs reference CPU: hidden NMSE {a:.2e}, logits NMSE {b:.2e}; decode@48: hidden {c:.2e}, logits {e:.2e}")
+    print(f"[{name}] prefill(80) vs reference CPU: hidden NMSE {a:.2e}, logits NMSE {b:.2e}; decode@80: hidden {c:.2e}, logits {e:.2e}")
     # the MFMA path multiplies F16-rounded activations (no Q8_K re-quantization): the reference's own backend tolerance for
     # MUL_MAT is NMSE <= 5e-4 (tests/test-backend-ops.cpp:1660); whole layer + head stays far below it
     assert a < 5e-4 and b < 1e-3
     assert c < 5e-4 and e < 1e-3
 
-    # (3) 12-token batch (speculative / parallel-sequence regime): mmq_i8.hip for the Q4_K / Q6_K matrices - the reference's integer
+    # (3) 40-token batch (two passes, 32 + 8 tokens; up to 64 tokens take this path - speculative / parallel-sequence / short-prompt regime): mmq_i8.hip for the Q4_K / Q6_K matrices - the reference's integer
     #     arithmetic on Q8_K activations, so it sits at mat-vec distance from the CPU backend, not at F16-GEMM distance
     w.kv_clear()
     hr = ref.model_new(d)
-    hid_s, lg_s, _ = w.decode(tokens=torch.from_numpy(toks[:12]).cuda(), pos0=0, want_argmax=True)
-    hs_ref, ls_ref = ref.model_eval(hr, d, tokens=toks[:12], pos0=0, n_threads=thr)
+    hid_s, lg_s, _ = w.decode(tokens=torch.from_numpy(toks[:40]).cuda(), pos0=0, want_argmax=True)
+    hs_ref, ls_ref = ref.model_eval(hr, d, tokens=toks[:40], pos0=0, n_threads=thr)
     ref.model_free(hr)
     f, g2 = _nmse(hid_s.cpu().numpy(), hs_ref), _nmse(lg_s.cpu().numpy(), ls_ref)
-    print(f"[{name}] small batch (12) vs reference CPU: hidden NMSE {f:.2e}, logits NMSE {g2:.2e}")
+    print(f"[{name}] small batch (40) vs reference CPU: hidden NMSE {f:.2e}, logits NMSE {g2:.2e}")
     # (what is left is the multi-token attention kernel's f32 softmax.V against the reference's F16-rounded probabilities: the distance
     #  is the same, 4.3e-6 / 1.3e-5, with PM355_NO_MMQ_I8=1, i.e. on the mat-vec path)
-    assert f < 2e-5 and g2 < 2e-4
+    # the Qwen2.5-72B shape has a Q8_0 ffn_down, which mmq_i8.hip does not serve: its 40-token batch takes the F16 GEMM path (per-layer
+    # decision in the engine) and sits at the prefill distance above
+    if name.startswith("llama3"):
+        assert f < 2e-5 and g2 < 2e-4
+    else:
+        assert f < 5e-4 and g2 < 1e-3
     w.close()
 
 
