@@ -78,7 +78,7 @@ template <> struct MT<PM_Q4_K> {
             b.qa[n] = ld_nt16(rw.base + (rw.off(n) + u * 16u));
             b.qb[n] = ld_nt16(rw.base + (rw.off(n) + (uint32_t) nb * 64u + u * 16u));
         }
-        b.h = ld_nt16(rw.base + (rw.off_h() + (uint32_t) nb * 128u + sb * 16u));
+        b.h = ld_c16(rw.base + (rw.off_h() + (uint32_t) nb * 128u + sb * 16u));   // cached: 4 steps share the line (as nt loads they re-fetched it from HBM: +29 % traffic)
     }
     static __device__ __forceinline__ void stash(const B & b, uint8_t * L, int lane) {
         const int rr = lane >> 3, c = lane & 7;
@@ -147,7 +147,7 @@ template <> struct MT<PM_Q6_K> {
             b.lb[n] = ld_nt16(rw.base + (rw.off(n) + (uint32_t) nb * 64u + u * 16u));
             b.qh[n] = ld_nt16(rw.base + (rw.off(n) + (uint32_t) nb * 128u + u * 16u));
         }
-        b.s = ld_nt16(rw.base + (rw.off_h() + (uint32_t) nb * 192u + sb * 16u));
+        b.s = ld_c16(rw.base + (rw.off_h() + (uint32_t) nb * 192u + sb * 16u));   // cached, like Q4_K's header
         // (d: one 2-byte load per lane (row lane % 32, super-block 2 pr + lane / 32), issued by the kernel with its own row offset)
     }
     static __device__ __forceinline__ void stash(const B & b, uint8_t * L, int lane) {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     typename M::A A0 = {}, A1 = {};                              // (inactive token lanes keep these zeros)
     auto issue_b = [&](int pr) __attribute__((always_inline)) {
         M::issue_b(R, rw, nsb, pr, lane);
-        if constexpr (TYPE == PM_Q6_K) R.d = ld_nt2(rw.base + (off_d + (uint32_t) min(2 * pr + g, nsb - 1) * 2u));
+        if constexpr (TYPE == PM_Q6_K) R.d = *(const PM_G uint16_t *) (rw.base + (off_d + (uint32_t) min(2 * pr + g, nsb - 1) * 2u));   // cached: 32 steps share the line
     };
     // the first weight tile and activation slice of a row group (in flight before anything waits)
     auto first = [&](int rg) __attribute__((always_inline)) {
@@ -271,12 +271,12 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
                 if constexpr (!(ABL & 2)) issue_b(min(pr + 1, pe - 1));  // unconditional (clamped): in flight during the whole step
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(ABL & 4)) M::template compute<NV>(A0, L, 0, r, g, dTl + sb0 * 32, out);
-                else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A0.q[s_])); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane))); }
+                else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A0.q[s_])); asm volatile("" :: "v"(A0.bs)); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane))); }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(ABL & 1)) M::issue_a(A0, xa, bs_lane, min(2 * pr + 2, nsb - 1), act);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(ABL & 4)) M::template compute<NV>(A1, L, 1, r, g, dTl + (2 * pr + 1 < nsb ? sb1 : nsb) * 32, out);
-                else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A1.q[s_])); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane + 1024))); }
+                else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A1.q[s_])); asm volatile("" :: "v"(A1.bs)); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane + 1024))); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -382,16 +382,12 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
         };
 #ifdef PM_MMQ_ABLATE      // measurement build (profiles/r02_small_batch_probe.txt): PM355_MMQ_ABL = 1 no activation loads | 2 no weight loads | 4 no compute
         static const int abl = [] { const char * e = getenv("PM355_MMQ_ABL"); return e ? atoi(e) : 0; }();
-        if (abl && type == PM_Q4_K && tn <= 8) {
-            switch (abl) {
-                case 1: go(mmq_i8_kernel<PM_Q4_K, 4, 1>); break;
-                case 2: go(mmq_i8_kernel<PM_Q4_K, 4, 2>); break;
-                case 3: go(mmq_i8_kernel<PM_Q4_K, 4, 3>); break;
-                case 4: go(mmq_i8_kernel<PM_Q4_K, 4, 4>); break;
-                case 5: go(mmq_i8_kernel<PM_Q4_K, 4, 5>); break;
-                case 6: go(mmq_i8_kernel<PM_Q4_K, 4, 6>); break;
-                default: go(mmq_i8_kernel<PM_Q4_K, 4, 7>); break;
-            }
+        if (abl && tn <= 8) {
+#define PM_ABL_CASE(T_) switch (abl) { case 1: go(mmq_i8_kernel<T_, 4, 1>); break; case 2: go(mmq_i8_kernel<T_, 4, 2>); break; case 3: go(mmq_i8_kernel<T_, 4, 3>); break; \
+                                       case 4: go(mmq_i8_kernel<T_, 4, 4>); break; case 5: go(mmq_i8_kernel<T_, 4, 5>); break; case 6: go(mmq_i8_kernel<T_, 4, 6>); break; \
+                                       default: go(mmq_i8_kernel<T_, 4, 7>); break; }
+            if (type == PM_Q4_K) PM_ABL_CASE(PM_Q4_K) else PM_ABL_CASE(PM_Q6_K)
+#undef PM_ABL_CASE
         } else
 #endif
         if (type == PM_Q4_K) { if (tn <= 8) go(mmq_i8_kernel<PM_Q4_K, 4>); else if (tn <= 16) go(mmq_i8_kernel<PM_Q4_K, 8>); else go(mmq_i8_kernel<PM_Q4_K, 16>); }
