@@ -260,6 +260,25 @@ def probe_prefill(hp, mixture, n_tok):
            "gemm_tflops_whole_prompt": round(flop / (ms / 1e3) / 1e12, 1), "mfma_peak_tflops_f16_dense": 2500.0,
            "note": "token embedding + all layers (MFMA v_mfma_f32_32x32x16_f16 weight GEMMs with on-the-fly dequantization, MFMA causal "
                    "attention) + result_norm + lm_head on the last token; gemm_tflops_whole_prompt counts the weight-GEMM FLOPs over the whole time"}
+    # small batches through the same window (speculative decoding / parallel sequences / short prompts): 4..64 tokens per step take the
+    # integer-matrix-core mat-mul (mmq_i8.hip: one weight pass per 32 tokens), whole model, KV positions advancing
+    try:
+        sb = {}
+        for T in (4, 8, 16, 32, 64):
+            if T > n_tok:
+                continue
+            win.kv_clear()
+            win.decode(tokens=toks[:T], pos0=0, want_hidden=False, want_logits=True)
+            torch.cuda.synchronize()
+            e0.record(st)
+            for i in range(3):
+                win.decode(tokens=toks[:T], pos0=T * (i + 1), want_hidden=False, want_logits=True)
+            e1.record(st)
+            torch.cuda.synchronize()
+            sb[str(T)] = {"ms_per_step": round(e0.elapsed_time(e1) / 3, 3), "tokens_per_s": round(3 * T / (e0.elapsed_time(e1) / 1e3), 1)}
+        out["small_batch"] = sb
+    except Exception as e:
+        out["small_batch"] = {"error": str(e)[:300]}
     # dominant kernel: ffn_gate GEMM [n_tok x n_embd] x [n_ff x n_embd]^T of layer 0 (its type decides the instantiation)
     try:
         lib = P.L.load()

@@ -337,8 +337,42 @@ int pm_mmq_i8_check(int type, int K, int N, int T) {
 // form (quantize.hip), or null and x_f32 [T][K] is quantized first. Y / resid token stride = N.
 // Tokens per launch: 32 for Q6_K; 16 for Q4_K (its 32-token instantiation needs 8 live 16-register MFMA tiles on top of the prefetch
 // registers and spills 420 B / lane - two 16-token passes are faster).
-// reuse_prep != 0: the previous pm_launch_mmq_i8 on this device and stream had the SAME activations (xq / x_f32 contents, T, K): its
-// quantized copy and tables are still valid, skip the prologue launches (q/k/v and gate/up share one activation set).
+namespace {
+// scratch for K (tables of two 32-token passes + a quantized copy of up to 64 f32 rows); false: allocation failed
+bool ensure_scratch(int dev, int K) {
+    const size_t xrow = pm_q8k_row_bytes(K), tab = (size_t) (K / 256) * (1024 + 128);
+    const size_t need = 2 * tab + (size_t) 64 * xrow + 256;
+    if (need <= g_scr_bytes[dev]) return true;
+    if (g_scr[dev]) { (void) hipDeviceSynchronize(); (void) hipFree(g_scr[dev]); }
+    if (hipMalloc((void **) &g_scr[dev], need) != hipSuccess) { g_scr[dev] = nullptr; g_scr_bytes[dev] = 0; return false; }
+    g_scr_bytes[dev] = need;
+    return true;
+}
+// activation tables of every 32-token pass
+void launch_prep(int dev, const void * xq, int K, int T, hipStream_t st) {
+    const int nsb = K / 256;
+    const size_t xrow = pm_q8k_row_bytes(K), tab = (size_t) nsb * (1024 + 128);
+    for (int t0 = 0, c = 0; t0 < T; t0 += 32, ++c) {
+        uint8_t * bsT = g_scr[dev] + c * tab;
+        hipLaunchKernelGGL(mmq_prep_kernel, dim3(nsb), dim3(64), 0, st, (const uint8_t *) xq + (size_t) t0 * xrow, (long) xrow, K, T - t0 < 32 ? T - t0 : 32,
+                           bsT, (float *) (bsT + (size_t) nsb * 1024));
+    }
+}
+}  // namespace
+
+// The prologue alone (tables for xq = T rows of row-SoA Q8_K): lets a caller fork streams between the prologue and several
+// pm_launch_mmq_i8(..., reuse_prep = 1, ...) launches that share the activations.
+int pm_launch_mmq_i8_prep(const void * xq, int K, int T, hipStream_t st) {
+    if (T < 1 || T > 64 || K % 256 || K < 512) return -2;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !ensure_scratch(dev, K)) return -3;
+    launch_prep(dev, xq, K, T, st);
+    return 0;
+}
+
+// reuse_prep != 0: the previous pm_launch_mmq_i8 / pm_launch_mmq_i8_prep on this device had the SAME activations (xq / x_f32 contents, T, K)
+// and is ordered before this launch: its quantized copy and tables are still valid, skip the prologue launches (q/k/v and gate/up share
+// one activation set).
 int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_f32, float * Y, int K, int N, int T,
                      const float * bias, const float * resid, int reuse_prep, hipStream_t st) {
     const int rc = pm_mmq_i8_check(type, K, N, T);
@@ -347,19 +381,13 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
     const int nsb = K / 256;
     const size_t xrow = pm_q8k_row_bytes(K), tab = (size_t) nsb * (1024 + 128);
-    const size_t need = 2 * tab + (xq ? 0 : ((size_t) T * xrow + 255) / 256 * 256);
-    if (need > g_scr_bytes[dev]) {
-        if (reuse_prep) return -3;                                 // (cannot happen: the previous call sized the scratch for this K)
-        if (g_scr[dev]) { (void) hipDeviceSynchronize(); (void) hipFree(g_scr[dev]); }
-        const size_t cap = 2 * tab + (size_t) 64 * xrow + 256;     // any later call with this K fits
-        if (hipMalloc((void **) &g_scr[dev], cap) != hipSuccess) { g_scr[dev] = nullptr; g_scr_bytes[dev] = 0; return -3; }
-        g_scr_bytes[dev] = cap;
-    }
+    if (reuse_prep ? (g_scr_bytes[dev] < 2 * tab) : !ensure_scratch(dev, K)) return -3;
     if (!xq) {
         uint8_t * q = g_scr[dev] + 2 * tab;
         if (!reuse_prep) pm_launch_quantize_q8k(x_f32, q, K, T, st);
         xq = q;
     }
+    if (!reuse_prep) launch_prep(dev, xq, K, T, st);
     const int cus = pm_device_cus();
     const int grid = N / 32 >= cus ? cus : (N + 31) / 32;
     const int rows = (N + grid - 1) / grid, nrg = (rows + 31) / 32;
@@ -369,7 +397,6 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
         const int tn = T - t0 < tmax ? T - t0 : tmax;
         uint8_t * bsT = g_scr[dev] + c * tab; float * dT = (float *) (bsT + (size_t) nsb * 1024);
         const uint8_t * xc = (const uint8_t *) xq + (size_t) t0 * xrow;
-        if (!reuse_prep) hipLaunchKernelGGL(mmq_prep_kernel, dim3(nsb), dim3(64), 0, st, xc, (long) xrow, K, tn, bsT, dT);
         MmqP p = {};
         p.W = (const uint8_t *) W; p.row_stride = (long) pm_weight_row_stride(type, K); p.N = N; p.K = K; p.T = tn;
         p.xq = xc; p.xq_stride = (long) xrow; p.bsT = bsT; p.dT = dT;

@@ -122,11 +122,28 @@ __global__ __launch_bounds__(256) void rmsnorm_q8k_kernel(const float * __restri
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nblk = K / PM_QK_K;
     const float * xr = x + (size_t) row * K;
-    // pass 1: sum of squares; products rounded to f32 like the reference, accumulated in f64
+    // A wave's blocks (wv, wv + 4, ...) are loaded ONCE, all loads in flight together, and stay in registers between the two passes
+    // (K <= 8192: 8 blocks per wave). With few rows (decode batches) the kernel is one latency chain per row: the former form - one
+    // dependent load per block and pass - took 12 us for K = 8192.
+    constexpr int HOLD = 8;
+    const bool held = nblk <= 4 * HOLD;
+    float4 f[HOLD];
+    if (held) {
+#pragma unroll
+        for (int i = 0; i < HOLD; ++i) { const int blk = min(wv + 4 * i, nblk - 1); f[i] = ((const float4 *) (xr + (size_t) blk * PM_QK_K))[lane]; }
+    }
+    // pass 1: sum of squares; products rounded to f32 like the reference, accumulated in f64 (same order as before: blocks ascending)
     double s = 0.0;
-    for (int blk = wv; blk < nblk; blk += 4) {
-        const float4 f = ((const float4 *) (xr + (size_t) blk * PM_QK_K))[lane];
-        s += (double) (f.x * f.x); s += (double) (f.y * f.y); s += (double) (f.z * f.z); s += (double) (f.w * f.w);
+    if (held) {
+#pragma unroll
+        for (int i = 0; i < HOLD; ++i) if (wv + 4 * i < nblk) {
+            s += (double) (f[i].x * f[i].x); s += (double) (f[i].y * f[i].y); s += (double) (f[i].z * f[i].z); s += (double) (f[i].w * f[i].w);
+        }
+    } else {
+        for (int blk = wv; blk < nblk; blk += 4) {
+            const float4 g = ((const float4 *) (xr + (size_t) blk * PM_QK_K))[lane];
+            s += (double) (g.x * g.x); s += (double) (g.y * g.y); s += (double) (g.z * g.z); s += (double) (g.w * g.w);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
@@ -135,10 +152,9 @@ __global__ __launch_bounds__(256) void rmsnorm_q8k_kernel(const float * __restri
     const double tot = (red[0] + red[1]) + (red[2] + red[3]);
     const float mean  = (float) (tot / K);
     const float scale = 1.0f / sqrtf(mean + eps);
-    // pass 2: normalise (+weight), write f32 and/or quantize (x is L2/L1 resident: K*4 <= 128 KB)
-    for (int blk = wv; blk < nblk; blk += 4) {
-        const float4 f = ((const float4 *) (xr + (size_t) blk * PM_QK_K))[lane];
-        float v[4] = {f.x * scale, f.y * scale, f.z * scale, f.w * scale};
+    // pass 2: normalise (+weight), write f32 and/or quantize
+    auto emit = [&](const float4 & fx, int blk) __attribute__((always_inline)) {
+        float v[4] = {fx.x * scale, fx.y * scale, fx.z * scale, fx.w * scale};
         if (w) {
             const float4 g = ((const float4 *) (w + (size_t) blk * PM_QK_K))[lane];
             v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
@@ -149,6 +165,12 @@ __global__ __launch_bounds__(256) void rmsnorm_q8k_kernel(const float * __restri
             ((h4 *) (yh + (size_t) row * K + (size_t) blk * PM_QK_K))[lane] = h4{(_Float16) v[0], (_Float16) v[1], (_Float16) v[2], (_Float16) v[3]};
         }
         if (yq) q8k_block_from_regs(v, lane, yq + (size_t) row * yq_row_bytes, K, blk);
+    };
+    if (held) {
+#pragma unroll
+        for (int i = 0; i < HOLD; ++i) if (wv + 4 * i < nblk) emit(f[i], wv + 4 * i);
+    } else {
+        for (int blk = wv; blk < nblk; blk += 4) emit(((const float4 *) (xr + (size_t) blk * PM_QK_K))[lane], blk);
     }
 }
 
