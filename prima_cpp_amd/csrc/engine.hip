@@ -235,11 +235,18 @@ void layer_release(pm355_model * m, int il, hipStream_t st) {
 }
 
 // quantize `src` [T][K] into the activation format(s) the given weights need; returns pointers
-struct ActQ { const void * k = nullptr; const void * z = nullptr; };
+struct ActQ { const void * k = nullptr; const void * z = nullptr; bool tab = false; };   // tab: the small-batch mat-mul's activation tables were written too
+const int MMQ_MIN_TOKENS = 4, MMQ_MAX_TOKENS = 64;
+// the table output of the Q8_K quantizers, when this batch size takes the small-batch mat-mul (mmq_i8.hip)
+pm_q8k_tables mmq_tables(const pm355_model * m, int K, int T) {
+    pm_q8k_tables tb;
+    if (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && pm_mmq_i8_tables(K, &tb) != 0) tb = pm_q8k_tables();
+    return (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq) ? tb : pm_q8k_tables();
+}
 ActQ quantize_for(pm355_model * m, const float * src, int K, int T, const Tensor * const * ws, int nw, hipStream_t st) {
     ActQ a; bool need_k = false, need_0 = false;
     for (int i = 0; i < nw; ++i) if (ws[i] && ws[i]->d) { if (ws[i]->type == PM_Q8_0) need_0 = true; else need_k = true; }
-    if (need_k) { pm_launch_quantize_q8k(src, m->aq_k, K, T, st); a.k = m->aq_k; }
+    if (need_k) { const pm_q8k_tables tb = mmq_tables(m, K, T); pm_launch_quantize_q8k(src, m->aq_k, K, T, st, tb); a.k = m->aq_k; a.tab = tb.base != nullptr; }
     if (need_0) { pm_launch_quantize_q80(src, m->aq_0, K, T, st); a.z = m->aq_0; }
     return a;
 }
@@ -248,8 +255,9 @@ ActQ norm_quantize_for(pm355_model * m, const float * src, const float * w, int 
     bool need_0 = false;
     for (int i = 0; i < nw; ++i) if (ws[i] && ws[i]->d && ws[i]->type == PM_Q8_0) need_0 = true;
     if (!need_0) {
-        pm_launch_rmsnorm_q8k(src, w, nullptr, m->aq_k, K, T, m->hp.rms_eps, st);
-        ActQ a; a.k = m->aq_k; return a;
+        const pm_q8k_tables tb = mmq_tables(m, K, T);
+        pm_launch_rmsnorm_q8k(src, w, nullptr, m->aq_k, K, T, m->hp.rms_eps, st, nullptr, tb);
+        ActQ a; a.k = m->aq_k; a.tab = tb.base != nullptr; return a;
     }
     pm_launch_rmsnorm_q8k(src, w, m->xn, nullptr, K, T, m->hp.rms_eps, st);
     return quantize_for(m, m->xn, K, T, ws, nw, st);
@@ -265,10 +273,9 @@ int gemv(const Tensor & w, const Tensor * w2, const ActQ & a, int T, float * y, 
 // 4..64 tokens: one pass over the weights per 32 tokens on the integer matrix cores (mmq_i8.hip) where the type / shape is served, else the mat-vec
 // (one to three passes per 8 columns). `prepped`: the kernel's activation tables already describe THIS activation set (set by the first
 // served call, cleared by the caller whenever the activations change)
-const int MMQ_MIN_TOKENS = 4, MMQ_MAX_TOKENS = 64;
 int matmul_small(pm355_model * m, const Tensor & w, const ActQ & a, int T, float * y, const float * bias, const float * resid, bool & prepped, hipStream_t st) {
     if (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && a.k && pm_mmq_i8_check(w.type, (int) w.K, (int) w.N, T) == 0) {
-        const int rc = pm_launch_mmq_i8(w.type, w.d, a.k, nullptr, y, (int) w.K, (int) w.N, T, bias, resid, prepped ? 1 : 0, st);
+        const int rc = pm_launch_mmq_i8(w.type, w.d, a.k, nullptr, y, (int) w.K, (int) w.N, T, bias, resid, (prepped || a.tab) ? 1 : 0, st);
         if (rc == 0) { prepped = true; return 0; }
     }
     return gemv(w, nullptr, a, T, y, bias, resid, st);

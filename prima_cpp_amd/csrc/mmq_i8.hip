@@ -253,7 +253,12 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
         if constexpr (ABL & 1) M::issue_a(A1, xa, bs_lane, 2 * pb, act);
     };
     if (rgi < nrg && pb < pe) first(rgi);                         // ... including the staging of the scale table:
-    for (int i = tid; i < nsb * 8; i += BLOCK) ((f32x4 *) dTl)[i] = *((const PM_G f32x4 *) p.dT + i);
+    for (int i = tid; i < nsb * 8; i += BLOCK) {                  // (slots >= T masked here: a quantizer that writes the table itself fills rows < T only)
+        f32x4 d4 = *((const PM_G f32x4 *) p.dT + i);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (((4 * i + c) & 31) >= p.T) d4[c] = 0.0f;
+        ((f32x4 *) dTl)[i] = d4;
+    }
     if (tid < 32) dTl[nsb * 32 + tid] = 0.0f;
     __syncthreads();
     for (int rg0 = 0; rg0 < nrg; rg0 += RGB) {
@@ -345,6 +350,7 @@ bool ensure_scratch(int dev, int K) {
     if (need <= g_scr_bytes[dev]) return true;
     if (g_scr[dev]) { (void) hipDeviceSynchronize(); (void) hipFree(g_scr[dev]); }
     if (hipMalloc((void **) &g_scr[dev], need) != hipSuccess) { g_scr[dev] = nullptr; g_scr_bytes[dev] = 0; return false; }
+    (void) hipMemset(g_scr[dev], 0, need);                          // table slots no quantizer ever wrote stay finite (they are multiplied by scale 0)
     g_scr_bytes[dev] = need;
     return true;
 }
@@ -359,6 +365,16 @@ void launch_prep(int dev, const void * xq, int K, int T, hipStream_t st) {
     }
 }
 }  // namespace
+
+// Where the tables for K live: pm_launch_quantize_q8k / pm_launch_rmsnorm_q8k write them as a second output (<= 64 rows), the mat-mul is
+// then launched with reuse_prep = 1 and no prologue launch at all.
+int pm_mmq_i8_tables(int K, pm_q8k_tables * out) {
+    if (K % 256 || K < 512) return -2;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !ensure_scratch(dev, K)) return -3;
+    out->base = g_scr[dev]; out->nsb = K / 256; out->tab_bytes = (size_t) (K / 256) * (1024 + 128);
+    return 0;
+}
 
 // The prologue alone (tables for xq = T rows of row-SoA Q8_K): lets a caller fork streams between the prologue and several
 // pm_launch_mmq_i8(..., reuse_prep = 1, ...) launches that share the activations.

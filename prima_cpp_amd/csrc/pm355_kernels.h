@@ -22,9 +22,13 @@ int pm_gemv_units_per_row(int type, int64_t K);
 // HBM layout != GGUF block order (repack.hip): Q4_K (12), Q6_K (14), Q8_0 (8)
 static inline bool pm_type_is_repacked(int type) { return type == 12 || type == 14 || type == 8; }
 
-void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStream_t st);
+// optional second output of the Q8_K quantizers: the activation tables of the small-batch mat-mul (mmq_i8.hip: per 32-row pass, the F16
+// 16-value sums in MFMA operand order | the transposed block scales) - that mat-mul then needs no prologue launch. base == null: off
+struct pm_q8k_tables { uint8_t * base = nullptr; size_t tab_bytes = 0; int nsb = 0; };
+void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStream_t st, pm_q8k_tables tab = {});
 void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStream_t st);
-void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st, void * ynorm_f16 = nullptr);
+void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st, void * ynorm_f16 = nullptr,
+                           pm_q8k_tables tab = {});
 
 // weight repack (row-local, bijective):  GGUF block order <-> HBM row-SoA (Q4_K, Q6_K, Q8_0); identity for the rest
 void pm_launch_repack(int type, const void * src, void * dst, int64_t K, int64_t nrows, int to_device_layout, hipStream_t st);
@@ -87,6 +91,7 @@ void pm_launch_barrier_probe(int n, void * ctr, hipStream_t st);       // measur
 // small-batch (1..32 tokens) quantized mat-mul on the integer matrix cores (mmq_i8.hip): Q4_K / Q6_K weights, Q8_K activations
 // (xq row-SoA, or x_f32 quantized first into a per-device scratch). 0, or -1 type / -2 shape / -3 device / -4 LDS
 int pm_mmq_i8_check(int type, int K, int N, int T);
+int pm_mmq_i8_tables(int K, pm_q8k_tables * out);      // where a quantizer writes the tables for K (<= 64 rows); then reuse_prep = 1
 int pm_launch_mmq_i8_prep(const void * xq, int K, int T, hipStream_t st);      // the activation tables alone (then reuse_prep = 1)
 int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_f32, float * Y, int K, int N, int T,
                      const float * bias, const float * resid, int reuse_prep, hipStream_t st);

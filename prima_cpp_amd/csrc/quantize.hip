@@ -44,7 +44,7 @@ __device__ __forceinline__ int wave_min_i(int v) {
 }
 
 // One wave quantizes one 256-value block held as 4 consecutive values per lane.
-__device__ __forceinline__ void q8k_block_from_regs(const float v[4], int lane, uint8_t * row_out, int K, int blk) {
+__device__ __forceinline__ void q8k_block_from_regs(const float v[4], int lane, uint8_t * row_out, int K, int blk, const pm_q8k_tables & tb = pm_q8k_tables(), int row = 0) {
     float a0 = fabsf(v[0]), a1 = fabsf(v[1]), a2 = fabsf(v[2]), a3 = fabsf(v[3]);
     const float amax = wave_max(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
     int8_t  * qs    = (int8_t *) row_out;
@@ -70,18 +70,24 @@ __device__ __forceinline__ void q8k_block_from_regs(const float v[4], int lane, 
             packed |= (uint32_t) (q & 0xFF) << (8 * i);
         }
         if (lane == 0) dd[blk] = 1 / iscale;
+        if (tb.base && lane == 0) ((float *) (tb.base + (size_t) (row >> 5) * tb.tab_bytes + (size_t) tb.nsb * 1024))[blk * 32 + (row & 31)] = 1 / iscale;
     } else if (lane == 0) {
         dd[blk] = 0.0f;
+        if (tb.base) ((float *) (tb.base + (size_t) (row >> 5) * tb.tab_bytes + (size_t) tb.nsb * 1024))[blk * 32 + (row & 31)] = 0.0f;
     }
     ((uint32_t *) (qs + (size_t) blk * PM_QK_K))[lane] = packed;
     // bsums: 16 values = 4 lanes (one quad)
     psum += dpp_i<0xB1>(psum);
     psum += dpp_i<0x4E>(psum);
     if ((lane & 3) == 0) bsums[blk * 16 + (lane >> 2)] = (int16_t) psum;
+    if (tb.base && (lane & 3) == 0) {              // group G = lane / 4 -> operand lane (row % 32) + 32 (G & 1), slot G / 2 (mmq_i8.hip mmq_prep_kernel)
+        const int G = lane >> 2;
+        ((_Float16 *) (tb.base + (size_t) (row >> 5) * tb.tab_bytes))[((size_t) blk * 64 + (row & 31) + 32 * (G & 1)) * 8 + (G >> 1)] = (_Float16) (float) psum;
+    }
 }
 
 __global__ __launch_bounds__(256) void quantize_q8k_kernel(const float * __restrict__ x, uint8_t * __restrict__ y,
-                                                           int K, int rows, size_t y_row_bytes) {
+                                                           int K, int rows, size_t y_row_bytes, pm_q8k_tables tb) {
     const int lane = threadIdx.x & 63;
     const int nblk = K / PM_QK_K;
     const long wave = (long) blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256) void quantize_q8k_kernel(const float * __restr
     const int row = (int) (wave / nblk), blk = (int) (wave % nblk);
     const float4 f = ((const float4 *) (x + (size_t) row * K + (size_t) blk * PM_QK_K))[lane];
     const float v[4] = {f.x, f.y, f.z, f.w};
-    q8k_block_from_regs(v, lane, y + (size_t) row * y_row_bytes, K, blk);
+    q8k_block_from_regs(v, lane, y + (size_t) row * y_row_bytes, K, blk, tb, row);
 }
 
 // Q8_0: 32-value blocks, 8 lanes x 4 values; amax over the 8-lane group.
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(256) void quantize_q80_kernel(const float * __restr
 // Optionally also writes the normalised f32 row (ynorm != nullptr).
 __global__ __launch_bounds__(256) void rmsnorm_q8k_kernel(const float * __restrict__ x, const float * __restrict__ w,
                                                           float * __restrict__ ynorm, uint8_t * __restrict__ yq,
-                                                          int K, float eps, size_t yq_row_bytes, _Float16 * __restrict__ yh) {
+                                                          int K, float eps, size_t yq_row_bytes, _Float16 * __restrict__ yh, pm_q8k_tables tb) {
     __shared__ double red[4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nblk = K / PM_QK_K;
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(256) void rmsnorm_q8k_kernel(const float * __restri
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
             ((h4 *) (yh + (size_t) row * K + (size_t) blk * PM_QK_K))[lane] = h4{(_Float16) v[0], (_Float16) v[1], (_Float16) v[2], (_Float16) v[3]};
         }
-        if (yq) q8k_block_from_regs(v, lane, yq + (size_t) row * yq_row_bytes, K, blk);
+        if (yq) q8k_block_from_regs(v, lane, yq + (size_t) row * yq_row_bytes, K, blk, tb, row);
     };
     if (held) {
 #pragma unroll
@@ -175,16 +181,16 @@ __global__ __launch_bounds__(256) void rmsnorm_q8k_kernel(const float * __restri
 }
 
 // ---- host launchers -------------------------------------------------------------------------------
-void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStream_t st) {
+void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStream_t st, pm_q8k_tables tab) {
     const long waves = (long) rows * (K / PM_QK_K);
     hipLaunchKernelGGL(quantize_q8k_kernel, dim3((unsigned) ((waves + 3) / 4)), dim3(256), 0, st,
-                       x, (uint8_t *) y, K, rows, pm_q8k_row_bytes(K));
+                       x, (uint8_t *) y, K, rows, pm_q8k_row_bytes(K), tab);
 }
 void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStream_t st) {
     const long n = (long) rows * (K / 4);
     hipLaunchKernelGGL(quantize_q80_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st,
                        x, (uint8_t *) y, K, rows, pm_q80_row_bytes(K));
 }
-void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st, void * ynorm_f16) {
-    hipLaunchKernelGGL(rmsnorm_q8k_kernel, dim3(rows), dim3(256), 0, st, x, w, ynorm, (uint8_t *) yq, K, eps, pm_q8k_row_bytes(K), (_Float16 *) ynorm_f16);
+void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st, void * ynorm_f16, pm_q8k_tables tab) {
+    hipLaunchKernelGGL(rmsnorm_q8k_kernel, dim3(rows), dim3(256), 0, st, x, w, ynorm, (uint8_t *) yq, K, eps, pm_q8k_row_bytes(K), (_Float16 *) ynorm_f16, tab);
 }
