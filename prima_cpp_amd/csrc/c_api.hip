@@ -179,6 +179,18 @@ int pm355_mul_mat_q_small(int type, const void * W, int64_t K, int64_t N, const 
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_mul_mat_q_small_multi(int type, int njobs, const void * const * W, const int64_t * N, float * const * y, const float * const * bias,
+                                const void * xq, int64_t K, int64_t n_tokens, pm355_stream_t st) {
+    (void) hipGetLastError();
+    if (njobs < 2 || njobs > 3 || !W || !N || !y || !xq) return fail(PM355_E_RANGE, "mul_mat_q_small_multi: 2..3 jobs, pre-quantized activations");
+    int n32[3];
+    for (int j = 0; j < njobs; ++j) n32[j] = (int) N[j];
+    const int rc = pm_launch_mmq_i8_multi(type, njobs, W, n32, y, bias, xq, (int) K, (int) n_tokens, 0, S(st));
+    if (rc == -5) return fail(PM355_E_UNSUPPORTED, "mul_mat_q_small_multi: Q4_K / Q6_K, n_tokens <= 16, K % 256 == 0 required");
+    if (rc) return fail(PM355_E_HIP, "mul_mat_q_small_multi: scratch allocation");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 int pm355_mul_mat_q_small_check(int type, int64_t K, int64_t N, int64_t n_tokens) {
     return pm_mmq_i8_check(type, (int) K, (int) N, (int) n_tokens) == 0 ? 0 : PM355_E_UNSUPPORTED;
 }

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <vector>
+#include <initializer_list>
 #include <algorithm>
 
 namespace {
@@ -44,6 +45,7 @@ struct pm355_model {
     int32_t * d_pos = nullptr, * d_tok = nullptr, * d_ctl = nullptr;   // d_pos[n_seq]; d_ctl = {current seq, n_seq}
     int n_seq = 1;
     bool no_fuse = false;                 // PM355_NO_FUSE=1: node-by-node kernels (debug / A-B)
+    bool no_multi = false;                // PM355_NO_MMQ_MULTI=1
     bool no_mmq = false;                  // PM355_NO_MMQ_I8=1: 4..64-token batches on the round-1 paths (mat-vec columns, F16 GEMM from 16 tokens)
     // EXPERIMENT (PM355_ATTN_WO=1, attn_wo.hip): attention + wo as ONE two-phase launch per layer - every workgroup first puts its wo
     // weight loads in flight, the 64 head workgroups run the latency-bound attention meanwhile, one device-wide barrier, then the wo
@@ -473,9 +475,32 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         ActQ a = norm_quantize_for(m, cur, (const float *) L.t[PM355_T_ATTN_NORM].d, E, T, qkv, 3, st);
         int rc = 0;
         bool prepped = false;
+        const bool small = T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && a.k != nullptr;
+        // matrices of one type that share the activations go out as ONE small-batch launch (<= 16 tokens): wq | wk (| wv), ffn_gate | ffn_up
+        auto multi = [&](std::initializer_list<const Tensor *> ws, std::initializer_list<float *> ys, std::initializer_list<const float *> bs) {
+            const void * W[3]; int N[3]; float * Y[3]; const float * B[3]; int n = 0;
+            for (const Tensor * w : ws) { W[n] = w->d; N[n] = (int) w->N; ++n; }
+            n = 0; for (float * y : ys) Y[n++] = y;
+            n = 0; for (const float * b : bs) B[n++] = b;
+            const Tensor * w0 = *ws.begin();
+            return pm_launch_mmq_i8_multi(w0->type, n, W, N, Y, B, a.k, (int) w0->K, T, (prepped || a.tab) ? 1 : 0, st);
+        };
+        const Tensor & wq_ = L.t[PM355_T_WQ], & wk_ = L.t[PM355_T_WK], & wv_ = L.t[PM355_T_WV];
+        const float * bq_ = (const float *) L.t[PM355_T_BQ].d, * bk_ = (const float *) L.t[PM355_T_BK].d, * bv_ = (const float *) L.t[PM355_T_BV].d;
+        bool qkv_done = false;
+        if (small && T <= 16 && !m->no_multi && wq_.type == wk_.type) {
+            if (wv_.type == wq_.type) {
+                if (multi({&wq_, &wk_, &wv_}, {m->q, m->k, m->v}, {bq_, bk_, bv_}) == 0) qkv_done = true;
+            } else if (multi({&wq_, &wk_}, {m->q, m->k}, {bq_, bk_}) == 0) {
+                prepped = true; qkv_done = true;
+                rc |= matmul_small(m, wv_, a, T, m->v, bv_, nullptr, prepped, st);
+            }
+        }
+        if (!qkv_done) {
         rc |= matmul_small(m, L.t[PM355_T_WQ], a, T, m->q, (const float *) L.t[PM355_T_BQ].d, nullptr, prepped, st);
         rc |= matmul_small(m, L.t[PM355_T_WK], a, T, m->k, (const float *) L.t[PM355_T_BK].d, nullptr, prepped, st);
         rc |= matmul_small(m, L.t[PM355_T_WV], a, T, m->v, (const float *) L.t[PM355_T_BV].d, nullptr, prepped, st);
+        }
         if (rc) return seterr(m, rc, "decode: qkv gemv");
         const long kv_stride = (long) hp.n_ctx * Hkv * dh;
         bool fused_attn = false;
@@ -501,6 +526,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         if (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && m->h2 && a.k && pm_mmq_i8_check(wg.type, (int) wg.K, (int) wg.N, T) == 0) {
             // gate and up: one weight pass each for all tokens, then silu(gate) * up (the pair mat-vec would take one launch per token)
             prepped = false;
+            if (!(T <= 16 && !m->no_multi && wg.type == wu.type && multi({&wg, &wu}, {m->h, m->h2}, {nullptr, nullptr}) == 0))
             if (matmul_small(m, wg, a, T, m->h, nullptr, nullptr, prepped, st) || matmul_small(m, wu, a, T, m->h2, nullptr, nullptr, prepped, st))
                 return seterr(m, PM355_E_UNSUPPORTED, "decode: gate/up small-batch mat-mul");
             pm_launch_silu_mul(m->h, m->h2, m->h, (long) T * F, st);
@@ -539,6 +565,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     m->rope.ext_factor = 0.0f; m->rope.attn_factor = 1.0f; m->rope.beta_fast = 32.0f; m->rope.beta_slow = 1.0f;
     pm_rope_params(m->rope);
     { const char * e = getenv("PM355_NO_FUSE"); m->no_fuse = e && e[0] == '1'; }
+    { const char * e = getenv("PM355_NO_MMQ_MULTI"); m->no_multi = e && e[0] == '1'; }   // small batches: one launch per matrix (A/B of the multi-job launches)
     { const char * e = getenv("PM355_NO_MMQ_I8"); m->no_mmq = e && e[0] == '1'; }     // 4..64-token batches: mat-vec columns / F16 GEMM from 16 (the round-1 paths)
     { const char * e = getenv("PM355_ATTN_WO"); m->attn_wo = e && e[0] == '1'; }       // measured: 8.74 vs 8.60 ms per 70B token -> opt-in experiment
     return m;

@@ -45,6 +45,9 @@ struct MmqP {
     const uint8_t * xq; long xq_stride;                            // row-SoA Q8_K activations [T]
     const uint8_t * bsT; const float * dT;                         // prologue tables: [nsb][64 lanes][8 f16], [nsb][32]
     float * y; long y_stride; const float * bias; const float * resid;
+    // multi-job launches (MJ kernels): up to 3 matrices of one type and K that share the activations (wq | wk | wv, ffn_gate | ffn_up) form
+    // ONE virtual row space [0, N): job j owns rows [start[j], start[j] + nj[j]); y / bias per job, output token stride nj[j]
+    const uint8_t * Wj[3]; float * yj[3]; const float * bj[3]; int start[3], nj[3], njobs;
 };
 
 __device__ __forceinline__ long pk(uint32_t a, uint32_t b) { return (long) (((uint64_t) b << 32) | a); }
@@ -58,10 +61,18 @@ __device__ __forceinline__ i32x16 mfma_i8x32(u32x4 a, u32x4 b, i32x16 c) {
 }
 
 // where the loader lanes of a wave point: lane (rr = lane / 8, c = lane % 8) fetches 16-byte chunk c of rows rr, rr + 8, rr + 16, rr + 24
-struct Rows {
-    const uint8_t * base; uint32_t stride; int lim /*last valid row of the group, relative*/, rr, rh;
-    __device__ __forceinline__ uint32_t off(int n) const { return (uint32_t) min(rr + 8 * n, lim) * stride; }
-    __device__ __forceinline__ uint32_t off_h() const { return (uint32_t) min(rh, lim) * stride; }
+template <bool MJ> struct Rows;
+template <> struct Rows<false> {          // one matrix: wave-uniform base + 32-bit lane offsets
+    const uint8_t * base; uint32_t stride, off_d; int lim /*last valid row of the group, relative*/, rr, rh;
+    __device__ __forceinline__ const uint8_t * at(int n, uint32_t x) const { return base + ((uint32_t) min(rr + 8 * n, lim) * stride + x); }
+    __device__ __forceinline__ const uint8_t * at_h(uint32_t x) const { return base + ((uint32_t) min(rh, lim) * stride + x); }
+    __device__ __forceinline__ const uint8_t * at_d(uint32_t x) const { return base + (off_d + x); }
+};
+template <> struct Rows<true> {           // several matrices: a lane's rows may sit in different allocations -> 64-bit row pointers per lane
+    const uint8_t * rp[4], * rph, * rpd;
+    __device__ __forceinline__ const uint8_t * at(int n, uint32_t x) const { return rp[n] + x; }
+    __device__ __forceinline__ const uint8_t * at_h(uint32_t x) const { return rph + x; }
+    __device__ __forceinline__ const uint8_t * at_d(uint32_t x) const { return rpd + x; }
 };
 
 template <int TYPE> struct MT;
@@ -71,14 +82,15 @@ template <> struct MT<PM_Q4_K> {
     static constexpr int QA = 0, QB = 32 * PITCH, HD = 64 * PITCH, WAVE_LDS = 64 * PITCH + 32 * PITCH_H;
     struct B { u32x4 qa[4], qb[4], h; };
     struct A { u32x4 q[8]; f16x8 bs; };
-    static __device__ __forceinline__ void issue_b(B & b, const Rows & rw, int nb, int pr, int lane) {
+    template <class RW>
+    static __device__ __forceinline__ void issue_b(B & b, const RW & rw, int nb, int pr, int lane) {
         const uint32_t u = (uint32_t) min(8 * pr + (lane & 7), 4 * nb - 1), sb = (uint32_t) min(2 * pr + (lane & 1), nb - 1);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            b.qa[n] = ld_nt16(rw.base + (rw.off(n) + u * 16u));
-            b.qb[n] = ld_nt16(rw.base + (rw.off(n) + (uint32_t) nb * 64u + u * 16u));
+            b.qa[n] = ld_nt16(rw.at(n, u * 16u));
+            b.qb[n] = ld_nt16(rw.at(n, (uint32_t) nb * 64u + u * 16u));
         }
-        b.h = ld_c16(rw.base + (rw.off_h() + (uint32_t) nb * 128u + sb * 16u));   // cached: 4 steps share the line (as nt loads they re-fetched it from HBM: +29 % traffic)
+        b.h = ld_c16(rw.at_h((uint32_t) nb * 128u + sb * 16u));   // cached: 4 steps share the line (as nt loads they re-fetched it from HBM: +29 % traffic)
     }
     static __device__ __forceinline__ void stash(const B & b, uint8_t * L, int lane) {
         const int rr = lane >> 3, c = lane & 7;
@@ -139,15 +151,16 @@ template <> struct MT<PM_Q6_K> {
     static constexpr int LA = 0, LB = 32 * PITCH, QH = 64 * PITCH, SC = 96 * PITCH, DD = SC + 32 * PITCH_H, WAVE_LDS = DD + 128;
     struct B { u32x4 la[4], lb[4], qh[4], s; uint16_t d; };
     struct A { u32x2 q[16]; f16x8 bs; };
-    static __device__ __forceinline__ void issue_b(B & b, const Rows & rw, int nb, int pr, int lane) {
+    template <class RW>
+    static __device__ __forceinline__ void issue_b(B & b, const RW & rw, int nb, int pr, int lane) {
         const uint32_t u = (uint32_t) min(8 * pr + (lane & 7), 4 * nb - 1), sb = (uint32_t) min(2 * pr + (lane & 1), nb - 1);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            b.la[n] = ld_nt16(rw.base + (rw.off(n) + u * 16u));
-            b.lb[n] = ld_nt16(rw.base + (rw.off(n) + (uint32_t) nb * 64u + u * 16u));
-            b.qh[n] = ld_nt16(rw.base + (rw.off(n) + (uint32_t) nb * 128u + u * 16u));
+            b.la[n] = ld_nt16(rw.at(n, u * 16u));
+            b.lb[n] = ld_nt16(rw.at(n, (uint32_t) nb * 64u + u * 16u));
+            b.qh[n] = ld_nt16(rw.at(n, (uint32_t) nb * 128u + u * 16u));
         }
-        b.s = ld_c16(rw.base + (rw.off_h() + (uint32_t) nb * 192u + sb * 16u));   // cached, like Q4_K's header
+        b.s = ld_c16(rw.at_h((uint32_t) nb * 192u + sb * 16u));   // cached, like Q4_K's header
         // (d: one 2-byte load per lane (row lane % 32, super-block 2 pr + lane / 32), issued by the kernel with its own row offset)
     }
     static __device__ __forceinline__ void stash(const B & b, uint8_t * L, int lane) {
@@ -215,7 +228,7 @@ template <> struct MT<PM_Q6_K> {
 };
 
 // ABL (measurement only, PM355_MMQ_ABL): 1 = no activation loads in the loop, 2 = no weight loads in the loop, 4 = no MFMA / VALU work
-template <int TYPE, int NV, int ABL = 0>      // NV result registers per lane in use: 4 (<= 8 tokens), 8 (<= 16), 16 (<= 32)
+template <int TYPE, int NV, int ABL = 0, bool MJ = false>      // NV result registers per lane in use: 4 (<= 8 tokens), 8 (<= 16), 16 (<= 32)
 __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     typedef MT<TYPE> M;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     float * dTl = (float *) smem;                                 // activation scales [nsb + 1][32] (0 for token slots >= T; last row all 0)
     uint8_t * stage = smem + (size_t) (nsb + 1) * 128;            // NWAVE x WAVE_LDS; afterwards the 32 KB reduction buffer
     const int G = (int) gridDim.x, w = (int) blockIdx.x;
-    const int r0 = (int) ((long) p.N * w / G), r1 = (int) ((long) p.N * (w + 1) / G);
+    const int r0 = (int) ((long) p.N * w / G), r1 = (int) ((long) p.N * (w + 1) / G);      // (MJ: virtual rows over all jobs)
     const int nrg = (r1 - r0 + 31) >> 5;
     const int RGB = 1 << p.rgb_log2, KS = NWAVE >> p.rgb_log2;
     const int rgi = wave & (RGB - 1), ks = wave >> p.rgb_log2;
@@ -234,20 +247,30 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     const uint8_t * xa = p.xq + (long) min(r, p.T - 1) * p.xq_stride + (TYPE == PM_Q4_K ? 16 : 8) * g;
     const uint8_t * bs_lane = p.bsT + lane * 16;
     const bool act = NV == 16 ? true : r < p.T;                                     // token slots >= T: operand bytes are don't-care (scale row 0, never stored)
-    Rows rw;
-    uint32_t off_d = 0;
+    Rows<MJ> rw;
     typename M::B R;
     typename M::A A0 = {}, A1 = {};                              // (inactive token lanes keep these zeros)
     auto issue_b = [&](int pr) __attribute__((always_inline)) {
         M::issue_b(R, rw, nsb, pr, lane);
-        if constexpr (TYPE == PM_Q6_K) R.d = *(const PM_G uint16_t *) (rw.base + (off_d + (uint32_t) min(2 * pr + g, nsb - 1) * 2u));   // cached: 32 steps share the line
+        if constexpr (TYPE == PM_Q6_K) R.d = *(const PM_G uint16_t *) rw.at_d((uint32_t) nsb * 208u + (uint32_t) min(2 * pr + g, nsb - 1) * 2u);   // cached: 32 steps share the line
     };
     // the first weight tile and activation slice of a row group (in flight before anything waits)
     auto first = [&](int rg) __attribute__((always_inline)) {
         const int rbase = r0 + 32 * rg;
-        rw.base = p.W + (long) rbase * p.row_stride;
-        rw.stride = (uint32_t) p.row_stride; rw.lim = r1 - 1 - rbase; rw.rr = lane >> 3; rw.rh = lane >> 1;
-        off_d = (uint32_t) min(r, rw.lim) * rw.stride + (uint32_t) nsb * 208u;
+        if constexpr (!MJ) {
+            rw.base = p.W + (long) rbase * p.row_stride;
+            rw.stride = (uint32_t) p.row_stride; rw.lim = r1 - 1 - rbase; rw.rr = lane >> 3; rw.rh = lane >> 1;
+            rw.off_d = (uint32_t) min(r, rw.lim) * rw.stride;
+        } else {
+            auto rowptr = [&](int v) __attribute__((always_inline)) {                     // virtual row -> its matrix row
+                v = min(v, r1 - 1);
+                const int j = (v >= p.start[1] && p.njobs > 1) + (v >= p.start[2] && p.njobs > 2);
+                return (j == 0 ? p.Wj[0] : j == 1 ? p.Wj[1] : p.Wj[2]) + (long) (v - (j == 0 ? 0 : j == 1 ? p.start[1] : p.start[2])) * p.row_stride;
+            };
+#pragma unroll
+            for (int n = 0; n < 4; ++n) rw.rp[n] = rowptr(rbase + (lane >> 3) + 8 * n);
+            rw.rph = rowptr(rbase + (lane >> 1)); rw.rpd = rowptr(rbase + r);
+        }
         issue_b(pb);
         M::issue_a(A0, xa, bs_lane, 2 * pb, act);
         if constexpr (ABL & 1) M::issue_a(A1, xa, bs_lane, 2 * pb, act);
@@ -298,9 +321,18 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
             for (int k = 0; k < KS; ++k) s += red[(((k << p.rgb_log2) + gi) * 16 + v) * 64 + l];
             const int t = 8 * (v >> 2) + 4 * (l >> 5) + (v & 3), row = r0 + 32 * (rg0 + gi) + (l & 31);
             if (t < p.T && row < r1) {
-                if (p.bias)  s += ld_g(p.bias + row);
-                if (p.resid) s += ld_g(p.resid + (long) t * p.y_stride + row);
-                st_g(p.y + (long) t * p.y_stride + row, s);
+                if constexpr (!MJ) {
+                    if (p.bias)  s += ld_g(p.bias + row);
+                    if (p.resid) s += ld_g(p.resid + (long) t * p.y_stride + row);
+                    st_g(p.y + (long) t * p.y_stride + row, s);
+                } else {
+                    const int j = (row >= p.start[1] && p.njobs > 1) + (row >= p.start[2] && p.njobs > 2);
+                    const int lr = row - (j == 0 ? 0 : j == 1 ? p.start[1] : p.start[2]), nj = j == 0 ? p.nj[0] : j == 1 ? p.nj[1] : p.nj[2];
+                    const float * bj = j == 0 ? p.bj[0] : j == 1 ? p.bj[1] : p.bj[2];
+                    float * yj = j == 0 ? p.yj[0] : j == 1 ? p.yj[1] : p.yj[2];
+                    if (bj) s += ld_g(bj + lr);
+                    st_g(yj + (long) t * nj + lr, s);
+                }
             }
         }
         __syncthreads();
@@ -438,5 +470,45 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
         else if (tn <= 16)   go(mmq_i8_kernel<PM_Q6_K, 8>);
         else                 go(mmq_i8_kernel<PM_Q6_K, 16>);
     }
+    return 0;
+}
+
+// Up to 3 matrices of ONE type and K sharing the activations (wq | wk | wv, ffn_gate | ffn_up) in one launch: one fill / drain of the
+// step pipeline instead of two or three (~10 us each). T <= 16 (the 32-token instantiations have no registers left for per-lane row
+// pointers); -5: not served, launch the jobs one by one. y[j]: [T][N[j]].
+int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const int * N, float * const * Y, const float * const * bias, const void * xq,
+                           int K, int T, int reuse_prep, hipStream_t st) {
+    if (njobs < 2 || njobs > 3 || T > 16) return -5;
+    long total = 0;
+    for (int j = 0; j < njobs; ++j) { if (pm_mmq_i8_check(type, K, N[j], T)) return -5; total += N[j]; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
+    const int nsb = K / 256;
+    const size_t xrow = pm_q8k_row_bytes(K), tab = (size_t) nsb * (1024 + 128);
+    if (reuse_prep ? (g_scr_bytes[dev] < 2 * tab) : !ensure_scratch(dev, K)) return -3;
+    if (!reuse_prep) launch_prep(dev, xq, K, T, st);
+    const int cus = pm_device_cus();
+    const int grid = total / 32 >= cus ? cus : (int) ((total + 31) / 32);
+    const int rows = (int) ((total + grid - 1) / grid), nrg = (rows + 31) / 32;
+    MmqP p = {};
+    p.row_stride = (long) pm_weight_row_stride(type, K); p.N = (int) total; p.K = K; p.T = T;
+    p.xq = (const uint8_t *) xq; p.xq_stride = (long) xrow; p.bsT = g_scr[dev]; p.dT = (const float *) (g_scr[dev] + (size_t) nsb * 1024);
+    p.njobs = njobs;
+    int at = 0;
+    for (int j = 0; j < 3; ++j) {
+        const int jj = j < njobs ? j : njobs - 1;
+        p.Wj[j] = (const uint8_t *) W[jj]; p.yj[j] = Y[jj]; p.bj[j] = bias ? bias[jj] : nullptr; p.nj[j] = N[jj];
+        p.start[j] = j < njobs ? at : (int) total;
+        if (j < njobs) at += N[j];
+    }
+    p.rgb_log2 = nrg >= 8 ? 3 : nrg >= 3 ? 2 : nrg == 2 ? 1 : 0;
+    const size_t lds = pm_mmq_i8_lds_bytes(type, K);
+    auto go = [&](auto kern) {
+        static bool attr[16] = {};
+        if (!attr[dev]) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr[dev] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, st, p);
+    };
+    if (type == PM_Q4_K) { if (T <= 8) go(mmq_i8_kernel<PM_Q4_K, 4, 0, true>); else go(mmq_i8_kernel<PM_Q4_K, 8, 0, true>); }
+    else                 { if (T <= 8) go(mmq_i8_kernel<PM_Q6_K, 4, 0, true>); else go(mmq_i8_kernel<PM_Q6_K, 8, 0, true>); }
     return 0;
 }

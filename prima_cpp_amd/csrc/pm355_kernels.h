@@ -95,3 +95,6 @@ int pm_mmq_i8_tables(int K, pm_q8k_tables * out);      // where a quantizer writ
 int pm_launch_mmq_i8_prep(const void * xq, int K, int T, hipStream_t st);      // the activation tables alone (then reuse_prep = 1)
 int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_f32, float * Y, int K, int N, int T,
                      const float * bias, const float * resid, int reuse_prep, hipStream_t st);
+// 2 or 3 matrices of one type and K that share the activations, as one launch (T <= 16); -5: not served, launch them one by one
+int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const int * N, float * const * Y, const float * const * bias, const void * xq,
+                           int K, int T, int reuse_prep, hipStream_t st);

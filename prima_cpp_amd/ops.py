@@ -252,6 +252,20 @@ def mul_mat_small(w, x=None, xq=None, n_tokens=None, bias=None, resid=None):
     return y
 
 
+def mul_mat_small_multi(ws, xq, n_tokens, biases=None):
+    """2 or 3 matrices of one type and K sharing the pre-quantized activations, one launch (mmq_i8.hip multi-job kernels) -> list of f32 [T, N_j]."""
+    import ctypes as C
+    lib = L.load()
+    n = len(ws)
+    lib.pm355_mul_mat_q_small_multi.restype = C.c_int
+    lib.pm355_mul_mat_q_small_multi.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    ys = [torch.empty((n_tokens, w.N), dtype=torch.float32, device=w.data.device) for w in ws]
+    Wp = (C.c_void_p * n)(*[ptr(w.data) for w in ws]); Np = (C.c_int64 * n)(*[w.N for w in ws]); Yp = (C.c_void_p * n)(*[ptr(y) for y in ys])
+    Bp = (C.c_void_p * n)(*[ptr(b) for b in biases]) if biases else None
+    check(lib.pm355_mul_mat_q_small_multi(ws[0].type, n, Wp, Np, Yp, Bp, ptr(xq), ws[0].K, n_tokens, stream_ptr()), "mul_mat_q_small_multi")
+    return ys
+
+
 def mul_mat_mfma(w, x, bias=None, resid=None):
     """Batched GEMM on MFMA: x f32 [T, K] -> f32 [T, N]."""
     import ctypes as C

@@ -216,6 +216,26 @@ def test_small_batch_matmul_on_integer_matrix_cores(P, oracle, t, T):
             assert np.allclose(y, y1, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("t", [Q4_K, Q6_K])
+def test_small_batch_matmul_multi_job_launch(P, oracle, t):
+    """wq | wk | wv and ffn_gate | ffn_up as ONE launch over a virtual row space: every job equals its own single-job launch (same integers; the
+    K split over waves may differ) and the oracle; row groups straddle the job boundaries (N not a multiple of 32)."""
+    rng = np.random.default_rng(300 + t)
+    for K, Ns, T in ((1024, (300, 70, 75), 5), (768, (2100, 2100), 16), (4096, (515, 40), 9)):
+        blocks = [rand_blocks(t, N, K, rng) for N in Ns]
+        ws = [P.upload_weight(t, b, K, N) for b, N in zip(blocks, Ns)]
+        x = rng.normal(0, 1, (T, K)).astype(np.float32)
+        biases = [rng.normal(0, 1, N).astype(np.float32) for N in Ns]
+        xq = P.quantize_act(_dev(P, x), P.vec_dot_act_type(t))
+        ys = P.mul_mat_small_multi(ws, xq, T, biases=[_dev(P, b) for b in biases])
+        for w, b, bias, y in zip(ws, blocks, biases, ys):
+            want = oracle.mul_mat(t, b, K, w.N, x) + bias[None]
+            got = y.cpu().numpy()
+            assert np.allclose(got, want, rtol=2e-5, atol=2e-5 * np.sqrt(K / 4096)), (K, w.N, np.abs(got - want).max())
+            one = P.mul_mat_small(w, xq=xq, n_tokens=T, bias=_dev(P, bias)).cpu().numpy()
+            assert np.allclose(got, one, rtol=1e-5, atol=1e-5)
+
+
 def test_rms_norm_matches_oracle(P, oracle):
     rng = np.random.default_rng(26)
     for K, eps in ((4096, 1e-5), (8192, 1e-6)):
