@@ -264,7 +264,7 @@ def probe_prefill(hp, mixture, n_tok):
     # integer-matrix-core mat-mul (mmq_i8.hip: one weight pass per 32 tokens), whole model, KV positions advancing
     try:
         sb = {}
-        for T in (4, 8, 16, 32, 64):
+        for T in (2, 3, 4, 8, 16, 32, 64):
             if T > n_tok:
                 continue
             win.kv_clear()

@@ -239,11 +239,13 @@ void layer_release(pm355_model * m, int il, hipStream_t st) {
 // quantize `src` [T][K] into the activation format(s) the given weights need; returns pointers
 struct ActQ { const void * k = nullptr; const void * z = nullptr; bool tab = false; };   // tab: the small-batch mat-mul's activation tables were written too
 const int MMQ_MIN_TOKENS = 4, MMQ_MAX_TOKENS = 64;
+const int MMQ_MULTI_MIN_TOKENS = 2;       // the fused wq | wk | wv and ffn_gate | ffn_up launches already win at 2 tokens (3 / 4 mat-vec launches otherwise)
 // the table output of the Q8_K quantizers, when this batch size takes the small-batch mat-mul (mmq_i8.hip)
 pm_q8k_tables mmq_tables(const pm355_model * m, int K, int T) {
     pm_q8k_tables tb;
-    if (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && pm_mmq_i8_tables(K, &tb) != 0) tb = pm_q8k_tables();
-    return (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq) ? tb : pm_q8k_tables();
+    const bool on = T >= (m->no_multi ? MMQ_MIN_TOKENS : MMQ_MULTI_MIN_TOKENS) && T <= MMQ_MAX_TOKENS && !m->no_mmq;
+    if (on && pm_mmq_i8_tables(K, &tb) != 0) tb = pm_q8k_tables();
+    return on ? tb : pm_q8k_tables();
 }
 ActQ quantize_for(pm355_model * m, const float * src, int K, int T, const Tensor * const * ws, int nw, hipStream_t st) {
     ActQ a; bool need_k = false, need_0 = false;
@@ -475,7 +477,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         ActQ a = norm_quantize_for(m, cur, (const float *) L.t[PM355_T_ATTN_NORM].d, E, T, qkv, 3, st);
         int rc = 0;
         bool prepped = false;
-        const bool small = T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && a.k != nullptr;
+        const bool small = T >= MMQ_MULTI_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && a.k != nullptr;   // (single launches: from MMQ_MIN_TOKENS, in matmul_small)
         // matrices of one type that share the activations go out as ONE small-batch launch (<= 16 tokens): wq | wk (| wv), ffn_gate | ffn_up
         auto multi = [&](std::initializer_list<const Tensor *> ws, std::initializer_list<float *> ys, std::initializer_list<const float *> bs) {
             const void * W[3]; int N[3]; float * Y[3]; const float * B[3]; int n = 0;
@@ -523,14 +525,19 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         if (L.t[PM355_T_FFN_GATE].type != L.t[PM355_T_FFN_UP].type)
             return seterr(m, PM355_E_UNSUPPORTED, "decode: ffn_gate and ffn_up of different types");
         const Tensor & wg = L.t[PM355_T_FFN_GATE], & wu = L.t[PM355_T_FFN_UP];
-        if (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && m->h2 && a.k && pm_mmq_i8_check(wg.type, (int) wg.K, (int) wg.N, T) == 0) {
+        bool gu_done = false;
+        if (small && m->h2 && pm_mmq_i8_check(wg.type, (int) wg.K, (int) wg.N, T) == 0) {
             // gate and up: one weight pass each for all tokens, then silu(gate) * up (the pair mat-vec would take one launch per token)
             prepped = false;
-            if (!(T <= 16 && !m->no_multi && wg.type == wu.type && multi({&wg, &wu}, {m->h, m->h2}, {nullptr, nullptr}) == 0))
-            if (matmul_small(m, wg, a, T, m->h, nullptr, nullptr, prepped, st) || matmul_small(m, wu, a, T, m->h2, nullptr, nullptr, prepped, st))
-                return seterr(m, PM355_E_UNSUPPORTED, "decode: gate/up small-batch mat-mul");
-            pm_launch_silu_mul(m->h, m->h2, m->h, (long) T * F, st);
-        } else
+            if (T <= 16 && !m->no_multi && wg.type == wu.type && multi({&wg, &wu}, {m->h, m->h2}, {nullptr, nullptr}) == 0) gu_done = true;
+            else if (T >= MMQ_MIN_TOKENS) {
+                if (matmul_small(m, wg, a, T, m->h, nullptr, nullptr, prepped, st) || matmul_small(m, wu, a, T, m->h2, nullptr, nullptr, prepped, st))
+                    return seterr(m, PM355_E_UNSUPPORTED, "decode: gate/up small-batch mat-mul");
+                gu_done = true;
+            }
+            if (gu_done) pm_launch_silu_mul(m->h, m->h2, m->h, (long) T * F, st);
+        }
+        if (!gu_done)
         if (gemv(L.t[PM355_T_FFN_GATE], &L.t[PM355_T_FFN_UP], a, T, m->h, nullptr, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: gate/up gemv");
         const Tensor * dn[1] = {&L.t[PM355_T_FFN_DOWN]};
         a = quantize_for(m, m->h, F, T, dn, 1, st);
@@ -674,7 +681,7 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
     auto A = [&](void ** p, size_t n) { return hipMalloc(p, n + 256) == hipSuccess; };
     bool ok = A((void **) &m->x, T * E * 4) && A((void **) &m->x1, T * E * 4) && A((void **) &m->xn, T * E * 4) &&
               A((void **) &m->q, T * Eq * 4) && A((void **) &m->k, T * Ekv * 4) && A((void **) &m->v, T * Ekv * 4) &&
-              A((void **) &m->att, T * Eq * 4) && A((void **) &m->h, T * F * 4) && (T < MMQ_MIN_TOKENS || A((void **) &m->h2, T * F * 4)) && A((void **) &m->logits, (size_t) hp.n_vocab * 4) &&
+              A((void **) &m->att, T * Eq * 4) && A((void **) &m->h, T * F * 4) && (T < MMQ_MULTI_MIN_TOKENS || A((void **) &m->h2, T * F * 4)) && A((void **) &m->logits, (size_t) hp.n_vocab * 4) &&
               A((void **) &m->aq_k, T * pm_q8k_row_bytes((int) ((maxK + 255) / 256 * 256))) &&
               A((void **) &m->aq_0, T * pm_q80_row_bytes((int) ((maxK + 31) / 32 * 32))) &&
               A((void **) &m->d_pos, 64 * 4) && A((void **) &m->d_ctl, 64) && A((void **) &m->d_tok, 64 + T * 4);

@@ -120,6 +120,15 @@ def test_model_shaped_layer_decode_and_prefill(E, oracle, name, monkeypatch):
         assert f < 2e-5 and g2 < 2e-4
     else:
         assert f < 5e-4 and g2 < 1e-3
+    # (4) 3-token step: wq | wk | wv and ffn_gate | ffn_up as one multi-job launch each (from 2 tokens), wo / down on the multi-column mat-vec
+    w.kv_clear()
+    hr = ref.model_new(d)
+    hid_3, lg_3, _ = w.decode(tokens=torch.from_numpy(toks[:3]).cuda(), pos0=0, want_argmax=True)
+    h3_ref, l3_ref = ref.model_eval(hr, d, tokens=toks[:3], pos0=0, n_threads=thr)
+    ref.model_free(hr)
+    f3, g3 = _nmse(hid_3.cpu().numpy(), h3_ref), _nmse(lg_3.cpu().numpy(), l3_ref)
+    print(f"[{name}] 3-token step vs reference CPU: hidden NMSE {f3:.2e}, logits NMSE {g3:.2e}")
+    assert f3 < 2e-5 and g3 < 2e-4
     w.close()
 
 
