@@ -535,12 +535,19 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
                     return seterr(m, PM355_E_UNSUPPORTED, "decode: gate/up small-batch mat-mul");
                 gu_done = true;
             }
-            if (gu_done) pm_launch_silu_mul(m->h, m->h2, m->h, (long) T * F, st);
         }
         if (!gu_done)
         if (gemv(L.t[PM355_T_FFN_GATE], &L.t[PM355_T_FFN_UP], a, T, m->h, nullptr, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: gate/up gemv");
         const Tensor * dn[1] = {&L.t[PM355_T_FFN_DOWN]};
-        a = quantize_for(m, m->h, F, T, dn, 1, st);
+        if (gu_done && L.t[PM355_T_FFN_DOWN].type != PM_Q8_0) {
+            // silu(gate) * up goes straight into the Q8_K rows (and activation tables) ffn_down reads: no f32 product, one launch less
+            const pm_q8k_tables tb = mmq_tables(m, F, T);
+            pm_launch_silu_mul_q8k(m->h, m->h2, m->aq_k, F, T, st, tb);
+            a = ActQ(); a.k = m->aq_k; a.tab = tb.base != nullptr;
+        } else {
+            if (gu_done) pm_launch_silu_mul(m->h, m->h2, m->h, (long) T * F, st);
+            a = quantize_for(m, m->h, F, T, dn, 1, st);
+        }
         // `cur` is dead after the wo GEMV consumed it as residual, so the other scratch buffer can be reused
         float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : ((x_mid == bufs[0]) ? bufs[1] : bufs[0]);
         prepped = false;

@@ -27,6 +27,8 @@ static inline bool pm_type_is_repacked(int type) { return type == 12 || type == 
 struct pm_q8k_tables { uint8_t * base = nullptr; size_t tab_bytes = 0; int nsb = 0; };
 void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStream_t st, pm_q8k_tables tab = {});
 void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStream_t st);
+// Q8_K rows of silu(gate) * up (the ffn_down activations of a small batch), no f32 product in HBM
+void pm_launch_silu_mul_q8k(const float * gate, const float * up, void * y, int K, int rows, hipStream_t st, pm_q8k_tables tab = {});
 void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st, void * ynorm_f16 = nullptr,
                            pm_q8k_tables tab = {});
 

@@ -98,6 +98,21 @@ __global__ __launch_bounds__(256) void quantize_q8k_kernel(const float * __restr
     q8k_block_from_regs(v, lane, y + (size_t) row * y_row_bytes, K, blk, tb, row);
 }
 
+// silu(gate) * up (ggml_silu + ggml_mul of llm_build_ffn, src/llama.cpp:9804; same f32 expressions as layer_ops.hip's silu_mul_kernel) fused with
+// the Q8_K quantization of the product: the ffn_down activations of a small batch, without the f32 round trip through HBM
+__global__ __launch_bounds__(256) void silu_mul_q8k_kernel(const float * __restrict__ gate, const float * __restrict__ up, uint8_t * __restrict__ y,
+                                                           int K, int rows, size_t y_row_bytes, pm_q8k_tables tb) {
+    const int lane = threadIdx.x & 63;
+    const int nblk = K / PM_QK_K;
+    const long wave = (long) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= (long) rows * nblk) return;
+    const int row = (int) (wave / nblk), blk = (int) (wave % nblk);
+    const float4 g = ((const float4 *) (gate + (size_t) row * K + (size_t) blk * PM_QK_K))[lane];
+    const float4 u = ((const float4 *) (up + (size_t) row * K + (size_t) blk * PM_QK_K))[lane];
+    const float v[4] = {g.x / (1.0f + expf(-g.x)) * u.x, g.y / (1.0f + expf(-g.y)) * u.y, g.z / (1.0f + expf(-g.z)) * u.z, g.w / (1.0f + expf(-g.w)) * u.w};
+    q8k_block_from_regs(v, lane, y + (size_t) row * y_row_bytes, K, blk, tb, row);
+}
+
 // Q8_0: 32-value blocks, 8 lanes x 4 values; amax over the 8-lane group.
 __global__ __launch_bounds__(256) void quantize_q80_kernel(const float * __restrict__ x, uint8_t * __restrict__ y,
                                                            int K, int rows, size_t y_row_bytes) {
@@ -185,6 +200,10 @@ void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStrea
     const long waves = (long) rows * (K / PM_QK_K);
     hipLaunchKernelGGL(quantize_q8k_kernel, dim3((unsigned) ((waves + 3) / 4)), dim3(256), 0, st,
                        x, (uint8_t *) y, K, rows, pm_q8k_row_bytes(K), tab);
+}
+void pm_launch_silu_mul_q8k(const float * gate, const float * up, void * y, int K, int rows, hipStream_t st, pm_q8k_tables tab) {
+    const long waves = (long) rows * (K / PM_QK_K);
+    hipLaunchKernelGGL(silu_mul_q8k_kernel, dim3((unsigned) ((waves + 3) / 4)), dim3(256), 0, st, gate, up, (uint8_t *) y, K, rows, pm_q8k_row_bytes(K), tab);
 }
 void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStream_t st) {
     const long n = (long) rows * (K / 4);
