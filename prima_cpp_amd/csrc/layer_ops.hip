@@ -143,12 +143,27 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float * q, const
     for (int i = tid; i < n_kv; i += 256) {
         const uint16_t * kr = kc + (long) i * Hkv * dh + (long) hk * dh;
         float acc = 0.0f;
-        for (int e = 0; e < dh; e += 8) {
-            const u32x4 kk = *(const u32x4 *) (kr + e);
+        for (int e0 = 0; e0 < dh; e0 += 32) {    // 4 loads in flight per step (dh % 32 == 0 for every head size served: 64, 128, 256; else the tail below)
+            if (e0 + 32 <= dh) {
+                u32x4 kk[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc += h2f((uint16_t) (kk[j] & 0xFFFF)) * qs[e + 2 * j];
-                acc += h2f((uint16_t) (kk[j] >> 16)) * qs[e + 2 * j + 1];
+                for (int c = 0; c < 4; ++c) kk[c] = *(const u32x4 *) (kr + e0 + 8 * c);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc += h2f((uint16_t) (kk[c][j] & 0xFFFF)) * qs[e0 + 8 * c + 2 * j];
+                        acc += h2f((uint16_t) (kk[c][j] >> 16)) * qs[e0 + 8 * c + 2 * j + 1];
+                    }
+            } else {
+                for (int e = e0; e < dh; e += 8) {
+                    const u32x4 kk = *(const u32x4 *) (kr + e);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc += h2f((uint16_t) (kk[j] & 0xFFFF)) * qs[e + 2 * j];
+                        acc += h2f((uint16_t) (kk[j] >> 16)) * qs[e + 2 * j + 1];
+                    }
+                }
             }
         }
         const float s = acc * scale;             // mask is 0 for visible keys
@@ -178,19 +193,30 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float * q, const
     for (int i = tid; i < n_pad; i += 256) sc[i] = i < n_kv ? h2f(f2h(sc[i] * inv)) : 0.0f;   // p rounded to F16
     __syncthreads();
     // ---- out[e] = sum_i V^T[hk*dh+e][i] * p[i]; wave w owns e = w, w+4, ...; 8 keys per lane per step
-    for (int e = wave; e < dh; e += 4) {
-        const uint16_t * vr = vc + (long) (hk * dh + e) * n_ctx;
-        float acc = 0.0f;
+    // (8 output elements per pass: their V loads are in flight together - one dependent load per element made this phase a chain of
+    //  dh / 4 L2 round trips, 22 us per layer for an 8-token batch of the 70B shape; same per-element summation order)
+    for (int e0 = wave; e0 < dh; e0 += 32) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int i = lane * 8; i < n_pad; i += 512) {
-            const u32x4 vv = *(const u32x4 *) (vr + i);
+            u32x4 vv[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc += h2f((uint16_t) (vv[j] & 0xFFFF)) * sc[i + 2 * j];
-                acc += h2f((uint16_t) (vv[j] >> 16)) * sc[i + 2 * j + 1];
-            }
+            for (int k = 0; k < 8; ++k) vv[k] = *(const u32x4 *) (vc + (long) (hk * dh + min(e0 + 4 * k, dh - 1)) * n_ctx + i);
+            float p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = sc[i + j];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[k] += h2f((uint16_t) (vv[k][j] & 0xFFFF)) * p[2 * j];
+                    acc[k] += h2f((uint16_t) (vv[k][j] >> 16)) * p[2 * j + 1];
+                }
         }
-        acc = wave_sum(acc);
-        if (lane == 0) out[((long) t * H + h) * dh + e] = acc;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float a = wave_sum(acc[k]);
+            if (lane == 0 && e0 + 4 * k < dh) out[((long) t * H + h) * dh + e0 + 4 * k] = a;
+        }
     }
 }
 
