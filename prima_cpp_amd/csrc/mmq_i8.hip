@@ -42,6 +42,7 @@ constexpr int PITCH_H = 48;           // same for the 2 x 16-byte per-row header
 
 struct MmqP {
     const uint8_t * W; long row_stride; int N, K, T, rgb_log2;     // 1 << rgb_log2 row groups per batch (1, 2, 4, 8)
+    int t_off;                                                     // first table slot of this pass (16-token passes of a 32-slot table)
     const uint8_t * xq; long xq_stride;                            // row-SoA Q8_K activations [T]
     const uint8_t * bsT; const float * dT;                         // prologue tables: [nsb][64 lanes][8 f16], [nsb][32]
     float * y; long y_stride; const float * bias; const float * resid;
@@ -67,12 +68,14 @@ template <> struct Rows<false> {          // one matrix: wave-uniform base + 32-
     __device__ __forceinline__ const uint8_t * at(int n, uint32_t x) const { return base + ((uint32_t) min(rr + 8 * n, lim) * stride + x); }
     __device__ __forceinline__ const uint8_t * at_h(uint32_t x) const { return base + ((uint32_t) min(rh, lim) * stride + x); }
     __device__ __forceinline__ const uint8_t * at_d(uint32_t x) const { return base + (off_d + x); }
+    __device__ __forceinline__ const uint8_t * at_row(int row, uint32_t x) const { return base + ((uint32_t) min(row, lim) * stride + x); }   // any row of the group
 };
 template <> struct Rows<true> {           // several matrices: a lane's rows may sit in different allocations -> 64-bit row pointers per lane
     const uint8_t * rp[4], * rph, * rpd;
     __device__ __forceinline__ const uint8_t * at(int n, uint32_t x) const { return rp[n] + x; }
     __device__ __forceinline__ const uint8_t * at_h(uint32_t x) const { return rph + x; }
     __device__ __forceinline__ const uint8_t * at_d(uint32_t x) const { return rpd + x; }
+    __device__ __forceinline__ const uint8_t * at_row(int, uint32_t) const { return nullptr; }     // (native-layout types are single-job only)
 };
 
 template <int TYPE> struct MT;
@@ -133,6 +136,74 @@ template <> struct MT<PM_Q4_K> {
         }
         const f32x16 fz = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const f32x16 ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.bs, bm, fz, 0, 0, 0);   // sum_s min_s * (bsum[2s] + bsum[2s+1]), exact
+        const float d = h2f((uint16_t) (hd[0] & 0xFFFF)), dmin = h2f((uint16_t) (hd[0] >> 16));
+#pragma unroll
+        for (int q = 0; q < NV / 4; ++q) {
+            const f32x4 yd = *(const f32x4 *) (yd_lds + 8 * q + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = 4 * q + i;
+                out[v] = fmaf(yd[i] * d, (float) isum[v], fmaf(-(yd[i] * dmin), ms[v], out[v]));
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------- Q5_K: native 176-byte blocks (d, dmin | scales[12] | qh[32] | qs[128]) ------
+// A step's 2 super-blocks are 352 contiguous bytes per row = 22 chunks of 16: lane l fetches chunks l, l + 64, ... (11 loads) of the 32 x 22
+// chunk tile; LDS row pitch 368 B (23 x 16: 16 consecutive rows -> 16 distinct bank slots).
+template <> struct MT<PM_Q5_K> {
+    static constexpr int RP = 368, WAVE_LDS = 32 * RP;
+    struct B { u32x4 c[11]; };
+    struct A { u32x4 q[8]; f16x8 bs; };
+    template <class RW>
+    static __device__ __forceinline__ void issue_b(B & b, const RW & rw, int nb, int pr, int lane) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            const int ci = lane + 64 * i, row = ci / 22, c = ci - row * 22;
+            const int sb = min(2 * pr + (c >= 11), nb - 1);
+            b.c[i] = ld_nt16(rw.at_row(row, (uint32_t) sb * 176u + (uint32_t) (c >= 11 ? c - 11 : c) * 16u));
+        }
+    }
+    static __device__ __forceinline__ void stash(const B & b, uint8_t * L, int lane) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            const int ci = lane + 64 * i, row = ci / 22, c = ci - row * 22;
+            *(u32x4 *) (L + row * RP + c * 16) = b.c[i];
+        }
+    }
+    static __device__ __forceinline__ void issue_a(A & a, const uint8_t * xa /*token row + 16 g*/, const uint8_t * bs_lane, int sb, bool act) {
+        if (act) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) a.q[s] = ld_c16(xa + sb * 256 + 32 * s);
+            a.bs = *(const PM_G f16x8 *) (bs_lane + (size_t) sb * 1024);
+        }
+    }
+    template <int NV>
+    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out) {
+        const uint8_t * blk = L + r * RP + sbi * 176;
+        const u32x4 hd = *(const u32x4 *) blk;
+        const u32x4 qh = *(const u32x4 *) (blk + 16 + 16 * g);       // bit s of byte l: fifth bit of weight l of sub-block s (l = 16 g + i)
+        const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        i32x16 isum = zero;
+        const uint32_t sc4[2] = {hd[1] & 0x3f3f3f3fu, (hd[3] & 0x0f0f0f0fu) | ((hd[1] >> 2) & 0x30303030u)};
+        const uint32_t mn4[2] = {hd[2] & 0x3f3f3f3fu, ((hd[3] >> 4) & 0x0f0f0f0fu) | ((hd[2] >> 2) & 0x30303030u)};
+        f16x8 bm;
+#pragma unroll
+        for (int sb = 0; sb < 8; ++sb) bm[sb] = (_Float16) (float) ((mn4[sb >> 2] >> (8 * (sb & 3))) & 0xFFu);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 w = *(const u32x4 *) (blk + 48 + 32 * j + 16 * g);
+            const int sc0 = (int) ((sc4[(2 * j) >> 2] >> (8 * ((2 * j) & 3))) & 0xFFu), sc1 = (int) ((sc4[(2 * j + 1) >> 2] >> (8 * ((2 * j + 1) & 3))) & 0xFFu);
+            i32x16 acc = mfma_i8x32(a.q[2 * j], (w & 0x0F0F0F0Fu) | (((qh >> (2 * j)) & 0x01010101u) << 4), zero);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) { isum[v] = __mul24(sc0, acc[v]) + isum[v]; asm volatile("" : "+v"(isum[v])); }
+            acc = mfma_i8x32(a.q[2 * j + 1], ((w >> 4) & 0x0F0F0F0Fu) | (((qh >> (2 * j + 1)) & 0x01010101u) << 4), zero);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) { isum[v] = __mul24(sc1, acc[v]) + isum[v]; asm volatile("" : "+v"(isum[v])); }
+        }
+        const f32x16 fz = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const f32x16 ms = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.bs, bm, fz, 0, 0, 0);
         const float d = h2f((uint16_t) (hd[0] & 0xFFFF)), dmin = h2f((uint16_t) (hd[0] >> 16));
 #pragma unroll
         for (int q = 0; q < NV / 4; ++q) {
@@ -244,8 +315,8 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     const int pb = npairs * ks / KS, pe = npairs * (ks + 1) / KS;
     uint8_t * L = stage + wave * M::WAVE_LDS;
     const int r = lane & 31, g = lane >> 5;
-    const uint8_t * xa = p.xq + (long) min(r, p.T - 1) * p.xq_stride + (TYPE == PM_Q4_K ? 16 : 8) * g;
-    const uint8_t * bs_lane = p.bsT + lane * 16;
+    const uint8_t * xa = p.xq + (long) min(r, p.T - 1) * p.xq_stride + (TYPE == PM_Q6_K ? 8 : 16) * g;
+    const uint8_t * bs_lane = p.bsT + (lane + p.t_off) * 16;
     const bool act = NV == 16 ? true : r < p.T;                                     // token slots >= T: operand bytes are don't-care (scale row 0, never stored)
     Rows<MJ> rw;
     typename M::B R;
@@ -276,11 +347,9 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
         if constexpr (ABL & 1) M::issue_a(A1, xa, bs_lane, 2 * pb, act);
     };
     if (rgi < nrg && pb < pe) first(rgi);                         // ... including the staging of the scale table:
-    for (int i = tid; i < nsb * 8; i += BLOCK) {                  // (slots >= T masked here: a quantizer that writes the table itself fills rows < T only)
-        f32x4 d4 = *((const PM_G f32x4 *) p.dT + i);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) if (((4 * i + c) & 31) >= p.T) d4[c] = 0.0f;
-        ((f32x4 *) dTl)[i] = d4;
+    for (int i = tid; i < nsb * 32; i += BLOCK) {                 // (slots >= T masked here: a quantizer that writes the table itself fills rows < T only)
+        const int t = i & 31;
+        dTl[i] = t < p.T ? *((const PM_G float *) p.dT + (i + p.t_off)) : 0.0f;
     }
     if (tid < 32) dTl[nsb * 32 + tid] = 0.0f;
     __syncthreads();
@@ -358,13 +427,13 @@ size_t g_scr_bytes[16] = {};
 }  // namespace
 
 size_t pm_mmq_i8_lds_bytes(int type, int K) {
-    const size_t w = type == PM_Q4_K ? MT<PM_Q4_K>::WAVE_LDS : MT<PM_Q6_K>::WAVE_LDS;
+    const size_t w = type == PM_Q4_K ? MT<PM_Q4_K>::WAVE_LDS : type == PM_Q5_K ? MT<PM_Q5_K>::WAVE_LDS : MT<PM_Q6_K>::WAVE_LDS;
     return (size_t) (K / 256 + 1) * 128 + NWAVE * w;
 }
 
 // 0 when pm_launch_mmq_i8 serves this shape
 int pm_mmq_i8_check(int type, int K, int N, int T) {
-    if (type != PM_Q4_K && type != PM_Q6_K) return -1;
+    if (type != PM_Q4_K && type != PM_Q5_K && type != PM_Q6_K) return -1;
     if (T < 1 || T > 64 || K % 256 || K < 512 || N < 1) return -2;
     if (pm_mmq_i8_lds_bytes(type, K) > 150 * 1024) return -4;
     return 0;
@@ -372,8 +441,6 @@ int pm_mmq_i8_check(int type, int K, int N, int T) {
 
 // Y[t][n] = W[n,:] . x[t,:] (+bias[n]) (+resid[t][n]) for 1 <= T <= 64 tokens (passes of up to 32). xq: activations already in the library's row-SoA Q8_K
 // form (quantize.hip), or null and x_f32 [T][K] is quantized first. Y / resid token stride = N.
-// Tokens per launch: 32 for Q6_K; 16 for Q4_K (its 32-token instantiation needs 8 live 16-register MFMA tiles on top of the prefetch
-// registers and spills 420 B / lane - two 16-token passes are faster).
 namespace {
 // scratch for K (tables of two 32-token passes + a quantized copy of up to 64 f32 rows); false: allocation failed
 bool ensure_scratch(int dev, int K) {
@@ -440,12 +507,13 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
     const int grid = N / 32 >= cus ? cus : (N + 31) / 32;
     const int rows = (N + grid - 1) / grid, nrg = (rows + 31) / 32;
     const size_t lds = pm_mmq_i8_lds_bytes(type, K);
-    const int tmax = 32;
+    const int tmax = type == PM_Q5_K ? 16 : 32;                    // (Q5_K: 11 weight registers more per step - its 32-token form spills 388 B / lane)
     for (int t0 = 0, c = 0; t0 < T; t0 += tmax, ++c) {
         const int tn = T - t0 < tmax ? T - t0 : tmax;
-        uint8_t * bsT = g_scr[dev] + c * tab; float * dT = (float *) (bsT + (size_t) nsb * 1024);
+        uint8_t * bsT = g_scr[dev] + (t0 / 32) * tab; float * dT = (float *) (bsT + (size_t) nsb * 1024);    // tables are per 32 tokens
         const uint8_t * xc = (const uint8_t *) xq + (size_t) t0 * xrow;
         MmqP p = {};
+        p.t_off = t0 % 32;
         p.W = (const uint8_t *) W; p.row_stride = (long) pm_weight_row_stride(type, K); p.N = N; p.K = K; p.T = tn;
         p.xq = xc; p.xq_stride = (long) xrow; p.bsT = bsT; p.dT = dT;
         p.y = Y + (size_t) t0 * N; p.y_stride = N; p.bias = bias; p.resid = resid ? resid + (size_t) t0 * N : nullptr;
@@ -466,6 +534,7 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
         } else
 #endif
         if (type == PM_Q4_K) { if (tn <= 8) go(mmq_i8_kernel<PM_Q4_K, 4>); else if (tn <= 16) go(mmq_i8_kernel<PM_Q4_K, 8>); else go(mmq_i8_kernel<PM_Q4_K, 16>); }
+        else if (type == PM_Q5_K) { if (tn <= 8) go(mmq_i8_kernel<PM_Q5_K, 4>); else go(mmq_i8_kernel<PM_Q5_K, 8>); }
         else if (tn <= 8)    go(mmq_i8_kernel<PM_Q6_K, 4>);
         else if (tn <= 16)   go(mmq_i8_kernel<PM_Q6_K, 8>);
         else                 go(mmq_i8_kernel<PM_Q6_K, 16>);
@@ -478,7 +547,7 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
 // pointers); -5: not served, launch the jobs one by one. y[j]: [T][N[j]].
 int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const int * N, float * const * Y, const float * const * bias, const void * xq,
                            int K, int T, int reuse_prep, hipStream_t st) {
-    if (njobs < 2 || njobs > 3 || T > 16) return -5;
+    if (njobs < 2 || njobs > 3 || T > 16 || (type != PM_Q4_K && type != PM_Q6_K)) return -5;
     long total = 0;
     for (int j = 0; j < njobs; ++j) { if (pm_mmq_i8_check(type, K, N[j], T)) return -5; total += N[j]; }
     int dev = 0;

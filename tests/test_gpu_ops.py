@@ -190,7 +190,7 @@ def test_gemv_epilogues_and_columns(P, oracle, t, C):
 
 
 @pytest.mark.parametrize("T", [1, 2, 5, 8, 16, 17, 32, 33, 64])
-@pytest.mark.parametrize("t", [Q4_K, Q6_K])
+@pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K])
 def test_small_batch_matmul_on_integer_matrix_cores(P, oracle, t, T):
     """mmq_i8.hip: same integer block sums as the mat-vec (vec_dot_q4_K_q8_K / vec_dot_q6_K_q8_K), f32 super-block terms added in a
     different order -> oracle.mul_mat within the mat-vec's tolerance. Shapes: ragged row slices (N = 70: clamped rows), several row
