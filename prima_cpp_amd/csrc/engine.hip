@@ -241,16 +241,16 @@ struct ActQ { const void * k = nullptr; const void * z = nullptr; bool tab = fal
 const int MMQ_MIN_TOKENS = 4, MMQ_MAX_TOKENS = 64;
 const int MMQ_MULTI_MIN_TOKENS = 2;       // the fused wq | wk | wv and ffn_gate | ffn_up launches already win at 2 tokens (3 / 4 mat-vec launches otherwise)
 // the table output of the Q8_K quantizers, when this batch size takes the small-batch mat-mul (mmq_i8.hip)
-pm_q8k_tables mmq_tables(const pm355_model * m, int K, int T) {
+pm_q8k_tables mmq_tables(const pm355_model * m, int K, int T, hipStream_t st) {
     pm_q8k_tables tb;
     const bool on = T >= (m->no_multi ? MMQ_MIN_TOKENS : MMQ_MULTI_MIN_TOKENS) && T <= MMQ_MAX_TOKENS && !m->no_mmq;
-    if (on && pm_mmq_i8_tables(K, &tb) != 0) tb = pm_q8k_tables();
+    if (on && pm_mmq_i8_tables(K, st, &tb) != 0) tb = pm_q8k_tables();
     return on ? tb : pm_q8k_tables();
 }
 ActQ quantize_for(pm355_model * m, const float * src, int K, int T, const Tensor * const * ws, int nw, hipStream_t st) {
     ActQ a; bool need_k = false, need_0 = false;
     for (int i = 0; i < nw; ++i) if (ws[i] && ws[i]->d) { if (ws[i]->type == PM_Q8_0) need_0 = true; else need_k = true; }
-    if (need_k) { const pm_q8k_tables tb = mmq_tables(m, K, T); pm_launch_quantize_q8k(src, m->aq_k, K, T, st, tb); a.k = m->aq_k; a.tab = tb.base != nullptr; }
+    if (need_k) { const pm_q8k_tables tb = mmq_tables(m, K, T, st); pm_launch_quantize_q8k(src, m->aq_k, K, T, st, tb); a.k = m->aq_k; a.tab = tb.base != nullptr; }
     if (need_0) { pm_launch_quantize_q80(src, m->aq_0, K, T, st); a.z = m->aq_0; }
     return a;
 }
@@ -259,7 +259,7 @@ ActQ norm_quantize_for(pm355_model * m, const float * src, const float * w, int 
     bool need_0 = false;
     for (int i = 0; i < nw; ++i) if (ws[i] && ws[i]->d && ws[i]->type == PM_Q8_0) need_0 = true;
     if (!need_0) {
-        const pm_q8k_tables tb = mmq_tables(m, K, T);
+        const pm_q8k_tables tb = mmq_tables(m, K, T, st);
         pm_launch_rmsnorm_q8k(src, w, nullptr, m->aq_k, K, T, m->hp.rms_eps, st, nullptr, tb);
         ActQ a; a.k = m->aq_k; a.tab = tb.base != nullptr; return a;
     }
@@ -541,7 +541,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         const Tensor * dn[1] = {&L.t[PM355_T_FFN_DOWN]};
         if (gu_done && L.t[PM355_T_FFN_DOWN].type != PM_Q8_0) {
             // silu(gate) * up goes straight into the Q8_K rows (and activation tables) ffn_down reads: no f32 product, one launch less
-            const pm_q8k_tables tb = mmq_tables(m, F, T);
+            const pm_q8k_tables tb = mmq_tables(m, F, T, st);
             pm_launch_silu_mul_q8k(m->h, m->h2, m->aq_k, F, T, st, tb);
             a = ActQ(); a.k = m->aq_k; a.tab = tb.base != nullptr;
         } else {

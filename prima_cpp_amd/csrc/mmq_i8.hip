@@ -29,6 +29,7 @@
 // group and their f32 partial tiles are added in a fixed order through LDS (bitwise reproducible).
 #include "pm355_device.h"
 #include "pm355_kernels.h"
+#include <mutex>
 
 namespace {
 
@@ -421,8 +422,13 @@ __global__ __launch_bounds__(64) void mmq_prep_kernel(const uint8_t * xq, long x
 }
 
 // per-device scratch (grown on demand, like mmq.hip's f16 activation copy): quantized activations of an f32 call + the two tables
-uint8_t * g_scr[16] = {};
-size_t g_scr_bytes[16] = {};
+// scratch per (device, stream): the tables of a pass and the quantized copy of an f32 call are written and read in stream order, so two
+// streams of one device (two ggml backends, the engine next to the plug-in) must not share them
+struct Scr { hipStream_t st; uint8_t * p; size_t bytes; uint64_t use; };
+constexpr int NSCR = 8;
+Scr g_scr[16][NSCR] = {};
+uint64_t g_tick = 0;
+std::mutex g_scr_mu;
 
 }  // namespace
 
@@ -442,23 +448,32 @@ int pm_mmq_i8_check(int type, int K, int N, int T) {
 // Y[t][n] = W[n,:] . x[t,:] (+bias[n]) (+resid[t][n]) for 1 <= T <= 64 tokens (passes of up to 32). xq: activations already in the library's row-SoA Q8_K
 // form (quantize.hip), or null and x_f32 [T][K] is quantized first. Y / resid token stride = N.
 namespace {
-// scratch for K (tables of two 32-token passes + a quantized copy of up to 64 f32 rows); false: allocation failed
-bool ensure_scratch(int dev, int K) {
+// scratch of (device, stream) for K: tables of two 32-token passes + a quantized copy of up to 64 f32 rows; null: allocation failed (or,
+// lookup_only, no scratch of this stream holds tables for K)
+Scr * scratch(int dev, hipStream_t st, int K, bool lookup_only) {
     const size_t xrow = pm_q8k_row_bytes(K), tab = (size_t) (K / 256) * (1024 + 128);
     const size_t need = 2 * tab + (size_t) 64 * xrow + 256;
-    if (need <= g_scr_bytes[dev]) return true;
-    if (g_scr[dev]) { (void) hipDeviceSynchronize(); (void) hipFree(g_scr[dev]); }
-    if (hipMalloc((void **) &g_scr[dev], need) != hipSuccess) { g_scr[dev] = nullptr; g_scr_bytes[dev] = 0; return false; }
-    (void) hipMemset(g_scr[dev], 0, need);                          // table slots no quantizer ever wrote stay finite (they are multiplied by scale 0)
-    g_scr_bytes[dev] = need;
-    return true;
+    std::lock_guard<std::mutex> lk(g_scr_mu);
+    Scr * e = nullptr, * lru = &g_scr[dev][0];
+    for (Scr & c : g_scr[dev]) {
+        if (c.p && c.st == st) { e = &c; break; }
+        if (!c.p) { if (lru->p) lru = &c; } else if (lru->p && c.use < lru->use) lru = &c;
+    }
+    if (e && (e->bytes >= need || (lookup_only && e->bytes >= 2 * tab))) { e->use = ++g_tick; return e; }
+    if (lookup_only) return nullptr;
+    if (!e) e = lru;
+    if (e->p) { (void) hipDeviceSynchronize(); (void) hipFree(e->p); e->p = nullptr; e->bytes = 0; }
+    if (hipMalloc((void **) &e->p, need) != hipSuccess) { e->p = nullptr; return nullptr; }
+    (void) hipMemset(e->p, 0, need);                                // table slots no quantizer ever wrote stay finite (they are multiplied by scale 0)
+    e->st = st; e->bytes = need; e->use = ++g_tick;
+    return e;
 }
 // activation tables of every 32-token pass
-void launch_prep(int dev, const void * xq, int K, int T, hipStream_t st) {
+void launch_prep(const Scr * sc, const void * xq, int K, int T, hipStream_t st) {
     const int nsb = K / 256;
     const size_t xrow = pm_q8k_row_bytes(K), tab = (size_t) nsb * (1024 + 128);
     for (int t0 = 0, c = 0; t0 < T; t0 += 32, ++c) {
-        uint8_t * bsT = g_scr[dev] + c * tab;
+        uint8_t * bsT = sc->p + c * tab;
         hipLaunchKernelGGL(mmq_prep_kernel, dim3(nsb), dim3(64), 0, st, (const uint8_t *) xq + (size_t) t0 * xrow, (long) xrow, K, T - t0 < 32 ? T - t0 : 32,
                            bsT, (float *) (bsT + (size_t) nsb * 1024));
     }
@@ -467,11 +482,13 @@ void launch_prep(int dev, const void * xq, int K, int T, hipStream_t st) {
 
 // Where the tables for K live: pm_launch_quantize_q8k / pm_launch_rmsnorm_q8k write them as a second output (<= 64 rows), the mat-mul is
 // then launched with reuse_prep = 1 and no prologue launch at all.
-int pm_mmq_i8_tables(int K, pm_q8k_tables * out) {
+int pm_mmq_i8_tables(int K, hipStream_t st, pm_q8k_tables * out) {
     if (K % 256 || K < 512) return -2;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !ensure_scratch(dev, K)) return -3;
-    out->base = g_scr[dev]; out->nsb = K / 256; out->tab_bytes = (size_t) (K / 256) * (1024 + 128);
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
+    const Scr * sc = scratch(dev, st, K, false);
+    if (!sc) return -3;
+    out->base = sc->p; out->nsb = K / 256; out->tab_bytes = (size_t) (K / 256) * (1024 + 128);
     return 0;
 }
 
@@ -480,8 +497,10 @@ int pm_mmq_i8_tables(int K, pm_q8k_tables * out) {
 int pm_launch_mmq_i8_prep(const void * xq, int K, int T, hipStream_t st) {
     if (T < 1 || T > 64 || K % 256 || K < 512) return -2;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !ensure_scratch(dev, K)) return -3;
-    launch_prep(dev, xq, K, T, st);
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
+    const Scr * sc = scratch(dev, st, K, false);
+    if (!sc) return -3;
+    launch_prep(sc, xq, K, T, st);
     return 0;
 }
 
@@ -496,13 +515,14 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
     const int nsb = K / 256;
     const size_t xrow = pm_q8k_row_bytes(K), tab = (size_t) nsb * (1024 + 128);
-    if (reuse_prep ? (g_scr_bytes[dev] < 2 * tab) : !ensure_scratch(dev, K)) return -3;
+    const Scr * sc = scratch(dev, st, K, reuse_prep != 0);
+    if (!sc) return -3;
     if (!xq) {
-        uint8_t * q = g_scr[dev] + 2 * tab;
+        uint8_t * q = sc->p + 2 * tab;
         if (!reuse_prep) pm_launch_quantize_q8k(x_f32, q, K, T, st);
         xq = q;
     }
-    if (!reuse_prep) launch_prep(dev, xq, K, T, st);
+    if (!reuse_prep) launch_prep(sc, xq, K, T, st);
     const int cus = pm_device_cus();
     const int grid = N / 32 >= cus ? cus : (N + 31) / 32;
     const int rows = (N + grid - 1) / grid, nrg = (rows + 31) / 32;
@@ -510,7 +530,7 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
     const int tmax = type == PM_Q5_K ? 16 : 32;                    // (Q5_K: 11 weight registers more per step - its 32-token form spills 388 B / lane)
     for (int t0 = 0, c = 0; t0 < T; t0 += tmax, ++c) {
         const int tn = T - t0 < tmax ? T - t0 : tmax;
-        uint8_t * bsT = g_scr[dev] + (t0 / 32) * tab; float * dT = (float *) (bsT + (size_t) nsb * 1024);    // tables are per 32 tokens
+        uint8_t * bsT = sc->p + (t0 / 32) * tab; float * dT = (float *) (bsT + (size_t) nsb * 1024);    // tables are per 32 tokens
         const uint8_t * xc = (const uint8_t *) xq + (size_t) t0 * xrow;
         MmqP p = {};
         p.t_off = t0 % 32;
@@ -553,15 +573,16 @@ int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const in
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
     const int nsb = K / 256;
-    const size_t xrow = pm_q8k_row_bytes(K), tab = (size_t) nsb * (1024 + 128);
-    if (reuse_prep ? (g_scr_bytes[dev] < 2 * tab) : !ensure_scratch(dev, K)) return -3;
-    if (!reuse_prep) launch_prep(dev, xq, K, T, st);
+    const size_t xrow = pm_q8k_row_bytes(K);
+    const Scr * sc = scratch(dev, st, K, reuse_prep != 0);
+    if (!sc) return -3;
+    if (!reuse_prep) launch_prep(sc, xq, K, T, st);
     const int cus = pm_device_cus();
     const int grid = total / 32 >= cus ? cus : (int) ((total + 31) / 32);
     const int rows = (int) ((total + grid - 1) / grid), nrg = (rows + 31) / 32;
     MmqP p = {};
     p.row_stride = (long) pm_weight_row_stride(type, K); p.N = (int) total; p.K = K; p.T = T;
-    p.xq = (const uint8_t *) xq; p.xq_stride = (long) xrow; p.bsT = g_scr[dev]; p.dT = (const float *) (g_scr[dev] + (size_t) nsb * 1024);
+    p.xq = (const uint8_t *) xq; p.xq_stride = (long) xrow; p.bsT = sc->p; p.dT = (const float *) (sc->p + (size_t) nsb * 1024);
     p.njobs = njobs;
     int at = 0;
     for (int j = 0; j < 3; ++j) {

@@ -93,7 +93,7 @@ void pm_launch_barrier_probe(int n, void * ctr, hipStream_t st);       // measur
 // small-batch (1..32 tokens) quantized mat-mul on the integer matrix cores (mmq_i8.hip): Q4_K / Q6_K weights, Q8_K activations
 // (xq row-SoA, or x_f32 quantized first into a per-device scratch). 0, or -1 type / -2 shape / -3 device / -4 LDS
 int pm_mmq_i8_check(int type, int K, int N, int T);
-int pm_mmq_i8_tables(int K, pm_q8k_tables * out);      // where a quantizer writes the tables for K (<= 64 rows); then reuse_prep = 1
+int pm_mmq_i8_tables(int K, hipStream_t st, pm_q8k_tables * out);      // where a quantizer writes the tables for K (<= 64 rows); then reuse_prep = 1
 int pm_launch_mmq_i8_prep(const void * xq, int K, int T, hipStream_t st);      // the activation tables alone (then reuse_prep = 1)
 int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_f32, float * Y, int K, int N, int T,
                      const float * bias, const float * resid, int reuse_prep, hipStream_t st);
