@@ -1,32 +1,37 @@
-// mmq_i8.hip — small-batch (up to 32 tokens per pass, 64 per call) quantized mat-mul on the INTEGER matrix cores (v_mfma_i32_32x32x16_i8).
+// mmq_i8.hip — small-batch (up to 32 tokens per pass, 64 per call) quantized mat-mul on the INTEGER matrix cores
+// (v_mfma_i32_32x32x32_i8 / v_mfma_i32_32x32x16_i8). Q4_K, Q5_K, Q6_K weights x Q8_K activations.
 //
-// What it replaces: for 2..32 activation rows the reference runs ggml_compute_forward_mul_mat's vec_dot loop once per (row, token)
-// (ggml/src/ggml.c ggml_compute_forward_mul_mat -> ggml_vec_dot_q4_K_q8_K / ggml_vec_dot_q6_K_q8_K, ggml-quants.c), its CUDA plug-in
-// the integer mmq tiles (ggml-cuda/mmq.cuh:2583). The arithmetic here is the reference's own: activations quantized to Q8_K, exact
-// int32 sums  sum_s scale_s * (q_w . q_a)  and  sum_s min_s * bsum_s  per 256-weight super-block, then ONE f32 multiply-add per
+// What it replaces: for 2..64 activation rows the reference runs ggml_compute_forward_mul_mat's vec_dot loop once per (row, token)
+// (ggml/src/ggml.c:12377 -> ggml_vec_dot_q4_K_q8_K / ggml_vec_dot_q5_K_q8_K / ggml_vec_dot_q6_K_q8_K, ggml-quants.c:7713 / :8281 / :8918), its
+// CUDA plug-in the integer mmq tiles (ggml-cuda/mmq.cuh:2583). The arithmetic here is the reference's own: activations quantized to Q8_K,
+// exact int32 sums  sum_s scale_s * (q_w . q_a)  and  sum_s min_s * bsum_s  per 256-weight super-block, then ONE f32 multiply-add per
 // super-block with d_w * d_a - only the order in which the super-block terms are added in f32 differs (K split over waves).
 //
 // Why a third mat-mul kernel: between the mat-vec (1 token: weight-stream bound) and the F16 MFMA GEMM (256-token tiles: a 16-token
-// batch pays for 256) sits the regime of speculative decoding, parallel sequences and prompt tails. The multi-column mat-vec
+// batch pays for 256) sits the regime of speculative decoding, parallel sequences and short prompts. The multi-column mat-vec
 // (mmvq_cols.hip) re-reads its activations from LDS for every decoded weight and costs ~10 us per extra column on the ffn_gate shape
-// (profiles/r02_cols_probe.txt); this kernel streams the weights ONCE for up to 32 tokens and does the products on the matrix cores.
+// (profiles/r02_small_batch_probe.txt); this kernel streams the weights ONCE per 32 tokens and does the products on the matrix cores.
 //
-// Mapping (one v_mfma_i32_32x32x16_i8 = 32 tokens x 32 weight rows x 16 k):
-//   A operand = activations: lane (t = lane % 32, g = lane / 32) holds 8 consecutive int8 of token t
-//   B operand = weights    : lane (r = lane % 32, g)            holds 8 int8 of weight row r  (same k as A)
+// Mapping (one MFMA = 32 tokens x 32 weight rows x 32 k for Q4_K / Q5_K = one 32-weight sub-block; x 16 k for Q6_K = one 16-weight group):
+//   A operand = activations: lane (t = lane % 32, g = lane / 32) holds 16 (8) consecutive int8 of token t
+//   B operand = weights    : lane (r = lane % 32, g)            holds the same k of weight row r
 //   result                 : lane (r, g) holds, for ITS OWN row r, tokens 8 (v / 4) + 4 g + v % 4, v = 0..15
-// so the per-row sub-block scale / min / d of a K-quant are lane-local scalars when the i32 tile is scaled. A 16-k MFMA never
-// crosses a scale group (Q4_K: 32, Q6_K: 16 weights per scale). The min / -32 terms are one more MFMA per super-block in F16
-// (v_mfma_f32_32x32x16_f16: 6-bit mins or int8 scales x 16-value activation sums <= 2032, all exact in F16, f32 accumulate exact).
+// so the per-row sub-block scale / min / d of a K-quant are lane-local scalars when the i32 tile is scaled (one v_mad_i32_i24 per result;
+// the instantiation keeps 4 / 8 / 16 result registers for <= 8 / 16 / 32 tokens). An MFMA never crosses a scale group. The min / -32
+// terms are one more MFMA per super-block in F16 (v_mfma_f32_32x32x16_f16: 6-bit mins or int8 scales x 16-value activation sums <= 2032,
+// all exact in F16, f32 accumulation of integers < 2^24 exact).
 //
-// Data movement: weights keep the mat-vec's row-SoA HBM layout (repack.hip). A wave owns 32 rows x 512 k per step: it loads them
-// with FULL 128-byte lines per row and stream (8 lanes per line, non-temporal), parks them in its private LDS tile and reads them
-// back in MFMA operand order - no barrier, a wave's LDS accesses execute in order. The next step's loads are in flight while the
-// current one is computed (VMEM returns in order: the activation loads a step waits for are always issued BEFORE the weight
-// prefetch that overlaps it). Activations come straight from L2 in operand order; two small tables made by a prologue launch hold
-// the activation scales (transposed, -> LDS) and the F16 group sums in A-operand order.
-// Work split: workgroup = 8 waves, a balanced slice of rows = up to 8 groups of 32; K is split over the waves that share a row
-// group and their f32 partial tiles are added in a fixed order through LDS (bitwise reproducible).
+// Data movement: weights keep the mat-vec's HBM layout (repack.hip; Q5_K native). A wave owns 32 rows x 512 k per step: it loads them
+// with FULL 128-byte lines per row and stream (8 lanes per line, non-temporal; the per-row headers / scales cached), parks them in its
+// private LDS tile and reads them back in MFMA operand order - no barrier, a wave's LDS accesses execute in order. The next step's loads
+// are in flight while the current one is computed (VMEM returns in order: the activation loads a step waits for are always issued BEFORE
+// the weight prefetch that overlaps it; scheduling barriers keep the compiler from sinking them). Activations come straight from L2 in
+// operand order; two small tables hold the activation scales (transposed, -> LDS) and the F16 group sums in A-operand order - written by
+// the Q8_K quantizers as a second output (pm_q8k_tables) or by a prologue launch.
+// Work split: workgroup = 8 waves, a balanced slice of rows = up to 8 groups of 32; K is split over the waves that share a row group and
+// their f32 partial tiles are added in a fixed order through LDS (bitwise reproducible). Multi-job form (MJ): up to 3 matrices of one
+// type and K that share the activations form one virtual row space (wq | wk | wv, ffn_gate | ffn_up): one launch, one fill / drain.
+// Measurements, ablation and what did not help: profiles/r02_small_batch_probe.txt, DESIGN.md section 3.
 #include "pm355_device.h"
 #include "pm355_kernels.h"
 #include <mutex>

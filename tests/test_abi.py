@@ -26,6 +26,26 @@ def test_library_exports_every_declared_symbol():
     assert lib.pm355_row_stride(14, 8192) == 6720 and lib.pm355_row_stride(14, 768) % 16 == 0
 
 
+def test_small_batch_matmul_shape_check_is_host_logic():
+    """pm355_mul_mat_q_small_check decides, without touching a device, which (type, K, N, n_tokens) the integer-matrix-core mat-mul serves:
+    the engine's per-layer path choice and the plug-in's MUL_MAT dispatch both rest on it."""
+    import prima_cpp_amd
+    lib = prima_cpp_amd.load()
+    chk = lib.pm355_mul_mat_q_small_check
+    chk.restype = C.c_int
+    chk.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64]
+    Q8_0, Q4_K, Q5_K, Q6_K = 8, 12, 13, 14
+    for t in (Q4_K, Q5_K, Q6_K):
+        for K, N in ((8192, 28672), (28672, 8192), (8192, 1024), (4096, 128256), (768, 70)):
+            for T in (1, 8, 16, 32, 33, 64):
+                assert chk(t, K, N, T) == 0, (t, K, N, T)
+    assert chk(Q8_0, 8192, 8192, 8) != 0            # Q8_0 weights pair with Q8_0 activations: not served
+    assert chk(Q4_K, 8192, 8192, 65) != 0 and chk(Q4_K, 8192, 8192, 0) != 0
+    assert chk(Q4_K, 256, 8192, 8) != 0             # K < 512
+    assert chk(Q4_K, 8192 + 64, 8192, 8) != 0       # K % 256
+    assert chk(Q6_K, 65536, 8192, 8) != 0           # scale table + 8 wave tiles exceed the LDS budget
+
+
 def test_plugin_header_declares_the_reference_entry_points():
     src = open(os.path.join(ROOT, "include", "ggml_backend_mi355.h")).read()
     for name in ("ggml_backend_mi355_reg", "ggml_backend_mi355_init", "ggml_backend_mi355_buffer_type",
