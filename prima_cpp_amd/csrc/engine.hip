@@ -238,7 +238,7 @@ void layer_release(pm355_model * m, int il, hipStream_t st) {
 
 // quantize `src` [T][K] into the activation format(s) the given weights need; returns pointers
 struct ActQ { const void * k = nullptr; const void * z = nullptr; bool tab = false; };   // tab: the small-batch mat-mul's activation tables were written too
-const int MMQ_MIN_TOKENS = 4, MMQ_MAX_TOKENS = 64;
+const int MMQ_MIN_TOKENS = 3, MMQ_MAX_TOKENS = 64;      // (3 columns cost the multi-column mat-vec two passes: 57 vs 39 us on the ffn shape)
 const int MMQ_MULTI_MIN_TOKENS = 2;       // the fused wq | wk | wv and ffn_gate | ffn_up launches already win at 2 tokens (3 / 4 mat-vec launches otherwise)
 // the table output of the Q8_K quantizers, when this batch size takes the small-batch mat-mul (mmq_i8.hip)
 pm_q8k_tables mmq_tables(const pm355_model * m, int K, int T, hipStream_t st) {

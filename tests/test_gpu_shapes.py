@@ -120,7 +120,7 @@ def test_model_shaped_layer_decode_and_prefill(E, oracle, name, monkeypatch):
         assert f < 2e-5 and g2 < 2e-4
     else:
         assert f < 5e-4 and g2 < 1e-3
-    # (4) 3-token step: wq | wk | wv and ffn_gate | ffn_up as one multi-job launch each (from 2 tokens), wo / down on the multi-column mat-vec
+    # (4) 3-token step: wq | wk | wv and ffn_gate | ffn_up as one multi-job launch each (from 2 tokens), wo / down single launches (from 3)
     w.kv_clear()
     hr = ref.model_new(d)
     hid_3, lg_3, _ = w.decode(tokens=torch.from_numpy(toks[:3]).cuda(), pos0=0, want_argmax=True)
@@ -128,7 +128,10 @@ def test_model_shaped_layer_decode_and_prefill(E, oracle, name, monkeypatch):
     ref.model_free(hr)
     f3, g3 = _nmse(hid_3.cpu().numpy(), h3_ref), _nmse(lg_3.cpu().numpy(), l3_ref)
     print(f"[{name}] 3-token step vs reference CPU: hidden NMSE {f3:.2e}, logits NMSE {g3:.2e}")
-    assert f3 < 2e-5 and g3 < 2e-4
+    # (llama3_70b: 2.4e-6 - with wo / down on the multi-column mat-vec instead it was 8e-14, i.e. every Q8_K rounding decision identical to the
+    #  CPU backend's; the small-batch kernel itself agrees with the mat-vec to NMSE 1e-14 on these shapes, tools/small_vs_vec_check.py, so what
+    #  is left are activation roundings that flip on f32-summation-order noise. The reference's own MUL_MAT tolerance is NMSE 5e-4.)
+    assert f3 < 5e-5 and g3 < 3e-4
     w.close()
 
 
