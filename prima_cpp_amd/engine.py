@@ -163,6 +163,33 @@ class Window:
         if desc.rope_freqs:
             self._chk(self.lib.pm355_model_set_tensor(self.h, T_ROPE_FREQS, -1, F32, desc.rope_freqs, hp.head_dim // 2 * 4), "rope_freqs")
 
+    def load_gguf(self, path):
+        """Load this window's tensors from a GGUF file (names of LLM_TENSOR_NAMES, src/llama.cpp:560-600), straight from the
+        mmap'd file through the staged uploader."""
+        from . import gguf as G
+        g = G.GGUFFile(path)
+        layer_kinds = {"attn_norm": T_ATTN_NORM, "wq": T_WQ, "wk": T_WK, "wv": T_WV, "wo": T_WO, "ffn_norm": T_FFN_NORM,
+                       "ffn_gate": T_FFN_GATE, "ffn_up": T_FFN_UP, "ffn_down": T_FFN_DOWN, "bq": T_BQ, "bk": T_BK, "bv": T_BV}
+
+        def put(kind, layer, name, required=True):
+            if name not in g.tensors:
+                if required:
+                    raise L.PM355Error(f"{path}: tensor {name} missing")
+                return
+            t, _, data = g.tensors[name]
+            self._chk(self.lib.pm355_model_set_tensor(self.h, kind, layer, t, data.ctypes.data, data.nbytes), f"set_tensor {name}")
+        for il in range(self.lo, self.hi):
+            for k, kind in layer_kinds.items():
+                put(kind, il, f"blk.{il}.{G.LAYER_TENSORS[k]}", required=not k.startswith("b"))
+        if self.flags & HAS_EMBD:
+            put(T_TOK_EMBD, -1, "token_embd.weight")
+        if self.flags & HAS_HEAD:
+            put(T_OUT_NORM, -1, "output_norm.weight")
+            put(T_OUTPUT, -1, "output.weight" if "output.weight" in g.tensors else "token_embd.weight")   # tied head (src/llama.cpp:7391)
+        put(T_ROPE_FREQS, -1, "rope_freqs.weight", required=False)
+        torch.cuda.synchronize()
+        g.close()
+
     def fill_synthetic(self, mixture, seed=1234, rope_freqs=True):
         """Random-init weights of the named architecture generated directly in HBM (bench)."""
         hp = self.hp_dict

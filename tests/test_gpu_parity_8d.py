@@ -1,0 +1,194 @@
+"""Whole-model parity on SURVEY §8d fixtures: N(0, 1/K) weights through the REFERENCE's quantizer
+(`ggml_quantize_chunk`), Q4_K_M mixture, 16-token prompt + 128 greedy tokens, at three shapes - a small 8-layer model, the
+Llama-3-8B shape and 8 layers of the Llama-3-70B shape - each in two flavours (tests/_fixtures8d.py):
+
+  * peaked : top-1 / top-2 margins >> the int8 re-quantization step. The reference's scalar and AVX2 builds agree 128/128 on it, and
+             the plug-in (through the reference's unmodified llama_decode, default and --flash-attn graphs) and the resident engine must
+             produce the SAME 128 tokens - equality, no margin gate (north_star: "bit-exact token IDs under greedy decode").
+  * plain  : flat logits (the fixture §8d specifies). Two float summation orders of the same arithmetic - the reference's own ISA
+             builds included - flip int8 roundings and drift ~1 % apart at the logits (DESIGN.md "parity"), so the un-gated match rate
+             and the margin statistics are REPORTED next to "reference AVX2 vs reference scalar", and the logits are held to the
+             reference-against-itself yardstick.
+
+PM355_8D_SIZES=small,8b,70b8 selects the shapes (default: all; generation + the scalar CPU runs of the two large shapes take
+~6 minutes of host time on the GPU box)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import _fixtures8d as F
+from _bind import Ref, best_ref_flavour, have_ref, llama_driver_path, run_llama_driver
+
+pytestmark = pytest.mark.gpu
+GPU_ARGS = ["--keep-out-in-cuda"]
+N_GEN, N_PROMPT = 128, 16
+
+SHAPES = {
+    "small": dict(n_layer=8, n_embd=1024, n_head=8, n_head_kv=2, n_ff=2816, n_vocab=8192, is_70b=False),
+    "8b": dict(n_layer=32, n_embd=4096, n_head=32, n_head_kv=8, n_ff=14336, n_vocab=128256, is_70b=False),
+    "70b8": dict(n_layer=8, n_embd=8192, n_head=64, n_head_kv=8, n_ff=28672, n_vocab=128256, is_70b=True),
+}
+SIZES = [s for s in os.environ.get("PM355_8D_SIZES", "small,8b,70b8").split(",") if s in SHAPES]
+N_CTX = 256
+
+
+def _nmse(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    return float(((a - b) ** 2).sum() / max((b ** 2).sum(), 1e-30))
+
+
+def _threads():
+    return F.n_threads()
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    if llama_driver_path() is None or not have_ref("scalar"):
+        pytest.skip("oracle/_ref not built")
+    return True
+
+
+class _Files:
+    """GGUFs + the reference CPU runs of one shape, built on first use and shared by the tests of the module."""
+
+    def __init__(self, tmp):
+        self.tmp, self.files, self.cpu = tmp, {}, {}
+        self.ref = Ref(best_ref_flavour())
+
+    def path(self, size, peaked):
+        key = (size, peaked)
+        if key not in self.files:
+            plain = os.path.join(self.tmp, f"s8d_{size}_plain.gguf")
+            t0 = time.time()
+            if (size, False) not in self.files:
+                F.write_model(plain, self.ref, tag=size, **SHAPES[size])
+                self.files[(size, False)] = plain
+                print(f"\n[8d {size}] plain GGUF {os.path.getsize(plain) / 1e9:.2f} GB quantized by the reference in {time.time() - t0:.0f} s ({_threads()} threads)")
+            if peaked:
+                t0 = time.time()
+                pk = os.path.join(self.tmp, f"s8d_{size}_peaked.gguf")
+                info = F.copy_with_new_head(plain, pk, self.ref, True, tag=size)
+                self.files[key] = pk
+                print(f"[8d {size}] peaked head (embd sigma {info['embd_sigma']:.2f}, gain {info['peak_gain']:.3f}) in {time.time() - t0:.0f} s")
+        return self.files[key]
+
+    def cpu_run(self, size, peaked, flavour, force=None, extra=()):
+        key = (size, peaked, flavour, None if force is None else tuple(int(t) for t in force), tuple(extra))
+        if key not in self.cpu:
+            V = SHAPES[size]["n_vocab"]
+            t0 = time.time()
+            self.cpu[key] = run_llama_driver(self.path(size, peaked), F.prompt_tokens(V, N_PROMPT), N_GEN, ngl=0, n_ctx=N_CTX, threads=_threads(),
+                                             flavour=flavour, force=force, extra_args=list(extra), timeout=3000)
+            st = self.cpu[key][2]
+            print(f"[8d {size} {'peaked' if peaked else 'plain'}] reference CPU {flavour}: {st['decode_tok_s']:.2f} tok/s ({time.time() - t0:.0f} s)")
+        return self.cpu[key]
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    f = _Files(str(tmp_path_factory.mktemp("s8d")))
+    yield f
+    for p in f.files.values():
+        try:
+            os.unlink(p)
+        except OSError:
+            pass
+
+
+def _margins(lg):
+    srt = np.sort(lg, axis=1)
+    return srt[:, -1] - srt[:, -2], lg.std(axis=1)
+
+
+def _engine_greedy(path, size, prompt, n_gen):
+    """Greedy decode on the resident engine (pm355_model_*): prompt as one batch, then token by token through the captured graph."""
+    import torch
+    import prima_cpp_amd.engine as eng
+    s = SHAPES[size]
+    hp = dict(arch=0, n_layer=s["n_layer"], n_embd=s["n_embd"], n_head=s["n_head"], n_head_kv=s["n_head_kv"], head_dim=s["n_embd"] // s["n_head"],
+              n_ff=s["n_ff"], n_vocab=s["n_vocab"], rms_eps=1e-5, rope_freq_base=500000.0)
+    w = eng.Window(hp, n_ctx=N_CTX)
+    w.load_gguf(path)
+    w.finalize(max_tokens=max(len(prompt), 1))
+    toks, logits = [], []
+    _, lg, _ = w.decode(tokens=torch.from_numpy(np.asarray(prompt, dtype=np.int32)).cuda(), pos0=0, want_hidden=False)
+    pos = len(prompt)
+    w.set_pos(pos)
+    tok_d = torch.empty(1, dtype=torch.int32, device="cuda")
+    lg_d = torch.empty(s["n_vocab"], dtype=torch.float32, device="cuda")
+    for i in range(n_gen):
+        l = lg.cpu().numpy()
+        t = int(np.argmax(l))
+        toks.append(t)
+        logits.append(l)
+        if i == n_gen - 1:
+            break
+        tok_d.fill_(t)
+        w.step(token=tok_d, logits=lg_d)          # single-token step: the replayed hipGraph, position advanced on the device
+        lg = lg_d
+    w.close()
+    return np.array(toks), np.stack(logits)
+
+
+@pytest.mark.parametrize("mode", ["plugin", "plugin-fa", "engine"])
+@pytest.mark.parametrize("size", SIZES)
+def test_peaked_fixture_greedy_tokens_identical(gpu, files, size, mode):
+    V = SHAPES[size]["n_vocab"]
+    prompt = F.prompt_tokens(V, N_PROMPT)
+    path = files.path(size, True)
+    ts, ls, _ = files.cpu_run(size, True, "scalar")
+    ta, la, _ = files.cpu_run(size, True, "avx2")
+    expect = [F.peaked_next(prompt[-1], V)]
+    for _ in range(N_GEN - 1):
+        expect.append(F.peaked_next(expect[-1], V))
+    marg, sd = _margins(ls)
+    print(f"\n[8d {size} peaked] reference scalar: top1-top2 margin / sigma min {(marg / sd).min():.2f} median {np.median(marg / sd):.2f}; "
+          f"AVX2 vs scalar: tokens {(ta == ts).sum()}/{N_GEN}, logits NMSE {_nmse(la, ls):.2e}, max |dlogit| / sigma {(np.abs(la - ls).max(axis=1) / sd).max():.3f}")
+    # the fixture itself: the reference's two ISA builds agree on every token, and the tokens are the ones the head was built to emit
+    assert ts.tolist() == expect
+    assert ta.tolist() == ts.tolist()
+    if mode == "engine":
+        tg, lg = _engine_greedy(path, size, prompt, N_GEN)
+    else:
+        tg, lg, st = run_llama_driver(path, prompt, N_GEN, ngl=99, n_ctx=N_CTX, threads=_threads(), timeout=1800,
+                                      extra_args=GPU_ARGS + (["-fa"] if mode == "plugin-fa" else []))
+        assert "MI355X0" in st["stderr"]
+    err = np.abs(lg - ls).max(axis=1)
+    print(f"[8d {size} peaked {mode}] tokens {(tg == ts).sum()}/{N_GEN} identical to the reference CPU; logits NMSE {_nmse(lg, ls):.2e}; "
+          f"max |dlogit| / sigma {(err / sd).max():.3f}; smallest margin / observed error {(marg / np.maximum(err, 1e-30)).min():.1f}")
+    assert tg.tolist() == ts.tolist()                     # 128/128, un-gated
+    # logits: within 1e-3 relative, or what the reference's other ISA build differs by on the same file (flash attention keeps P in f32
+    # and the reference's CPU flash kernel an F16 accumulator: its own backend tolerance applies there)
+    nm_ref = _nmse(la, ls)
+    assert _nmse(lg, ls) < max(1e-6, 3 * nm_ref) * (10 if mode == "plugin-fa" else 1), (_nmse(lg, ls), nm_ref)
+
+
+@pytest.mark.parametrize("size", SIZES)
+def test_plain_fixture_statistics(gpu, files, size):
+    V = SHAPES[size]["n_vocab"]
+    prompt = F.prompt_tokens(V, N_PROMPT)
+    path = files.path(size, False)
+    tg, lg, st = run_llama_driver(path, prompt, N_GEN, ngl=99, n_ctx=N_CTX, threads=_threads(), extra_args=GPU_ARGS, timeout=1800)
+    ts, ls, _ = files.cpu_run(size, False, "scalar", force=tg[:-1])          # teacher-forced with the GPU's tokens
+    ta, la, _ = files.cpu_run(size, False, "avx2", force=tg[:-1])
+    marg, sd = _margins(ls)
+    err, spread = np.abs(lg - ls).max(axis=1), np.abs(la - ls).max(axis=1)
+    bad = [i for i in range(N_GEN) if tg[i] != ts[i]]
+    bad_a = [i for i in range(N_GEN) if ta[i] != ts[i]]
+    print(f"\n[8d {size} plain] plug-in {st['decode_tok_s']:.1f} tok/s; margin / sigma min {(marg / sd).min():.4f} median {np.median(marg / sd):.3f}\n"
+          f"   plug-in vs scalar: tokens {N_GEN - len(bad)}/{N_GEN} (un-gated), logits NMSE {_nmse(lg, ls):.2e}, max |dlogit| / sigma {(err / sd).max():.3f}\n"
+          f"   AVX2    vs scalar: tokens {N_GEN - len(bad_a)}/{N_GEN} (un-gated), logits NMSE {_nmse(la, ls):.2e}, max |dlogit| / sigma {(spread / sd).max():.3f}\n"
+          f"   mismatching steps (step, margin / sigma): plug-in {[(i, round(float(marg[i] / sd[i]), 4)) for i in bad]} AVX2 {[(i, round(float(marg[i] / sd[i]), 4)) for i in bad_a]}")
+    nm_gpu, nm_ref = _nmse(lg, ls), _nmse(la, ls)
+    assert nm_gpu < max(1e-6, 3 * nm_ref), (nm_gpu, nm_ref)
+    assert err.max() <= max(1e-3 * float(np.abs(ls).max()), 3 * spread.max()), (err.max(), spread.max())
+    for i in bad:                                       # a flipped argmax only inside the observed logit noise
+        assert marg[i] <= 2 * err[i], (i, marg[i], err[i])
+    # the plug-in must not flip more often than the reference's other ISA build does (+ binomial slack)
+    assert len(bad) <= 2 * len(bad_a) + 6, (len(bad), len(bad_a))
