@@ -210,8 +210,7 @@ def probe_dominant_kernel(win, hp, iters=40):
            "bytes_per_launch": nbytes, "avg_us": us, "gbs": nbytes / us / 1e3, "launch": launch}
     # what a pure streaming read of the same number of bytes achieves on this box (measured peak next to spec)
     try:
-        lib.pm355_probe_stream_read.restype = C.c_int
-        lib.pm355_probe_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        plib = P.L.load_probe()                       # measurement helpers live in their own library (tools/csrc)
         span = ((nbytes + (1 << 20) - 1) >> 20) << 20
         nspan = 6                                     # > 1.5 GB rotated: nothing survives in the 256 MB infinity cache
         buf = torch.empty(nspan * span, dtype=torch.uint8, device="cuda")
@@ -220,7 +219,7 @@ def probe_dominant_kernel(win, hp, iters=40):
         ts = []
         for rep in range(2 * nspan):
             e0.record(st)
-            P.check(lib.pm355_probe_stream_read(buf.data_ptr() + (rep % nspan) * span, nbytes, 1, 8, sink.data_ptr(), st.cuda_stream), "stream probe")
+            P.check(plib.pm355_probe_stream_read(buf.data_ptr() + (rep % nspan) * span, nbytes, 1, 8, sink.data_ptr(), st.cuda_stream), "stream probe")
             e1.record(st)
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)

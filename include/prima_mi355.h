@@ -254,6 +254,26 @@ typedef struct {
 #define PM355_ATTN_K_Q8_0     4
 #define PM355_ATTN_V_Q8_0     8
 PM355_API int pm355_attn_token(const pm355_attn_token_args * a, const pm355_rope_params * rp, pm355_stream_t stream);
+/* Single-token decode with the RoPE and the KV store in the EPILOGUE of the wq | wk | wv launch (round 3; NORM-mode rope - build_llama):
+ *   pm355_rope_table       this token's cos / sin per rotation pair, table[2 i] / table[2 i + 1], built with the reference's running
+ *                          product theta_i = theta_{i-1} * theta_scale (ggml_rope_cache_init, ggml.c:14117-14131; rope_yarn :14094) - one
+ *                          launch per token serves every layer
+ *   pm355_mul_mat_vec_qkv  jobs = {wq, wk, wv}: rms_norm + Q8_K quantize + the three mat-vecs (+bias) like pm355_mul_mat_vec_fused, then
+ *                          ROPE on adjacent row pairs (ggml.c:14224-14237), q rounded to F16 (the conversion MUL_MAT applies to src1 of
+ *                          K.q, ggml.c:12445-12473) -> jobs[0].y as f32, k -> F16 row of cache cell d_cell_nkv[0] (or d_pos[0] when
+ *                          d_cell_nkv == NULL), v -> F16 V cache (llm_build_kv_store, src/llama.cpp:9688-9716). jobs[1].y / jobs[2].y unused.
+ *   pm355_attn_cached      MUL_MAT(k, q) -> SOFT_MAX_EXT -> MUL_MAT(v, kq) over cells [0, d_cell_nkv[1]) (or [0, d_pos[0]]) that are all in
+ *                          the cache; same rounding points and mask / flags as pm355_attn_token's one-workgroup-per-head path. */
+typedef struct {
+    const float * rope_table; const int32_t * d_pos; const int32_t * d_cell_nkv; void * k_cache; void * v_cache;
+    int32_t n_head_kv, head_dim, n_ctx, n_rot /* rope n_dims */, v_rowmajor, pad_;
+} pm355_qkv_store;
+PM355_API int pm355_rope_table(const pm355_rope_params * rp, const int32_t * d_pos, const float * freq_factors, float * table, pm355_stream_t stream);
+PM355_API int pm355_mul_mat_vec_qkv(const pm355_matvec_job * jobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
+                                    const pm355_qkv_store * s, pm355_stream_t stream);
+PM355_API int pm355_attn_cached(const float * q_rot, void * k_cache, void * v_cache, const int32_t * d_pos, const int32_t * d_cell_nkv,
+                                const void * mask, float * out, int n_head, int n_head_kv, int head_dim, int n_ctx, float kq_scale,
+                                int max_keys, int flags, pm355_stream_t stream);
 /* p[0] = a, p[1] = b on the stream (values travel as kernel arguments: no host buffer lifetime to manage) */
 PM355_API int pm355_set_i32x2(int32_t * d_p, int32_t a, int32_t b, pm355_stream_t stream);
 /* greedy sampler (src/llama-sampling.cpp:390-397): index of the first maximum */
@@ -263,18 +283,6 @@ PM355_API int pm355_add(const float * a, const float * b, float * y, int64_t n, 
 PM355_API int pm355_mul(const float * a, const float * b, float * y, int64_t n, int64_t nb, pm355_stream_t stream);
 PM355_API int pm355_silu_mul(const float * g, const float * u, float * y, int64_t n, pm355_stream_t stream);
 PM355_API int pm355_scale(const float * a, float * y, float s, int64_t n, pm355_stream_t stream);
-/* measurement helper (bench.py "measured HBM read ceiling"): streams `bytes` from HBM exactly once with the
- * mat-vec's access pattern (one 1024-thread workgroup per CU x wg_per_cu, every wave reads its own contiguous span with
- * `unroll` (4 or 8) 16-byte non-temporal loads in flight per lane); `sink` = 4 writable bytes. Not on the product path. */
-PM355_API int pm355_probe_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, pm355_stream_t stream);
-/* measurement helper: average cost (microseconds) of one split device-wide barrier (the one inside the opt-in two-phase
- * attention + wo kernel, attn_wo.hip), measured on a kernel of n_phases empty phases. Not on the product path. */
-PM355_API int pm355_probe_grid_barrier(int n_phases, float * us_per_barrier, pm355_stream_t stream);
-/* measurement skeleton of a persistent decode layer on a run-ahead LDS-DMA weight loader (engine_probe.hip, tools/engine_probe.py):
- * real byte counts and seams, stand-in consumer arithmetic. Not on the product path. */
-PM355_API int pm355_probe_engine(const void * w, int64_t region_stride, int n_regions, int n_layers, int nph, const int * chunks,
-                                 const int * act_n, const int * out_n, int attn_ph, float attn_us, float * act, int64_t act_stride,
-                                 void * ctr, int nw, int ns, int nt, int thin, float * us, int * err_out, pm355_stream_t stream);
 /* synthetic weights generated directly in HBM (bench): random VALID blocks of `type`, |w| ~ scale */
 PM355_API int pm355_fill_random_blocks(int type, void * dst, int64_t K, int64_t nrows, uint64_t seed, float scale,
                                        pm355_stream_t stream);

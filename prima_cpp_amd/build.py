@@ -1,17 +1,27 @@
 """Builds libprima_mi355.so (hand-written HIP for gfx950) in-tree with hipcc. No JIT, no torch extension
-machinery: the .so travels with the repo snapshot to the GPU box."""
+machinery: the .so travels with the repo snapshot to the GPU box.
+
+build()            the product library prima_cpp_amd/libprima_mi355.so
+build_probe()      tools/csrc -> prima_cpp_amd/libprima_mi355_probe.so: measurement helpers (HBM streaming-read ceiling, persistent-layer
+                   skeleton) that bench.py / tools/ load separately - nothing of them is inside the product library
+build(tag=, extra=)  an A/B or measurement variant of the product library with extra compiler flags -> ab/<tag>.so, objects under
+                   ab/obj_<tag>/ (select it at run time with PM355_LIB=ab/<tag>.so)"""
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libprima_mi355.so")
-SOURCES = ["c_api.hip", "quantize.hip", "mmvq.hip", "mmvq_cols.hip", "repack.hip", "layer_ops.hip", "ggml_ops.hip", "engine.hip", "mmq.hip", "mmq_i8.hip", "probe.hip", "engine_probe.hip", "attn_prefill.hip", "attn_split.hip", "attn_flash.hip", "attn_q8.hip", "attn_wo.hip", "ring.hip", "upload.hip"]
+PROBE_LIB = os.path.join(HERE, "libprima_mi355_probe.so")
+SOURCES = ["c_api.hip", "quantize.hip", "mmvq.hip", "mmvq_cols.hip", "repack.hip", "layer_ops.hip", "ggml_ops.hip", "engine.hip", "mmq.hip", "mmq_i8.hip",
+           "attn_prefill.hip", "attn_cached.hip", "attn_split.hip", "attn_flash.hip", "attn_q8.hip", "ring.hip", "upload.hip", "ts.hip"]
+PROBE_SOURCES = ["probe.hip", "engine_probe.hip", "probe_api.hip"]
 # -ffp-contract=off: the quantizers must round exactly like the reference (no fused multiply-add where
 # the reference has a separate multiply and add); FMAs we want are written as fmaf().
 EXTRA = os.environ.get("PM355_EXTRA_FLAGS", "").split()
-FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-const-variable", "-Wno-unused-value", "-Wno-unused-function", "-Wno-unused-result"]
 
 
@@ -22,27 +32,56 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def _compile(srcs, hdrs, objdir, lib, flags, force, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
-           [os.path.join(os.path.dirname(HERE), "include", "prima_mi355.h")]
-    objs = []
+    os.makedirs(objdir, exist_ok=True)
+    objs, procs = [], []
     for s in srcs:
-        o = s[:-4] + ".o"
+        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
-    if force or _newer(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
+            procs.append((cmd, subprocess.Popen(cmd)))
+            if len(procs) >= (os.cpu_count() or 4):
+                c, pr = procs.pop(0)
+                if pr.wait():
+                    raise subprocess.CalledProcessError(pr.returncode, c)
+    for c, pr in procs:
+        if pr.wait():
+            raise subprocess.CalledProcessError(pr.returncode, c)
+    if force or _newer(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl", "-lpthread"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "prima_mi355.h")]
+
+
+def build(force=False, verbose=False, tag=None, extra=()):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if tag:
+        ab = os.path.join(ROOT, "ab")
+        return _compile(srcs, _headers(), os.path.join(ab, "obj_" + tag), os.path.join(ab, tag + ".so"), EXTRA + list(extra) + FLAGS, force, verbose)
+    return _compile(srcs, _headers(), CSRC, LIB, EXTRA + FLAGS, force, verbose)
+
+
+def build_probe(force=False, verbose=False):
+    d = os.path.join(ROOT, "tools", "csrc")
+    srcs = [os.path.join(d, s) for s in PROBE_SOURCES]
+    hdrs = _headers() + [os.path.join(d, "pm355_probe.h")]
+    return _compile(srcs, hdrs, os.path.join(d, "obj"), PROBE_LIB, FLAGS + ["-I" + CSRC], force, verbose)
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if args:                                   # python -m prima_cpp_amd.build <tag> [-DFLAG ...]
+        print(build(force="--force" in sys.argv, verbose=True, tag=args[0], extra=[a for a in sys.argv[2:] if a.startswith("-D")]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))
+        print(build_probe(force="--force" in sys.argv, verbose=True))

@@ -1,5 +1,5 @@
-// attn_device.h — device code of the fused single-token attention (RoPE + KV store + K.q + softmax + V.p), shared by
-// layer_ops.hip's stand-alone launch and the two-phase attention + wo kernel (attn_wo.hip). Design notes: layer_ops.hip.
+// attn_device.h — device code of the fused single-token attention (RoPE + KV store + K.q + softmax + V.p) launched by
+// layer_ops.hip. Design notes: layer_ops.hip.
 #pragma once
 #include "pm355_device.h"
 
@@ -35,18 +35,21 @@ struct AttnP {
     const int32_t * dyn; const float * mask;
     // mask_f16 != 0: `mask` points to F16 values (the flash-attention graphs cast the KQ mask, build_inp_KQ_mask src/llama.cpp:10466)
     int mask_f16;
+    unsigned long long * ts;                 // measurement builds (-DPM_TS)
 };
 __device__ __forceinline__ float attn_mask_at(const void * mask, int f16, int i) {
     if (!mask) return 0.0f;
     return f16 ? h2f(((const PM_G uint16_t *) mask)[i]) : ((const PM_G float *) mask)[i];
 }
 
-// Body of one query head `h`. Written for 256 ACTIVE threads; a larger workgroup (attn_wo.hip) passes
-// its extra threads through: they only take part in the barriers.
+// Body of one query head `h`. Written for 256 ACTIVE threads; a larger workgroup passes its extra threads through: they only take
+// part in the barriers.
 // VM = layout of the V cache: 0 = transposed [n_embd_v_gqa][n_ctx] (llm_build_kv_store without flash attention, src/llama.cpp:9712),
 // 1 = row-major [n_ctx][n_embd_v_gqa] like K (flash-attention graphs, :9705) - with the reference's flash-attention rounding points
 // (ggml_compute_forward_flash_attn_ext_f16, ggml.c:15870-16050): q -> F16, probabilities stay f32 (no F16 rounding of P).
-template <int DH, bool COH, int VM = 0>
+// CACHED: the wq | wk | wv launch already rotated q (F16-rounded values in a.q) and stored this token's K row / V column (QkvEpi,
+// mmvq_device.h): no rope, no store, the token's own key is a cached key like any other.
+template <int DH, bool COH, int VM = 0, bool CACHED = false>
 __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * smem, float * redf /*[8]*/, double * redd /*[4]*/) {
     // all of these are device-global memory: the explicit address space keeps the accesses global_* (not FLAT) when the
     // pointers may come out of a descriptor in memory
@@ -56,6 +59,7 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
     const float * freq_factors = a.freq_factors; float * out = a.out;
     const int H = a.H, Hkv = a.Hkv, n_ctx = a.n_ctx; const float scale = a.scale; const RopeP r = a.r;
     const bool active = threadIdx.x < 256;
+    unsigned long long tsv[6] = {PM_TS_NOW(), 0, 0, 0, 0, 0};
     constexpr int PARTS = 256 / DH;
     constexpr int KQ = DH / 8;                   // 16-byte pieces per K row
     float * qs   = (float *) smem;               // [DH]  f16-rounded rotated q
@@ -74,6 +78,9 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
     const bool is_k = tid >= DH / 2;
     const int pair = is_k ? tid - DH / 2 : tid;
     int ia = 0, ib = 0; float x0 = 0.0f, x1 = 0.0f, vnew = 0.0f;
+    if (CACHED) {
+        if (tid < DH) x0 = q[(long) h * DH + tid];
+    } else {
     if (tid < DH) {
         const PM_G float * src = is_k ? k + (long) hk * DH : q + (long) h * DH;
         if (pair < half) { ia = neox ? pair : 2 * pair; ib = neox ? pair + half : 2 * pair + 1; }
@@ -81,6 +88,7 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
         x0 = src[ia]; x1 = src[ib];
     }
     if (DH > 128 || tid >= 128) { const int e = DH > 128 ? tid : tid - 128; if (e < DH) vnew = v[(long) hk * DH + e]; }
+    }
     // ---- (1) + (2) position and the first K / V^T loads. The ADDRESSES of this thread's K row of the first sweep (cell = tid) and of its
     //      first two V^T chunks do not depend on the position, only on the sequence's slab - so with a single slab (seq_stride == 0)
     //      they are issued together with the position / q / k / v loads: ONE exposed memory latency instead of two (which cells are
@@ -119,6 +127,7 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
         slot = pos; n_kv = pos + 1;
         if (a.dyn) { slot = __builtin_amdgcn_readfirstlane(dyn0); n_kv = __builtin_amdgcn_readfirstlane(dyn1); }
     }
+    if (CACHED) slot = -1;                        // nothing to exclude: every attended cell is read from the cache
     const void * mask = a.mask; const int mf16 = a.mask_f16;
     kc += (long) seq * seq_stride; vc += (long) seq * seq_stride;
     if (seq_stride != 0 && seq_ptr) first_loads(kc, vc);
@@ -126,6 +135,9 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
     const bool have_k = tid < n_kv && tid != slot;
     const PM_G uint16_t * vrow = vc + (long) (hk * DH + ve) * n_ctx;
     // rotate q (threads 0..DH/2-1) and k (threads DH/2..DH-1): each thread builds its own cos/sin
+    if (CACHED) {
+        if (tid < DH) qs[tid] = x0;
+    } else {
     if (tid < DH) {
         float o0 = x0, o1 = x1;
         if (pair < half) {
@@ -152,7 +164,9 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
             }
         }
     }
+    }
     __syncthreads();
+    tsv[1] = PM_TS_NOW();                        // loads back, rope done
     // ---- scores: cached cells (thread per key; first sweep from the pre-loaded registers), current key from LDS
     float lmax = -INFINITY;
     auto dot_row = [&](const u32x4 (&kk)[KQ]) __attribute__((always_inline)) {
@@ -177,7 +191,7 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
         sc[i] = s_;
         lmax = fmaxf(lmax, s_);
     }
-    if (wave == 3) {                             // the current key (from LDS): one wave, lanes over the head dimension
+    if (!CACHED && wave == 3) {                  // the current key (from LDS): one wave, lanes over the head dimension
         float acc = 0.0f;
 #pragma unroll
         for (int e = lane; e < DH; e += 64) acc += kcur[e] * qs[e];
@@ -189,6 +203,7 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
     for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
     if (lane == 0 && active) redf[wave] = lmax;
     __syncthreads();
+    tsv[2] = PM_TS_NOW();                        // scores
     const float mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
     double lsum = 0.0;
     for (int i = tid; i < n_kv; i += 256) {
@@ -202,11 +217,12 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
     __syncthreads();
     const double tot = (redd[0] + redd[1]) + (redd[2] + redd[3]);
     const float inv = (float) (1.0 / tot);
-    const float p_cur = VM == 0 ? h2f(f2h(sc[slot] * inv)) : sc[slot] * inv;   // every thread reads exp() of the current key
+    const float p_cur = CACHED ? 0.0f : (VM == 0 ? h2f(f2h(sc[slot] * inv)) : sc[slot] * inv);   // every thread reads exp() of the current key
     __syncthreads();
     for (int i = tid; i < n_pad; i += 256)                             // VM 0: p rounded to F16; pad and `slot` = 0
         sc[i] = (i < n_kv && i != slot) ? (VM == 0 ? h2f(f2h(sc[i] * inv)) : sc[i] * inv) : 0.0f;
     __syncthreads();
+    tsv[3] = PM_TS_NOW();                        // softmax
     if (VM == 1) {
         // ---- PV, row-major V: thread (16-byte chunk c8, key slot ks) takes rows ks, ks + NSL, ... (first two pre-loaded)
         const int c8 = tid % C8, ks = tid / C8;
@@ -237,7 +253,7 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
             float o = 0.0f;
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl) o += part[sl * DH + tid];
-            o += vcur[tid] * p_cur;
+            if (!CACHED) o += vcur[tid] * p_cur;
             st_act<COH>(out + (long) h * DH + tid, o);
         }
         return;
@@ -260,11 +276,14 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
         if (active) part[tid] = acc;
     }
     __syncthreads();
+    tsv[4] = PM_TS_NOW();                        // P.V partials
     if (tid < DH) {
         float acc = 0.0f;
 #pragma unroll
         for (int pt = 0; pt < PARTS; ++pt) acc += part[pt * DH + tid];
-        acc += vcur[tid] * p_cur;
+        if (!CACHED) acc += vcur[tid] * p_cur;
         st_act<COH>(out + (long) h * DH + tid, acc);
     }
+    tsv[5] = PM_TS_NOW();
+    pm_ts_store(a.ts, 2, tsv);
 }

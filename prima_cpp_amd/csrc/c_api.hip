@@ -272,6 +272,47 @@ int pm355_attn_rope_fused(const float * q, const float * k, const float * v, voi
     HIP_TRY(hipGetLastError());
     return 0;
 }
+static pm_rope_cfg rope_cfg_of(const pm355_rope_params * rp) {
+    pm_rope_cfg c;
+    c.n_dims = rp->n_dims; c.mode = rp->mode; c.n_ctx_orig = rp->n_ctx_orig; c.freq_base = rp->freq_base; c.freq_scale = rp->freq_scale;
+    c.ext_factor = rp->ext_factor; c.attn_factor = rp->attn_factor; c.beta_fast = rp->beta_fast; c.beta_slow = rp->beta_slow;
+    pm_rope_params(c);
+    return c;
+}
+int pm355_rope_table(const pm355_rope_params * rp, const int32_t * d_pos, const float * ff, float * table, pm355_stream_t st) {
+    if (!rp || rp->n_dims % 2 || rp->n_dims > 256 || !d_pos || !table) return fail(PM355_E_SHAPE, "rope_table: n_dims (even, <= 256), d_pos and table required");
+    pm_launch_rope_table(rope_cfg_of(rp), d_pos, nullptr, ff, table, S(st));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pm355_mul_mat_vec_qkv(const pm355_matvec_job * jobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
+                          const pm355_qkv_store * s, pm355_stream_t st) {
+    if (!jobs || !x_f32 || !s || !s->rope_table || !s->k_cache || !s->v_cache || (!s->d_pos && !s->d_cell_nkv)) return fail(PM355_E_SHAPE, "mul_mat_vec_qkv: null pointer");
+    pm_gemv_fused f = {};
+    f.K = (int) K; f.njobs = 3; f.xf = x_f32; f.norm_w = norm_w; f.eps = eps;
+    for (int j = 0; j < 3; ++j) {
+        f.job[j].type = jobs[j].type; f.job[j].N = (int) jobs[j].N; f.job[j].W = jobs[j].W; f.job[j].W2 = nullptr;
+        f.job[j].y = jobs[j].y; f.job[j].bias = jobs[j].bias; f.job[j].resid = nullptr;
+    }
+    const pm_qkv_epi e = {s->rope_table, s->d_pos, nullptr, s->d_cell_nkv, 0, s->k_cache, s->v_cache, s->n_head_kv, s->head_dim, s->n_ctx, s->n_rot,
+                          s->v_rowmajor};
+    f.epi = &e;
+    (void) hipGetLastError();
+    const int rc = pm_launch_gemv_fused(f, S(st));
+    if (rc == -5) return fail(PM355_E_UNSUPPORTED, "mul_mat_vec_qkv: every workgroup's row slices must hold whole rotation pairs (N % (2 * CUs) == 0), N_k == N_v == n_head_kv * head_dim");
+    if (rc) return gemv_rc(rc);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pm355_attn_cached(const float * q_rot, void * kc, void * vc, const int32_t * d_pos, const int32_t * d_cell_nkv, const void * mask,
+                      float * out, int H, int Hkv, int dh, int n_ctx, float kq_scale, int max_keys, int flags, pm355_stream_t st) {
+    if (!q_rot || !kc || !vc || !out || (!d_pos && !d_cell_nkv)) return fail(PM355_E_SHAPE, "attn_cached: null pointer");
+    if (pm_launch_attn_cached(q_rot, kc, vc, d_pos, nullptr, 0, out, H, Hkv, dh, n_ctx, kq_scale, S(st), d_cell_nkv, mask, max_keys,
+                              flags & PM355_ATTN_V_ROWMAJOR, flags & PM355_ATTN_MASK_F16))
+        return fail(PM355_E_UNSUPPORTED, "attn_cached: head_dim must be 64/128/256, n_ctx % 8 == 0 and max_keys fit LDS");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 int pm355_attn_token(const pm355_attn_token_args * a, const pm355_rope_params * rp, pm355_stream_t st) {
     if (!a || !rp || rp->n_dims % 2 || rp->n_dims > a->head_dim) return fail(PM355_E_SHAPE, "attn_token: n_dims");
     if (!a->d_pos || !a->d_cell_nkv || !a->q || !a->k || !a->v || !a->k_cache || !a->v_cache || !a->out) return fail(PM355_E_SHAPE, "attn_token: null pointer");
@@ -336,63 +377,4 @@ int pm355_fill_random_blocks(int type, void * dst, int64_t K, int64_t nrows, uin
     if (!pm_weight_row_bytes(type, K)) return fail(PM355_E_UNSUPPORTED, "fill_random_blocks: type");
     pm_launch_fill_random_blocks(type, dst, K, nrows, seed, scale, S(st)); HIP_TRY(hipGetLastError()); return 0;
 }
-int pm355_probe_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, pm355_stream_t st) {
-    if (pm_launch_stream_read(src, bytes, wg_per_cu, unroll, sink, S(st))) return fail(PM355_E_SHAPE, "probe_stream_read: buffer too small");
-    HIP_TRY(hipGetLastError()); return 0;
-}
-/* measurement skeleton (engine_probe.hip): n_layers decode layers as ONE persistent launch on a run-ahead LDS-DMA weight loader.
- * w: region_stride * n_regions bytes of anything; act: n_layers * nph * act_stride floats; ctr: 33*128 + 64 zeroed bytes.
- * *err_out = watchdog code (0 = clean). Times the SECOND of two launches with HIP events: *us = microseconds per launch. */
-int pm355_probe_engine(const void * w, int64_t region_stride, int n_regions, int n_layers, int nph, const int * chunks, const int * act_n,
-                       const int * out_n, int attn_ph, float attn_us, float * act, int64_t act_stride, void * ctr, int nw, int ns, int nt,
-                       int thin, float * us, int * err_out, pm355_stream_t st) {
-    hipEvent_t e0, e1;
-    (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
-    int rc = 0;
-    for (int it = 0; it < 2 && !rc; ++it) {
-        if (it == 1) (void) hipEventRecord(e0, S(st));
-        rc = pm_launch_engine_probe(w, (long) region_stride, n_regions, n_layers, nph, chunks, act_n, out_n, attn_ph, attn_us, act,
-                                    (long) act_stride, ctr, nw, ns, nt, thin, S(st));
-        if (it == 1) (void) hipEventRecord(e1, S(st));
-        (void) hipStreamSynchronize(S(st));
-    }
-    float ms = 0.0f;
-    if (!rc) (void) hipEventElapsedTime(&ms, e0, e1);
-    int err = 0;
-    (void) hipMemcpy(&err, (char *) ctr + 33 * 128, 4, hipMemcpyDeviceToHost);
-    if (err) (void) hipMemset(ctr, 0, 33 * 128 + 64);
-    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
-    if (us) *us = ms * 1e3f;
-    if (err_out) *err_out = err;
-    if (rc) return fail(PM355_E_SHAPE, "probe_engine: geometry");
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-/* measurement helper: one kernel of n_phases empty phases separated by the split device-wide barrier of mmvq_device.h;
- * returns the average microseconds per barrier in *us_per_barrier */
-int pm355_probe_grid_barrier(int n_phases, float * us_per_barrier, pm355_stream_t st) {
-    void * ctr = nullptr;
-    const size_t nb = pm_attn_wo_bar_bytes();
-    if (n_phases < 1) return fail(PM355_E_RANGE, "probe_grid_barrier: n_phases");
-    HIP_TRY(hipMalloc(&ctr, nb));
-    (void) hipMemset(ctr, 0, nb);
-    hipEvent_t e0, e1;
-    (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
-    pm_launch_barrier_probe(n_phases, ctr, S(st));
-    (void) hipStreamSynchronize(S(st));
-    (void) hipEventRecord(e0, S(st));
-    pm_launch_barrier_probe(n_phases, ctr, S(st));
-    (void) hipEventRecord(e1, S(st));
-    (void) hipStreamSynchronize(S(st));
-    float ms = 0.0f;
-    (void) hipEventElapsedTime(&ms, e0, e1);
-    int err = 0;
-    (void) hipMemcpy(&err, (char *) ctr + nb - 64, 4, hipMemcpyDeviceToHost);
-    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
-    (void) hipFree(ctr);
-    if (us_per_barrier) *us_per_barrier = ms * 1e3f / (float) n_phases;
-    return err ? fail(PM355_E_HIP, "probe_grid_barrier: watchdog fired") : 0;
-}
-
 } // extern "C"

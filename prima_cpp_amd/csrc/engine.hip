@@ -47,11 +47,10 @@ struct pm355_model {
     bool no_fuse = false;                 // PM355_NO_FUSE=1: node-by-node kernels (debug / A-B)
     bool no_multi = false;                // PM355_NO_MMQ_MULTI=1
     bool no_mmq = false;                  // PM355_NO_MMQ_I8=1: 4..64-token batches on the round-1 paths (mat-vec columns, F16 GEMM from 16 tokens)
-    // EXPERIMENT (PM355_ATTN_WO=1, attn_wo.hip): attention + wo as ONE two-phase launch per layer - every workgroup first puts its wo
-    // weight loads in flight, the 64 head workgroups run the latency-bound attention meanwhile, one device-wide barrier, then the wo
-    // mat-vec: 4 launches per layer instead of 5. Bit-identical, but the barrier + first-touch fetch of the heads' outputs costs what
-    // the launch boundary cost: 8.74 vs 8.60 ms per Llama-3-70B token, 1.72 vs 1.66 ms per 8B token
-    bool attn_wo = false;
+    // single-token decode, short contexts, NORM-mode rope: RoPE + F16 KV store happen in the epilogue of the wq | wk | wv launch (per-token cos / sin
+    // table `rope_tab`), the attention launch reads everything from the cache (attn_cached.hip). PM355_QKV_EPI=0: the round-2 form (raw q / k / v,
+    // rope + store inside the attention kernel)
+    bool qkv_epi = true; float * rope_tab = nullptr;
     // WINDOW STREAMING (pm355_model_set_streaming): the layer tensors live in pinned HOST memory (in the HBM layout) and are streamed
     // through `slots` device-side layer slots by a copy stream, slot (l - lo) % n_slots for layer l, one layer ahead of the compute
     // stream per free slot - the GPU-side form of prima.cpp's "prefetch the next layer window while this one computes"
@@ -61,7 +60,7 @@ struct pm355_model {
     std::vector<Slot> slots;
     hipStream_t copy_stream = nullptr;
     size_t slot_bytes[12] = {};
-    uint64_t streamed_bytes = 0; void * aw_ctr = nullptr;       // barrier state of that kernel (zero between launches) + watchdog flag
+    uint64_t streamed_bytes = 0;
     // long-context decode attention (attn_split.hip): the host mirrors the device position counters to choose, per step, between
     // the fused one-workgroup-per-head kernel and the keys-split-over-workgroups path (different launch sequences = different
     // captured graphs). PM355_ATTN_SPLIT_MIN positions (default 640: measured crossover on the 70B head shape).
@@ -288,9 +287,9 @@ int matmul_small(pm355_model * m, const Tensor & w, const ActQ & a, int T, float
 // single-token fused GEMV launch helper: jobs share the f32 activation `xf` (rms_norm'ed with norm_w when given)
 int gemv_f32(pm355_model * m, const Tensor * const * ws, const Tensor * const * w2s, float * const * ys,
              const float * const * biases, const float * const * resids, int nj,
-             const float * xf, const float * norm_w, hipStream_t st) {
+             const float * xf, const float * norm_w, hipStream_t st, const pm_qkv_epi * epi = nullptr) {
     pm_gemv_fused f = {};
-    f.K = (int) ws[0]->K; f.njobs = nj; f.xf = xf; f.norm_w = norm_w; f.eps = m->hp.rms_eps;
+    f.K = (int) ws[0]->K; f.njobs = nj; f.xf = xf; f.norm_w = norm_w; f.eps = m->hp.rms_eps; f.epi = epi;
     for (int j = 0; j < nj; ++j) {
         f.job[j].type = ws[j]->type; f.job[j].N = (int) ws[j]->N; f.job[j].W = ws[j]->d; f.job[j].W2 = w2s ? (w2s[j] ? w2s[j]->d : nullptr) : nullptr;
         f.job[j].y = ys[j]; f.job[j].bias = biases ? biases[j] : nullptr; f.job[j].resid = resids ? resids[j] : nullptr;
@@ -330,6 +329,9 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
     const int H = hp.n_head, Hkv = hp.n_head_kv, dh = hp.head_dim;
     const float kq_scale = 1.0f / sqrtf((float) dh);
     float * bufs[2] = {m->x, m->x1};
+    // rope + KV store in the QKV epilogue: NORM-mode rope, one-workgroup-per-head attention regime
+    bool epi = m->qkv_epi && m->rope_tab && !(m->rope.mode & 2) && !m->long_ctx;
+    if (epi) pm_launch_rope_table(m->rope, m->d_pos, m->d_ctl, (const float *) m->rope_freqs.d, m->rope_tab, st);
     for (int il = m->lo; il < m->hi; ++il) {
         Layer Lv = layer_acquire(m, il, st); Layer & L = Lv;
         float * q = m->q, * k = m->k, * v = m->v, * att = m->att, * hbuf = m->h;
@@ -340,23 +342,23 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
             float * ys[3] = {q, k, v};
             const float * bs[3] = {(const float *) L.t[PM355_T_BQ].d, (const float *) L.t[PM355_T_BK].d, (const float *) L.t[PM355_T_BV].d};
             const float * nw = (const float *) L.t[PM355_T_ATTN_NORM].d;
-            if (gemv_f32(m, ws, nullptr, ys, bs, nullptr, 3, cur, nw, st)) {
+            const long kvs_e = m->n_seq > 1 ? (long) hp.n_ctx * Hkv * dh : 0;
+            const pm_qkv_epi qe = {m->rope_tab, m->d_pos, m->d_ctl, nullptr, kvs_e, L.kc, L.vc, Hkv, dh, hp.n_ctx, m->rope.n_dims, 0};
+            bool qkv_done = false;
+            if (epi) {
+                qkv_done = gemv_f32(m, ws, nullptr, ys, bs, nullptr, 3, cur, nw, st, &qe) == 0;
+                if (!qkv_done) {
+                    if (il != m->lo) return seterr(m, PM355_E_UNSUPPORTED, "decode: QKV epilogue served for some layers only");
+                    epi = false;                       // (shape / type mix without the epilogue kernel: the whole window takes the round-2 form)
+                }
+            }
+            if (!qkv_done && gemv_f32(m, ws, nullptr, ys, bs, nullptr, 3, cur, nw, st)) {
                 for (int j = 0; j < 3; ++j)               // type mix without a 3-job kernel: one launch per matrix
                     if (gemv_f32(m, ws + j, nullptr, ys + j, bs + j, nullptr, 1, cur, nw, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused qkv gemv");
             }
         }
         const long kvs = m->n_seq > 1 ? (long) hp.n_ctx * Hkv * dh : 0;     // one slab: the kernels may address the cache before the sequence id arrives
-        bool aw_done = false;
-        if (m->attn_wo && m->aw_ctr && !m->long_ctx) {
-            const Tensor & wo = L.t[PM355_T_WO];
-            pm_gemv_fused f = {};
-            f.K = (int) wo.K; f.njobs = 1; f.xf = att; f.eps = hp.rms_eps;
-            f.job[0].type = wo.type; f.job[0].N = (int) wo.N; f.job[0].W = wo.d; f.job[0].y = x_mid; f.job[0].resid = cur;
-            aw_done = pm_launch_attn_wo(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d, att, H, Hkv, dh,
-                                        hp.n_ctx, kq_scale, m->rope, f, m->aw_ctr, st) == 0;
-        }
-        if (aw_done) {
-        } else if (m->long_ctx && m->use_flash) {
+        if (m->long_ctx && m->use_flash) {
             // long context: keys split over workgroups, rope + KV store + online softmax + in-launch merge in ONE launch (attn_flash.hip)
             if (pm_launch_attn_flash(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d, att, m->split_scratch,
                                      H, Hkv, dh, hp.n_ctx, kq_scale, m->rope, st, nullptr, nullptr, 0, 0, m->flash_cells))
@@ -366,13 +368,17 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
             if (pm_launch_attn_split(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d, att, m->split_scratch,
                                      H, Hkv, dh, hp.n_ctx, kq_scale, &m->rope, st))
                 return seterr(m, PM355_E_RANGE, "decode: split attention unsupported for this shape");
+        } else if (epi) {
+            if (pm_launch_attn_cached(q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, att, H, Hkv, dh, hp.n_ctx, kq_scale, st, nullptr, nullptr,
+                                      (m->split_scratch && m->split_min + 8 < hp.n_ctx) ? m->split_min + 8 : 0))
+                return seterr(m, PM355_E_RANGE, "decode: cached attention unsupported for this head_dim / n_ctx");
         } else if (pm_launch_attn_rope_fused(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d,
                                              att, H, Hkv, dh, hp.n_ctx, kq_scale, m->rope, st, nullptr, nullptr,
                                              // with the split path available this kernel only ever sees < split_min cells: its LDS
                                              // score buffer is sized for that, not for n_ctx (long contexts stay launchable)
                                              (m->split_scratch && m->split_min + 8 < hp.n_ctx) ? m->split_min + 8 : 0))
             return seterr(m, PM355_E_RANGE, "decode: fused attention unsupported for this head_dim / n_ctx");
-        if (!aw_done) {
+        {
             const Tensor * w[1] = {&L.t[PM355_T_WO]}; float * y[1] = {x_mid}; const float * r[1] = {cur};
             if (gemv_f32(m, w, nullptr, y, nullptr, r, 1, att, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused wo gemv");
         }
@@ -581,7 +587,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     { const char * e = getenv("PM355_NO_FUSE"); m->no_fuse = e && e[0] == '1'; }
     { const char * e = getenv("PM355_NO_MMQ_MULTI"); m->no_multi = e && e[0] == '1'; }   // small batches: one launch per matrix (A/B of the multi-job launches)
     { const char * e = getenv("PM355_NO_MMQ_I8"); m->no_mmq = e && e[0] == '1'; }     // 4..64-token batches: mat-vec columns / F16 GEMM from 16 (the round-1 paths)
-    { const char * e = getenv("PM355_ATTN_WO"); m->attn_wo = e && e[0] == '1'; }       // measured: 8.74 vs 8.60 ms per 70B token -> opt-in experiment
+    { const char * e = getenv("PM355_QKV_EPI"); m->qkv_epi = !(e && e[0] == '0'); }
     return m;
 }
 
@@ -589,14 +595,13 @@ void pm355_model_free(pm355_model * m) {
     if (!m) return;
     (void) hipDeviceSynchronize();
     for (auto & g : m->graphs) (void) hipGraphExecDestroy(g.exec);
-    if (m->aw_ctr) (void) hipFree(m->aw_ctr);
     if (m->copy_stream) { (void) hipStreamSynchronize(m->copy_stream); (void) hipStreamDestroy(m->copy_stream); }
     for (auto & S : m->slots) { for (auto p : S.d) if (p) (void) hipFree(p); if (S.ready) (void) hipEventDestroy(S.ready); if (S.free_) (void) hipEventDestroy(S.free_); }
     for (auto & L : m->layers) for (auto p : L.host) if (p) (void) hipHostFree(p);
     for (auto & L : m->layers) { for (auto & t : L.t) if (t.d) (void) hipFree(t.d); if (L.kc) (void) hipFree(L.kc); if (L.vc) (void) hipFree(L.vc); }
     Tensor * g[4] = {&m->tok_embd, &m->out_norm, &m->output, &m->rope_freqs};
     for (auto t : g) if (t->d) (void) hipFree(t->d);
-    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->h2, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->split_scratch};
+    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->h2, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->split_scratch, m->rope_tab};
     for (auto p : s) if (p) (void) hipFree(p);
     pm355_uploader_free(m->up);
     if (m->cap_stream) (void) hipStreamDestroy(m->cap_stream);
@@ -691,7 +696,8 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
               A((void **) &m->att, T * Eq * 4) && A((void **) &m->h, T * F * 4) && (T < MMQ_MULTI_MIN_TOKENS || A((void **) &m->h2, T * F * 4)) && A((void **) &m->logits, (size_t) hp.n_vocab * 4) &&
               A((void **) &m->aq_k, T * pm_q8k_row_bytes((int) ((maxK + 255) / 256 * 256))) &&
               A((void **) &m->aq_0, T * pm_q80_row_bytes((int) ((maxK + 31) / 32 * 32))) &&
-              A((void **) &m->d_pos, 64 * 4) && A((void **) &m->d_ctl, 64) && A((void **) &m->d_tok, 64 + T * 4);
+              A((void **) &m->d_pos, 64 * 4) && A((void **) &m->d_ctl, 64) && A((void **) &m->d_tok, 64 + T * 4) &&
+              A((void **) &m->rope_tab, (size_t) hp.head_dim * 4);
     if (!ok) return seterr(m, PM355_E_NOMEM, "finalize: scratch");
     if (hp.n_head / hp.n_head_kv <= 8 && (hp.head_dim == 64 || hp.head_dim == 128) &&
         !A((void **) &m->split_scratch, std::max(pm_attn_split_scratch_floats(hp.n_head, hp.head_dim, hp.n_ctx),
@@ -710,11 +716,6 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
         }
         (void) hipDeviceSynchronize();
         for (int i = 0; i < m->n_slots; ++i) stream_prefetch(m, m->lo + i);
-        m->attn_wo = false;
-    }
-    if (m->attn_wo && !m->aw_ctr) {
-        if (hipMalloc(&m->aw_ctr, pm_attn_wo_bar_bytes()) != hipSuccess) m->aw_ctr = nullptr;
-        else (void) hipMemset(m->aw_ctr, 0, pm_attn_wo_bar_bytes());
     }
     m->h_pos.assign(n_seq, 0); m->h_seq = 0;
     { const char * e = getenv("PM355_ATTN_SPLIT_MIN"); if (e && e[0]) m->split_min = atoi(e); }
@@ -860,16 +861,10 @@ int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * 
     return commit();
 }
 
-// Non-zero when the barrier watchdog of the two-phase attention + wo kernel (PM355_ATTN_WO=1) fired (a workgroup was never
-// scheduled): results since then are invalid. Synchronizes the device.
+// Synchronizes the device; non-zero if the window's launches left an error behind.
 int pm355_model_check(pm355_model * m) {
     if (!m) return PM355_E_SHAPE;
-    (void) hipDeviceSynchronize();
-    if (m->aw_ctr) {
-        int e = 0;
-        if (hipMemcpy(&e, (char *) m->aw_ctr + pm_attn_wo_bar_bytes() - 64, 4, hipMemcpyDeviceToHost) == hipSuccess && e)
-            return seterr(m, PM355_E_HIP, "attention + wo kernel: device-wide barrier timed out");
-    }
+    if (hipDeviceSynchronize() != hipSuccess) return seterr(m, PM355_E_HIP, "check: device error");
     return 0;
 }
 

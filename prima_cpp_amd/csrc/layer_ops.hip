@@ -356,7 +356,7 @@ int pm_launch_attn_rope_fused(const float * q, const float * k, const float * v,
     auto launch = [&](auto kern) {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         AttnP a = {q, k, v, (uint16_t *) kc, (uint16_t *) vc, pos0, seq, seq_stride, freq_factors, out, H, Hkv, n_ctx, scale, r, dyn,
-                   (const float *) mask, mask_f16};
+                   (const float *) mask, mask_f16, pm_ts_next_slot()};
         hipLaunchKernelGGL(kern, dim3(H), dim3(256), lds, st, a);
     };
     if (v_rowmajor) {

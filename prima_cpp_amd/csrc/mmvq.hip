@@ -30,15 +30,15 @@ using namespace pmv;
 
 namespace {
 
-template <int TA, int TB, bool PAIR, bool DBG>
+template <int TA, int TB, bool PAIR, bool DBG, bool EPI = false>
 __global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(GemvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double nred[PM_GEMV_NW];
-    gemv_body<TA, TB, PAIR, DBG, false>(p, smem, nred, GridBar{nullptr, nullptr, 0, 1, 1});
+    gemv_body<TA, TB, PAIR, DBG, 1, EPI>(p, smem, nred);
 }
 
 template <int TA, int TB>
-int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, hipStream_t st) {
+int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, hipStream_t st, bool epi = false) {
     const GemvP & p = p_in;
     auto go = [&](auto kern) {
         static bool attr_set[16] = {};                // one flag per instantiation (lambda is instantiated per kern type) and device
@@ -49,6 +49,9 @@ int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, 
     if (pair) {
         if (TA != TB) return -1;
         if (dbg) go(gemv_q_kernel<TA, TA, true, true>); else go(gemv_q_kernel<TA, TA, true, false>);
+    } else if (epi) {
+        if (dbg) return -1;
+        go(gemv_q_kernel<TA, TB, false, false, true>);
     } else {
         if (dbg) go(gemv_q_kernel<TA, TB, false, true>); else go(gemv_q_kernel<TA, TB, false, false>);
     }
@@ -128,6 +131,20 @@ int pmv::gemv_fill(const pm_gemv_fused & a, int grid_fixed, GemvP & p, int & ta_
         g.W = (const uint8_t *) s.W; g.W2 = (const uint8_t *) s.W2; g.y = s.y; g.bias = s.bias; g.resid = s.resid;
         g.N = s.N; g.is_b = (s.type != ta); g.U = a.K / nv_of(s.type);
         g.row_stride = (long) pm_weight_row_stride(s.type, a.K);
+        g.role = 0; g.split = 0;
+        if (a.epi) {
+            // wq | wk | wv with the RoPE + KV-store epilogue: every workgroup's slice must hold whole rotation pairs; a matrix that gives a
+            // workgroup fewer rows than it has waves is dealt out step by step (row, chunk) so that all 16 waves share its rows
+            if (pair || a.njobs != 3 || s.N % (2 * grid) || a.dbg_int) return -5;
+            g.role = j + 1;
+            const int upl = (g.U + 63) >> 6, ch = nv_of(s.type) == 64 ? PM_CH64 : PM_CH32, cpr = (upl + ch - 1) / ch;
+            g.split = (j > 0 && s.N / grid < PM_GEMV_NW && cpr > 1) ? 1 : 0;
+        }
+    }
+    if (a.epi) {
+        const pm_qkv_epi & e = *a.epi;
+        if (grid_fixed > 0 || e.dh % 2 || e.n_rot % 2 || e.n_rot > e.dh || a.job[0].N % e.dh || a.job[1].N != e.Hkv * e.dh || a.job[2].N != e.Hkv * e.dh) return -5;
+        p.epi = QkvEpi{e.tab, e.pos, e.seq, e.dyn, e.seq_stride, (uint16_t *) e.kc, (uint16_t *) e.vc, e.Hkv * e.dh, e.dh, e.n_ctx, e.n_rot, e.v_rowmajor};
     }
     if (p.job[0].is_b)                                // the kernel pre-issues job 0 with the TA code path: put a TA job first
         for (int j = 1; j < 3; ++j) if (p.job[j].N > 0 && !p.job[j].is_b) { const GemvJob t = p.job[0]; p.job[0] = p.job[j]; p.job[j] = t; break; }
@@ -150,7 +167,8 @@ int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st) {
     GemvP p; int ta, tb, grid; bool pair; size_t lds;
     const int rc = gemv_fill(a, 0, p, ta, tb, pair, lds, grid);
     if (rc) return rc;
-#define PM_L(TA_, TB_) return launch_types<TA_, TB_>(p, pair, grid, lds, a.dbg_int != nullptr, st)
+    p.ts = pm_ts_next_slot();
+#define PM_L(TA_, TB_) return launch_types<TA_, TB_>(p, pair, grid, lds, a.dbg_int != nullptr, st, a.epi != nullptr)
     if (ta == PM_Q4_K && tb == PM_Q4_K) PM_L(PM_Q4_K, PM_Q4_K);
     if (ta == PM_Q5_K && tb == PM_Q5_K) PM_L(PM_Q5_K, PM_Q5_K);
     if (ta == PM_Q6_K && tb == PM_Q6_K) PM_L(PM_Q6_K, PM_Q6_K);

@@ -17,7 +17,7 @@ template <int T, int NC>
 __global__ __launch_bounds__(PM_GEMV_BLOCK, 2) void gemv_q_cols_kernel(GemvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double nred[PM_GEMV_NW];
-    gemv_body<T, T, false, false, false, NC>(p, smem, nred, GridBar{nullptr, nullptr, 0, 1, 1});
+    gemv_body<T, T, false, false, NC>(p, smem, nred);
 }
 
 template <int T>

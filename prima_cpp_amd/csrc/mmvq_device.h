@@ -1,5 +1,5 @@
-// mmvq_device.h — device code of the batch-1 quantized mat-vec (shared by mmvq.hip's stand-alone launches and the
-// two-phase attention + wo kernel of attn_wo.hip). See mmvq.hip for the design notes.
+// mmvq_device.h — device code of the batch-1 quantized mat-vec (shared by mmvq.hip and the multi-column mmvq_cols.hip).
+// See mmvq.hip for the design notes.
 #pragma once
 #include "pm355_device.h"
 #include "pm355_kernels.h"
@@ -14,6 +14,15 @@ struct GemvJob {
     const uint8_t * W; const uint8_t * W2; float * y; const float * bias; const float * resid;
     long row_stride;
     int N, is_b /*uses TB*/, U /*units per row*/;
+    int role;    // QKV epilogue (GemvP::epi): 0 none, 1 = query rows (rotate, round to F16), 2 = key rows (rotate, store in the K cache), 3 = value rows (store in the V cache)
+    int split;   // items of this job are (row, chunk) steps instead of whole rows: a few long rows spread over all waves (wk / wv next to wq)
+};
+// RoPE + F16 KV store in the epilogue of the wq | wk | wv launch (NORM-mode rope: a pair = two adjacent rows of one workgroup's slice).
+// tab[i] = (cos, sin) of rotation pair i at this token's position, built once per token by rope_table_kernel (layer_ops.hip) with the
+// reference's running product (ggml_rope_cache_init, ggml.c:14117-14131); cell / sequence as in attn_device.h (dyn: ggml-graph mode).
+struct QkvEpi {
+    const float * tab; const int32_t * pos_ptr, * seq_ptr, * dyn; long seq_stride;
+    uint16_t * kc, * vc; int kv_dim /*Hkv * dh*/, dh, n_ctx, n_rot, v_rowmajor;
 };
 struct GemvP {
     GemvJob job[3];
@@ -24,6 +33,8 @@ struct GemvP {
     int32_t * dbg;
     int ncols;                              // activation columns served by one launch (xmode 0 only when > 1)
     long xq_stride, y_stride;               // bytes between quantized activation rows; floats between output columns
+    unsigned long long * ts;                // measurement builds (-DPM_TS): this launch's timestamp slot, else null
+    QkvEpi epi;                             // used by the EPI instantiation only
 };
 
 // Per-type traits. A unit's NV values come in NV/16 groups of 16 CONTIGUOUS activations; group_base() gives the
@@ -318,7 +329,7 @@ __device__ __forceinline__ double sumsq4(const float4 & f) {
 
 template <int ABLK, bool COH>
 __device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_t * xs_q, int * xs_gs, float * xs_d, double * nred,
-                                             int wave, int lane, int ncols = 1, int col_bytes = 0) {
+                                             int wave, int lane, int ncols = 1, int col_bytes = 0, unsigned long long * t_norm = nullptr) {
     const int tid = threadIdx.x;
     const int K = p.K;
     if (p.xmode == 0) {
@@ -362,6 +373,7 @@ __device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_
         ss = wave_sum_f64(ss);
         if (lane == 0) nred[wave] = ss;
         __syncthreads();
+        if (t_norm) *t_norm = PM_TS_NOW();
         double tot = 0.0;
 #pragma unroll
         for (int k = 0; k < PM_GEMV_NW; ++k) tot += nred[k];
@@ -558,78 +570,98 @@ template <int TYPE, bool PAIR, int NC = 1> struct Item {
             consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
         }
     }
+    // SPLIT jobs: an item is ONE step (row, chunk); every step's partial sum goes to out[item] and write_out adds the chunks of a row in
+    // chunk order. Used for the few rows of wk / wv per workgroup next to wq: (rows x chunks) items spread over all 16 waves instead of
+    // whole rows that load only `rows` of them (a wave with a k or v row ran 6 steps where the others ran 4).
+    template <bool DBG>
+    static __device__ __forceinline__ void run_job_split(Regs & ga, Regs & gb, const GemvP & p, const GemvJob & jb, const XLds & xs, float * out,
+                                                         int first, int n_items, int r0, int r1, int lane) {
+        static_assert(R == 1 && !PAIR && NC == 1, "split jobs: single rows, one column");
+        if (first >= n_items) return;
+        const int upl = (jb.U + 63) >> 6, cpr = (upl + CH - 1) / CH;
+        float acc[R][NM][NC];
+        acc[0][0][0] = 0.0f;
+        auto step = [&](Regs & g, int id) __attribute__((always_inline)) {
+            const int row = r0 + id / cpr, c = id - (id / cpr) * cpr;
+            consume<DBG>(g, acc, p, jb, xs, row, r1, c * CH, lane);
+            const float o = wave_sum(acc[0][0][0]); acc[0][0][0] = 0.0f;
+            if (lane == 0) out[id] = o;
+        };
+        int id = first;
+        issue(ga, p, jb, r0 + id / cpr, r1, (id - (id / cpr) * cpr) * CH, lane);
+        for (; id + 2 * PM_GEMV_NW < n_items; id += 2 * PM_GEMV_NW) {
+            const int i1 = id + PM_GEMV_NW, i2 = id + 2 * PM_GEMV_NW;
+            issue(gb, p, jb, r0 + i1 / cpr, r1, (i1 - (i1 / cpr) * cpr) * CH, lane);
+            step(ga, id);
+            issue(ga, p, jb, r0 + i2 / cpr, r1, (i2 - (i2 / cpr) * cpr) * CH, lane);
+            step(gb, i1);
+        }
+        if (id + PM_GEMV_NW < n_items) {
+            const int i1 = id + PM_GEMV_NW;
+            issue(gb, p, jb, r0 + i1 / cpr, r1, (i1 - (i1 / cpr) * cpr) * CH, lane);
+            step(ga, id);
+            step(gb, i1);
+        } else step(ga, id);
+    }
 };
 
+// chunks (steps) per row of a job, as Item<>::run_job counts them
+template <int TYPE> __device__ __forceinline__ int job_cpr(const GemvJob & jb) {
+    constexpr int CH = QT<TYPE>::NV == 64 ? PM_CH64 : PM_CH32;
+    return (((jb.U + 63) >> 6) + CH - 1) / CH;
+}
+// result of row `row` (index inside the workgroup's slice) of a job whose results start at outbuf[ob]
+__device__ __forceinline__ float row_result(const GemvJob & jb, const float * outbuf, int ob, int row, int cpr) {
+    if (!jb.split) return outbuf[ob + row];
+    float o = outbuf[ob + row * cpr];
+    for (int c = 1; c < cpr; ++c) o += outbuf[ob + row * cpr + c];           // chunk order: deterministic
+    return o;
+}
+
 template <bool COH, int NC>
-__device__ __forceinline__ void write_out(const GemvJob & jb, const float * outbuf, int r0, int r1, int ob, int tid, long y_stride) {
+__device__ __forceinline__ void write_out(const GemvJob & jb, const float * outbuf, int r0, int r1, int ob, int tid, long y_stride, int cpr = 1) {
     for (int t = tid; t < (r1 - r0) * NC; t += PM_GEMV_BLOCK) {
         const int c = NC == 1 ? 0 : t / (r1 - r0), row = NC == 1 ? t : t - c * (r1 - r0);     // consecutive threads -> consecutive rows
-        float out = outbuf[(ob + row) * NC + c];
+        float out = NC == 1 ? row_result(jb, outbuf, ob, row, cpr) : outbuf[(ob + row) * NC + c];
         if (jb.bias)  out += ld_g(jb.bias + r0 + row);
         if (jb.resid) out += ld_act<false>(jb.resid + c * y_stride + r0 + row);
         st_act<COH>(jb.y + c * y_stride + r0 + row, out);
     }
 }
 
-// Split-phase grid barrier (used inside one launch by attn_wo.hip): a phase first puts its weight loads in flight,
-// THEN waits for the previous phase of all workgroups (whose outputs are its activations).
-// No cache maintenance inside the kernel: activations are WRITTEN with write-through device-scope stores (st_act) and
-// every activation buffer is written exactly once per kernel (the engine gives each layer its own scratch set), so a
-// reader can never hold a stale line of it: plain cached loads are correct and are shared by the 32 CUs of an XCD through
-// its L2 (device-coherent dword loads instead were measured 2x slower for the whole token: 256 workgroups x 32 KB of
-// uncached requests on the same 32 KB). arrive = "my stores are acknowledged" + count; wait = poll the count.
-// Counters (one 128-byte line each): ctr[0] = top, ctr[32 (1 + g)] = arrivals of group g, ctr[32 (17 + g)] = release flag of
-// group g. Arrival is two-level - 256 device-scope atomics on ONE address serialize at the memory side (~80 ns each:
-// 20 us per barrier, measured); 16 groups of 16 take ~1.3 us per level. The workgroup that completes the last group
-// publishes the phase number in every group's release flag; a workgroup polls only its own group's flag (16 pollers per
-// line - 256 pollers on the counter line starved the arriving atomics: 10 us per barrier, measured). All values are
-// monotonic within a launch (reset by a memset node before the kernel).
-struct GridBar { unsigned * ctr; int * err; unsigned phase, ngroups, gsize; unsigned last = 0; };   // last: final phase of the launch
-__device__ __forceinline__ void grid_wait(const GridBar & gb) {
-#ifdef PM_EXP_NOBAR
-    if (false) {
-#else
-    if (threadIdx.x == 0 && gb.phase > 0) {
-#endif
-        const unsigned * flag = gb.ctr + 32 * (17 + blockIdx.x / gb.gsize);
-        int spins = 0;
-        while (__hip_atomic_load((const PM_G unsigned *) flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gb.phase) {   // phases 0 .. phase-1 complete
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1 << 20)) { st_g(gb.err, 1); break; }          // watchdog: never hang the GPU (host checks err)
+// wq | wk | wv epilogue: RoPE on adjacent row pairs, q -> F16-rounded f32 in y, k -> F16 K-cache row of this token's cell, v -> F16 V cache
+// (ggml_compute_forward_rope_f32 NORM mode ggml.c:14224-14237 with the per-token cos / sin table; llm_build_kv_store's CPY F32 -> F16,
+// src/llama.cpp:9688-9716; the F16 rounding of q is the conversion ggml_compute_forward_mul_mat applies to src1 of the K.q product).
+// cs: this thread's (cos, sin), loaded by the caller before the barrier in front of the epilogue.
+__device__ __forceinline__ void write_out_qkv(const GemvJob & jb, const QkvEpi & e, const float * outbuf, int r0, int r1, int ob, int tid, int cpr,
+                                              int slot, long kv_off) {
+    const int np = (r1 - r0) >> 1;
+    for (int pr = tid; pr < np; pr += PM_GEMV_BLOCK) {
+        const int row = r0 + 2 * pr;
+        float o0 = row_result(jb, outbuf, ob, 2 * pr, cpr), o1 = row_result(jb, outbuf, ob, 2 * pr + 1, cpr);
+        if (jb.bias) { o0 += ld_g(jb.bias + row); o1 += ld_g(jb.bias + row + 1); }
+        if (jb.role == 3) {
+            const uint16_t h0 = f2h(o0), h1 = f2h(o1);
+            if (e.v_rowmajor) st_g((uint32_t *) (e.vc + kv_off + (long) slot * e.kv_dim + row), (uint32_t) h0 | ((uint32_t) h1 << 16));
+            else { st_g(e.vc + kv_off + (long) row * e.n_ctx + slot, h0); st_g(e.vc + kv_off + (long) (row + 1) * e.n_ctx + slot, h1); }
+            continue;
         }
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ void grid_arrive(const GridBar & gb) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's (write-through, sc1) stores are acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned * g = gb.ctr + 32 * (1 + blockIdx.x / gb.gsize);
-        const unsigned old = __hip_atomic_fetch_add((PM_G unsigned *) g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((old + 1) % gb.gsize == 0) {                               // last workgroup of this group for this phase
-            const unsigned t = __hip_atomic_fetch_add((PM_G unsigned *) gb.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t + 1 == gb.ngroups * (gb.phase + 1)) {                // last group
-                if (gb.last) {
-                    // final phase: nobody waits any more and every workgroup has arrived -> put the barrier state back to zero, so
-                    // the next launch of this plan needs no memset node in front of it (a graph node costs ~1.7 us)
-                    __hip_atomic_store((PM_G unsigned *) gb.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    for (unsigned k = 0; k < gb.ngroups; ++k) {
-                        __hip_atomic_store((PM_G unsigned *) (gb.ctr + 32 * (1 + k)), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store((PM_G unsigned *) (gb.ctr + 32 * (17 + k)), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                } else {                                               // release everybody
-                    for (unsigned k = 0; k < gb.ngroups; ++k)
-                        __hip_atomic_store((PM_G unsigned *) (gb.ctr + 32 * (17 + k)), gb.phase + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+        const int d = row % e.dh;                                  // even: pair d / 2 of its head
+        if (d < e.n_rot) {
+            const float c = ld_g(e.tab + d), s_ = ld_g(e.tab + d + 1);
+            const float x0 = o0, x1 = o1;
+            o0 = x0 * c - x1 * s_; o1 = x0 * s_ + x1 * c;
         }
+        const uint16_t h0 = f2h(o0), h1 = f2h(o1);
+        if (jb.role == 2) st_g((uint32_t *) (e.kc + kv_off + (long) slot * e.kv_dim + row), (uint32_t) h0 | ((uint32_t) h1 << 16));
+        else { st_g(jb.y + row, h2f(h0)); st_g(jb.y + row + 1, h2f(h1)); }
     }
 }
 
-// The whole mat-vec of one workgroup. MEGA: called as a later phase of a multi-phase launch (attn_wo.hip; p lives in global memory, `bar` is the
-// barrier to pass before the activations may be read); otherwise the body of gemv_q_kernel.
-template <int TA, int TB, bool PAIR, bool DBG, bool MEGA, int NC = 1>
-__device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double * nred, const GridBar & bar) {
+// The whole mat-vec of one workgroup (body of gemv_q_kernel / gemv_q_cols_kernel).
+template <int TA, int TB, bool PAIR, bool DBG, int NC = 1, bool EPI = false>
+__device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double * nred) {
+    constexpr bool MEGA = false;      // (outputs are plain stores: kernel boundaries do the cache maintenance)
     constexpr int ABLK = QT<TA>::ABLK;
     typedef Item<TA, PAIR, NC> IA;
     typedef Item<TB, PAIR, NC> IB;
@@ -650,16 +682,31 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
     const int r0_0 = (int) ((long) p.job[0].N * b / G), r1_0 = (int) ((long) p.job[0].N * (b + 1) / G);
     const int r0_1 = (int) ((long) p.job[1].N * b / G), r1_1 = (int) ((long) p.job[1].N * (b + 1) / G);
     const int r0_2 = (int) ((long) p.job[2].N * b / G), r1_2 = (int) ((long) p.job[2].N * (b + 1) / G);
-    const int ni_0 = (r1_0 - r0_0 + R - 1) / R, ni_1 = (r1_1 - r0_1 + R - 1) / R, ni_2 = (r1_2 - r0_2 + R - 1) / R;
-    const int ob_1 = r1_0 - r0_0, ob_2 = ob_1 + (r1_1 - r0_1);
+    // split jobs (EPI launches: wk / wv): items = (row, chunk) steps, results = one partial per item
+    const int cpr_1 = !EPI || !p.job[1].split ? 1 : (TA != TB && p.job[1].is_b ? job_cpr<TB>(p.job[1]) : job_cpr<TA>(p.job[1]));
+    const int cpr_2 = !EPI || !p.job[2].split ? 1 : (TA != TB && p.job[2].is_b ? job_cpr<TB>(p.job[2]) : job_cpr<TA>(p.job[2]));
+    const int ni_0 = (r1_0 - r0_0 + R - 1) / R;
+    const int ni_1 = cpr_1 > 1 ? (r1_1 - r0_1) * cpr_1 : (r1_1 - r0_1 + R - 1) / R, ni_2 = cpr_2 > 1 ? (r1_2 - r0_2) * cpr_2 : (r1_2 - r0_2 + R - 1) / R;
+    const int ob_1 = r1_0 - r0_0, ob_2 = ob_1 + (r1_1 - r0_1) * cpr_1;
+    // QKV epilogue: this token's cache cell and slab, fetched through the scalar cache now, used after the rows
+    int epi_slot = 0; long epi_off = 0;
+    if (EPI) {
+        if (p.epi.dyn) epi_slot = uniform_const_ptr(p.epi.dyn)[0];
+        else {
+            const int seq = p.epi.seq_ptr ? uniform_const_ptr(p.epi.seq_ptr)[0] : 0;
+            epi_slot = uniform_const_ptr(p.epi.pos_ptr)[seq];
+            epi_off = (long) seq * p.epi.seq_stride;
+        }
+    }
 
     // (1) activation row -> LDS (quantized, bit-exact with the reference quantizers).
     //     [Measured and rejected: pre-issuing the first item's 16-byte weight loads across the prologue (spills under the
     //      128-VGPR budget, -20 %); an L2 prefetch of that item with one dword per 128-B line (-7 % even when limited to
     //      the small wq/wo launches: the in-order VMEM return delays the prologue and the lines are fetched twice); and
     //      splitting the workgroup into 8 prologue waves + 8 waves that pre-issue their first step (-3 %, A/B on one box).]
+    unsigned long long tsv[6] = {PM_TS_NOW(), 0, 0, 0, 0, 0};
     ActRegs areg;
-    if (!MEGA) stage_issue<ABLK, MEGA>(p, areg, wave, lane);                  // activation loads go out first (they return first)
+    stage_issue<ABLK, MEGA>(p, areg, wave, lane);                             // activation loads go out first (they return first)
     typename IA::Regs g0, g1;                                           // job 0 is always of type TA (host side orders the jobs)
 #ifndef PM_NO_PREISSUE
     IA::issue(g0, p, p.job[0], r0_0 + wave * R, r1_0, 0, lane);
@@ -670,9 +717,9 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
     }
 #endif
 #endif
-    if (MEGA) { grid_wait(bar); stage_issue<ABLK, MEGA>(p, areg, wave, lane); }   // multi-phase launch: the activations exist only now
-    stage_finish<ABLK, MEGA>(p, areg, xs_q, xs_gs, xs_d, nred, wave, lane, NC, col_bytes);
+    stage_finish<ABLK, MEGA>(p, areg, xs_q, xs_gs, xs_d, nred, wave, lane, NC, col_bytes, &tsv[1]);
     __syncthreads();
+    tsv[2] = PM_TS_NOW();
     const XLds xs = {xs_q, xs_gs, xs_d, col_bytes};
     // (2) rows. Items of the jobs are dealt to the waves round-robin, continuing across jobs (wave offset rotates) so that
     //     the small k / v slices do not all land on wave 0.
@@ -685,18 +732,44 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
 #endif
     typename IB::Regs gB, gB1;
     if (ni_1 > 0) {
-        if (TA != TB && p.job[1].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[1], xs, outbuf + ob_1 * NC, w1, ni_1, r0_1, r1_1, lane);
-        else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[1], xs, outbuf + ob_1 * NC, w1, ni_1, r0_1, r1_1, lane);
+        if constexpr (EPI && !PAIR && NC == 1 && R == 1) {
+            if (cpr_1 > 1) {
+                if (TA != TB && p.job[1].is_b) IB::template run_job_split<DBG>(gB, gB1, p, p.job[1], xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
+                else                           IA::template run_job_split<DBG>(g0, g1, p, p.job[1], xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
+            }
+        }
+        if (cpr_1 == 1) {
+            if (TA != TB && p.job[1].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[1], xs, outbuf + ob_1 * NC, w1, ni_1, r0_1, r1_1, lane);
+            else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[1], xs, outbuf + ob_1 * NC, w1, ni_1, r0_1, r1_1, lane);
+        }
     }
     if (ni_2 > 0) {
-        if (TA != TB && p.job[2].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[2], xs, outbuf + ob_2 * NC, w2, ni_2, r0_2, r1_2, lane);
-        else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[2], xs, outbuf + ob_2 * NC, w2, ni_2, r0_2, r1_2, lane);
+        if constexpr (EPI && !PAIR && NC == 1 && R == 1) {
+            if (cpr_2 > 1) {
+                if (TA != TB && p.job[2].is_b) IB::template run_job_split<DBG>(gB, gB1, p, p.job[2], xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
+                else                           IA::template run_job_split<DBG>(g0, g1, p, p.job[2], xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
+            }
+        }
+        if (cpr_2 == 1) {
+            if (TA != TB && p.job[2].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[2], xs, outbuf + ob_2 * NC, w2, ni_2, r0_2, r1_2, lane);
+            else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[2], xs, outbuf + ob_2 * NC, w2, ni_2, r0_2, r1_2, lane);
+        }
     }
+    tsv[3] = PM_TS_NOW();                              // (wave 0 has finished its rows)
     __syncthreads();
+    tsv[4] = PM_TS_NOW();                              // (all 16 waves have)
     // (4) coalesced write-out (+bias, +residual)
-    write_out<MEGA, NC>(p.job[0], outbuf, r0_0, r1_0, 0, tid, p.y_stride);
-    write_out<MEGA, NC>(p.job[1], outbuf, r0_1, r1_1, ob_1, tid, p.y_stride);
-    write_out<MEGA, NC>(p.job[2], outbuf, r0_2, r1_2, ob_2, tid, p.y_stride);
+    if (EPI && p.epi.tab) {
+        write_out_qkv(p.job[0], p.epi, outbuf, r0_0, r1_0, 0, tid, 1, epi_slot, epi_off);
+        write_out_qkv(p.job[1], p.epi, outbuf, r0_1, r1_1, ob_1, tid, cpr_1, epi_slot, epi_off);
+        write_out_qkv(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off);
+    } else {
+        write_out<MEGA, NC>(p.job[0], outbuf, r0_0, r1_0, 0, tid, p.y_stride);
+        write_out<MEGA, NC>(p.job[1], outbuf, r0_1, r1_1, ob_1, tid, p.y_stride, cpr_1);
+        write_out<MEGA, NC>(p.job[2], outbuf, r0_2, r1_2, ob_2, tid, p.y_stride, cpr_2);
+    }
+    tsv[5] = PM_TS_NOW();
+    pm_ts_store(p.ts, 1 | (PAIR ? 16 : 0) | (p.xmode << 8) | (p.K << 12), tsv);
 }
 
 

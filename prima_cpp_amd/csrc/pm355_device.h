@@ -133,6 +133,28 @@ __device__ __forceinline__ void k4_scale_min_pair(uint32_t s0, uint32_t s1, uint
     m0  = (int) (m & 0xFF);  m1  = (int) (m >> 8);
 }
 
+// ---- seam anatomy (measurement builds only: -DPM_TS, tools/seam_anatomy.py) ----------------------------------------
+// Every instrumented launch gets a slot of PM_TS_WGS x 8 timestamps of the chip-wide 100 MHz counter (s_memrealtime: comparable
+// across workgroups, XCDs and kernels); thread 0 of a workgroup keeps its stamps in SGPRs and stores them when it leaves.
+#define PM_TS_WGS 256
+#ifdef PM_TS
+#define PM_TS_NOW() __builtin_amdgcn_s_memrealtime()
+unsigned long long * pm_ts_next_slot();          // host (ts.hip): device address of the next launch's slot, or null when disabled
+#else
+#define PM_TS_NOW() 0ull
+static inline unsigned long long * pm_ts_next_slot() { return nullptr; }
+#endif
+__device__ __forceinline__ void pm_ts_store(unsigned long long * ts, int tag, const unsigned long long (&t)[6]) {
+#ifdef PM_TS
+    if (ts && threadIdx.x == 0 && blockIdx.x < PM_TS_WGS) {
+        unsigned long long * o = ts + (size_t) blockIdx.x * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o[i] = t[i];
+        o[6] = (unsigned long long) tag; o[7] = (unsigned long long) gridDim.x;
+    }
+#endif
+}
+
 // ---- device-coherent activation traffic inside one launch ------------------------------------------------------
 // Activations written by one workgroup and read by another INSIDE one kernel (attn_wo.hip) go through agent-scope
 // relaxed atomics: global_load / global_store ... sc1, which are coherent across the 8 XCD L2s without any cache

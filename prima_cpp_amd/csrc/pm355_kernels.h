@@ -55,12 +55,19 @@ struct pm_gemv_job {
     const void * W; const void * W2;    // W2 != null: y = silu(W.x) * (W2.x) (all jobs of a launch alike)
     float * y; const float * bias; const float * resid;
 };
+// RoPE + KV store in the epilogue of a wq | wk | wv launch (jobs in that order). Served for NORM-mode rope when every workgroup's row
+// slices start and end on even rows (pm_gemv_fused_check tells); tab = this token's cos / sin table (pm_launch_rope_table)
+struct pm_qkv_epi {
+    const float * tab; const int32_t * pos, * seq, * dyn; long seq_stride;
+    void * kc, * vc; int Hkv, dh, n_ctx, n_rot, v_rowmajor;
+};
 struct pm_gemv_fused {
     int K; int njobs;
     pm_gemv_job job[3];
     const void * xq;                    // pre-quantized activation row, or null
     const float * xf; const float * norm_w; float eps;
     int32_t * dbg_int;
+    const pm_qkv_epi * epi;             // null: plain outputs
 };
 int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st);
 int pm_gemv_fused_check(const pm_gemv_fused & a);      // the validation part of pm_launch_gemv_fused only
@@ -74,21 +81,8 @@ int pm_launch_gemm_q_ex(int type, const void * W, const float * X, float * Y, in
 int pm_launch_gemm_q_h(int type, const void * W, const float * X, const void * x_f16, float * Y, void * y_f16, int K, int N, int T,
                        const float * bias, const float * resid, const float * silu_gate, int reuse_x, hipStream_t st);
 
-// measurement helper (probe.hip): stream `bytes` from HBM once with the mat-vec's access pattern
-int pm_launch_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, hipStream_t st);
 int pm_device_cus();
-// measurement skeleton of a persistent LDS-DMA loader / consumer decode layer (engine_probe.hip)
-int pm_launch_engine_probe(const void * w, long region_stride, int n_regions, int n_layers, int nph, const int * chunks, const int * act_n,
-                           const int * out_n, int attn_ph, float attn_us, float * act, long act_stride, void * ctr, int nw, int ns, int nt,
-                           int thin, hipStream_t st);
-
 struct pm_rope_cfg;
-// attention + wo mat-vec (+ residual) of one layer as ONE two-phase launch (attn_wo.hip); -1: no kernel for this shape / type
-int  pm_launch_attn_wo(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos0, const int32_t * seq,
-                       long seq_stride, const float * freq_factors, float * att, int H, int Hkv, int dh, int n_ctx, float scale,
-                       const pm_rope_cfg & c, const pm_gemv_fused & f, void * ctr, hipStream_t st);
-size_t pm_attn_wo_bar_bytes();
-void pm_launch_barrier_probe(int n, void * ctr, hipStream_t st);       // measurement: n device-wide barriers in one launch
 
 // small-batch (1..32 tokens) quantized mat-mul on the integer matrix cores (mmq_i8.hip): Q4_K / Q6_K weights, Q8_K activations
 // (xq row-SoA, or x_f32 quantized first into a per-device scratch). 0, or -1 type / -2 shape / -3 device / -4 LDS

@@ -77,6 +77,22 @@ def load():
     return _lib
 
 
+_probe = None
+
+
+def load_probe():
+    """libprima_mi355_probe.so: measurement helpers (tools/csrc), kept out of the product library."""
+    global _probe
+    if _probe is None:
+        path = os.path.join(HERE, "libprima_mi355_probe.so")
+        if not os.path.exists(path):
+            raise PM355Error(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _probe = C.CDLL(path)
+        _probe.pm355_probe_stream_read.restype = C.c_int
+        _probe.pm355_probe_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    return _probe
+
+
 def get():
     return load()
 

@@ -277,3 +277,55 @@ def mul_mat_mfma(w, x, bias=None, resid=None):
     check(lib.pm355_mul_mat_q_mfma(w.type, ptr(w.data), w.K, w.N, ptr(x2), x2.shape[0], ptr(y), ptr(bias), ptr(resid), stream_ptr()),
           "mul_mat_q_mfma")
     return y
+
+
+class QkvStore(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("rope_table", _C.c_void_p), ("d_pos", _C.c_void_p), ("d_cell_nkv", _C.c_void_p), ("k_cache", _C.c_void_p),
+                ("v_cache", _C.c_void_p), ("n_head_kv", _C.c_int32), ("head_dim", _C.c_int32), ("n_ctx", _C.c_int32),
+                ("n_rot", _C.c_int32), ("v_rowmajor", _C.c_int32), ("pad_", _C.c_int32)]
+
+
+def rope_table(pos, head_dim, freq_factors=None, mode=0, n_ctx_orig=8192, freq_base=10000.0, freq_scale=1.0, ext_factor=0.0,
+               attn_factor=1.0, beta_fast=32.0, beta_slow=1.0, n_dims=None):
+    """This token's (cos, sin) per rotation pair: f32 [n_dims] = c0, s0, c1, s1, ... (ggml_rope_cache_init). pos: int32 device tensor [1]."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_rope_table.restype = C.c_int
+    lib.pm355_rope_table.argtypes = [C.c_void_p] * 5
+    rp = RopeParams(n_dims or head_dim, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow)
+    tab = torch.empty(n_dims or head_dim, dtype=torch.float32, device=pos.device)
+    check(lib.pm355_rope_table(C.addressof(rp), ptr(pos), ptr(freq_factors), ptr(tab), stream_ptr()), "rope_table")
+    return tab
+
+
+def mul_mat_vec_qkv(ws, x, tab, pos, k_cache, v_cache, n_head_kv, head_dim, n_ctx, norm_w=None, eps=0.0, biases=None, n_rot=None,
+                    v_rowmajor=False, cell_nkv=None):
+    """wq | wk | wv mat-vecs with RoPE + F16 KV store in the epilogue: returns the rotated, F16-rounded query row [N_q] (f32);
+    the K row / V column of cache cell pos[0] (or cell_nkv[0]) are written."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_mul_mat_vec_qkv.restype = C.c_int
+    lib.pm355_mul_mat_vec_qkv.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    jobs = (MatvecJob * 3)()
+    q = torch.empty(ws[0].N, dtype=torch.float32, device=x.device)
+    for j, w in enumerate(ws):
+        jobs[j] = MatvecJob(w.type, 0, w.N, ptr(w.data), None, ptr(q) if j == 0 else None,
+                            ptr(biases[j]) if biases and biases[j] is not None else None, None)
+    s = QkvStore(ptr(tab), ptr(pos), ptr(cell_nkv), ptr(k_cache), ptr(v_cache), n_head_kv, head_dim, n_ctx, n_rot or head_dim,
+                 int(v_rowmajor), 0)
+    check(lib.pm355_mul_mat_vec_qkv(C.addressof(jobs), ws[0].K, ptr(x), ptr(norm_w), float(eps), C.addressof(s), stream_ptr()),
+          "mul_mat_vec_qkv")
+    return q
+
+
+def attn_cached(q_rot, k_cache, v_cache, pos, n_head, n_head_kv, head_dim, n_ctx, scale, cell_nkv=None, mask=None, max_keys=0, flags=0):
+    """Single-token attention over cells that are all in the cache (q rotated and F16-rounded). pos: int32 device tensor [1]."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_attn_cached.restype = C.c_int
+    lib.pm355_attn_cached.argtypes = [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_int, C.c_void_p]
+    out = torch.empty_like(q_rot)
+    check(lib.pm355_attn_cached(ptr(q_rot), ptr(k_cache), ptr(v_cache), ptr(pos), ptr(cell_nkv), ptr(mask), ptr(out), n_head, n_head_kv,
+                                head_dim, n_ctx, float(scale), max_keys, flags, stream_ptr()), "attn_cached")
+    return out

@@ -492,3 +492,77 @@ def test_mfma_prefill_gemm_vs_oracle(P, oracle, t, K, N, T):
     ref = oracle.mul_mat(t, blocks, K, N, x) + bias + resid
     nm_ref = ((got - ref) ** 2).sum() / (ref ** 2).sum()
     assert nm_ref < 5e-4, nm_ref
+
+
+@pytest.mark.parametrize("tv", [Q6_K, Q5_K, Q4_K])
+@pytest.mark.parametrize("dh,H,Hkv", [(128, 8, 4), (64, 16, 8)])
+def test_qkv_epilogue_and_cached_attention_equal_the_fused_attention_path(P, oracle, tv, dh, H, Hkv):
+    """Round-3 decode form - RoPE + F16 KV store in the EPILOGUE of the wq | wk | wv launch (per-token cos / sin table, wk / wv dealt out
+    step by step over all waves), attention over cached cells only (one-barrier kernel up to 64 cells, per-head body beyond) - against
+    the round-2 form (plain mat-vecs, rope + store inside the fused attention kernel) on a run of tokens that crosses the 64-cell
+    boundary; the mat-vec outputs against the oracle's mul_mat."""
+    torch = P.torch
+    rng = np.random.default_rng(61)
+    K, n_ctx = 1024, 128
+    Nq, Nkv = H * dh, Hkv * dh
+    assert Nq % 512 == 0 and Nkv % 512 == 0
+    blocks = [rand_blocks(Q4_K, Nq, K, rng), rand_blocks(Q4_K, Nkv, K, rng), rand_blocks(tv, Nkv, K, rng)]
+    ws = [P.upload_weight(Q4_K, blocks[0], K, Nq), P.upload_weight(Q4_K, blocks[1], K, Nkv), P.upload_weight(tv, blocks[2], K, Nkv)]
+    nw = _dev(P, (1 + rng.normal(0, 0.05, K)).astype(np.float32))
+    bias = [_dev(P, rng.normal(0, 0.3, n).astype(np.float32)) for n in (Nq, Nkv, Nkv)]
+    ff = _dev(P, (1 + rng.uniform(0, 7, dh // 2)).astype(np.float32))
+    kcA = torch.zeros(n_ctx * Nkv, dtype=torch.int16, device="cuda"); vcA = torch.zeros_like(kcA)
+    kcB = torch.zeros_like(kcA); vcB = torch.zeros_like(kcA)
+    scale = 1.0 / np.sqrt(dh)
+    worst = 0.0
+    for pos in list(range(0, 6)) + [31, 32, 62, 63, 64, 65, 90]:
+        x = rng.normal(0, 1, (1, K)).astype(np.float32)
+        xd = _dev(P, x)
+        qA, kA, vA = P.mul_mat_vec_fused(ws, xd, norm_w=nw, eps=1e-5, biases=bias)
+        outA = P.attn_rope_fused(qA, kA, vA, kcA, vcA, pos, H, Hkv, dh, n_ctx, scale, freq_factors=ff, freq_base=500000.0)
+        pd = torch.tensor([pos], dtype=torch.int32, device="cuda")
+        tab = P.rope_table(pd, dh, freq_factors=ff, freq_base=500000.0)
+        qB = P.mul_mat_vec_qkv(ws, xd, tab, pd, kcB, vcB, Hkv, dh, n_ctx, norm_w=nw, eps=1e-5, biases=bias)
+        outB = P.attn_cached(qB, kcB, vcB, pd, H, Hkv, dh, n_ctx, scale)
+        torch.cuda.synchronize()
+        # the K row / V column of this cell: the same F16 values up to the summation order of the split wk / wv rows (<= 1 F16 ulp, rarely)
+        a = kcA.cpu().numpy().view(np.float16).astype(np.float32).reshape(n_ctx, Nkv)[pos]
+        b = kcB.cpu().numpy().view(np.float16).astype(np.float32).reshape(n_ctx, Nkv)[pos]
+        assert np.abs(a - b).max() <= 2e-3 * max(1.0, np.abs(a).max()) and (a != b).mean() < 0.02, (pos, np.abs(a - b).max(), (a != b).mean())
+        va = vcA.cpu().numpy().view(np.float16).astype(np.float32).reshape(Nkv, n_ctx)[:, pos]
+        vb = vcB.cpu().numpy().view(np.float16).astype(np.float32).reshape(Nkv, n_ctx)[:, pos]
+        assert np.abs(va - vb).max() <= 2e-3 * max(1.0, np.abs(va).max()) and (va != vb).mean() < 0.02
+        # q: rotated + F16-rounded == F16 rounding of the oracle's rope of the round-2 q
+        q_ref = oracle.rope(qA.cpu().numpy().reshape(1, H, dh), np.array([pos], dtype=np.int32), freq_factors=ff.cpu().numpy(), freq_base=500000.0)
+        q_ref = q_ref.astype(np.float16).astype(np.float32).reshape(-1)
+        qb = qB.cpu().numpy()
+        assert np.abs(qb - q_ref).max() <= 2e-3 * max(1.0, np.abs(q_ref).max()) and (qb != q_ref).mean() < 0.02
+        # from here on both caches must hold the SAME bytes, or later cells would compare different histories
+        kcB.copy_(kcA); vcB.copy_(vcA)
+        wa, wb = outA.cpu().numpy(), outB.cpu().numpy()
+        worst = max(worst, float(np.abs(wa - wb).max() / max(1.0, np.abs(wa).max())))
+        assert np.abs(wa - wb).max() <= 3e-3 * max(1.0, np.abs(wa).max()), (pos, np.abs(wa - wb).max())
+        # cells in between: identical random history for both paths
+        if pos >= 5:
+            nxt = {5: 31, 31: 32, 32: 62, 62: 63, 63: 64, 64: 65, 65: 90}.get(pos)
+            if nxt:
+                fill_k = rng.normal(0, 1, (nxt - pos - 1, Nkv)).astype(np.float16).view(np.int16)
+                fill_v = rng.normal(0, 1, (Nkv, nxt - pos - 1)).astype(np.float16).view(np.int16)
+                if fill_k.size:
+                    kcA.view(n_ctx, Nkv)[pos + 1:nxt] = torch.from_numpy(fill_k).cuda()
+                    vcA.view(Nkv, n_ctx)[:, pos + 1:nxt] = torch.from_numpy(fill_v).cuda()
+                    kcB.copy_(kcA); vcB.copy_(vcA)
+    print(f"\n[qkv epilogue + cached attention, dh {dh}, attn_v type {tv}] max |d out| / max |out| = {worst:.2e}")
+    # and the epilogue's mat-vecs against the oracle (q before rope is not observable: check k / v through the cache at one more cell)
+    x = rng.normal(0, 1, (1, K)).astype(np.float32)
+    pd = torch.tensor([100], dtype=torch.int32, device="cuda")
+    tab = P.rope_table(pd, dh, freq_factors=ff, freq_base=500000.0)
+    P.mul_mat_vec_qkv(ws, _dev(P, x), tab, pd, kcB, vcB, Hkv, dh, n_ctx, norm_w=nw, eps=1e-5, biases=bias)
+    xn = oracle.rms_norm(x, nw.cpu().numpy(), 1e-5)
+    v_ref = oracle.mul_mat(tv, blocks[2], K, Nkv, xn)[0] + bias[2].cpu().numpy()
+    v_got = vcB.cpu().numpy().view(np.float16).astype(np.float32).reshape(Nkv, n_ctx)[:, 100]
+    assert np.allclose(v_got, v_ref.astype(np.float16).astype(np.float32), rtol=2e-3, atol=2e-3)
+    k_ref = oracle.mul_mat(Q4_K, blocks[1], K, Nkv, xn)[0] + bias[1].cpu().numpy()
+    k_ref = oracle.rope(k_ref.reshape(1, Hkv, dh), np.array([100], dtype=np.int32), freq_factors=ff.cpu().numpy(), freq_base=500000.0).reshape(-1)
+    k_got = kcB.cpu().numpy().view(np.float16).astype(np.float32).reshape(n_ctx, Nkv)[100]
+    assert np.allclose(k_got, k_ref.astype(np.float16).astype(np.float32), rtol=2e-3, atol=2e-3)

@@ -26,7 +26,7 @@ GPU_ARGS = ["--keep-out-in-cuda"]
 N_GEN, N_PROMPT = 128, 16
 
 SHAPES = {
-    "small": dict(n_layer=8, n_embd=1024, n_head=8, n_head_kv=2, n_ff=2816, n_vocab=8192, is_70b=False),
+    "small": dict(n_layer=8, n_embd=1024, n_head=8, n_head_kv=4, n_ff=2816, n_vocab=8192, is_70b=False),
     "8b": dict(n_layer=32, n_embd=4096, n_head=32, n_head_kv=8, n_ff=14336, n_vocab=128256, is_70b=False),
     "70b8": dict(n_layer=8, n_embd=8192, n_head=64, n_head_kv=8, n_ff=28672, n_vocab=128256, is_70b=True),
 }

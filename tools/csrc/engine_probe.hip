@@ -18,7 +18,7 @@
 //   * the attention phase has no weights: 64 workgroups hold for `attn_us` microseconds (the latency chain), all others pass
 // Every spin is bounded; a time-out raises *err, sets an LDS give-up word and the kernel runs to completion without waiting.
 #include "pm355_device.h"
-#include "pm355_kernels.h"
+#include "pm355_probe.h"
 
 namespace {
 
@@ -267,7 +267,8 @@ int pm_launch_engine_probe(const void * w, long region_stride, int n_regions, in
     if (nph < 1 || nph > MAXPH || ns < 2 || ns > 8 || (nw != 4 && nw != 8 && nw != 16)) return -1;
     EngP p = {};
     p.w = (const uint8_t *) w; p.region_stride = region_stride; p.n_regions = n_regions; p.n_layers = n_layers; p.nph = nph;
-    const int grid = pm_device_cus();
+    hipDeviceProp_t pr_; int dev_ = 0; (void) hipGetDevice(&dev_);
+    const int grid = hipGetDeviceProperties(&pr_, dev_) == hipSuccess ? pr_.multiProcessorCount : 256;
     long off = 0;
     for (int i = 0; i < nph; ++i) {
         p.chunks[i] = chunks[i]; p.act_n[i] = act_n[i]; p.out_n[i] = out_n[i]; p.off[i] = off;

@@ -2,7 +2,7 @@
 // the access pattern of the mat-vec (every wave streams its own contiguous span with 16-byte non-temporal loads, one
 // 1024-thread workgroup per CU), reported next to the 8 TB/s spec peak by bench.py ("confirm on the box").
 #include "pm355_device.h"
-#include "pm355_kernels.h"
+#include "pm355_probe.h"
 
 namespace {
 

@@ -1,0 +1,41 @@
+// probe_api.hip — extern "C" surface of libprima_mi355_probe.so (measurement helpers only; see pm355_probe.h).
+#include "pm355_probe.h"
+
+static inline hipStream_t S(void * s) { return (hipStream_t) s; }
+
+extern "C" {
+
+int pm355_probe_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, void * st) {
+    if (pm_launch_stream_read(src, bytes, wg_per_cu, unroll, sink, S(st))) return -3;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+/* measurement skeleton (engine_probe.hip): n_layers decode layers as ONE persistent launch on a run-ahead LDS-DMA weight loader.
+ * w: region_stride * n_regions bytes of anything; act: n_layers * nph * act_stride floats; ctr: 33*128 + 64 zeroed bytes.
+ * *err_out = watchdog code (0 = clean). Times the SECOND of two launches with HIP events: *us = microseconds per launch. */
+int pm355_probe_engine(const void * w, int64_t region_stride, int n_regions, int n_layers, int nph, const int * chunks, const int * act_n,
+                       const int * out_n, int attn_ph, float attn_us, float * act, int64_t act_stride, void * ctr, int nw, int ns, int nt,
+                       int thin, float * us, int * err_out, void * st) {
+    hipEvent_t e0, e1;
+    (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+    int rc = 0;
+    for (int it = 0; it < 2 && !rc; ++it) {
+        if (it == 1) (void) hipEventRecord(e0, S(st));
+        rc = pm_launch_engine_probe(w, (long) region_stride, n_regions, n_layers, nph, chunks, act_n, out_n, attn_ph, attn_us, act,
+                                    (long) act_stride, ctr, nw, ns, nt, thin, S(st));
+        if (it == 1) (void) hipEventRecord(e1, S(st));
+        (void) hipStreamSynchronize(S(st));
+    }
+    float ms = 0.0f;
+    if (!rc) (void) hipEventElapsedTime(&ms, e0, e1);
+    int err = 0;
+    (void) hipMemcpy(&err, (char *) ctr + 33 * 128, 4, hipMemcpyDeviceToHost);
+    if (err) (void) hipMemset(ctr, 0, 33 * 128 + 64);
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    if (us) *us = ms * 1e3f;
+    if (err_out) *err_out = err;
+    if (rc) return -3;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+
+} // extern "C"

@@ -13,12 +13,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import prima_cpp_amd.ops as P  # noqa: E402
 
 lib = P.L.load()
+plib = P.L.load_probe()
 IP = C.POINTER(C.c_int)
-lib.pm355_probe_engine.restype = C.c_int
-lib.pm355_probe_engine.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, IP, IP, IP, C.c_int, C.c_float, C.c_void_p, C.c_int64,
+plib.pm355_probe_engine.restype = C.c_int
+plib.pm355_probe_engine.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, IP, IP, IP, C.c_int, C.c_float, C.c_void_p, C.c_int64,
                                    C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), IP, C.c_void_p]
-lib.pm355_probe_stream_read.restype = C.c_int
-lib.pm355_probe_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+plib.pm355_probe_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 
 CUS = torch.cuda.get_device_properties(0).multi_processor_count
 FILL = 16384
@@ -47,7 +47,7 @@ def run(ch, act_n, out_n, attn_ph, attn_us, n_layers, nw, ns, nt, thin, region_s
     us, err = C.c_float(0), C.c_int(0)
     best = 1e30
     for _ in range(3):
-        rc = lib.pm355_probe_engine(w.data_ptr(), region_stride, n_reg, n_layers, len(ch), arr(ch), arr(act_n), arr(out_n), attn_ph, attn_us,
+        rc = plib.pm355_probe_engine(w.data_ptr(), region_stride, n_reg, n_layers, len(ch), arr(ch), arr(act_n), arr(out_n), attn_ph, attn_us,
                                     act.data_ptr(), ACT_STRIDE, ctr.data_ptr(), nw, ns, nt, thin, C.byref(us), C.byref(err), P.stream_ptr())
         if rc or err.value:
             return None, (rc, err.value)
@@ -61,7 +61,7 @@ def stream_ref(nbytes):
     for rep in range(6):
         off = (rep % (N_REG - 1)) * layer_bytes
         e0.record()
-        P.check(lib.pm355_probe_stream_read(w.data_ptr() + off, nbytes, 1, 8, sink.data_ptr(), P.stream_ptr()), "probe")
+        P.check(plib.pm355_probe_stream_read(w.data_ptr() + off, nbytes, 1, 8, sink.data_ptr(), P.stream_ptr()), "probe")
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)

@@ -12,8 +12,8 @@ import prima_cpp_amd.ops as P  # noqa: E402
 
 def main():
     lib = P.L.load()
-    lib.pm355_probe_stream_read.restype = C.c_int
-    lib.pm355_probe_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    plib = P.L.load_probe()
+    plib.pm355_probe_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     nbytes = 2 << 30
     src = torch.randint(0, 255, (nbytes,), dtype=torch.uint8, device="cuda")
     sink = torch.zeros(4, dtype=torch.int32, device="cuda")
@@ -25,7 +25,7 @@ def main():
                 for rep in range(5):
                     off = (rep % 2) * (1 << 30)      # alternate halves: nothing survives in the 256 MB infinity cache
                     e0.record()
-                    P.check(lib.pm355_probe_stream_read(src.data_ptr() + off, span, wg, un, sink.data_ptr(), P.stream_ptr()), "probe")
+                    P.check(plib.pm355_probe_stream_read(src.data_ptr() + off, span, wg, un, sink.data_ptr(), P.stream_ptr()), "probe")
                     e1.record()
                     torch.cuda.synchronize()
                     best = min(best, e0.elapsed_time(e1) * 1e3)

@@ -10,8 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import prima_cpp_amd.ops as P  # noqa: E402
 
 lib = P.L.load()
-lib.pm355_probe_stream_read.restype = C.c_int
-lib.pm355_probe_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+plib = P.L.load_probe()
+plib.pm355_probe_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 total = 4 << 30
 src = torch.empty(total, dtype=torch.uint8, device="cuda")
 src.random_(0, 255)
@@ -19,7 +19,7 @@ sink = torch.zeros(4, dtype=torch.int32, device="cuda")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 def timed(off, span, wg, unroll):
     e0.record()
-    P.check(lib.pm355_probe_stream_read(src.data_ptr() + off, span, wg, unroll, sink.data_ptr(), P.stream_ptr()), "probe")
+    P.check(plib.pm355_probe_stream_read(src.data_ptr() + off, span, wg, unroll, sink.data_ptr(), P.stream_ptr()), "probe")
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3
@@ -47,7 +47,7 @@ for span_mb in (36, 128):
         for rep in range(24):
             off = ((rep * span) % (total - span)) if mode == "rotate" else 0
             e0.record()
-            P.check(lib.pm355_probe_stream_read(src.data_ptr() + off, span, 1, 8, sink.data_ptr(), P.stream_ptr()), "probe")
+            P.check(plib.pm355_probe_stream_read(src.data_ptr() + off, span, 1, 8, sink.data_ptr(), P.stream_ptr()), "probe")
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
