@@ -25,18 +25,19 @@
 //    different quant types (Q4_K_M: attn_v is Q6_K/Q5_K next to Q4_K q/k); every workgroup takes an equal slice of
 //    the rows of every job.
 #include "mmvq_device.h"
+#include <stdlib.h>
 
 using namespace pmv;
 
 namespace {
 
-template <int TA, int TB, bool PAIR, bool DBG, bool EPI = false>
+template <int TA, int TB, bool PAIR, bool DBG, bool EPI = false, int NPRE = 2>
 __global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(GemvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double nred[PM_GEMV_NW];
-    gemv_body<TA, TB, PAIR, DBG, 1, EPI>(p, smem, nred);
+    // (Q5_K: two 32-weight units per lane and step = 24-VGPR sets with the high-bit plane; a second pre-issued set spills)
+    gemv_body<TA, TB, PAIR, DBG, 1, EPI, (TA == PM_Q5_K && NPRE == 2) ? 1 : NPRE>(p, smem, nred);
 }
-
 template <int TA, int TB>
 int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, hipStream_t st, bool epi = false) {
     const GemvP & p = p_in;
@@ -48,12 +49,14 @@ int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, 
     };
     if (pair) {
         if (TA != TB) return -1;
-        if (dbg) go(gemv_q_kernel<TA, TA, true, true>); else go(gemv_q_kernel<TA, TA, true, false>);
+        // (pair launches: one step of pre-issue - two sets of two matrices next to the activation registers spill)
+        if (dbg) go(gemv_q_kernel<TA, TA, true, true, false, 1>); else go(gemv_q_kernel<TA, TA, true, false, false, 1>);
     } else if (epi) {
         if (dbg) return -1;
         go(gemv_q_kernel<TA, TB, false, false, true>);
     } else {
-        if (dbg) go(gemv_q_kernel<TA, TB, false, true>); else go(gemv_q_kernel<TA, TB, false, false>);
+        if (dbg) go(gemv_q_kernel<TA, TB, false, true>);
+        else go(gemv_q_kernel<TA, TB, false, false>);
     }
     return 0;
 }

@@ -284,8 +284,8 @@ __device__ __forceinline__ void q80_block_to_lds(const float v[4], int i4 /*inde
 //                      float4 at element 64 k + 4 j of that block. Two passes (K <= 32768; K <= 16384 with norm weights)
 //                      are loaded ONCE and stay in registers between the sum-of-squares and the quantization.
 //   ABLK = 32  (Q8_0): thread t owns the float4s t, t + 1024, ... (8 lanes = one 32-block); K <= 16384 held in registers.
-#define PM_PRE2 1     // non-pair launches put their first TWO steps in flight before the activation prologue
-struct ActRegs { float4 f[2][4]; float4 g[4]; };
+// f[0] / f[1]: the two passes of a row of up to 128 blocks; with norm weights (held for <= 64 blocks = one pass) f[1] carries the weights
+struct ActRegs { float4 f[2][4]; };
 
 template <int ABLK>
 __device__ __forceinline__ bool act_held(const GemvP & p) {
@@ -309,7 +309,7 @@ __device__ __forceinline__ void stage_issue(const GemvP & p, ActRegs & a, int wa
         if (p.xmode == 2) {
             const int B = min(4 * wave + r, nblk - 1);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a.g[k] = ld_g(nw4 + (B * 64 + 16 * k + j));
+            for (int k = 0; k < 4; ++k) a.f[1][k] = ld_g(nw4 + (B * 64 + 16 * k + j));
         }
     } else {
         const int tid = threadIdx.x, n4 = p.K / 4;
@@ -317,7 +317,7 @@ __device__ __forceinline__ void stage_issue(const GemvP & p, ActRegs & a, int wa
         for (int k = 0; k < 4; ++k) {
             const int i = tid + k * PM_GEMV_BLOCK;
             a.f[0][k] = ld_act4<false>(xf4 + (i < n4 ? i : 0));
-            if (p.xmode == 2) a.g[k] = ld_g(nw4 + (i < n4 ? i : 0));
+            if (p.xmode == 2) a.f[1][k] = ld_g(nw4 + (i < n4 ? i : 0));
         }
     }
 }
@@ -392,13 +392,13 @@ __device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_
         };
         if (held) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) if (4 * (wave + PM_GEMV_NW * t) < nblk) rows(a.f[t], a.g, 4 * (wave + PM_GEMV_NW * t) + r);
+            for (int t = 0; t < 2; ++t) if (4 * (wave + PM_GEMV_NW * t) < nblk) rows(a.f[t], a.f[1], 4 * (wave + PM_GEMV_NW * t) + r);
         } else {
             for (int B0 = 4 * wave; B0 < nblk; B0 += 4 * PM_GEMV_NW) {
                 const int Bc = min(B0 + r, nblk - 1);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { a.f[0][k] = ld_act4<false>(xf4 + (Bc * 64 + 16 * k + j)); if (p.xmode == 2) a.g[k] = ld_g(nw4 + (Bc * 64 + 16 * k + j)); }
-                rows(a.f[0], a.g, B0 + r);
+                for (int k = 0; k < 4; ++k) { a.f[0][k] = ld_act4<false>(xf4 + (Bc * 64 + 16 * k + j)); if (p.xmode == 2) a.f[1][k] = ld_g(nw4 + (Bc * 64 + 16 * k + j)); }
+                rows(a.f[0], a.f[1], B0 + r);
             }
         }
     } else {
@@ -408,14 +408,14 @@ __device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_
                 for (int k = 0; k < 4; ++k) {
                     const int i = i0 + k * PM_GEMV_BLOCK;
                     a.f[0][k] = ld_act4<false>(xf4 + (i < n4 ? i : 0));
-                    if (p.xmode == 2) a.g[k] = ld_g(nw4 + (i < n4 ? i : 0));
+                    if (p.xmode == 2) a.f[1][k] = ld_g(nw4 + (i < n4 ? i : 0));
                 }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = i0 + k * PM_GEMV_BLOCK;
                 if (i - lane < n4) {                 // wave-uniform (n4 is a multiple of 8 = one 32-block)
-                    const float4 f = a.f[0][k], g = a.g[k];
+                    const float4 f = a.f[0][k], g = a.f[1][k];
                     float v[4] = {f.x, f.y, f.z, f.w};
                     if (p.xmode == 2) { v[0] = v[0] * scale * g.x; v[1] = v[1] * scale * g.y; v[2] = v[2] * scale * g.z; v[3] = v[3] * scale * g.w; }
                     if (i < n4) q80_block_to_lds(v, i, xs_q, xs_gs, xs_d);
@@ -504,15 +504,21 @@ template <int TYPE, bool PAIR, int NC = 1> struct Item {
         }
     }
     // All items of ONE job that belong to this wave (item ids first, first+NW, ... < n_job_items), flattened into STEPS
-    // (item, chunk) and software-pipelined with two statically named register sets: the loads of step s+1 are in flight
+    // (item, chunk) and software-pipelined with statically named register sets: the loads of step s+1 are in flight
     // while step s is consumed. The steady-state loop body is straight-line code - every issue() in it is unconditional -
     // so the compiler can use counted s_waitcnt vmcnt(N); the last one or two steps are peeled off behind the loop.
     // (All waves start in lock-step after the prologue barrier: without the overlap the whole chip would alternate
     //  between "only loading" and "only computing".)
-    // PRE: the first step's loads were already issued into `ga` by the kernel (before the activation prologue).
-    template <bool DBG, bool PRE>
-    static __device__ __forceinline__ void run_job(Regs & ga, Regs & gb, const GemvP & p, const GemvJob & jb, const XLds & xs, float * out /*job slice*/,
-                                                   int first, int n_job_items, int r0, int r1, int lane) {
+    // NPRE (0, 1, 2): the kernel already issued the loads of this job's first NPRE steps into ga (, gb) before the activation prologue
+    // (step 1 a clamped copy where the wave has one step only). [Round 3, measured and rejected: 3 or 4 pre-issued steps (12-VGPR Q4_K
+    // sets fit next to the activation registers once the norm weights share the second pass's registers) - the extra 12-25 MB per launch sit
+    // in every CU's load queue in front of the activation rows of the waves behind them: the prologue grows by what the extra steps cover
+    // (QKV 4.5 -> 5.6-6.0 us, wo 2.3 -> 3.7-3.8 us, also when they are issued only after the wave's own activation row has arrived),
+    // 116.0 vs 118.0 tok/s on the 70B shape, 588 vs 598 on the 8B shape.]
+    template <bool DBG, int NPRE>
+    static __device__ __forceinline__ void run_job(Regs & ga, Regs & gb, const GemvP & p, const GemvJob & jb, const XLds & xs,
+                                                   float * out /*job slice*/, int first, int n_job_items, int r0, int r1, int lane) {
+        static_assert(NPRE >= 0 && NPRE <= 2, "pre-issue depth");
         if (first >= n_job_items) return;
         const int upl = (jb.U + 63) >> 6;            // units per lane
         const int cpr = (upl + CH - 1) / CH;         // chunks (steps) per item
@@ -542,32 +548,34 @@ template <int TYPE, bool PAIR, int NC = 1> struct Item {
             }
             next(crow, cc);
         };
-        if (!PRE) issue(ga, p, jb, irow, r1, ic * CH, lane);
-        next(irow, ic);
-        int s_ = 0;
-#ifdef PM_PRE2
-        if (PRE && !PAIR) {                          // steps 0 AND 1 are already in flight (gb holds step 1, clamped if S == 1)
-            if (S == 1) { consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish(); return; }
+        auto eat = [&](Regs & g) __attribute__((always_inline)) { consume<DBG>(g, acc, p, jb, xs, crow, r1, cc * CH, lane); finish(); };
+        auto put = [&](Regs & g) __attribute__((always_inline)) { issue(g, p, jb, irow, r1, ic * CH, lane); next(irow, ic); };
+        {
+            if (NPRE == 0) issue(ga, p, jb, irow, r1, ic * CH, lane);
             next(irow, ic);
-            consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
-            if (S == 2) { consume<DBG>(gb, acc, p, jb, xs, crow, r1, cc * CH, lane); finish(); return; }
-            issue(ga, p, jb, irow, r1, ic * CH, lane); next(irow, ic);
-            consume<DBG>(gb, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
+        }
+        int s_ = 0;
+        if (NPRE >= 2) {                             // steps 0 AND 1 are already in flight (gb holds step 1, clamped if S == 1)
+            if (S == 1) { eat(ga); return; }
+            next(irow, ic);
+            eat(ga);
+            if (S == 2) { eat(gb); return; }
+            put(ga);
+            eat(gb);
             s_ = 2;
         }
-#endif
         for (; s_ + 2 < S; s_ += 2) {
-            issue(gb, p, jb, irow, r1, ic * CH, lane); next(irow, ic);
-            consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
-            issue(ga, p, jb, irow, r1, ic * CH, lane); next(irow, ic);
-            consume<DBG>(gb, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
+            put(gb);
+            eat(ga);
+            put(ga);
+            eat(gb);
         }
         if (s_ + 1 < S) {
             issue(gb, p, jb, irow, r1, ic * CH, lane);
-            consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
-            consume<DBG>(gb, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
+            eat(ga);
+            eat(gb);
         } else {
-            consume<DBG>(ga, acc, p, jb, xs, crow, r1, cc * CH, lane); finish();
+            eat(ga);
         }
     }
     // SPLIT jobs: an item is ONE step (row, chunk); every step's partial sum goes to out[item] and write_out adds the chunks of a row in
@@ -659,7 +667,7 @@ __device__ __forceinline__ void write_out_qkv(const GemvJob & jb, const QkvEpi &
 }
 
 // The whole mat-vec of one workgroup (body of gemv_q_kernel / gemv_q_cols_kernel).
-template <int TA, int TB, bool PAIR, bool DBG, int NC = 1, bool EPI = false>
+template <int TA, int TB, bool PAIR, bool DBG, int NC = 1, bool EPI = false, int NPRE = 2>
 __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double * nred) {
     constexpr bool MEGA = false;      // (outputs are plain stores: kernel boundaries do the cache maintenance)
     constexpr int ABLK = QT<TA>::ABLK;
@@ -707,16 +715,14 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
     unsigned long long tsv[6] = {PM_TS_NOW(), 0, 0, 0, 0, 0};
     ActRegs areg;
     stage_issue<ABLK, MEGA>(p, areg, wave, lane);                             // activation loads go out first (they return first)
-    typename IA::Regs g0, g1;                                           // job 0 is always of type TA (host side orders the jobs)
-#ifndef PM_NO_PREISSUE
-    IA::issue(g0, p, p.job[0], r0_0 + wave * R, r1_0, 0, lane);
-#ifdef PM_PRE2
-    if (!PAIR) {   // second step of this wave: next chunk of the same row(s), or the first chunk of its next item
+    typename IA::Regs g0, g1;                                   // job 0 is always of type TA (host side orders the jobs)
+    {   // the first NPRE steps of this wave in job 0 (same cursor sequence as run_job: chunks of a row, then the wave's next item)
         const int cpr0 = (((p.job[0].U + 63) >> 6) + IA::CH - 1) / IA::CH;
-        IA::issue(g1, p, p.job[0], cpr0 > 1 ? r0_0 + wave * R : r0_0 + (wave + PM_GEMV_NW) * R, r1_0, cpr0 > 1 ? IA::CH : 0, lane);
+        int prow = r0_0 + wave * R, pc = 0;
+        auto adv = [&]() __attribute__((always_inline)) { if (++pc == cpr0) { pc = 0; prow += PM_GEMV_NW * R; } };
+        IA::issue(g0, p, p.job[0], prow, r1_0, pc * IA::CH, lane); adv();
+        if (NPRE >= 2) { IA::issue(g1, p, p.job[0], prow, r1_0, pc * IA::CH, lane); adv(); }
     }
-#endif
-#endif
     stage_finish<ABLK, MEGA>(p, areg, xs_q, xs_gs, xs_d, nred, wave, lane, NC, col_bytes, &tsv[1]);
     __syncthreads();
     tsv[2] = PM_TS_NOW();
@@ -725,11 +731,7 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
     //     the small k / v slices do not all land on wave 0.
     const int w1 = (wave + PM_GEMV_NW - ni_0 % PM_GEMV_NW) % PM_GEMV_NW;            // first item id of this wave in job 1
     const int w2 = (wave + 2 * PM_GEMV_NW - (ni_0 + ni_1) % PM_GEMV_NW) % PM_GEMV_NW;
-#ifndef PM_NO_PREISSUE
-    IA::template run_job<DBG, true>(g0, g1, p, p.job[0], xs, outbuf, wave, ni_0, r0_0, r1_0, lane);
-#else
-    IA::template run_job<DBG, false>(g0, g1, p, p.job[0], xs, outbuf, wave, ni_0, r0_0, r1_0, lane);
-#endif
+    IA::template run_job<DBG, NPRE>(g0, g1, p, p.job[0], xs, outbuf, wave, ni_0, r0_0, r1_0, lane);
     typename IB::Regs gB, gB1;
     if (ni_1 > 0) {
         if constexpr (EPI && !PAIR && NC == 1 && R == 1) {
@@ -739,8 +741,8 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
             }
         }
         if (cpr_1 == 1) {
-            if (TA != TB && p.job[1].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[1], xs, outbuf + ob_1 * NC, w1, ni_1, r0_1, r1_1, lane);
-            else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[1], xs, outbuf + ob_1 * NC, w1, ni_1, r0_1, r1_1, lane);
+            if (TA != TB && p.job[1].is_b) IB::template run_job<DBG, 0>(gB, gB1, p, p.job[1], xs, outbuf + ob_1 * NC, w1, ni_1, r0_1, r1_1, lane);
+            else                           IA::template run_job<DBG, 0>(g0, g1, p, p.job[1], xs, outbuf + ob_1 * NC, w1, ni_1, r0_1, r1_1, lane);
         }
     }
     if (ni_2 > 0) {
@@ -751,8 +753,8 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
             }
         }
         if (cpr_2 == 1) {
-            if (TA != TB && p.job[2].is_b) IB::template run_job<DBG, false>(gB, gB1, p, p.job[2], xs, outbuf + ob_2 * NC, w2, ni_2, r0_2, r1_2, lane);
-            else                           IA::template run_job<DBG, false>(g0, g1, p, p.job[2], xs, outbuf + ob_2 * NC, w2, ni_2, r0_2, r1_2, lane);
+            if (TA != TB && p.job[2].is_b) IB::template run_job<DBG, 0>(gB, gB1, p, p.job[2], xs, outbuf + ob_2 * NC, w2, ni_2, r0_2, r1_2, lane);
+            else                           IA::template run_job<DBG, 0>(g0, g1, p, p.job[2], xs, outbuf + ob_2 * NC, w2, ni_2, r0_2, r1_2, lane);
         }
     }
     tsv[3] = PM_TS_NOW();                              // (wave 0 has finished its rows)

@@ -112,6 +112,23 @@ def main():
     if len(rows) >= 5 * n_l:
         tk = us(rows[-1]["t5"].max() - rows[0]["t0"].min())
         print(f"token (first launch entry -> last launch exit): {tk:.1f} us")
+    # who finishes late? finish time of the row phase (t4) relative to the launch's first t2, per workgroup, averaged over the layers:
+    # by XCD (workgroup id % 8: consecutive workgroups go to consecutive XCDs) and the slowest / fastest workgroups
+    for name in ("gate/up", "down", "QKV", "wo"):
+        sel = [r for r in rows if r.get("name") == name and r["n"] == WGS]
+        if not sel:
+            continue
+        rel = np.mean([(r["t4"] - r["t2"].min()) / 100.0 for r in sel], axis=0)          # [256] us
+        ent = np.mean([(r["t0"] - r["t0"].min()) / 100.0 for r in sel], axis=0)
+        by_xcd = [rel[x::8].mean() for x in range(8)]
+        by_xcd_ent = [ent[x::8].mean() for x in range(8)]
+        order = np.argsort(rel)
+        print(f"{name:8s} row-phase finish by XCD (us): " + " ".join(f"{v:6.2f}" for v in by_xcd) + f" | entry by XCD: " + " ".join(f"{v:5.2f}" for v in by_xcd_ent))
+        print(f"{'':8s} mean {rel.mean():.2f} min {rel.min():.2f} max {rel.max():.2f}; slowest workgroups {order[-8:].tolist()} fastest {order[:8].tolist()}")
+        # is it the same workgroups every layer? correlation of per-workgroup finish between two halves of the layers
+        h = len(sel) // 2
+        a_ = np.mean([(r["t4"] - r["t2"].min()) / 100.0 for r in sel[:h]], axis=0); b_ = np.mean([(r["t4"] - r["t2"].min()) / 100.0 for r in sel[h:]], axis=0)
+        print(f"{'':8s} correlation of per-workgroup finish times, first vs second half of the layers: {np.corrcoef(a_, b_)[0, 1]:.2f}")
     # split the two kinds of `down` (Q6_K on more-bits layers)
     if "down" in per:
         sp = np.array([x["span"] for x in per["down"]])
