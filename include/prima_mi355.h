@@ -271,6 +271,8 @@ typedef struct {
 PM355_API int pm355_rope_table(const pm355_rope_params * rp, const int32_t * d_pos, const float * freq_factors, float * table, pm355_stream_t stream);
 PM355_API int pm355_mul_mat_vec_qkv(const pm355_matvec_job * jobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
                                     const pm355_qkv_store * s, pm355_stream_t stream);
+/* 0 when pm355_mul_mat_vec_qkv can serve this wq | wk | wv list (types, K, every workgroup's row slices hold whole rotation pairs) */
+PM355_API int pm355_mul_mat_vec_qkv_check(const pm355_matvec_job * jobs, int64_t K, int n_head_kv, int head_dim, int n_rot);
 PM355_API int pm355_attn_cached(const float * q_rot, void * k_cache, void * v_cache, const int32_t * d_pos, const int32_t * d_cell_nkv,
                                 const void * mask, float * out, int n_head, int n_head_kv, int head_dim, int n_ctx, float kq_scale,
                                 int max_keys, int flags, pm355_stream_t stream);

@@ -304,6 +304,16 @@ int pm355_mul_mat_vec_qkv(const pm355_matvec_job * jobs, int64_t K, const float 
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_mul_mat_vec_qkv_check(const pm355_matvec_job * jobs, int64_t K, int n_head_kv, int head_dim, int n_rot) {
+    if (!jobs) return fail(PM355_E_SHAPE, "mul_mat_vec_qkv_check: jobs");
+    pm_gemv_fused f = {};
+    f.K = (int) K; f.njobs = 3; f.xf = (const float *) 16;
+    for (int j = 0; j < 3; ++j) { f.job[j].type = jobs[j].type; f.job[j].N = (int) jobs[j].N; f.job[j].W = jobs[j].W; f.job[j].bias = jobs[j].bias; }
+    const pm_qkv_epi e = {(const float *) 16, (const int32_t *) 16, nullptr, nullptr, 0, (void *) 16, (void *) 16, n_head_kv, head_dim, 8, n_rot, 0};
+    f.epi = &e;
+    const int rc = pm_gemv_fused_check(f);
+    return rc == -5 ? PM355_E_UNSUPPORTED : gemv_rc(rc);
+}
 int pm355_attn_cached(const float * q_rot, void * kc, void * vc, const int32_t * d_pos, const int32_t * d_cell_nkv, const void * mask,
                       float * out, int H, int Hkv, int dh, int n_ctx, float kq_scale, int max_keys, int flags, pm355_stream_t st) {
     if (!q_rot || !kc || !vc || !out || (!d_pos && !d_cell_nkv)) return fail(PM355_E_SHAPE, "attn_cached: null pointer");

@@ -115,6 +115,8 @@ struct backend_ctx {
     int32_t * d_i32 = nullptr;                       // small device scratch (positions)
     // graph lowering (ggml_graph_plan.h)
     int32_t * d_dyn = nullptr;                       // device int32[2]: {KV cell of the token, cells attended}
+    float * rope_tab = nullptr;                      // device float[256]: this token's cos / sin per rotation pair (round-3 attention block)
+    bool qkv_epi = true;                             // GGML_MI355_QKV_EPI=0: rope + KV store inside the attention kernel (the round-2 form)
     float * qkv = nullptr; size_t qkv_floats = 0;    // raw q / k / v projections of one token
     float * split = nullptr; size_t split_floats = 0;
     std::vector<graph_entry *> graphs;
@@ -316,7 +318,7 @@ void backend_free(ggml_backend_t b) {
                 g_ht.ns_set / 1e6, (unsigned long long) g_ht.n_set.load(), g_ht.ns_get / 1e6, (unsigned long long) g_ht.n_get.load(),
                 g_ht.ns_sync / 1e6, (unsigned long long) g_ht.n_sync.load());
     for (graph_entry * e : c->graphs) { if (e->exec) pm355_graph_free(e->exec); delete e; }
-    dfree(c->scratch); dfree(c->d_i32); dfree(c->d_dyn); dfree(c->qkv); dfree(c->split);
+    dfree(c->scratch); dfree(c->d_i32); dfree(c->d_dyn); dfree(c->rope_tab); dfree(c->qkv); dfree(c->split);
     if (c->null_ev) pm355_event_destroy(c->null_ev);
     if (!plan_only()) pm355_stream_destroy(c->stream);
     delete c; delete b;
@@ -549,6 +551,20 @@ float * plan_split_scratch(void * user, size_t n) {
     return c->split;
 }
 
+// two small device arrays with the same bytes? (plan time only: the per-layer copies of rope_freqs.weight)
+bool plan_same_bytes(void * user, const void * a, const void * b, size_t n) {
+    backend_ctx * c = (backend_ctx *) user;
+    if (n > 4096) return false;
+    char ha[4096], hb[4096];
+    if (plan_only()) { memcpy(ha, a, n); memcpy(hb, b, n); }
+    else {
+        dsync(c->stream); dsync(nullptr);
+        if (pm355_memcpy_d2h(ha, a, n, nullptr) || pm355_memcpy_d2h(hb, b, n, nullptr)) return false;
+        dsync(nullptr);
+    }
+    return memcmp(ha, hb, n) == 0;
+}
+
 // the launch sequence of a plan on the backend's stream (also what gets captured into a hipGraph)
 bool run_plan(backend_ctx * c, struct ggml_cgraph * g, const mi355::plan & p) {
     for (const mi355::step & s : p.steps) {
@@ -558,6 +574,16 @@ bool run_plan(backend_ctx * c, struct ggml_cgraph * g, const mi355::plan & p) {
                 break;
             case mi355::STEP_ATTN:
                 MI355_CHECK(pm355_attn_token(&s.attn, &s.rope, c->stream));
+                break;
+            case mi355::STEP_ROPE_TAB:
+                MI355_CHECK(pm355_rope_table(&s.rope, s.attn.d_pos, s.attn.freq_factors, (float *) s.qs.rope_table, c->stream));
+                break;
+            case mi355::STEP_QKV:
+                MI355_CHECK(pm355_mul_mat_vec_qkv(s.job, s.K, s.x, s.norm_w, s.eps, &s.qs, c->stream));
+                break;
+            case mi355::STEP_ATTN_CACHED:
+                MI355_CHECK(pm355_attn_cached(s.attn.q, s.attn.k_cache, s.attn.v_cache, nullptr, s.attn.d_cell_nkv, s.attn.mask, s.attn.out, s.attn.n_head,
+                                              s.attn.n_head_kv, s.attn.head_dim, s.attn.n_ctx, s.attn.kq_scale, s.attn.max_keys, s.attn.flags, c->stream));
                 break;
             case mi355::STEP_ATTN_BATCH:
                 MI355_CHECK(pm355_attn_prefill_masked_ex(s.ab.q, s.ab.kc, s.ab.vc, s.ab.mask, s.ab.mask_stride, s.ab.out, s.ab.n_tokens, s.ab.n_head,
@@ -582,17 +608,19 @@ void print_plan(const backend_ctx * c, struct ggml_cgraph * g, const mi355::plan
             (int) p.single_token, cell, n_kv, (int) (p.single_token && p.fast_ok));
     if (!env_on("GGML_MI355_DEBUG_PLAN_STEPS")) return;
     for (const mi355::step & s : p.steps) {
-        if (s.kind == mi355::STEP_GEMV) {
-            fprintf(stderr, "  [%d,%d) matvec K=%lld norm=%d jobs=%d:", s.node_lo, s.node_hi, (long long) s.K, s.norm_w != nullptr, s.njobs);
+        if (s.kind == mi355::STEP_ROPE_TAB) {
+            fprintf(stderr, "  [%d] rope table n_dims=%d mode=%d ff=%d\n", s.node_lo, s.rope.n_dims, s.rope.mode, s.attn.freq_factors != nullptr);
+        } else if (s.kind == mi355::STEP_GEMV || s.kind == mi355::STEP_QKV) {
+            fprintf(stderr, "  [%d,%d) matvec%s K=%lld norm=%d jobs=%d:", s.node_lo, s.node_hi, s.kind == mi355::STEP_QKV ? " + rope + KV store" : "", (long long) s.K, s.norm_w != nullptr, s.njobs);
             for (int j = 0; j < s.njobs; ++j) fprintf(stderr, " {%s N=%lld%s%s%s}", ggml_type_name((enum ggml_type) s.job[j].type), (long long) s.job[j].N,
                                                      s.job[j].W2 ? " pair" : "", s.job[j].bias ? " +bias" : "", s.job[j].resid ? " +resid" : "");
             fprintf(stderr, "\n");
         } else if (s.kind == mi355::STEP_ATTN_BATCH) {
             fprintf(stderr, "  [%d,%d) batch attention T=%d H=%d Hkv=%d dh=%d n_kv=%d (MFMA, masked)\n", s.node_lo, s.node_hi, s.ab.n_tokens, s.ab.n_head,
                     s.ab.n_head_kv, s.ab.head_dim, s.ab.n_kv);
-        } else if (s.kind == mi355::STEP_ATTN) {
+        } else if (s.kind == mi355::STEP_ATTN || s.kind == mi355::STEP_ATTN_CACHED) {
             fprintf(stderr, "  [%d,%d) attention H=%d Hkv=%d dh=%d n_ctx=%d %s mask=%d ff=%d\n", s.node_lo, s.node_hi, s.attn.n_head, s.attn.n_head_kv, s.attn.head_dim,
-                    s.attn.n_ctx, s.attn.split ? "split" : "fused", s.attn.mask != nullptr, s.attn.freq_factors != nullptr);
+                    s.attn.n_ctx, s.kind == mi355::STEP_ATTN_CACHED ? "cached" : (s.attn.split ? "split" : "fused"), s.attn.mask != nullptr, s.attn.freq_factors != nullptr);
         } else {
             fprintf(stderr, "  [%d] %s '%s'\n", s.node, ggml_op_name(ggml_graph_node(g, s.node)->op), ggml_graph_node(g, s.node)->name);
         }
@@ -615,12 +643,13 @@ enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g)
     ++c->n_compute; ++c->tick;
     if (n_nodes == 0) return GGML_STATUS_SUCCESS;
     if (!c->d_dyn) { c->d_dyn = (int32_t *) dmalloc(64); GGML_ASSERT(c->d_dyn); }
+    if (!c->rope_tab && c->qkv_epi) { c->rope_tab = (float *) dmalloc(1024 + 64); GGML_ASSERT(c->rope_tab); }
 
     mi355::graph_fingerprint(g, c->fp_tmp);
     graph_entry * e = nullptr;
     for (graph_entry * x : c->graphs) if (x->plan.fast_ok && mi355::fingerprint_equal(x->fp, c->fp_tmp)) { e = x; ++c->n_fp_hit; break; }
     if (!e) {
-        mi355::plan_ctx pc = { c, plan_qkv_scratch, plan_split_scratch, c->d_dyn, c->split_min, c->fuse };
+        mi355::plan_ctx pc = { c, plan_qkv_scratch, plan_split_scratch, c->d_dyn, c->split_min, c->fuse, c->qkv_epi ? c->rope_tab : nullptr, plan_same_bytes };
         mi355::plan p;
         mi355::planner(g, pc).build(p);
         ++c->n_plan;
@@ -806,6 +835,7 @@ ggml_backend_t ggml_backend_mi355_init(int device) {
     backend_ctx * c = new backend_ctx{device, std::string(GGML_MI355_NAME "X") + std::to_string(device), plan_only() ? (pm355_stream_t) 1 : pm355_stream_create()};
     if (!c->stream) { delete c; return nullptr; }
     c->fuse = !env_on("GGML_MI355_NO_FUSE");                          // node-by-node kernels only (debug / A-B)
+    if (const char * qe = getenv("GGML_MI355_QKV_EPI")) if (qe[0] == '0') c->qkv_epi = false;   // rope + KV store inside the attention kernel (round-2 form)
     c->use_graphs = !env_on("GGML_MI355_NO_GRAPH") && !plan_only();   // no hipGraph capture / replay
     c->debug_plan = env_on("GGML_MI355_DEBUG_PLAN") || plan_only();
     if (const char * sm = getenv("GGML_MI355_ATTN_SPLIT_MIN")) if (sm[0]) c->split_min = atoi(sm);

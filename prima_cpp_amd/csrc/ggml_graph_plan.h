@@ -33,7 +33,9 @@
 
 namespace mi355 {
 
-enum step_kind : int32_t { STEP_NODE = 0, STEP_GEMV = 1, STEP_ATTN = 2, STEP_ATTN_BATCH = 3 };
+// STEP_ROPE_TAB / STEP_QKV / STEP_ATTN_CACHED: the round-3 form of launches 1 and 2 - one cos / sin table launch per graph, RoPE + KV store in the
+// epilogue of the wq | wk | wv launch, attention over cached cells (pm355_rope_table / pm355_mul_mat_vec_qkv / pm355_attn_cached)
+enum step_kind : int32_t { STEP_NODE = 0, STEP_GEMV = 1, STEP_ATTN = 2, STEP_ATTN_BATCH = 3, STEP_ROPE_TAB = 4, STEP_QKV = 5, STEP_ATTN_CACHED = 6 };
 
 struct tensor_fp {                                   // everything a node-equivalent kernel reads from a tensor
     const void * data; int32_t type; int32_t pad_; int64_t ne[4]; size_t nb[4];
@@ -47,8 +49,10 @@ struct step {
     int32_t node_lo, node_hi;                        // graph nodes [lo, hi) this step stands for
     // STEP_GEMV
     int64_t K; int32_t njobs; float eps; const float * x; const float * norm_w; pm355_matvec_job job[3];
-    // STEP_ATTN
+    // STEP_ATTN (STEP_ATTN_CACHED: the same arguments, q = rotated rows; STEP_ROPE_TAB: rope, attn.d_pos, attn.freq_factors, qs.rope_table)
     pm355_attn_token_args attn; pm355_rope_params rope;
+    // STEP_QKV (with the STEP_GEMV fields)
+    pm355_qkv_store qs;
     // STEP_ATTN_BATCH (multi-token): pm355_attn_prefill_masked
     struct { const float * q; const void * kc, * vc; const void * mask; int64_t mask_stride; float * out;
              int32_t n_tokens, n_head, n_head_kv, head_dim, n_ctx, n_kv; float scale; int32_t flags; } ab;
@@ -75,6 +79,10 @@ struct plan_ctx {                                    // what the backend provide
     int32_t * d_dyn;                                 // device int32[2] {cell, cells attended}
     int split_min;                                   // cells attended from which the split attention is used
     bool fuse;
+    // round-3 form of the attention block: device table of 256 floats (null: off) and a comparison of two small device arrays
+    // (the per-layer copies of rope_freqs hold the same numbers: one table serves every layer)
+    float * rope_tab = nullptr;
+    bool (*same_bytes)(void * user, const void * a, const void * b, size_t n) = nullptr;
 };
 
 // ---- small pointer -> count map (open addressing; graphs have a few thousand nodes) ---------------------------------------
@@ -435,11 +443,37 @@ private:
         pm355_matvec_job jobs[3] = { job_of(mq, sq, bq, nullptr), job_of(mk, sk, bk, nullptr), job_of(mv, sv, bv, nullptr) };
         const bool one_launch = pm355_mul_mat_vec_fused_check(jobs, 3, E) == 0;
         if (!one_launch) for (int j = 0; j < 3; ++j) if (pm355_mul_mat_vec_fused_check(jobs + j, 1, E)) return 0;
-        if (one_launch) push_gemv(p, i0, hi, jobs, 3, E, (const float *) x->data, nw, eps);
+        // round-3 form: NORM-mode rope, F16 caches, one-workgroup-per-head regime, every workgroup's row slices hold whole rotation pairs, and
+        // the same cos / sin table as the layers planned before (same parameters, positions and frequency factors)
+        pm355_rope_params rp_; rope_params_of(rq, rp_);
+        const float * ff_ = rq->src[2] ? (const float *) rq->src[2]->data : nullptr;
+        bool epi = c_.rope_tab && one_launch && !q8 && !split && !(rp_.mode & 2) && rp_.n_dims <= 256 &&
+                   pm355_mul_mat_vec_qkv_check(jobs, E, (int) Hkv, (int) dh, rp_.n_dims) == 0;
+        if (epi && tab_set_) {
+            const bool same_ff = ff_ == tab_ff_ || (ff_ && tab_ff_ && c_.same_bytes && c_.same_bytes(c_.user, ff_, tab_ff_, (size_t) rp_.n_dims / 2 * 4));
+            if (memcmp(&rp_, &tab_rp_, sizeof(rp_)) || rq->src[1]->data != tab_pos_ || !same_ff) epi = false;
+        }
+        if (epi && !tab_set_) {
+            step t; memset(&t, 0, sizeof(t));
+            t.kind = STEP_ROPE_TAB; t.node = -1; t.node_lo = i0; t.node_hi = i0;
+            t.rope = rp_; t.attn.d_pos = (const int32_t *) rq->src[1]->data; t.attn.freq_factors = ff_; t.qs.rope_table = c_.rope_tab;
+            p.steps.push_back(t);
+            tab_set_ = true; tab_rp_ = rp_; tab_pos_ = rq->src[1]->data; tab_ff_ = ff_;
+        }
+        if (epi) {
+            step g; memset(&g, 0, sizeof(g));
+            g.kind = STEP_QKV; g.node = -1; g.node_lo = i0; g.node_hi = hi;
+            g.K = E; g.njobs = 3; g.eps = eps; g.x = (const float *) x->data; g.norm_w = nw;
+            for (int j = 0; j < 3; ++j) g.job[j] = jobs[j];
+            g.qs.rope_table = c_.rope_tab; g.qs.d_pos = nullptr; g.qs.d_cell_nkv = c_.d_dyn; g.qs.k_cache = kcache->data; g.qs.v_cache = vcache->data;
+            g.qs.n_head_kv = (int32_t) Hkv; g.qs.head_dim = (int32_t) dh; g.qs.n_ctx = (int32_t) n_ctx; g.qs.n_rot = rp_.n_dims; g.qs.v_rowmajor = fa ? 1 : 0;
+            p.steps.push_back(g);
+            ++p.n_gemv;
+        } else if (one_launch) push_gemv(p, i0, hi, jobs, 3, E, (const float *) x->data, nw, eps);
         else for (int j = 0; j < 3; ++j) push_gemv(p, i0, hi, jobs + j, 1, E, (const float *) x->data, nw, eps);
-        // launch 2: rope + KV store + attention
+        // launch 2: rope + KV store + attention (round-3 form: attention over cached cells)
         step s; memset(&s, 0, sizeof(s));
-        s.kind = STEP_ATTN; s.node = -1; s.node_lo = i0; s.node_hi = hi;
+        s.kind = epi ? STEP_ATTN_CACHED : STEP_ATTN; s.node = -1; s.node_lo = i0; s.node_hi = hi;
         s.attn.q = sq; s.attn.k = sk; s.attn.v = sv; s.attn.k_cache = kcache->data; s.attn.v_cache = vcache->data;
         s.attn.d_pos = (const int32_t *) rq->src[1]->data; s.attn.d_cell_nkv = c_.d_dyn;
         s.attn.mask = mask ? mask->data : nullptr;
@@ -461,6 +495,7 @@ private:
         return hi - i0;
     }
     int64_t cell_ = -1, n_kv_ = -1;
+    bool tab_set_ = false; pm355_rope_params tab_rp_; const void * tab_pos_ = nullptr; const float * tab_ff_ = nullptr;
 
     // ---- launch 4 (ffn gate/up pair) and the head: RMS_NORM MUL then mat-vecs that all read the normalised row ----------------
     int try_norm_matvec(plan & p, int i0) {

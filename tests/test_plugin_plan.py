@@ -97,3 +97,32 @@ def test_flash_attn_prompt_batches_use_the_mfma_attention(tmp_path):
     n_layer = int(z["hp_n_layer"])
     assert f"{n_layer} multi-token attention chain(s) -> MFMA masked attention" in st["stderr"]
     assert "batch attention T=3" in st["stderr"]
+
+
+@pytest.mark.parametrize("fa", [False, True])
+def test_round3_attention_block_rope_in_the_qkv_epilogue(fa, tmp_path):
+    """Where every workgroup's wq | wk | wv row slices hold whole rotation pairs (N % 512 == 0) and the rope is NORM-mode, the attention
+    block lowers to: ONE cos / sin table launch per graph (the per-layer rope_freqs copies hold the same numbers), the mat-vec launch
+    with RoPE + KV store in its epilogue, and the attention over cached cells - still five launches per layer, plus the table."""
+    from _bind import Ref, best_ref_flavour
+    import _fixtures8d as F
+    ref = Ref(best_ref_flavour())
+    path = str(tmp_path / "m.gguf")
+    F.write_model(path, ref, n_layer=3, n_embd=1024, n_head=8, n_head_kv=4, n_ff=1024, n_vocab=512, tag="plan")
+    _, _, st = run_llama_driver(path, [1, 5, 9], 4, ngl=99, n_ctx=64, threads=1, extra_args=["--keep-out-in-cuda"] + (["-fa"] if fa else []),
+                                env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1"}, flavour="avx2", timeout=120)
+    plans = [tuple(int(x) for x in m.groups()) for m in PLAN.finditer(st["stderr"])]
+    decode = [p for p in plans if p[0] > 3 and p[6] == 1]
+    assert len(decode) >= 3, st["stderr"][-3000:]
+    for p in decode:
+        nodes, launches, gemv, attn, node_eq, fused, single, cell, n_kv, graphable = p
+        assert attn == 3 and gemv == 12 and graphable == 1, p
+        assert launches == 5 * 3 + 1 + node_eq, p                  # + the rope table
+    segs = [g for g in st["stderr"].split("ggml-mi355 plan:") if "single_token=1" in g and "rope table" in g]
+    assert segs, st["stderr"][-3000:]
+    body = segs[-1]
+    assert body.count("rope table") == 1 and body.count("matvec + rope + KV store") == 3 and body.count("cached mask=") == 3, body[:3000]
+    # and the switch back to the round-2 form
+    _, _, st0 = run_llama_driver(path, [1, 5, 9], 2, ngl=99, n_ctx=64, threads=1, extra_args=["--keep-out-in-cuda"] + (["-fa"] if fa else []),
+                                 env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1", "GGML_MI355_QKV_EPI": "0"}, flavour="avx2", timeout=120)
+    assert "rope table" not in st0["stderr"] and "fused mask=" in st0["stderr"]
