@@ -140,6 +140,8 @@ int pm_launch_attn_cached(const float * q, void * kc, void * vc, const int32_t *
     const size_t lds = (size_t) (4 * dh + (v_rowmajor ? 2048 : 256) + (max_keys > 0 ? ((max_keys + 7) & ~7) : n_ctx) + 8) * 4;
     if (lds > 150 * 1024) return -1;
     RopeP r = {};
+    if (!pos0) pos0 = dyn;                       // ggml-graph mode: cells come from dyn; keep every pointer the kernel may touch valid
+    if (!pos0) return -1;
     auto launch = [&](auto kern) {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         AttnP a = {q, nullptr, nullptr, (uint16_t *) kc, (uint16_t *) vc, pos0, seq, seq_stride, nullptr, out, H, Hkv, n_ctx, scale, r, dyn,

@@ -147,7 +147,8 @@ int pmv::gemv_fill(const pm_gemv_fused & a, int grid_fixed, GemvP & p, int & ta_
     if (a.epi) {
         const pm_qkv_epi & e = *a.epi;
         if (grid_fixed > 0 || e.dh % 2 || e.n_rot % 2 || e.n_rot > e.dh || a.job[0].N % e.dh || a.job[1].N != e.Hkv * e.dh || a.job[2].N != e.Hkv * e.dh) return -5;
-        p.epi = QkvEpi{e.tab, e.pos, e.seq, e.dyn, e.seq_stride, (uint16_t *) e.kc, (uint16_t *) e.vc, e.Hkv * e.dh, e.dh, e.n_ctx, e.n_rot, e.v_rowmajor};
+        // (ggml-graph mode has no position pointer: the scalar loads of the un-taken branch may still be issued - give them a valid address)
+        p.epi = QkvEpi{e.tab, e.pos ? e.pos : e.dyn, e.seq, e.dyn, e.seq_stride, (uint16_t *) e.kc, (uint16_t *) e.vc, e.Hkv * e.dh, e.dh, e.n_ctx, e.n_rot, e.v_rowmajor};
     }
     if (p.job[0].is_b)                                // the kernel pre-issues job 0 with the TA code path: put a TA job first
         for (int j = 1; j < 3; ++j) if (p.job[j].N > 0 && !p.job[j].is_b) { const GemvJob t = p.job[0]; p.job[0] = p.job[j]; p.job[j] = t; break; }

@@ -513,6 +513,8 @@ def test_qkv_epilogue_and_cached_attention_equal_the_fused_attention_path(P, ora
     ff = _dev(P, (1 + rng.uniform(0, 7, dh // 2)).astype(np.float32))
     kcA = torch.zeros(n_ctx * Nkv, dtype=torch.int16, device="cuda"); vcA = torch.zeros_like(kcA)
     kcB = torch.zeros_like(kcA); vcB = torch.zeros_like(kcA)
+    kcC = torch.zeros_like(kcA); vcC = torch.zeros_like(kcA)          # ggml-graph mode of the same launches (cell / cells attended + mask)
+    mask0 = torch.zeros(n_ctx, dtype=torch.float32, device="cuda")
     scale = 1.0 / np.sqrt(dh)
     worst = 0.0
     for pos in list(range(0, 6)) + [31, 32, 62, 63, 64, 65, 90]:
@@ -524,7 +526,11 @@ def test_qkv_epilogue_and_cached_attention_equal_the_fused_attention_path(P, ora
         tab = P.rope_table(pd, dh, freq_factors=ff, freq_base=500000.0)
         qB = P.mul_mat_vec_qkv(ws, xd, tab, pd, kcB, vcB, Hkv, dh, n_ctx, norm_w=nw, eps=1e-5, biases=bias)
         outB = P.attn_cached(qB, kcB, vcB, pd, H, Hkv, dh, n_ctx, scale)
+        dyn = torch.tensor([pos, pos + 1], dtype=torch.int32, device="cuda")
+        qC = P.mul_mat_vec_qkv(ws, xd, tab, None, kcC, vcC, Hkv, dh, n_ctx, norm_w=nw, eps=1e-5, biases=bias, cell_nkv=dyn)
+        outC = P.attn_cached(qC, kcC, vcC, None, H, Hkv, dh, n_ctx, scale, cell_nkv=dyn, mask=mask0, max_keys=n_ctx)
         torch.cuda.synchronize()
+        assert torch.equal(qC, qB) and torch.equal(outC, outB) and torch.equal(kcC, kcB) and torch.equal(vcC, vcB), pos
         # the K row / V column of this cell: the same F16 values up to the summation order of the split wk / wv rows (<= 1 F16 ulp, rarely)
         a = kcA.cpu().numpy().view(np.float16).astype(np.float32).reshape(n_ctx, Nkv)[pos]
         b = kcB.cpu().numpy().view(np.float16).astype(np.float32).reshape(n_ctx, Nkv)[pos]
@@ -538,7 +544,7 @@ def test_qkv_epilogue_and_cached_attention_equal_the_fused_attention_path(P, ora
         qb = qB.cpu().numpy()
         assert np.abs(qb - q_ref).max() <= 2e-3 * max(1.0, np.abs(q_ref).max()) and (qb != q_ref).mean() < 0.02
         # from here on both caches must hold the SAME bytes, or later cells would compare different histories
-        kcB.copy_(kcA); vcB.copy_(vcA)
+        kcB.copy_(kcA); vcB.copy_(vcA); kcC.copy_(kcA); vcC.copy_(vcA)
         wa, wb = outA.cpu().numpy(), outB.cpu().numpy()
         worst = max(worst, float(np.abs(wa - wb).max() / max(1.0, np.abs(wa).max())))
         assert np.abs(wa - wb).max() <= 3e-3 * max(1.0, np.abs(wa).max()), (pos, np.abs(wa - wb).max())
@@ -551,7 +557,7 @@ def test_qkv_epilogue_and_cached_attention_equal_the_fused_attention_path(P, ora
                 if fill_k.size:
                     kcA.view(n_ctx, Nkv)[pos + 1:nxt] = torch.from_numpy(fill_k).cuda()
                     vcA.view(Nkv, n_ctx)[:, pos + 1:nxt] = torch.from_numpy(fill_v).cuda()
-                    kcB.copy_(kcA); vcB.copy_(vcA)
+                    kcB.copy_(kcA); vcB.copy_(vcA); kcC.copy_(kcA); vcC.copy_(vcA)
     print(f"\n[qkv epilogue + cached attention, dh {dh}, attn_v type {tv}] max |d out| / max |out| = {worst:.2e}")
     # and the epilogue's mat-vecs against the oracle (q before rope is not observable: check k / v through the cache at one more cell)
     x = rng.normal(0, 1, (1, K)).astype(np.float32)
