@@ -490,29 +490,41 @@ def main():
     with torch.cuda.stream(stream):
         win = E.Window(hp, lo=lo, hi=hi, flags=flags, n_ctx=a.n_ctx)
         win.fill_synthetic(mixture, seed=1234)
-        win.finalize(max_tokens=1, n_seq=world)
+        RING_UBATCH = 512                                  # tokens per hop of the pipelined prompt pass (the reference's n_ubatch)
+        win.finalize(max_tokens=RING_UBATCH if world > 1 else 1, n_seq=world)
         use_graph = not a.no_graph
         comp = EngineCompute(win, world, use_graph=use_graph)
         # N > 1 over RCCL: the transport is the C one (pm355_ring_*: ncclSend / ncclRecv on the library's communication stream, event
         # hand-off, no host wait per micro-step); PM355_RING_TRANSPORT=torch keeps torch.distributed's batch_isend_irecv instead
+        # The ring itself is C (pm355_ring_*: multi-token hand-off, pipelined prompt pass, single-sequence loop); its exchanges travel over
+        # RCCL (ncclSend / ncclRecv on the library's communication stream, event hand-off, no host wait per micro-step) or - PM355_DIST_BACKEND=gloo,
+        # several ranks on one GPU, or PM355_RING_TRANSPORT=torch - over torch.distributed through the C API's transport callbacks
         c_ring = None
-        if world > 1 and os.environ.get("PM355_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("PM355_RING_TRANSPORT", "c") == "c":
+        ring_transport = None
+        if world > 1:
             from prima_cpp_amd.ring import CRing
-            ok = torch.ones(1, device="cuda")
-            try:
-                c_ring = CRing(rank, world)
-            except Exception as e:                       # every rank must take the same path: agree on it below
-                print(f"[rank {rank}] C ring transport unavailable ({e}); falling back to torch.distributed", file=sys.stderr, flush=True)
-                ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if ok.item() < 1:
-                if c_ring is not None:
-                    c_ring.close()
-                c_ring = None
+            want = "rccl" if (os.environ.get("PM355_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("PM355_RING_TRANSPORT", "c") == "c") else "torch"
+            ok = torch.ones(1, device="cuda" if dist.get_backend() != "gloo" else "cpu")
+            if want == "rccl":
+                try:
+                    c_ring = CRing(rank, world, transport="rccl")
+                except Exception as e:                       # every rank must take the same path: agree on it below
+                    print(f"[rank {rank}] RCCL transport unavailable ({e}); falling back to torch.distributed", file=sys.stderr, flush=True)
+                    ok.zero_()
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if ok.item() < 1:
+                    if c_ring is not None:
+                        c_ring.close()
+                    c_ring = None
+            ring_transport = "rccl" if c_ring is not None else "torch"
+            if c_ring is None:
+                c_ring = CRing(rank, world, transport="torch")
         drv = RingDriver(comp, rank, world, c_ring=c_ring)
         rng = np.random.default_rng(1234)
         prompt = rng.integers(0, hp["n_vocab"], size=(world, a.prompt))
         prompt[:, 0] = 128000 % hp["n_vocab"]            # BOS first, like llama-bench
+
+        first_tok = None                                   # world > 1: the token each sequence starts its decode with (after the prompt pass)
 
         def one_step(step_idx):
             """every in-flight sequence advances one token: `world` micro-steps on every rank"""
@@ -520,8 +532,10 @@ def main():
                 forced = None
                 if rank == 0:
                     seq = (drv.m) % world
-                    if step_idx < a.prompt:
+                    if world == 1 and step_idx < a.prompt:
                         forced = int(prompt[seq, step_idx])
+                    elif world > 1 and drv.m < world:
+                        forced = first_tok[seq]
                 drv.micro_step(forced_token=forced)
 
         def sync():
@@ -530,11 +544,31 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
-        # prompt (token by token through the same path) + warmup, untimed
+        # prompt + warmup, untimed. One GPU: token by token through the decode path. Ring: the prompts go through the ranks as
+        # [n_tokens][n_embd] hand-offs, pipelined (pm355_ring_prefill), the last rank returns each prompt's last row to rank 0 for the head
         n_pre = a.prompt + a.warmup
-        assert n_pre + a.steps + 2 <= a.n_ctx, "n_ctx too small for prompt+warmup+steps"
-        for s in range(n_pre):
-            one_step(s)
+        assert n_pre + 2 * a.steps + 2 <= a.n_ctx, "n_ctx too small for prompt+warmup+steps"
+        ring_prompt = None
+        if world > 1:
+            toks_d = torch.from_numpy(prompt.astype(np.int32)).cuda() if rank == 0 else None
+            rows = torch.zeros((world, hp["n_embd"]), dtype=torch.float32, device="cuda") if rank == 0 else None
+            sync()
+            tp0 = time.perf_counter()
+            c_ring.prefill(win, toks_d, world, a.prompt, min(RING_UBATCH, a.prompt), rows)
+            sync()
+            ring_prompt = time.perf_counter() - tp0
+            if rank == 0:
+                am = torch.empty(1, dtype=torch.int32, device="cuda")
+                first_tok = []
+                for q in range(world):
+                    win.head(rows[q], argmax=am)
+                    first_tok.append(int(am.item()))
+            win.set_seq(0)                                  # the staggered decode meets the sequences in the order 0, 1, ...
+            for s in range(a.warmup):
+                one_step(a.prompt + s)
+        else:
+            for s in range(n_pre):
+                one_step(s)
         sync()
         t0 = time.perf_counter()
         for s in range(a.steps):
@@ -543,11 +577,44 @@ def main():
         t1 = time.perf_counter()
         dt = t1 - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() != "gloo" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         drv.flush()
         sync()
+
+        # The reference's own mode next to the aggregate: ONE sequence in flight, every token once round the ring with the other ranks idle
+        # (rank 0 blocked in recv until it returns, src/llama.cpp:18509) - what exposes the hop latency. And the pipelined prompt pass.
+        single = ring_pf = None
+        if world > 1:
+            tok1 = torch.tensor([1], dtype=torch.int32, device="cuda") if rank == 0 else None
+            for _ in range(3):
+                c_ring.single_token(win, 0, tok1)
+            c_ring.wait(); sync()
+            ts0 = time.perf_counter()
+            for _ in range(a.steps):
+                c_ring.single_token(win, 0, tok1)
+            c_ring.wait(); sync()
+            dts = time.perf_counter() - ts0
+            n_pf = min(2048, a.n_ctx // 2)
+            pf_tok = torch.from_numpy(rng.integers(0, hp["n_vocab"], size=(world, n_pf)).astype(np.int32)).cuda() if rank == 0 else None
+            pf_rows = torch.zeros((world, hp["n_embd"]), dtype=torch.float32, device="cuda") if rank == 0 else None
+            c_ring.prefill(win, pf_tok, world, n_pf, RING_UBATCH, pf_rows)          # warm: scratch growth, function attributes
+            sync()
+            tq0 = time.perf_counter()
+            c_ring.prefill(win, pf_tok, world, n_pf, RING_UBATCH, pf_rows)
+            sync()
+            dtp = time.perf_counter() - tq0
+            if world > 1:
+                t2 = torch.tensor([dts, dtp], dtype=torch.float64, device="cuda" if dist.get_backend() != "gloo" else "cpu")
+                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+                dts, dtp = float(t2[0].item()), float(t2[1].item())
+            single = {"tokens_per_s": round(a.steps / dts, 3), "ms_per_token": round(dts / a.steps * 1e3, 4), "steps": a.steps,
+                      "note": "ONE sequence in flight (pm355_ring_single_token): a token visits every rank in turn, rank 0 waits for the last rank's row "
+                              "before the head - the reference's llama_decode ring loop; no speed-up over one GPU is possible, the difference is the hops"}
+            ring_pf = {"prompt_tokens": n_pf, "sequences": world, "ubatch": RING_UBATCH, "tokens_per_s": round(world * n_pf / dtp, 1), "ms": round(dtp * 1e3, 2),
+                       "first_prompt_pass_s": round(ring_prompt, 4) if ring_prompt is not None else None,
+                       "note": "pm355_ring_prefill: chunk g of the prompts on rank r at pipeline step g + r, [ubatch][n_embd] f32 per hop; aggregate over the sequences"}
 
         tokens = a.steps * world
         value = tokens / dt
@@ -564,13 +631,16 @@ def main():
                 "config": {"workload": f"{model_name} batch-1 greedy decode, {a.prompt}-token synthetic prompt, "
                                        f"{world} sequence(s) in flight, n_ctx {a.n_ctx}, F16 KV cache",
                            "parallelism": "single GPU" if world == 1 else f"piped-ring layer split pp{world} "
-                                          f"(windows {wins}), RCCL send/recv ({'C transport pm355_ring_*: comm stream + events, no host wait' if c_ring else 'torch.distributed'})",
+                                          f"(windows {wins}), ring in C (pm355_ring_*), transport {'RCCL send/recv: comm stream + events, no host wait' if ring_transport == 'rccl' else 'torch.distributed ' + dist.get_backend() + ' through the transport callbacks'}",
                            "weights_bytes_per_token": total_w, "kv_bytes_per_token_mid_run": kv_b,
                            "hip_graph": use_graph},
                 "hbm_roofline_tokens_per_s": round(HBM_PEAK_GBS * 1e9 / total_w * world, 2),
                 "frac_of_hbm_roofline_weights_only": round(value * total_w / world / (HBM_PEAK_GBS * 1e9), 4),
                 "frac_of_hbm_roofline_weights_plus_kv": round(value * (total_w + kv_b) / world / (HBM_PEAK_GBS * 1e9), 4),
             }
+            if single:
+                result["single_stream"] = single
+                result["ring_prefill"] = ring_pf
             pr = probe_dominant_kernel(win, hp)
             if pr:
                 result["roofline"] = {"bound": "hbm", "achieved": round(pr["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -74,6 +74,9 @@ PM355_API void * pm355_host_malloc(size_t bytes);                 /* pinned */
 PM355_API void   pm355_host_free(void * hptr);
 PM355_API int    pm355_memcpy_h2d(void * dst, const void * src, size_t bytes, pm355_stream_t stream);
 PM355_API int    pm355_memcpy_d2h(void * dst, const void * src, size_t bytes, pm355_stream_t stream);
+/* 1 when `p` is page-locked host memory known to the HIP runtime (hipHostMalloc / hipHostRegister): an asynchronous copy FROM it really is
+ * asynchronous (the DMA reads it after the call returned), unlike a copy from pageable memory, which is staged before the call returns */
+PM355_API int    pm355_host_is_pinned(const void * p);
 PM355_API int    pm355_memcpy_d2d(void * dst, const void * src, size_t bytes, pm355_stream_t stream);
 PM355_API int    pm355_memset(void * dst, int value, size_t bytes, pm355_stream_t stream);
 
@@ -366,6 +369,10 @@ PM355_API void * pm355_model_tensor_ptr(pm355_model * m, int kind, int layer, in
  * Equivalent of the per-sub-graph body of llama_decode_internal's ring loop (src/llama.cpp:18503-18564). */
 PM355_API int pm355_model_decode(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, int n_tokens, int pos0,
                                  float * d_x_out, float * d_logits, int32_t * d_argmax, pm355_stream_t stream);
+/* the same for sequence `seq` (its KV slab and position counter) of a window finalized with n_seq > 1; `seq` stays the current sequence */
+PM355_API int pm355_model_decode_seq(pm355_model * m, int seq, const int32_t * d_tokens, const float * d_x_in, int n_tokens, int pos0,
+                                     float * d_x_out, float * d_logits, int32_t * d_argmax, pm355_stream_t stream);
+PM355_API int pm355_model_n_embd(const pm355_model * m);
 /* Device-resident greedy loop (needs HAS_EMBD|HAS_HEAD and the whole model in one window): starting from the token
  * in d_tokens_io[0] at position pos0, generate n_steps tokens; step i reads d_tokens_io[i], writes d_tokens_io[i+1].
  * One captured hipGraph per step, replayed; no host synchronisation inside. */
@@ -415,6 +422,34 @@ PM355_API int pm355_ring_wait(pm355_ring * r, pm355_stream_t compute_stream);
 PM355_API int pm355_ring_step(pm355_ring * r, pm355_model * m, const int32_t * d_token, const float * x_in, float * x_out,
                               float * d_logits, int32_t * d_argmax, int advance, int rotate, int head_first, int use_graph,
                               int do_send, float * recv_next, int64_t n_embd, pm355_stream_t compute_stream);
+/* A ring whose exchanges go through the CALLER's transport instead of RCCL (tests: two ranks on one GPU over gloo; any other fabric):
+ * exchange(user, send, n_send, recv, n_recv, stream) moves n_send f32 from device memory `send` to the next rank and n_recv f32 from
+ * the previous rank into device memory `recv` (either may be NULL / 0); wait(user, stream) returns once the last exchange is complete
+ * (for the compute stream). Everything above the transport - pm355_ring_step_tokens, pm355_ring_prefill, pm355_ring_single_token -
+ * is the same code for both. */
+typedef int (*pm355_ring_exchange_fn)(void * user, const float * send, int64_t n_send, float * recv, int64_t n_recv, pm355_stream_t stream);
+typedef int (*pm355_ring_wait_fn)(void * user, pm355_stream_t stream);
+PM355_API pm355_ring * pm355_ring_init_cb(int rank, int world, pm355_ring_exchange_fn exchange, pm355_ring_wait_fn wait, void * user);
+/* the general exchange: different element counts in the two directions (the last rank returns one row, a window hands on a ubatch) */
+PM355_API int pm355_ring_exchange2(pm355_ring * r, const float * send, int64_t n_send, float * recv, int64_t n_recv, pm355_stream_t compute_stream);
+/* Multi-token micro-step: the window of sequence `seq` over n_tokens tokens at positions pos0.. (tokens on the first rank, x_in
+ * [n_tokens][n_embd] elsewhere - the reference hands the whole ubatch [n_embd, n_tokens] per hop, llama_send_tensors src/llama.cpp:18031-18052),
+ * then the exchange {send n_send f32 from send_ptr (inside x_out) when non-NULL, receive n_recv f32 into recv_next when non-NULL} */
+PM355_API int pm355_ring_step_tokens(pm355_ring * r, pm355_model * m, int seq, const int32_t * d_tokens, const float * x_in, float * x_out,
+                                     int n_tokens, int pos0, const float * send_ptr, int64_t n_send, float * recv_next, int64_t n_recv,
+                                     pm355_stream_t compute_stream);
+/* Prompt processing pipelined over the ranks (what prima.cpp does one ubatch at a time with every other rank idle, src/llama.cpp:18503-18564):
+ * the n_seq prompts of n_prompt tokens are cut into chunks of `ubatch` tokens; chunk g runs on rank r at pipeline step g + r while chunk g + 1
+ * runs on rank r - 1; a window hands its [n_tokens][n_embd] output to the next rank; the last rank returns the LAST row of a prompt's final
+ * chunk to rank 0 (final_rows[seq][n_embd], rank 0 only) for the head. d_tokens: [n_seq][n_prompt] int32 on rank 0 (NULL elsewhere).
+ * Every rank calls it with the same n_seq / n_prompt / ubatch; the window must be finalized with max_tokens >= ubatch, n_seq >= n_seq. Positions
+ * of the sequences are left at n_prompt. Asynchronous on compute_stream (pm355_ring_wait before reading final_rows). */
+PM355_API int pm355_ring_prefill(pm355_ring * r, pm355_model * m, int n_seq, const int32_t * d_tokens, int n_prompt, int ubatch,
+                                 float * final_rows, pm355_stream_t compute_stream);
+/* ONE sequence in flight, the reference's own mode (rank 0 blocked until the token has been round the ring, src/llama.cpp:18509): one token of
+ * sequence `seq` per call on every rank. Rank 0: embeds *d_token, runs its window, sends, receives the last rank's row, runs the head and writes
+ * the next token to *d_token (and the logits to d_logits when non-NULL); other ranks: receive, window, send. */
+PM355_API int pm355_ring_single_token(pm355_ring * r, pm355_model * m, int seq, int32_t * d_token, float * d_logits, pm355_stream_t compute_stream);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,11 @@ int pm355_device_info(int d, char * name, size_t name_len, size_t * free_b, size
     }
     return 0;
 }
+int pm355_host_is_pinned(const void * p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void) hipGetLastError(); return 0; }      // unknown to the runtime: pageable
+    return a.type == hipMemoryTypeHost ? 1 : 0;
+}
 int pm355_sync(pm355_stream_t s) { HIP_TRY(s ? hipStreamSynchronize(S(s)) : hipDeviceSynchronize()); return 0; }
 
 pm355_stream_t pm355_stream_create(void) { hipStream_t s = nullptr; return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? (pm355_stream_t) s : nullptr; }

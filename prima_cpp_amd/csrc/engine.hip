@@ -793,6 +793,20 @@ int pm355_model_decode(pm355_model * m, const int32_t * d_tokens, const float * 
     return run_window(m, d_tokens, d_x_in, T, d_x_out, d_logits, d_argmax, (hipStream_t) st);   // device counter and mirror stay at pos0
 }
 
+// the same for sequence `seq` of a window finalized with n_seq > 1 (its KV slab, its position counter); leaves `seq` current
+int pm355_model_decode_seq(pm355_model * m, int seq, const int32_t * d_tokens, const float * d_x_in, int T, int pos0,
+                           float * d_x_out, float * d_logits, int32_t * d_argmax, pm355_stream_t st) {
+    if (!m->finalized) return seterr(m, PM355_E_SHAPE, "decode: model not finalized");
+    if (seq < 0 || seq >= m->n_seq) return seterr(m, PM355_E_RANGE, "decode_seq: seq >= n_seq");
+    if (T < 1 || T > m->max_tokens) return seterr(m, PM355_E_RANGE, "decode: n_tokens exceeds finalize(max_tokens)");
+    if (pos0 < 0 || pos0 + T > m->hp.n_ctx) return seterr(m, PM355_E_RANGE, "decode: position outside n_ctx");
+    int rc = pm355_model_set_seq_pos(m, seq, pos0, st);
+    if (!rc) rc = pm355_model_set_seq(m, seq, st);
+    if (rc) return rc;
+    return run_window(m, d_tokens, d_x_in, T, d_x_out, d_logits, d_argmax, (hipStream_t) st);
+}
+int pm355_model_n_embd(const pm355_model * m) { return m ? m->hp.n_embd : 0; }
+
 // head_first != 0 (ring rank 0): d_x_in is the LAST rank's activation; apply the head to it (-> d_argmax / d_logits),
 // then embed the token found at d_token (which may be d_argmax itself) and run the window -> d_x_out.
 static int step_body(pm355_model * m, const int32_t * d_token, const float * d_x_in, float * d_x_out,

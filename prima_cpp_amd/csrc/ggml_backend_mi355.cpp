@@ -200,7 +200,12 @@ void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void 
     }
     buf_drain(c);
     if (!soa && !plan_only() && size <= ((size_t) 1 << 20) && !env_on("GGML_MI355_SYNC_UPLOAD")) {
+        // per-token graph inputs: enqueued on the null stream, the compute stream is ordered behind them on the device. The source bytes
+        // have left `data` when hipMemcpyAsync returns ONLY for pageable memory (the runtime stages it); a page-locked source - e.g. a
+        // tensor of the plug-in's own host buffer type handed over by ggml_backend_tensor_copy - is read by the DMA later, and the
+        // scheduler relies on the copy being complete on return (ggml-backend.cpp:2110): wait for it.
         MI355_CHECK(h2d((char *) t->data + off, data, size, nullptr));
+        if (pm355_host_is_pinned(data)) { MI355_CHECK(dsync(nullptr)); return; }
         g_null_epoch.fetch_add(1, std::memory_order_release);
         return;
     }

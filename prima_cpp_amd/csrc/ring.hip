@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 
 namespace {
 
@@ -34,14 +35,12 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     bool ok = false;
 };
-Rccl & rccl() {
-    static Rccl r;
-    if (r.h) return r;
+static void rccl_load(Rccl & r) {
     for (const char * name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (r.h) break;
     }
-    if (!r.h) return r;
+    if (!r.h) return;
     r.GetUniqueId = (decltype(r.GetUniqueId)) dlsym(r.h, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank)) dlsym(r.h, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy)) dlsym(r.h, "ncclCommDestroy");
@@ -51,6 +50,11 @@ Rccl & rccl() {
     r.GroupStart = (decltype(r.GroupStart)) dlsym(r.h, "ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd)) dlsym(r.h, "ncclGroupEnd");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Send && r.Recv && r.GroupStart && r.GroupEnd;
+}
+Rccl & rccl() {                              // resolved once, whoever comes first (a launcher may run one rank per thread)
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_load(r); });
     return r;
 }
 
@@ -70,7 +74,22 @@ struct pm355_ring {
     hipEvent_t ready = nullptr;               // compute -> comm: the buffer to send is complete
     hipEvent_t done = nullptr;                // comm -> compute: the exchange (send left, input arrived) is complete
     bool pending = false;                     // an exchange was enqueued since the last wait
+    // caller-supplied transport (pm355_ring_init_cb) instead of RCCL
+    pm355_ring_exchange_fn cb_exchange = nullptr; pm355_ring_wait_fn cb_wait = nullptr; void * cb_user = nullptr;
+    // prompt pipeline / single-stream buffers: [2] inputs + [2] outputs of up to buf_floats f32
+    float * pin[2] = {nullptr, nullptr}, * pout[2] = {nullptr, nullptr}; size_t buf_floats = 0;
 };
+
+static int ring_buffers(pm355_ring * r, size_t n_floats) {
+    if (n_floats <= r->buf_floats) return 0;
+    (void) hipDeviceSynchronize();
+    for (int i = 0; i < 2; ++i) { if (r->pin[i]) (void) hipFree(r->pin[i]); if (r->pout[i]) (void) hipFree(r->pout[i]); r->pin[i] = r->pout[i] = nullptr; }
+    r->buf_floats = 0;
+    for (int i = 0; i < 2; ++i)
+        if (hipMalloc((void **) &r->pin[i], n_floats * 4 + 256) != hipSuccess || hipMalloc((void **) &r->pout[i], n_floats * 4 + 256) != hipSuccess) return -1;
+    r->buf_floats = n_floats;
+    return 0;
+}
 
 extern "C" {
 
@@ -106,9 +125,18 @@ pm355_ring * pm355_ring_init(const void * id128, int rank, int world) {
     return r;
 }
 
+pm355_ring * pm355_ring_init_cb(int rank, int world, pm355_ring_exchange_fn exchange, pm355_ring_wait_fn wait, void * user) {
+    if (!exchange || !wait || world < 1 || rank < 0 || rank >= world) { rfail(PM355_E_RANGE, "ring_init_cb: rank / world / callbacks"); return nullptr; }
+    pm355_ring * r = new pm355_ring();
+    r->rank = rank; r->world = world; r->next = (rank + 1) % world; r->prev = (rank + world - 1) % world;
+    r->cb_exchange = exchange; r->cb_wait = wait; r->cb_user = user;
+    return r;
+}
+
 void pm355_ring_free(pm355_ring * r) {
     if (!r) return;
     if (r->cs) { (void) hipStreamSynchronize(r->cs); }
+    for (int i = 0; i < 2; ++i) { if (r->pin[i]) (void) hipFree(r->pin[i]); if (r->pout[i]) (void) hipFree(r->pout[i]); }
     if (r->comm) (void) rccl().CommDestroy(r->comm);
     if (r->cs) (void) hipStreamDestroy(r->cs);
     if (r->ready) (void) hipEventDestroy(r->ready);
@@ -121,14 +149,26 @@ void pm355_ring_free(pm355_ring * r) {
 // `compute_stream` (the producer of `send`); the completion is published through an event that pm355_ring_wait hands to the
 // compute stream. Nothing here blocks the host.
 int pm355_ring_exchange(pm355_ring * r, const float * send, float * recv, int64_t n, pm355_stream_t compute_stream) {
-    Rccl & R = rccl();
-    if (!r || !R.ok) return rfail(PM355_E_SHAPE, "ring_exchange: no ring");
+    return pm355_ring_exchange2(r, send, send ? n : 0, recv, recv ? n : 0, compute_stream);
+}
+int pm355_ring_exchange2(pm355_ring * r, const float * send, int64_t n_send, float * recv, int64_t n_recv, pm355_stream_t compute_stream) {
+    if (!r) return rfail(PM355_E_SHAPE, "ring_exchange: no ring");
+    if (!n_send) send = nullptr;
+    if (!n_recv) recv = nullptr;
     if (!send && !recv) return 0;
+    if (r->cb_exchange) {
+        const int rc = r->cb_exchange(r->cb_user, send, send ? n_send : 0, recv, recv ? n_recv : 0, compute_stream);
+        if (rc) return rfail(PM355_E_HIP, "ring_exchange: transport callback failed");
+        r->pending = true;
+        return 0;
+    }
+    Rccl & R = rccl();
+    if (!R.ok) return rfail(PM355_E_SHAPE, "ring_exchange: no ring");
     hipStream_t st = (hipStream_t) compute_stream;
     if (hipEventRecord(r->ready, st) != hipSuccess || hipStreamWaitEvent(r->cs, r->ready, 0) != hipSuccess) return rfail(PM355_E_HIP, "ring_exchange: event hand-off");
     int rc = R.GroupStart();
-    if (rc == ncclSuccess && send) rc = R.Send(send, (size_t) n, ncclFloat32, r->next, r->comm, r->cs);
-    if (rc == ncclSuccess && recv) rc = R.Recv(recv, (size_t) n, ncclFloat32, r->prev, r->comm, r->cs);
+    if (rc == ncclSuccess && send) rc = R.Send(send, (size_t) n_send, ncclFloat32, r->next, r->comm, r->cs);
+    if (rc == ncclSuccess && recv) rc = R.Recv(recv, (size_t) n_recv, ncclFloat32, r->prev, r->comm, r->cs);
     const int rc2 = R.GroupEnd();
     if (rc != ncclSuccess || rc2 != ncclSuccess) return rfail(PM355_E_HIP, "ring_exchange: ncclSend / ncclRecv", rc != ncclSuccess ? rc : rc2);
     if (hipEventRecord(r->done, r->cs) != hipSuccess) return rfail(PM355_E_HIP, "ring_exchange: event record");
@@ -140,6 +180,11 @@ int pm355_ring_exchange(pm355_ring * r, const float * send, float * recv, int64_
 int pm355_ring_wait(pm355_ring * r, pm355_stream_t compute_stream) {
     if (!r) return rfail(PM355_E_SHAPE, "ring_wait: no ring");
     if (!r->pending) return 0;
+    if (r->cb_wait) {
+        if (r->cb_wait(r->cb_user, compute_stream)) return rfail(PM355_E_HIP, "ring_wait: transport callback failed");
+        r->pending = false;
+        return 0;
+    }
     if (hipStreamWaitEvent((hipStream_t) compute_stream, r->done, 0) != hipSuccess) return rfail(PM355_E_HIP, "ring_wait");
     r->pending = false;
     return 0;
@@ -157,6 +202,102 @@ int pm355_ring_step(pm355_ring * r, pm355_model * m, const int32_t * d_token, co
     rc = pm355_model_step_ex(m, d_token, x_in, x_out, d_logits, d_argmax, advance, rotate, head_first, use_graph, compute_stream);
     if (rc) return rfail(rc, pm355_model_error(m));
     return pm355_ring_exchange(r, do_send ? x_out : nullptr, recv_next, n_embd, compute_stream);
+}
+
+int pm355_ring_step_tokens(pm355_ring * r, pm355_model * m, int seq, const int32_t * d_tokens, const float * x_in, float * x_out, int n_tokens,
+                           int pos0, const float * send_ptr, int64_t n_send, float * recv_next, int64_t n_recv, pm355_stream_t compute_stream) {
+    int rc = pm355_ring_wait(r, compute_stream);
+    if (rc) return rc;
+    rc = pm355_model_decode_seq(m, seq, d_tokens, d_tokens ? nullptr : x_in, n_tokens, pos0, x_out, nullptr, nullptr, compute_stream);
+    if (rc) return rfail(rc, pm355_model_error(m));
+    return pm355_ring_exchange2(r, send_ptr, n_send, recv_next, n_recv, compute_stream);
+}
+
+int pm355_ring_prefill(pm355_ring * r, pm355_model * m, int n_seq, const int32_t * d_tokens, int n_prompt, int ubatch, float * final_rows,
+                       pm355_stream_t compute_stream) {
+    if (!r || !m || n_seq < 1 || n_prompt < 1 || ubatch < 1) return rfail(PM355_E_RANGE, "ring_prefill: arguments");
+    const int W = r->world, rank = r->rank;
+    const int64_t E = pm355_model_n_embd(m);
+    const int C = (n_prompt + ubatch - 1) / ubatch, G = n_seq * C;
+    if (rank == 0 && (!d_tokens || !final_rows)) return rfail(PM355_E_SHAPE, "ring_prefill: rank 0 needs the tokens and final_rows");
+    if (ring_buffers(r, (size_t) ubatch * E)) return rfail(PM355_E_NOMEM, "ring_prefill: activation buffers");
+    hipStream_t st = (hipStream_t) compute_stream;
+    auto chunk_len = [&](int g) { const int c = g % C; return c == C - 1 ? n_prompt - c * ubatch : ubatch; };
+    if (W == 1) {                                             // no hand-off: chunk after chunk, keep each prompt's last row
+        for (int g = 0; g < G; ++g) {
+            const int seq = g / C, c = g % C, T = chunk_len(g);
+            int rc = pm355_model_decode_seq(m, seq, d_tokens + (size_t) seq * n_prompt + (size_t) c * ubatch, nullptr, T, c * ubatch, r->pout[0], nullptr, nullptr, compute_stream);
+            if (rc) return rfail(rc, pm355_model_error(m));
+            if (c == C - 1 && hipMemcpyAsync(final_rows + (size_t) seq * E, r->pout[0] + (size_t) (T - 1) * E, E * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return rfail(PM355_E_HIP, "ring_prefill: copy of the final row");
+        }
+        for (int seq = 0; seq < n_seq; ++seq) { int rc = pm355_model_set_seq_pos(m, seq, n_prompt, compute_stream); if (rc) return rfail(rc, pm355_model_error(m)); }
+        return 0;
+    }
+    for (int s = 0; s <= G + W - 2; ++s) {
+        const int g = s - rank;
+        const bool valid = g >= 0 && g < G;
+        int rc = pm355_ring_wait(r, compute_stream);          // the previous step's exchange: this chunk's input is here, the last output has left
+        if (rc) return rc;
+        float * out = r->pout[g & 1];
+        int T = 0;
+        if (valid) {
+            const int seq = g / C, c = g % C;
+            T = chunk_len(g);
+            rc = pm355_model_decode_seq(m, seq, rank == 0 ? d_tokens + (size_t) seq * n_prompt + (size_t) c * ubatch : nullptr,
+                                        rank == 0 ? nullptr : r->pin[g & 1], T, c * ubatch, out, nullptr, nullptr, compute_stream);
+            if (rc) return rfail(rc, pm355_model_error(m));
+        }
+        // what leaves: a window's whole ubatch to the next rank; from the last rank only the last row of a prompt's final chunk, to rank 0
+        const float * snd = nullptr; int64_t n_snd = 0;
+        if (valid) {
+            if (rank < W - 1) { snd = out; n_snd = (int64_t) T * E; }
+            else if (g % C == C - 1) { snd = out + (size_t) (T - 1) * E; n_snd = E; }
+        }
+        // what arrives for the NEXT step: rank > 0 its next chunk; rank 0 the row the last rank sends at the end of THIS step
+        float * rcv = nullptr; int64_t n_rcv = 0;
+        if (rank > 0) {
+            const int gn = g + 1;
+            if (gn >= 0 && gn < G) { rcv = r->pin[gn & 1]; n_rcv = (int64_t) chunk_len(gn) * E; }
+        } else {
+            const int gl = s - (W - 1);                       // the chunk the last rank is working on in this step
+            if (gl >= 0 && gl < G && gl % C == C - 1) { rcv = final_rows + (size_t) (gl / C) * E; n_rcv = E; }
+        }
+        rc = pm355_ring_exchange2(r, snd, n_snd, rcv, n_rcv, compute_stream);
+        if (rc) return rc;
+    }
+    for (int seq = 0; seq < n_seq; ++seq) { int rc = pm355_model_set_seq_pos(m, seq, n_prompt, compute_stream); if (rc) return rfail(rc, pm355_model_error(m)); }
+    return 0;
+}
+
+int pm355_ring_single_token(pm355_ring * r, pm355_model * m, int seq, int32_t * d_token, float * d_logits, pm355_stream_t compute_stream) {
+    if (!r || !m) return rfail(PM355_E_SHAPE, "ring_single_token: no ring / window");
+    const int W = r->world, rank = r->rank;
+    const int64_t E = pm355_model_n_embd(m);
+    int rc = pm355_model_set_seq(m, seq, compute_stream);
+    if (rc) return rfail(rc, pm355_model_error(m));
+    if (W == 1) {
+        rc = pm355_model_step_ex(m, d_token, nullptr, nullptr, d_logits, d_token, 1, 0, 0, 1, compute_stream);
+        return rc ? rfail(rc, pm355_model_error(m)) : 0;
+    }
+    if (ring_buffers(r, (size_t) E)) return rfail(PM355_E_NOMEM, "ring_single_token: buffers");
+    if (rank == 0) {
+        if (!d_token) return rfail(PM355_E_SHAPE, "ring_single_token: rank 0 needs d_token");
+        rc = pm355_ring_wait(r, compute_stream);
+        if (!rc) { rc = pm355_model_step_ex(m, d_token, nullptr, r->pout[0], nullptr, nullptr, 1, 0, 0, 1, compute_stream); if (rc) return rfail(rc, pm355_model_error(m)); }
+        if (!rc) rc = pm355_ring_exchange2(r, r->pout[0], E, r->pin[0], E, compute_stream);      // out to rank 1; the last rank's row comes back
+        if (!rc) rc = pm355_ring_wait(r, compute_stream);
+        if (rc) return rc;
+        rc = pm355_model_head(m, r->pin[0], d_logits, d_token, compute_stream);
+        return rc ? rfail(rc, pm355_model_error(m)) : 0;
+    }
+    rc = pm355_ring_wait(r, compute_stream);
+    if (!rc) rc = pm355_ring_exchange2(r, nullptr, 0, r->pin[0], E, compute_stream);
+    if (!rc) rc = pm355_ring_wait(r, compute_stream);
+    if (rc) return rc;
+    rc = pm355_model_step_ex(m, nullptr, r->pin[0], r->pout[0], nullptr, nullptr, 1, 0, 0, 1, compute_stream);
+    if (rc) return rfail(rc, pm355_model_error(m));
+    return pm355_ring_exchange2(r, r->pout[0], E, nullptr, 0, compute_stream);
 }
 
 int pm355_ring_rank(const pm355_ring * r) { return r ? r->rank : -1; }

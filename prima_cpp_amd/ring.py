@@ -44,6 +44,43 @@ def partition_layers(layer_bytes, head_bytes, world):
     return out
 
 
+def prefill_schedule(rank, world, n_seq, n_prompt, ubatch):
+    """The pipelined prompt pass of pm355_ring_prefill (csrc/ring.hip) as data: for every pipeline step s = 0 .. G + world - 2 the tuple
+    (chunk or None, tokens, send_floats_per_embd, recv_floats_per_embd) of this rank, in units of n_embd floats. Chunk g = seq * C + c runs
+    on rank r at step g + r; a window sends its whole [tokens][n_embd] output to the next rank, the last rank sends only the last row of a
+    prompt's final chunk (to rank 0, which receives it at the end of the same step). Host-side mirror used by the CPU tests: every send
+    must meet a receive of the same size on the neighbour in the same step."""
+    C = (n_prompt + ubatch - 1) // ubatch
+    G = n_seq * C
+
+    def clen(g):
+        c = g % C
+        return n_prompt - c * ubatch if c == C - 1 else ubatch
+    out = []
+    for s in range(G + world - 1) if world > 1 else range(G):
+        g = s - rank
+        valid = 0 <= g < G
+        T = clen(g) if valid else 0
+        snd = 0
+        if valid and world > 1:
+            if rank < world - 1:
+                snd = T
+            elif g % C == C - 1:
+                snd = 1
+        rcv = 0
+        if world > 1:
+            if rank > 0:
+                gn = g + 1
+                if 0 <= gn < G:
+                    rcv = clen(gn)
+            else:
+                gl = s - (world - 1)
+                if 0 <= gl < G and gl % C == C - 1:
+                    rcv = 1
+        out.append((g if valid else None, T, snd, rcv))
+    return out
+
+
 class RankCompute:
     """What a rank does inside one micro-step. Buffers are torch tensors on the rank's device."""
 
@@ -144,46 +181,128 @@ class RingDriver:
 
 
 class CRing:
-    """RCCL transport in C (prima_cpp_amd/csrc/ring.hip). The 128-byte unique id is created on rank 0 and handed to the other
-    ranks by the launcher - here through the already initialised torch.distributed group (process launch is all Python keeps)."""
+    """The ring in C (prima_cpp_amd/csrc/ring.hip, pm355_ring_* of include/prima_mi355.h): exchanges, multi-token micro-steps, the
+    pipelined prompt pass and the single-sequence token loop. Two transports under the same C code:
+      transport="rccl"  ncclSend / ncclRecv on the library's communication stream (one GPU per rank); the 128-byte unique id is created
+                        on rank 0 and handed to the other ranks through the already initialised torch.distributed group
+      transport="torch" the exchanges are carried by torch.distributed point-to-point operations of `group` (any backend; with gloo the
+                        device buffers are staged through host memory) via the C API's transport callbacks - how two ranks share ONE GPU
+                        in the tests and in `PM355_DIST_BACKEND=gloo python -m torch.distributed.run ... bench.py --gpus 2`."""
 
-    def __init__(self, rank, world, group=None):
+    def __init__(self, rank, world, group=None, transport="rccl"):
         import ctypes as C
         from . import lib as L
         self.lib = L.load()
-        self.lib.pm355_ring_init.restype = C.c_void_p
-        self.lib.pm355_ring_init.argtypes = [C.c_void_p, C.c_int, C.c_int]
-        self.lib.pm355_ring_free.argtypes = [C.c_void_p]
-        self.lib.pm355_ring_error.restype = C.c_char_p
-        self.lib.pm355_ring_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
-        self.lib.pm355_ring_wait.argtypes = [C.c_void_p, C.c_void_p]
-        ident = [None]
-        if rank == 0:
-            buf = C.create_string_buffer(128)
-            rc = self.lib.pm355_ring_unique_id(buf)
-            if rc:
-                raise L.PM355Error(f"pm355_ring_unique_id rc={rc}: {self.lib.pm355_ring_error().decode()}")
-            ident[0] = bytes(buf.raw)
-        if world > 1:
-            dist.broadcast_object_list(ident, src=0, group=group)
-        self.h = self.lib.pm355_ring_init(ident[0], rank, world)
+        self.L = L
+        lib = self.lib
+        lib.pm355_ring_init.restype = C.c_void_p
+        lib.pm355_ring_init.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.pm355_ring_init_cb.restype = C.c_void_p
+        lib.pm355_ring_free.argtypes = [C.c_void_p]
+        lib.pm355_ring_error.restype = C.c_char_p
+        lib.pm355_ring_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        lib.pm355_ring_exchange2.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+        lib.pm355_ring_wait.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pm355_ring_prefill.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.pm355_ring_single_token.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pm355_ring_step_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+        self.rank, self.world, self.group, self.transport = rank, world, group, transport
+        self.h = None
+        if transport == "torch":
+            XF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p)
+            WF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+            self._pend = None
+            self._xf, self._wf = XF(self._cb_exchange), WF(self._cb_wait)      # (kept alive with the object)
+            lib.pm355_ring_init_cb.argtypes = [C.c_int, C.c_int, XF, WF, C.c_void_p]
+            self.h = lib.pm355_ring_init_cb(rank, world, self._xf, self._wf, None)
+        else:
+            # every rank must leave the broadcast, also when rank 0 cannot create the id (then all of them fail together)
+            ident = [None]
+            err = None
+            if rank == 0:
+                buf = C.create_string_buffer(128)
+                rc = lib.pm355_ring_unique_id(buf)
+                if rc:
+                    err = f"pm355_ring_unique_id rc={rc}: {lib.pm355_ring_error().decode()}"
+                else:
+                    ident[0] = bytes(buf.raw)
+            if world > 1:
+                dist.broadcast_object_list(ident, src=0, group=group)
+            if ident[0] is None:
+                raise L.PM355Error(err or "rank 0 could not create the RCCL unique id")
+            self.h = lib.pm355_ring_init(ident[0], rank, world)
         if not self.h:
-            raise L.PM355Error(f"pm355_ring_init failed: {self.lib.pm355_ring_error().decode()}")
-        self.rank, self.world = rank, world
+            raise L.PM355Error(f"pm355_ring_init failed: {lib.pm355_ring_error().decode()}")
+
+    # ---- transport callbacks (transport="torch"): device buffers travel through torch.distributed ------------------------------
+    def _cb_exchange(self, user, send, n_send, recv, n_recv, stream):
+        try:
+            lib = self.lib
+            nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+            on_dev = dist.get_backend(self.group) != "gloo"
+            ops, hs, hr = [], None, None
+            dev = torch.device("cuda", torch.cuda.current_device())
+            if send and n_send:
+                hs = torch.empty(n_send, dtype=torch.float32, device=dev if on_dev else "cpu")
+                cp = lib.pm355_memcpy_d2d if on_dev else lib.pm355_memcpy_d2h
+                if cp(hs.data_ptr(), send, n_send * 4, stream) or lib.pm355_sync(stream):
+                    return 1
+                ops.append(dist.P2POp(dist.isend, hs, nxt, self.group))
+            if recv and n_recv:
+                hr = torch.empty(n_recv, dtype=torch.float32, device=dev if on_dev else "cpu")
+                ops.append(dist.P2POp(dist.irecv, hr, prv, self.group))
+            self._pend = (dist.batch_isend_irecv(ops) if ops else [], hs, hr, recv, n_recv, on_dev)
+            return 0
+        except Exception as e:                         # never let an exception cross the C frames
+            print(f"[ring transport] exchange failed: {e}", flush=True)
+            return 1
+
+    def _cb_wait(self, user, stream):
+        try:
+            if self._pend is None:
+                return 0
+            reqs, hs, hr, recv, n_recv, on_dev = self._pend
+            self._pend = None
+            for q in reqs:
+                q.wait()
+            if hr is not None:
+                if on_dev:
+                    torch.cuda.current_stream().synchronize()
+                cp = self.lib.pm355_memcpy_d2d if on_dev else self.lib.pm355_memcpy_h2d
+                if cp(recv, hr.data_ptr(), n_recv * 4, stream) or self.lib.pm355_sync(stream):
+                    return 1
+            return 0
+        except Exception as e:
+            print(f"[ring transport] wait failed: {e}", flush=True)
+            return 1
 
     def _chk(self, rc, what):
         if rc:
-            from . import lib as L
-            raise L.PM355Error(f"{what} rc={rc}: {self.lib.pm355_ring_error().decode()}")
+            raise self.L.PM355Error(f"{what} rc={rc}: {self.lib.pm355_ring_error().decode()}")
 
     def exchange(self, send, recv):
-        n = (send if send is not None else recv).numel() if (send is not None or recv is not None) else 0
         st = torch.cuda.current_stream().cuda_stream
-        self._chk(self.lib.pm355_ring_exchange(self.h, send.data_ptr() if send is not None else None,
-                                               recv.data_ptr() if recv is not None else None, n, st), "pm355_ring_exchange")
+        self._chk(self.lib.pm355_ring_exchange2(self.h, send.data_ptr() if send is not None else None, send.numel() if send is not None else 0,
+                                                recv.data_ptr() if recv is not None else None, recv.numel() if recv is not None else 0, st),
+                  "pm355_ring_exchange")
 
     def wait(self):
         self._chk(self.lib.pm355_ring_wait(self.h, torch.cuda.current_stream().cuda_stream), "pm355_ring_wait")
+
+    def prefill(self, window, tokens, n_seq, n_prompt, ubatch, final_rows):
+        """Pipelined prompt pass (pm355_ring_prefill): tokens int32 [n_seq, n_prompt] on rank 0 (None elsewhere); final_rows f32
+        [n_seq, n_embd] on rank 0 receives each prompt's last hidden row from the last rank. The window needs finalize(max_tokens >= ubatch)."""
+        st = torch.cuda.current_stream().cuda_stream
+        self._chk(self.lib.pm355_ring_prefill(self.h, window.h, n_seq, tokens.data_ptr() if tokens is not None else None, n_prompt, ubatch,
+                                              final_rows.data_ptr() if final_rows is not None else None, st), "pm355_ring_prefill")
+        self.wait()
+
+    def single_token(self, window, seq, token, logits=None):
+        """ONE sequence in flight (the reference's mode): a token of `seq` once round the ring; rank 0 gets the next token in `token`."""
+        st = torch.cuda.current_stream().cuda_stream
+        self._chk(self.lib.pm355_ring_single_token(self.h, window.h, seq, token.data_ptr() if token is not None else None,
+                                                   logits.data_ptr() if logits is not None else None, st), "pm355_ring_single_token")
 
     def close(self):
         if self.h:

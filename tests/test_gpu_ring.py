@@ -156,3 +156,127 @@ def test_c_ring_transport_world1_self_send():
     for (h0, t0), (h1, t1) in zip(*outs):
         assert t0 == t1 and np.array_equal(h0, h1)
     ring.close()
+
+
+def _worker_c(rank, world, port, prompts, ubatch, n_single, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from _bind import tiny_model
+    import prima_cpp_amd.engine as E
+    from prima_cpp_amd.ring import CRing
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = tiny_model(np.random.default_rng(61), arch=0, n_layer=4, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=320, n_ctx=64, rope_freqs=True)
+    lo, hi = (0, 2) if rank == 0 else (2, 4)
+    n_seq, n_prompt = prompts.shape
+    with torch.cuda.stream(torch.cuda.Stream()):
+        w = E.Window(_hp(d), lo=lo, hi=hi, flags=(E.HAS_EMBD | E.HAS_HEAD) if rank == 0 else 0, n_ctx=64)
+        w.load_desc(d)
+        w.finalize(max_tokens=ubatch, n_seq=n_seq)
+        ring = CRing(rank, world, transport="torch")             # the C ring over gloo: both ranks on the one GPU
+        toks = torch.from_numpy(prompts.astype(np.int32)).cuda() if rank == 0 else None
+        rows = torch.zeros((n_seq, d.n_embd), dtype=torch.float32, device="cuda") if rank == 0 else None
+        ring.prefill(w, toks, n_seq, n_prompt, ubatch, rows)     # pipelined prompt pass, [n_tokens][n_embd] per hop
+        torch.cuda.synchronize()
+        out = {}
+        if rank == 0:
+            out["rows"] = rows.cpu().numpy()
+            first = []
+            lg = torch.empty(d.n_vocab, dtype=torch.float32, device="cuda")
+            am = torch.empty(1, dtype=torch.int32, device="cuda")
+            for s in range(n_seq):
+                w.head(rows[s], logits=lg, argmax=am)
+                torch.cuda.synchronize()
+                first.append(int(am.item()))
+            out["first"] = first
+        # ONE sequence in flight (the reference's mode): sequence 0, n_single tokens once round the ring each
+        tok = torch.tensor([out["first"][0]], dtype=torch.int32, device="cuda") if rank == 0 else None
+        gen = []
+        for _ in range(n_single):
+            ring.single_token(w, 0, tok)
+            if rank == 0:
+                torch.cuda.synchronize()
+                gen.append(int(tok.item()))
+        ring.wait()
+        torch.cuda.synchronize()
+        if rank == 0:
+            out["single"] = gen
+            q.put(out)
+        ring.close()
+        w.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c_ring_pipelined_prefill_and_single_stream_two_ranks():
+    """pm355_ring_prefill (ubatch-wide hand-off [n_tokens][n_embd], chunk g on rank r at pipeline step g + r, the last rank returns each
+    prompt's last row to rank 0) and pm355_ring_single_token (one sequence in flight, the reference's mode) - the C schedule on two ranks
+    sharing the test GPU over gloo (transport callbacks) - against ONE full-model window fed the same chunks."""
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    sys.path.insert(0, ROOT)
+    from _bind import tiny_model
+    import prima_cpp_amd.engine as E
+    world, ubatch, n_single = 2, 4, 5
+    prompts = np.random.default_rng(9).integers(0, 320, (2, 11))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c, args=(r, world, port, prompts, ubatch, n_single, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    d = tiny_model(np.random.default_rng(61), arch=0, n_layer=4, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=320, n_ctx=64, rope_freqs=True)
+    for s in range(prompts.shape[0]):
+        w = E.Window(_hp(d), n_ctx=64)
+        w.load_desc(d)
+        w.finalize(max_tokens=ubatch)
+        hid = None
+        for c0 in range(0, prompts.shape[1], ubatch):
+            chunk = torch.from_numpy(prompts[s, c0:c0 + ubatch].astype(np.int32)).cuda()
+            hid, lg, _ = w.decode(tokens=chunk, pos0=c0)
+        torch.cuda.synchronize()
+        assert np.array_equal(hid[-1].cpu().numpy(), got["rows"][s]), s          # same kernels, same order: bit-identical
+        first = int(np.argmax(lg.cpu().numpy()))
+        assert first == got["first"][s]
+        if s == 0:
+            io = torch.zeros(n_single + 1, dtype=torch.int32, device="cuda")
+            io[0] = first
+            w.generate(io, prompts.shape[1], n_single, use_graph=True)
+            torch.cuda.synchronize()
+            assert got["single"] == io.cpu().numpy()[1:].tolist(), (got["single"], io.cpu().numpy())
+        w.close()
+
+
+def test_bench_two_ranks_on_one_gpu_end_to_end():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), with PM355_DIST_BACKEND=gloo so
+    that both ranks can share the one test GPU: window partition, the C ring (pipelined prompt pass with [n_tokens][n_embd] hand-offs,
+    staggered multi-sequence decode, single-sequence loop) and the JSON contract. The first real multi-GPU RCCL run is then not the first
+    run of this code."""
+    import json
+    import subprocess
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    env = dict(os.environ, PM355_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "llama3-8b", "--steps", "4", "--warmup", "2",
+           "--no-extras", "--no-cpu-baseline", "--prefill", "0", "--n-ctx", "2048"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["metric"] == "decode_tokens_per_s" and d["value"] > 0 and d["scaling"] == "weak"
+    assert "pp2" in d["config"]["parallelism"] and "ring in C" in d["config"]["parallelism"]
+    assert d["single_stream"]["tokens_per_s"] > 0 and d["ring_prefill"]["tokens_per_s"] > 0 and d["ring_prefill"]["ubatch"] == 512
+    print(f"\n[bench --gpus 2, gloo, one GPU] aggregate {d['value']:.1f} tok/s, single stream {d['single_stream']['tokens_per_s']:.1f} tok/s, "
+          f"ring prompt pass {d['ring_prefill']['tokens_per_s']:.0f} tok/s")

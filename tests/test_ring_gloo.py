@@ -138,3 +138,29 @@ def test_partition_layers_balances_bytes():
     loads = [sum(lb[lo:hi]) + (862 if i == 0 else 0) for i, (lo, hi) in enumerate(wins)]
     assert max(loads) <= 11 * 513          # 80 layers + head over 8 ranks: nobody gets more than 11 layers' worth
     assert partition_layers([1, 1, 1], 0, 3) == [(0, 1), (1, 2), (2, 3)]
+
+
+def test_pipelined_prompt_schedule_every_send_meets_its_receive():
+    """The prompt pipeline of pm355_ring_prefill (mirrored by ring.prefill_schedule): in every step the number of rows a rank sends equals
+    what its successor receives, every chunk visits the ranks in order one step apart, and rank 0 collects exactly one row per prompt."""
+    from prima_cpp_amd.ring import prefill_schedule
+    for world in (1, 2, 3, 8):
+        for n_seq, n_prompt, ubatch in ((1, 5, 512), (2, 11, 4), (3, 2048, 512), (8, 16, 16), (2, 1000, 512)):
+            sch = [prefill_schedule(r, world, n_seq, n_prompt, ubatch) for r in range(world)]
+            steps = len(sch[0])
+            assert all(len(x) == steps for x in sch)
+            C = (n_prompt + ubatch - 1) // ubatch
+            for s in range(steps):
+                for r in range(world):
+                    g, T, snd, rcv = sch[r][s]
+                    nxt = (r + 1) % world
+                    if world > 1:
+                        assert snd == sch[nxt][s][3], (world, n_seq, n_prompt, ubatch, s, r)      # same step, same size
+                    if g is not None:
+                        assert s == g + r and T == (n_prompt - (g % C) * ubatch if g % C == C - 1 else ubatch)
+            for r in range(world):
+                done = [g for g, *_ in sch[r] if g is not None]
+                assert done == list(range(n_seq * C))                                              # every chunk, in order, once
+            if world > 1:
+                assert sum(x[3] for x in sch[0]) == n_seq                                            # one returned row per prompt
+                assert sum(x[1] for x in sch[1]) == n_seq * n_prompt
