@@ -128,18 +128,30 @@ def cpu_baseline(hp, mixture, seconds):
                       "attention excluded, which favours the CPU)"}
 
 
+def kernel_source_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "prima_cpp_amd", "csrc")
+    for f in ("mmvq.hip", "mmvq_device.h", "pm355_device.h"):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(bytes_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r02_pmc_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE on tools/pmc_probe.py, x1024 B and the gfx950 x2 correction of MI355X_MICROARCH.md).
-    Counters cannot be read from inside the timed process, so this is the recorded measurement for the same kernel and
-    shape; None when the workload's launch does not match the recorded one."""
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass of this round (profiles/rNN_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on tools/pmc_probe.py in separate passes, x1024 B and the gfx950 x2 correction of
+    MI355X_MICROARCH.md; tools/collect_profiles.sh). Counters cannot be read from inside the timed process, so this is the recorded
+    measurement - accepted only when it was taken on the SAME kernel sources (sha of mmvq.hip / mmvq_device.h / pm355_device.h recorded
+    next to it) and the same launch shape; otherwise None (re-run tools/collect_profiles.sh)."""
     try:
         prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        name = "r02_pmc_traffic.json" if os.path.exists(os.path.join(prof, "r02_pmc_traffic.json")) else "r01_c_pmc_traffic.json"
-        with open(os.path.join(prof, name)) as f:
-            t = json.load(f)
-        if int(t["algorithmic_bytes_per_launch"]) == int(bytes_per_launch):
-            return int(t["hbm_read_bytes_per_launch"]) + int(t["hbm_write_bytes_per_launch_uncalibrated"])
+        names = sorted((n for n in os.listdir(prof) if n.endswith("_pmc_traffic.json")), reverse=True)
+        for name in names:
+            with open(os.path.join(prof, name)) as f:
+                t = json.load(f)
+            if t.get("kernel_source_sha16") == kernel_source_sha16() and int(t["algorithmic_bytes_per_launch"]) == int(bytes_per_launch):
+                return int(t["hbm_read_bytes_per_launch"]) + int(t["hbm_write_bytes_per_launch_uncalibrated"])
     except Exception:
         pass
     return None
@@ -428,6 +440,38 @@ def plugin_decode(tmp, n_gen=64, prompt_len=16):
     return out, path
 
 
+def plugin_decode_70b(tmp, hp70, engine_ms_per_token, n_gen=48):
+    """The HEADLINE shape through the drop-in boundary: Llama-3-70B-shaped Q4_K_M GGUFs of 8 and 16 layers decoded by the reference's
+    llama_decode + the MI355 plug-in (-ngl 99 --keep-out-in-cuda); per-layer and fixed cost from the two depths, the 80-layer token
+    time they imply, and that against the resident engine's measured token (what the scheduler path costs at this shape)."""
+    from prima_cpp_amd import gguf as G
+    B, drv = _driver()
+    if drv is None:
+        return None
+    prompt = np.random.default_rng(1234).integers(0, 128256, 16)
+    prompt[0] = 128000
+    ms = {}
+    for L in (8, 16):
+        p = os.path.join(tmp, f"pm355_bench_llama3_70b_shape_{L}l.gguf")
+        G.write_synthetic_model(p, arch=0, n_layer=L, n_embd=hp70["n_embd"], n_head=hp70["n_head"], n_head_kv=hp70["n_head_kv"],
+                                n_ff=hp70["n_ff"], n_vocab=hp70["n_vocab"], is_70b=True)
+        _, _, st = B.run_llama_driver(p, prompt, n_gen, ngl=99, n_ctx=4096, threads=usable_cores(), extra_args=["--keep-out-in-cuda"], timeout=300)
+        ms[L] = (st["decode_ms_avg"], st["decode_ms_min"])
+        os.unlink(p)
+    per_layer = (ms[16][0] - ms[8][0]) / 8.0
+    fixed = ms[8][0] - 8 * per_layer
+    tok_ms = fixed + hp70["n_layer"] * per_layer
+    out = {"workload": "Llama-3-70B-shaped Q4_K_M GGUFs of 8 and 16 layers (random valid blocks, no_vocab) through the reference's llama_decode + MI355 "
+                       f"plug-in: -ngl 99 --keep-out-in-cuda, 16-token prompt, {n_gen} greedy tokens, n_ctx 4096",
+           "ms_per_token_at_depth": {"8": round(ms[8][0], 4), "16": round(ms[16][0], 4)}, "best_ms_per_token_at_depth": {"8": round(ms[8][1], 4), "16": round(ms[16][1], 4)},
+           "ms_per_layer": round(per_layer, 4), "ms_fixed": round(fixed, 4), "ms_per_token_80_layers": round(tok_ms, 4), "tokens_per_s_80_layers": round(1e3 / tok_ms, 2),
+           "timing": "wall clock around llama_decode + llama_synchronize per token, first 5 tokens dropped"}
+    if engine_ms_per_token:
+        out["engine_ms_per_token"] = round(engine_ms_per_token, 4)
+        out["frac_of_engine"] = round(engine_ms_per_token / tok_ms, 4)
+    return out
+
+
 def cpu_llama_decode(tmp, path_8b, hp70):
     """The reference's own llama_decode on this host's cores (-ngl 0): (a) the 8B-shaped GGUF of plugin_decode, (b) the metric's
     model shape (Llama-3-70B Q4_K_M) at two reduced depths so that a whole-token time for 80 layers follows from the measured
@@ -438,25 +482,28 @@ def cpu_llama_decode(tmp, path_8b, hp70):
         return None
     cores = usable_cores()
     out = {"cores": cores, "kind": "reference", "binary": os.path.basename(drv),
-           "timing": "wall clock around llama_decode per token (-ngl 0), first tokens dropped"}
+           "timing": "llama_perf_context (t_eval_ms / n_eval) of llama_decode at -ngl 0"}
     prompt = np.random.default_rng(1234).integers(0, 128256, 16)
     if path_8b and os.path.exists(path_8b):
         _, _, st = B.run_llama_driver(path_8b, prompt, 12, ngl=0, n_ctx=512, threads=cores, timeout=240)
         out["llama3_8b_q4km"] = {"tokens_per_s": round(st["decode_tok_s"], 3), "prompt_tokens_per_s": round(st["prompt_tok_s"], 2)}
-    ms = {}
-    for L in (2, 6):
+    # llama_perf_context (src/llama.cpp:23832-23851: t_eval_ms / n_eval of the single-token evals) on three depths; least-squares line
+    depths, ms = (2, 6, 12), {}
+    for L in depths:
         p = os.path.join(tmp, f"pm355_bench_llama3_70b_shape_{L}l.gguf")
         G.write_synthetic_model(p, arch=0, n_layer=L, n_embd=hp70["n_embd"], n_head=hp70["n_head"], n_head_kv=hp70["n_head_kv"],
                                 n_ff=hp70["n_ff"], n_vocab=hp70["n_vocab"], is_70b=True)
-        _, _, st = B.run_llama_driver(p, prompt, 10, ngl=0, n_ctx=512, threads=cores, timeout=240)
-        ms[L] = st["decode_ms_avg"]
+        _, _, st = B.run_llama_driver(p, prompt, 10, ngl=0, n_ctx=512, threads=cores, timeout=300)
+        ms[L] = st["perf_t_eval_ms"] / max(st["perf_n_eval"], 1) if st.get("perf_n_eval") else st["decode_ms_avg"]
         os.unlink(p)
-    per_layer = (ms[6] - ms[2]) / 4.0
-    fixed = ms[2] - 2 * per_layer
+    xs, ys = np.array(depths, dtype=np.float64), np.array([ms[L] for L in depths])
+    per_layer, fixed = np.polyfit(xs, ys, 1)
+    resid = float(np.abs(ys - (fixed + per_layer * xs)).max() / ys.max())
     tok_ms = fixed + hp70["n_layer"] * per_layer
-    out["llama3_70b_q4km"] = {"tokens_per_s": round(1e3 / tok_ms, 3), "ms_per_layer": round(per_layer, 3), "ms_fixed": round(fixed, 3),
-                              "method": f"llama_decode timed on 70B-shaped GGUFs of 2 and 6 layers ({ms[2]:.1f} / {ms[6]:.1f} ms per token); "
-                                        f"token time for {hp70['n_layer']} layers = fixed + n_layer * per-layer (layers alternate the Q4_K_M type mixture with period 2)"}
+    out["llama3_70b_q4km"] = {"tokens_per_s": round(1e3 / tok_ms, 3), "ms_per_layer": round(float(per_layer), 3), "ms_fixed": round(float(fixed), 3),
+                              "fit_max_residual_rel": round(resid, 4), "ms_per_token_at_depth": {str(L): round(ms[L], 2) for L in depths},
+                              "method": "llama_perf_context t_eval / n_eval of the reference's llama_decode on 70B-shaped GGUFs of 2, 6 and 12 layers; "
+                                        f"least-squares line, token time for {hp70['n_layer']} layers = fixed + n_layer * per-layer (layers alternate the Q4_K_M type mixture with period 2)"}
     return out
 
 
@@ -689,6 +736,13 @@ def main():
                     result["plugin_decode_tokens_per_s"] = pd["tokens_per_s"]
             except Exception as e:
                 result["plugin_decode"] = {"error": str(e)[-600:]}
+            try:
+                import prima_cpp_amd.engine as E3
+                p70 = plugin_decode_70b(a.tmp, E3.LLAMA3_70B, result["ms_per_step"] if a.model == "llama3-70b" else None)
+                if p70:
+                    result["plugin_decode_70b"] = p70
+            except Exception as e:
+                result["plugin_decode_70b"] = {"error": str(e)[-600:]}
             if not a.no_cpu_baseline:
                 try:
                     import prima_cpp_amd.engine as E2
@@ -700,7 +754,7 @@ def main():
                             result["cpu_baseline"]["matvec_only_tokens_per_s"] = result["cpu_baseline"]["value"]
                             result["cpu_baseline"]["value"] = ld["llama3_70b_q4km"]["tokens_per_s"]
                             result["cpu_baseline"]["sample"] = ("reference llama_decode (-ngl 0, unmodified libllama + ggml CPU backend built from /root/reference, "
-                                                                f"{ld['cores']} threads) on Llama-3-70B-shaped Q4_K_M GGUFs of 2 and 6 layers, extrapolated to 80 layers "
+                                                                f"{ld['cores']} threads, llama_perf_context timing) on Llama-3-70B-shaped Q4_K_M GGUFs of 2, 6 and 12 layers, least-squares line to 80 layers "
                                                                 "(see llama_decode.llama3_70b_q4km.method); matvec_only_tokens_per_s = " + result["cpu_baseline"]["sample"])
                 except Exception as e:
                     if "cpu_baseline" in result:

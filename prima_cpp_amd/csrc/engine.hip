@@ -60,7 +60,7 @@ struct pm355_model {
     std::vector<Slot> slots;
     hipStream_t copy_stream = nullptr;
     size_t slot_bytes[12] = {};
-    uint64_t streamed_bytes = 0;
+    uint64_t streamed_bytes = 0, stream_step = 0;
     // long-context decode attention (attn_split.hip): the host mirrors the device position counters to choose, per step, between
     // the fused one-workgroup-per-head kernel and the keys-split-over-workgroups path (different launch sequences = different
     // captured graphs). PM355_ATTN_SPLIT_MIN positions (default 640: measured crossover on the 70B head shape).
@@ -202,9 +202,9 @@ namespace {
 
 // ---- window streaming ------------------------------------------------------------------------------------------------------------
 // enqueue the H2D copies of layer `il` into its slot on the copy stream (after the slot was released by its previous user)
-void stream_prefetch(pm355_model * m, int il) {
+void stream_prefetch(pm355_model * m, int il, int slot) {
     const int n = m->hi - m->lo;
-    Slot & S = m->slots[(il - m->lo) % m->n_slots];
+    Slot & S = m->slots[slot];
     Layer & L = m->layers[il - m->lo];
     (void) hipStreamWaitEvent(m->copy_stream, S.free_, 0);
     for (int k = 0; k < 12; ++k) if (L.host[k]) {
@@ -219,8 +219,11 @@ void stream_prefetch(pm355_model * m, int il) {
 Layer layer_acquire(pm355_model * m, int il, hipStream_t st) {
     Layer L = m->layers[il - m->lo];
     if (!m->n_slots) return L;
-    Slot & S = m->slots[(il - m->lo) % m->n_slots];
-    if (S.layer != il) stream_prefetch(m, il);                          // (only after an interrupted pass; normally already in flight)
+    // slots are dealt out by a running step counter, not by layer index: with n % n_slots != 0 a layer-indexed slot made the layer
+    // that wraps round to the next token land on a slot that still held an unconsumed prefetched layer (redundant, un-overlapped copies)
+    const int slot = (int) (m->stream_step % (uint64_t) m->n_slots);
+    Slot & S = m->slots[slot];
+    if (S.layer != il) stream_prefetch(m, il, slot);                    // (only after an interrupted pass; normally already in flight)
     (void) hipStreamWaitEvent(st, S.ready, 0);
     for (int k = 0; k < 12; ++k) if (L.host[k]) L.t[k].d = S.d[k];
     return L;
@@ -230,9 +233,12 @@ Layer layer_acquire(pm355_model * m, int il, hipStream_t st) {
 void layer_release(pm355_model * m, int il, hipStream_t st) {
     if (!m->n_slots) return;
     const int n = m->hi - m->lo;
-    Slot & S = m->slots[(il - m->lo) % m->n_slots];
+    const int slot = (int) (m->stream_step % (uint64_t) m->n_slots);
+    Slot & S = m->slots[slot];
     (void) hipEventRecord(S.free_, st);
-    if (n > m->n_slots) stream_prefetch(m, m->lo + (il - m->lo + m->n_slots) % n);
+    // the layer that is executed n_slots steps from now takes the slot that has just been released
+    if (n > m->n_slots) stream_prefetch(m, m->lo + (il - m->lo + m->n_slots) % n, slot);
+    ++m->stream_step;
 }
 
 // quantize `src` [T][K] into the activation format(s) the given weights need; returns pointers
@@ -715,7 +721,8 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
             (void) hipEventRecord(S.free_, nullptr);
         }
         (void) hipDeviceSynchronize();
-        for (int i = 0; i < m->n_slots; ++i) stream_prefetch(m, m->lo + i);
+        for (int i = 0; i < m->n_slots; ++i) stream_prefetch(m, m->lo + i, i);
+        m->stream_step = 0;
     }
     m->h_pos.assign(n_seq, 0); m->h_seq = 0;
     { const char * e = getenv("PM355_ATTN_SPLIT_MIN"); if (e && e[0]) m->split_min = atoi(e); }

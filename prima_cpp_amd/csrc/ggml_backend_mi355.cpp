@@ -103,7 +103,7 @@ void * buf_stage(buf_ctx * c, size_t n) {
 }
 // one lowered graph the backend has seen: its per-token fingerprint, its launch plan and (after a warm-up run) the captured hipGraph
 struct graph_entry {
-    std::vector<mi355::graph_fp_node> fp;
+    mi355::graph_fp fp;
     mi355::plan plan;
     pm355_graph_t exec = nullptr;
     int runs = 0;
@@ -120,7 +120,7 @@ struct backend_ctx {
     float * qkv = nullptr; size_t qkv_floats = 0;    // raw q / k / v projections of one token
     float * split = nullptr; size_t split_floats = 0;
     std::vector<graph_entry *> graphs;
-    std::vector<mi355::graph_fp_node> fp_tmp;
+    mi355::graph_fp fp_tmp;
     uint64_t tick = 0;
     bool fuse = true, use_graphs = true, debug_plan = false;
     int split_min = 640;

@@ -114,34 +114,34 @@ inline void fill_tensor_fp(tensor_fp & f, const ggml_tensor * t) {
 
 // ---- per-token fingerprint of a graph: equal fingerprints => equal plans (view offsets into F16 leaf tensors = the KV cell views
 //      are left out on purpose: they are the per-token `dyn` values) ----------------------------------------------------------
-struct graph_fp_node { int32_t op, type, flags; uint32_t params; const void * base; int64_t ne[4]; size_t nb[4]; const void * src[3]; };
+// The fingerprint is a 128-bit hash + the node count (round 3; it used to be one 112-byte record per node, filled and memcmp'ed on every
+// graph_compute: 40-50 us of host time for the 1056-node split of an 8B model - a 16-byte compare now, ~10 us to hash).
+struct graph_fp { uint64_t h0 = 0, h1 = 0; int32_t n = -1; };
 
 inline const void * fp_base(const ggml_tensor * t) {
     const ggml_tensor * r = t->view_src;           // F16 leaf, or a 1-D Q8_0 leaf (quantized KV cache)
     if (r && (r->type == GGML_TYPE_F16 || (r->type == GGML_TYPE_Q8_0 && r->ne[1] == 1)) && r->op == GGML_OP_NONE && !r->view_src) return r->data;
     return t->data;
 }
-inline void graph_fingerprint(struct ggml_cgraph * g, std::vector<graph_fp_node> & out) {
+inline void graph_fingerprint(struct ggml_cgraph * g, graph_fp & out) {
     const int n = ggml_graph_n_nodes(g);
-    out.resize(n);
+    uint64_t a = 0x9E3779B97F4A7C15ULL, b = 0xC2B2AE3D27D4EB4FULL;
+    auto mix = [&](uint64_t v) { a = (a ^ v) * 0xff51afd7ed558ccdULL; a ^= a >> 32; b = (b + v) * 0xc4ceb9fe1a85ec53ULL; b ^= b >> 29; };
     for (int i = 0; i < n; ++i) {
         const ggml_tensor * t = ggml_graph_node(g, i);
-        graph_fp_node & f = out[i];
-        memset(&f, 0, sizeof(f));
-        f.op = (int32_t) t->op; f.type = (int32_t) t->type; f.flags = t->flags; f.base = fp_base(t);
-        uint32_t h = 2166136261u;
+        const void * base = fp_base(t);
+        mix(((uint64_t) (uint32_t) t->op << 40) ^ ((uint64_t) (uint32_t) t->type << 20) ^ (uint64_t) (uint32_t) t->flags);
+        mix((uint64_t) (uintptr_t) base);
         // (a VIEW keeps its byte offset in op_params, ggml_view_impl ggml.c:6490: for the KV cell views that offset is the per-token value the
-        // fingerprint leaves out - hashing it made every token miss and re-plan the whole split, ~80 us of host time per graph_compute)
-        const bool cell_view = t->op == GGML_OP_VIEW && fp_base(t) != t->data;
-        if (!cell_view) for (int k = 0; k < 16; ++k) { h ^= (uint32_t) t->op_params[k]; h *= 16777619u; }
-        f.params = h;
-        for (int k = 0; k < 4; ++k) { f.ne[k] = t->ne[k]; f.nb[k] = t->nb[k]; }
-        for (int k = 0; k < 3; ++k) f.src[k] = t->src[k] ? fp_base(t->src[k]) : nullptr;
+        // fingerprint leaves out - hashing it made every token miss and re-plan the whole split)
+        const bool cell_view = t->op == GGML_OP_VIEW && base != t->data;
+        if (!cell_view) for (int k = 0; k < 16; k += 2) mix(((uint64_t) (uint32_t) t->op_params[k] << 32) | (uint32_t) t->op_params[k + 1]);
+        for (int k = 0; k < 4; ++k) { mix((uint64_t) t->ne[k]); mix((uint64_t) t->nb[k]); }
+        for (int k = 0; k < 3; ++k) mix(t->src[k] ? (uint64_t) (uintptr_t) fp_base(t->src[k]) : 0);
     }
+    out.h0 = a; out.h1 = b; out.n = n;
 }
-inline bool fingerprint_equal(const std::vector<graph_fp_node> & a, const std::vector<graph_fp_node> & b) {
-    return a.size() == b.size() && (a.empty() || memcmp(a.data(), b.data(), a.size() * sizeof(graph_fp_node)) == 0);
-}
+inline bool fingerprint_equal(const graph_fp & a, const graph_fp & b) { return a.n == b.n && a.h0 == b.h0 && a.h1 == b.h1; }
 
 // ---- the planner -------------------------------------------------------------------------------------------------------------
 class planner {

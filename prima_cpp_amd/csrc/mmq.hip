@@ -566,8 +566,7 @@ int pm_launch_gemm_q_h(int type, const void * W, const float * X, const void * x
         const dim3 grid2((n + BM2 - 1) / BM2, (T + BN2 - 1) / BN2);
         const size_t lds2 = (size_t) 2 * (BM2 + BN2) * LDS_STRIDE * sizeof(_Float16);
         auto go2 = [&](auto kern) {
-            static bool attr[16] = {};                // per instantiation AND per device
-            if (!attr[dev]) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds2); attr[dev] = true; }
+            pm_allow_big_lds((const void *) kern, lds2 > 48 * 1024 ? lds2 : 48 * 1024 + 1);
             hipLaunchKernelGGL(kern, grid2, dim3(512), lds2, st, p);
         };
         switch (type) {
@@ -582,8 +581,7 @@ int pm_launch_gemm_q_h(int type, const void * W, const float * X, const void * x
         const dim3 grid((n + BM - 1) / BM, (T + BN - 1) / BN);
         const size_t lds = (size_t) 2 * (BM + BN) * LDS_STRIDE * sizeof(_Float16);
         auto go = [&](auto kern) {
-            static bool attr[16] = {};                // per instantiation AND per device
-            if (!attr[dev]) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr[dev] = true; }
+            pm_allow_big_lds((const void *) kern, lds > 48 * 1024 ? lds : 48 * 1024 + 1);
             hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p);
         };
         switch (type) {

@@ -544,8 +544,7 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
         p.y = Y + (size_t) t0 * N; p.y_stride = N; p.bias = bias; p.resid = resid ? resid + (size_t) t0 * N : nullptr;
         p.rgb_log2 = nrg >= 8 ? 3 : nrg >= 3 ? 2 : nrg == 2 ? 1 : 0;
         auto go = [&](auto kern) {
-            static bool attr[16] = {};
-            if (!attr[dev]) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr[dev] = true; }
+            pm_allow_big_lds((const void *) kern, 150 * 1024);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, st, p);
         };
 #ifdef PM_MMQ_ABLATE      // measurement build (profiles/r02_small_batch_probe.txt): PM355_MMQ_ABL = 1 no activation loads | 2 no weight loads | 4 no compute
@@ -599,8 +598,7 @@ int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const in
     p.rgb_log2 = nrg >= 8 ? 3 : nrg >= 3 ? 2 : nrg == 2 ? 1 : 0;
     const size_t lds = pm_mmq_i8_lds_bytes(type, K);
     auto go = [&](auto kern) {
-        static bool attr[16] = {};
-        if (!attr[dev]) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr[dev] = true; }
+        pm_allow_big_lds((const void *) kern, 150 * 1024);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, st, p);
     };
     if (type == PM_Q4_K) { if (T <= 8) go(mmq_i8_kernel<PM_Q4_K, 4, 0, true>); else go(mmq_i8_kernel<PM_Q4_K, 8, 0, true>); }

@@ -42,9 +42,7 @@ template <int TA, int TB>
 int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, hipStream_t st, bool epi = false) {
     const GemvP & p = p_in;
     auto go = [&](auto kern) {
-        static bool attr_set[16] = {};                // one flag per instantiation (lambda is instantiated per kern type) and device
-        const int dv = lds > 48 * 1024 ? pm_cur_dev() : 0;
-        if (lds > 48 * 1024 && !attr_set[dv]) { (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set[dv] = true; }
+        pm_allow_big_lds((const void *) kern, lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(PM_GEMV_BLOCK), lds, st, p);
     };
     if (pair) {

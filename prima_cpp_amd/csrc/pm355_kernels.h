@@ -8,6 +8,19 @@
 // through the plug-in: hipFuncSetAttribute and the CU count are per device, not per process)
 static inline int pm_cur_dev() { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 16) ? d : 0; }
 
+// one-time hipFuncSetAttribute(MaxDynamicSharedMemorySize) per (kernel, device). Keyed on the kernel POINTER: a `static bool` inside a generic
+// lambda is shared by every instantiation that decays to the same function-pointer type, so only the first kernel launched would get it.
+static inline void pm_allow_big_lds(const void * kern, size_t lds) {
+    if (lds <= 48 * 1024) return;
+    struct E { const void * k; int dev; };
+    static E done[256]; static int n_done = 0;
+    static hipError_t (*set)(const void *, hipFuncAttribute, int) = hipFuncSetAttribute;
+    const int dev = pm_cur_dev();
+    for (int i = 0; i < n_done && i < 256; ++i) if (done[i].k == kern && done[i].dev == dev) return;
+    (void) set(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);       // (idempotent: a lost race sets it twice)
+    if (n_done < 256) { done[n_done].k = kern; done[n_done].dev = dev; ++n_done; }
+}
+
 // bytes of one quantized ACTIVATION row in the library's internal row-SoA layout (quantize.hip)
 static inline size_t pm_q8k_row_bytes(int K) { return (size_t) K + (size_t) (K / 256) * 4 + (size_t) (K / 16) * 2; }
 static inline size_t pm_q80_row_bytes(int K) { return (size_t) K + (size_t) (K / 32) * 2; }

@@ -3,7 +3,7 @@
 # repo root:  bash tools/collect_profiles.sh r02
 # kernel-trace / stats passes and PMC passes are SEPARATE runs (never --pmc together with trace domains other than --kernel-trace).
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=$PWD/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -20,7 +20,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cp $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) $OUT/${R}_pmc_$c.csv
 done
 python - <<PY
-import csv, json
+import csv, hashlib, json
+def src_hash():       # the kernel this measurement belongs to: bench.py refuses the file once these sources change
+    h = hashlib.sha256()
+    for f in ("mmvq.hip", "mmvq_device.h", "pm355_device.h"):
+        h.update(open("$OLDPWD/prima_cpp_amd/csrc/" + f, "rb").read())
+    return h.hexdigest()[:16]
 def vals(path):
     return [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if "gemv_q_kernel" in r["Kernel_Name"]]
 f, w = vals("$OUT/${R}_pmc_FETCH_SIZE.csv"), vals("$OUT/${R}_pmc_WRITE_SIZE.csv")
@@ -31,7 +36,7 @@ json.dump({"source": "rocprofv3 --pmc <counter> --kernel-trace --output-format c
            "kernel": "gemv_q_kernel<12,12,true> Q4_K gate/up pair, K=8192, N=28672 (Llama-3-70B ffn), row-SoA layout",
            "algorithmic_bytes_per_launch": alg, "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
            "hbm_read_bytes_per_launch": int(fr), "hbm_write_bytes_per_launch_uncalibrated": int(wr),
-           "traffic_over_algorithmic": fr / alg}, open("$OUT/${R}_pmc_traffic.json", "w"), indent=1)
+           "traffic_over_algorithmic": fr / alg, "kernel_source_sha16": src_hash()}, open("$OUT/${R}_pmc_traffic.json", "w"), indent=1)
 print("traffic/algorithmic", fr / alg)
 PY
 # (3) prefill GEMM: achieved TFLOP/s + MFMA / VALU / LDS utilisation counters, one pass per counter
