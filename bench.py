@@ -361,10 +361,11 @@ def extra_config(name, steps=32, warmup=8, prompt=16, n_ctx=4096):
     dt = time.perf_counter() - t0
     drv.flush()
     torch.cuda.synchronize()
+    finite = bool(torch.isfinite(drv.c.x_out[drv.c.k]).all().item())
     win.close()
     roof = HBM_PEAK_GBS * 1e9 / total_w
     return {"workload": f"{model_name} batch-1 greedy decode, {prompt}-token synthetic prompt, n_ctx {n_ctx}, F16 KV cache, 1 GPU",
-            "tokens_per_s": round(steps / dt, 2), "ms_per_token": round(dt / steps * 1e3, 4), "weights_bytes_per_token": total_w,
+            "tokens_per_s": round(steps / dt, 2), "ms_per_token": round(dt / steps * 1e3, 4), "weights_bytes_per_token": total_w, "activations_finite": finite,
             "hbm_roofline_tokens_per_s": round(roof, 1), "frac_of_hbm_roofline": round(steps / dt / roof, 4)}
 
 
@@ -629,6 +630,9 @@ def main():
             dt = float(t.item())
         drv.flush()
         sync()
+        # sanity of the synthetic workload: the activations the timed steps produced are finite (a fill that leaves NaNs behind times the
+        # same kernels but is not a model)
+        finite = bool(torch.isfinite(comp.x_out[comp.k]).all().item())
 
         # The reference's own mode next to the aggregate: ONE sequence in flight, every token once round the ring with the other ranks idle
         # (rank 0 blocked in recv until it returns, src/llama.cpp:18509) - what exposes the hop latency. And the pipelined prompt pass.
@@ -680,7 +684,7 @@ def main():
                            "parallelism": "single GPU" if world == 1 else f"piped-ring layer split pp{world} "
                                           f"(windows {wins}), ring in C (pm355_ring_*), transport {'RCCL send/recv: comm stream + events, no host wait' if ring_transport == 'rccl' else 'torch.distributed ' + dist.get_backend() + ' through the transport callbacks'}",
                            "weights_bytes_per_token": total_w, "kv_bytes_per_token_mid_run": kv_b,
-                           "hip_graph": use_graph},
+                           "hip_graph": use_graph, "activations_finite": finite},
                 "hbm_roofline_tokens_per_s": round(HBM_PEAK_GBS * 1e9 / total_w * world, 2),
                 "frac_of_hbm_roofline_weights_only": round(value * total_w / world / (HBM_PEAK_GBS * 1e9), 4),
                 "frac_of_hbm_roofline_weights_plus_kv": round(value * (total_w + kv_b) / world / (HBM_PEAK_GBS * 1e9), 4),

@@ -182,7 +182,10 @@ __global__ void fill_random_f16_kernel(uint16_t * dst, long n, uint64_t seed, fl
 }
 
 void pm_launch_fill_random_blocks(int type, void * dst, int64_t K, int64_t nrows, uint64_t seed, float scale, hipStream_t st) {
-    const size_t rb = pm_weight_row_bytes(type, K);
+    // rows in the HBM layout: the row STRIDE (== ggml_row_size except where the trailing fp16 stream of a row-SoA layout is padded to 16 bytes,
+    // e.g. Q8_0 at K = 29568). Filling with the unpadded row size put every scale of such a matrix in the wrong place (NaN activations in the
+    // synthetic Qwen2.5-72B model of rounds 1-2: its timing was unaffected, its values were garbage).
+    const size_t rb = (type == PM_F32 || type == PM_F16) ? pm_weight_row_bytes(type, K) : pm_weight_row_stride(type, K);
     const long n = (long) (rb * nrows);
     if (type == PM_F32) { hipLaunchKernelGGL(fill_random_f32_kernel, dim3((unsigned) ((n / 4 + 255) / 256)), dim3(256), 0, st, (float *) dst, n / 4, seed, 0.0f, scale); return; }
     if (type == PM_F16) { hipLaunchKernelGGL(fill_random_f16_kernel, dim3((unsigned) ((n / 2 + 255) / 256)), dim3(256), 0, st, (uint16_t *) dst, n / 2, seed, scale); return; }

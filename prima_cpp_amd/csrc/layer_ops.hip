@@ -268,7 +268,9 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float * x, int n, in
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 16; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-        *out_idx = idx;
+        // nothing compared greater than -inf (every logit NaN or -inf): index 0, like llama_sampler_greedy's loop that starts from entry 0
+        // (src/llama-sampling.cpp:390-397) - never an out-of-range id that the next step would use as an embedding row
+        *out_idx = (idx < 0 || idx >= n) ? 0 : idx;
         if (out_val) *out_val = best;
     }
 }

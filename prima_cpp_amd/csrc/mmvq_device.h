@@ -189,6 +189,10 @@ struct XLds { const int8_t * q; const int * gs; const float * d; int col_bytes; 
 // wave min, result in every lane (lanes that receive nothing from a DPP step keep their own value)
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ int dpp_keep_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_keepf(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ int wave_min_keep(int v) {
     v = min(v, dpp_keep_i<0xB1>(v)); v = min(v, dpp_keep_i<0x4E>(v)); v = min(v, dpp_keep_i<0x141>(v)); v = min(v, dpp_keep_i<0x140>(v));
     v = min(v, dpp_keep_i<0x142, 0xA>(v)); v = min(v, dpp_keep_i<0x143, 0xC>(v));
@@ -224,31 +228,48 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // wave instruction stream: every workgroup quantizes the whole activation row redundantly, so the per-block instruction
 // count (not bytes) is what the prologue costs - 16 lanes x 16 values needs 4 DPP steps per reduction and a quarter of
 // the instructions of the one-block-per-wave form.
+__device__ __forceinline__ float row16_min_f(float v) {
+    v = fminf(v, dpp_keepf<0xB1>(v)); v = fminf(v, dpp_keepf<0x4E>(v)); v = fminf(v, dpp_keepf<0x141>(v)); v = fminf(v, dpp_keepf<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float row16_max_f(float v) {
+    v = fmaxf(v, dpp_keepf<0xB1>(v)); v = fmaxf(v, dpp_keepf<0x4E>(v)); v = fmaxf(v, dpp_keepf<0x141>(v)); v = fmaxf(v, dpp_keepf<0x140>(v));
+    return v;
+}
+// Every workgroup repeats this for the whole activation row, on every CU: its VALU instruction count is wall time (seam anatomy: ~1.5 us
+// of a 4.5 us prologue at K = 8192, ~3 us at K = 28672). Round 3: signed max / min instead of |x| + an index key per element (the index
+// path only where +a and -a of equal magnitude tie for the maximum), v_rndne + v_cvt for nearest_int, v_perm byte packing, v_dot4 for the
+// 16-value sums: ~11 -> ~7 instructions per value, same bits.
 __device__ __forceinline__ void q8k_rows_to_lds(const float (&v)[4][4], int j, bool valid, int8_t * xs_q, int * xs_gs, float * xs_d, int blk) {
-    float amax = 0.0f;
+    float mx = v[0][0], mn = v[0][0];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fabsf(v[k][i]));
-    amax = row16_max(amax);
-    int key = 0x7fffffff;                            // lowest index with |x| == amax; low bit = its sign
+        for (int i = 0; i < 4; ++i) { mx = fmaxf(mx, v[k][i]); mn = fminf(mn, v[k][i]); }
+    mx = row16_max_f(mx); mn = row16_min_f(mn);
+    const float amax = fmaxf(mx, -mn);
+    bool neg = -mn > mx;                             // the element with the largest |x| (quantize_row_q8_K_ref keeps its SIGNED value) ...
+    if (mx == -mn && amax != 0.0f) {                 // ... and on a tie between +a and -a the FIRST of them: lowest index, low bit = its sign
+        int key = 0x7fffffff;
 #pragma unroll
-    for (int k = 3; k >= 0; --k)
+        for (int k = 3; k >= 0; --k)
 #pragma unroll
-        for (int i = 3; i >= 0; --i)
-            key = fabsf(v[k][i]) == amax ? (((64 * k + 4 * j + i) << 1) | (v[k][i] < 0.0f ? 1 : 0)) : key;
-    key = row16_min(key);
-    const float iscale = amax != 0.0f ? -127.f / ((key & 1) ? -amax : amax) : 0.0f;
+            for (int i = 3; i >= 0; --i)
+                key = fabsf(v[k][i]) == amax ? (((64 * k + 4 * j + i) << 1) | (v[k][i] < 0.0f ? 1 : 0)) : key;
+        key = row16_min(key);
+        neg = key & 1;
+    }
+    const float iscale = amax != 0.0f ? -127.f / (neg ? -amax : amax) : 0.0f;
     uint32_t packed[4]; int psum[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        packed[k] = 0; psum[k] = 0;
+        int q[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int q = nearest_int_rne(iscale * v[k][i]);
-            q = q > 127 ? 127 : q;
-            psum[k] += q; packed[k] |= (uint32_t) (q & 0xFF) << (8 * i);
-        }
+        for (int i = 0; i < 4; ++i) q[i] = (int) fminf(rintf(iscale * v[k][i]), 127.0f);      // nearest_int (RNE, |.| < 2^22), then MIN(127, .)
+        const uint32_t p01 = __builtin_amdgcn_perm((uint32_t) q[1], (uint32_t) q[0], 0x0c0c0400u);
+        const uint32_t p23 = __builtin_amdgcn_perm((uint32_t) q[3], (uint32_t) q[2], 0x0c0c0400u);
+        packed[k] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+        psum[k] = dot4(packed[k], 0x01010101u, 0);
         psum[k] += dpp_i<0xB1>(psum[k]); psum[k] += dpp_i<0x4E>(psum[k]);       // 16 consecutive values = one quad of lanes
     }
     if (valid) {
@@ -640,11 +661,22 @@ __device__ __forceinline__ void write_out(const GemvJob & jb, const float * outb
 // wq | wk | wv epilogue: RoPE on adjacent row pairs, q -> F16-rounded f32 in y, k -> F16 K-cache row of this token's cell, v -> F16 V cache
 // (ggml_compute_forward_rope_f32 NORM mode ggml.c:14224-14237 with the per-token cos / sin table; llm_build_kv_store's CPY F32 -> F16,
 // src/llama.cpp:9688-9716; the F16 rounding of q is the conversion ggml_compute_forward_mul_mat applies to src1 of the K.q product).
-// cs: this thread's (cos, sin), loaded by the caller before the barrier in front of the epilogue.
+// (c, s_): this thread's (cos, sin) of pair `tid`, fetched by qkv_cs() BEFORE the barrier in front of the epilogue (a workgroup's slice
+// holds at most PM_MAX_ROWS_PER_WG / 2 pairs < PM_GEMV_BLOCK: one pair per thread) - loaded after the barrier the table's L2 latency
+// sat in the tail of every workgroup (store phase 1.6 us instead of 0.5).
+__device__ __forceinline__ void qkv_cs(const GemvJob & jb, const QkvEpi & e, int r0, int r1, int tid, float & c, float & s_) {
+    c = 1.0f; s_ = 0.0f;
+    if (jb.role == 1 || jb.role == 2) {
+        const int d = (r0 + 2 * tid) % e.dh;
+        if (2 * tid < r1 - r0 && d < e.n_rot) { c = ld_g(e.tab + d); s_ = ld_g(e.tab + d + 1); }
+    }
+}
 __device__ __forceinline__ void write_out_qkv(const GemvJob & jb, const QkvEpi & e, const float * outbuf, int r0, int r1, int ob, int tid, int cpr,
-                                              int slot, long kv_off) {
+                                              int slot, long kv_off, float c, float s_) {
     const int np = (r1 - r0) >> 1;
-    for (int pr = tid; pr < np; pr += PM_GEMV_BLOCK) {
+    {
+        const int pr = tid;
+        if (pr >= np) return;
         const int row = r0 + 2 * pr;
         float o0 = row_result(jb, outbuf, ob, 2 * pr, cpr), o1 = row_result(jb, outbuf, ob, 2 * pr + 1, cpr);
         if (jb.bias) { o0 += ld_g(jb.bias + row); o1 += ld_g(jb.bias + row + 1); }
@@ -652,11 +684,9 @@ __device__ __forceinline__ void write_out_qkv(const GemvJob & jb, const QkvEpi &
             const uint16_t h0 = f2h(o0), h1 = f2h(o1);
             if (e.v_rowmajor) st_g((uint32_t *) (e.vc + kv_off + (long) slot * e.kv_dim + row), (uint32_t) h0 | ((uint32_t) h1 << 16));
             else { st_g(e.vc + kv_off + (long) row * e.n_ctx + slot, h0); st_g(e.vc + kv_off + (long) (row + 1) * e.n_ctx + slot, h1); }
-            continue;
+            return;
         }
-        const int d = row % e.dh;                                  // even: pair d / 2 of its head
-        if (d < e.n_rot) {
-            const float c = ld_g(e.tab + d), s_ = ld_g(e.tab + d + 1);
+        if (row % e.dh < e.n_rot) {                                // (even row: pair (row % dh) / 2 of its head)
             const float x0 = o0, x1 = o1;
             o0 = x0 * c - x1 * s_; o1 = x0 * s_ + x1 * c;
         }
@@ -758,13 +788,19 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
         }
     }
     tsv[3] = PM_TS_NOW();                              // (wave 0 has finished its rows)
+    float ec0 = 1.0f, es0 = 0.0f, ec1 = 1.0f, es1 = 0.0f, ec2 = 1.0f, es2 = 0.0f;
+    if (EPI && p.epi.tab) {
+        qkv_cs(p.job[0], p.epi, r0_0, r1_0, tid, ec0, es0);
+        qkv_cs(p.job[1], p.epi, r0_1, r1_1, tid, ec1, es1);
+        qkv_cs(p.job[2], p.epi, r0_2, r1_2, tid, ec2, es2);
+    }
     __syncthreads();
     tsv[4] = PM_TS_NOW();                              // (all 16 waves have)
     // (4) coalesced write-out (+bias, +residual)
     if (EPI && p.epi.tab) {
-        write_out_qkv(p.job[0], p.epi, outbuf, r0_0, r1_0, 0, tid, 1, epi_slot, epi_off);
-        write_out_qkv(p.job[1], p.epi, outbuf, r0_1, r1_1, ob_1, tid, cpr_1, epi_slot, epi_off);
-        write_out_qkv(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off);
+        write_out_qkv(p.job[0], p.epi, outbuf, r0_0, r1_0, 0, tid, 1, epi_slot, epi_off, ec0, es0);
+        write_out_qkv(p.job[1], p.epi, outbuf, r0_1, r1_1, ob_1, tid, cpr_1, epi_slot, epi_off, ec1, es1);
+        write_out_qkv(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off, ec2, es2);
     } else {
         write_out<MEGA, NC>(p.job[0], outbuf, r0_0, r1_0, 0, tid, p.y_stride);
         write_out<MEGA, NC>(p.job[1], outbuf, r0_1, r1_1, ob_1, tid, p.y_stride, cpr_1);

@@ -1,0 +1,74 @@
+"""Why a 3-token step through the small-batch mat-mul (mmq_i8.hip) sits at NMSE ~2e-6 against the CPU while the same step through the
+mat-vec sits at ~1e-13 although the two kernels agree to ~1e-7 per element: count the int8 activation roundings
+that tip over between the two paths, stage by stage of a Llama-3-70B-shaped layer.
+
+Both paths compute the SAME integers per super-block; they differ in the order of the f32 multiply-adds over the super-blocks (the mat-vec:
+lanes stride over the row, DPP tree; the small-batch kernel: k split over waves, fixed-order LDS sum). That moves an output by ~1e-7
+relative. The next mat-mul quantizes its input row to int8 with step = max|x| / 127 per 256 values: an input whose value / step lies within
+~1e-7 x (its magnitude / step) of a half-integer rounds the other way, a full step (1/127 of the block's maximum). The census below prints
+how many of the K bytes differ, where the first one sits and how close to the half-integer it was."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gemv_bench import P, Q4_K, rand_weight  # noqa: E402
+from prima_cpp_amd.lib import Q6_K, Q8_K  # noqa: E402
+
+E, F, T = 8192, 28672, 3
+SEEDS = int(os.environ.get("FLIP_SEEDS", "24"))
+
+
+def q8k_bytes(a):
+    return P.act_to_ggml_blocks(P.quantize_act(a, Q8_K), Q8_K, a.shape[-1], a.shape[0]).reshape(a.shape[0], -1, 292)[:, :, 4:260].reshape(a.shape[0], -1).view(np.int8)
+
+
+def census(name, a, b):
+    qa, qb = q8k_bytes(a), q8k_bytes(b)
+    diff = np.argwhere(qa != qb)
+    rel = float(((a - b).double().abs().max() / a.double().abs().max()).item())
+    msg = f"{name}: max |d| / max |y| = {rel:.2e}; int8 activation bytes that differ: {len(diff)} of {qa.size}"
+    if len(diff):
+        t, i = diff[0]
+        blk = i // 256
+        row = a[t].cpu().numpy()
+        step = np.abs(row[blk * 256:(blk + 1) * 256]).max() / 127.0
+        v = row[i] / step
+        msg += (f"; first: token {t} element {i}: {int(qa[t, i])} vs {int(qb[t, i])}, value / step = {v:.6f} "
+                f"(distance to the half-integer {abs(abs(v) % 1 - 0.5):.2e}), |a - b| / step = {abs(float(a[t, i] - b[t, i])) / step:.2e}")
+    print(msg, flush=True)
+    return len(diff)
+
+
+wo, wg, wu, wd = rand_weight(Q4_K, E, E), rand_weight(Q4_K, E, F), rand_weight(Q4_K, E, F), rand_weight(Q6_K, F, E)
+tot_a = tot_h = hit = 0
+for seed in range(SEEDS):
+    torch.manual_seed(seed)
+    x = torch.randn(T, E, device="cuda")
+    nw = torch.ones(E, device="cuda") + 0.02 * torch.randn(E, device="cuda")
+    print(f"== activations of seed {seed}, {T} tokens (ffn_down Q6_K)")
+    att = torch.randn(T, E, device="cuda")
+    xq = P.quantize_act(att, Q8_K)
+    mid_vec = P.mul_mat_vec(wo, xq=xq, ncols=T, resid=x)                     # ffn_inp = wo . att + x, mat-vec path
+    mid_mmq = P.mul_mat_small(wo, xq=xq, n_tokens=T, resid=x)                # the same through the small-batch mat-mul
+    tot_a += census("wo output -> input of ffn_gate / ffn_up (after rms_norm)", P.rms_norm(mid_vec, nw, 1e-5), P.rms_norm(mid_mmq, nw, 1e-5))
+    xn = P.rms_norm(mid_vec, nw, 1e-5)
+    xnq = P.quantize_act(xn, Q8_K)
+    hv = torch.nn.functional.silu(P.mul_mat_vec(wg, xq=xnq, ncols=T)) * P.mul_mat_vec(wu, xq=xnq, ncols=T)
+    hm = torch.nn.functional.silu(P.mul_mat_small(wg, xq=xnq, n_tokens=T)) * P.mul_mat_small(wu, xq=xnq, n_tokens=T)
+    n = census("silu(gate) * up -> input of ffn_down (K = 28672)", hv, hm)
+    hq = P.quantize_act(hv, Q8_K)
+    out_v = P.mul_mat_vec(wd, xq=hq, ncols=T, resid=mid_vec)
+    out_m = P.mul_mat_small(wd, xq=hq, n_tokens=T, resid=mid_vec)
+    d = (out_v - out_m).double()
+    print(f"ffn_down on IDENTICAL int8 input: NMSE between the two kernels {(d.pow(2).sum() / out_v.double().pow(2).sum()).item():.2e}")
+    if n:
+        out_m2 = P.mul_mat_small(wd, xq=P.quantize_act(hm, Q8_K), n_tokens=T, resid=mid_mmq)
+        d = (out_v - out_m2).double()
+        print(f"ffn_down on each path's OWN int8 input ({n} bytes apart): NMSE {(d.pow(2).sum() / out_v.double().pow(2).sum()).item():.2e}  <- the order of the whole-step figure")
+        hit += 1
+    tot_h += n
+print(f"\n{SEEDS} activation sets x {T} tokens: {tot_a} of {SEEDS * T * E} ffn-input bytes and {tot_h} of {SEEDS * T * F} ffn_down-input bytes rounded the other way; "
+      f"{hit} of {SEEDS} steps carry at least one flipped ffn_down byte")
