@@ -242,7 +242,7 @@ def probe_dominant_kernel(win, hp, iters=40):
     return out
 
 
-def probe_prefill(hp, mixture, n_tok):
+def probe_prefill(hp, mixture, n_tok, small_batches=(2, 3, 4, 8, 16, 32, 64)):
     """Prefill probe (reported as an extra, not the metric): an n_tok-token prompt through the WHOLE model (token embedding, every
     layer on the MFMA GEMM + MFMA attention path, result_norm + lm_head on the last token), plus `roofline` for its dominant kernel
     - the ffn gate / up GEMM - timed with HIP events on its launch stream."""
@@ -275,7 +275,7 @@ def probe_prefill(hp, mixture, n_tok):
     # integer-matrix-core mat-mul (mmq_i8.hip: one weight pass per 32 tokens), whole model, KV positions advancing
     try:
         sb = {}
-        for T in (2, 3, 4, 8, 16, 32, 64):
+        for T in small_batches:
             if T > n_tok:
                 continue
             win.kv_clear()
@@ -728,6 +728,14 @@ def main():
                 except Exception as e:
                     extras.append({"workload": name, "error": str(e)[:300]})
             result["extra_configs"] = extras
+            # BASELINE.json config 5's prompt pass on one GPU: Qwen2.5-72B Q6_K, 2048-token prompt (every weight GEMM the Q6_K instantiation)
+            try:
+                hq, mq, nq = model_cfg("qwen2.5-72b")
+                pq = probe_prefill(hq, mq, 2048, small_batches=(8, 32))
+                pq["workload"] = f"{nq}: 2048-token prompt, whole model, 1 GPU (config 5's prefill; the 8-GPU pipelined form is `ring_prefill` of --gpus N)"
+                result["prefill_qwen25_72b_q6k"] = pq
+            except Exception as e:
+                result["prefill_qwen25_72b_q6k"] = {"error": str(e)[-400:]}
             try:
                 result["weight_streaming"] = streaming_probe()
             except Exception as e:

@@ -313,7 +313,9 @@ PM355_API int pm355_op_flash_attn_ext(const pm355_tensor * q, const pm355_tensor
                                       const pm355_tensor * dst, float scale, float max_bias, float logit_softcap, pm355_stream_t stream);
 PM355_API int pm355_op_rope(const pm355_tensor * a, const int32_t * d_pos, const float * freq_factors, const pm355_tensor * dst,
                             const pm355_rope_params * rp, pm355_stream_t stream);
-/* MUL_MAT with F16 / F32 src0 (the K.q and V.p products of llm_build_kqv): src1 F32 rounded to F16 when src0 is F16 */
+/* MUL_MAT with F16 / F32 src0 (the K.q and V.p products of llm_build_kqv): src1 F32 rounded to F16 when src0 is F16; or with a Q8_0 src0 in
+ * ggml's native 34-byte blocks (a view of a `-ctk q8_0` cache without flash attention): src1 rows quantized to Q8_0 (quantize_row_q8_0_ref,
+ * ggml-quants.c:848), integer dots x d_k x d_q (ggml_vec_dot_q8_0_q8_0, :5518) */
 PM355_API int pm355_op_mul_mat_f(const pm355_tensor * a, const pm355_tensor * b, const pm355_tensor * dst, pm355_stream_t stream);
 PM355_API int pm355_op_get_rows_f32(const pm355_tensor * a, const int32_t * d_idx, int64_t n_idx, const pm355_tensor * dst,
                                     pm355_stream_t stream);

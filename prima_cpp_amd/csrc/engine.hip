@@ -439,9 +439,14 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         const Tensor * qkv[3] = {&L.t[PM355_T_WQ], &L.t[PM355_T_WK], &L.t[PM355_T_WV]};
         // 16..64 tokens take the small-batch path below unless its per-token attention kernel cannot hold n_ctx scores in LDS
         const bool small_attn_ok = (size_t) (dh + hp.n_ctx) * 4 <= 150 * 1024;
-        bool small_ok = !m->no_mmq && small_attn_ok;              // ... and unless one of the layer's large matrices has a type mmq_i8.hip does not serve
-        for (int k : {PM355_T_WQ, PM355_T_WO, PM355_T_FFN_GATE, PM355_T_FFN_UP, PM355_T_FFN_DOWN})
-            small_ok = small_ok && pm_mmq_i8_check(L.t[k].type, (int) L.t[k].K, (int) L.t[k].N, T < 1 ? 1 : (T > MMQ_MAX_TOKENS ? MMQ_MAX_TOKENS : T)) == 0;
+        bool small_ok = !m->no_mmq && small_attn_ok;              // ... and unless one of the layer's large matrices has a type neither small-batch path serves
+        for (int k : {PM355_T_WQ, PM355_T_WO, PM355_T_FFN_GATE, PM355_T_FFN_UP, PM355_T_FFN_DOWN}) {
+            // Q4_K / Q5_K / Q6_K: integer matrix cores (mmq_i8.hip). Q8_0 (Qwen2.5-72B's ffn_down: 29568 % 256 != 0, src/llama.cpp:19547): the
+            // multi-column mat-vec with Q8_0 activations = ggml_vec_dot_q8_0_q8_0's arithmetic, 8 columns per pass over the weights - slower than
+            // an MFMA pass would be, but the batch stays at mat-vec distance from the CPU instead of dropping the whole layer to the F16 GEMM
+            const bool served = pm_mmq_i8_check(L.t[k].type, (int) L.t[k].K, (int) L.t[k].N, T < 1 ? 1 : (T > MMQ_MAX_TOKENS ? MMQ_MAX_TOKENS : T)) == 0;
+            small_ok = small_ok && (served || L.t[k].type == PM_Q8_0);
+        }
         if (T > (small_ok ? MMQ_MAX_TOKENS : 15) && !m->no_fuse) {
             // ---- prefill: batched GEMMs on the MFMA matrix cores (mmq.hip), f32 activations
             // F16 plumbing: the producers of GEMM activations write them as F16 (the rounding the GEMM's own conversion pass would apply) into

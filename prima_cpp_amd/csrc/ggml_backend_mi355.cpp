@@ -381,6 +381,9 @@ bool supports_op_impl(const struct ggml_tensor * op) {
             return true;
         case GGML_OP_MUL_MAT:
             if (mul_mat_quant_ok(op)) return true;
+            // K.q on a `-ctk q8_0` cache without flash attention: src0 = a view of native Q8_0 blocks (never a row-SoA weight matrix)
+            if (a->type == GGML_TYPE_Q8_0 && !is_soa_tensor(a) && b->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && a->ne[0] % 32 == 0 &&
+                a->nb[0] == ggml_type_size(a->type)) return true;
             return (a->type == GGML_TYPE_F16 || a->type == GGML_TYPE_F32) && b->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 &&
                    a->nb[0] == ggml_type_size(a->type) && b->nb[0] == 4;
         case GGML_OP_RMS_NORM:
@@ -396,6 +399,8 @@ bool supports_op_impl(const struct ggml_tensor * op) {
             // KV store into a quantized cache: f32 rows -> contiguous native Q8_0 blocks of a 1-D cache tensor (attn_q8.hip)
             if (op->op == GGML_OP_CPY && ts == GGML_TYPE_F32 && td == GGML_TYPE_Q8_0)
                 return a->nb[0] == 4 && a->ne[0] % 32 == 0 && ggml_is_contiguous(op) && op->view_src && !is_soa_tensor(op);
+            // K-shift of a quantized cache: dequantizing copy of native Q8_0 rows (build_k_shift, src/llama.cpp:10665)
+            if (ts == GGML_TYPE_Q8_0 && td == GGML_TYPE_F32) return !is_soa_tensor(a) && a->ne[0] % 32 == 0 && a->nb[0] == ggml_type_size(a->type);
             return (ts == GGML_TYPE_F32 || ts == GGML_TYPE_F16) && (td == GGML_TYPE_F32 || td == GGML_TYPE_F16);
         }
         case GGML_OP_SOFT_MAX:

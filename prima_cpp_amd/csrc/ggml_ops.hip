@@ -174,6 +174,50 @@ __global__ __launch_bounds__(256) void mul_mat_f_kernel(TD a, int at, TD b, TD d
     if (lane == 0) *(float *) (d.data + i0 * d.nb[0] + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]) = acc;
 }
 
+// MUL_MAT with a Q8_0 src0 in ggml's NATIVE 34-byte blocks and arbitrary row strides: the K.q product of llm_build_kqv on a `-ctk q8_0` cache
+// WITHOUT flash attention (src/llama.cpp:10062-10068: k = view of the quantized cache [dh, n_kv, Hkv]). vec_dot_type of Q8_0 is Q8_0
+// (ggml.c:865-881): the f32 row of src1 is quantized per 32 values (quantize_row_q8_0_ref, ggml-quants.c:848: d = max|x| / 127 stored as F16,
+// q = roundf(x / d)), the dot is ggml_vec_dot_q8_0_q8_0 (:5518): sum over blocks of (int32 dot) * d_k * d_q. One wave per output element,
+// one lane per block of the row (head_dim / 32 lanes busy: a node-equivalent op for a few KB, not a bandwidth kernel).
+__global__ __launch_bounds__(256) void mul_mat_q80_kernel(TD a, TD b, TD d, long r2, long r3, long n_out) {
+    const long o = (long) blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (o >= n_out) return;
+    long r = o;
+    const long i0 = r % d.ne[0]; r /= d.ne[0]; const long i1 = r % d.ne[1]; r /= d.ne[1]; const long i2 = r % d.ne[2]; const long i3 = r / d.ne[2];
+    const char * ap = a.data + i0 * a.nb[1] + (i2 / r2) * a.nb[2] + (i3 / r3) * a.nb[3];
+    const char * bp = b.data + i1 * b.nb[1] + i2 * b.nb[2] + i3 * b.nb[3];
+    float acc = 0.0f;
+    for (long blk = lane; blk < a.ne[0] / 32; blk += 64) {
+        float x[32], amax = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { x[j] = *(const float *) (bp + (blk * 32 + j) * b.nb[0]); amax = fmaxf(amax, fabsf(x[j])); }
+        const float dq = amax / 127, id = dq ? 1.0f / dq : 0.0f;
+        const uint8_t * kb = (const uint8_t *) (ap + blk * 34);
+        const float dk = h2f((uint16_t) (kb[0] | (kb[1] << 8)));
+        int sumi = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) sumi += (int) (int8_t) kb[2 + j] * (int) roundf(x[j] * id);
+        acc += (float) sumi * (dk * h2f(f2h(dq)));
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) *(float *) (d.data + i0 * d.nb[0] + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]) = acc;
+}
+
+// CPY / CAST Q8_0 (native blocks, any row strides) -> F32: the K-shift graph of a quantized cache dequantizes the rows it rotates
+// (build_k_shift, src/llama.cpp:10665-10690: ggml_cast(k, F32) -> rope -> cpy back); dequantize_row_q8_0 (ggml-quants.c:1616)
+__global__ void cpy_q80_f32_kernel(TD s, TD d, long n) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long r = i;
+    const long d0 = r % d.ne[0]; r /= d.ne[0]; const long d1 = r % d.ne[1]; r /= d.ne[1]; const long d2 = r % d.ne[2]; const long d3 = r / d.ne[2];
+    r = i;
+    const long s0 = r % s.ne[0]; r /= s.ne[0]; const long s1 = r % s.ne[1]; r /= s.ne[1]; const long s2 = r % s.ne[2]; const long s3 = r / s.ne[2];
+    const uint8_t * blk = (const uint8_t *) (s.data + (s0 / 32) * 34 + s1 * s.nb[1] + s2 * s.nb[2] + s3 * s.nb[3]);
+    const float v = h2f((uint16_t) (blk[0] | (blk[1] << 8))) * (float) (int8_t) blk[2 + (s0 & 31)];
+    *(float *) (d.data + d0 * d.nb[0] + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3]) = v;
+}
+
 __global__ void get_rows_f32_kernel(TD a, const int32_t * idx, long n_idx, TD d) {
     const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.ne[0] * n_idx) return;
@@ -276,6 +320,13 @@ int pm355_op_cpy(const pm355_tensor * src, const pm355_tensor * dst, pm355_strea
         if (pm_launch_cpy_f32_q8_0(src, dst->data, S(st))) return PM355_E_UNSUPPORTED;
         OKRET();
     }
+    if (ts == PM_Q8_0 && td == PM_F32) {             // dequantizing copy (K-shift of a quantized cache); src = native 34-byte blocks
+        if (nelem(src) != nelem(dst) || src->ne[0] % 32) return PM355_E_SHAPE;
+        const long nq = nelem(dst);
+        (void) hipGetLastError();
+        hipLaunchKernelGGL(cpy_q80_f32_kernel, GRID(nq), 0, S(st), to_td(src), to_td(dst), nq);
+        OKRET();
+    }
     if ((ts != PM_F32 && ts != PM_F16) || (td != PM_F32 && td != PM_F16) || nelem(src) != nelem(dst)) return PM355_E_UNSUPPORTED;
     const long n = nelem(dst);
     (void) hipGetLastError();
@@ -373,10 +424,16 @@ int pm355_op_rope(const pm355_tensor * a, const int32_t * d_pos, const float * f
     OKRET();
 }
 int pm355_op_mul_mat_f(const pm355_tensor * a, const pm355_tensor * b, const pm355_tensor * dst, pm355_stream_t st) {
-    if ((a->type != PM_F16 && a->type != PM_F32) || b->type != PM_F32 || dst->type != PM_F32) return PM355_E_UNSUPPORTED;
+    if ((a->type != PM_F16 && a->type != PM_F32 && a->type != PM_Q8_0) || b->type != PM_F32 || dst->type != PM_F32) return PM355_E_UNSUPPORTED;
     if (a->ne[0] != b->ne[0] || b->ne[2] % a->ne[2] || b->ne[3] % a->ne[3]) return PM355_E_SHAPE;
     const long n = nelem(dst);
     (void) hipGetLastError();
+    if (a->type == PM_Q8_0) {                        // native Q8_0 blocks (a view of a quantized K cache): Q8_0 x Q8_0 integer dots
+        if (a->ne[0] % 32) return PM355_E_SHAPE;
+        hipLaunchKernelGGL(mul_mat_q80_kernel, dim3((unsigned) ((n + 3) / 4)), dim3(256), 0, S(st), to_td(a), to_td(b), to_td(dst),
+                           b->ne[2] / a->ne[2], b->ne[3] / a->ne[3], n);
+        OKRET();
+    }
     hipLaunchKernelGGL(mul_mat_f_kernel, dim3((unsigned) ((n + 3) / 4)), dim3(256), 0, S(st), to_td(a), a->type, to_td(b), to_td(dst),
                        b->ne[2] / a->ne[2], b->ne[3] / a->ne[3], n);
     OKRET();

@@ -204,3 +204,20 @@ def test_llama_decode_plugin_8b_shape(gpu, tmp_path):
     tg, lg, sg = run_llama_driver(path, prompt, n, ngl=99, n_ctx=512, threads=thr, extra_args=GPU_ARGS, timeout=1200)
     print(f"\n[8B-shape] plug-in decode {sg['decode_tok_s']:.1f} tok/s (prompt {sg['prompt_tok_s']:.0f} tok/s)")
     _check("8B-shape", tg, lg, path, prompt, n, 512, threads=thr)
+
+
+@pytest.mark.parametrize("name", ["llama", "qwen2"])
+def test_llama_decode_plugin_quantized_k_cache_without_flash_attn(gpu, name, tmp_path):
+    """-ctk q8_0 WITHOUT --flash-attn (the V cache stays F16 and transposed): llm_build_kqv multiplies a view of the quantized K cache with
+    the query (MUL_MAT with a Q8_0 src0 in native blocks -> the reference quantizes q to Q8_0, ggml_vec_dot_q8_0_q8_0) - served by the
+    plug-in (pm355_op_mul_mat_f on native Q8_0 blocks), nothing of the layer window falls back to the CPU backend: two graph_compute calls
+    per decoded token (layers + head), like the F16 cache."""
+    z = np.load(os.path.join(HERE, "golden", f"tiny_{name}_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / f"tiny_{name}.gguf"), z)
+    n = len(z["tokens"])
+    kv = ["-ctk", "q8_0"]
+    toks, logits, stats = run_llama_driver(path, z["prompt"], n, ngl=99, n_ctx=64, extra_args=GPU_ARGS + kv, env={"GGML_MI355_STATS": "1"})
+    assert "K (q8_0)" in stats["stderr"] and "V (f16)" in stats["stderr"] and "MI355X0 KV buffer" in stats["stderr"], stats["stderr"][-1500:]
+    m = re.search(r"graph_compute (\d+),", stats["stderr"])
+    assert m and int(m.group(1)) <= 2 * (n + 2), stats["stderr"][-800:]          # prompt + warm-up + n - 1 tokens, two splits each
+    _check(f"tiny_{name} -ctk q8_0 (no flash attention)", toks, logits, path, z["prompt"], n, 64, cpu_args=kv, nmse_floor=1e-3, err_floor=5e-2)

@@ -572,3 +572,57 @@ def test_qkv_epilogue_and_cached_attention_equal_the_fused_attention_path(P, ora
     k_ref = oracle.rope(k_ref.reshape(1, Hkv, dh), np.array([100], dtype=np.int32), freq_factors=ff.cpu().numpy(), freq_base=500000.0).reshape(-1)
     k_got = kcB.cpu().numpy().view(np.float16).astype(np.float32).reshape(n_ctx, Nkv)[100]
     assert np.allclose(k_got, k_ref.astype(np.float16).astype(np.float32), rtol=2e-3, atol=2e-3)
+
+
+def _pm_tensor(C, t, type_, ne, nb):
+    class PMT(C.Structure):
+        _fields_ = [("data", C.c_void_p), ("type", C.c_int32), ("pad_", C.c_int32), ("ne", C.c_int64 * 4), ("nb", C.c_size_t * 4)]
+    x = PMT()
+    x.data, x.type, x.pad_ = t.data_ptr(), type_, 0
+    for i in range(4):
+        x.ne[i] = ne[i] if i < len(ne) else 1
+        x.nb[i] = nb[i] if i < len(nb) else nb[len(nb) - 1] * (ne[len(nb) - 1] if len(nb) == len(ne) else 1)
+    return x
+
+
+def test_native_q8_0_cache_view_matmul_and_dequantizing_copy(P, oracle):
+    """The two node-equivalent ops a `-ctk q8_0` cache needs outside flash attention, on a strided view of native 34-byte blocks shaped like
+    llm_build_kqv's k view [head_dim, n_kv, n_head_kv] (row stride = a whole cache row): MUL_MAT(k, q) = quantize_row_q8_0(q) +
+    ggml_vec_dot_q8_0_q8_0, against the oracle's mul_mat per head; and CPY -> F32 (K-shift graphs) = dequantize_row_q8_0."""
+    import ctypes as C
+    torch = P.torch
+    lib = P.L.load()
+    rng = np.random.default_rng(77)
+    dh, Hkv, H, n_kv, n_ctx, T = 128, 2, 4, 40, 64, 3
+    Ekv = dh * Hkv
+    kf = rng.normal(0, 1, (n_ctx, Ekv)).astype(np.float32)
+    blocks = np.concatenate([oracle.quantize_row_q8_0(kf[i]) for i in range(n_ctx)])          # cache rows in native block order
+    kc = torch.from_numpy(blocks).cuda()
+    row_b, head_b = Ekv // 32 * 34, dh // 32 * 34
+    q = rng.normal(0, 1, (H, T, dh)).astype(np.float32)
+    qd = torch.from_numpy(q).cuda()
+    out = torch.zeros((H, T, n_kv), dtype=torch.float32, device="cuda")
+    a = _pm_tensor(C, kc, Q8_0, [dh, n_kv, Hkv, 1], [34, row_b, head_b, n_ctx * row_b])
+    b = _pm_tensor(C, qd, 0, [dh, T, H, 1], [4, dh * 4, T * dh * 4, H * T * dh * 4])
+    d = _pm_tensor(C, out, 0, [n_kv, T, H, 1], [4, n_kv * 4, T * n_kv * 4, H * T * n_kv * 4])
+    lib.pm355_op_mul_mat_f.restype = C.c_int
+    lib.pm355_op_mul_mat_f.argtypes = [C.c_void_p] * 4
+    assert lib.pm355_op_mul_mat_f(C.addressof(a), C.addressof(b), C.addressof(d), P.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    kb = blocks.reshape(n_ctx, Hkv, head_b)
+    for h in range(H):
+        hk = h // (H // Hkv)
+        w = np.ascontiguousarray(kb[:n_kv, hk]).reshape(-1)
+        want = oracle.mul_mat(Q8_0, w, dh, n_kv, q[h])                                           # [T, n_kv]
+        assert np.allclose(got[h], want, rtol=1e-5, atol=1e-5), (h, np.abs(got[h] - want).max())
+    # dequantizing copy of the view [dh, Hkv, n_ctx] -> contiguous f32
+    deq = torch.zeros((n_ctx, Hkv, dh), dtype=torch.float32, device="cuda")
+    s = _pm_tensor(C, kc, Q8_0, [dh, Hkv, n_ctx, 1], [34, head_b, row_b, n_ctx * row_b])
+    t = _pm_tensor(C, deq, 0, [dh, Hkv, n_ctx, 1], [4, dh * 4, Hkv * dh * 4, n_ctx * Hkv * dh * 4])
+    lib.pm355_op_cpy.restype = C.c_int
+    lib.pm355_op_cpy.argtypes = [C.c_void_p] * 3
+    assert lib.pm355_op_cpy(C.addressof(s), C.addressof(t), P.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    want = np.stack([oracle.dequantize_row(Q8_0, blocks[i * row_b:(i + 1) * row_b], Ekv) for i in range(n_ctx)]).reshape(n_ctx, Hkv, dh)
+    assert np.array_equal(deq.cpu().numpy(), want)
