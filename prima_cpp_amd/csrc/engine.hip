@@ -66,6 +66,7 @@ struct pm355_model {
     // captured graphs). PM355_ATTN_SPLIT_MIN positions (default 640: measured crossover on the 70B head shape).
     float * split_scratch = nullptr;
     std::vector<int> h_pos; int h_seq = 0; int split_min = 640; bool long_ctx = false;
+    bool attn_mfma = true;                        // long contexts in the QKV-epilogue form: matrix-core attention (attn_flash_mfma.hip); PM355_ATTN_MFMA=0 = round-2 kernel
     int flash_cells = 0; bool use_flash = true;   // long contexts: one-launch flash-decoding (attn_flash.hip), grid sized for `flash_cells` (a power-of-two bucket of the position)
     // staging for set_tensor
     pm355_uploader * up = nullptr;        // pinned ring + copier threads + private stream (upload.hip)
@@ -339,7 +340,8 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
     const float kq_scale = 1.0f / sqrtf((float) dh);
     float * bufs[2] = {m->x, m->x1};
     // rope + KV store in the QKV epilogue: NORM-mode rope, one-workgroup-per-head attention regime
-    bool epi = m->qkv_epi && m->rope_tab && !(m->rope.mode & 2) && !m->long_ctx;
+    bool epi = m->qkv_epi && m->rope_tab && !(m->rope.mode & 2) &&
+               (!m->long_ctx || (m->use_flash && m->attn_mfma && (dh == 64 || dh == 128) && H / Hkv <= 8 && hp.n_ctx % 8 == 0));
     if (epi) pm_launch_rope_table(m->rope, m->d_pos, m->d_ctl, (const float *) m->rope_freqs.d, m->rope_tab, st);
     for (int il = m->lo; il < m->hi; ++il) {
         Layer Lv = layer_acquire(m, il, st); Layer & L = Lv;
@@ -367,7 +369,12 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
             }
         }
         const long kvs = m->n_seq > 1 ? (long) hp.n_ctx * Hkv * dh : 0;     // one slab: the kernels may address the cache before the sequence id arrives
-        if (m->long_ctx && m->use_flash) {
+        if (m->long_ctx && epi) {
+            // long context, cells complete: scores and P.V on the matrix cores, keys split over workgroups, in-launch merge (attn_flash_mfma.hip)
+            if (pm_launch_attn_flash_cached(q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, att, m->split_scratch, H, Hkv, dh, hp.n_ctx, kq_scale, st,
+                                            nullptr, nullptr, 0, m->flash_cells))
+                return seterr(m, PM355_E_RANGE, "decode: matrix-core flash-decoding attention unsupported for this shape");
+        } else if (m->long_ctx && m->use_flash) {
             // long context: keys split over workgroups, rope + KV store + online softmax + in-launch merge in ONE launch (attn_flash.hip)
             if (pm_launch_attn_flash(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d, att, m->split_scratch,
                                      H, Hkv, dh, hp.n_ctx, kq_scale, m->rope, st, nullptr, nullptr, 0, 0, m->flash_cells))
@@ -735,6 +742,7 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
     m->h_pos.assign(n_seq, 0); m->h_seq = 0;
     { const char * e = getenv("PM355_ATTN_SPLIT_MIN"); if (e && e[0]) m->split_min = atoi(e); }
     { const char * e = getenv("PM355_ATTN_FLASH"); m->use_flash = !(e && e[0] == '0'); }
+    { const char * e = getenv("PM355_ATTN_MFMA"); m->attn_mfma = !(e && e[0] == '0'); }
     (void) hipMemset(m->d_pos, 0, 64 * 4);
     { const int32_t ctl[2] = {0, n_seq}; (void) hipMemcpy(m->d_ctl, ctl, 8, hipMemcpyHostToDevice); }
     (void) hipDeviceSynchronize();

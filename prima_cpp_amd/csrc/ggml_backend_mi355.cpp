@@ -116,6 +116,7 @@ struct backend_ctx {
     // graph lowering (ggml_graph_plan.h)
     int32_t * d_dyn = nullptr;                       // device int32[2]: {KV cell of the token, cells attended}
     float * rope_tab = nullptr;                      // device float[256]: this token's cos / sin per rotation pair (round-3 attention block)
+    bool attn_mfma = true;                           // GGML_MI355_ATTN_MFMA=0: long contexts keep the round-2 flash-decoding kernel
     bool qkv_epi = true;                             // GGML_MI355_QKV_EPI=0: rope + KV store inside the attention kernel (the round-2 form)
     float * qkv = nullptr; size_t qkv_floats = 0;    // raw q / k / v projections of one token
     float * split = nullptr; size_t split_floats = 0;
@@ -592,6 +593,11 @@ bool run_plan(backend_ctx * c, struct ggml_cgraph * g, const mi355::plan & p) {
                 MI355_CHECK(pm355_mul_mat_vec_qkv(s.job, s.K, s.x, s.norm_w, s.eps, &s.qs, c->stream));
                 break;
             case mi355::STEP_ATTN_CACHED:
+                if (s.attn.split) {
+                    MI355_CHECK(pm355_attn_cached_long(s.attn.q, s.attn.k_cache, s.attn.v_cache, nullptr, s.attn.d_cell_nkv, s.attn.mask, s.attn.out, s.attn.scratch,
+                                                       s.attn.n_head, s.attn.n_head_kv, s.attn.head_dim, s.attn.n_ctx, s.attn.kq_scale, s.attn.max_keys, s.attn.flags, c->stream));
+                    break;
+                }
                 MI355_CHECK(pm355_attn_cached(s.attn.q, s.attn.k_cache, s.attn.v_cache, nullptr, s.attn.d_cell_nkv, s.attn.mask, s.attn.out, s.attn.n_head,
                                               s.attn.n_head_kv, s.attn.head_dim, s.attn.n_ctx, s.attn.kq_scale, s.attn.max_keys, s.attn.flags, c->stream));
                 break;
@@ -630,7 +636,7 @@ void print_plan(const backend_ctx * c, struct ggml_cgraph * g, const mi355::plan
                     s.ab.n_head_kv, s.ab.head_dim, s.ab.n_kv);
         } else if (s.kind == mi355::STEP_ATTN || s.kind == mi355::STEP_ATTN_CACHED) {
             fprintf(stderr, "  [%d,%d) attention H=%d Hkv=%d dh=%d n_ctx=%d %s mask=%d ff=%d\n", s.node_lo, s.node_hi, s.attn.n_head, s.attn.n_head_kv, s.attn.head_dim,
-                    s.attn.n_ctx, s.kind == mi355::STEP_ATTN_CACHED ? "cached" : (s.attn.split ? "split" : "fused"), s.attn.mask != nullptr, s.attn.freq_factors != nullptr);
+                    s.attn.n_ctx, s.kind == mi355::STEP_ATTN_CACHED ? (s.attn.split ? "cached-split" : "cached") : (s.attn.split ? "split" : "fused"), s.attn.mask != nullptr, s.attn.freq_factors != nullptr);
         } else {
             fprintf(stderr, "  [%d] %s '%s'\n", s.node, ggml_op_name(ggml_graph_node(g, s.node)->op), ggml_graph_node(g, s.node)->name);
         }
@@ -659,7 +665,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g)
     graph_entry * e = nullptr;
     for (graph_entry * x : c->graphs) if (x->plan.fast_ok && mi355::fingerprint_equal(x->fp, c->fp_tmp)) { e = x; ++c->n_fp_hit; break; }
     if (!e) {
-        mi355::plan_ctx pc = { c, plan_qkv_scratch, plan_split_scratch, c->d_dyn, c->split_min, c->fuse, c->qkv_epi ? c->rope_tab : nullptr, plan_same_bytes };
+        mi355::plan_ctx pc = { c, plan_qkv_scratch, plan_split_scratch, c->d_dyn, c->split_min, c->attn_mfma, c->fuse, c->qkv_epi ? c->rope_tab : nullptr, plan_same_bytes };
         mi355::plan p;
         mi355::planner(g, pc).build(p);
         ++c->n_plan;
@@ -845,6 +851,7 @@ ggml_backend_t ggml_backend_mi355_init(int device) {
     backend_ctx * c = new backend_ctx{device, std::string(GGML_MI355_NAME "X") + std::to_string(device), plan_only() ? (pm355_stream_t) 1 : pm355_stream_create()};
     if (!c->stream) { delete c; return nullptr; }
     c->fuse = !env_on("GGML_MI355_NO_FUSE");                          // node-by-node kernels only (debug / A-B)
+    if (const char * am = getenv("GGML_MI355_ATTN_MFMA")) if (am[0] == '0') c->attn_mfma = false;
     if (const char * qe = getenv("GGML_MI355_QKV_EPI")) if (qe[0] == '0') c->qkv_epi = false;   // rope + KV store inside the attention kernel (round-2 form)
     c->use_graphs = !env_on("GGML_MI355_NO_GRAPH") && !plan_only();   // no hipGraph capture / replay
     c->debug_plan = env_on("GGML_MI355_DEBUG_PLAN") || plan_only();

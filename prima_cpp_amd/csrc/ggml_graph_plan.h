@@ -78,6 +78,7 @@ struct plan_ctx {                                    // what the backend provide
     float * (*split_scratch)(void * user, size_t n_floats);
     int32_t * d_dyn;                                 // device int32[2] {cell, cells attended}
     int split_min;                                   // cells attended from which the split attention is used
+    bool attn_mfma;                                  // long contexts in the round-3 form: matrix-core attention over cached cells
     bool fuse;
     // round-3 form of the attention block: device table of 256 floats (null: off) and a comparison of two small device arrays
     // (the per-layer copies of rope_freqs hold the same numbers: one table serves every layer)
@@ -447,7 +448,7 @@ private:
         // the same cos / sin table as the layers planned before (same parameters, positions and frequency factors)
         pm355_rope_params rp_; rope_params_of(rq, rp_);
         const float * ff_ = rq->src[2] ? (const float *) rq->src[2]->data : nullptr;
-        bool epi = c_.rope_tab && one_launch && !q8 && !split && !(rp_.mode & 2) && rp_.n_dims <= 256 &&
+        bool epi = c_.rope_tab && one_launch && !q8 && (!split || (!fa && c_.attn_mfma)) && !(rp_.mode & 2) && rp_.n_dims <= 256 &&
                    pm355_mul_mat_vec_qkv_check(jobs, E, (int) Hkv, (int) dh, rp_.n_dims) == 0;
         if (epi && tab_set_) {
             const bool same_ff = ff_ == tab_ff_ || (ff_ && tab_ff_ && c_.same_bytes && c_.same_bytes(c_.user, ff_, tab_ff_, (size_t) rp_.n_dims / 2 * 4));

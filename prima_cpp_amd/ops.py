@@ -167,6 +167,15 @@ def attn_decode_split(q_rot, k_cache, v_cache, pos, n_head, n_head_kv, head_dim,
     return out
 
 
+def attn_split_scratch(n_head, head_dim, n_ctx, device="cuda"):
+    """Zeroed scratch of the long-context attention kernels (partials + tickets; the kernels leave the tickets at zero)."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_attn_split_scratch_floats.restype = C.c_size_t
+    lib.pm355_attn_split_scratch_floats.argtypes = [C.c_int] * 3
+    return torch.zeros(lib.pm355_attn_split_scratch_floats(n_head, head_dim, n_ctx), dtype=torch.float32, device=device)
+
+
 def attn_prefill(q, k_cache, v_cache, pos0, n_head, n_head_kv, head_dim, n_ctx, scale):
     """Causal multi-token attention on MFMA (same contract as attn_decode)."""
     import ctypes as C
@@ -319,10 +328,18 @@ def mul_mat_vec_qkv(ws, x, tab, pos, k_cache, v_cache, n_head_kv, head_dim, n_ct
     return q
 
 
-def attn_cached(q_rot, k_cache, v_cache, pos, n_head, n_head_kv, head_dim, n_ctx, scale, cell_nkv=None, mask=None, max_keys=0, flags=0):
-    """Single-token attention over cells that are all in the cache (q rotated and F16-rounded). pos: int32 device tensor [1]."""
+def attn_cached(q_rot, k_cache, v_cache, pos, n_head, n_head_kv, head_dim, n_ctx, scale, cell_nkv=None, mask=None, max_keys=0, flags=0, scratch=None):
+    """Single-token attention over cells that are all in the cache (q rotated and F16-rounded). pos: int32 device tensor [1].
+    scratch (zero-initialised f32 tensor of attn_split_scratch_floats): the long-context matrix-core kernel, max_keys = grid cells."""
     import ctypes as C
     lib = L.load()
+    if scratch is not None:
+        lib.pm355_attn_cached_long.restype = C.c_int
+        lib.pm355_attn_cached_long.argtypes = [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_int, C.c_void_p]
+        out = torch.empty_like(q_rot)
+        check(lib.pm355_attn_cached_long(ptr(q_rot), ptr(k_cache), ptr(v_cache), ptr(pos), ptr(cell_nkv), ptr(mask), ptr(out), ptr(scratch), n_head,
+                                         n_head_kv, head_dim, n_ctx, float(scale), max_keys, flags, stream_ptr()), "attn_cached_long")
+        return out
     lib.pm355_attn_cached.restype = C.c_int
     lib.pm355_attn_cached.argtypes = [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_int, C.c_void_p]
     out = torch.empty_like(q_rot)

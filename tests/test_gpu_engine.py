@@ -193,16 +193,18 @@ def test_prefill_mfma_path_vs_oracle(E, oracle, arch):
     w.close()
 
 
-@pytest.mark.parametrize("flash,n_head", [("1", 8), ("1", 4), ("0", 8)])
-def test_long_context_split_attention_path(E, monkeypatch, flash, n_head):
+@pytest.mark.parametrize("flash,n_head,n_embd,n_head_kv", [("1", 8, 512, 2), ("1", 4, 512, 2), ("0", 8, 512, 2), ("1", 8, 1024, 4), ("1", 16, 1024, 8)])
+def test_long_context_split_attention_path(E, monkeypatch, flash, n_head, n_embd, n_head_kv):
     """Beyond PM355_ATTN_SPLIT_MIN positions the engine switches from the one-workgroup-per-head attention kernel to the
     keys-split-over-workgroups path - one launch of flash-decoding with an in-launch merge (attn_flash.hip; head_dim 64 and 128, up to
     three spans merged here), or with PM355_ATTN_FLASH=0 the three-launch form (attn_split.hip) - in another captured graph: hidden
-    state and logits agree at every position, through graph replay and through plain decode()."""
+    state and logits agree at every position, through graph replay and through plain decode(). The n_embd 1024 shapes have wk / wv row
+    slices that take the QKV epilogue (rope + KV store there), so their long-context regime is the matrix-core kernel over cached cells
+    (attn_flash_mfma.hip, head_dim 128 and 64)."""
     torch = E.torch
     rng = np.random.default_rng(78)
     monkeypatch.setenv("PM355_ATTN_FLASH", flash)
-    d = tiny_model(rng, arch=0, n_layer=2, n_embd=512, n_head=n_head, n_head_kv=2, n_ff=1024, n_vocab=320, n_ctx=320, rope_freqs=True)
+    d = tiny_model(rng, arch=0, n_layer=2, n_embd=n_embd, n_head=n_head, n_head_kv=n_head_kv, n_ff=1024, n_vocab=320, n_ctx=320, rope_freqs=True)
     toks = rng.integers(0, d.n_vocab, 300).astype(np.int32)
     res = []
     for split_min in ("100000", "40"):

@@ -574,6 +574,62 @@ def test_qkv_epilogue_and_cached_attention_equal_the_fused_attention_path(P, ora
     assert np.allclose(k_got, k_ref.astype(np.float16).astype(np.float32), rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("dh,H,Hkv", [(128, 8, 1), (128, 8, 2), (64, 8, 4), (64, 4, 4), (64, 16, 1)])
+def test_long_context_matrix_core_attention_over_cached_cells(P, dh, H, Hkv):
+    """attn_flash_mfma.hip: scores and P.V of a GQA group on v_mfma_f32_32x32x16_f16 with permuted key rows, per-wave online softmax, spans
+    merged in the launch - against softmax(K q * scale + mask) V in float64 on the same F16 cache values, over cells-attended that
+    exercise: one partial tile, one span, several spans with a ragged tail, the doubled span (> 8k cells), with and without a mask that
+    hides cells (-inf), position given as d_pos and as {cell, cells attended}."""
+    torch = P.torch
+    rng = np.random.default_rng(77 + dh + H)
+    n_ctx = 16640
+    Nkv = Hkv * dh
+    R = H // Hkv
+    kc = rng.normal(0, 1, (n_ctx, Nkv)).astype(np.float16)
+    vt = rng.normal(0, 1, (Nkv, n_ctx)).astype(np.float16)
+    kcd = torch.from_numpy(kc.view(np.int16)).cuda().reshape(-1)
+    vcd = torch.from_numpy(vt.view(np.int16)).cuda().reshape(-1)
+    scratch = P.attn_split_scratch(H, dh, n_ctx)
+    scale = 1.0 / np.sqrt(dh)
+    worst = 0.0
+    for n_kv, use_mask, dyn_mode in [(1, False, False), (33, False, True), (700, True, True), (2000, False, False), (2049, True, True),
+                                     (5000, False, True), (8192, False, False), (16300, True, True)]:
+        q = (rng.normal(0, 1, (H, dh)) * 1.5).astype(np.float16).astype(np.float32)      # (the epilogue hands over F16-rounded values)
+        qd = torch.from_numpy(q.reshape(1, -1)).cuda()
+        mask = None
+        mnp = np.zeros(n_kv, dtype=np.float64)
+        if use_mask:
+            m32 = np.zeros(n_ctx, dtype=np.float32)
+            hide = rng.random(n_kv) < 0.3
+            hide[n_kv - 1] = False
+            m32[:n_kv][hide] = -np.inf
+            m32[n_kv:] = -np.inf
+            mask = torch.from_numpy(m32).cuda()
+            mnp = m32[:n_kv].astype(np.float64)
+        cells = 1024
+        while cells < n_kv: cells *= 2
+        cells = min(cells, n_ctx)
+        if dyn_mode:
+            dyn = torch.tensor([n_kv - 1, n_kv], dtype=torch.int32, device="cuda")
+            out = P.attn_cached(qd, kcd, vcd, None, H, Hkv, dh, n_ctx, scale, cell_nkv=dyn, mask=mask, max_keys=cells, scratch=scratch)
+        else:
+            pd = torch.tensor([n_kv - 1], dtype=torch.int32, device="cuda")
+            out = P.attn_cached(qd, kcd, vcd, pd, H, Hkv, dh, n_ctx, scale, mask=mask, max_keys=0, scratch=scratch)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().reshape(H, dh)
+        for h in range(H):
+            g = h // R
+            Kh = kc[:n_kv, g * dh:(g + 1) * dh].astype(np.float64)
+            Vh = vt[g * dh:(g + 1) * dh, :n_kv].astype(np.float64)
+            s = Kh @ q[h].astype(np.float64) * scale + mnp
+            pr = np.exp(s - s.max()); pr /= pr.sum()
+            ref = Vh @ pr
+            err = np.abs(got[h] - ref).max() / max(1e-3, np.abs(ref).max())
+            worst = max(worst, float(err))
+            assert err < 2e-3, (n_kv, h, err)
+    print(f"\n[matrix-core long-context attention dh {dh} H {H} Hkv {Hkv}] worst max|d| / max|ref| = {worst:.2e}")
+
+
 def _pm_tensor(C, t, type_, ne, nb):
     class PMT(C.Structure):
         _fields_ = [("data", C.c_void_p), ("type", C.c_int32), ("pad_", C.c_int32), ("ne", C.c_int64 * 4), ("nb", C.c_size_t * 4)]

@@ -106,14 +106,14 @@ def _margins(lg):
     return srt[:, -1] - srt[:, -2], lg.std(axis=1)
 
 
-def _engine_greedy(path, size, prompt, n_gen):
+def _engine_greedy(path, size, prompt, n_gen, n_ctx=N_CTX):
     """Greedy decode on the resident engine (pm355_model_*): prompt as one batch, then token by token through the captured graph."""
     import torch
     import prima_cpp_amd.engine as eng
     s = SHAPES[size]
     hp = dict(arch=0, n_layer=s["n_layer"], n_embd=s["n_embd"], n_head=s["n_head"], n_head_kv=s["n_head_kv"], head_dim=s["n_embd"] // s["n_head"],
               n_ff=s["n_ff"], n_vocab=s["n_vocab"], rms_eps=1e-5, rope_freq_base=500000.0)
-    w = eng.Window(hp, n_ctx=N_CTX)
+    w = eng.Window(hp, n_ctx=n_ctx)
     w.load_gguf(path)
     w.finalize(max_tokens=max(len(prompt), 1))
     toks, logits = [], []
@@ -167,6 +167,35 @@ def test_peaked_fixture_greedy_tokens_identical(gpu, files, size, mode):
     # and the reference's CPU flash kernel an F16 accumulator: its own backend tolerance applies there)
     nm_ref = _nmse(la, ls)
     assert _nmse(lg, ls) < max(1e-6, 3 * nm_ref) * (10 if mode == "plugin-fa" else 1), (_nmse(lg, ls), nm_ref)
+
+
+@pytest.mark.parametrize("mode", ["plugin", "engine"])
+def test_peaked_fixture_long_context_tokens_identical(gpu, files, mode):
+    """The same equality beyond the long-context threshold (640 cells): a 700-token prompt, then 24 greedy tokens whose attention runs on
+    the matrix-core kernel over cached cells (attn_flash_mfma.hip: rope + KV store in the QKV epilogue, keys split over workgroups,
+    spans merged in the launch) - through the plug-in's default graph and on the resident engine."""
+    if "small" not in SIZES:
+        pytest.skip("PM355_8D_SIZES without 'small'")
+    size, n_prompt, n_gen, n_ctx = "small", 700, 24, 1024
+    V = SHAPES[size]["n_vocab"]
+    prompt = F.prompt_tokens(V, n_prompt)
+    path = files.path(size, True)
+    ts, ls, _ = run_llama_driver(path, prompt, n_gen, ngl=0, n_ctx=n_ctx, threads=_threads(), flavour="scalar", timeout=3000)
+    expect = [F.peaked_next(prompt[-1], V)]
+    for _ in range(n_gen - 1):
+        expect.append(F.peaked_next(expect[-1], V))
+    assert ts.tolist() == expect
+    if mode == "engine":
+        tg, lg = _engine_greedy(path, size, prompt, n_gen, n_ctx=n_ctx)
+    else:
+        tg, lg, st = run_llama_driver(path, prompt, n_gen, ngl=99, n_ctx=n_ctx, threads=_threads(), timeout=1800, extra_args=GPU_ARGS,
+                                      env={"GGML_MI355_DEBUG_PLAN": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1"})
+        assert "cached-split" in st["stderr"], st["stderr"][-2000:]
+    print(f"\n[8d small peaked, 700-token prompt, {mode}] tokens {(tg == ts).sum()}/{n_gen} identical to the reference CPU; logits NMSE {_nmse(lg, ls):.2e}")
+    assert tg.tolist() == ts.tolist()
+    # (the 700-token batch runs the MFMA prefill path - F16 activations x dequantized F16 weights - and the reference the int8 path:
+    # north_star's 1e-3 tier for fp16 accumulation)
+    assert _nmse(lg, ls) < 1e-3
 
 
 @pytest.mark.parametrize("size", SIZES)

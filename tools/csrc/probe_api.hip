@@ -9,6 +9,11 @@ int pm355_probe_stream_read(const void * src, size_t bytes, int wg_per_cu, int u
     if (pm_launch_stream_read(src, bytes, wg_per_cu, unroll, sink, S(st))) return -3;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+int pm355_probe_chunk_read(const void * src, int n_wg, int nx, int64_t wgx_stride, int64_t wgy_stride, int64_t wave_stride, int64_t outer_stride,
+                           int64_t inner_stride, int64_t piece_stride, int chunk, int n_outer, void * sink, void * st) {
+    if (pm_launch_chunk_read(src, n_wg, nx, wgx_stride, wgy_stride, wave_stride, outer_stride, inner_stride, piece_stride, chunk, n_outer, sink, S(st))) return -3;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 /* measurement skeleton (engine_probe.hip): n_layers decode layers as ONE persistent launch on a run-ahead LDS-DMA weight loader.
  * w: region_stride * n_regions bytes of anything; act: n_layers * nph * act_stride floats; ctr: 33*128 + 64 zeroed bytes.
  * *err_out = watchdog code (0 = clean). Times the SECOND of two launches with HIP events: *us = microseconds per launch. */
