@@ -10,6 +10,8 @@
 //   REFDRV_OUT     binary dump: int32 {magic 0x52444c4c, n_prompt, n_gen, n_vocab}, int32 tokens[n_gen],
 //                  float logits[n_gen][n_vocab] (logits that produced each generated token)
 //   REFDRV_FORCE   comma-separated token ids fed instead of the argmax (teacher forcing; logits are still dumped)
+//   REFDRV_SHIFT   "step,n_keep,n_discard": before generation step `step` the context is shifted the way examples/main/main.cpp does when it
+//                  runs out of cells (llama_kv_cache_seq_rm + llama_kv_cache_seq_add, :583-:601): the next llama_decode runs the K-shift graph
 //   REFDRV_CHUNK   prompt tokens per llama_decode call (default: all = one prefill batch; clamped to n_batch)
 // Timing is wall-clock around llama_decode + llama_synchronize and the reference's llama_perf_context
 // (src/llama.cpp:23832-23862), printed as one JSON line on stdout.
@@ -81,6 +83,7 @@ int main(int argc, char ** argv) {
 
     // ---- greedy generation (first maximum wins, like llama_sampler_greedy, src/llama-sampling.cpp:390-397)
     std::vector<double> step_ms;
+    const std::vector<int> shift = parse_ids(getenv("REFDRV_SHIFT"));
     for (int i = 0; i < n_gen; ++i) {
         const float * lg = llama_get_logits_ith(ctx, -1);
         int best = 0;
@@ -89,6 +92,12 @@ int main(int argc, char ** argv) {
         all_logits.insert(all_logits.end(), lg, lg + n_vocab);
         if (i == n_gen - 1) break;
         llama_token next = (i < (int) force.size()) ? force[i] : best;
+        if (shift.size() == 3 && i == shift[0]) {
+            const int n_keep = shift[1], n_discard = shift[2];
+            llama_kv_cache_seq_rm (ctx, 0, n_keep, n_keep + n_discard);
+            llama_kv_cache_seq_add(ctx, 0, n_keep + n_discard, n_past, -n_discard);
+            n_past -= n_discard;
+        }
         const double t0 = now_ms();
         if (llama_decode(ctx, llama_batch_get_one(&next, 1, n_past, 0))) { fprintf(stderr, "refdrv: llama_decode(step %d) failed\n", i); return 5; }
         llama_synchronize(ctx);

@@ -409,7 +409,8 @@ bool supports_op_impl(const struct ggml_tensor * op) {
                    (!b || b->type == GGML_TYPE_F32 || b->type == GGML_TYPE_F16);
         case GGML_OP_ROPE: {
             const int mode = ((const int32_t *) op->op_params)[2];
-            return a->type == GGML_TYPE_F32 && (mode == 0 || mode == 2) && a->ne[0] % 2 == 0;
+            // F16: the in-place K-shift of an F16 cache (build_k_shift, src/llama.cpp:10708-10713)
+            return (a->type == GGML_TYPE_F32 || a->type == GGML_TYPE_F16) && op->type == a->type && (mode == 0 || mode == 2) && a->ne[0] % 2 == 0;
         }
         case GGML_OP_FLASH_ATTN_EXT: {
             // F16 K / V (the default KV cache type), or Q8_0 K and / or V (-ctk / -ctv q8_0: native blocks, attn_q8.hip)

@@ -123,7 +123,11 @@ __global__ __launch_bounds__(256) void soft_max_kernel(TD a, const char * mask, 
 
 // rope on x [d, heads, T, ne3] (strided) -> y (strided). pos int32 [T]. One 64-thread workgroup per (head, token, i3).
 struct RopeG { int n_dims, mode; float theta_scale, freq_scale, ext_factor, attn_factor, corr0, corr1; };
+// F16: x converted to f32, rotated, rounded back (ggml_compute_forward_rope_f16, ggml.c:14269-14391: the in-place K-shift of an F16 cache)
+template <bool F16>
 __global__ __launch_bounds__(64) void rope_generic_kernel(TD a, const int32_t * pos, const float * ff, TD d, RopeG r) {
+    auto ld = [](const char * p_) { return F16 ? h2f(*(const uint16_t *) p_) : *(const float *) p_; };
+    auto st = [](char * p_, float v) { if (F16) *(uint16_t *) p_ = f2h(v); else *(float *) p_ = v; };
     const long h = blockIdx.x, t = blockIdx.y, i3 = blockIdx.z;
     const char * src = a.data + h * a.nb[1] + t * a.nb[2] + i3 * a.nb[3];
     char * dst = d.data + h * d.nb[1] + t * d.nb[2] + i3 * d.nb[3];
@@ -144,13 +148,13 @@ __global__ __launch_bounds__(64) void rope_generic_kernel(TD a, const int32_t * 
                 ms *= 1.0f + 0.1f * logf(1.0f / r.freq_scale);
             }
             const float c = cosf(th) * ms, s = sinf(th) * ms;
-            const float x0 = *(const float *) (src + ia * a.nb[0]), x1 = *(const float *) (src + ib * a.nb[0]);
+            const float x0 = ld(src + ia * a.nb[0]), x1 = ld(src + ib * a.nb[0]);
             o0 = x0 * c - x1 * s; o1 = x0 * s + x1 * c;
         } else {
             ia = r.n_dims + 2 * (pair - half); ib = ia + 1;
-            o0 = *(const float *) (src + ia * a.nb[0]); o1 = *(const float *) (src + ib * a.nb[0]);
+            o0 = ld(src + ia * a.nb[0]); o1 = ld(src + ib * a.nb[0]);
         }
-        *(float *) (dst + ia * d.nb[0]) = o0; *(float *) (dst + ib * d.nb[0]) = o1;
+        st(dst + ia * d.nb[0], o0); st(dst + ib * d.nb[0], o1);
     }
 }
 
@@ -411,7 +415,7 @@ int pm355_op_flash_attn_ext(const pm355_tensor * q, const pm355_tensor * k, cons
 }
 int pm355_op_rope(const pm355_tensor * a, const int32_t * d_pos, const float * freq_factors, const pm355_tensor * dst,
                   const pm355_rope_params * rp, pm355_stream_t st) {
-    if (a->type != PM_F32 || dst->type != PM_F32 || !rp || rp->n_dims % 2 || rp->n_dims > a->ne[0] || a->ne[0] % 2) return PM355_E_UNSUPPORTED;
+    if ((a->type != PM_F32 && a->type != PM_F16) || dst->type != a->type || !rp || rp->n_dims % 2 || rp->n_dims > a->ne[0] || a->ne[0] % 2) return PM355_E_UNSUPPORTED;
     if (rp->mode & ~2) return PM355_E_UNSUPPORTED;                   // only NORM (0) and NEOX (2)
     pm_rope_cfg c;
     c.n_dims = rp->n_dims; c.mode = rp->mode; c.n_ctx_orig = rp->n_ctx_orig; c.freq_base = rp->freq_base; c.freq_scale = rp->freq_scale;
@@ -419,8 +423,12 @@ int pm355_op_rope(const pm355_tensor * a, const int32_t * d_pos, const float * f
     pm_rope_params(c);
     RopeG r = {c.n_dims, c.mode, c.theta_scale, c.freq_scale, c.ext_factor, c.attn_factor, c.corr0, c.corr1};
     (void) hipGetLastError();
-    hipLaunchKernelGGL(rope_generic_kernel, dim3((unsigned) a->ne[1], (unsigned) a->ne[2], (unsigned) a->ne[3]), dim3(64), 0, S(st),
-                       to_td(a), d_pos, freq_factors, to_td(dst), r);
+    if (a->type == PM_F16)
+        hipLaunchKernelGGL(rope_generic_kernel<true>, dim3((unsigned) a->ne[1], (unsigned) a->ne[2], (unsigned) a->ne[3]), dim3(64), 0, S(st),
+                           to_td(a), d_pos, freq_factors, to_td(dst), r);
+    else
+        hipLaunchKernelGGL(rope_generic_kernel<false>, dim3((unsigned) a->ne[1], (unsigned) a->ne[2], (unsigned) a->ne[3]), dim3(64), 0, S(st),
+                           to_td(a), d_pos, freq_factors, to_td(dst), r);
     OKRET();
 }
 int pm355_op_mul_mat_f(const pm355_tensor * a, const pm355_tensor * b, const pm355_tensor * dst, pm355_stream_t st) {

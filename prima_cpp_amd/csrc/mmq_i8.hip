@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64) void mmq_prep_kernel(const uint8_t * xq, long x
 // per-device scratch (grown on demand, like mmq.hip's f16 activation copy): quantized activations of an f32 call + the two tables
 // scratch per (device, stream): the tables of a pass and the quantized copy of an f32 call are written and read in stream order, so two
 // streams of one device (two ggml backends, the engine next to the plug-in) must not share them
-struct Scr { hipStream_t st; uint8_t * p; size_t bytes; uint64_t use; };
+struct Scr { hipStream_t st; uint8_t * p; size_t bytes; uint64_t use; int tab_K; };   // tab_K: the K the tables in p were last written for (0: none)
 constexpr int NSCR = 8;
 Scr g_scr[16][NSCR] = {};
 uint64_t g_tick = 0;
@@ -464,13 +464,21 @@ Scr * scratch(int dev, hipStream_t st, int K, bool lookup_only) {
         if (c.p && c.st == st) { e = &c; break; }
         if (!c.p) { if (lru->p) lru = &c; } else if (lru->p && c.use < lru->use) lru = &c;
     }
-    if (e && (e->bytes >= need || (lookup_only && e->bytes >= 2 * tab))) { e->use = ++g_tick; return e; }
-    if (lookup_only) return nullptr;
+    // lookup_only (a consumer that re-uses tables a producer wrote): the entry of this stream must still exist (not evicted by a ninth
+    // stream, not re-allocated for a larger K in between) AND hold tables for this K - else the launch fails instead of reading zeros
+    if (lookup_only) {
+        if (!e || e->tab_K != K || e->bytes < 2 * tab) return nullptr;
+        e->use = ++g_tick;
+        return e;
+    }
+    if (e && e->bytes >= need) { e->use = ++g_tick; e->tab_K = K; return e; }
     if (!e) e = lru;
     if (e->p) { (void) hipDeviceSynchronize(); (void) hipFree(e->p); e->p = nullptr; e->bytes = 0; }
     if (hipMalloc((void **) &e->p, need) != hipSuccess) { e->p = nullptr; return nullptr; }
-    (void) hipMemset(e->p, 0, need);                                // table slots no quantizer ever wrote stay finite (they are multiplied by scale 0)
-    e->st = st; e->bytes = need; e->use = ++g_tick;
+    // table slots no quantizer ever wrote stay finite (they are multiplied by scale 0). ON THE OWNING STREAM: a null-stream memset is not ordered
+    // against a non-blocking stream and zeroed the tables the first producer had just written (two ranks on one GPU, tests/test_gpu_ring.py)
+    (void) hipMemsetAsync(e->p, 0, need, st);
+    e->st = st; e->bytes = need; e->use = ++g_tick; e->tab_K = K;
     return e;
 }
 // activation tables of every 32-token pass

@@ -221,3 +221,26 @@ def test_llama_decode_plugin_quantized_k_cache_without_flash_attn(gpu, name, tmp
     m = re.search(r"graph_compute (\d+),", stats["stderr"])
     assert m and int(m.group(1)) <= 2 * (n + 2), stats["stderr"][-800:]          # prompt + warm-up + n - 1 tokens, two splits each
     _check(f"tiny_{name} -ctk q8_0 (no flash attention)", toks, logits, path, z["prompt"], n, 64, cpu_args=kv, nmse_floor=1e-3, err_floor=5e-2)
+
+
+# F16 caches only: with a quantized K cache the reference's own CPU backend cannot run the K-shift graph at all - its CPY / CAST Q8_0 -> F32
+# falls into GGML_ABORT("fatal error") (ggml_compute_forward_dup, ggml.c:8992-8996; the abort handler then hangs on its gdb fork) - so there
+# is no reference run to compare with. The plug-in serves that graph's ops (tests/test_gpu_ops.py::test_native_q8_0_cache_view_matmul_and_
+# dequantizing_copy, tests/test_plugin_plan.py::test_k_shift_graph_is_accepted_by_the_plugin) like the CUDA plug-in does.
+@pytest.mark.parametrize("kv", [[]], ids=["f16"])
+def test_llama_decode_plugin_context_shift(gpu, kv, tmp_path, monkeypatch):
+    """A context shift in mid-generation the way examples/main/main.cpp does it (llama_kv_cache_seq_rm + llama_kv_cache_seq_add, :583-:601):
+    the next llama_decode runs build_k_shift (src/llama.cpp:10665-10719) on the plug-in's KV buffer - ROPE in place on the strided F16 view
+    of the K cache (ggml_compute_forward_rope_f16), or for a Q8_0 cache CPY Q8_0 -> F32, ROPE, CPY F32 -> Q8_0 - and the shifted cache is
+    what every later token attends to. Same binary, same shift at -ngl 0 is the reference."""
+    z = np.load(os.path.join(HERE, "golden", "tiny_llama_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / "tiny.gguf"), z)
+    n = 12
+    t0, l0, _ = run_llama_driver(path, z["prompt"], n, ngl=99, n_ctx=64, extra_args=GPU_ARGS + kv)
+    monkeypatch.setenv("REFDRV_SHIFT", "4,2,3")
+    toks, logits, st = run_llama_driver(path, z["prompt"], n, ngl=99, n_ctx=64, extra_args=GPU_ARGS + kv)
+    assert "MI355X0 KV buffer size" in st["stderr"]
+    # the shift happened: identical up to the step it is applied at (same tokens fed so far), different logits right after it
+    assert _nmse(logits[:5], l0[:5]) < 1e-12 and _nmse(logits[5], l0[5]) > 1e-4
+    _check(f"tiny_llama context shift {' '.join(kv)}", toks, logits, path, z["prompt"], n, 64, cpu_args=kv,
+           nmse_floor=1e-3 if kv else 1e-6, err_floor=5e-2 if kv else 1e-3)

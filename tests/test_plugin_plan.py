@@ -144,3 +144,19 @@ def test_round3_long_context_attention_lowers_to_the_matrix_core_kernel(tmp_path
         assert segs, st["stderr"][-3000:]
         body = segs[-1]
         assert body.count(want) == 2 and never not in body, body[:3000]
+
+
+@pytest.mark.parametrize("kv", [[], ["-ctk", "q8_0"]], ids=["f16", "k_q8_0"])
+def test_k_shift_graph_is_accepted_by_the_plugin(kv, tmp_path, monkeypatch):
+    """build_k_shift (src/llama.cpp:10665) after a context shift: every node lands on the plug-in's pre-allocated KV buffer, so supports_op
+    must accept ROPE on the F16 cache view (and the CPY pair around an F32 ROPE for a Q8_0 cache) - the scheduler aborts otherwise
+    ("pre-allocated tensor in a backend that cannot run the operation")."""
+    z = np.load(os.path.join(HERE, "golden", "tiny_llama_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / "tiny_llama.gguf"), z)
+    monkeypatch.setenv("REFDRV_SHIFT", "2,2,3")
+    _, _, st = run_llama_driver(path, z["prompt"], 6, ngl=99, n_ctx=64, threads=1, extra_args=["--keep-out-in-cuda"] + kv,
+                                env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1"}, flavour="avx2", timeout=120)
+    assert "cannot run the operation" not in st["stderr"]
+    assert "ROPE 'cache_k_l0 (view)" in st["stderr"] and "ROPE 'cache_k_l1 (view)" in st["stderr"], st["stderr"][-3000:]
+    if kv:
+        assert st["stderr"].count("CPY 'cache_k_l0 (view) (copy") == 2

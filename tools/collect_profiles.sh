@@ -39,8 +39,8 @@ json.dump({"source": "rocprofv3 --pmc <counter> --kernel-trace --output-format c
            "traffic_over_algorithmic": fr / alg, "kernel_source_sha16": src_hash()}, open("$OUT/${R}_pmc_traffic.json", "w"), indent=1)
 print("traffic/algorithmic", fr / alg)
 PY
-# (3) prefill GEMM: achieved TFLOP/s + MFMA / VALU / LDS utilisation counters, one pass per counter
-{ echo "prefill GEMM (ffn_gate shape, T = 2048), tools/gemm_probe.py; counters: separate rocprofv3 --pmc <counter> --kernel-trace passes, 4 launches each";
+# (3) prefill GEMM: achieved TFLOP/s + MFMA / VALU / LDS utilisation counters, one pass per counter (SKIP_PREFILL=1: leave it out)
+[ "${SKIP_PREFILL:-0}" = 1 ] || { echo "prefill GEMM (ffn_gate shape, T = 2048), tools/gemm_probe.py; counters: separate rocprofv3 --pmc <counter> --kernel-trace passes, 4 launches each";
   for k in 1 2; do echo "== PM355_GEMM_KERNEL=$k (1 = 128x256 tile, first generation; 2 = 256x256 tile, fragment double buffering)";
     for s in gate wo down wk; do PM355_GEMM_KERNEL=$k python $OLDPWD/tools/gemm_probe.py 2048 $s 2>/dev/null; done; done
   echo "== default kernel selection"; for s in gate wo down wk; do python $OLDPWD/tools/gemm_probe.py 2048 $s 2>/dev/null; done
