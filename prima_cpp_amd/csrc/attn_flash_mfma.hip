@@ -196,17 +196,21 @@ __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
         const int idx = (int) (t - base);
         if (idx == nact - 1) __hip_atomic_store((PM_G unsigned *) (p.ticket + 16 + g), t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int me = idx - (nact - NM);
+        int me_ = me;
         if (me >= 0) {
-            for (int spin = 0; spin < (1 << 22); ++spin) {
+            int spin = 0;
+            for (; spin < (1 << 22); ++spin) {
                 if (__hip_atomic_load((PM_G unsigned *) (p.ticket + g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base >= (unsigned) nact) break;
                 __builtin_amdgcn_s_sleep(1);
             }
+            if (spin == (1 << 22)) me_ = me + (1 << 20);          // never seen; if it ever happens the merger writes NaN instead of a wrong sum
         }
-        last_flag = me;
+        last_flag = me_;
     }
     __syncthreads();
     tsv[4] = PM_TS_NOW();
-    const int me = last_flag;
+    const bool timed_out = last_flag >= (1 << 20);
+    const int me = timed_out ? last_flag - (1 << 20) : last_flag;
 #ifdef PM_TS
     auto ts_out = [&]() {
         const int lin = blockIdx.y * gridDim.x + blockIdx.x;
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
     if (tid < cnt) {
         float4 a = red[tid];
         for (int sl = 1; sl < SL; ++sl) { const float4 b = red[sl * cnt + tid]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        if (timed_out) a.x = a.y = a.z = a.w = __builtin_nanf("");      // (a workgroup of this KV head never arrived: fail loudly downstream)
         *((float4 *) (p.out + (long) g * R * DH) + i0 + tid) = a;
     }
 #ifdef PM_TS
