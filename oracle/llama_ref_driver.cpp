@@ -12,6 +12,8 @@
 //   REFDRV_FORCE   comma-separated token ids fed instead of the argmax (teacher forcing; logits are still dumped)
 //   REFDRV_SHIFT   "step,n_keep,n_discard": before generation step `step` the context is shifted the way examples/main/main.cpp does when it
 //                  runs out of cells (llama_kv_cache_seq_rm + llama_kv_cache_seq_add, :583-:601): the next llama_decode runs the K-shift graph
+//   REFDRV_RM      "step,p0,p1": before generation step `step` positions [p0, p1) of the sequence are removed (llama_kv_cache_seq_rm): holes
+//   REFDRV_DEFRAG  "step": before generation step `step` llama_kv_cache_defrag + llama_kv_cache_update (build_defrag, src/llama.cpp:10721)
 //   REFDRV_CHUNK   prompt tokens per llama_decode call (default: all = one prefill batch; clamped to n_batch)
 // Timing is wall-clock around llama_decode + llama_synchronize and the reference's llama_perf_context
 // (src/llama.cpp:23832-23862), printed as one JSON line on stdout.
@@ -84,6 +86,7 @@ int main(int argc, char ** argv) {
     // ---- greedy generation (first maximum wins, like llama_sampler_greedy, src/llama-sampling.cpp:390-397)
     std::vector<double> step_ms;
     const std::vector<int> shift = parse_ids(getenv("REFDRV_SHIFT"));
+    const std::vector<int> rm = parse_ids(getenv("REFDRV_RM")), defrag = parse_ids(getenv("REFDRV_DEFRAG"));
     for (int i = 0; i < n_gen; ++i) {
         const float * lg = llama_get_logits_ith(ctx, -1);
         int best = 0;
@@ -98,6 +101,8 @@ int main(int argc, char ** argv) {
             llama_kv_cache_seq_add(ctx, 0, n_keep + n_discard, n_past, -n_discard);
             n_past -= n_discard;
         }
+        if (rm.size() == 3 && i == rm[0]) llama_kv_cache_seq_rm(ctx, 0, rm[1], rm[2]);
+        if (defrag.size() == 1 && i == defrag[0]) { llama_kv_cache_defrag(ctx); llama_kv_cache_update(ctx); }
         const double t0 = now_ms();
         if (llama_decode(ctx, llama_batch_get_one(&next, 1, n_past, 0))) { fprintf(stderr, "refdrv: llama_decode(step %d) failed\n", i); return 5; }
         llama_synchronize(ctx);

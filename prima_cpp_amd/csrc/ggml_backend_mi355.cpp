@@ -400,6 +400,10 @@ bool supports_op_impl(const struct ggml_tensor * op) {
             // KV store into a quantized cache: f32 rows -> contiguous native Q8_0 blocks of a 1-D cache tensor (attn_q8.hip)
             if (op->op == GGML_OP_CPY && ts == GGML_TYPE_F32 && td == GGML_TYPE_Q8_0)
                 return a->nb[0] == 4 && a->ne[0] % 32 == 0 && ggml_is_contiguous(op) && op->view_src && !is_soa_tensor(op);
+            // defragmentation of a quantized cache: block-wise copy between two views of native Q8_0 blocks (build_defrag, src/llama.cpp:10721)
+            if (ts == GGML_TYPE_Q8_0 && td == GGML_TYPE_Q8_0)
+                return op->op == GGML_OP_CPY && !is_soa_tensor(a) && !is_soa_tensor(op) && a->ne[0] % 32 == 0 && ggml_are_same_shape(a, op) &&
+                       a->nb[0] == ggml_type_size(a->type) && op->nb[0] == ggml_type_size(op->type);
             // K-shift of a quantized cache: dequantizing copy of native Q8_0 rows (build_k_shift, src/llama.cpp:10665)
             if (ts == GGML_TYPE_Q8_0 && td == GGML_TYPE_F32) return !is_soa_tensor(a) && a->ne[0] % 32 == 0 && a->nb[0] == ggml_type_size(a->type);
             return (ts == GGML_TYPE_F32 || ts == GGML_TYPE_F16) && (td == GGML_TYPE_F32 || td == GGML_TYPE_F16);

@@ -222,6 +222,20 @@ __global__ void cpy_q80_f32_kernel(TD s, TD d, long n) {
     *(float *) (d.data + d0 * d.nb[0] + d1 * d.nb[1] + d2 * d.nb[2] + d3 * d.nb[3]) = v;
 }
 
+// CPY Q8_0 -> Q8_0 between views of native blocks (any row strides): the cell moves of build_defrag on a quantized cache
+// (src/llama.cpp:10721-10790; the CPU backend copies bytes: ggml_compute_forward_dup_bytes, ggml.c:8527). One thread per 34-byte block.
+__global__ void cpy_q80_q80_kernel(TD s, TD d, long n_blocks) {
+    const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_blocks) return;
+    const long nb0 = d.ne[0] / 32;
+    long r = i;
+    const long b0 = r % nb0; r /= nb0; const long i1 = r % d.ne[1]; r /= d.ne[1]; const long i2 = r % d.ne[2]; const long i3 = r / d.ne[2];
+    const uint16_t * sp = (const uint16_t *) (s.data + b0 * 34 + i1 * s.nb[1] + i2 * s.nb[2] + i3 * s.nb[3]);
+    uint16_t * dp = (uint16_t *) (d.data + b0 * 34 + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+#pragma unroll
+    for (int k = 0; k < 17; ++k) dp[k] = sp[k];
+}
+
 __global__ void get_rows_f32_kernel(TD a, const int32_t * idx, long n_idx, TD d) {
     const long i = (long) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.ne[0] * n_idx) return;
@@ -318,6 +332,14 @@ extern "C" {
 
 int pm355_op_cpy(const pm355_tensor * src, const pm355_tensor * dst, pm355_stream_t st) {
     const int ts = src->type, td = dst->type;
+    if (ts == PM_Q8_0 && td == PM_Q8_0) {            // cell moves of the defragmentation graph on a quantized cache: same shape, block-wise bytes
+        for (int i = 0; i < 4; ++i) if (src->ne[i] != dst->ne[i]) return PM355_E_SHAPE;
+        if (src->ne[0] % 32 || src->nb[0] != 34 || dst->nb[0] != 34) return PM355_E_SHAPE;
+        const long nblk = nelem(dst) / 32;
+        (void) hipGetLastError();
+        hipLaunchKernelGGL(cpy_q80_q80_kernel, GRID(nblk), 0, S(st), to_td(src), to_td(dst), nblk);
+        OKRET();
+    }
     if (td == PM_Q8_0) {                             // KV store into a quantized cache (attn_q8.hip); dst = contiguous native blocks
         if (nelem(src) != nelem(dst)) return PM355_E_SHAPE;
         (void) hipGetLastError();

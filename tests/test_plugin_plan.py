@@ -160,3 +160,37 @@ def test_k_shift_graph_is_accepted_by_the_plugin(kv, tmp_path, monkeypatch):
     assert "ROPE 'cache_k_l0 (view)" in st["stderr"] and "ROPE 'cache_k_l1 (view)" in st["stderr"], st["stderr"][-3000:]
     if kv:
         assert st["stderr"].count("CPY 'cache_k_l0 (view) (copy") == 2
+
+
+@pytest.mark.parametrize("kv", [[], ["-ctk", "q8_0"], ["-fa", "-ctk", "q8_0", "-ctv", "q8_0"]], ids=["f16", "k_q8_0", "fa_kv_q8_0"])
+def test_defrag_graph_is_accepted_by_the_plugin(kv, tmp_path, monkeypatch):
+    """build_defrag (src/llama.cpp:10721-10790) after holes were cut into the cache (llama_kv_cache_seq_rm) and llama_kv_cache_defrag +
+    llama_kv_cache_update were called: one CPY between two views of the K cache and one of the V cache per layer and run of moved cells -
+    F16 strided views, or views of native Q8_0 blocks (block-wise copy) - all on the plug-in's pre-allocated KV buffer."""
+    z = np.load(os.path.join(HERE, "golden", "tiny_llama_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / "tiny_llama.gguf"), z)
+    monkeypatch.setenv("REFDRV_RM", "3,2,5")
+    monkeypatch.setenv("REFDRV_DEFRAG", "5")
+    _, _, st = run_llama_driver(path, z["prompt"], 8, ngl=99, n_ctx=64, threads=1, extra_args=["--keep-out-in-cuda"] + kv,
+                                env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1"}, flavour="avx2", timeout=120)
+    assert "cannot run the operation" not in st["stderr"]
+    segs = [g for g in st["stderr"].split("ggml-mi355 plan:") if "CPY 'cache_k_l0 (view) (copy of cache_k_l0 (view))'" in g]
+    assert len(segs) == 1 and segs[0].count("CPY 'cache_") == 4, st["stderr"][-3000:]
+
+
+def test_reference_defrag_leaves_an_f16_cache_decode_unchanged(tmp_path, monkeypatch):
+    """What the driver's REFDRV_RM / REFDRV_DEFRAG options do, on the reference's CPU backend: defragmentation moves cells, the logits of the
+    following tokens do not change (F16 cache). With a Q8_0 cache the reference's own byte copy mis-sizes block rows (ggml_compute_forward_
+    dup_same_cont multiplies ELEMENT counts with the 34-byte block size, ggml.c:7865-7893) and the logits move by half their range: there is no
+    parity target for defragmentation of quantized caches - the plug-in moves whole blocks (cpy_q80_q80_kernel)."""
+    z = np.load(os.path.join(HERE, "golden", "tiny_llama_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / "tiny_llama.gguf"), z)
+    monkeypatch.setenv("REFDRV_RM", "3,2,5")
+    t0, l0, _ = run_llama_driver(path, z["prompt"], 10, ngl=0, n_ctx=64, flavour="scalar")
+    monkeypatch.setenv("REFDRV_DEFRAG", "5")
+    t1, l1, _ = run_llama_driver(path, z["prompt"], 10, ngl=0, n_ctx=64, flavour="scalar", force=t0[:-1])
+    assert np.abs(l1 - l0).max() <= 1e-4 * np.abs(l0).max()
+    t2, l2, _ = run_llama_driver(path, z["prompt"], 10, ngl=0, n_ctx=64, flavour="scalar", force=t0[:-1], extra_args=["-ctk", "q8_0"])
+    monkeypatch.delenv("REFDRV_DEFRAG")
+    t3, l3, _ = run_llama_driver(path, z["prompt"], 10, ngl=0, n_ctx=64, flavour="scalar", force=t0[:-1], extra_args=["-ctk", "q8_0"])
+    assert np.abs(l2[:6] - l3[:6]).max() == 0.0 and np.abs(l2[6:] - l3[6:]).max() > 0.05 * np.abs(l3).max()      # the reference's bug, pinned
