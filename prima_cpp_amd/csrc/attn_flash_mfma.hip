@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
     for (int it = 0; it < 2; ++it) {
         const int u = tid + 256 * it;                // (cnt x SL <= 512 units)
         const int item = u % max(cnt, 1), sl = u / max(cnt, 1);
-        const int c_lo = sl * nact / SL, c_hi = (sl + 1) * nact / SL;
+        const int c_lo = sl * nact / SL;
         const float4 * src = (const float4 *) (p.P + (long) g * R * DH) + min(i0 + item, items - 1);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
