@@ -279,7 +279,8 @@ PM355_API int pm355_mul_mat_vec_qkv_check(const pm355_matvec_job * jobs, int64_t
 PM355_API int pm355_attn_cached(const float * q_rot, void * k_cache, void * v_cache, const int32_t * d_pos, const int32_t * d_cell_nkv,
                                 const void * mask, float * out, int n_head, int n_head_kv, int head_dim, int n_ctx, float kq_scale,
                                 int max_keys, int flags, pm355_stream_t stream);
-/* The same over LONG contexts (cells attended >= the caller's split threshold): the GQA group's scores and the P.V product on the matrix
+/* The same (llm_build_kqv's MUL_MAT(k, q) -> SOFT_MAX_EXT -> MUL_MAT(v, kq), src/llama.cpp:10032-10095; CUDA plug-in: fattn-vec-f16.cuh) over LONG
+ * contexts (cells attended >= the caller's split threshold): the GQA group's scores and the P.V product on the matrix
  * cores, keys split over workgroups, partials merged in the launch (attn_flash_mfma.hip). Transposed F16 V cache (no flash-attention
  * layout), head_dim 64 / 128, <= 16 query heads per KV head. scratch = pm355_attn_split_scratch_floats() floats, zeroed once by the
  * caller; max_cells sizes the grid (>= cells attended; 0 = n_ctx). flags: PM355_ATTN_MASK_F16 only. */
