@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-extras", action="store_true", help="skip extra_configs / plugin_decode / the llama_decode CPU baseline")
     ap.add_argument("--tmp", default=os.environ.get("TMPDIR", "/tmp"), help="where the synthetic GGUF files of the plug-in legs go")
+    ap.add_argument("--section", default="", help="(internal) run ONE extra leg in this process and print its JSON: prefill_qwen")
     return ap.parse_args()
 
 
@@ -508,8 +509,20 @@ def cpu_llama_decode(tmp, path_8b, hp70):
     return out
 
 
+def section_prefill_qwen():
+    """BASELINE.json config 5's prompt pass on one GPU: Qwen2.5-72B Q6_K, 2048-token prompt (every weight GEMM the Q6_K instantiation)."""
+    hq, mq, nq = model_cfg("qwen2.5-72b")
+    pq = probe_prefill(hq, mq, 2048, small_batches=(8, 32))
+    pq["workload"] = f"{nq}: 2048-token prompt, whole model, 1 GPU (config 5's prefill; the 8-GPU pipelined form is `ring_prefill` of --gpus N)"
+    print(json.dumps(pq), flush=True)
+
+
 def main():
     a = parse()
+    if a.section == "prefill_qwen":
+        assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+        section_prefill_qwen()
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -729,11 +742,12 @@ def main():
                     extras.append({"workload": name, "error": str(e)[:300]})
             result["extra_configs"] = extras
             # BASELINE.json config 5's prompt pass on one GPU: Qwen2.5-72B Q6_K, 2048-token prompt (every weight GEMM the Q6_K instantiation)
+            # (in a process of its own: the newest leg must not be able to take the driver line down with it)
             try:
-                hq, mq, nq = model_cfg("qwen2.5-72b")
-                pq = probe_prefill(hq, mq, 2048, small_batches=(8, 32))
-                pq["workload"] = f"{nq}: 2048-token prompt, whole model, 1 GPU (config 5's prefill; the 8-GPU pipelined form is `ring_prefill` of --gpus N)"
-                result["prefill_qwen25_72b_q6k"] = pq
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--section", "prefill_qwen"], capture_output=True, text=True, timeout=420)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                result["prefill_qwen25_72b_q6k"] = json.loads(line[-1]) if line else {"error": f"rc {r.returncode}: {r.stderr[-400:]}"}
             except Exception as e:
                 result["prefill_qwen25_72b_q6k"] = {"error": str(e)[-400:]}
             try:
