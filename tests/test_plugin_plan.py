@@ -194,3 +194,20 @@ def test_reference_defrag_leaves_an_f16_cache_decode_unchanged(tmp_path, monkeyp
     monkeypatch.delenv("REFDRV_DEFRAG")
     t3, l3, _ = run_llama_driver(path, z["prompt"], 10, ngl=0, n_ctx=64, flavour="scalar", force=t0[:-1], extra_args=["-ctk", "q8_0"])
     assert np.abs(l2[:6] - l3[:6]).max() == 0.0 and np.abs(l2[6:] - l3[6:]).max() > 0.05 * np.abs(l3).max()      # the reference's bug, pinned
+
+
+def test_neox_rope_graphs_keep_the_round2_attention_form(tmp_path):
+    """build_qwen2 rotates with NEOX pairs (i, i + n_dims / 2): a workgroup's row slice of wq / wk does not hold both halves of a pair, so the
+    QKV epilogue cannot rotate there - the planner must keep RoPE + KV store inside the attention kernel (no rope table, no epilogue step)
+    however the shapes divide."""
+    from _bind import Ref, best_ref_flavour
+    import _fixtures8d as F
+    ref = Ref(best_ref_flavour())
+    path = str(tmp_path / "q.gguf")
+    F.write_model(path, ref, arch=1, n_layer=2, n_embd=1024, n_head=8, n_head_kv=4, n_ff=1024, n_vocab=512, tag="planq")
+    _, _, st = run_llama_driver(path, [1, 5, 9], 3, ngl=99, n_ctx=64, threads=1, extra_args=["--keep-out-in-cuda"],
+                                env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1"}, flavour="avx2", timeout=120)
+    plans = [tuple(int(x) for x in m.groups()) for m in PLAN.finditer(st["stderr"])]
+    decode = [p for p in plans if p[0] > 3 and p[6] == 1]
+    assert decode and all(p[3] == 2 and p[2] == 8 for p in decode), plans           # 2 attention + 8 fused mat-vec launches for 2 layers
+    assert "rope table" not in st["stderr"] and "matvec + rope + KV store" not in st["stderr"] and "fused mask=" in st["stderr"]
