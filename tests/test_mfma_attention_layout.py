@@ -71,3 +71,29 @@ def test_rows_of_the_two_score_tiles_cover_every_key_of_the_tile_once():
     col = np.arange(16)
     a = 8 * (col // 4) + col % 4
     assert sorted(np.concatenate([a, a + 4]).tolist()) == list(range(32))
+
+
+def test_merger_partition_covers_every_output_and_partial_exactly_once():
+    """The span merge of attn_flash_mfma.hip, as index arithmetic: NM = min(8, nact) mergers, merger `me` owns float4 items [me ipm, me ipm + cnt),
+    a thread unit u = (item, slice) sums the partials [sl nact / SL, (sl + 1) nact / SL) - at most 8 per unit, at most 2 x 256 units per
+    merger. Every (output item, partial) pair must be summed exactly once, for every head count, head_dim and number of active spans."""
+    for DH in (64, 128):
+        for R in range(1, 17):
+            items = R * DH // 4
+            for nact in range(1, 65):
+                NM = min(8, nact)
+                ipm = (items + NM - 1) // NM
+                seen = np.zeros((items, nact), dtype=np.int32)
+                for me in range(NM):
+                    i0 = me * ipm
+                    cnt = max(0, min(ipm, items - i0))
+                    SL = min(8, nact)
+                    if cnt * SL > 512:
+                        SL = 512 // cnt
+                    assert SL >= 1 and cnt * SL <= 512, (DH, R, nact, me)
+                    for u in range(cnt * SL):
+                        item, sl = u % cnt, u // cnt
+                        c_lo, c_hi = sl * nact // SL, (sl + 1) * nact // SL
+                        assert c_hi - c_lo <= 8, (DH, R, nact, me, sl)
+                        seen[i0 + item, c_lo:c_hi] += 1
+                assert (seen == 1).all(), (DH, R, nact)
