@@ -287,6 +287,9 @@ PM355_API int pm355_attn_cached(const float * q_rot, void * k_cache, void * v_ca
 PM355_API int pm355_attn_cached_long(const float * q_rot, void * k_cache, void * v_cache, const int32_t * d_pos, const int32_t * d_cell_nkv,
                                      const void * mask, float * out, float * scratch, int n_head, int n_head_kv, int head_dim, int n_ctx,
                                      float kq_scale, int max_cells, int flags, pm355_stream_t stream);
+/* 0 when pm355_attn_cached_long serves the shape (head_dim 64 / 128, <= 16 KV heads, <= 16 query heads per KV head, n_ctx % 8 == 0); callers
+ * keep pm355_attn_token's split form otherwise (e.g. MHA models with 32 / 40 KV heads). No device work. */
+PM355_API int pm355_attn_cached_long_check(int n_head, int n_head_kv, int head_dim, int n_ctx);
 /* p[0] = a, p[1] = b on the stream (values travel as kernel arguments: no host buffer lifetime to manage) */
 PM355_API int pm355_set_i32x2(int32_t * d_p, int32_t a, int32_t b, pm355_stream_t stream);
 /* greedy sampler (src/llama-sampling.cpp:390-397): index of the first maximum */

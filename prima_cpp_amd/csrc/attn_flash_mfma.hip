@@ -25,6 +25,7 @@
 // tolerance for these ops, NMSE 5e-4 - tests compare against float64 on the same cache values at 2e-3 of max |out|).
 #include "attn_device.h"
 #include "pm355_layer_ops.h"
+#include "pm355_kernels.h"
 
 namespace {
 
@@ -296,10 +297,20 @@ __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
 
 // q = rotated, F16-rounded query rows; the caches already hold this token (transposed V cache). scratch: pm_attn_flash_scratch_floats()
 // zeroed once. -1: shape not served (head_dim 64 / 128, <= 16 query heads per KV head, n_ctx % 8 == 0).
+// Shapes the matrix-core kernel serves: head_dim 64 / 128, <= 16 query heads per KV head, n_ctx % 8 == 0, and <= 16 KV heads - the arrival
+// counters live at ticket[g] / ticket[16 + g] and the bounded spin of the merging workgroups assumes that the whole grid (n_head_kv x <= 64 spans
+// <= 2 x CUs workgroups of 4 waves) is resident. MHA models (Llama-2-7B / 13B: 32 / 40 KV heads) keep the round-2 kernel (attn_flash.hip).
+int pm_attn_flash_cached_ok(int H, int Hkv, int dh, int n_ctx) {
+    if ((dh != 64 && dh != 128) || Hkv < 1 || H % Hkv || H / Hkv > RMAXM || n_ctx % 8 || Hkv > 16) return -1;
+    int parts = 256 / Hkv;
+    parts = parts < 16 ? 16 : parts > 64 ? 64 : parts;
+    return Hkv * parts <= 2 * pm_device_cus() ? 0 : -1;
+}
+
 int pm_launch_attn_flash_cached(const float * q, void * kc, void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride, float * out,
                                 float * scratch, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st, const int32_t * dyn,
                                 const void * mask, int mask_f16, int max_cells) {
-    if ((dh != 64 && dh != 128) || H % Hkv || H / Hkv > RMAXM || n_ctx % 8 || !scratch || Hkv > 16) return -1;   // (16 x NMERGE spinning workgroups at most; counters at ticket[g], ticket[16 + g])
+    if (!scratch || pm_attn_flash_cached_ok(H, Hkv, dh, n_ctx)) return -1;
     if (!pos0) pos0 = dyn;
     if (!pos0) return -1;
     const int CK = 128;

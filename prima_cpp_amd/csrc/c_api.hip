@@ -338,6 +338,7 @@ int pm355_attn_cached_long(const float * q_rot, void * kc, void * vc, const int3
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_attn_cached_long_check(int H, int Hkv, int dh, int n_ctx) { return pm_attn_flash_cached_ok(H, Hkv, dh, n_ctx) ? PM355_E_UNSUPPORTED : 0; }
 int pm355_attn_token(const pm355_attn_token_args * a, const pm355_rope_params * rp, pm355_stream_t st) {
     if (!a || !rp || rp->n_dims % 2 || rp->n_dims > a->head_dim) return fail(PM355_E_SHAPE, "attn_token: n_dims");
     if (!a->d_pos || !a->d_cell_nkv || !a->q || !a->k || !a->v || !a->k_cache || !a->v_cache || !a->out) return fail(PM355_E_SHAPE, "attn_token: null pointer");

@@ -341,7 +341,7 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
     float * bufs[2] = {m->x, m->x1};
     // rope + KV store in the QKV epilogue: NORM-mode rope, one-workgroup-per-head attention regime
     bool epi = m->qkv_epi && m->rope_tab && !(m->rope.mode & 2) &&
-               (!m->long_ctx || (m->use_flash && m->attn_mfma && (dh == 64 || dh == 128) && H / Hkv <= 8 && hp.n_ctx % 8 == 0));
+               (!m->long_ctx || (m->use_flash && m->attn_mfma && H / Hkv <= 8 && pm_attn_flash_cached_ok(H, Hkv, dh, hp.n_ctx) == 0));
     if (epi) pm_launch_rope_table(m->rope, m->d_pos, m->d_ctl, (const float *) m->rope_freqs.d, m->rope_tab, st);
     for (int il = m->lo; il < m->hi; ++il) {
         Layer Lv = layer_acquire(m, il, st); Layer & L = Lv;

@@ -211,3 +211,28 @@ def test_neox_rope_graphs_keep_the_round2_attention_form(tmp_path):
     decode = [p for p in plans if p[0] > 3 and p[6] == 1]
     assert decode and all(p[3] == 2 and p[2] == 8 for p in decode), plans           # 2 attention + 8 fused mat-vec launches for 2 layers
     assert "rope table" not in st["stderr"] and "matvec + rope + KV store" not in st["stderr"] and "fused mask=" in st["stderr"]
+
+
+def test_mha_models_keep_the_round2_long_context_kernel(tmp_path):
+    """More than 16 KV heads (Llama-2-7B / 13B style multi-head attention): the matrix-core long-context kernel does not serve the shape
+    (pm355_attn_cached_long_check), so beyond the split threshold the planner must NOT emit the QKV-epilogue + cached-split form - the launch
+    would be refused at run time - but the round-2 one (plain QKV mat-vec, rope + KV store + split attention in one launch); a GQA
+    model with the same threshold does take the matrix-core form."""
+    from _bind import Ref, best_ref_flavour
+    import _fixtures8d as F
+    ref = Ref(best_ref_flavour())
+    for n_head_kv, want in ((32, "split"), (8, "cached-split")):
+        path = str(tmp_path / f"mha{n_head_kv}.gguf")
+        F.write_model(path, ref, arch=0, n_layer=1, n_embd=2048, n_head=32, n_head_kv=n_head_kv, n_ff=1024, n_vocab=512, tag=f"planmha{n_head_kv}")
+        _, _, st = run_llama_driver(path, list(range(1, 41)), 3, ngl=99, n_ctx=128, threads=1, extra_args=["--keep-out-in-cuda"],
+                                    env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1", "GGML_MI355_ATTN_SPLIT_MIN": "32"},
+                                    flavour="avx2", timeout=180)
+        plans = [tuple(int(x) for x in m.groups()) for m in PLAN.finditer(st["stderr"])]
+        decode = [p for p in plans if p[0] > 3 and p[6] == 1 and p[8] >= 32]
+        assert decode and all(p[3] == 1 and p[2] == 4 for p in decode), (n_head_kv, plans)
+        segs = [g for g in st["stderr"].split("ggml-mi355 plan: ")[1:] if "single_token=1" in g.split("\n")[0] and " attention H=" in g]
+        segs = [g for g in segs if int(re.search(r"n_kv=(\d+)", g).group(1)) >= 32]
+        assert segs, st["stderr"][-2000:]
+        for g in segs:
+            assert f"Hkv={n_head_kv} dh=64 n_ctx=128 {want} " in g, (n_head_kv, g[-1500:])
+            assert ("matvec + rope + KV store" in g) == (want == "cached-split"), g[-1500:]
