@@ -151,6 +151,14 @@ PM355_API int pm355_mul_mat_vec_fused_check(const pm355_matvec_job * jobs, int n
  * in for the reference CUDA plug-in's mul_mat_q / dequantize+cuBLAS large-batch path (ggml-cuda/mmq.cuh:2583). */
 PM355_API int pm355_mul_mat_q_mfma(int type, const void * W, int64_t K, int64_t N, const float * x, int64_t n_tokens, float * y,
                                    const float * bias, const float * resid, pm355_stream_t stream);
+/* Prompt-sized batches on the INTEGER matrix cores (v_mfma_i32_32x32x32_i8, prima_cpp_amd/csrc/mmq_big.hip): x is quantized to Q8_K
+ * (quantize_row_q8_K, ggml-quants.c:3785) and multiplied with the CPU reference's own integer arithmetic (ggml_vec_dot_q4_K_q8_K /
+ * ggml_vec_dot_q6_K_q8_K, ggml-quants.c:7713 / :8918): exact int32 sub-block sums, one f32 multiply-add per 256-weight super-block - the
+ * design of the reference's CUDA plug-in for these batches (ggml-cuda/mmq.cuh:2583, quantize.cu:41-126). Q4_K / Q6_K weights, K % 1024 == 0;
+ * any n_tokens (tiles of 128 tokens: meant for >= 128). pm355_mul_mat_q_i8_check: 0 when the shape is served. */
+PM355_API int pm355_mul_mat_q_i8(int type, const void * W, int64_t K, int64_t N, const float * x, int64_t n_tokens, float * y,
+                                 const float * bias, const float * resid, pm355_stream_t stream);
+PM355_API int pm355_mul_mat_q_i8_check(int type, int64_t K, int64_t N, int64_t n_tokens);
 /* Small batches, 1 <= n_tokens <= 64 (speculative decoding, parallel sequences, short prompts): the weights are streamed ONCE per 32
  * tokens and the products run on the integer matrix cores (v_mfma_i32_32x32x16_i8, prima_cpp_amd/csrc/mmq_i8.hip) with the
  * reference's own integer arithmetic - activations quantized to Q8_K, exact int32 block sums, one f32 multiply-add per 256-weight

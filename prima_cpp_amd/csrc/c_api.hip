@@ -172,6 +172,17 @@ int pm355_mul_mat_q_mfma(int type, const void * W, int64_t K, int64_t N, const f
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_mul_mat_q_i8(int type, const void * W, int64_t K, int64_t N, const float * x, int64_t n_tokens, float * y,
+                       const float * bias, const float * resid, pm355_stream_t st) {
+    if (!W || !x || !y) return fail(PM355_E_SHAPE, "mul_mat_q_i8: null pointer");
+    const int rc = pm_launch_mmq_big_f32(type, W, x, y, (int) K, (int) N, (int) n_tokens, bias, resid, 0, S(st));
+    if (rc == -1) return fail(PM355_E_UNSUPPORTED, "mul_mat_q_i8: weight type (Q4_K / Q6_K)");
+    if (rc == -2) return fail(PM355_E_SHAPE, "mul_mat_q_i8: K % 1024 == 0 required");
+    if (rc) return fail(PM355_E_HIP, "mul_mat_q_i8: scratch allocation");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pm355_mul_mat_q_i8_check(int type, int64_t K, int64_t N, int64_t n_tokens) { return pm_mmq_big_check(type, (int) K, (int) N, (int) n_tokens) ? PM355_E_UNSUPPORTED : 0; }
 int pm355_mul_mat_q_small(int type, const void * W, int64_t K, int64_t N, const void * xq, const float * x, int64_t n_tokens, float * y,
                           const float * bias, const float * resid, pm355_stream_t st) {
     (void) hipGetLastError();

@@ -51,6 +51,10 @@ struct pm355_model {
     // table `rope_tab`), the attention launch reads everything from the cache (attn_cached.hip). PM355_QKV_EPI=0: the round-2 form (raw q / k / v,
     // rope + store inside the attention kernel)
     bool qkv_epi = true; float * rope_tab = nullptr;
+    // PM355_PROMPT_I8=1: prompts (> 64 tokens) run their Q4_K / Q6_K matrices on the integer matrix cores over Q8_K activations (mmq_big.hip) - the CPU
+    // reference's own arithmetic, at 0.6-0.75 of the F16 GEMMs' rate (mmq.hip, the default); tab_big = the activation tables of the current
+    // activation set (pm_q8k_tables)
+    bool no_big = true; uint8_t * tab_big = nullptr;
     // WINDOW STREAMING (pm355_model_set_streaming): the layer tensors live in pinned HOST memory (in the HBM layout) and are streamed
     // through `slots` device-side layer slots by a copy stream, slot (l - lo) % n_slots for layer l, one layer ahead of the compute
     // stream per free slot - the GPU-side form of prima.cpp's "prefetch the next layer window while this one computes"
@@ -454,6 +458,51 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
             const bool served = pm_mmq_i8_check(L.t[k].type, (int) L.t[k].K, (int) L.t[k].N, T < 1 ? 1 : (T > MMQ_MAX_TOKENS ? MMQ_MAX_TOKENS : T)) == 0;
             small_ok = small_ok && (served || L.t[k].type == PM_Q8_0);
         }
+        // prompts: every large matrix the integer kernel serves (Q4_K / Q6_K, K % 1024 == 0) runs on Q8_K activations with the CPU reference's
+        // arithmetic; wv alone may stay on the F16 GEMM (Llama-3-70B Q4_K_M: Q5_K in half the layers, src/llama.cpp:19360-19373)
+        bool big_ok = T > MMQ_MAX_TOKENS && !m->no_fuse && !m->no_big && m->tab_big && m->h2;
+        for (int k : {PM355_T_WQ, PM355_T_WK, PM355_T_WO, PM355_T_FFN_GATE, PM355_T_FFN_UP, PM355_T_FFN_DOWN})
+            big_ok = big_ok && pm_mmq_big_check(L.t[k].type, (int) L.t[k].K, (int) L.t[k].N, T) == 0;
+        if (big_ok) {
+            auto TB = [&](int K) { pm_q8k_tables tb; tb.base = m->tab_big; tb.tab_bytes = (size_t) (K / 256) * (1024 + 128); tb.nsb = K / 256; return tb; };
+            auto GI = [&](const Tensor & w, float * y, const float * bias, const float * resid, hipStream_t s2 = nullptr) {
+                return pm_launch_mmq_big(w.type, w.d, m->aq_k, m->tab_big, y, (int) w.K, (int) w.N, T, bias, resid, s2 ? s2 : st);
+            };
+            const Tensor & wv = L.t[PM355_T_WV];
+            const bool wv8 = pm_mmq_big_check(wv.type, (int) wv.K, (int) wv.N, T) == 0;
+            pm_launch_rmsnorm_q8k(cur, (const float *) L.t[PM355_T_ATTN_NORM].d, nullptr, m->aq_k, E, T, hp.rms_eps, st, wv8 ? nullptr : m->xn, TB(E));
+            int rc = GI(L.t[PM355_T_WQ], m->q, (const float *) L.t[PM355_T_BQ].d, nullptr);
+            if (!m->side) {
+                if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->side_a, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&m->side_b, hipEventDisableTiming) != hipSuccess) return seterr(m, PM355_E_HIP, "prefill: side stream");
+            }
+            (void) hipEventRecord(m->side_a, st);
+            (void) hipStreamWaitEvent(m->side, m->side_a, 0);
+            rc |= GI(L.t[PM355_T_WK], m->k, (const float *) L.t[PM355_T_BK].d, nullptr);
+            rc |= wv8 ? GI(wv, m->v, (const float *) L.t[PM355_T_BV].d, nullptr, m->side)
+                      : pm_launch_gemm_q_h(wv.type, wv.d, nullptr, m->xn, m->v, nullptr, (int) wv.K, (int) wv.N, T, (const float *) L.t[PM355_T_BV].d, nullptr, nullptr, 0, m->side);
+            (void) hipEventRecord(m->side_b, m->side);
+            (void) hipStreamWaitEvent(st, m->side_b, 0);
+            if (rc) return seterr(m, PM355_E_UNSUPPORTED, "prefill: qkv mat-mul (integer matrix cores)");
+            const long kvs = (long) hp.n_ctx * Hkv * dh;
+            pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kvs,
+                                    (const float *) m->rope_freqs.d, T, H, Hkv, dh, hp.n_ctx, m->rope, st);
+            if (pm_launch_attn_prefill(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st) &&
+                pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
+                return seterr(m, PM355_E_RANGE, "prefill: n_ctx too large for the attention kernel");
+            pm_launch_quantize_q8k(m->att, m->aq_k, Eq, T, st, TB(Eq));
+            float * x_mid = (cur == bufs[0]) ? bufs[1] : bufs[0];
+            if (GI(L.t[PM355_T_WO], x_mid, nullptr, cur)) return seterr(m, PM355_E_UNSUPPORTED, "prefill: wo mat-mul");
+            pm_launch_rmsnorm_q8k(x_mid, (const float *) L.t[PM355_T_FFN_NORM].d, nullptr, m->aq_k, E, T, hp.rms_eps, st, nullptr, TB(E));
+            if (GI(L.t[PM355_T_FFN_GATE], m->h, nullptr, nullptr) || GI(L.t[PM355_T_FFN_UP], m->h2, nullptr, nullptr))
+                return seterr(m, PM355_E_UNSUPPORTED, "prefill: gate/up mat-mul");
+            pm_launch_silu_mul_q8k(m->h, m->h2, m->aq_k, F, T, st, TB(F));                   // silu(gate) * up straight into ffn_down's Q8_K rows
+            float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : ((x_mid == bufs[0]) ? bufs[1] : bufs[0]);
+            if (GI(L.t[PM355_T_FFN_DOWN], x_next, nullptr, x_mid)) return seterr(m, PM355_E_UNSUPPORTED, "prefill: down mat-mul");
+            layer_release(m, il, st);
+            cur = x_next;
+            continue;
+        }
         if (T > (small_ok ? MMQ_MAX_TOKENS : 15) && !m->no_fuse) {
             // ---- prefill: batched GEMMs on the MFMA matrix cores (mmq.hip), f32 activations
             // F16 plumbing: the producers of GEMM activations write them as F16 (the rounding the GEMM's own conversion pass would apply) into
@@ -609,6 +658,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     { const char * e = getenv("PM355_NO_MMQ_MULTI"); m->no_multi = e && e[0] == '1'; }   // small batches: one launch per matrix (A/B of the multi-job launches)
     { const char * e = getenv("PM355_NO_MMQ_I8"); m->no_mmq = e && e[0] == '1'; }     // 4..64-token batches: mat-vec columns / F16 GEMM from 16 (the round-1 paths)
     { const char * e = getenv("PM355_QKV_EPI"); m->qkv_epi = !(e && e[0] == '0'); }
+    { const char * e = getenv("PM355_PROMPT_I8"); m->no_big = !(e && e[0] == '1'); }
     return m;
 }
 
@@ -622,7 +672,7 @@ void pm355_model_free(pm355_model * m) {
     for (auto & L : m->layers) { for (auto & t : L.t) if (t.d) (void) hipFree(t.d); if (L.kc) (void) hipFree(L.kc); if (L.vc) (void) hipFree(L.vc); }
     Tensor * g[4] = {&m->tok_embd, &m->out_norm, &m->output, &m->rope_freqs};
     for (auto t : g) if (t->d) (void) hipFree(t->d);
-    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->h2, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->split_scratch, m->rope_tab};
+    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->h2, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->split_scratch, m->rope_tab, m->tab_big};
     for (auto p : s) if (p) (void) hipFree(p);
     pm355_uploader_free(m->up);
     if (m->cap_stream) (void) hipStreamDestroy(m->cap_stream);
@@ -719,6 +769,7 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
               A((void **) &m->aq_0, T * pm_q80_row_bytes((int) ((maxK + 31) / 32 * 32))) &&
               A((void **) &m->d_pos, 64 * 4) && A((void **) &m->d_ctl, 64) && A((void **) &m->d_tok, 64 + T * 4) &&
               A((void **) &m->rope_tab, (size_t) hp.head_dim * 4);
+    if (ok && T > MMQ_MAX_TOKENS && !m->no_big) ok = A((void **) &m->tab_big, pm_mmq_big_table_bytes((int) ((maxK + 255) / 256 * 256), (int) T));
     if (!ok) return seterr(m, PM355_E_NOMEM, "finalize: scratch");
     if (hp.n_head / hp.n_head_kv <= 8 && (hp.head_dim == 64 || hp.head_dim == 128) &&
         !A((void **) &m->split_scratch, std::max(pm_attn_split_scratch_floats(hp.n_head, hp.head_dim, hp.n_ctx),

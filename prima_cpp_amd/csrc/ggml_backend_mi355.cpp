@@ -457,6 +457,13 @@ bool compute_node(backend_ctx * c, struct ggml_tensor * op) {
                     MI355_CHECK(pm355_mul_mat_q_small((int) a->type, a->data, K, N, nullptr, (const float *) b->data, ncols, (float *) op->data, nullptr, nullptr, st));
                     return true;
                 }
+                // GGML_MI355_PROMPT_I8=1: prompt batches with the CPU backend's own arithmetic - src1 quantized to Q8_K, integer matrix cores
+                // (mmq_big.hip; the CUDA plug-in's mul_mat_q design, ggml-cuda/mmq.cuh:2583) - at 0.6-0.75 of the F16 GEMM's rate (the default below)
+                static const bool prompt_i8 = [] { const char * e = getenv("GGML_MI355_PROMPT_I8"); return e && e[0] == '1'; }();
+                if (prompt_i8 && ncols > 64 && pm355_mul_mat_q_i8_check((int) a->type, K, N, ncols) == 0) {
+                    MI355_CHECK(pm355_mul_mat_q_i8((int) a->type, a->data, K, N, (const float *) b->data, ncols, (float *) op->data, nullptr, nullptr, st));
+                    return true;
+                }
                 if (ncols >= 16 && K % 64 == 0 && N % 4 == 0) {          // prefill: batched GEMM on the MFMA matrix cores
                     MI355_CHECK(pm355_mul_mat_q_mfma((int) a->type, a->data, K, N, (const float *) b->data, ncols, (float *) op->data, nullptr, nullptr, st));
                     return true;

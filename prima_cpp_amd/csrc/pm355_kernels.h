@@ -107,3 +107,13 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
 // 2 or 3 matrices of one type and K that share the activations, as one launch (T <= 16); -5: not served, launch them one by one
 int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const int * N, float * const * Y, const float * const * bias, const void * xq,
                            int K, int T, int reuse_prep, hipStream_t st);
+
+// prompt-sized batches (>= 128 tokens) on the integer matrix cores (mmq_big.hip): Q4_K / Q6_K weights x Q8_K activations, the CPU reference's
+// integer arithmetic. xq = T rows of row-SoA Q8_K, tab = the activation tables a quantizer wrote for them (pm_q8k_tables{tab, (K / 256) * 1152, K / 256};
+// pm_mmq_big_table_bytes(K, T) bytes). 0, or -1 type / -2 shape / -3 device
+int pm_mmq_big_check(int type, int K, int N, int T);
+size_t pm_mmq_big_table_bytes(int K, int T);
+int pm_launch_mmq_big(int type, const void * W, const void * xq, const void * tab, float * Y, int K, int N, int T,
+                      const float * bias, const float * resid, hipStream_t st);
+int pm_launch_mmq_big_f32(int type, const void * W, const float * X, float * Y, int K, int N, int T, const float * bias, const float * resid,
+                          int reuse_x, hipStream_t st);

@@ -275,6 +275,18 @@ def mul_mat_small_multi(ws, xq, n_tokens, biases=None):
     return ys
 
 
+def mul_mat_i8(w, x, bias=None, resid=None):
+    """Prompt-sized batches on the integer matrix cores (mmq_big.hip): x f32 [T, K] -> Q8_K on device -> f32 [T, N]."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_mul_mat_q_i8.restype = C.c_int
+    lib.pm355_mul_mat_q_i8.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    x2 = x.contiguous().view(-1, w.K)
+    y = torch.empty((x2.shape[0], w.N), dtype=torch.float32, device=x.device)
+    check(lib.pm355_mul_mat_q_i8(w.type, ptr(w.data), w.K, w.N, ptr(x2), x2.shape[0], ptr(y), ptr(bias), ptr(resid), stream_ptr()), "mul_mat_q_i8")
+    return y
+
+
 def mul_mat_mfma(w, x, bias=None, resid=None):
     """Batched GEMM on MFMA: x f32 [T, K] -> f32 [T, N]."""
     import ctypes as C

@@ -217,6 +217,31 @@ def test_small_batch_matmul_on_integer_matrix_cores(P, oracle, t, T):
 
 
 @pytest.mark.parametrize("t", [Q4_K, Q6_K])
+def test_prompt_matmul_on_integer_matrix_cores(P, oracle, t):
+    """mmq_big.hip: prompt-sized batches with the CPU reference's integer arithmetic (Q8_K activations, exact int32 sub-block sums, one f32
+    multiply-add per super-block, super-blocks in k order) -> oracle.mul_mat within f32 summation order, where the F16 GEMM sits at 1e-3.
+    Shapes: ragged token and row tiles (T = 130 / 200, N = 70 / 300: clamped rows and tokens, tables of a partial 32-token pass), several
+    tiles per XCD (N = 4100), many super-blocks (K = 8192), bias + residual epilogue; and the mat-vec's own result for the same rows."""
+    rng = np.random.default_rng(900 + t)
+    for K, N, T in ((1024, 70, 130), (2048, 300, 200), (8192, 520, 128), (1024, 4100, 257)):
+        b = rand_blocks(t, N, K, rng)
+        x = rng.normal(0, 1, (T, K)).astype(np.float32)
+        bias = rng.normal(0, 1, N).astype(np.float32)
+        resid = rng.normal(0, 1, (T, N)).astype(np.float32)
+        w = P.upload_weight(t, b, K, N)
+        want = oracle.mul_mat(t, b, K, N, x)
+        tol = dict(rtol=2e-5, atol=2e-5 * np.sqrt(K / 4096))
+        y = P.mul_mat_i8(w, _dev(P, x)).cpu().numpy()
+        assert np.isfinite(y).all()
+        assert np.allclose(y, want, **tol), (K, N, T, np.abs(y - want).max(), np.argwhere(~np.isclose(y, want, **tol))[:8])
+        y2 = P.mul_mat_i8(w, _dev(P, x), bias=_dev(P, bias), resid=_dev(P, resid)).cpu().numpy()
+        assert np.allclose(y2, want + bias[None] + resid, **tol)
+        xq = P.quantize_act(_dev(P, x[:4]), P.vec_dot_act_type(t))
+        y1 = P.mul_mat_vec(w, xq=xq, ncols=4).cpu().numpy()
+        assert np.allclose(y[:4], y1, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("t", [Q4_K, Q6_K])
 def test_small_batch_matmul_multi_job_launch(P, oracle, t):
     """wq | wk | wv and ffn_gate | ffn_up as ONE launch over a virtual row space: every job equals its own single-job launch (same integers; the
     K split over waves may differ) and the oracle; row groups straddle the job boundaries (N not a multiple of 32)."""
