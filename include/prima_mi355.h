@@ -46,6 +46,8 @@ PM355_API int    pm355_set_device(int device);
 PM355_API int    pm355_device_info(int device, char * name, size_t name_len, size_t * free_bytes, size_t * total_bytes,
                                    int * compute_units);
 PM355_API int    pm355_sync(pm355_stream_t stream);
+/* waits for the work enqueued on the NULL stream only (small synchronous uploads), not for the other streams of the device */
+PM355_API int    pm355_sync_null_stream(void);
 /* streams / events for the plug-in's ggml_backend_i (a ggml backend IS a stream) and ggml_backend_event */
 typedef void * pm355_event_t;            /* hipEvent_t */
 PM355_API pm355_stream_t pm355_stream_create(void);
@@ -265,7 +267,8 @@ typedef struct {
 #define PM355_ATTN_K_Q8_0     4
 #define PM355_ATTN_V_Q8_0     8
 PM355_API int pm355_attn_token(const pm355_attn_token_args * a, const pm355_rope_params * rp, pm355_stream_t stream);
-/* Single-token decode with the RoPE and the KV store in the EPILOGUE of the wq | wk | wv launch (round 3; NORM-mode rope - build_llama):
+/* Single-token decode with the RoPE and the KV store in the EPILOGUE of the wq | wk | wv launch (NORM-mode rope - build_llama - and, with
+ * rope_neox set, NEOX pairs (i, i + n_rot / 2) - build_qwen2, ggml.c:14238-14253 - where n_rot == head_dim and the row slices are powers of two):
  *   pm355_rope_table       this token's cos / sin per rotation pair, table[2 i] / table[2 i + 1], built with the reference's running
  *                          product theta_i = theta_{i-1} * theta_scale (ggml_rope_cache_init, ggml.c:14117-14131; rope_yarn :14094) - one
  *                          launch per token serves every layer
@@ -277,13 +280,14 @@ PM355_API int pm355_attn_token(const pm355_attn_token_args * a, const pm355_rope
  *                          the cache; same rounding points and mask / flags as pm355_attn_token's one-workgroup-per-head path. */
 typedef struct {
     const float * rope_table; const int32_t * d_pos; const int32_t * d_cell_nkv; void * k_cache; void * v_cache;
-    int32_t n_head_kv, head_dim, n_ctx, n_rot /* rope n_dims */, v_rowmajor, pad_;
+    int32_t n_head_kv, head_dim, n_ctx, n_rot /* rope n_dims */, v_rowmajor, rope_neox /* rope mode & 2 */;
 } pm355_qkv_store;
 PM355_API int pm355_rope_table(const pm355_rope_params * rp, const int32_t * d_pos, const float * freq_factors, float * table, pm355_stream_t stream);
 PM355_API int pm355_mul_mat_vec_qkv(const pm355_matvec_job * jobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
                                     const pm355_qkv_store * s, pm355_stream_t stream);
 /* 0 when pm355_mul_mat_vec_qkv can serve this wq | wk | wv list (types, K, every workgroup's row slices hold whole rotation pairs) */
 PM355_API int pm355_mul_mat_vec_qkv_check(const pm355_matvec_job * jobs, int64_t K, int n_head_kv, int head_dim, int n_rot);
+PM355_API int pm355_mul_mat_vec_qkv_check_ex(const pm355_matvec_job * jobs, int64_t K, int n_head_kv, int head_dim, int n_rot, int rope_neox);
 PM355_API int pm355_attn_cached(const float * q_rot, void * k_cache, void * v_cache, const int32_t * d_pos, const int32_t * d_cell_nkv,
                                 const void * mask, float * out, int n_head, int n_head_kv, int head_dim, int n_ctx, float kq_scale,
                                 int max_keys, int flags, pm355_stream_t stream);

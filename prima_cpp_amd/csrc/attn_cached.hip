@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256) void attn_cached_kernel(AttnP a) {
             seq = a.seq_ptr ? uniform_const_ptr(a.seq_ptr)[0] : 0;
             n_kv = uniform_const_ptr(a.pos0_ptr)[seq] + 1;
         }
-        if (n_kv <= 64) {
+        // (short path: a lane owns a key and reads whole V^T chunks of KPP cells - only where the cache holds at least 64 cells per row; a smaller
+        //  n_ctx takes the general body below, whose loads are bounded by n_kv: ADVICE r3)
+        if (n_kv <= 64 && n_ctx >= 64) {
             const PM_G uint16_t * kc = (const PM_G uint16_t *) a.kc + (long) seq * a.seq_stride;
             const PM_G uint16_t * vc = (const PM_G uint16_t *) a.vc + (long) seq * a.seq_stride;
             const int key = lane < n_ctx ? lane : 0;

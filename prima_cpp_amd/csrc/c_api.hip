@@ -5,6 +5,8 @@
 #include "pm355_layer_ops.h"
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 
 static thread_local char g_err[256] = "";
 static int fail(int code, const char * what, hipError_t e = hipSuccess) {
@@ -35,11 +37,26 @@ int pm355_device_info(int d, char * name, size_t name_len, size_t * free_b, size
     }
     return 0;
 }
+// Is `p` page-locked host memory? Asked for every small upload of a token (positions, mask, ...): the driver call (and, for pageable memory,
+// the error it returns) is paid once per 4 KiB page - a direct-mapped cache of verdicts, flushed whenever this library allocates or frees
+// pinned memory itself (pm355_host_malloc / pm355_host_free: the plug-in's host buffer type), the one way a page's status changes under it.
+// (A "pinned" verdict that has gone stale only costs a wait; a page the application pins later by other means is seen after the next flush.)
+namespace { struct PinE { uintptr_t page; int pinned; }; PinE g_pin[256] = {}; std::atomic<unsigned> g_pin_gen{1}; unsigned g_pin_seen = 0; std::mutex g_pin_mu; }
 int pm355_host_is_pinned(const void * p) {
+    const uintptr_t page = ((uintptr_t) p >> 12) + 1;                 // (+1: 0 marks an empty slot)
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    const unsigned gen = g_pin_gen.load(std::memory_order_acquire);
+    if (gen != g_pin_seen) { memset(g_pin, 0, sizeof(g_pin)); g_pin_seen = gen; }
+    PinE & e = g_pin[page & 255];
+    if (e.page == page) return e.pinned;
     hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void) hipGetLastError(); return 0; }      // unknown to the runtime: pageable
-    return a.type == hipMemoryTypeHost ? 1 : 0;
+    int pinned = 0;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) (void) hipGetLastError();                   // unknown to the runtime: pageable
+    else pinned = a.type == hipMemoryTypeHost ? 1 : 0;
+    e.page = page; e.pinned = pinned;
+    return pinned;
 }
+int pm355_sync_null_stream(void) { HIP_TRY(hipStreamSynchronize(nullptr)); return 0; }
 int pm355_sync(pm355_stream_t s) { HIP_TRY(s ? hipStreamSynchronize(S(s)) : hipDeviceSynchronize()); return 0; }
 
 pm355_stream_t pm355_stream_create(void) { hipStream_t s = nullptr; return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? (pm355_stream_t) s : nullptr; }
@@ -52,8 +69,8 @@ int pm355_event_sync(pm355_event_t e) { HIP_TRY(hipEventSynchronize((hipEvent_t)
 
 void * pm355_malloc(size_t n) { void * p = nullptr; return hipMalloc(&p, n) == hipSuccess ? p : nullptr; }
 void   pm355_free(void * p) { if (p) (void) hipFree(p); }
-void * pm355_host_malloc(size_t n) { void * p = nullptr; return hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
-void   pm355_host_free(void * p) { if (p) (void) hipHostFree(p); }
+void * pm355_host_malloc(size_t n) { void * p = nullptr; g_pin_gen.fetch_add(1, std::memory_order_release); return hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+void   pm355_host_free(void * p) { g_pin_gen.fetch_add(1, std::memory_order_release); if (p) (void) hipHostFree(p); }
 int pm355_memcpy_h2d(void * d, const void * s, size_t n, pm355_stream_t st) { HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, S(st))); return 0; }
 int pm355_memcpy_d2h(void * d, const void * s, size_t n, pm355_stream_t st) { HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, S(st))); return 0; }
 int pm355_memcpy_d2d(void * d, const void * s, size_t n, pm355_stream_t st) { HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, S(st))); return 0; }
@@ -311,7 +328,7 @@ int pm355_mul_mat_vec_qkv(const pm355_matvec_job * jobs, int64_t K, const float 
         f.job[j].y = jobs[j].y; f.job[j].bias = jobs[j].bias; f.job[j].resid = nullptr;
     }
     const pm_qkv_epi e = {s->rope_table, s->d_pos, nullptr, s->d_cell_nkv, 0, s->k_cache, s->v_cache, s->n_head_kv, s->head_dim, s->n_ctx, s->n_rot,
-                          s->v_rowmajor};
+                          s->v_rowmajor, s->rope_neox};
     f.epi = &e;
     (void) hipGetLastError();
     const int rc = pm_launch_gemv_fused(f, S(st));
@@ -320,15 +337,18 @@ int pm355_mul_mat_vec_qkv(const pm355_matvec_job * jobs, int64_t K, const float 
     HIP_TRY(hipGetLastError());
     return 0;
 }
-int pm355_mul_mat_vec_qkv_check(const pm355_matvec_job * jobs, int64_t K, int n_head_kv, int head_dim, int n_rot) {
+int pm355_mul_mat_vec_qkv_check_ex(const pm355_matvec_job * jobs, int64_t K, int n_head_kv, int head_dim, int n_rot, int rope_neox) {
     if (!jobs) return fail(PM355_E_SHAPE, "mul_mat_vec_qkv_check: jobs");
     pm_gemv_fused f = {};
     f.K = (int) K; f.njobs = 3; f.xf = (const float *) 16;
     for (int j = 0; j < 3; ++j) { f.job[j].type = jobs[j].type; f.job[j].N = (int) jobs[j].N; f.job[j].W = jobs[j].W; f.job[j].bias = jobs[j].bias; }
-    const pm_qkv_epi e = {(const float *) 16, (const int32_t *) 16, nullptr, nullptr, 0, (void *) 16, (void *) 16, n_head_kv, head_dim, 8, n_rot, 0};
+    const pm_qkv_epi e = {(const float *) 16, (const int32_t *) 16, nullptr, nullptr, 0, (void *) 16, (void *) 16, n_head_kv, head_dim, 8, n_rot, 0, rope_neox ? 1 : 0};
     f.epi = &e;
     const int rc = pm_gemv_fused_check(f);
     return rc == -5 ? PM355_E_UNSUPPORTED : gemv_rc(rc);
+}
+int pm355_mul_mat_vec_qkv_check(const pm355_matvec_job * jobs, int64_t K, int n_head_kv, int head_dim, int n_rot) {
+    return pm355_mul_mat_vec_qkv_check_ex(jobs, K, n_head_kv, head_dim, n_rot, 0);
 }
 int pm355_attn_cached(const float * q_rot, void * kc, void * vc, const int32_t * d_pos, const int32_t * d_cell_nkv, const void * mask,
                       float * out, int H, int Hkv, int dh, int n_ctx, float kq_scale, int max_keys, int flags, pm355_stream_t st) {

@@ -344,7 +344,8 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
     const float kq_scale = 1.0f / sqrtf((float) dh);
     float * bufs[2] = {m->x, m->x1};
     // rope + KV store in the QKV epilogue: NORM-mode rope, one-workgroup-per-head attention regime
-    bool epi = m->qkv_epi && m->rope_tab && !(m->rope.mode & 2) &&
+    // (NEOX rope - build_qwen2 - where every workgroup's slice of wq / wk holds both halves of its rotation pairs: pm_launch_gemv_fused tells)
+    bool epi = m->qkv_epi && m->rope_tab && (m->rope.mode == 0 || m->rope.mode == 2) &&
                (!m->long_ctx || (m->use_flash && m->attn_mfma && H / Hkv <= 8 && pm_attn_flash_cached_ok(H, Hkv, dh, hp.n_ctx) == 0));
     if (epi) pm_launch_rope_table(m->rope, m->d_pos, m->d_ctl, (const float *) m->rope_freqs.d, m->rope_tab, st);
     for (int il = m->lo; il < m->hi; ++il) {
@@ -358,7 +359,7 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
             const float * bs[3] = {(const float *) L.t[PM355_T_BQ].d, (const float *) L.t[PM355_T_BK].d, (const float *) L.t[PM355_T_BV].d};
             const float * nw = (const float *) L.t[PM355_T_ATTN_NORM].d;
             const long kvs_e = m->n_seq > 1 ? (long) hp.n_ctx * Hkv * dh : 0;
-            const pm_qkv_epi qe = {m->rope_tab, m->d_pos, m->d_ctl, nullptr, kvs_e, L.kc, L.vc, Hkv, dh, hp.n_ctx, m->rope.n_dims, 0};
+            const pm_qkv_epi qe = {m->rope_tab, m->d_pos, m->d_ctl, nullptr, kvs_e, L.kc, L.vc, Hkv, dh, hp.n_ctx, m->rope.n_dims, 0, (m->rope.mode & 2) ? 1 : 0};
             bool qkv_done = false;
             if (epi) {
                 qkv_done = gemv_f32(m, ws, nullptr, ys, bs, nullptr, 3, cur, nw, st, &qe) == 0;

@@ -206,7 +206,7 @@ void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void 
         // tensor of the plug-in's own host buffer type handed over by ggml_backend_tensor_copy - is read by the DMA later, and the
         // scheduler relies on the copy being complete on return (ggml-backend.cpp:2110): wait for it.
         MI355_CHECK(h2d((char *) t->data + off, data, size, nullptr));
-        if (pm355_host_is_pinned(data)) { MI355_CHECK(dsync(nullptr)); return; }
+        if (pm355_host_is_pinned(data)) { MI355_CHECK(pm355_sync_null_stream()); return; }      // (the copy's own stream, not the whole device)
         g_null_epoch.fetch_add(1, std::memory_order_release);
         return;
     }

@@ -448,8 +448,8 @@ private:
         // the same cos / sin table as the layers planned before (same parameters, positions and frequency factors)
         pm355_rope_params rp_; rope_params_of(rq, rp_);
         const float * ff_ = rq->src[2] ? (const float *) rq->src[2]->data : nullptr;
-        bool epi = c_.rope_tab && one_launch && !q8 && (!split || (!fa && c_.attn_mfma && pm355_attn_cached_long_check((int) H, (int) Hkv, (int) dh, (int) n_ctx) == 0)) && !(rp_.mode & 2) && rp_.n_dims <= 256 &&
-                   pm355_mul_mat_vec_qkv_check(jobs, E, (int) Hkv, (int) dh, rp_.n_dims) == 0;
+        bool epi = c_.rope_tab && one_launch && !q8 && (!split || (!fa && c_.attn_mfma && pm355_attn_cached_long_check((int) H, (int) Hkv, (int) dh, (int) n_ctx) == 0)) && (rp_.mode == 0 || rp_.mode == 2) && rp_.n_dims <= 256 &&
+                   pm355_mul_mat_vec_qkv_check_ex(jobs, E, (int) Hkv, (int) dh, rp_.n_dims, rp_.mode & 2) == 0;
         if (epi && tab_set_) {
             const bool same_ff = ff_ == tab_ff_ || (ff_ && tab_ff_ && c_.same_bytes && c_.same_bytes(c_.user, ff_, tab_ff_, (size_t) rp_.n_dims / 2 * 4));
             if (memcmp(&rp_, &tab_rp_, sizeof(rp_)) || rq->src[1]->data != tab_pos_ || !same_ff) epi = false;
@@ -467,7 +467,7 @@ private:
             g.K = E; g.njobs = 3; g.eps = eps; g.x = (const float *) x->data; g.norm_w = nw;
             for (int j = 0; j < 3; ++j) g.job[j] = jobs[j];
             g.qs.rope_table = c_.rope_tab; g.qs.d_pos = nullptr; g.qs.d_cell_nkv = c_.d_dyn; g.qs.k_cache = kcache->data; g.qs.v_cache = vcache->data;
-            g.qs.n_head_kv = (int32_t) Hkv; g.qs.head_dim = (int32_t) dh; g.qs.n_ctx = (int32_t) n_ctx; g.qs.n_rot = rp_.n_dims; g.qs.v_rowmajor = fa ? 1 : 0;
+            g.qs.n_head_kv = (int32_t) Hkv; g.qs.head_dim = (int32_t) dh; g.qs.n_ctx = (int32_t) n_ctx; g.qs.n_rot = rp_.n_dims; g.qs.v_rowmajor = fa ? 1 : 0; g.qs.rope_neox = (rp_.mode & 2) ? 1 : 0;
             p.steps.push_back(g);
             ++p.n_gemv;
         } else if (one_launch) push_gemv(p, i0, hi, jobs, 3, E, (const float *) x->data, nw, eps);

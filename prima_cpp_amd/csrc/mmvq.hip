@@ -53,7 +53,7 @@ int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, 
         if (dbg) return -1;
         go(gemv_q_kernel<TA, TB, false, false, true>);
     } else {
-        if (dbg) go(gemv_q_kernel<TA, TB, false, true>);
+        if (dbg) go(gemv_q_kernel<TA, TB, false, true, false, 1>);     // (test hook: one pre-issued step - with two, the Q6_K form sat on the 128-VGPR cliff with a spilled register)
         else go(gemv_q_kernel<TA, TB, false, false>);
     }
     return 0;
@@ -140,13 +140,23 @@ int pmv::gemv_fill(const pm_gemv_fused & a, int grid_fixed, GemvP & p, int & ta_
             g.role = j + 1;
             const int upl = (g.U + 63) >> 6, ch = nv_of(s.type) == 64 ? PM_CH64 : PM_CH32, cpr = (upl + ch - 1) / ch;
             g.split = (j > 0 && s.N / grid < PM_GEMV_NW && cpr > 1) ? 1 : 0;
+            if (a.epi->neox && j < 2) {
+                // NEOX pairs (i, i + n_rot / 2): the slice of every workgroup = two runs of sl / 2 rows, n_rot / 2 apart, inside one head
+                const int sl = s.N / grid, dh = a.epi->dh;
+                auto pow2 = [](int v) { return v > 0 && !(v & (v - 1)); };
+                if (a.epi->n_rot != dh || !pow2(dh) || !pow2(sl) || sl < 2 || sl > dh) return -5;
+                int ls = 0, ld = 0;
+                while ((1 << ls) < sl) ++ls;
+                while ((1 << ld) < dh) ++ld;
+                g.nx_s = ls; g.nx_dh = ld; g.nx_hrot = a.epi->n_rot / 2;
+            }
         }
     }
     if (a.epi) {
         const pm_qkv_epi & e = *a.epi;
         if (grid_fixed > 0 || e.dh % 2 || e.n_rot % 2 || e.n_rot > e.dh || a.job[0].N % e.dh || a.job[1].N != e.Hkv * e.dh || a.job[2].N != e.Hkv * e.dh) return -5;
         // (ggml-graph mode has no position pointer: the scalar loads of the un-taken branch may still be issued - give them a valid address)
-        p.epi = QkvEpi{e.tab, e.pos ? e.pos : e.dyn, e.seq, e.dyn, e.seq_stride, (uint16_t *) e.kc, (uint16_t *) e.vc, e.Hkv * e.dh, e.dh, e.n_ctx, e.n_rot, e.v_rowmajor};
+        p.epi = QkvEpi{e.tab, e.pos ? e.pos : e.dyn, e.seq, e.dyn, e.seq_stride, (uint16_t *) e.kc, (uint16_t *) e.vc, e.Hkv * e.dh, e.dh, e.n_ctx, e.n_rot, e.v_rowmajor, e.neox};
     }
     if (p.job[0].is_b)                                // the kernel pre-issues job 0 with the TA code path: put a TA job first
         for (int j = 1; j < 3; ++j) if (p.job[j].N > 0 && !p.job[j].is_b) { const GemvJob t = p.job[0]; p.job[0] = p.job[j]; p.job[j] = t; break; }

@@ -16,13 +16,25 @@ struct GemvJob {
     int N, is_b /*uses TB*/, U /*units per row*/;
     int role;    // QKV epilogue (GemvP::epi): 0 none, 1 = query rows (rotate, round to F16), 2 = key rows (rotate, store in the K cache), 3 = value rows (store in the V cache)
     int split;   // items of this job are (row, chunk) steps instead of whole rows: a few long rows spread over all waves (wk / wv next to wq)
+    // NEOX rope in the QKV epilogue (build_qwen2): a rotation pair is (i, i + n_rot / 2) of one head (ggml.c:14238-14253), so a workgroup's slice of
+    // s = 2^nx_s rows is made of TWO runs of s / 2 rows, n_rot / 2 apart: logical row L of the job (what the item loops count in) is matrix row
+    // job_row(L). nx_s == 0: identity (NORM rope pairs adjacent rows; every other job).
+    int nx_s, nx_dh /*log2 head_dim*/, nx_hrot /*n_rot / 2*/;
 };
+// logical -> matrix row of a job (wave-uniform arithmetic: shifts and masks, head_dim and the slice size are powers of two)
+__device__ __forceinline__ int job_row(const GemvJob & jb, int L) {
+    const int sh = jb.nx_s > 0 ? jb.nx_s : 1, half = 1 << (sh - 1);                // (branch-free: scalar selects, the row loops stay straight-line code)
+    const int w = L & ((1 << jb.nx_dh) - 1), l = w & ((1 << sh) - 1), q = w >> sh;
+    const int m = (L - w) + q * half + (l < half ? l : jb.nx_hrot + l - half);
+    return jb.nx_s > 0 ? m : L;
+}
 // RoPE + F16 KV store in the epilogue of the wq | wk | wv launch (NORM-mode rope: a pair = two adjacent rows of one workgroup's slice).
 // tab[i] = (cos, sin) of rotation pair i at this token's position, built once per token by rope_table_kernel (layer_ops.hip) with the
 // reference's running product (ggml_rope_cache_init, ggml.c:14117-14131); cell / sequence as in attn_device.h (dyn: ggml-graph mode).
 struct QkvEpi {
     const float * tab; const int32_t * pos_ptr, * seq_ptr, * dyn; long seq_stride;
     uint16_t * kc, * vc; int kv_dim /*Hkv * dh*/, dh, n_ctx, n_rot, v_rowmajor;
+    int neox;    // rotation pairs (i, i + n_rot / 2) instead of (2 i, 2 i + 1): the q / k jobs carry the row mapping (GemvJob::nx_s)
 };
 struct GemvP {
     GemvJob job[3];
@@ -492,7 +504,7 @@ template <int TYPE, bool PAIR, int NC = 1> struct Item {
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 const int u = min(lane + 64 * (c0 + i), jb.U - 1);
-                T::issue(g.w[r][0][i], jb.W + (long) rr * jb.row_stride, p.K, u);
+                T::issue(g.w[r][0][i], jb.W + (long) job_row(jb, rr) * jb.row_stride, p.K, u);
                 if (PAIR) T::issue(g.w[r][NM - 1][i], jb.W2 + (long) rr * jb.row_stride, p.K, u);
             }
         }
@@ -667,8 +679,13 @@ __device__ __forceinline__ void write_out(const GemvJob & jb, const float * outb
 __device__ __forceinline__ void qkv_cs(const GemvJob & jb, const QkvEpi & e, int r0, int r1, int tid, float & c, float & s_) {
     c = 1.0f; s_ = 0.0f;
     if (jb.role == 1 || jb.role == 2) {
-        const int d = (r0 + 2 * tid) % e.dh;
-        if (2 * tid < r1 - r0 && d < e.n_rot) { c = ld_g(e.tab + d); s_ = ld_g(e.tab + d + 1); }
+        if (jb.nx_s) {                                                 // NEOX: pair `tid` of the slice = matrix rows (p0, p0 + n_rot / 2), table entry p0 % dh
+            const int ic = job_row(jb, r0 + tid) & (e.dh - 1);
+            if (2 * tid < r1 - r0) { c = ld_g(e.tab + 2 * ic); s_ = ld_g(e.tab + 2 * ic + 1); }
+        } else {
+            const int d = (r0 + 2 * tid) % e.dh;
+            if (2 * tid < r1 - r0 && d < e.n_rot) { c = ld_g(e.tab + d); s_ = ld_g(e.tab + d + 1); }
+        }
     }
 }
 __device__ __forceinline__ void write_out_qkv(const GemvJob & jb, const QkvEpi & e, const float * outbuf, int r0, int r1, int ob, int tid, int cpr,
@@ -677,6 +694,19 @@ __device__ __forceinline__ void write_out_qkv(const GemvJob & jb, const QkvEpi &
     {
         const int pr = tid;
         if (pr >= np) return;
+        if (jb.nx_s) {
+            // NEOX (ggml_compute_forward_rope_f32, ggml.c:14238-14253): x0 = row p0, x1 = row p0 + n_rot / 2 of the same head; the slice holds both
+            // (logical rows pr and pr + np). n_rot == head_dim here (gemv_fill): every row of a q / k head is rotated.
+            const int p0 = job_row(jb, r0 + pr), p1 = p0 + jb.nx_hrot;
+            float o0 = row_result(jb, outbuf, ob, pr, cpr), o1 = row_result(jb, outbuf, ob, pr + np, cpr);
+            if (jb.bias) { o0 += ld_g(jb.bias + p0); o1 += ld_g(jb.bias + p1); }
+            const float x0 = o0, x1 = o1;
+            o0 = x0 * c - x1 * s_; o1 = x0 * s_ + x1 * c;
+            const uint16_t h0 = f2h(o0), h1 = f2h(o1);
+            if (jb.role == 2) { st_g(e.kc + kv_off + (long) slot * e.kv_dim + p0, h0); st_g(e.kc + kv_off + (long) slot * e.kv_dim + p1, h1); }
+            else { st_g(jb.y + p0, h2f(h0)); st_g(jb.y + p1, h2f(h1)); }
+            return;
+        }
         const int row = r0 + 2 * pr;
         float o0 = row_result(jb, outbuf, ob, 2 * pr, cpr), o1 = row_result(jb, outbuf, ob, 2 * pr + 1, cpr);
         if (jb.bias) { o0 += ld_g(jb.bias + row); o1 += ld_g(jb.bias + row + 1); }

@@ -73,6 +73,7 @@ struct pm_gemv_job {
 struct pm_qkv_epi {
     const float * tab; const int32_t * pos, * seq, * dyn; long seq_stride;
     void * kc, * vc; int Hkv, dh, n_ctx, n_rot, v_rowmajor;
+    int neox;                           // rope mode 2 (build_qwen2): pairs (i, i + n_rot / 2); needs n_rot == head_dim and power-of-two slices
 };
 struct pm_gemv_fused {
     int K; int njobs;

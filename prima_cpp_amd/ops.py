@@ -321,7 +321,7 @@ def rope_table(pos, head_dim, freq_factors=None, mode=0, n_ctx_orig=8192, freq_b
 
 
 def mul_mat_vec_qkv(ws, x, tab, pos, k_cache, v_cache, n_head_kv, head_dim, n_ctx, norm_w=None, eps=0.0, biases=None, n_rot=None,
-                    v_rowmajor=False, cell_nkv=None):
+                    v_rowmajor=False, cell_nkv=None, neox=False):
     """wq | wk | wv mat-vecs with RoPE + F16 KV store in the epilogue: returns the rotated, F16-rounded query row [N_q] (f32);
     the K row / V column of cache cell pos[0] (or cell_nkv[0]) are written."""
     import ctypes as C
@@ -334,7 +334,7 @@ def mul_mat_vec_qkv(ws, x, tab, pos, k_cache, v_cache, n_head_kv, head_dim, n_ct
         jobs[j] = MatvecJob(w.type, 0, w.N, ptr(w.data), None, ptr(q) if j == 0 else None,
                             ptr(biases[j]) if biases and biases[j] is not None else None, None)
     s = QkvStore(ptr(tab), ptr(pos), ptr(cell_nkv), ptr(k_cache), ptr(v_cache), n_head_kv, head_dim, n_ctx, n_rot or head_dim,
-                 int(v_rowmajor), 0)
+                 int(v_rowmajor), int(neox))
     check(lib.pm355_mul_mat_vec_qkv(C.addressof(jobs), ws[0].K, ptr(x), ptr(norm_w), float(eps), C.addressof(s), stream_ptr()),
           "mul_mat_vec_qkv")
     return q

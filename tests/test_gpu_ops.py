@@ -519,15 +519,19 @@ def test_mfma_prefill_gemm_vs_oracle(P, oracle, t, K, N, T):
     assert nm_ref < 5e-4, nm_ref
 
 
+@pytest.mark.parametrize("mode", [0, 2])
 @pytest.mark.parametrize("tv", [Q6_K, Q5_K, Q4_K])
 @pytest.mark.parametrize("dh,H,Hkv", [(128, 8, 4), (64, 16, 8)])
-def test_qkv_epilogue_and_cached_attention_equal_the_fused_attention_path(P, oracle, tv, dh, H, Hkv):
+def test_qkv_epilogue_and_cached_attention_equal_the_fused_attention_path(P, oracle, tv, dh, H, Hkv, mode):
     """Round-3 decode form - RoPE + F16 KV store in the EPILOGUE of the wq | wk | wv launch (per-token cos / sin table, wk / wv dealt out
     step by step over all waves), attention over cached cells only (one-barrier kernel up to 64 cells, per-head body beyond) - against
     the round-2 form (plain mat-vecs, rope + store inside the fused attention kernel) on a run of tokens that crosses the 64-cell
-    boundary; the mat-vec outputs against the oracle's mul_mat."""
+    boundary; the mat-vec outputs against the oracle's mul_mat. mode 2 = NEOX rope (build_qwen2: pairs (i, i + n_rot / 2); every workgroup's
+    slice of wq / wk is two runs of rows n_rot / 2 apart, GemvJob::nx_s)."""
     torch = P.torch
     rng = np.random.default_rng(61)
+    if tv != Q4_K and mode == 2 and dh == 64:
+        pytest.skip("one attn_v type per NEOX shape is enough")
     K, n_ctx = 1024, 128
     Nq, Nkv = H * dh, Hkv * dh
     assert Nq % 512 == 0 and Nkv % 512 == 0
@@ -546,13 +550,13 @@ def test_qkv_epilogue_and_cached_attention_equal_the_fused_attention_path(P, ora
         x = rng.normal(0, 1, (1, K)).astype(np.float32)
         xd = _dev(P, x)
         qA, kA, vA = P.mul_mat_vec_fused(ws, xd, norm_w=nw, eps=1e-5, biases=bias)
-        outA = P.attn_rope_fused(qA, kA, vA, kcA, vcA, pos, H, Hkv, dh, n_ctx, scale, freq_factors=ff, freq_base=500000.0)
+        outA = P.attn_rope_fused(qA, kA, vA, kcA, vcA, pos, H, Hkv, dh, n_ctx, scale, freq_factors=ff, freq_base=500000.0, mode=mode)
         pd = torch.tensor([pos], dtype=torch.int32, device="cuda")
-        tab = P.rope_table(pd, dh, freq_factors=ff, freq_base=500000.0)
-        qB = P.mul_mat_vec_qkv(ws, xd, tab, pd, kcB, vcB, Hkv, dh, n_ctx, norm_w=nw, eps=1e-5, biases=bias)
+        tab = P.rope_table(pd, dh, freq_factors=ff, freq_base=500000.0, mode=mode)
+        qB = P.mul_mat_vec_qkv(ws, xd, tab, pd, kcB, vcB, Hkv, dh, n_ctx, norm_w=nw, eps=1e-5, biases=bias, neox=mode == 2)
         outB = P.attn_cached(qB, kcB, vcB, pd, H, Hkv, dh, n_ctx, scale)
         dyn = torch.tensor([pos, pos + 1], dtype=torch.int32, device="cuda")
-        qC = P.mul_mat_vec_qkv(ws, xd, tab, None, kcC, vcC, Hkv, dh, n_ctx, norm_w=nw, eps=1e-5, biases=bias, cell_nkv=dyn)
+        qC = P.mul_mat_vec_qkv(ws, xd, tab, None, kcC, vcC, Hkv, dh, n_ctx, norm_w=nw, eps=1e-5, biases=bias, cell_nkv=dyn, neox=mode == 2)
         outC = P.attn_cached(qC, kcC, vcC, None, H, Hkv, dh, n_ctx, scale, cell_nkv=dyn, mask=mask0, max_keys=n_ctx)
         torch.cuda.synchronize()
         assert torch.equal(qC, qB) and torch.equal(outC, outB) and torch.equal(kcC, kcB) and torch.equal(vcC, vcB), pos
@@ -564,7 +568,7 @@ def test_qkv_epilogue_and_cached_attention_equal_the_fused_attention_path(P, ora
         vb = vcB.cpu().numpy().view(np.float16).astype(np.float32).reshape(Nkv, n_ctx)[:, pos]
         assert np.abs(va - vb).max() <= 2e-3 * max(1.0, np.abs(va).max()) and (va != vb).mean() < 0.02
         # q: rotated + F16-rounded == F16 rounding of the oracle's rope of the round-2 q
-        q_ref = oracle.rope(qA.cpu().numpy().reshape(1, H, dh), np.array([pos], dtype=np.int32), freq_factors=ff.cpu().numpy(), freq_base=500000.0)
+        q_ref = oracle.rope(qA.cpu().numpy().reshape(1, H, dh), np.array([pos], dtype=np.int32), freq_factors=ff.cpu().numpy(), freq_base=500000.0, mode=mode)
         q_ref = q_ref.astype(np.float16).astype(np.float32).reshape(-1)
         qb = qB.cpu().numpy()
         assert np.abs(qb - q_ref).max() <= 2e-3 * max(1.0, np.abs(q_ref).max()) and (qb != q_ref).mean() < 0.02
@@ -587,14 +591,14 @@ def test_qkv_epilogue_and_cached_attention_equal_the_fused_attention_path(P, ora
     # and the epilogue's mat-vecs against the oracle (q before rope is not observable: check k / v through the cache at one more cell)
     x = rng.normal(0, 1, (1, K)).astype(np.float32)
     pd = torch.tensor([100], dtype=torch.int32, device="cuda")
-    tab = P.rope_table(pd, dh, freq_factors=ff, freq_base=500000.0)
-    P.mul_mat_vec_qkv(ws, _dev(P, x), tab, pd, kcB, vcB, Hkv, dh, n_ctx, norm_w=nw, eps=1e-5, biases=bias)
+    tab = P.rope_table(pd, dh, freq_factors=ff, freq_base=500000.0, mode=mode)
+    P.mul_mat_vec_qkv(ws, _dev(P, x), tab, pd, kcB, vcB, Hkv, dh, n_ctx, norm_w=nw, eps=1e-5, biases=bias, neox=mode == 2)
     xn = oracle.rms_norm(x, nw.cpu().numpy(), 1e-5)
     v_ref = oracle.mul_mat(tv, blocks[2], K, Nkv, xn)[0] + bias[2].cpu().numpy()
     v_got = vcB.cpu().numpy().view(np.float16).astype(np.float32).reshape(Nkv, n_ctx)[:, 100]
     assert np.allclose(v_got, v_ref.astype(np.float16).astype(np.float32), rtol=2e-3, atol=2e-3)
     k_ref = oracle.mul_mat(Q4_K, blocks[1], K, Nkv, xn)[0] + bias[1].cpu().numpy()
-    k_ref = oracle.rope(k_ref.reshape(1, Hkv, dh), np.array([100], dtype=np.int32), freq_factors=ff.cpu().numpy(), freq_base=500000.0).reshape(-1)
+    k_ref = oracle.rope(k_ref.reshape(1, Hkv, dh), np.array([100], dtype=np.int32), freq_factors=ff.cpu().numpy(), freq_base=500000.0, mode=mode).reshape(-1)
     k_got = kcB.cpu().numpy().view(np.float16).astype(np.float32).reshape(n_ctx, Nkv)[100]
     assert np.allclose(k_got, k_ref.astype(np.float16).astype(np.float32), rtol=2e-3, atol=2e-3)
 

@@ -196,21 +196,26 @@ def test_reference_defrag_leaves_an_f16_cache_decode_unchanged(tmp_path, monkeyp
     assert np.abs(l2[:6] - l3[:6]).max() == 0.0 and np.abs(l2[6:] - l3[6:]).max() > 0.05 * np.abs(l3).max()      # the reference's bug, pinned
 
 
-def test_neox_rope_graphs_keep_the_round2_attention_form(tmp_path):
-    """build_qwen2 rotates with NEOX pairs (i, i + n_dims / 2): a workgroup's row slice of wq / wk does not hold both halves of a pair, so the
-    QKV epilogue cannot rotate there - the planner must keep RoPE + KV store inside the attention kernel (no rope table, no epilogue step)
-    however the shapes divide."""
+def test_neox_rope_graphs_take_the_qkv_epilogue_where_slices_hold_both_halves_of_a_pair(tmp_path):
+    """build_qwen2 rotates with NEOX pairs (i, i + n_dims / 2). Round 4: the wq | wk | wv launch gives every workgroup a slice made of two runs of
+    rows n_dims / 2 apart (GemvJob::nx_s), so the epilogue rotates there too - rope table + 'matvec + rope + KV store' + cached attention, as for
+    build_llama - whenever head_dim and the slice sizes are powers of two and n_rot == head_dim; a shape whose slices do not divide that way keeps
+    the round-2 form (RoPE + KV store inside the attention kernel)."""
     from _bind import Ref, best_ref_flavour
     import _fixtures8d as F
     ref = Ref(best_ref_flavour())
-    path = str(tmp_path / "q.gguf")
-    F.write_model(path, ref, arch=1, n_layer=2, n_embd=1024, n_head=8, n_head_kv=4, n_ff=1024, n_vocab=512, tag="planq")
-    _, _, st = run_llama_driver(path, [1, 5, 9], 3, ngl=99, n_ctx=64, threads=1, extra_args=["--keep-out-in-cuda"],
-                                env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1"}, flavour="avx2", timeout=120)
-    plans = [tuple(int(x) for x in m.groups()) for m in PLAN.finditer(st["stderr"])]
-    decode = [p for p in plans if p[0] > 3 and p[6] == 1]
-    assert decode and all(p[3] == 2 and p[2] == 8 for p in decode), plans           # 2 attention + 8 fused mat-vec launches for 2 layers
-    assert "rope table" not in st["stderr"] and "matvec + rope + KV store" not in st["stderr"] and "fused mask=" in st["stderr"]
+    for n_head, n_head_kv, epi in ((8, 4, True), (6, 3, False)):          # N_q = 1024 / 768 rows over 256 workgroups: slices of 4 / 3 rows
+        path = str(tmp_path / f"q{n_head}.gguf")
+        F.write_model(path, ref, arch=1, n_layer=2, n_embd=128 * n_head, n_head=n_head, n_head_kv=n_head_kv, n_ff=1024, n_vocab=512, tag=f"planq{n_head}")
+        _, _, st = run_llama_driver(path, [1, 5, 9], 3, ngl=99, n_ctx=64, threads=1, extra_args=["--keep-out-in-cuda"],
+                                    env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1"}, flavour="avx2", timeout=120)
+        plans = [tuple(int(x) for x in m.groups()) for m in PLAN.finditer(st["stderr"])]
+        decode = [p for p in plans if p[0] > 3 and p[6] == 1]
+        assert decode and all(p[3] == 2 and p[2] == 8 for p in decode), plans           # 2 attention + 8 fused mat-vec launches for 2 layers
+        if epi:
+            assert "rope table n_dims=128 mode=2" in st["stderr"] and "matvec + rope + KV store" in st["stderr"] and " cached mask=" in st["stderr"]
+        else:
+            assert "rope table" not in st["stderr"] and "matvec + rope + KV store" not in st["stderr"] and "fused mask=" in st["stderr"]
 
 
 def test_mha_models_keep_the_round2_long_context_kernel(tmp_path):
