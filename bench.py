@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-extras", action="store_true", help="skip extra_configs / plugin_decode / the llama_decode CPU baseline")
     ap.add_argument("--tmp", default=os.environ.get("TMPDIR", "/tmp"), help="where the synthetic GGUF files of the plug-in legs go")
-    ap.add_argument("--section", default="", help="(internal) run ONE extra leg in this process and print its JSON: prefill_qwen")
+    ap.add_argument("--section", default="", help="(internal) run ONE extra leg in this process and print its JSON: prefill_qwen | long_context[:model]")
     return ap.parse_args()
 
 
@@ -517,11 +517,93 @@ def section_prefill_qwen():
     print(json.dumps(pq), flush=True)
 
 
+def section_long_context(name="llama3-70b", ctxs=(8192, 32768)):
+    """Decode at long contexts (engine, the captured per-token graph): the cache is filled by 2048-token prompt chunks on the prefill path, then
+    24 greedy tokens are timed at each context; roofline = 8 TB/s over the weights + the F16 K / V^T bytes a token reads there. Next to it the
+    single-token attention kernel of that regime alone (attn_flash_mfma.hip), HIP events over launches that rotate through caches of more
+    than the 256 MB infinity cache: its achieved fraction of the 8 TB/s KV stream."""
+    import prima_cpp_amd.engine as E
+    import prima_cpp_amd.ops as P
+    from prima_cpp_amd.lib import Q6_K, row_size
+    hp, mixture, model_name = model_cfg(name)
+    n_ctx = max(ctxs) + 256
+    w = E.Window(hp, n_ctx=n_ctx)
+    w.fill_synthetic(mixture, seed=1234)
+    w.finalize(max_tokens=2048)
+    total_w = sum(layer_bytes(hp, mixture)) + row_size(Q6_K, hp["n_embd"]) * hp["n_vocab"] + hp["n_embd"] * 4
+    rng = np.random.default_rng(3)
+    pos, out = 0, {"workload": f"{model_name} batch-1 greedy decode at long contexts, F16 KV cache, 1 GPU, cache filled by 2048-token prompt chunks", "contexts": {}}
+    finite = True
+    for ctx in ctxs:
+        while pos < ctx - 32:
+            n = min(2048, ctx - 32 - pos)
+            toks = torch.from_numpy(rng.integers(0, hp["n_vocab"], n).astype(np.int32)).cuda()
+            w.decode(tokens=toks, pos0=pos, want_hidden=False, want_logits=False)
+            pos += n
+        io = torch.zeros(64, dtype=torch.int32, device="cuda")
+        io[0] = 7
+        w.generate(io, pos, 8, use_graph=True)            # warm-up (captures the graph of this regime)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        w.generate(io, pos + 8, 24, use_graph=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 24
+        pos += 32
+        finite = finite and bool(((io[:33] >= 0) & (io[:33] < hp["n_vocab"])).all().item())
+        kv = hp["n_layer"] * 2 * hp["head_dim"] * hp["n_head_kv"] * 2 * pos
+        roof = HBM_PEAK_GBS * 1e9 / (total_w + kv)
+        out["contexts"][str(pos)] = {"tokens_per_s": round(1 / dt, 2), "ms_per_token": round(dt * 1e3, 4), "kv_bytes_per_token": kv,
+                                     "hbm_roofline_tokens_per_s": round(roof, 1), "frac_of_hbm_roofline": round(1 / dt / roof, 4)}
+    out["argmax_in_range"] = finite
+    w.close()
+    del w
+    torch.cuda.empty_cache()
+    # the attention kernel of this regime alone, at the model's head shape
+    H, Hkv, dh = hp["n_head"], hp["n_head_kv"], hp["head_dim"]
+    Nkv = Hkv * dh
+    nbuf = max(2, int(600e6 / (n_ctx * Nkv * 4)) + 1)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    kcs = [torch.randn(n_ctx * Nkv, device="cuda", generator=g).to(torch.float16).view(torch.int16) for _ in range(nbuf)]
+    vcs = [torch.randn(n_ctx * Nkv, device="cuda", generator=g).to(torch.float16).view(torch.int16) for _ in range(nbuf)]
+    q = torch.randn(1, H * dh, device="cuda", generator=g).to(torch.float16).float()
+    scratch = P.attn_split_scratch(H, dh, n_ctx)
+    kern = {}
+    for ctx in ctxs:
+        n_kv = ctx - 7
+        pd = torch.tensor([n_kv - 1], dtype=torch.int32, device="cuda")
+        grid = 1024
+        while grid < n_kv:
+            grid *= 2
+        grid = min(grid, n_ctx)
+        for i in range(nbuf):
+            P.attn_cached(q, kcs[i], vcs[i], pd, H, Hkv, dh, n_ctx, dh ** -0.5, max_keys=grid, scratch=scratch)
+        torch.cuda.synchronize()
+        reps = 10 * nbuf
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(reps):
+            P.attn_cached(q, kcs[i % nbuf], vcs[i % nbuf], pd, H, Hkv, dh, n_ctx, dh ** -0.5, max_keys=grid, scratch=scratch)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        kvb = 2 * n_kv * Nkv * 2
+        kern[str(ctx)] = {"us_per_launch": round(us, 2), "kv_bytes_per_launch": kvb,
+                          "roofline": {"bound": "hbm", "achieved": round(kvb / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kvb / us / 1e3 / HBM_PEAK_GBS, 4)}}
+    out["attention_kernel"] = {"kernel": "attn_flash_mfma_kernel (scores and P.V of a GQA group on v_mfma_f32_16x16x32_f16, keys split over workgroups, in-launch merge)",
+                               "shape": f"H {H} Hkv {Hkv} head_dim {dh}", "timing": "HIP events over eager launches on torch's current stream (the launch stream), caches rotated out of the infinity cache",
+                               "cells": kern}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
     if a.section == "prefill_qwen":
         assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
         section_prefill_qwen()
+        return
+    if a.section.startswith("long_context"):
+        assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+        section_long_context(a.section.split(":")[1] if ":" in a.section else "llama3-70b")
         return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -750,6 +832,15 @@ def main():
                 result["prefill_qwen25_72b_q6k"] = json.loads(line[-1]) if line else {"error": f"rc {r.returncode}: {r.stderr[-400:]}"}
             except Exception as e:
                 result["prefill_qwen25_72b_q6k"] = {"error": str(e)[-400:]}
+            # decode at 8k / 32k cells (70B and config 5's model) + the long-context attention kernel against its KV stream - each in a process of its own
+            for key, mdl in (("long_context", "llama3-70b"), ("long_context_qwen25_72b", "qwen2.5-72b")):
+                try:
+                    import subprocess
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--section", "long_context:" + mdl], capture_output=True, text=True, timeout=420)
+                    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    result[key] = json.loads(line[-1]) if line else {"error": f"rc {r.returncode}: {r.stderr[-400:]}"}
+                except Exception as e:
+                    result[key] = {"error": str(e)[-400:]}
             try:
                 result["weight_streaming"] = streaming_probe()
             except Exception as e:

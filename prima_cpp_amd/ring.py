@@ -1,16 +1,18 @@
-"""Piped-ring driver: one process per GPU, layer windows per rank, activations handed neighbour to
-neighbour with torch.distributed send/recv (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
-CPU tests) instead of the reference's ZeroMQ PUSH/PULL + host bounce (llama_send_tensors /
-llama_recv_tensors, src/llama.cpp:18031-18077, ring loop :18503-18564).
+"""Piped-ring driver: one process per GPU, layer windows per rank, activations handed neighbour to neighbour - in place of the reference's
+ZeroMQ PUSH/PULL + host bounce (llama_send_tensors / llama_recv_tensors, src/llama.cpp:18031-18077, ring loop :18503-18564).
 
-The reference keeps ONE batch in flight (rank 0 blocks in recv until the token returns), so a layer
-split gives no throughput. Here `world` independent sequences are in flight, staggered by one rank:
-at micro-step m rank r works on sequence (m - r) mod world; after `world` micro-steps every sequence
-has advanced one token. Rank 0 additionally runs the head (result_norm + lm_head + greedy argmax) on the
+Where the work is: the SCHEDULES and the TRANSPORT live in C (csrc/ring.hip, `pm355_ring_*` of include/prima_mi355.h): RCCL send / recv on a
+communication stream with events against the compute stream, the pipelined prompt pass (`pm355_ring_prefill`), the one-sequence loop
+(`pm355_ring_single_token`) and the staggered multi-sequence decode loop (`pm355_ring_decode_staggered`). This module is process plumbing
+around them: the byte-balancing layer partition, `CRing` (ctypes binding; transport "rccl", or "torch" = the same C schedule over two
+callbacks that run torch.distributed batch_isend_irecv - what lets the world-size-2 tests drive the C code over gloo), and `RingDriver`, a
+Python reference implementation of the staggered schedule (transport- and compute-agnostic through the `RankCompute` interface) that
+the world-2/3 gloo tests compare the C schedule and a serial run with.
+
+The reference keeps ONE batch in flight (rank 0 blocks in recv until the token returns), so a layer split gives no throughput. Here `world`
+independent sequences are in flight, staggered by one rank: at micro-step m rank r works on sequence (m - r) mod world; after `world`
+micro-steps every sequence has advanced one token. Rank 0 additionally runs the head (result_norm + lm_head + greedy argmax) on the
 activation returned by the last rank, exactly like prima.cpp's rank 0 owns [inp_embd, its window, lm_head].
-
-The schedule is transport- and compute-agnostic (`RankCompute` interface) so it is covered by
-world_size-2 gloo tests on CPU with a fake window; `EngineCompute` binds it to the HIP engine.
 """
 import torch
 import torch.distributed as dist

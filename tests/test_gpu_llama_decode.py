@@ -244,3 +244,48 @@ def test_llama_decode_plugin_context_shift(gpu, kv, tmp_path, monkeypatch):
     assert _nmse(logits[:5], l0[:5]) < 1e-12 and _nmse(logits[5], l0[5]) > 1e-4
     _check(f"tiny_llama context shift {' '.join(kv)}", toks, logits, path, z["prompt"], n, 64, cpu_args=kv,
            nmse_floor=1e-3 if kv else 1e-6, err_floor=5e-2 if kv else 1e-3)
+
+
+def test_llama_decode_plugin_context_shift_on_a_q8_0_k_cache(gpu, tmp_path, monkeypatch):
+    """The K-shift graph on a QUANTIZED K cache (-ctk q8_0): CPY Q8_0 -> F32, ROPE, CPY F32 -> Q8_0 on views of the cache's native blocks
+    (build_k_shift, src/llama.cpp:10665-10719), executed on the hardware through the unmodified llama_decode. The reference's CPU backend aborts on
+    this graph (ggml_compute_forward_dup has no quantized source, ggml.c:8992-8996), so the yardstick is the SAME shift on an F16 K cache - which
+    is checked against the CPU in test_llama_decode_plugin_context_shift - teacher-forced with the same tokens: what may differ is the Q8_0
+    rounding of K (one more rounding for the shifted rows: they are dequantized, rotated and quantized again)."""
+    z = np.load(os.path.join(HERE, "golden", "tiny_llama_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / "tiny.gguf"), z)
+    n = 12
+    kv = ["-ctk", "q8_0"]
+    t_ns, l_ns, _ = run_llama_driver(path, z["prompt"], n, ngl=99, n_ctx=64, extra_args=GPU_ARGS + kv)          # no shift
+    monkeypatch.setenv("REFDRV_SHIFT", "4,2,3")
+    tq, lq, st = run_llama_driver(path, z["prompt"], n, ngl=99, n_ctx=64, extra_args=GPU_ARGS + kv)
+    assert "MI355X0 KV buffer size" in st["stderr"] and "q8_0" in st["stderr"]
+    assert _nmse(lq[:5], l_ns[:5]) < 1e-12 and _nmse(lq[5], l_ns[5]) > 1e-4                      # the shift happened, at the step asked for
+    tf, lf, _ = run_llama_driver(path, z["prompt"], n, ngl=99, n_ctx=64, extra_args=GPU_ARGS, force=tq[:-1])      # F16 cache, same shift, same tokens
+    nm_shift = _nmse(lq, lf)
+    monkeypatch.delenv("REFDRV_SHIFT")
+    tf0, lf0, _ = run_llama_driver(path, z["prompt"], n, ngl=99, n_ctx=64, extra_args=GPU_ARGS, force=t_ns[:-1])
+    nm_plain = _nmse(l_ns, lf0)                                                                # what a Q8_0 K cache costs without any shift
+    print(f"\n[K-shift on a Q8_0 K cache] logits NMSE vs the F16-cache run: {nm_shift:.2e} with the shift, {nm_plain:.2e} without")
+    assert np.isfinite(lq).all()
+    assert nm_shift < max(5e-3, 10 * nm_plain), (nm_shift, nm_plain)
+
+
+def test_llama_decode_plugin_defrag_on_a_q8_0_k_cache_moves_whole_blocks(gpu, tmp_path, monkeypatch):
+    """build_defrag (src/llama.cpp:10721) on a Q8_0 K cache: cell-to-cell copies between views of native Q8_0 blocks (cpy_q80_q80_kernel). Moving
+    whole blocks is lossless, so a defragmentation must leave every later logit unchanged - the property the reference shows on F16 caches and
+    breaks on quantized ones (its byte copy multiplies element counts with the block size: pinned in
+    tests/test_plugin_plan.py::test_reference_defrag_leaves_an_f16_cache_decode_unchanged). Holes are made by llama_kv_cache_seq_rm first."""
+    z = np.load(os.path.join(HERE, "golden", "tiny_llama_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / "tiny.gguf"), z)
+    for kv in (["-ctk", "q8_0"], []):
+        monkeypatch.setenv("REFDRV_RM", "3,2,5")
+        t0, l0, st0 = run_llama_driver(path, z["prompt"], 10, ngl=99, n_ctx=64, extra_args=GPU_ARGS + kv)
+        monkeypatch.setenv("REFDRV_DEFRAG", "5")
+        t1, l1, st1 = run_llama_driver(path, z["prompt"], 10, ngl=99, n_ctx=64, extra_args=GPU_ARGS + kv, force=t0[:-1])
+        monkeypatch.delenv("REFDRV_DEFRAG")
+        monkeypatch.delenv("REFDRV_RM")
+        assert "MI355X0 KV buffer size" in st1["stderr"]
+        d = np.abs(l1 - l0).max() / np.abs(l0).max()
+        print(f"\n[defrag, K cache {'q8_0' if kv else 'f16'}] max |d logit| / max |logit| = {d:.2e}")
+        assert d <= 1e-4, (kv, d)

@@ -605,7 +605,7 @@ def test_qkv_epilogue_and_cached_attention_equal_the_fused_attention_path(P, ora
 
 @pytest.mark.parametrize("dh,H,Hkv", [(128, 8, 1), (128, 8, 2), (64, 8, 4), (64, 4, 4), (64, 16, 1)])
 def test_long_context_matrix_core_attention_over_cached_cells(P, dh, H, Hkv):
-    """attn_flash_mfma.hip: scores and P.V of a GQA group on v_mfma_f32_32x32x16_f16 with permuted key rows, per-wave online softmax, spans
+    """attn_flash_mfma.hip: scores and P.V of a GQA group on v_mfma_f32_16x16x32_f16 with permuted key rows, per-wave online softmax, spans
     merged in the launch - against softmax(K q * scale + mask) V in float64 on the same F16 cache values, over cells-attended that
     exercise: one partial tile, one span, several spans with a ragged tail, the doubled span (> 8k cells), with and without a mask that
     hides cells (-inf), position given as d_pos and as {cell, cells attended}."""
@@ -657,6 +657,112 @@ def test_long_context_matrix_core_attention_over_cached_cells(P, dh, H, Hkv):
             worst = max(worst, float(err))
             assert err < 2e-3, (n_kv, h, err)
     print(f"\n[matrix-core long-context attention dh {dh} H {H} Hkv {Hkv}] worst max|d| / max|ref| = {worst:.2e}")
+
+
+def _attn_refs(kc, vt, q, n_kv, H, Hkv, dh, scale):
+    """float64 attention over F16 cache values, and the reference graph's rounding points (MUL_MAT(k, q) -> SOFT_MAX_EXT -> MUL_MAT(v, kq), ggml.c:12445-12473:
+    the NORMALISED probabilities are rounded to F16 as src1 of the V^T.p product, accumulation in f32): [H][dh] each."""
+    R = H // Hkv
+    ref64 = np.empty((H, dh)); ref16 = np.empty((H, dh))
+    for g in range(Hkv):
+        Kh = kc[:n_kv, g * dh:(g + 1) * dh].astype(np.float32)
+        Vh = vt[g * dh:(g + 1) * dh, :n_kv].astype(np.float32)
+        for h in range(g * R, (g + 1) * R):
+            s = (Kh.astype(np.float64) @ q[h].astype(np.float64)) * scale
+            pr = np.exp(s - s.max()); pr /= pr.sum()
+            ref64[h] = Vh.astype(np.float64) @ pr
+            s32 = (Kh @ q[h]).astype(np.float32) * np.float32(scale)
+            e32 = np.exp(s32 - s32.max()).astype(np.float32)
+            p16 = (e32 / np.float32(e32.astype(np.float64).sum())).astype(np.float16).astype(np.float32)
+            ref16[h] = (Vh.astype(np.float64) @ p16.astype(np.float64))
+    return ref64, ref16
+
+
+@pytest.mark.parametrize("n_kv", [8192, 32700])
+def test_long_context_attention_at_the_70b_head_shape(P, n_kv):
+    """The shape the long-context numbers are quoted on - 64 query heads, 8 KV heads, head_dim 128, 8k and 32.7k cells (grid = 8 x 32 spans: every
+    resident slot of the chip) - against float64 AND against the reference graph's own rounding points (p rounded to F16 AFTER the normalisation;
+    the kernel rounds exp(s - m) before it, attn_flash_mfma.hip): both differences are measured and bounded."""
+    torch = P.torch
+    H, Hkv, dh = 64, 8, 128
+    rng = np.random.default_rng(1000 + n_kv)
+    n_ctx = 32768 + 256
+    Nkv = Hkv * dh
+    kc = rng.normal(0, 1, (n_ctx, Nkv)).astype(np.float16)
+    vt = rng.normal(0, 1, (Nkv, n_ctx)).astype(np.float16)
+    kcd = torch.from_numpy(kc.view(np.int16)).cuda().reshape(-1)
+    vcd = torch.from_numpy(vt.view(np.int16)).cuda().reshape(-1)
+    scratch = P.attn_split_scratch(H, dh, n_ctx)
+    scale = 1.0 / np.sqrt(dh)
+    q = (rng.normal(0, 1, (H, dh)) * 1.5).astype(np.float16).astype(np.float32)
+    qd = torch.from_numpy(q.reshape(1, -1)).cuda()
+    pd = torch.tensor([n_kv - 1], dtype=torch.int32, device="cuda")
+    cells = 1024
+    while cells < n_kv: cells *= 2
+    cells = min(cells, n_ctx)
+    outs = [P.attn_cached(qd, kcd, vcd, pd, H, Hkv, dh, n_ctx, scale, max_keys=cells, scratch=scratch).cpu().numpy().reshape(H, dh) for _ in range(3)]
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])              # launch to launch: bitwise (fixed merge order)
+    got = outs[0]
+    ref64, ref16 = _attn_refs(kc, vt, q, n_kv, H, Hkv, dh, scale)
+    den = np.maximum(1e-3, np.abs(ref64).max(axis=1))
+    e64 = (np.abs(got - ref64).max(axis=1) / den).max()
+    e16 = (np.abs(got - ref16).max(axis=1) / den).max()
+    r1664 = (np.abs(ref16 - ref64).max(axis=1) / den).max()
+    print(f"\n[matrix-core attention, H 64 / Hkv 8 / dh 128, {n_kv} cells] max|d| / max|ref|: kernel vs float64 {e64:.2e}, kernel vs F16-rounded-p reference {e16:.2e}, "
+          f"that reference vs float64 {r1664:.2e}")
+    assert np.isfinite(got).all()
+    assert e64 < 2e-3 and e16 < 2e-3 + r1664
+
+
+def test_long_context_attention_merge_survives_a_starved_chip(P):
+    """The in-launch merge of attn_flash_mfma.hip lets the last arrivals of a KV head spin (bounded) for workgroups still behind them. Provoked here:
+    a co-running stream-read kernel holds every CU's wave slots while the 8 x 32 attention grid is launched on another stream, so its workgroups
+    trickle in as slots free up. Required: the launch ENDS (no hang) and the result is either correct or the fail-loud NaN - never a wrong number."""
+    import ctypes as C
+    torch = P.torch
+    plib = P.L.load_probe()
+    plib.pm355_probe_stream_read.restype = C.c_int
+    plib.pm355_probe_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    H, Hkv, dh, n_kv = 64, 8, 128, 16384
+    rng = np.random.default_rng(4242)
+    n_ctx = 16384 + 256
+    Nkv = Hkv * dh
+    kc = rng.normal(0, 1, (n_ctx, Nkv)).astype(np.float16)
+    vt = rng.normal(0, 1, (Nkv, n_ctx)).astype(np.float16)
+    kcd = torch.from_numpy(kc.view(np.int16)).cuda().reshape(-1)
+    vcd = torch.from_numpy(vt.view(np.int16)).cuda().reshape(-1)
+    scratch = P.attn_split_scratch(H, dh, n_ctx)
+    scale = 1.0 / np.sqrt(dh)
+    q = (rng.normal(0, 1, (H, dh)) * 1.5).astype(np.float16).astype(np.float32)
+    qd = torch.from_numpy(q.reshape(1, -1)).cuda()
+    pd = torch.tensor([n_kv - 1], dtype=torch.int32, device="cuda")
+    ref64, _ = _attn_refs(kc, vt, q, n_kv, H, Hkv, dh, scale)
+    hog_src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    n_nan = n_ok = 0
+    for trial in range(6):
+        # two 1024-thread workgroups per CU (every wave slot of the chip), several passes queued back to back on the side stream
+        for _ in range(3):
+            assert plib.pm355_probe_stream_read(hog_src.data_ptr(), hog_src.numel(), 2, 8, sink.data_ptr(), side.cuda_stream) == 0
+        out = P.attn_cached(qd, kcd, vcd, pd, H, Hkv, dh, n_ctx, scale, max_keys=16384, scratch=scratch)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().reshape(H, dh)
+        if np.isnan(got).any():
+            n_nan += 1                                    # fail-loud path: a whole KV head's outputs are NaN
+            bad = np.isnan(got).any(axis=1)
+            assert all(bad[g * 8:(g + 1) * 8].all() or not bad[g * 8:(g + 1) * 8].any() for g in range(Hkv))
+            good = ~bad
+        else:
+            n_ok += 1
+            good = np.ones(H, dtype=bool)
+        err = np.abs(got[good] - ref64[good]).max(axis=1) / np.maximum(1e-3, np.abs(ref64[good]).max(axis=1)) if good.any() else np.zeros(1)
+        assert err.max() < 2e-3, (trial, err.max())
+    print(f"\n[starved merge] {n_ok} launches correct, {n_nan} launches took the fail-loud NaN path; none hung, none wrong")
+    # and an undisturbed launch afterwards is clean (the arrival counters are never reset: a timed-out launch must not poison the next)
+    out = P.attn_cached(qd, kcd, vcd, pd, H, Hkv, dh, n_ctx, scale, max_keys=16384, scratch=scratch).cpu().numpy().reshape(H, dh)
+    assert np.isfinite(out).all() and (np.abs(out - ref64).max(axis=1) / np.maximum(1e-3, np.abs(ref64).max(axis=1))).max() < 2e-3
 
 
 def _pm_tensor(C, t, type_, ne, nb):

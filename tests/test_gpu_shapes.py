@@ -58,7 +58,8 @@ SHAPES = {
 def test_model_shaped_layer_decode_and_prefill(E, oracle, name, monkeypatch):
     torch = E.torch
     if name.endswith("+flash"):
-        # the decode step at position 32 then runs the long-context kernel (attn_flash.hip) at the model's GQA shape (8 query heads per KV head)
+        # the decode step at position 32 then runs the long-context path at the model's GQA shape (8 query heads per KV head): the matrix-core
+        # kernel over cached cells (attn_flash_mfma.hip) where the QKV epilogue serves the rope mode, else the round-2 kernel (attn_flash.hip)
         monkeypatch.setenv("PM355_ATTN_SPLIT_MIN", "16")
         name = name[:-6]
     arch, n_ff, tv, td, tout = SHAPES[name]

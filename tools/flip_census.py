@@ -43,7 +43,7 @@ def census(name, a, b):
 
 
 wo, wg, wu, wd = rand_weight(Q4_K, E, E), rand_weight(Q4_K, E, F), rand_weight(Q4_K, E, F), rand_weight(Q6_K, F, E)
-tot_a = tot_h = hit = 0
+tot_a = tot_h = hit = valid = 0
 for seed in range(SEEDS):
     torch.manual_seed(seed)
     x = torch.randn(T, E, device="cuda")
@@ -58,6 +58,12 @@ for seed in range(SEEDS):
     xnq = P.quantize_act(xn, Q8_K)
     hv = torch.nn.functional.silu(P.mul_mat_vec(wg, xq=xnq, ncols=T)) * P.mul_mat_vec(wu, xq=xnq, ncols=T)
     hm = torch.nn.functional.silu(P.mul_mat_small(wg, xq=xnq, n_tokens=T)) * P.mul_mat_small(wu, xq=xnq, n_tokens=T)
+    if not (torch.isfinite(hv).all() and torch.isfinite(hm).all() and torch.isfinite(mid_vec).all()):
+        # (round 3 printed `nan` / NMSE 0 for two sets and counted them as agreement: silu(gate) * up of random blocks can overflow f32)
+        print(f"   set {seed}: non-finite activations ({int((~torch.isfinite(hv)).sum())} of {hv.numel()} values of silu(gate) * up) - EXCLUDED from the census")
+        tot_a -= 0
+        continue
+    valid += 1
     n = census("silu(gate) * up -> input of ffn_down (K = 28672)", hv, hm)
     hq = P.quantize_act(hv, Q8_K)
     out_v = P.mul_mat_vec(wd, xq=hq, ncols=T, resid=mid_vec)
@@ -70,5 +76,5 @@ for seed in range(SEEDS):
         print(f"ffn_down on each path's OWN int8 input ({n} bytes apart): NMSE {(d.pow(2).sum() / out_v.double().pow(2).sum()).item():.2e}  <- the order of the whole-step figure")
         hit += 1
     tot_h += n
-print(f"\n{SEEDS} activation sets x {T} tokens: {tot_a} of {SEEDS * T * E} ffn-input bytes and {tot_h} of {SEEDS * T * F} ffn_down-input bytes rounded the other way; "
-      f"{hit} of {SEEDS} steps carry at least one flipped ffn_down byte")
+print(f"\n{valid} finite activation sets (of {SEEDS} drawn) x {T} tokens: {tot_a} of {SEEDS * T * E} ffn-input bytes and {tot_h} of {valid * T * F} ffn_down-input bytes rounded the other way; "
+      f"{hit} of {valid} steps carry at least one flipped ffn_down byte")
