@@ -342,27 +342,26 @@ def extra_config(name, steps=32, warmup=8, prompt=16, n_ctx=4096):
     token): tokens/s and fraction of that model's HBM roofline."""
     import prima_cpp_amd.engine as E
     from prima_cpp_amd.lib import Q6_K, row_size
-    from prima_cpp_amd.ring import EngineCompute, RingDriver
+    from prima_cpp_amd.ring import CRing
     hp, mixture, model_name = model_cfg(name)
     lb = layer_bytes(hp, mixture)
     total_w = sum(lb) + row_size(Q6_K, hp["n_embd"]) * hp["n_vocab"] + hp["n_embd"] * 4
     win = E.Window(hp, lo=0, hi=hp["n_layer"], flags=E.HAS_EMBD | E.HAS_HEAD, n_ctx=n_ctx)
     win.fill_synthetic(mixture, seed=1234)
     win.finalize(max_tokens=1, n_seq=1)
-    drv = RingDriver(EngineCompute(win, 1, use_graph=True), 0, 1)
+    ring = CRing(0, 1, transport="local")
     rng = np.random.default_rng(1234)
     toks = rng.integers(0, hp["n_vocab"], size=prompt)
-    for s_ in range(prompt + warmup):
-        drv.micro_step(forced_token=int(toks[s_]) if s_ < prompt else None)
+    ring.decode_staggered(win, prompt + warmup, forced=[int(toks[s_]) if s_ < prompt else None for s_ in range(prompt + warmup)], reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        drv.micro_step(forced_token=None)
+    ring.decode_staggered(win, steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    drv.flush()
+    ring.wait()
     torch.cuda.synchronize()
-    finite = bool(torch.isfinite(drv.c.x_out[drv.c.k]).all().item())
+    finite = bool(torch.isfinite(ring.last_output(hp["n_embd"])).all().item())
+    ring.close()
     win.close()
     roof = HBM_PEAK_GBS * 1e9 / total_w
     return {"workload": f"{model_name} batch-1 greedy decode, {prompt}-token synthetic prompt, n_ctx {n_ctx}, F16 KV cache, 1 GPU",
@@ -621,7 +620,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import prima_cpp_amd.engine as E
-    from prima_cpp_amd.ring import EngineCompute, RingDriver, partition_layers
+    from prima_cpp_amd.ring import partition_layers
     hp, mixture, model_name = model_cfg(a.model)
     from prima_cpp_amd.lib import Q6_K, row_size
     lb = layer_bytes(hp, mixture)
@@ -636,7 +635,6 @@ def main():
         RING_UBATCH = 512                                  # tokens per hop of the pipelined prompt pass (the reference's n_ubatch)
         win.finalize(max_tokens=RING_UBATCH if world > 1 else 1, n_seq=world)
         use_graph = not a.no_graph
-        comp = EngineCompute(win, world, use_graph=use_graph)
         # N > 1 over RCCL: the transport is the C one (pm355_ring_*: ncclSend / ncclRecv on the library's communication stream, event
         # hand-off, no host wait per micro-step); PM355_RING_TRANSPORT=torch keeps torch.distributed's batch_isend_irecv instead
         # The ring itself is C (pm355_ring_*: multi-token hand-off, pipelined prompt pass, single-sequence loop); its exchanges travel over
@@ -662,25 +660,15 @@ def main():
             ring_transport = "rccl" if c_ring is not None else "torch"
             if c_ring is None:
                 c_ring = CRing(rank, world, transport="torch")
-        drv = RingDriver(comp, rank, world, c_ring=c_ring)
+        if c_ring is None:
+            from prima_cpp_amd.ring import CRing
+            c_ring = CRing(0, 1, transport="local")          # one window: the same C loop, no communicator
         rng = np.random.default_rng(1234)
         prompt = rng.integers(0, hp["n_vocab"], size=(world, a.prompt))
         prompt[:, 0] = 128000 % hp["n_vocab"]            # BOS first, like llama-bench
 
-        first_tok = None                                   # world > 1: the token each sequence starts its decode with (after the prompt pass)
-
-        def one_step(step_idx):
-            """every in-flight sequence advances one token: `world` micro-steps on every rank"""
-            for j in range(world):
-                forced = None
-                if rank == 0:
-                    seq = (drv.m) % world
-                    if world == 1 and step_idx < a.prompt:
-                        forced = int(prompt[seq, step_idx])
-                    elif world > 1 and drv.m < world:
-                        forced = first_tok[seq]
-                drv.micro_step(forced_token=forced)
-
+        # The decode loop is C (pm355_ring_decode_staggered): `world` sequences in flight one rank apart, a step = every sequence advances one
+        # token = `world` micro-steps on every rank; one call enqueues all of them, no interpreter between the steps of the timed region.
         def sync():
             torch.cuda.synchronize()
             if world > 1:
@@ -700,22 +688,20 @@ def main():
             c_ring.prefill(win, toks_d, world, a.prompt, min(RING_UBATCH, a.prompt), rows)
             sync()
             ring_prompt = time.perf_counter() - tp0
+            first_tok = [None] * world                     # the token each sequence starts its decode with (after the prompt pass)
             if rank == 0:
                 am = torch.empty(1, dtype=torch.int32, device="cuda")
-                first_tok = []
                 for q in range(world):
                     win.head(rows[q], argmax=am)
-                    first_tok.append(int(am.item()))
+                    first_tok[q] = int(am.item())
             win.set_seq(0)                                  # the staggered decode meets the sequences in the order 0, 1, ...
-            for s in range(a.warmup):
-                one_step(a.prompt + s)
+            n_w = max(a.warmup, 1) * world
+            c_ring.decode_staggered(win, n_w, forced=(first_tok + [None] * (n_w - world)) if rank == 0 else None, reset=True, use_graph=use_graph)
         else:
-            for s in range(n_pre):
-                one_step(s)
+            c_ring.decode_staggered(win, n_pre, forced=[int(prompt[0, s_]) if s_ < a.prompt else None for s_ in range(n_pre)], reset=True, use_graph=use_graph)
         sync()
         t0 = time.perf_counter()
-        for s in range(a.steps):
-            one_step(n_pre + s)
+        c_ring.decode_staggered(win, a.steps * world, use_graph=use_graph)
         sync()
         t1 = time.perf_counter()
         dt = t1 - t0
@@ -723,11 +709,12 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() != "gloo" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        drv.flush()
+        c_ring.wait()
         sync()
         # sanity of the synthetic workload: the activations the timed steps produced are finite (a fill that leaves NaNs behind times the
         # same kernels but is not a model)
-        finite = bool(torch.isfinite(comp.x_out[comp.k]).all().item())
+        lo_ = c_ring.last_output(hp["n_embd"])
+        finite = bool(lo_ is not None and torch.isfinite(lo_).all().item())
 
         # The reference's own mode next to the aggregate: ONE sequence in flight, every token once round the ring with the other ranks idle
         # (rank 0 blocked in recv until it returns, src/llama.cpp:18509) - what exposes the hop latency. And the pipelined prompt pass.

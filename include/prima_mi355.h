@@ -475,6 +475,18 @@ PM355_API int pm355_ring_prefill(pm355_ring * r, pm355_model * m, int n_seq, con
  * sequence `seq` per call on every rank. Rank 0: embeds *d_token, runs its window, sends, receives the last rank's row, runs the head and writes
  * the next token to *d_token (and the logits to d_logits when non-NULL); other ranks: receive, window, send. */
 PM355_API int pm355_ring_single_token(pm355_ring * r, pm355_model * m, int seq, int32_t * d_token, float * d_logits, pm355_stream_t compute_stream);
+/* The staggered multi-sequence decode loop in C (what produces the N-GPU aggregate of bench.py --gpus N): `world` sequences in flight one rank
+ * apart - at micro-step m rank r works on sequence (m - r) mod world - where the reference keeps one batch in flight and rank 0 blocks until the
+ * token has been round the ring (llama_decode_internal, src/llama.cpp:18503-18564). The window must be finalized with n_seq == world. Per
+ * micro-step: wait (device-side) for the previous exchange -> window step (rank 0: head on the returned activation -> argmax -> embed -> window,
+ * one captured graph) -> grouped exchange. Nothing blocks the host. forced: host array [n_micro] for rank 0 (token to feed instead of the head's
+ * argmax, < 0 = none; required for the first `world` micro-steps after a reset), else NULL. d_tokens_out: device int32 [n_micro] on rank 0
+ * (token fed at each micro-step), or NULL. reset != 0 restarts the schedule at micro-step 0. Finish with pm355_ring_wait. */
+PM355_API int pm355_ring_decode_staggered(pm355_ring * ring, pm355_model * m, int n_micro, const int32_t * forced, int32_t * d_tokens_out, int reset,
+                                          int use_graph, pm355_stream_t compute_stream);
+PM355_API const float * pm355_ring_decode_last_output(const pm355_ring * ring);
+/* a ring of world size 1 without a communicator (the schedules above on a single window) */
+PM355_API pm355_ring * pm355_ring_init_local(void);
 
 #ifdef __cplusplus
 }

@@ -78,6 +78,9 @@ struct pm355_ring {
     pm355_ring_exchange_fn cb_exchange = nullptr; pm355_ring_wait_fn cb_wait = nullptr; void * cb_user = nullptr;
     // prompt pipeline / single-stream buffers: [2] inputs + [2] outputs of up to buf_floats f32
     float * pin[2] = {nullptr, nullptr}, * pout[2] = {nullptr, nullptr}; size_t buf_floats = 0;
+    // staggered multi-sequence decode (pm355_ring_decode_staggered): micro-step counter, output toggle, the last output (world 1: it is the next
+    // step's input), rank 0's token slot on the device
+    long stag_m = 0; int stag_k = 0; float * stag_last = nullptr; int32_t * d_cur = nullptr;
 };
 
 static int ring_buffers(pm355_ring * r, size_t n_floats) {
@@ -133,10 +136,18 @@ pm355_ring * pm355_ring_init_cb(int rank, int world, pm355_ring_exchange_fn exch
     return r;
 }
 
+// world size 1 without a communicator: the schedules below run on one window (no exchange is ever enqueued)
+pm355_ring * pm355_ring_init_local(void) {
+    pm355_ring * r = new pm355_ring();
+    r->rank = 0; r->world = 1; r->next = r->prev = 0;
+    return r;
+}
+
 void pm355_ring_free(pm355_ring * r) {
     if (!r) return;
     if (r->cs) { (void) hipStreamSynchronize(r->cs); }
     for (int i = 0; i < 2; ++i) { if (r->pin[i]) (void) hipFree(r->pin[i]); if (r->pout[i]) (void) hipFree(r->pout[i]); }
+    if (r->d_cur) (void) hipFree(r->d_cur);
     if (r->comm) (void) rccl().CommDestroy(r->comm);
     if (r->cs) (void) hipStreamDestroy(r->cs);
     if (r->ready) (void) hipEventDestroy(r->ready);
@@ -299,6 +310,63 @@ int pm355_ring_single_token(pm355_ring * r, pm355_model * m, int seq, int32_t * 
     if (rc) return rfail(rc, pm355_model_error(m));
     return pm355_ring_exchange2(r, r->pout[0], E, nullptr, 0, compute_stream);
 }
+
+// The staggered multi-sequence decode loop of the ring, in C (was RingDriver.micro_step in prima_cpp_amd/ring.py: one interpreter round trip per
+// ~1 ms micro-step and rank). The reference keeps ONE batch in flight - rank 0 blocks in recv until the token has been round the ring
+// (llama_decode_internal, src/llama.cpp:18503-18564) - so a layer split cannot speed it up; here `world` sequences are in flight, one rank apart:
+// at micro-step m rank r works on sequence (m - r) mod world, every rank's window holds `world` KV slabs and rotates its sequence counter in the
+// captured graph. Per micro-step and rank, all enqueued, no host wait:
+//   wait for the previous exchange -> window step (rank 0: head on the activation the last rank returned -> argmax -> embed -> its window, ONE
+//   graph; other ranks: their window on the incoming row) -> grouped exchange {send the output row on, receive the next step's input}.
+// forced (host, rank 0 only, may be NULL): token id to feed at micro-step i of this call instead of the head's argmax (prompt tokens, the first
+// token after a prompt pass; < 0 = none); mandatory while no activation has come back yet (the first `world` micro-steps). d_tokens_out (device,
+// rank 0, may be NULL): slot i receives the token fed at micro-step i of this call. reset != 0: the schedule starts again at micro-step 0.
+int pm355_ring_decode_staggered(pm355_ring * r, pm355_model * m, int n_micro, const int32_t * forced, int32_t * d_tokens_out, int reset, int use_graph,
+                                pm355_stream_t compute_stream) {
+    if (!r || !m || n_micro < 0) return rfail(PM355_E_SHAPE, "ring_decode_staggered: arguments");
+    const int W = r->world, rank = r->rank;
+    const int64_t E = pm355_model_n_embd(m);
+    hipStream_t st = (hipStream_t) compute_stream;
+    if (ring_buffers(r, (size_t) E)) return rfail(PM355_E_NOMEM, "ring_decode_staggered: buffers");
+    if (!r->d_cur && hipMalloc((void **) &r->d_cur, 64) != hipSuccess) return rfail(PM355_E_NOMEM, "ring_decode_staggered: token slot");
+    if (reset) { r->stag_m = 0; r->stag_k = 0; r->stag_last = nullptr; }
+    auto need_recv = [&](long mm) { return W > 1 && (rank == 0 ? mm >= W : mm >= rank); };
+    for (int i = 0; i < n_micro; ++i) {
+        const long mm = r->stag_m++;
+        const bool active = mm >= rank;
+        int rc = pm355_ring_wait(r, compute_stream);          // previous exchange: our last row has left, this step's input is here
+        if (rc) return rc;
+        float * out = nullptr;
+        if (active) {
+            r->stag_k ^= 1;
+            out = r->pout[r->stag_k];
+            const float * x_in = W == 1 ? r->stag_last : (need_recv(mm) ? r->pin[mm & 1] : nullptr);
+            if (rank == 0) {
+                const bool have_forced = forced && forced[i] >= 0;
+                if (have_forced || !x_in) {
+                    if (!have_forced && mm < W) return rfail(PM355_E_SHAPE, "ring_decode_staggered: the first `world` micro-steps of rank 0 need forced tokens");
+                    if (have_forced && pm355_set_i32x2(r->d_cur, forced[i], 0, compute_stream)) return rfail(PM355_E_HIP, "ring_decode_staggered: token upload");
+                    rc = pm355_model_step_ex(m, r->d_cur, nullptr, out, nullptr, nullptr, 1, 1, 0, use_graph, compute_stream);
+                } else {
+                    rc = pm355_model_step_ex(m, r->d_cur, x_in, out, nullptr, r->d_cur, 1, 1, 1, use_graph, compute_stream);     // head -> argmax -> embed -> window
+                }
+                if (!rc && d_tokens_out && hipMemcpyAsync(d_tokens_out + i, r->d_cur, 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    return rfail(PM355_E_HIP, "ring_decode_staggered: token copy");
+            } else {
+                rc = pm355_model_step_ex(m, nullptr, x_in, out, nullptr, nullptr, 1, 1, 0, use_graph, compute_stream);
+            }
+            if (rc) return rfail(rc, pm355_model_error(m));
+            r->stag_last = out;
+        }
+        if (W > 1) {
+            rc = pm355_ring_exchange2(r, active ? out : nullptr, E, need_recv(mm + 1) ? r->pin[(mm + 1) & 1] : nullptr, E, compute_stream);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+// the last output row of this rank's staggered loop (device pointer; NULL before the first active micro-step)
+const float * pm355_ring_decode_last_output(const pm355_ring * r) { return r ? r->stag_last : nullptr; }
 
 int pm355_ring_rank(const pm355_ring * r) { return r ? r->rank : -1; }
 int pm355_ring_world(const pm355_ring * r) { return r ? r->world : 0; }

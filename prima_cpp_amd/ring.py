@@ -209,9 +209,16 @@ class CRing:
         lib.pm355_ring_single_token.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pm355_ring_step_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+        lib.pm355_ring_decode_staggered.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.pm355_ring_decode_last_output.restype = C.c_void_p
+        lib.pm355_ring_decode_last_output.argtypes = [C.c_void_p]
+        lib.pm355_ring_init_local.restype = C.c_void_p
         self.rank, self.world, self.group, self.transport = rank, world, group, transport
         self.h = None
-        if transport == "torch":
+        if transport == "local":
+            assert world == 1 and rank == 0
+            self.h = lib.pm355_ring_init_local()
+        elif transport == "torch":
             XF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p)
             WF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
             self._pend = None
@@ -305,6 +312,27 @@ class CRing:
         st = torch.cuda.current_stream().cuda_stream
         self._chk(self.lib.pm355_ring_single_token(self.h, window.h, seq, token.data_ptr() if token is not None else None,
                                                    logits.data_ptr() if logits is not None else None, st), "pm355_ring_single_token")
+
+    def decode_staggered(self, window, n_micro, forced=None, tokens_out=None, reset=False, use_graph=True):
+        """n_micro micro-steps of the staggered multi-sequence decode schedule in C (pm355_ring_decode_staggered): no interpreter in the loop.
+        forced: per micro-step token ids for rank 0 (None / negative = the head's argmax); tokens_out: int32 device tensor [n_micro] on rank 0."""
+        import ctypes as C
+        st = torch.cuda.current_stream().cuda_stream
+        fa = None
+        if forced is not None:
+            fa = (C.c_int32 * n_micro)(*[-1 if f is None else int(f) for f in forced])
+        self._chk(self.lib.pm355_ring_decode_staggered(self.h, window.h, n_micro, fa, tokens_out.data_ptr() if tokens_out is not None else None,
+                                                       1 if reset else 0, 1 if use_graph else 0, st), "pm355_ring_decode_staggered")
+
+    def last_output(self, n_embd):
+        """this rank's last output row of the staggered loop, as a torch view (debug / finiteness checks)"""
+        import ctypes as C
+        p = self.lib.pm355_ring_decode_last_output(self.h)
+        if not p:
+            return None
+        t = torch.empty(n_embd, dtype=torch.float32, device="cuda")
+        self._chk(self.lib.pm355_memcpy_d2d(t.data_ptr(), p, n_embd * 4, torch.cuda.current_stream().cuda_stream), "copy of the last output row")
+        return t
 
     def close(self):
         if self.h:

@@ -210,20 +210,22 @@ def test_peaked_fixture_long_context_tokens_identical(gpu, files, mode, monkeypa
         assert _nmse(lg, ls) < 1e-3
 
 
-def test_peaked_fixture_8k_prompt_tokens_identical_at_the_8b_shape(gpu, files):
-    """the long-context path at a real model shape. Llama-3-8B shape (32 query / 8 KV heads, head_dim 128, 32 layers), an 8200-token
-    prompt - prompt chunks on the prefill path, then 16 greedy tokens whose attention runs the matrix-core kernel over > 8k cached cells - against the
-    reference CPU (AVX2 build: the scalar one would take an hour on this prompt) through the plug-in's default graph and on the resident engine:
-    the same 16 tokens, logits within the F16-accumulation tier."""
-    if "8b" not in SIZES:
-        pytest.skip("PM355_8D_SIZES without '8b'")
-    size, n_prompt, n_gen, n_ctx = "8b", 8200, 16, 8448
+def test_peaked_fixture_8k_prompt_tokens_identical(gpu, files):
+    """whole-model equality beyond 8k cached cells. An 8200-token prompt - prompt chunks on the prefill path, then 16 greedy tokens
+    whose attention runs the matrix-core kernel over > 8k cached cells - against the reference CPU through the plug-in's default graph and on the
+    resident engine: the same 16 tokens, logits within the F16-accumulation tier. Default: the small 8-layer shape (the CPU reference needs ~1 min
+    for the prompt); PM355_8D_LONG=8b runs it at the Llama-3-8B shape (32 layers, 32 query / 8 KV heads: ~20 min of host time for the CPU's
+    prompt pass - measured once in round 4, profiles/r04_parity_long_context.txt)."""
+    size = os.environ.get("PM355_8D_LONG", "small")
+    if size not in SHAPES:
+        pytest.skip("PM355_8D_LONG names no shape")
+    n_prompt, n_gen, n_ctx = 8200, 16, 8448
     V = SHAPES[size]["n_vocab"]
     prompt = F.prompt_tokens(V, n_prompt)
     path = files.path(size, True)
     t0 = time.time()
-    ta, la, sa = run_llama_driver(path, prompt, n_gen, ngl=0, n_ctx=n_ctx, threads=_threads(), flavour=best_ref_flavour(), timeout=3000)
-    print(f"\n[8d 8b peaked, 8200-token prompt] reference CPU ({best_ref_flavour()}) in {time.time() - t0:.0f} s")
+    ta, la, sa = run_llama_driver(path, prompt, n_gen, ngl=0, n_ctx=n_ctx, threads=_threads(), flavour=best_ref_flavour(), timeout=3000 if size != "small" else 900)
+    print(f"\n[8d {size} peaked, 8200-token prompt] reference CPU ({best_ref_flavour()}) in {time.time() - t0:.0f} s")
     expect = [F.peaked_next(prompt[-1], V)]
     for _ in range(n_gen - 1):
         expect.append(F.peaked_next(expect[-1], V))
@@ -233,7 +235,7 @@ def test_peaked_fixture_8k_prompt_tokens_identical_at_the_8b_shape(gpu, files):
     assert "cached-split" in st["stderr"], st["stderr"][-2000:]
     te, le = _engine_greedy(path, size, prompt, n_gen, n_ctx=n_ctx)
     for mode, t_, l_ in (("plugin", tg, lg), ("engine", te, le)):
-        print(f"[8d 8b peaked, 8200-token prompt, {mode}] tokens {(t_ == ta).sum()}/{n_gen} identical to the reference CPU; logits NMSE {_nmse(l_, la):.2e}")
+        print(f"[8d {size} peaked, 8200-token prompt, {mode}] tokens {(t_ == ta).sum()}/{n_gen} identical to the reference CPU; logits NMSE {_nmse(l_, la):.2e}")
         assert t_.tolist() == ta.tolist()
         assert _nmse(l_, la) < 1e-3
 

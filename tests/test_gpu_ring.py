@@ -97,6 +97,92 @@ def test_two_rank_ring_matches_single_window():
     w.close()
 
 
+def _worker_stag(rank, world, port, n_rounds, first, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from _bind import tiny_model
+    import prima_cpp_amd.engine as E
+    from prima_cpp_amd.ring import CRing
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = tiny_model(np.random.default_rng(61), arch=0, n_layer=4, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=320, n_ctx=64, rope_freqs=True)
+    lo, hi = (0, 2) if rank == 0 else (2, 4)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        w = E.Window(_hp(d), lo=lo, hi=hi, flags=(E.HAS_EMBD | E.HAS_HEAD) if rank == 0 else 0, n_ctx=64)
+        w.load_desc(d)
+        w.finalize(max_tokens=1, n_seq=world)
+        ring = CRing(rank, world, transport="torch")
+        total = world * (n_rounds + 1)
+        out = torch.full((total,), -1, dtype=torch.int32, device="cuda") if rank == 0 else None
+        # in two calls: the schedule's state (micro-step counter, buffer toggles) lives in the ring object
+        n1 = world + 3
+        ring.decode_staggered(w, n1, forced=(list(first) + [None] * (n1 - world)) if rank == 0 else None, tokens_out=out, reset=True)
+        ring.decode_staggered(w, total - n1, tokens_out=out[n1:] if rank == 0 else None)
+        ring.wait()
+        torch.cuda.synchronize()
+        if rank == 0:
+            fed = out.cpu().numpy().tolist()                                   # token fed at micro-step m = generated for sequence m % world
+            q.put([[fed[m] for m in range(world + s_, total, world)] for s_ in range(world)])
+        ring.close()
+        w.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c_staggered_decode_loop_two_ranks_matches_single_window():
+    """pm355_ring_decode_staggered - the N-sequences-in-flight decode loop in C (was RingDriver.micro_step) - on two ranks sharing the test GPU over
+    gloo (transport callbacks): every sequence's token stream equals the one a single full-model window generates for it. And the same loop
+    on a world-1 local ring against Window.generate."""
+    import torch
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    sys.path.insert(0, ROOT)
+    from _bind import tiny_model
+    import prima_cpp_amd.engine as E
+    from prima_cpp_amd.ring import CRing
+    world, n_rounds = 2, 6
+    first = [17, 101]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_stag, args=(r, world, port, n_rounds, first, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    d = tiny_model(np.random.default_rng(61), arch=0, n_layer=4, n_embd=256, n_head=4, n_head_kv=2, n_ff=512, n_vocab=320, n_ctx=64, rope_freqs=True)
+    w = E.Window(_hp(d), n_ctx=64)
+    w.load_desc(d)
+    w.finalize(1)
+    want = []
+    for s in range(world):
+        w.kv_clear()
+        io = torch.zeros(n_rounds + 1, dtype=torch.int32, device="cuda")
+        io[0] = first[s]
+        w.generate(io, 0, n_rounds, use_graph=True)
+        torch.cuda.synchronize()
+        want.append(io.cpu().numpy()[1:].tolist())
+        assert got[s][:n_rounds] == want[s], (s, got[s], want[s])
+    # world 1, no communicator: forced first token, then the head's argmax fed back
+    w.kv_clear()
+    w.set_pos(0)
+    ring = CRing(0, 1, transport="local")
+    out = torch.full((n_rounds + 1,), -1, dtype=torch.int32, device="cuda")
+    ring.decode_staggered(w, n_rounds + 1, forced=[first[0]] + [None] * n_rounds, tokens_out=out, reset=True)
+    ring.wait()
+    torch.cuda.synchronize()
+    assert out.cpu().numpy()[1:].tolist() == want[0], (out.cpu().numpy(), want[0])
+    ring.close()
+    w.close()
+
+
 def test_c_ring_transport_world1_self_send():
     """The RCCL transport in C (pm355_ring_*, prima_cpp_amd/csrc/ring.hip) with world size 1: rank 0's next and previous rank are
     itself, so one grouped ncclSend + ncclRecv moves a buffer through the communicator; then whole micro-steps through
