@@ -31,10 +31,17 @@ using namespace pmv;
 
 namespace {
 
+// The first things a workgroup does - the activation loads and the pre-issued weight loads of job 0 - need six values of the argument block. They
+// travel as LEADING scalar kernel arguments as well, which the dispatcher preloads into SGPRs (-mllvm -amdgpu-kernarg-preload-count, build.py):
+// the wave starts issuing its loads without first waiting for an s_load of the kernarg segment (a by-value struct is never preloaded).
 template <int TA, int TB, bool PAIR, bool DBG, bool EPI = false, int NPRE = 2>
-__global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(GemvP p) {
+__global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(const float * xf, const float * norm_w, const uint8_t * W0, const uint8_t * W0b, long row_stride0,
+                                                                  int K, int xmode, int N0, int U0, GemvP p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double nred[PM_GEMV_NW];
+    GemvP p = p_in;
+    p.xf = xf; p.norm_w = norm_w; p.K = K; p.xmode = xmode;
+    p.job[0].W = W0; p.job[0].W2 = W0b; p.job[0].row_stride = row_stride0; p.job[0].N = N0; p.job[0].U = U0;
     // (Q5_K: two 32-weight units per lane and step = 24-VGPR sets with the high-bit plane; a second pre-issued set spills)
     gemv_body<TA, TB, PAIR, DBG, 1, EPI, (TA == PM_Q5_K && NPRE == 2) ? 1 : NPRE>(p, smem, nred);
 }
@@ -43,7 +50,7 @@ int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, 
     const GemvP & p = p_in;
     auto go = [&](auto kern) {
         pm_allow_big_lds((const void *) kern, lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(PM_GEMV_BLOCK), lds, st, p);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(PM_GEMV_BLOCK), lds, st, p.xf, p.norm_w, p.job[0].W, p.job[0].W2, p.job[0].row_stride, p.K, p.xmode, p.job[0].N, p.job[0].U, p);
     };
     if (pair) {
         if (TA != TB) return -1;
