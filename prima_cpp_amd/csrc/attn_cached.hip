@@ -41,7 +41,12 @@ __device__ __forceinline__ float wave_max_all(float v) {
 }
 
 template <int DH, int VM>
-__global__ __launch_bounds__(256) void attn_cached_kernel(AttnP a) {
+__global__ __launch_bounds__(256) void attn_cached_kernel(AttnP a_in) {
+    // grid.y = tokens of a small batch (engine: 2..64-token steps after rope_kv_store has rotated / rounded q and stored every token's K / V):
+    // token t attends cells [0, pos0 + t], its q / out rows are t * H * DH further on
+    AttnP a = a_in;
+    a.tok = (int) blockIdx.y;
+    a.q += (long) a.tok * a.H * DH; a.out += (long) a.tok * a.H * DH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float redf[8];
     __shared__ double redd[4];
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256) void attn_cached_kernel(AttnP a) {
         if (a.dyn) n_kv = uniform_const_ptr(a.dyn)[1];
         else {
             seq = a.seq_ptr ? uniform_const_ptr(a.seq_ptr)[0] : 0;
-            n_kv = uniform_const_ptr(a.pos0_ptr)[seq] + 1;
+            n_kv = uniform_const_ptr(a.pos0_ptr)[seq] + 1 + a.tok;
         }
         // (short path: a lane owns a key and reads whole V^T chunks of KPP cells - only where the cache holds at least 64 cells per row; a smaller
         //  n_ctx takes the general body below, whose loads are bounded by n_kv: ADVICE r3)
@@ -137,8 +142,8 @@ void pm_launch_rope_table(const pm_rope_cfg & c, const int32_t * pos, const int3
 // q = rotated, F16-rounded query rows; caches already hold this token. Same arguments as pm_launch_attn_rope_fused otherwise.
 int pm_launch_attn_cached(const float * q, void * kc, void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride, float * out,
                           int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st, const int32_t * dyn, const void * mask,
-                          int max_keys, int v_rowmajor, int mask_f16) {
-    if ((dh != 64 && dh != 128 && dh != 256) || n_ctx % 8) return -1;
+                          int max_keys, int v_rowmajor, int mask_f16, int n_tok) {
+    if ((dh != 64 && dh != 128 && dh != 256) || n_ctx % 8 || n_tok < 1 || (n_tok > 1 && dyn)) return -1;
     const size_t lds = (size_t) (4 * dh + (v_rowmajor ? 2048 : 256) + (max_keys > 0 ? ((max_keys + 7) & ~7) : n_ctx) + 8) * 4;
     if (lds > 150 * 1024) return -1;
     RopeP r = {};
@@ -148,7 +153,7 @@ int pm_launch_attn_cached(const float * q, void * kc, void * vc, const int32_t *
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         AttnP a = {q, nullptr, nullptr, (uint16_t *) kc, (uint16_t *) vc, pos0, seq, seq_stride, nullptr, out, H, Hkv, n_ctx, scale, r, dyn,
                    (const float *) mask, mask_f16, pm_ts_next_slot()};
-        hipLaunchKernelGGL(kern, dim3(H), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(kern, dim3(H, n_tok), dim3(256), lds, st, a);
     };
     if (v_rowmajor) {
         if (dh == 64) launch(attn_cached_kernel<64, 1>);

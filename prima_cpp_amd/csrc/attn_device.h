@@ -36,6 +36,7 @@ struct AttnP {
     // mask_f16 != 0: `mask` points to F16 values (the flash-attention graphs cast the KQ mask, build_inp_KQ_mask src/llama.cpp:10466)
     int mask_f16;
     unsigned long long * ts;                 // measurement builds (-DPM_TS)
+    int tok;                                 // engine mode, cached form: token index of a multi-token launch (position = pos0 + tok; q / out rows are advanced by the kernel)
 };
 __device__ __forceinline__ float attn_mask_at(const void * mask, int f16, int i) {
     if (!mask) return 0.0f;
@@ -120,10 +121,10 @@ __device__ __forceinline__ void attn_rope_body(const AttnP & a, int h, char * sm
     if (seq_stride == 0 || !seq_ptr) first_loads(kc, vc);
     if (seq_ptr) {
         seq = __builtin_amdgcn_readfirstlane(sv);
-        pos = __builtin_amdgcn_readlane(pv, seq);
+        pos = __builtin_amdgcn_readlane(pv, seq) + a.tok;
         slot = pos; n_kv = pos + 1;
     } else {
-        pos = __builtin_amdgcn_readfirstlane(pv);
+        pos = __builtin_amdgcn_readfirstlane(pv) + a.tok;
         slot = pos; n_kv = pos + 1;
         if (a.dyn) { slot = __builtin_amdgcn_readfirstlane(dyn0); n_kv = __builtin_amdgcn_readfirstlane(dyn1); }
     }

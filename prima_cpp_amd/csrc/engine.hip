@@ -587,9 +587,12 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
             fused_attn = pm_launch_attn_rope_fused(m->q, m->k, m->v, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride,
                                                    (const float *) m->rope_freqs.d, m->att, H, Hkv, dh, hp.n_ctx, kq_scale, m->rope, st) == 0;
         if (!fused_attn) {
+        // q rotated AND rounded to F16, every token's K row / V column stored: the attention of a small batch then is the single-token kernel over
+        // cached cells, one workgroup per (head, token) (attn_cached.hip: one barrier up to 64 cells; 11 -> ~4 us per layer at 2..8 tokens)
         pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride,
-                                (const float *) m->rope_freqs.d, T, H, Hkv, dh, hp.n_ctx, m->rope, st);
-        if (pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
+                                (const float *) m->rope_freqs.d, T, H, Hkv, dh, hp.n_ctx, m->rope, st, 1);
+        if (pm_launch_attn_cached(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride, m->att, H, Hkv, dh, hp.n_ctx, kq_scale, st, nullptr, nullptr, 0, 0, 0, T) &&
+            pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
             return seterr(m, PM355_E_RANGE, "decode: n_ctx too large for the decode-attention kernel");
         }
         const Tensor * wo[1] = {&L.t[PM355_T_WO]};

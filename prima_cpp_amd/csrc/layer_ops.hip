@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void rope_kv_store_kernel(const float * q, cons
                                                            uint16_t * kc, uint16_t * vc,
                                                            const int32_t * pos0_ptr, const int32_t * seq_ptr, long seq_stride,
                                                            const float * freq_factors,
-                                                           int H, int Hkv, int dh, int n_ctx, RopeP r) {
+                                                           int H, int Hkv, int dh, int n_ctx, RopeP r, int round_q) {
     const int head = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
     const int seq = seq_ptr ? *seq_ptr : 0;              // multi-sequence: one KV slab and one position per sequence
     const int pos = pos0_ptr[seq] + t;
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(64) void rope_kv_store_kernel(const float * q, cons
         }
         if (is_q) {
             float * d = q_out + ((long) t * H + hh) * dh;
+            if (round_q) { o0 = h2f(f2h(o0)); o1 = h2f(f2h(o1)); }
             d[a] = o0; d[b] = o1;
         } else {
             if (k_out_f32) { float * d = k_out_f32 + ((long) t * Hkv + hh) * dh; d[a] = o0; d[b] = o1; }
@@ -322,12 +323,12 @@ void pm_rope_params(pm_rope_cfg & c) {
 void pm_launch_rope_kv_store(const float * q, const float * k, const float * v, float * q_out, float * k_out_f32,
                              void * kc, void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride,
                              const float * freq_factors,
-                             int n_tok, int H, int Hkv, int dh, int n_ctx, const pm_rope_cfg & c, hipStream_t st) {
+                             int n_tok, int H, int Hkv, int dh, int n_ctx, const pm_rope_cfg & c, hipStream_t st, int round_q) {
     RopeP r;
     r.n_dims = c.n_dims; r.mode = c.mode; r.n_ctx_orig = c.n_ctx_orig; r.theta_scale = c.theta_scale;
     r.freq_scale = c.freq_scale; r.ext_factor = c.ext_factor; r.attn_factor = c.attn_factor; r.corr0 = c.corr0; r.corr1 = c.corr1;
     hipLaunchKernelGGL(rope_kv_store_kernel, dim3(H + Hkv, n_tok), dim3(64), 0, st,
-                       q, k, v, q_out, k_out_f32, (uint16_t *) kc, (uint16_t *) vc, pos0, seq, seq_stride, freq_factors, H, Hkv, dh, n_ctx, r);
+                       q, k, v, q_out, k_out_f32, (uint16_t *) kc, (uint16_t *) vc, pos0, seq, seq_stride, freq_factors, H, Hkv, dh, n_ctx, r, round_q);
 }
 
 int pm_launch_attn_decode(const float * q, const void * kc, const void * vc, const int32_t * pos0,

@@ -15,7 +15,8 @@ void pm_launch_embed(int type, const void * table, int K, const int32_t * tokens
 void pm_launch_rope_kv_store(const float * q, const float * k, const float * v, float * q_out, float * k_out_f32,
                              void * kc, void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride,
                              const float * freq_factors,
-                             int n_tok, int H, int Hkv, int dh, int n_ctx, const pm_rope_cfg & c, hipStream_t st);
+                             int n_tok, int H, int Hkv, int dh, int n_ctx, const pm_rope_cfg & c, hipStream_t st,
+                             int round_q = 0);       // q_out rounded to F16 (what MUL_MAT(k, q) does to its src1): the form pm_launch_attn_cached reads
 int  pm_launch_attn_decode(const float * q, const void * kc, const void * vc, const int32_t * pos0,
                            const int32_t * seq, long seq_stride, float * out,
                            int n_tok, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st);
@@ -52,7 +53,8 @@ int  pm_launch_attn_rope_fused(const float * q, const float * k, const float * v
 void pm_launch_rope_table(const pm_rope_cfg & c, const int32_t * pos, const int32_t * seq, const float * freq_factors, float * tab, hipStream_t st);
 int  pm_launch_attn_cached(const float * q, void * kc, void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride, float * out,
                            int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st, const int32_t * dyn = nullptr,
-                           const void * mask = nullptr, int max_keys = 0, int v_rowmajor = 0, int mask_f16 = 0);
+                           const void * mask = nullptr, int max_keys = 0, int v_rowmajor = 0, int mask_f16 = 0,
+                           int n_tok = 1);          // n_tok > 1 (engine mode): token t of a small batch attends cells [0, pos0 + t], q / out rows t
 // ggml-graph mode of the two launchers above: dyn = device int32[2] {cache cell the token is stored in, cells attended}, the RoPE
 // position is pos0[0], mask = additive KQ-mask row [cells attended] (f32, or F16 with mask_f16) or null; v_rowmajor = the V cache is
 // [n_ctx][n_embd_v_gqa] (flash-attention graphs) instead of transposed, with flash-attention rounding points; max_keys (> 0) sizes the fused kernel's LDS score

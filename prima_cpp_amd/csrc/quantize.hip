@@ -136,32 +136,35 @@ __global__ __launch_bounds__(256) void quantize_q80_kernel(const float * __restr
 
 // rms_norm (+ weight) fused with Q8_K quantization. One 256-thread workgroup per row.
 // Optionally also writes the normalised f32 row (ynorm != nullptr).
-__global__ __launch_bounds__(256) void rmsnorm_q8k_kernel(const float * __restrict__ x, const float * __restrict__ w,
+// NWV waves per row: 4 for many rows (prompts: one small workgroup per row fills the chip), 16 for a handful of rows (decode batches of 2..64
+// tokens are ONE latency chain per row - load, reduce, quantize block after block: with 4 waves a K = 8192 row took 11 us, a fifth of a 2-token layer)
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void rmsnorm_q8k_kernel(const float * __restrict__ x, const float * __restrict__ w,
                                                           float * __restrict__ ynorm, uint8_t * __restrict__ yq,
                                                           int K, float eps, size_t yq_row_bytes, _Float16 * __restrict__ yh, pm_q8k_tables tb) {
-    __shared__ double red[4];
+    __shared__ double red[NWV];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nblk = K / PM_QK_K;
     const float * xr = x + (size_t) row * K;
     // A wave's blocks (wv, wv + 4, ...) are loaded ONCE, all loads in flight together, and stay in registers between the two passes
     // (K <= 8192: 8 blocks per wave). With few rows (decode batches) the kernel is one latency chain per row: the former form - one
     // dependent load per block and pass - took 12 us for K = 8192.
-    constexpr int HOLD = 8;
-    const bool held = nblk <= 4 * HOLD;
+    constexpr int HOLD = NWV == 4 ? 8 : 2;
+    const bool held = nblk <= NWV * HOLD;
     float4 f[HOLD];
     if (held) {
 #pragma unroll
-        for (int i = 0; i < HOLD; ++i) { const int blk = min(wv + 4 * i, nblk - 1); f[i] = ((const float4 *) (xr + (size_t) blk * PM_QK_K))[lane]; }
+        for (int i = 0; i < HOLD; ++i) { const int blk = min(wv + NWV * i, nblk - 1); f[i] = ((const float4 *) (xr + (size_t) blk * PM_QK_K))[lane]; }
     }
     // pass 1: sum of squares; products rounded to f32 like the reference, accumulated in f64 (same order as before: blocks ascending)
     double s = 0.0;
     if (held) {
 #pragma unroll
-        for (int i = 0; i < HOLD; ++i) if (wv + 4 * i < nblk) {
+        for (int i = 0; i < HOLD; ++i) if (wv + NWV * i < nblk) {
             s += (double) (f[i].x * f[i].x); s += (double) (f[i].y * f[i].y); s += (double) (f[i].z * f[i].z); s += (double) (f[i].w * f[i].w);
         }
     } else {
-        for (int blk = wv; blk < nblk; blk += 4) {
+        for (int blk = wv; blk < nblk; blk += NWV) {
             const float4 g = ((const float4 *) (xr + (size_t) blk * PM_QK_K))[lane];
             s += (double) (g.x * g.x); s += (double) (g.y * g.y); s += (double) (g.z * g.z); s += (double) (g.w * g.w);
         }
@@ -170,7 +173,9 @@ __global__ __launch_bounds__(256) void rmsnorm_q8k_kernel(const float * __restri
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) red[wv] = s;
     __syncthreads();
-    const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+    double tot = (red[0] + red[1]) + (red[2] + red[3]);
+#pragma unroll
+    for (int i = 4; i < NWV; i += 4) tot += (red[i] + red[i + 1]) + (red[i + 2] + red[i + 3]);
     const float mean  = (float) (tot / K);
     const float scale = 1.0f / sqrtf(mean + eps);
     // pass 2: normalise (+weight), write f32 and/or quantize
@@ -189,9 +194,9 @@ __global__ __launch_bounds__(256) void rmsnorm_q8k_kernel(const float * __restri
     };
     if (held) {
 #pragma unroll
-        for (int i = 0; i < HOLD; ++i) if (wv + 4 * i < nblk) emit(f[i], wv + 4 * i);
+        for (int i = 0; i < HOLD; ++i) if (wv + NWV * i < nblk) emit(f[i], wv + NWV * i);
     } else {
-        for (int blk = wv; blk < nblk; blk += 4) emit(((const float4 *) (xr + (size_t) blk * PM_QK_K))[lane], blk);
+        for (int blk = wv; blk < nblk; blk += NWV) emit(((const float4 *) (xr + (size_t) blk * PM_QK_K))[lane], blk);
     }
 }
 
@@ -211,5 +216,6 @@ void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStrea
                        x, (uint8_t *) y, K, rows, pm_q80_row_bytes(K));
 }
 void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st, void * ynorm_f16, pm_q8k_tables tab) {
-    hipLaunchKernelGGL(rmsnorm_q8k_kernel, dim3(rows), dim3(256), 0, st, x, w, ynorm, (uint8_t *) yq, K, eps, pm_q8k_row_bytes(K), (_Float16 *) ynorm_f16, tab);
+    if (rows <= 64) hipLaunchKernelGGL(rmsnorm_q8k_kernel<16>, dim3(rows), dim3(1024), 0, st, x, w, ynorm, (uint8_t *) yq, K, eps, pm_q8k_row_bytes(K), (_Float16 *) ynorm_f16, tab);
+    else            hipLaunchKernelGGL(rmsnorm_q8k_kernel<4>, dim3(rows), dim3(256), 0, st, x, w, ynorm, (uint8_t *) yq, K, eps, pm_q8k_row_bytes(K), (_Float16 *) ynorm_f16, tab);
 }
