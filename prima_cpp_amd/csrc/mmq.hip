@@ -382,6 +382,22 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel2(GemmP p) {
                 const long nb4 = p.K / 256;
                 R.w[0].r[0] = *(const u32x4 *) (wptr + (long) ahalf * nb4 * 64 + 16 * (4 * (long) b + u));
                 if (ahalf == 0) R.w[0].r[1] = *(const u32x4 *) (wptr + nb4 * 128 + (long) b * 16);
+            } else if (TYPE == PM_Q6_K) {
+                // Q6_K: the two threads of a row (32-k halves = sub-blocks 2 j, 2 j + 1) work inside ONE 128-weight half (b, hh) of the super-block for
+                // two consecutive k-steps: what they need of it - 32 bytes of their own ql stream (la: sub-blocks 0, 2; lb: 1, 3: both nibbles),
+                // the 32 qh bytes, 8 scales and d - is loaded ONCE per two steps, the shared pieces by one lane each (qh piece `ahalf`, the scale
+                // word by lane 0, d by lane 1) and exchanged through DPP at staging time: 2 load instructions per thread and k-step instead of
+                // the 8 of two fetch_w calls (two 16-byte pieces + a 1-byte scale + a 2-byte d each) - the loads, not the arithmetic, were what
+                // held this instantiation at half the Q4_K rate (round 3: 433 vs 881 TFLOP/s).
+                if ((k0 & 127) == 0) {
+                    const int b = k0 >> 8, hh = (k0 & 255) >> 7;
+                    const long nb = p.K / 256;
+                    R.w[0].r[0] = *(const u32x4 *) (wptr + (long) ahalf * nb * 64 + 16 * (4 * (long) b + 2 * hh));
+                    R.w[0].r[1] = *(const u32x4 *) (wptr + (long) ahalf * nb * 64 + 16 * (4 * (long) b + 2 * hh + 1));
+                    R.w[0].r[2] = *(const u32x4 *) (wptr + nb * 128 + (long) b * 64 + 32 * hh + 16 * ahalf);
+                    if (ahalf == 0) { const u32x2 s8 = *(const u32x2 *) (wptr + nb * 192 + (long) b * 16 + 8 * hh); R.w[1].r[0][0] = s8[0]; R.w[1].r[0][1] = s8[1]; }
+                    else R.w[1].r[0][0] = (uint32_t) ((const uint16_t *) (wptr + nb * 208))[b];
+                }
             } else {
                 fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, 0, R.w[0]);
                 fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, 1, R.w[1]);
@@ -419,6 +435,30 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel2(GemmP p) {
             convert_q4k_pair_h(wa, wb, k0, o);
 #pragma unroll
             for (int q = 0; q < 4; ++q) *(half8 *) (da + 8 * q) = o[q];
+        } else
+        if (PM_GEMM_F16_DEQUANT && TYPE == PM_Q6_K) {
+            // pair exchange (quad_perm [1,0,3,2]): the neighbour's qh piece, the scale word (held by the even lane) and d (held by the odd lane)
+            const int kq = (k0 >> 5) & 3;
+            const uint32_t o0 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) R.w[1].r[0][0], 0xB1, 0xF, 0xF, true);
+            const uint32_t o1 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) R.w[1].r[0][1], 0xB1, 0xF, 0xF, true);
+            const uint32_t sc_lo = ahalf ? o0 : R.w[1].r[0][0], sc_hi = ahalf ? o1 : R.w[1].r[0][1];
+            const uint32_t dbits = ahalf ? R.w[1].r[0][0] : o0;
+            const uint64_t sc8 = ((uint64_t) sc_hi << 32) | sc_lo;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                RawW w;
+                w.r[0] = part ? R.w[0].r[1] : R.w[0].r[0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t own = R.w[0].r[2][q];
+                    const uint32_t oth = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) own, 0xB1, 0xF, 0xF, true);
+                    w.r[1][q] = part == ahalf ? own : oth;
+                }
+                w.s = (uint32_t) ((sc8 >> (8 * (2 * kq + part))) & 0xFF) | (dbits << 16);
+                half8 o[2];
+                convert_w_h<TYPE>(w, k0, o);
+                *(half8 *) (da + 16 * part) = o[0]; *(half8 *) (da + 16 * part + 8) = o[1];
+            }
         } else
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
