@@ -73,6 +73,56 @@ template <int TYPE> struct Stage {
     static constexpr int ACT = 0, BS = TM * 256, DD = BS + 4 * 1024, WQ = DD + 512, HD = WQ + B::NSTREAM * B::TN * 64, BYTES = HD + B::TN * 16;
 };
 
+// ---- one stage = super-block b of a workgroup tile -> LDS buffer `buf`, by LDS-DMA; instruction q of the list is issued by wave q % 8.
+//      Addresses = wave-uniform 64-bit base (SGPRs) + 32-bit lane offset, formed anew for every stage from an opaque copy of the lane id:
+//      hoisted out of the k loop, the ~10 per-lane 64-bit addresses of a wave's instructions lived across the whole kernel (spills).
+template <int TYPE>
+__device__ __forceinline__ void issue_stage(const BigP & p, int b, uint8_t * buf, int T0, int N0, int P0, int nsb, int wave, int lane) {
+    typedef BT<TYPE> B; typedef Stage<TYPE> S;
+    constexpr int TN = B::TN;
+    constexpr int NQ_ACT = TM / 4, NQ_W = B::NSTREAM * TN / 16, NQ_HD = TN / 64;
+    constexpr int NQ = NQ_ACT + 4 + 1 + NQ_W + NQ_HD;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const uint8_t * xb = p.xq + (long) b * 256, * tbs = p.tab + (long) b * 1024, * tdd = p.tab + (long) nsb * 1024 + (long) b * 128;
+    const uint8_t * wb = p.W + (long) b * 64, * hb = p.W + (long) nsb * B::HDR_OFF + (long) b * 16;
+    for (int q = wave; q < NQ; q += 8) {
+        if (q < NQ_ACT) {                                   // 4 tokens x 256 bytes
+            const int t = 4 * q + (ln >> 4), c = (ln & 15) ^ (t & 15);
+            const uint32_t tg = (uint32_t) min(T0 + t, p.T - 1);
+            dma16(xb + (tg * (uint32_t) p.xq_stride + (uint32_t) (c * 16)), buf + S::ACT + q * 1024);
+        } else if (q < NQ_ACT + 4) {                        // F16 group sums of one 32-token pass, already in A-operand order
+            const int i = q - NQ_ACT; const uint32_t ps = (uint32_t) min(P0 + i, p.n_pass - 1);
+            dma16(tbs + (ps * (uint32_t) p.tab_bytes + (uint32_t) (ln * 16)), buf + S::BS + i * 1024);
+        } else if (q == NQ_ACT + 4) {                       // block scales of the four passes: 4 x 128 bytes
+            if (ln < 32) {
+                const uint32_t ps = (uint32_t) min(P0 + (ln >> 3), p.n_pass - 1);
+                dma16(tdd + (ps * (uint32_t) p.tab_bytes + (uint32_t) ((ln & 7) * 16)), buf + S::DD);
+            }
+        } else if (q < NQ_ACT + 5 + NQ_W) {                 // 16 rows x 64 bytes of one nibble stream
+            const int i = q - (NQ_ACT + 5), stream = i / (TN / 16), rb = i % (TN / 16);
+            const int n = 16 * rb + (ln >> 2), j = (ln & 3) ^ ((n >> 2) & 3);
+            const uint32_t ng = (uint32_t) min(N0 + n, p.N - 1);
+            dma16(wb + (long) stream * nsb * 64 + (ng * (uint32_t) p.row_stride + (uint32_t) (j * 16)), buf + S::WQ + stream * (TN * 64) + rb * 1024);
+        } else {                                            // 64 rows x 16 bytes: Q4_K d | dmin | scales[12]; Q6_K int8 scales[16]
+            const int i = q - (NQ_ACT + 5 + NQ_W);
+            const uint32_t ng = (uint32_t) min(N0 + 64 * i + ln, p.N - 1);
+            dma16(hb + ng * (uint32_t) p.row_stride, buf + S::HD + i * 1024);
+        }
+    }
+}
+
+// block id -> tile of the workgroup: XCD x = id % 8, slot = id / 8; an XCD's consecutive slots sweep the token tiles of one row tile, its row tiles are
+// x, x + 8, ... (the workgroups that run together on an XCD share two row tiles of weights and the activations in its L2). false: no tile (grid padding)
+__device__ __forceinline__ bool tile_of_block(const BigP & p, int tn, int & tile_t, int & tile_n) {
+    const int nt_n = (p.N + tn - 1) / tn;
+    const int id = (int) blockIdx.x, x = id & 7, slot = id >> 3;
+    const int per_x = (nt_n + 7 - x) >> 3;                 // row tiles of XCD x
+    if (slot >= per_x * p.nt_t) return false;
+    tile_n = x + 8 * (slot / p.nt_t); tile_t = slot % p.nt_t;
+    return true;
+}
+
 template <int TYPE>
 __global__ __launch_bounds__(NTHR, 2) void mmq_big_kernel(BigP p) {
     typedef BT<TYPE> B; typedef Stage<TYPE> S;
@@ -96,42 +146,6 @@ __global__ __launch_bounds__(NTHR, 2) void mmq_big_kernel(BigP p) {
     const int T0 = tile_t * TM, N0 = tile_n * TN;
     const int P0 = T0 >> 5;
 
-    // ---- one stage = super-block b of this tile -> LDS buffer `buf`, by LDS-DMA; instruction q of the list is issued by wave q % 8.
-    //      Addresses = wave-uniform 64-bit base (SGPRs) + 32-bit lane offset, formed anew for every stage from an opaque copy of the lane id:
-    //      hoisted out of the k loop, the ~10 per-lane 64-bit addresses of a wave's instructions lived across the whole kernel (spills).
-    auto issue_stage = [&](int b, uint8_t * buf) __attribute__((always_inline)) {
-        constexpr int NQ_ACT = TM / 4, NQ_W = B::NSTREAM * TN / 16, NQ_HD = TN / 64;
-        constexpr int NQ = NQ_ACT + 4 + 1 + NQ_W + NQ_HD;
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const uint8_t * xb = p.xq + (long) b * 256, * tbs = p.tab + (long) b * 1024, * tdd = p.tab + (long) nsb * 1024 + (long) b * 128;
-        const uint8_t * wb = p.W + (long) b * 64, * hb = p.W + (long) nsb * B::HDR_OFF + (long) b * 16;
-        for (int q = wave; q < NQ; q += 8) {
-            if (q < NQ_ACT) {                                   // 4 tokens x 256 bytes
-                const int t = 4 * q + (ln >> 4), c = (ln & 15) ^ (t & 15);
-                const uint32_t tg = (uint32_t) min(T0 + t, p.T - 1);
-                dma16(xb + (tg * (uint32_t) p.xq_stride + (uint32_t) (c * 16)), buf + S::ACT + q * 1024);
-            } else if (q < NQ_ACT + 4) {                        // F16 group sums of one 32-token pass, already in A-operand order
-                const int i = q - NQ_ACT; const uint32_t ps = (uint32_t) min(P0 + i, p.n_pass - 1);
-                dma16(tbs + (ps * (uint32_t) p.tab_bytes + (uint32_t) (ln * 16)), buf + S::BS + i * 1024);
-            } else if (q == NQ_ACT + 4) {                       // block scales of the four passes: 4 x 128 bytes
-                if (ln < 32) {
-                    const uint32_t ps = (uint32_t) min(P0 + (ln >> 3), p.n_pass - 1);
-                    dma16(tdd + (ps * (uint32_t) p.tab_bytes + (uint32_t) ((ln & 7) * 16)), buf + S::DD);
-                }
-            } else if (q < NQ_ACT + 5 + NQ_W) {                 // 16 rows x 64 bytes of one nibble stream
-                const int i = q - (NQ_ACT + 5), stream = i / (TN / 16), rb = i % (TN / 16);
-                const int n = 16 * rb + (ln >> 2), j = (ln & 3) ^ ((n >> 2) & 3);
-                const uint32_t ng = (uint32_t) min(N0 + n, p.N - 1);
-                dma16(wb + (long) stream * nsb * 64 + (ng * (uint32_t) p.row_stride + (uint32_t) (j * 16)), buf + S::WQ + stream * (TN * 64) + rb * 1024);
-            } else {                                            // 64 rows x 16 bytes: Q4_K d | dmin | scales[12]; Q6_K int8 scales[16]
-                const int i = q - (NQ_ACT + 5 + NQ_W);
-                const uint32_t ng = (uint32_t) min(N0 + 64 * i + ln, p.N - 1);
-                dma16(hb + ng * (uint32_t) p.row_stride, buf + S::HD + i * 1024);
-            }
-        }
-    };
-
     f32x16 out[NTN][2];
 #pragma unroll
     for (int a = 0; a < NTN; ++a)
@@ -153,14 +167,14 @@ __global__ __launch_bounds__(NTHR, 2) void mmq_big_kernel(BigP p) {
         }
     };
     load_d(0, dq_next);
-    issue_stage(0, smem);
+    issue_stage<TYPE>(p, 0, smem, T0, N0, P0, nsb, wave, lane);
     for (int b = 0; b < nsb; ++b) {
         uint8_t * buf = smem + (b & 1) * S::BYTES;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of stage b (and its d values) has landed ...
         __syncthreads();                                         // ... and everybody's; everybody is done with the other buffer
 #pragma unroll
         for (int a = 0; a < NTN; ++a) dq[a] = dq_next[a];
-        if (b + 1 < nsb) { issue_stage(b + 1, smem + ((b + 1) & 1) * S::BYTES); load_d(b + 1, dq_next); }
+        if (b + 1 < nsb) { issue_stage<TYPE>(p, b + 1, smem + ((b + 1) & 1) * S::BYTES, T0, N0, P0, nsb, wave, lane); load_d(b + 1, dq_next); }
         // ---- multiply stage b
 #pragma unroll
         for (int a = 0; a < NTN; ++a) {
@@ -190,6 +204,10 @@ __global__ __launch_bounds__(NTHR, 2) void mmq_big_kernel(BigP p) {
                 const uint8_t * arow0 = buf + S::ACT + t0 * 256, * arow1 = buf + S::ACT + t1 * 256;
                 const int x0 = t0 & 15, x1 = t1 & 15;
                 i32x16 alo0 = zero, ahi0 = zero, alo1 = zero, ahi1 = zero;
+                // (Measured and rejected, round 4: a wave = ONE 32-row group x all 128 tokens, token tiles walked one at a time with two accumulator sets so that
+                //  the operand preparation serves four tiles and every tile's super-block epilogue hides behind the next tile's MFMAs - 7.7 instead of 11.9
+                //  vector instructions per MFMA on paper, 256 VGPRs + 19 spilled and every wave reading the whole activation tile from LDS in practice:
+                //  551 vs 657 TOP/s on ffn_gate.)
                 // Software-pipelined by hand, two stages deep. Region j of the unit loop holds (1) the LDS reads of unit j + 1's activation operands
                 // and unit j + 2's nibbles, fenced at the top; (2) the vector work that turns unit j + 1's nibbles into B operands, and (3) the eight
                 // MFMAs of unit j - (2) and (3) are independent, so the wave's own vector instructions issue in the shadow of its MFMAs. Left alone
