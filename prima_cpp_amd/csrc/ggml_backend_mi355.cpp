@@ -70,7 +70,9 @@ struct buf_ctx { int device; void * base; size_t size; std::string name; void * 
 // the repack run on the uploader's private stream. Everything that must observe the data drains the pending uploaders first:
 // every other buffer operation on that buffer, and graph_compute (all buffers). g_up_pending keeps that check to one load.
 // host-side time spent inside the plug-in (GGML_MI355_STATS=1 prints it): where a token's wall time goes besides the kernels
-struct host_timers { std::atomic<uint64_t> ns_compute{0}, ns_set{0}, ns_get{0}, ns_sync{0}, n_set{0}, n_get{0}, n_sync{0}; };
+struct host_timers { std::atomic<uint64_t> ns_compute{0}, ns_set{0}, ns_get{0}, ns_sync{0}, n_set{0}, n_get{0}, n_sync{0};
+                     // phases of graph_compute: ordering behind uploads, fingerprint, plan lookup / build, KV cell lookup + patch, launch (replay / capture / eager)
+                     std::atomic<uint64_t> ns_order{0}, ns_fp{0}, ns_plan{0}, ns_dyn{0}, ns_launch{0}; };
 host_timers g_ht;
 struct scoped_ns {
     std::atomic<uint64_t> & acc; std::chrono::steady_clock::time_point t0;
@@ -323,6 +325,10 @@ void backend_free(ggml_backend_t b) {
                         "synchronize %.3f ms in %llu calls\n", g_ht.ns_compute / 1e6, c->n_compute ? g_ht.ns_compute / 1e3 / (double) c->n_compute : 0.0,
                 g_ht.ns_set / 1e6, (unsigned long long) g_ht.n_set.load(), g_ht.ns_get / 1e6, (unsigned long long) g_ht.n_get.load(),
                 g_ht.ns_sync / 1e6, (unsigned long long) g_ht.n_sync.load());
+    if (env_on("GGML_MI355_STATS") && c->n_compute)
+        fprintf(stderr, "ggml-mi355 graph_compute phases, us per call: order behind uploads %.1f, fingerprint %.1f, plan lookup / build %.1f, KV cell lookup + patch %.1f, launch %.1f\n",
+                g_ht.ns_order / 1e3 / (double) c->n_compute, g_ht.ns_fp / 1e3 / (double) c->n_compute, g_ht.ns_plan / 1e3 / (double) c->n_compute,
+                g_ht.ns_dyn / 1e3 / (double) c->n_compute, g_ht.ns_launch / 1e3 / (double) c->n_compute);
     for (graph_entry * e : c->graphs) { if (e->exec) pm355_graph_free(e->exec); delete e; }
     dfree(c->scratch); dfree(c->d_i32); dfree(c->d_dyn); dfree(c->rope_tab); dfree(c->qkv); dfree(c->split);
     if (c->null_ev) pm355_event_destroy(c->null_ev);
@@ -665,16 +671,18 @@ enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g)
     scoped_ns tm(g_ht.ns_compute);
     backend_ctx * c = (backend_ctx *) b->context;
     dsetdev(c->device);
-    drain_all_uploads();                               // weights staged asynchronously by set_tensor (one atomic load when none are pending)
-    order_after_null_stream(c);                        // the graph inputs uploaded since the last call
+    { scoped_ns t1(g_ht.ns_order);
+      drain_all_uploads();                             // weights staged asynchronously by set_tensor (one atomic load when none are pending)
+      order_after_null_stream(c); }                    // the graph inputs uploaded since the last call
     const int n_nodes = ggml_graph_n_nodes(g);        // public accessors: struct ggml_cgraph is private to ggml (ggml-impl.h:183)
     ++c->n_compute; ++c->tick;
     if (n_nodes == 0) return GGML_STATUS_SUCCESS;
     if (!c->d_dyn) { c->d_dyn = (int32_t *) dmalloc(64); GGML_ASSERT(c->d_dyn); }
     if (!c->rope_tab && c->qkv_epi) { c->rope_tab = (float *) dmalloc(1024 + 64); GGML_ASSERT(c->rope_tab); }
 
-    mi355::graph_fingerprint(g, c->fp_tmp);
+    { scoped_ns t1(g_ht.ns_fp); mi355::graph_fingerprint(g, c->fp_tmp); }
     graph_entry * e = nullptr;
+    const auto t_plan0 = std::chrono::steady_clock::now();
     for (graph_entry * x : c->graphs) if (x->plan.fast_ok && mi355::fingerprint_equal(x->fp, c->fp_tmp)) { e = x; ++c->n_fp_hit; break; }
     if (!e) {
         mi355::plan_ctx pc = { c, plan_qkv_scratch, plan_split_scratch, c->d_dyn, c->split_min, c->attn_mfma, c->fuse, c->qkv_epi ? c->rope_tab : nullptr, plan_same_bytes };
@@ -698,6 +706,8 @@ enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g)
         }
     }
     e->last_use = c->tick;
+    const auto t_dyn0 = std::chrono::steady_clock::now();
+    g_ht.ns_plan += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(t_dyn0 - t_plan0).count();
     const mi355::plan & p = e->plan;
     int32_t cell = 0, n_kv = 0;
     if (!mi355::plan_dyn(g, p, cell, n_kv)) { fprintf(stderr, "ggml-mi355: cannot locate the KV cell of a planned graph\n"); return GGML_STATUS_FAILED; }
@@ -705,6 +715,8 @@ enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g)
     if (plan_only()) return GGML_STATUS_SUCCESS;
 
     if (p.has_attn) MI355_CHECK(pm355_set_i32x2(c->d_dyn, cell, n_kv, c->stream));
+    g_ht.ns_dyn += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_dyn0).count();
+    scoped_ns t_launch(g_ht.ns_launch);
     const bool graphable = c->use_graphs && p.single_token && p.n_gemv > 0 && p.steps.size() >= 3;
     if (graphable && e->exec) { MI355_CHECK(pm355_graph_launch(e->exec, c->stream)); ++e->runs; ++c->n_replay; return GGML_STATUS_SUCCESS; }
     if (graphable && e->runs >= 1) {
