@@ -442,8 +442,8 @@ def plugin_decode(tmp, n_gen=64, prompt_len=16):
 
 
 def plugin_decode_70b(tmp, hp70, engine_ms_per_token, n_gen=48):
-    """The HEADLINE shape through the drop-in boundary: Llama-3-70B-shaped Q4_K_M GGUFs of 8 and 16 layers decoded by the reference's
-    llama_decode + the MI355 plug-in (-ngl 99 --keep-out-in-cuda); per-layer and fixed cost from the two depths, the 80-layer token
+    """The HEADLINE shape through the drop-in boundary: Llama-3-70B-shaped Q4_K_M GGUFs of 8, 16 and 32 layers decoded by the reference's
+    llama_decode + the MI355 plug-in (-ngl 99 --keep-out-in-cuda); per-layer and fixed cost from a line through the depths, the 80-layer token
     time they imply, and that against the resident engine's measured token (what the scheduler path costs at this shape)."""
     from prima_cpp_amd import gguf as G
     B, drv = _driver()
@@ -452,21 +452,26 @@ def plugin_decode_70b(tmp, hp70, engine_ms_per_token, n_gen=48):
     prompt = np.random.default_rng(1234).integers(0, 128256, 16)
     prompt[0] = 128000
     ms = {}
-    for L in (8, 16):
+    depths = (8, 16, 32)
+    for L in depths:
         p = os.path.join(tmp, f"pm355_bench_llama3_70b_shape_{L}l.gguf")
         G.write_synthetic_model(p, arch=0, n_layer=L, n_embd=hp70["n_embd"], n_head=hp70["n_head"], n_head_kv=hp70["n_head_kv"],
                                 n_ff=hp70["n_ff"], n_vocab=hp70["n_vocab"], is_70b=True)
-        _, _, st = B.run_llama_driver(p, prompt, n_gen, ngl=99, n_ctx=4096, threads=usable_cores(), extra_args=["--keep-out-in-cuda"], timeout=300)
-        ms[L] = (st["decode_ms_avg"], st["decode_ms_min"])
-        os.unlink(p)
-    per_layer = (ms[16][0] - ms[8][0]) / 8.0
-    fixed = ms[8][0] - 8 * per_layer
+        try:
+            _, _, st = B.run_llama_driver(p, prompt, n_gen, ngl=99, n_ctx=4096, threads=usable_cores(), extra_args=["--keep-out-in-cuda"], timeout=300)
+            ms[L] = (st["decode_ms_avg"], st["decode_ms_min"])
+        finally:
+            os.unlink(p)
+    # least-squares line through the depths (two points made the slope - and with it the 80-layer figure - swing by 10 % between boxes)
+    A = np.stack([np.array(depths, dtype=np.float64), np.ones(len(depths))], axis=1)
+    (per_layer, fixed), *_ = np.linalg.lstsq(A, np.array([ms[L][0] for L in depths]), rcond=None)
+    per_layer, fixed = float(per_layer), float(fixed)
     tok_ms = fixed + hp70["n_layer"] * per_layer
-    out = {"workload": "Llama-3-70B-shaped Q4_K_M GGUFs of 8 and 16 layers (random valid blocks, no_vocab) through the reference's llama_decode + MI355 "
+    out = {"workload": f"Llama-3-70B-shaped Q4_K_M GGUFs of {' / '.join(str(L) for L in depths)} layers (random valid blocks, no_vocab) through the reference's llama_decode + MI355 "
                        f"plug-in: -ngl 99 --keep-out-in-cuda, 16-token prompt, {n_gen} greedy tokens, n_ctx 4096",
-           "ms_per_token_at_depth": {"8": round(ms[8][0], 4), "16": round(ms[16][0], 4)}, "best_ms_per_token_at_depth": {"8": round(ms[8][1], 4), "16": round(ms[16][1], 4)},
+           "ms_per_token_at_depth": {str(L): round(ms[L][0], 4) for L in depths}, "best_ms_per_token_at_depth": {str(L): round(ms[L][1], 4) for L in depths},
            "ms_per_layer": round(per_layer, 4), "ms_fixed": round(fixed, 4), "ms_per_token_80_layers": round(tok_ms, 4), "tokens_per_s_80_layers": round(1e3 / tok_ms, 2),
-           "timing": "wall clock around llama_decode + llama_synchronize per token, first 5 tokens dropped"}
+           "timing": "wall clock around llama_decode + llama_synchronize per token, first 5 tokens dropped; least-squares line over the depths"}
     if engine_ms_per_token:
         out["engine_ms_per_token"] = round(engine_ms_per_token, 4)
         out["frac_of_engine"] = round(engine_ms_per_token / tok_ms, 4)

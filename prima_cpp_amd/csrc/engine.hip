@@ -46,6 +46,7 @@ struct pm355_model {
     int n_seq = 1;
     bool no_fuse = false;                 // PM355_NO_FUSE=1: node-by-node kernels (debug / A-B)
     bool no_multi = false;                // PM355_NO_MMQ_MULTI=1
+    bool no_small_cols = false;           // PM355_SMALL_COLS=0
     bool no_mmq = false;                  // PM355_NO_MMQ_I8=1: 4..64-token batches on the round-1 paths (mat-vec columns, F16 GEMM from 16 tokens)
     // single-token decode, short contexts, NORM-mode rope: RoPE + F16 KV store happen in the epilogue of the wq | wk | wv launch (per-token cos / sin
     // table `rope_tab`), the attention launch reads everything from the cache (attn_cached.hip). PM355_QKV_EPI=0: the round-2 form (raw q / k / v,
@@ -252,6 +253,7 @@ void layer_release(pm355_model * m, int il, hipStream_t st) {
 // quantize `src` [T][K] into the activation format(s) the given weights need; returns pointers
 struct ActQ { const void * k = nullptr; const void * z = nullptr; bool tab = false; };   // tab: the small-batch mat-mul's activation tables were written too
 const int MMQ_MIN_TOKENS = 3, MMQ_MAX_TOKENS = 64;      // (3 columns cost the multi-column mat-vec two passes: 57 vs 39 us on the ffn shape)
+const int MMQ_COLS_MAX_TOKENS = 4;        // single matrices up to here: multi-column mat-vec (mmvq_cols.hip)
 const int MMQ_MULTI_MIN_TOKENS = 2;       // the fused wq | wk | wv and ffn_gate | ffn_up launches already win at 2 tokens (3 / 4 mat-vec launches otherwise)
 // the table output of the Q8_K quantizers, when this batch size takes the small-batch mat-mul (mmq_i8.hip)
 pm_q8k_tables mmq_tables(const pm355_model * m, int K, int T, hipStream_t st) {
@@ -291,6 +293,9 @@ int gemv(const Tensor & w, const Tensor * w2, const ActQ & a, int T, float * y, 
 // (one to three passes per 8 columns). `prepped`: the kernel's activation tables already describe THIS activation set (set by the first
 // served call, cleared by the caller whenever the activations change)
 int matmul_small(pm355_model * m, const Tensor & w, const ActQ & a, int T, float * y, const float * bias, const float * resid, bool & prepped, hipStream_t st) {
+    // 3 / 4 tokens: the 4-slot multi-column mat-vec (two rows per activation fetch) beats the matrix-core kernel's fill / drain on single matrices
+    // (ffn_down Q6_K 46 vs 73 us, wo 16 vs 17 us, a lone wv 10 vs 14 us); the multi-matrix launches (wq | wk | wv, ffn_gate | ffn_up) stay where they are
+    if (T <= MMQ_COLS_MAX_TOKENS && !m->no_small_cols) return gemv(w, nullptr, a, T, y, bias, resid, st);
     if (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && a.k && pm_mmq_i8_check(w.type, (int) w.K, (int) w.N, T) == 0) {
         const int rc = pm_launch_mmq_i8(w.type, w.d, a.k, nullptr, y, (int) w.K, (int) w.N, T, bias, resid, (prepped || a.tab) ? 1 : 0, st);
         if (rc == 0) { prepped = true; return 0; }
@@ -606,7 +611,10 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
             return seterr(m, PM355_E_UNSUPPORTED, "decode: ffn_gate and ffn_up of different types");
         const Tensor & wg = L.t[PM355_T_FFN_GATE], & wu = L.t[PM355_T_FFN_UP];
         bool gu_done = false;
-        if (small && m->h2 && pm_mmq_i8_check(wg.type, (int) wg.K, (int) wg.N, T) == 0) {
+        // 2 tokens: the pair mat-vec with two column slots - one pass over both matrices, silu(gate) * up in its epilogue (~50 us against 60 for the
+        // two-matrix launch of the matrix-core kernel + the product launch)
+        const bool pair_cols = T == 2 && !m->no_small_cols && wg.type == wu.type && (wg.type == PM_Q4_K || wg.type == PM_Q6_K);
+        if (!pair_cols && small && m->h2 && pm_mmq_i8_check(wg.type, (int) wg.K, (int) wg.N, T) == 0) {
             // gate and up: one weight pass each for all tokens, then silu(gate) * up (the pair mat-vec would take one launch per token)
             prepped = false;
             if (T <= 16 && !m->no_multi && wg.type == wu.type && multi({&wg, &wu}, {m->h, m->h2}, {nullptr, nullptr}) == 0) gu_done = true;
@@ -659,6 +667,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     m->rope.ext_factor = 0.0f; m->rope.attn_factor = 1.0f; m->rope.beta_fast = 32.0f; m->rope.beta_slow = 1.0f;
     pm_rope_params(m->rope);
     { const char * e = getenv("PM355_NO_FUSE"); m->no_fuse = e && e[0] == '1'; }
+    { const char * e = getenv("PM355_SMALL_COLS"); m->no_small_cols = e && e[0] == '0'; }   // A/B: 2..4-token steps without the round-4 multi-column choices
     { const char * e = getenv("PM355_NO_MMQ_MULTI"); m->no_multi = e && e[0] == '1'; }   // small batches: one launch per matrix (A/B of the multi-job launches)
     { const char * e = getenv("PM355_NO_MMQ_I8"); m->no_mmq = e && e[0] == '1'; }     // 4..64-token batches: mat-vec columns / F16 GEMM from 16 (the round-1 paths)
     { const char * e = getenv("PM355_QKV_EPI"); m->qkv_epi = !(e && e[0] == '0'); }

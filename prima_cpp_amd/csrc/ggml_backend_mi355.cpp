@@ -72,8 +72,15 @@ struct buf_ctx { int device; void * base; size_t size; std::string name; void * 
 // host-side time spent inside the plug-in (GGML_MI355_STATS=1 prints it): where a token's wall time goes besides the kernels
 struct host_timers { std::atomic<uint64_t> ns_compute{0}, ns_set{0}, ns_get{0}, ns_sync{0}, n_set{0}, n_get{0}, n_sync{0};
                      // phases of graph_compute: ordering behind uploads, fingerprint, plan lookup / build, KV cell lookup + patch, launch (replay / capture / eager)
-                     std::atomic<uint64_t> ns_order{0}, ns_fp{0}, ns_plan{0}, ns_dyn{0}, ns_launch{0}; };
+                     std::atomic<uint64_t> ns_order{0}, ns_fp{0}, ns_plan{0}, ns_dyn{0}, ns_launch{0}, ns_seta{0}, ns_geta{0}; };
 host_timers g_ht;
+// steady state: the counters at the first hipGraph replay (everything before it is model load, prompt, planning and capture) and the time of the last one
+struct host_snapshot { uint64_t v[12] = {}; std::chrono::steady_clock::time_point t0, t_last; bool taken = false; };
+host_snapshot g_snap;
+void host_counters(uint64_t (&v)[12]) {
+    const uint64_t x[12] = {g_ht.ns_compute, g_ht.ns_set, g_ht.ns_get, g_ht.ns_sync, g_ht.ns_order, g_ht.ns_fp, g_ht.ns_plan, g_ht.ns_dyn, g_ht.ns_launch, g_ht.ns_seta, g_ht.ns_geta, 0};
+    for (int i = 0; i < 12; ++i) v[i] = x[i];
+}
 struct scoped_ns {
     std::atomic<uint64_t> & acc; std::chrono::steady_clock::time_point t0;
     explicit scoped_ns(std::atomic<uint64_t> & a) : acc(a), t0(std::chrono::steady_clock::now()) {}
@@ -329,6 +336,16 @@ void backend_free(ggml_backend_t b) {
         fprintf(stderr, "ggml-mi355 graph_compute phases, us per call: order behind uploads %.1f, fingerprint %.1f, plan lookup / build %.1f, KV cell lookup + patch %.1f, launch %.1f\n",
                 g_ht.ns_order / 1e3 / (double) c->n_compute, g_ht.ns_fp / 1e3 / (double) c->n_compute, g_ht.ns_plan / 1e3 / (double) c->n_compute,
                 g_ht.ns_dyn / 1e3 / (double) c->n_compute, g_ht.ns_launch / 1e3 / (double) c->n_compute);
+    if (env_on("GGML_MI355_STATS") && g_snap.taken && c->n_replay > g_snap.v[11] + 1) {
+        // from the first replay to the last: one replay per token, so (last - first) spans n - 1 whole tokens
+        uint64_t now[12]; host_counters(now);
+        const double n = (double) (c->n_replay - g_snap.v[11] - 1);
+        const double wall = std::chrono::duration_cast<std::chrono::nanoseconds>(g_snap.t_last - g_snap.t0).count() / 1e3 / n;
+        auto d = [&](int i) { return (double) (now[i] - g_snap.v[i]) / 1e3 / n; };
+        fprintf(stderr, "ggml-mi355 steady state, us per token over %.0f tokens: wall %.1f = graph_compute %.1f (fingerprint %.1f, plan lookup %.1f, KV patch %.1f, launch %.1f) "
+                        "+ input uploads %.1f + output download (waits for the device) %.1f + synchronize %.1f + outside the plug-in (libllama graph build / scheduler, sampling) %.1f\n",
+                n, wall, d(0), d(5), d(6), d(7), d(8), d(1) + d(9), d(2) + d(10), d(3), wall - d(0) - d(1) - d(9) - d(2) - d(10) - d(3));
+    }
     for (graph_entry * e : c->graphs) { if (e->exec) pm355_graph_free(e->exec); delete e; }
     dfree(c->scratch); dfree(c->d_i32); dfree(c->d_dyn); dfree(c->rope_tab); dfree(c->qkv); dfree(c->split);
     if (c->null_ev) pm355_event_destroy(c->null_ev);
@@ -336,6 +353,7 @@ void backend_free(ggml_backend_t b) {
     delete c; delete b;
 }
 void backend_set_async(ggml_backend_t b, struct ggml_tensor * t, const void * data, size_t off, size_t size) {
+    scoped_ns tm(g_ht.ns_seta);
     backend_ctx * c = (backend_ctx *) b->context;
     dsetdev(c->device);
     drain_all_uploads();
@@ -344,6 +362,7 @@ void backend_set_async(ggml_backend_t b, struct ggml_tensor * t, const void * da
     MI355_CHECK(h2d((char *) t->data + off, data, size, c->stream));
 }
 void backend_get_async(ggml_backend_t b, const struct ggml_tensor * t, void * data, size_t off, size_t size) {
+    scoped_ns tm(g_ht.ns_geta);                        // (a copy into pageable host memory returns when the bytes have arrived: this is where a token waits for the device)
     backend_ctx * c = (backend_ctx *) b->context;
     dsetdev(c->device);
     drain_all_uploads();
@@ -718,7 +737,12 @@ enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g)
     g_ht.ns_dyn += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_dyn0).count();
     scoped_ns t_launch(g_ht.ns_launch);
     const bool graphable = c->use_graphs && p.single_token && p.n_gemv > 0 && p.steps.size() >= 3;
-    if (graphable && e->exec) { MI355_CHECK(pm355_graph_launch(e->exec, c->stream)); ++e->runs; ++c->n_replay; return GGML_STATUS_SUCCESS; }
+    if (graphable && e->exec) {
+        if (!g_snap.taken) { g_snap.taken = true; host_counters(g_snap.v); g_snap.v[11] = c->n_replay; g_snap.t0 = std::chrono::steady_clock::now(); }
+        MI355_CHECK(pm355_graph_launch(e->exec, c->stream)); ++e->runs; ++c->n_replay;
+        g_snap.t_last = std::chrono::steady_clock::now();
+        return GGML_STATUS_SUCCESS;
+    }
     if (graphable && e->runs >= 1) {
         MI355_CHECK(pm355_capture_begin(c->stream));
         const bool ok = run_plan(c, g, p);

@@ -25,10 +25,15 @@
 // with FULL 128-byte lines per row and stream (8 lanes per line, non-temporal; the per-row headers / scales cached), parks them in its
 // private LDS tile and reads them back in MFMA operand order - no barrier, a wave's LDS accesses execute in order. The next step's loads
 // are in flight while the current one is computed (VMEM returns in order: the activation loads a step waits for are always issued BEFORE
-// the weight prefetch that overlaps it; scheduling barriers keep the compiler from sinking them). Activations come straight from L2 in
-// operand order; two small tables hold the activation scales (transposed, -> LDS) and the F16 group sums in A-operand order - written by
-// the Q8_K quantizers as a second output (pm_q8k_tables) or by a prologue launch.
-// Work split: workgroup = 8 waves, a balanced slice of rows = up to 8 groups of 32; K is split over the waves that share a row group and
+// the weight prefetch that overlaps it; scheduling barriers keep the compiler from sinking them). Activations come from L2 as ONE coalesced
+// kilobyte per 32-value sub-block out of a table in A-operand order; two more small tables hold the activation scales (transposed, -> LDS) and the
+// F16 group sums in A-operand order - all three written by the Q8_K quantizers as a second output (pm_q8k_tables) or by a prologue launch.
+// [Round 4: the operand-ordered table replaced per-token loads (one cache line per token and instruction, 16 B of it used: at 8 tokens the
+//  activation loads cost 11 of the 67 us of an ffn_down launch, at 32 tokens more); Q6_K's 16-k products take their halves from the 16-byte
+//  loads through v_permlane32_swap. The loads are buffer loads whose token slots >= T carry an out-of-range offset - unconditional instructions
+//  (a branch around them made the compiler's vmcnt bookkeeping wait for the NEXT weight tile before THIS step's products).]
+// Work split: workgroup = 8 waves, a balanced slice of rows = up to 8 groups of 32; K is split over the waves that share a row group -
+// interleaved pair by pair, so that those waves read adjacent 128-byte pieces of a row at the same time (ffn_down Q6_K: 76 -> 70 us) - and
 // their f32 partial tiles are added in a fixed order through LDS (bitwise reproducible). Multi-job form (MJ): up to 3 matrices of one
 // type and K that share the activations form one virtual row space (wq | wk | wv, ffn_gate | ffn_up): one launch, one fill / drain.
 // Measurements, ablation and what did not help: profiles/r02_small_batch_probe.txt, DESIGN.md section 3.
@@ -51,6 +56,7 @@ struct MmqP {
     int t_off;                                                     // first table slot of this pass (16-token passes of a 32-slot table)
     const uint8_t * xq; long xq_stride;                            // row-SoA Q8_K activations [T]
     const uint8_t * bsT; const float * dT;                         // prologue tables: [nsb][64 lanes][8 f16], [nsb][32]
+    const uint8_t * qT;                                            // the activations in A-operand order: [nsb][8 sub-blocks][64 lanes][16 B]
     float * y; long y_stride; const float * bias; const float * resid;
     // multi-job launches (MJ kernels): up to 3 matrices of one type and K that share the activations (wq | wk | wv, ffn_gate | ffn_up) form
     // ONE virtual row space [0, N): job j owns rows [start[j], start[j] + nj[j]); y / bias per job, output token stride nj[j]
@@ -84,6 +90,18 @@ template <> struct Rows<true> {           // several matrices: a lane's rows may
     __device__ __forceinline__ const uint8_t * at_row(int, uint32_t) const { return nullptr; }     // (native-layout types are single-job only)
 };
 
+// Where a lane's activation operand comes from. Token slots >= T must not cost memory traffic (the texture path is paid per ACTIVE lane,
+// tools/small_batch_probe.py ablation) - but an `if (lane is a token)` around the loads becomes a branch over them, and the compiler's
+// s_waitcnt vmcnt bookkeeping then assumes the loads behind it may not have been issued: the wait for THIS step's activations also waited for
+// the NEXT step's whole weight tile (ISA: vmcnt(14) where 31 loads were in flight), i.e. the prefetch overlapped half a step. Buffer loads
+// instead: unconditional instructions, the lanes without a token carry an out-of-range offset, return 0 and touch no memory.
+struct ActSrc {
+    __amdgpu_buffer_rsrc_t rx, rb; uint32_t xo, bo;        // xo / bo: this lane's byte offset into the operand-ordered activations / the group-sum table (or out of range)
+    // sub-block s of super-block sb: lane (t, g) gets the 16 bytes k = 32 s + 16 g .. + 15 of token t (one coalesced kilobyte per wave and 32 tokens)
+    __device__ __forceinline__ u32x4 ld_sub(int sb, int s) const { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int) xo, sb * 8192 + s * 1024, 0)); }
+    __device__ __forceinline__ f16x8 ld_bs(int sb) const { return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, (int) bo, sb * 1024, 0)); }
+};
+
 template <int TYPE> struct MT;
 
 // ---------------------------------------------------------------- Q4_K: row = qa[U][16] | qb[U][16] | hdr[nb][16] ------------
@@ -91,15 +109,13 @@ template <> struct MT<PM_Q4_K> {
     static constexpr int QA = 0, QB = 32 * PITCH, HD = 64 * PITCH, WAVE_LDS = 64 * PITCH + 32 * PITCH_H;
     struct B { u32x4 qa[4], qb[4], h; };
     struct A { u32x4 q[8]; f16x8 bs; };
+    // part n of a step's tile (4 parts: rows rr + 8 n of both nibble streams; part 0 also the headers)
     template <class RW>
-    static __device__ __forceinline__ void issue_b(B & b, const RW & rw, int nb, int pr, int lane) {
+    static __device__ __forceinline__ void issue_b_part(B & b, const RW & rw, int nb, int pr, int lane, int n) {
         const uint32_t u = (uint32_t) min(8 * pr + (lane & 7), 4 * nb - 1), sb = (uint32_t) min(2 * pr + (lane & 1), nb - 1);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            b.qa[n] = ld_nt16(rw.at(n, u * 16u));
-            b.qb[n] = ld_nt16(rw.at(n, (uint32_t) nb * 64u + u * 16u));
-        }
-        b.h = ld_c16(rw.at_h((uint32_t) nb * 128u + sb * 16u));   // cached: 4 steps share the line (as nt loads they re-fetched it from HBM: +29 % traffic)
+        b.qa[n] = ld_nt16(rw.at(n, u * 16u));
+        b.qb[n] = ld_nt16(rw.at(n, (uint32_t) nb * 64u + u * 16u));
+        if (n == 0) b.h = ld_c16(rw.at_h((uint32_t) nb * 128u + sb * 16u));   // cached: 4 steps share the line (as nt loads they re-fetched it from HBM: +29 % traffic)
     }
     static __device__ __forceinline__ void stash(const B & b, uint8_t * L, int lane) {
         const int rr = lane >> 3, c = lane & 7;
@@ -111,15 +127,13 @@ template <> struct MT<PM_Q4_K> {
         *(u32x4 *) (L + HD + (lane >> 1) * PITCH_H + (lane & 1) * 16) = b.h;
     }
     // sub-block s (32 weights) = the 16 bytes at 32 s + 16 g of the super-block
-    static __device__ __forceinline__ void issue_a(A & a, const uint8_t * xa /*token row + 16 g*/, const uint8_t * bs_lane, int sb, bool act) {
-        if (act) {                                   // exec-masked: the texture path is paid per ACTIVE lane (tools/small_batch_probe.py ablation)
+    static __device__ __forceinline__ void issue_a(A & a, const ActSrc & x, int sb) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s) a.q[s] = ld_c16(xa + sb * 256 + 32 * s);
-            a.bs = *(const PM_G f16x8 *) (bs_lane + (size_t) sb * 1024);
-        }
+        for (int s = 0; s < 8; ++s) a.q[s] = x.ld_sub(sb, s);
+        a.bs = x.ld_bs(sb);
     }
-    template <int NV>
-    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out) {
+    template <int NV, class F>
+    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out, F && between) {
         const u32x4 hd = *(const u32x4 *) (L + HD + r * PITCH_H + sbi * 16);
         const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         i32x16 isum = zero;
@@ -131,6 +145,7 @@ template <> struct MT<PM_Q4_K> {
         for (int sb = 0; sb < 8; ++sb) bm[sb] = (_Float16) (float) ((mn4[sb >> 2] >> (8 * (sb & 3))) & 0xFFu);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            between(j);
             const u32x4 w = *(const u32x4 *) (L + (g ? QB : QA) + r * PITCH + (4 * sbi + j) * 16);
             const int sc0 = (int) ((sc4[(2 * j) >> 2] >> (8 * ((2 * j) & 3))) & 0xFFu), sc1 = (int) ((sc4[(2 * j + 1) >> 2] >> (8 * ((2 * j + 1) & 3))) & 0xFFu);
             i32x16 acc = mfma_i8x32(a.q[2 * j], w & 0x0F0F0F0Fu, zero);                    // one 32-k MFMA = one 32-weight sub-block
@@ -163,9 +178,9 @@ template <> struct MT<PM_Q5_K> {
     struct B { u32x4 c[11]; };
     struct A { u32x4 q[8]; f16x8 bs; };
     template <class RW>
-    static __device__ __forceinline__ void issue_b(B & b, const RW & rw, int nb, int pr, int lane) {
+    static __device__ __forceinline__ void issue_b_part(B & b, const RW & rw, int nb, int pr, int lane, int n) {
 #pragma unroll
-        for (int i = 0; i < 11; ++i) {
+        for (int i = 3 * n; i < (n == 3 ? 11 : 3 * n + 3); ++i) {
             const int ci = lane + 64 * i, row = ci / 22, c = ci - row * 22;
             const int sb = min(2 * pr + (c >= 11), nb - 1);
             b.c[i] = ld_nt16(rw.at_row(row, (uint32_t) sb * 176u + (uint32_t) (c >= 11 ? c - 11 : c) * 16u));
@@ -178,15 +193,13 @@ template <> struct MT<PM_Q5_K> {
             *(u32x4 *) (L + row * RP + c * 16) = b.c[i];
         }
     }
-    static __device__ __forceinline__ void issue_a(A & a, const uint8_t * xa /*token row + 16 g*/, const uint8_t * bs_lane, int sb, bool act) {
-        if (act) {
+    static __device__ __forceinline__ void issue_a(A & a, const ActSrc & x, int sb) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s) a.q[s] = ld_c16(xa + sb * 256 + 32 * s);
-            a.bs = *(const PM_G f16x8 *) (bs_lane + (size_t) sb * 1024);
-        }
+        for (int s = 0; s < 8; ++s) a.q[s] = x.ld_sub(sb, s);
+        a.bs = x.ld_bs(sb);
     }
-    template <int NV>
-    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out) {
+    template <int NV, class F>
+    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out, F && between) {
         const uint8_t * blk = L + r * RP + sbi * 176;
         const u32x4 hd = *(const u32x4 *) blk;
         const u32x4 qh = *(const u32x4 *) (blk + 16 + 16 * g);       // bit s of byte l: fifth bit of weight l of sub-block s (l = 16 g + i)
@@ -199,6 +212,7 @@ template <> struct MT<PM_Q5_K> {
         for (int sb = 0; sb < 8; ++sb) bm[sb] = (_Float16) (float) ((mn4[sb >> 2] >> (8 * (sb & 3))) & 0xFFu);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            between(j);
             const u32x4 w = *(const u32x4 *) (blk + 48 + 32 * j + 16 * g);
             const int sc0 = (int) ((sc4[(2 * j) >> 2] >> (8 * ((2 * j) & 3))) & 0xFFu), sc1 = (int) ((sc4[(2 * j + 1) >> 2] >> (8 * ((2 * j + 1) & 3))) & 0xFFu);
             i32x16 acc = mfma_i8x32(a.q[2 * j], (w & 0x0F0F0F0Fu) | (((qh >> (2 * j)) & 0x01010101u) << 4), zero);
@@ -227,17 +241,14 @@ template <> struct MT<PM_Q5_K> {
 template <> struct MT<PM_Q6_K> {
     static constexpr int LA = 0, LB = 32 * PITCH, QH = 64 * PITCH, SC = 96 * PITCH, DD = SC + 32 * PITCH_H, WAVE_LDS = DD + 128;
     struct B { u32x4 la[4], lb[4], qh[4], s; uint16_t d; };
-    struct A { u32x2 q[16]; f16x8 bs; };
+    struct A { u32x4 q[8]; f16x8 bs; };       // as loaded: lane (t, g) holds the WHOLE 16-weight group 2 s + g of sub-block s (operand(): the halves the 16-k products need)
     template <class RW>
-    static __device__ __forceinline__ void issue_b(B & b, const RW & rw, int nb, int pr, int lane) {
+    static __device__ __forceinline__ void issue_b_part(B & b, const RW & rw, int nb, int pr, int lane, int n) {
         const uint32_t u = (uint32_t) min(8 * pr + (lane & 7), 4 * nb - 1), sb = (uint32_t) min(2 * pr + (lane & 1), nb - 1);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            b.la[n] = ld_nt16(rw.at(n, u * 16u));
-            b.lb[n] = ld_nt16(rw.at(n, (uint32_t) nb * 64u + u * 16u));
-            b.qh[n] = ld_nt16(rw.at(n, (uint32_t) nb * 128u + u * 16u));
-        }
-        b.s = ld_c16(rw.at_h((uint32_t) nb * 192u + sb * 16u));   // cached, like Q4_K's header
+        b.la[n] = ld_nt16(rw.at(n, u * 16u));
+        b.lb[n] = ld_nt16(rw.at(n, (uint32_t) nb * 64u + u * 16u));
+        b.qh[n] = ld_nt16(rw.at(n, (uint32_t) nb * 128u + u * 16u));
+        if (n == 0) b.s = ld_c16(rw.at_h((uint32_t) nb * 192u + sb * 16u));   // cached, like Q4_K's header
         // (d: one 2-byte load per lane (row lane % 32, super-block 2 pr + lane / 32), issued by the kernel with its own row offset)
     }
     static __device__ __forceinline__ void stash(const B & b, uint8_t * L, int lane) {
@@ -252,23 +263,34 @@ template <> struct MT<PM_Q6_K> {
         *(uint16_t *) (L + DD + lane * 2) = b.d;                     // [c = lane / 32][r = lane % 32]
     }
     // 16-weight group G = the 8 bytes at 16 G + 8 g of the super-block
-    static __device__ __forceinline__ void issue_a(A & a, const uint8_t * xa /*token row + 8 g*/, const uint8_t * bs_lane, int sb, bool act) {
-        if (act) {
+    static __device__ __forceinline__ void issue_a(A & a, const ActSrc & x, int sb) {
 #pragma unroll
-            for (int G = 0; G < 16; ++G) a.q[G] = ld_c8(xa + sb * 256 + 16 * G);
-            a.bs = *(const PM_G f16x8 *) (bs_lane + (size_t) sb * 1024);
+        for (int s = 0; s < 8; ++s) a.q[s] = x.ld_sub(sb, s);
+        a.bs = x.ld_bs(sb);
+    }
+    // A operand of the 16-k product over group G: lane (t, g) needs bytes 8 g .. 8 g + 7 of group G. The lane pair (t, 0) / (t, 1) holds groups
+    // 2 s / 2 s + 1 whole: v_permlane32_swap hands the upper half of the even group to lane (t, 1) and the lower half of the odd group to (t, 0)
+    static __device__ __forceinline__ void operands(const u32x4 & v, u32x2 & even, u32x2 & odd) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u32x2 r = __builtin_bit_cast(u32x2, __builtin_amdgcn_permlane32_swap(v[i], v[2 + i], false, false));
+            even[i] = r[0]; odd[i] = r[1];
         }
     }
-    template <int NV>
-    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out) {
+    template <int NV, class F>
+    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out, F && between) {
         const u32x4 s16 = *(const u32x4 *) (L + SC + r * PITCH_H + sbi * 16);
         const float d = h2f(*(const uint16_t *) (L + DD + (sbi * 32 + r) * 2));
         const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         i32x16 isum = zero;
+        u32x2 aop[16];                                   // (the swaps work in place on the registers of a.q)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) operands(a.q[s], aop[2 * s], aop[2 * s + 1]);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int v2 = 0; v2 < 2; ++v2) {
+                between(2 * hh + v2);
                 const int uo = (4 * sbi + 2 * hh + v2) * 16 + 8 * g;
                 const u32x2 la = *(const u32x2 *) (L + LA + r * PITCH + uo), lb = *(const u32x2 *) (L + LB + r * PITCH + uo),
                             qh = *(const u32x2 *) (L + QH + r * PITCH + uo);
@@ -281,7 +303,7 @@ template <> struct MT<PM_Q6_K> {
                 for (int c = 0; c < 4; ++c) {
                     const int G = 8 * hh + 2 * c + v2;                                   // group index inside the super-block = scale index
                     const int sc = (int) (int8_t) (s16[G >> 2] >> (8 * (G & 3)));
-                    const i32x16 acc = mfma_i8(pk(a.q[G][0], a.q[G][1]), pk(qv[c][0], qv[c][1]), zero);
+                    const i32x16 acc = mfma_i8(pk(aop[G][0], aop[G][1]), pk(qv[c][0], qv[c][1]), zero);
 #pragma unroll
                     for (int v = 0; v < NV; ++v) { isum[v] = __mul24(sc, acc[v]) + isum[v]; if constexpr (NV < 16) asm volatile("" : "+v"(isum[v])); }   // |acc| <= 16*63*127 (NV = 16: the barrier costs 100 B of spills)
                 }
@@ -309,7 +331,7 @@ template <int TYPE, int NV, int ABL = 0, bool MJ = false>      // NV result regi
 __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     typedef MT<TYPE> M;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (a scalar: the K slice, the loop counters and the buffer loads' scalar offsets derive from it)
     const int nsb = p.K / 256, npairs = (nsb + 1) >> 1;
     float * dTl = (float *) smem;                                 // activation scales [nsb + 1][32] (0 for token slots >= T; last row all 0)
     uint8_t * stage = smem + (size_t) (nsb + 1) * 128;            // NWAVE x WAVE_LDS; afterwards the 32 KB reduction buffer
@@ -318,18 +340,35 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     const int nrg = (r1 - r0 + 31) >> 5;
     const int RGB = 1 << p.rgb_log2, KS = NWAVE >> p.rgb_log2;
     const int rgi = wave & (RGB - 1), ks = wave >> p.rgb_log2;
-    const int pb = npairs * ks / KS, pe = npairs * (ks + 1) / KS;
+#ifdef PM_MMQ_KCONTIG
+    const int pb = npairs * ks / KS, pe = npairs * (ks + 1) / KS, pstep = 1;
+#else
+    // K slices INTERLEAVED over the waves that share a row group: at any time those waves read ADJACENT 128-byte pieces of a row (KS x 128 B
+    // contiguous per row and stream) instead of pieces a whole slice apart - HBM sees longer bursts per open page
+    const int pstep = KS, pb = ks, pe = npairs <= ks ? ks : ks + ((npairs - ks + KS - 1) / KS) * KS;      // pairs pb, pb + KS, ... < pe
+#endif
     uint8_t * L = stage + wave * M::WAVE_LDS;
     const int r = lane & 31, g = lane >> 5;
-    const uint8_t * xa = p.xq + (long) min(r, p.T - 1) * p.xq_stride + (TYPE == PM_Q6_K ? 8 : 16) * g;
-    const uint8_t * bs_lane = p.bsT + (lane + p.t_off) * 16;
     const bool act = NV == 16 ? true : r < p.T;                                     // token slots >= T: operand bytes are don't-care (scale row 0, never stored)
+    ActSrc xs;
+    xs.rx = __builtin_amdgcn_make_buffer_rsrc((void *) p.qT, 0, nsb * 8192, 0x00020000);
+    xs.rb = __builtin_amdgcn_make_buffer_rsrc((void *) p.bsT, 0, nsb * 1024 + 512, 0x00020000);      // (+ t_off slots of the last super-block: inside the table allocation)
+    xs.xo = act ? (uint32_t) ((32 * g + r + p.t_off) * 16) : 0x80000000u;
+    xs.bo = act ? (uint32_t) ((lane + p.t_off) * 16) : 0x80000000u;
     Rows<MJ> rw;
     typename M::B R;
     typename M::A A0 = {}, A1 = {};                              // (inactive token lanes keep these zeros)
+    // a step's weight tile goes out in FOUR parts. Issued in one burst (13 x 1 KiB per wave, 100 KB per CU) the wave sat in the issue itself until the
+    // CU's miss queues had taken the whole tile - and only then started on the tile it holds: load time and compute time added up
+    // (ffn_down Q6_K, 8 tokens: 41 us stream + 19 us compute + 12 fixed = 70). One part in front of every quarter of the first super-block's
+    // products keeps both busy.
+    auto issue_b_part = [&](int pr, int n) __attribute__((always_inline)) {
+        M::issue_b_part(R, rw, nsb, pr, lane, n);
+        if constexpr (TYPE == PM_Q6_K) if (n == 0) R.d = *(const PM_G uint16_t *) rw.at_d((uint32_t) nsb * 208u + (uint32_t) min(2 * pr + g, nsb - 1) * 2u);   // cached: 32 steps share the line
+    };
     auto issue_b = [&](int pr) __attribute__((always_inline)) {
-        M::issue_b(R, rw, nsb, pr, lane);
-        if constexpr (TYPE == PM_Q6_K) R.d = *(const PM_G uint16_t *) rw.at_d((uint32_t) nsb * 208u + (uint32_t) min(2 * pr + g, nsb - 1) * 2u);   // cached: 32 steps share the line
+#pragma unroll
+        for (int n = 0; n < 4; ++n) issue_b_part(pr, n);
     };
     // the first weight tile and activation slice of a row group (in flight before anything waits)
     auto first = [&](int rg) __attribute__((always_inline)) {
@@ -349,8 +388,8 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
             rw.rph = rowptr(rbase + (lane >> 1)); rw.rpd = rowptr(rbase + r);
         }
         issue_b(pb);
-        M::issue_a(A0, xa, bs_lane, 2 * pb, act);
-        if constexpr (ABL & 1) M::issue_a(A1, xa, bs_lane, 2 * pb, act);
+        M::issue_a(A0, xs, 2 * pb);
+        if constexpr (ABL & 1) M::issue_a(A1, xs, 2 * pb);
     };
     if (rgi < nrg && pb < pe) first(rgi);                         // ... including the staging of the scale table:
     for (int i = tid; i < nsb * 32; i += BLOCK) {                 // (slots >= T masked here: a quantizer that writes the table itself fills rows < T only)
@@ -364,21 +403,27 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
         f32x16 out = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (rg < nrg && pb < pe) {
             if (rg0 > 0) first(rg);
-            for (int pr = pb; pr < pe; ++pr) {
+            for (int pr = pb; pr < pe; pr += pstep) {
                 M::stash(R, L, lane);                                  // waits for this step's weights only
                 const int sb0 = 2 * pr, sb1 = min(2 * pr + 1, nsb - 1);
                 // Issue order is the design (VMEM returns in order): the compiler's schedulers must not sink the prefetches towards
                 // their uses - no conditional code in the step (an odd tail super-block is computed on clamped data with the all-zero
                 // scale row) and scheduling barriers around the issue points.
-                if constexpr (!(ABL & 1)) M::issue_a(A1, xa, bs_lane, sb1, act);
-                if constexpr (!(ABL & 2)) issue_b(min(pr + 1, pe - 1));  // unconditional (clamped): in flight during the whole step
+                if constexpr (!(ABL & 1)) M::issue_a(A1, xs, sb1);
+                const int prn = min(pr + pstep, pe - pstep);             // the wave's next pair (clamped: the last step re-loads its own)
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(ABL & 4)) M::template compute<NV>(A0, L, 0, r, g, dTl + sb0 * 32, out);
+                // (the 32-token Q6_K form has no registers for it - 404 B of spills, 88 -> 205 us: its tile still goes out in one burst)
+                constexpr bool SPREAD = !(TYPE == PM_Q6_K && NV == 16) && !(ABL & 4);
+                if constexpr (!SPREAD && !(ABL & 2)) { issue_b(prn); __builtin_amdgcn_sched_barrier(0); }
+                auto part = [&](int n) __attribute__((always_inline)) {   // next tile, part n: unconditional, pinned between the quarters
+                    if constexpr (SPREAD && !(ABL & 2)) { __builtin_amdgcn_sched_barrier(0); issue_b_part(prn, n); __builtin_amdgcn_sched_barrier(0); }
+                };
+                if constexpr (!(ABL & 4)) M::template compute<NV>(A0, L, 0, r, g, dTl + sb0 * 32, out, part);
                 else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A0.q[s_])); asm volatile("" :: "v"(A0.bs)); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane))); }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(ABL & 1)) M::issue_a(A0, xa, bs_lane, min(2 * pr + 2, nsb - 1), act);
+                if constexpr (!(ABL & 1)) M::issue_a(A0, xs, min(2 * prn, nsb - 1));
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(ABL & 4)) M::template compute<NV>(A1, L, 1, r, g, dTl + (2 * pr + 1 < nsb ? sb1 : nsb) * 32, out);
+                if constexpr (!(ABL & 4)) M::template compute<NV>(A1, L, 1, r, g, dTl + (2 * pr + 1 < nsb ? sb1 : nsb) * 32, out, [](int) {});
                 else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A1.q[s_])); asm volatile("" :: "v"(A1.bs)); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane + 1024))); }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -415,9 +460,13 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
 }
 
 // prologue: per super-block, the activation group sums as F16 in A-operand order and the transposed activation scales
-__global__ __launch_bounds__(64) void mmq_prep_kernel(const uint8_t * xq, long xq_stride, int K, int T, uint8_t * bsT, float * dT) {
+__global__ __launch_bounds__(64) void mmq_prep_kernel(const uint8_t * xq, long xq_stride, int K, int T, uint8_t * bsT, float * dT, uint8_t * qT) {
     const int sb = (int) blockIdx.x, l = (int) threadIdx.x, t = l & 31, g = l >> 5;
     const uint8_t * row = xq + (long) min(t, T - 1) * xq_stride;
+    if (t < T) {                                                   // the values in A-operand order (token slots >= T are never loaded)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) *(u32x4 *) (qT + (size_t) sb * 8192 + s * 1024 + l * 16) = *(const u32x4 *) (row + sb * 256 + 32 * s + 16 * g);
+    }
     const int16_t * bsums = (const int16_t *) (row + K + (K / 256) * 4);
     f16x8 h;
 #pragma unroll
@@ -455,9 +504,9 @@ int pm_mmq_i8_check(int type, int K, int N, int T) {
 namespace {
 // scratch of (device, stream) for K: tables of two 32-token passes + a quantized copy of up to 64 f32 rows; null: allocation failed (or,
 // lookup_only, no scratch of this stream holds tables for K)
+size_t scr_q_off(int K) { return ((2 * (size_t) (K / 256) * (1024 + 128) + (size_t) 64 * pm_q8k_row_bytes(K) + 256) + 255) & ~(size_t) 255; }
 Scr * scratch(int dev, hipStream_t st, int K, bool lookup_only) {
-    const size_t xrow = pm_q8k_row_bytes(K), tab = (size_t) (K / 256) * (1024 + 128);
-    const size_t need = 2 * tab + (size_t) 64 * xrow + 256;
+    const size_t need = scr_q_off(K) + 2 * (size_t) (K / 256) * 8192;          // tables of two passes | quantized copy of 64 rows | operand-ordered values of two passes
     std::lock_guard<std::mutex> lk(g_scr_mu);
     Scr * e = nullptr, * lru = &g_scr[dev][0];
     for (Scr & c : g_scr[dev]) {
@@ -467,7 +516,7 @@ Scr * scratch(int dev, hipStream_t st, int K, bool lookup_only) {
     // lookup_only (a consumer that re-uses tables a producer wrote): the entry of this stream must still exist (not evicted by a ninth
     // stream, not re-allocated for a larger K in between) AND hold tables for this K - else the launch fails instead of reading zeros
     if (lookup_only) {
-        if (!e || e->tab_K != K || e->bytes < 2 * tab) return nullptr;
+        if (!e || e->tab_K != K || e->bytes < need) return nullptr;
         e->use = ++g_tick;
         return e;
     }
@@ -488,7 +537,7 @@ void launch_prep(const Scr * sc, const void * xq, int K, int T, hipStream_t st) 
     for (int t0 = 0, c = 0; t0 < T; t0 += 32, ++c) {
         uint8_t * bsT = sc->p + c * tab;
         hipLaunchKernelGGL(mmq_prep_kernel, dim3(nsb), dim3(64), 0, st, (const uint8_t *) xq + (size_t) t0 * xrow, (long) xrow, K, T - t0 < 32 ? T - t0 : 32,
-                           bsT, (float *) (bsT + (size_t) nsb * 1024));
+                           bsT, (float *) (bsT + (size_t) nsb * 1024), sc->p + scr_q_off(K) + (size_t) c * nsb * 8192);
     }
 }
 }  // namespace
@@ -501,7 +550,7 @@ int pm_mmq_i8_tables(int K, hipStream_t st, pm_q8k_tables * out) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
     const Scr * sc = scratch(dev, st, K, false);
     if (!sc) return -3;
-    out->base = sc->p; out->nsb = K / 256; out->tab_bytes = (size_t) (K / 256) * (1024 + 128);
+    out->base = sc->p; out->nsb = K / 256; out->tab_bytes = (size_t) (K / 256) * (1024 + 128); out->qbase = sc->p + scr_q_off(K);
     return 0;
 }
 
@@ -548,7 +597,7 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
         MmqP p = {};
         p.t_off = t0 % 32;
         p.W = (const uint8_t *) W; p.row_stride = (long) pm_weight_row_stride(type, K); p.N = N; p.K = K; p.T = tn;
-        p.xq = xc; p.xq_stride = (long) xrow; p.bsT = bsT; p.dT = dT;
+        p.xq = xc; p.xq_stride = (long) xrow; p.bsT = bsT; p.dT = dT; p.qT = sc->p + scr_q_off(K) + (size_t) (t0 / 32) * nsb * 8192;
         p.y = Y + (size_t) t0 * N; p.y_stride = N; p.bias = bias; p.resid = resid ? resid + (size_t) t0 * N : nullptr;
         p.rgb_log2 = nrg >= 8 ? 3 : nrg >= 3 ? 2 : nrg == 2 ? 1 : 0;
         auto go = [&](auto kern) {
@@ -594,7 +643,7 @@ int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const in
     const int rows = (int) ((total + grid - 1) / grid), nrg = (rows + 31) / 32;
     MmqP p = {};
     p.row_stride = (long) pm_weight_row_stride(type, K); p.N = (int) total; p.K = K; p.T = T;
-    p.xq = (const uint8_t *) xq; p.xq_stride = (long) xrow; p.bsT = sc->p; p.dT = (const float *) (sc->p + (size_t) nsb * 1024);
+    p.xq = (const uint8_t *) xq; p.xq_stride = (long) xrow; p.bsT = sc->p; p.dT = (const float *) (sc->p + (size_t) nsb * 1024); p.qT = sc->p + scr_q_off(K);
     p.njobs = njobs;
     int at = 0;
     for (int j = 0; j < 3; ++j) {

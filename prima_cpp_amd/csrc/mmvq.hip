@@ -210,10 +210,12 @@ int pm_launch_gemv(const pm_gemv_args & a, hipStream_t st) {
         f.job[0].y = a.y + (size_t) c * a.y_stride; f.job[0].bias = a.bias;
         f.job[0].resid = a.resid ? a.resid + (size_t) c * a.y_stride : nullptr;
         const int left = a.ncols - c;
-        int nc = (a.W2 || a.dbg_int || left < 2) ? 1 : (left >= 8 && a.type != PM_Q5_K ? 8 : left >= 4 ? 4 : 2);   // (8 Q5_K columns spill even at 256 VGPRs)
+        const bool pair = a.W2 != nullptr;
+        // column slots of the launch: 8 / 4 / 2 (3 columns take the 4-slot form with one slot idle: one pass instead of 2 + 1); pair launches: 2
+        int nc = (a.dbg_int || left < 2) ? 1 : pair ? ((a.type == PM_Q4_K || a.type == PM_Q6_K) ? 2 : 1) : (left >= 8 && a.type != PM_Q5_K ? 8 : left >= 3 ? 4 : 2);   // (8 Q5_K columns spill even at 256 VGPRs)
         if (nc > 1) {
-            GemvP p; int ta, tb, grid; bool pair; size_t lds1;
-            int rc = gemv_fill(f, 0, p, ta, tb, pair, lds1, grid);
+            GemvP p; int ta, tb, grid; bool pr; size_t lds1;
+            int rc = gemv_fill(f, 0, p, ta, tb, pr, lds1, grid);
             if (rc) return rc;
             // LDS: nc activation columns + nc results per row
             const int ablk = ta == PM_Q8_0 ? 32 : 256;
@@ -221,11 +223,12 @@ int pm_launch_gemv(const pm_gemv_args & a, hipStream_t st) {
             const size_t rows = (size_t) ((a.N + grid - 1) / grid + 4);
             while (nc > 1 && nc * col + rows * nc * 4 > 150 * 1024) nc /= 2;
             if (nc > 1) {
-                p.ncols = nc; p.xq_stride = (long) xrow; p.y_stride = (long) a.y_stride;
+                const int served = left < nc ? left : nc;
+                p.ncols = served; p.xq_stride = (long) xrow; p.y_stride = (long) a.y_stride;
                 const size_t lds = nc * col + rows * nc * 4;
-                rc = pm_launch_gemv_cols(ta, p, nc, grid, lds, st);      // mmvq_cols.hip (512-thread workgroups, 256-VGPR budget)
+                rc = pm_launch_gemv_cols(ta, p, nc, pair, grid, lds, st);      // mmvq_cols.hip (512-thread workgroups, 256-VGPR budget)
                 if (rc) return rc;
-                c += nc;
+                c += served;
                 continue;
             }
         }

@@ -7,43 +7,49 @@
 // SIMD = the full 256-VGPR budget; the grid stays one workgroup per CU.
 // Replaces the batch>1 rows of ggml_mul_mat's vec_dot loop (reference ggml/src/ggml.c ggml_compute_forward_mul_mat, nrc = 1 per column).
 #define PM_GEMV_BLOCK 512
+#define PM_RCOLS(NC_) ((NC_) <= 4 ? 2 : 1)
 #include "mmvq_device.h"
 
 using namespace pmv;
 
 namespace {
 
-template <int T, int NC>
+template <int T, int NC, bool PAIR>
 __global__ __launch_bounds__(PM_GEMV_BLOCK, 2) void gemv_q_cols_kernel(GemvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double nred[PM_GEMV_NW];
-    gemv_body<T, T, false, false, NC>(p, smem, nred);
+    gemv_body<T, T, PAIR, false, NC>(p, smem, nred);
 }
 
 template <int T>
-int launch_cols(const GemvP & p, int nc, int grid, size_t lds, hipStream_t st) {
+int launch_cols(const GemvP & p, int nc, bool pair, int grid, size_t lds, hipStream_t st) {
     auto go = [&](auto kern) {
         (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(PM_GEMV_BLOCK), lds, st, p);
     };
+    if (pair) {                                       // ffn_gate | ffn_up of a 2-token step: silu(gate) * up per column, one pass over both matrices
+        if constexpr (T == PM_Q4_K || T == PM_Q6_K) { if (nc == 2) { go(gemv_q_cols_kernel<T, 2, true>); return 0; } }
+        return -1;
+    }
     if (nc == 8) {
         if constexpr (T == PM_Q5_K) return -1;        // 8 Q5_K accumulator sets spill (168 B / lane): the caller issues 2 x 4
-        else go(gemv_q_cols_kernel<T, 8>);
-    } else if (nc == 4) go(gemv_q_cols_kernel<T, 4>);
-    else if (nc == 2) go(gemv_q_cols_kernel<T, 2>);
+        else go(gemv_q_cols_kernel<T, 8, false>);
+    } else if (nc == 4) go(gemv_q_cols_kernel<T, 4, false>);
+    else if (nc == 2) go(gemv_q_cols_kernel<T, 2, false>);
     else return -1;
     return 0;
 }
 
 }  // namespace
 
-// p: filled by gemv_fill (mmvq.hip) for ONE job, with ncols / xq_stride / y_stride set; grid = one workgroup per CU
-int pm_launch_gemv_cols(int type, const GemvP & p, int nc, int grid, size_t lds, hipStream_t st) {
+// p: filled by gemv_fill (mmvq.hip) for ONE job, with ncols (the columns of the batch, <= nc: the kernel's column slots) / xq_stride / y_stride set;
+// grid = one workgroup per CU
+int pm_launch_gemv_cols(int type, const GemvP & p, int nc, bool pair, int grid, size_t lds, hipStream_t st) {
     switch (type) {
-        case PM_Q4_K: return launch_cols<PM_Q4_K>(p, nc, grid, lds, st);
-        case PM_Q5_K: return launch_cols<PM_Q5_K>(p, nc, grid, lds, st);
-        case PM_Q6_K: return launch_cols<PM_Q6_K>(p, nc, grid, lds, st);
-        case PM_Q8_0: return launch_cols<PM_Q8_0>(p, nc, grid, lds, st);
+        case PM_Q4_K: return launch_cols<PM_Q4_K>(p, nc, pair, grid, lds, st);
+        case PM_Q5_K: return launch_cols<PM_Q5_K>(p, nc, pair, grid, lds, st);
+        case PM_Q6_K: return launch_cols<PM_Q6_K>(p, nc, pair, grid, lds, st);
+        case PM_Q8_0: return launch_cols<PM_Q8_0>(p, nc, pair, grid, lds, st);
     }
     return -1;
 }

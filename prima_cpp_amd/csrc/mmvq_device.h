@@ -368,7 +368,7 @@ __device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_
     if (p.xmode == 0) {
         // pre-quantized row-SoA: int8 qs[K] | scales. Copy + group sums, one LDS region per activation column.
         for (int c = 0; c < ncols; ++c) {
-            const uint8_t * xq = p.xq + (size_t) c * p.xq_stride;
+            const uint8_t * xq = p.xq + (size_t) (p.ncols > 0 && c >= p.ncols ? p.ncols - 1 : c) * p.xq_stride;   // (3 columns run the 4-column form: slot 3 repeats column 2, never stored)
             int8_t * cq = xs_q + c * col_bytes; int * cgs = (int *) ((char *) xs_gs + c * col_bytes); float * cd = (float *) ((char *) xs_d + c * col_bytes);
             for (int g = tid; g < K / 16; g += PM_GEMV_BLOCK) {
                 const u32x4 t = *(const u32x4 *) (xq + 16 * g);
@@ -493,7 +493,12 @@ template <int TYPE, bool PAIR, int NC = 1> struct Item {
 #define PM_RPAIR 1
 #endif
     static constexpr int CH = T::NV == 64 ? PM_CH64 : PM_CH32;   // units per lane per row and register set (two sets in flight)
-    static constexpr int R  = PAIR ? PM_RPAIR : PM_RSINGLE;              // rows in flight per wave
+#ifndef PM_RCOLS
+#define PM_RCOLS(NC_) 1
+#endif
+    // rows in flight per wave. Multi-column launches (mmvq_cols.hip): two rows share every activation slice fetched from LDS - the column loop is
+    // bound by those LDS reads (4 columns: ffn_gate 51 -> 40 us, ffn_down Q6_K 52 -> 46 us; 8 columns x 2 rows spill at 256 VGPRs and keep 1)
+    static constexpr int R  = PAIR ? PM_RPAIR : (NC > 1 ? (TYPE == PM_Q5_K && NC > 2 ? 1 : PM_RCOLS(NC)) : PM_RSINGLE);   // (Q5_K: 4 columns x 2 rows spill 200 B)
     struct Regs { typename T::Wr w[R][NM][CH]; };
 
     // unconditional loads (row / unit clamped): conditional loads make the compiler drain the VMEM queue
@@ -660,9 +665,10 @@ __device__ __forceinline__ float row_result(const GemvJob & jb, const float * ou
 }
 
 template <bool COH, int NC>
-__device__ __forceinline__ void write_out(const GemvJob & jb, const float * outbuf, int r0, int r1, int ob, int tid, long y_stride, int cpr = 1) {
+__device__ __forceinline__ void write_out(const GemvJob & jb, const float * outbuf, int r0, int r1, int ob, int tid, long y_stride, int cpr = 1, int ncols = NC) {
     for (int t = tid; t < (r1 - r0) * NC; t += PM_GEMV_BLOCK) {
         const int c = NC == 1 ? 0 : t / (r1 - r0), row = NC == 1 ? t : t - c * (r1 - r0);     // consecutive threads -> consecutive rows
+        if (NC > 1 && c >= ncols) break;                                                        // (column slots past the batch)
         float out = NC == 1 ? row_result(jb, outbuf, ob, row, cpr) : outbuf[(ob + row) * NC + c];
         if (jb.bias)  out += ld_g(jb.bias + r0 + row);
         if (jb.resid) out += ld_act<false>(jb.resid + c * y_stride + r0 + row);
@@ -832,9 +838,10 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
         write_out_qkv(p.job[1], p.epi, outbuf, r0_1, r1_1, ob_1, tid, cpr_1, epi_slot, epi_off, ec1, es1);
         write_out_qkv(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off, ec2, es2);
     } else {
-        write_out<MEGA, NC>(p.job[0], outbuf, r0_0, r1_0, 0, tid, p.y_stride);
-        write_out<MEGA, NC>(p.job[1], outbuf, r0_1, r1_1, ob_1, tid, p.y_stride, cpr_1);
-        write_out<MEGA, NC>(p.job[2], outbuf, r0_2, r1_2, ob_2, tid, p.y_stride, cpr_2);
+        const int ncw = NC > 1 && p.ncols > 0 ? p.ncols : NC;
+        write_out<MEGA, NC>(p.job[0], outbuf, r0_0, r1_0, 0, tid, p.y_stride, 1, ncw);
+        write_out<MEGA, NC>(p.job[1], outbuf, r0_1, r1_1, ob_1, tid, p.y_stride, cpr_1, ncw);
+        write_out<MEGA, NC>(p.job[2], outbuf, r0_2, r1_2, ob_2, tid, p.y_stride, cpr_2, ncw);
     }
     tsv[5] = PM_TS_NOW();
     pm_ts_store(p.ts, 1 | (PAIR ? 16 : 0) | (p.xmode << 8) | (p.K << 12), tsv);
@@ -847,4 +854,4 @@ int gemv_fill(const pm_gemv_fused & a, int grid_fixed, GemvP & p, int & ta, int 
 } // namespace pmv
 
 // multi-column launch (mmvq_cols.hip): nc = 2 / 4 / 8 activation columns per pass over the weights
-int pm_launch_gemv_cols(int type, const pmv::GemvP & p, int nc, int grid, size_t lds, hipStream_t st);
+int pm_launch_gemv_cols(int type, const pmv::GemvP & p, int nc, bool pair, int grid, size_t lds, hipStream_t st);

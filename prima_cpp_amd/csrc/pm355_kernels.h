@@ -37,7 +37,10 @@ static inline bool pm_type_is_repacked(int type) { return type == 12 || type == 
 
 // optional second output of the Q8_K quantizers: the activation tables of the small-batch mat-mul (mmq_i8.hip: per 32-row pass, the F16
 // 16-value sums in MFMA operand order | the transposed block scales) - that mat-mul then needs no prologue launch. base == null: off
-struct pm_q8k_tables { uint8_t * base = nullptr; size_t tab_bytes = 0; int nsb = 0; };
+// qbase (optional third table, mmq_i8.hip): the int8 values themselves in the matrix cores' A-operand order, nsb * 8192 bytes per 32 rows -
+// [super-block][32-value sub-block s][operand lane = 32 * (k / 16 % 2) + row % 32][16 bytes]: one coalesced load per sub-block instead of one
+// cache line per token
+struct pm_q8k_tables { uint8_t * base = nullptr; size_t tab_bytes = 0; int nsb = 0; uint8_t * qbase = nullptr; };
 void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStream_t st, pm_q8k_tables tab = {});
 void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStream_t st);
 // Q8_K rows of silu(gate) * up (the ffn_down activations of a small batch), no f32 product in HBM

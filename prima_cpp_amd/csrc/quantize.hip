@@ -76,6 +76,8 @@ __device__ __forceinline__ void q8k_block_from_regs(const float v[4], int lane, 
         if (tb.base) ((float *) (tb.base + (size_t) (row >> 5) * tb.tab_bytes + (size_t) tb.nsb * 1024))[blk * 32 + (row & 31)] = 0.0f;
     }
     ((uint32_t *) (qs + (size_t) blk * PM_QK_K))[lane] = packed;
+    // A-operand order (pm_q8k_tables::qbase): values 4 lane .. 4 lane + 3 = bytes 4 (lane % 4) of sub-block lane / 8, half (lane / 4) % 2
+    if (tb.qbase) *(uint32_t *) (tb.qbase + (size_t) (row >> 5) * tb.nsb * 8192 + (size_t) blk * 8192 + (lane >> 3) * 1024 + ((((lane >> 2) & 1) * 32 + (row & 31)) * 16) + 4 * (lane & 3)) = packed;
     // bsums: 16 values = 4 lanes (one quad)
     psum += dpp_i<0xB1>(psum);
     psum += dpp_i<0x4E>(psum);

@@ -168,7 +168,7 @@ def test_gemv_integer_partials_bitexact_and_float_close(P, oracle, t, K, N):
         assert abs(y[r] - want) <= 4e-6 * mag + 1e-30, (TYPE_NAMES[t], K, r, y[r], want)
 
 
-@pytest.mark.parametrize("C", [3, 4, 7, 8])       # 2+1, 4, 4+2+1, 8 columns per launch group (mmvq_cols.hip)
+@pytest.mark.parametrize("C", [2, 3, 4, 5, 7, 8])       # column slots per launch group (mmvq_cols.hip): 2, 4 (one idle), 4, 4+1, 4+4 (one idle), 8; pairs: 2 per launch
 @pytest.mark.parametrize("t", QUANT_TYPES)
 def test_gemv_epilogues_and_columns(P, oracle, t, C):
     rng = np.random.default_rng(25)

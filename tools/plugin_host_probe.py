@@ -27,7 +27,7 @@ def one(name):
     err = st['stderr']
     print(f"== {name}: decode {st['decode_tok_s']:.1f} tok/s, {st['decode_ms_avg'] * 1e3:.1f} us per token")
     for ln in err.splitlines():
-        if 'ggml-mi355' in ln and ('stats' in ln or 'host time' in ln or 'phases' in ln): print('  ' + ln.strip())
+        if "ggml-mi355" in ln and any(k in ln for k in ("stats", "host time", "phases", "steady state")): print('  ' + ln.strip())
     m = re.search(r'graph_compute ([\d.]+) ms total \(([\d.]+) us per call\).*synchronize ([\d.]+) ms in (\d+) calls', err)
     n = re.search(r'stats: graph_compute (\d+)', err)
     if m and n:
