@@ -253,7 +253,6 @@ void layer_release(pm355_model * m, int il, hipStream_t st) {
 // quantize `src` [T][K] into the activation format(s) the given weights need; returns pointers
 struct ActQ { const void * k = nullptr; const void * z = nullptr; bool tab = false; };   // tab: the small-batch mat-mul's activation tables were written too
 const int MMQ_MIN_TOKENS = 3, MMQ_MAX_TOKENS = 64;      // (3 columns cost the multi-column mat-vec two passes: 57 vs 39 us on the ffn shape)
-const int MMQ_COLS_MAX_TOKENS = 4;        // single matrices up to here: multi-column mat-vec (mmvq_cols.hip)
 const int MMQ_MULTI_MIN_TOKENS = 2;       // the fused wq | wk | wv and ffn_gate | ffn_up launches already win at 2 tokens (3 / 4 mat-vec launches otherwise)
 // the table output of the Q8_K quantizers, when this batch size takes the small-batch mat-mul (mmq_i8.hip)
 pm_q8k_tables mmq_tables(const pm355_model * m, int K, int T, hipStream_t st) {
@@ -293,9 +292,8 @@ int gemv(const Tensor & w, const Tensor * w2, const ActQ & a, int T, float * y, 
 // (one to three passes per 8 columns). `prepped`: the kernel's activation tables already describe THIS activation set (set by the first
 // served call, cleared by the caller whenever the activations change)
 int matmul_small(pm355_model * m, const Tensor & w, const ActQ & a, int T, float * y, const float * bias, const float * resid, bool & prepped, hipStream_t st) {
-    // 3 / 4 tokens: the 4-slot multi-column mat-vec (two rows per activation fetch) beats the matrix-core kernel's fill / drain on single matrices
-    // (ffn_down Q6_K 46 vs 73 us, wo 16 vs 17 us, a lone wv 10 vs 14 us); the multi-matrix launches (wq | wk | wv, ffn_gate | ffn_up) stay where they are
-    if (T <= MMQ_COLS_MAX_TOKENS && !m->no_small_cols) return gemv(w, nullptr, a, T, y, bias, resid, st);
+    // (3 / 4 tokens on the 4-slot multi-column mat-vec - two rows per activation fetch: ffn_down Q6_K 46 us - measured against this kernel once it had
+    //  its operand-ordered activation table (54 us without the prologue launch): 177 vs 172 us per layer, so the matrix-core kernel keeps them)
     if (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && a.k && pm_mmq_i8_check(w.type, (int) w.K, (int) w.N, T) == 0) {
         const int rc = pm_launch_mmq_i8(w.type, w.d, a.k, nullptr, y, (int) w.K, (int) w.N, T, bias, resid, (prepped || a.tab) ? 1 : 0, st);
         if (rc == 0) { prepped = true; return 0; }
