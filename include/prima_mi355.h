@@ -165,8 +165,9 @@ PM355_API int pm355_mul_mat_q_i8_check(int type, int64_t K, int64_t N, int64_t n
  * tokens and the products run on the integer matrix cores (v_mfma_i32_32x32x16_i8, prima_cpp_amd/csrc/mmq_i8.hip) with the
  * reference's own integer arithmetic - activations quantized to Q8_K, exact int32 block sums, one f32 multiply-add per 256-weight
  * super-block (ggml_vec_dot_q4_K_q8_K / ggml_vec_dot_q6_K_q8_K, ggml/src/ggml-quants.c; CUDA plug-in: ggml-cuda/mmq.cuh:2583).
- * Q4_K / Q5_K / Q6_K weights. xq = n_tokens rows already quantized by pm355_quantize_q8_K, or NULL and x = f32 [n_tokens][K].
- * y / resid: [n_tokens][N]. pm355_mul_mat_q_small_check: 0 when the shape is served. */
+ * Q4_K / Q5_K / Q6_K weights, and Q8_0 weights with Q8_0 activations (ggml_vec_dot_q8_0_q8_0, ggml-quants.c:5518: one 32-k matrix
+ * instruction per block, K % 32 == 0). xq = n_tokens rows already quantized by pm355_quantize_q8_K (Q8_0: pm355_quantize_q8_0), or NULL
+ * and x = f32 [n_tokens][K]. y / resid: [n_tokens][N]. pm355_mul_mat_q_small_check: 0 when the shape is served. */
 PM355_API int pm355_mul_mat_q_small(int type, const void * W, int64_t K, int64_t N, const void * xq, const float * x, int64_t n_tokens,
                                     float * y, const float * bias, const float * resid, pm355_stream_t stream);
 PM355_API int pm355_mul_mat_q_small_check(int type, int64_t K, int64_t N, int64_t n_tokens);

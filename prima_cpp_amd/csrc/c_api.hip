@@ -205,8 +205,8 @@ int pm355_mul_mat_q_small(int type, const void * W, int64_t K, int64_t N, const 
     (void) hipGetLastError();
     if (!xq && !x) return fail(PM355_E_RANGE, "mul_mat_q_small: neither xq nor x given");
     const int rc = pm_launch_mmq_i8(type, W, xq, x, y, (int) K, (int) N, (int) n_tokens, bias, resid, 0, S(st));
-    if (rc == -1) return fail(PM355_E_UNSUPPORTED, "mul_mat_q_small: weight type (Q4_K / Q5_K / Q6_K)");
-    if (rc == -2) return fail(PM355_E_SHAPE, "mul_mat_q_small: 1 <= n_tokens <= 64, K % 256 == 0, K >= 512 required");
+    if (rc == -1) return fail(PM355_E_UNSUPPORTED, "mul_mat_q_small: weight type (Q4_K / Q5_K / Q6_K / Q8_0)");
+    if (rc == -2) return fail(PM355_E_SHAPE, "mul_mat_q_small: 1 <= n_tokens <= 64, K % 256 == 0 (Q8_0: K % 32 == 0), K >= 512 required");
     if (rc == -4) return fail(PM355_E_RANGE, "mul_mat_q_small: K too large for the LDS tiles");
     if (rc) return fail(PM355_E_HIP, "mul_mat_q_small: scratch allocation");
     HIP_TRY(hipGetLastError());

@@ -294,9 +294,11 @@ int gemv(const Tensor & w, const Tensor * w2, const ActQ & a, int T, float * y, 
 int matmul_small(pm355_model * m, const Tensor & w, const ActQ & a, int T, float * y, const float * bias, const float * resid, bool & prepped, hipStream_t st) {
     // (3 / 4 tokens on the 4-slot multi-column mat-vec - two rows per activation fetch: ffn_down Q6_K 46 us - measured against this kernel once it had
     //  its operand-ordered activation table (54 us without the prologue launch): 177 vs 172 us per layer, so the matrix-core kernel keeps them)
-    if (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && a.k && pm_mmq_i8_check(w.type, (int) w.K, (int) w.N, T) == 0) {
-        const int rc = pm_launch_mmq_i8(w.type, w.d, a.k, nullptr, y, (int) w.K, (int) w.N, T, bias, resid, (prepped || a.tab) ? 1 : 0, st);
-        if (rc == 0) { prepped = true; return 0; }
+    const bool q80 = w.type == PM_Q8_0;                  // Q8_0 weights take Q8_0 activations; the kernel builds their tables per call
+    const void * xa = q80 ? a.z : a.k;
+    if (T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && xa && pm_mmq_i8_check(w.type, (int) w.K, (int) w.N, T) == 0) {
+        const int rc = pm_launch_mmq_i8(w.type, w.d, xa, nullptr, y, (int) w.K, (int) w.N, T, bias, resid, q80 ? 0 : ((prepped || a.tab) ? 1 : 0), st);
+        if (rc == 0) { if (!q80) prepped = true; return 0; }
     }
     return gemv(w, nullptr, a, T, y, bias, resid, st);
 }
@@ -456,9 +458,8 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         const bool small_attn_ok = (size_t) (dh + hp.n_ctx) * 4 <= 150 * 1024;
         bool small_ok = !m->no_mmq && small_attn_ok;              // ... and unless one of the layer's large matrices has a type neither small-batch path serves
         for (int k : {PM355_T_WQ, PM355_T_WO, PM355_T_FFN_GATE, PM355_T_FFN_UP, PM355_T_FFN_DOWN}) {
-            // Q4_K / Q5_K / Q6_K: integer matrix cores (mmq_i8.hip). Q8_0 (Qwen2.5-72B's ffn_down: 29568 % 256 != 0, src/llama.cpp:19547): the
-            // multi-column mat-vec with Q8_0 activations = ggml_vec_dot_q8_0_q8_0's arithmetic, 8 columns per pass over the weights - slower than
-            // an MFMA pass would be, but the batch stays at mat-vec distance from the CPU instead of dropping the whole layer to the F16 GEMM
+            // Q4_K / Q5_K / Q6_K and (round 4) Q8_0 - Qwen2.5-72B's ffn_down: 29568 % 256 != 0, src/llama.cpp:19547 - on the integer matrix cores
+            // (mmq_i8.hip; Q8_0 with Q8_0 activations = ggml_vec_dot_q8_0_q8_0's arithmetic); a Q8_0 shape it does not serve falls back to the multi-column mat-vec
             const bool served = pm_mmq_i8_check(L.t[k].type, (int) L.t[k].K, (int) L.t[k].N, T < 1 ? 1 : (T > MMQ_MAX_TOKENS ? MMQ_MAX_TOKENS : T)) == 0;
             small_ok = small_ok && (served || L.t[k].type == PM_Q8_0);
         }

@@ -100,6 +100,9 @@ struct ActSrc {
     // sub-block s of super-block sb: lane (t, g) gets the 16 bytes k = 32 s + 16 g .. + 15 of token t (one coalesced kilobyte per wave and 32 tokens)
     __device__ __forceinline__ u32x4 ld_sub(int sb, int s) const { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int) xo, sb * 8192 + s * 1024, 0)); }
     __device__ __forceinline__ f16x8 ld_bs(int sb) const { return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, (int) bo, sb * 1024, 0)); }
+    // Q8_0 (32-value blocks): block blk of the operand-ordered values, and the four activation scales of tokens 8 q + 4 g .. + 3 (bo = 16 g)
+    __device__ __forceinline__ u32x4 ld_blk(int blk) const { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int) xo, blk * 1024, 0)); }
+    __device__ __forceinline__ f32x4 ld_d4(int blk, int q) const { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int) bo, blk * 128 + 32 * q, 0)); }
 };
 
 template <int TYPE> struct MT;
@@ -127,6 +130,7 @@ template <> struct MT<PM_Q4_K> {
         *(u32x4 *) (L + HD + (lane >> 1) * PITCH_H + (lane & 1) * 16) = b.h;
     }
     // sub-block s (32 weights) = the 16 bytes at 32 s + 16 g of the super-block
+    template <int NV>
     static __device__ __forceinline__ void issue_a(A & a, const ActSrc & x, int sb) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) a.q[s] = x.ld_sub(sb, s);
@@ -193,6 +197,7 @@ template <> struct MT<PM_Q5_K> {
             *(u32x4 *) (L + row * RP + c * 16) = b.c[i];
         }
     }
+    template <int NV>
     static __device__ __forceinline__ void issue_a(A & a, const ActSrc & x, int sb) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) a.q[s] = x.ld_sub(sb, s);
@@ -263,6 +268,7 @@ template <> struct MT<PM_Q6_K> {
         *(uint16_t *) (L + DD + lane * 2) = b.d;                     // [c = lane / 32][r = lane % 32]
     }
     // 16-weight group G = the 8 bytes at 16 G + 8 g of the super-block
+    template <int NV>
     static __device__ __forceinline__ void issue_a(A & a, const ActSrc & x, int sb) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) a.q[s] = x.ld_sub(sb, s);
@@ -326,15 +332,70 @@ template <> struct MT<PM_Q6_K> {
     }
 };
 
+// ---------------------------------------------------------------- Q8_0: row = qa[nb][16] | qb[nb][16] | d[nb] (f16), nb = K / 32 ------------
+// Weights and activations in 32-value blocks (ggml_vec_dot_q8_0_q8_0, ggml-quants.c:5518: sumf += sumi * d_w * d_a per block): one 32-k MFMA is one
+// block, its 32 x 32 integer tile is scaled by d_w (lane-local: the lane's own row) x d_a (the token of the result register). In this kernel's
+// terms a "super-block" is 128 weights = 4 blocks and a step 8 blocks - per row the same 128 + 128 + 16 bytes as a Q4_K step, so the tile loader
+// and its LDS image are Q4_K's. K need not be a multiple of 256 (Qwen2.5-72B's ffn_down, K = 29568, falls back to this type: src/llama.cpp:19447):
+// blocks past the row are clamped weight bytes against out-of-range (= zero) activations and scales.
+template <> struct MT<PM_Q8_0> {
+    static constexpr int QA = 0, QB = 32 * PITCH, HD = 64 * PITCH, WAVE_LDS = 64 * PITCH + 32 * PITCH_H;
+    struct B { u32x4 qa[4], qb[4], h; };
+    struct A { u32x4 q[4]; f32x4 da[4][2]; };
+    template <class RW>
+    static __device__ __forceinline__ void issue_b_part(B & b, const RW & rw, int nb /*blocks per row*/, int pr, int lane, int n) {
+        const uint32_t u = (uint32_t) min(8 * pr + (lane & 7), nb - 1);
+        b.qa[n] = ld_nt16(rw.at(n, u * 16u));
+        b.qb[n] = ld_nt16(rw.at(n, (uint32_t) nb * 16u + u * 16u));
+        if (n == 0) b.h = ld_c16(rw.at_h((uint32_t) nb * 32u + (uint32_t) pr * 16u));   // the step's 8 block scales (row padding keeps the last piece inside the row)
+    }
+    static __device__ __forceinline__ void stash(const B & b, uint8_t * L, int lane) {
+        const int rr = lane >> 3, c = lane & 7;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            *(u32x4 *) (L + QA + (rr + 8 * n) * PITCH + c * 16) = b.qa[n];
+            *(u32x4 *) (L + QB + (rr + 8 * n) * PITCH + c * 16) = b.qb[n];
+        }
+        if ((lane & 1) == 0) *(u32x4 *) (L + HD + (lane >> 1) * PITCH_H) = b.h;
+    }
+    template <int NV>
+    static __device__ __forceinline__ void issue_a(A & a, const ActSrc & x, int sb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a.q[j] = x.ld_blk(4 * sb + j);
+#pragma unroll
+            for (int q = 0; q < NV / 4; ++q) a.da[j][q] = x.ld_d4(4 * sb + j, q);
+        }
+    }
+    template <int NV, class F>
+    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float *, f32x16 & out, F && between) {
+        static_assert(NV <= 8, "Q8_0: up to 16 tokens per pass");
+        const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const u32x2 d4 = *(const u32x2 *) (L + HD + r * PITCH_H + sbi * 8);              // this row's four block scales (f16)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            between(j);
+            const u32x4 w = *(const u32x4 *) (L + (g ? QB : QA) + r * PITCH + (4 * sbi + j) * 16);
+            const uint32_t hb = (d4[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            const float dw = (hb & 0x7C00u) == 0x7C00u ? 0.0f : h2f((uint16_t) hb);       // (a block past the row: whatever the padding holds, times zero)
+            const i32x16 acc = mfma_i8x32(a.q[j], w, zero);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) out[v] = fmaf((float) acc[v], dw * a.da[j][v >> 2][v & 3], out[v]);
+        }
+    }
+};
+
 // ABL (measurement only, PM355_MMQ_ABL): 1 = no activation loads in the loop, 2 = no weight loads in the loop, 4 = no MFMA / VALU work
 template <int TYPE, int NV, int ABL = 0, bool MJ = false>      // NV result registers per lane in use: 4 (<= 8 tokens), 8 (<= 16), 16 (<= 32)
 __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     typedef MT<TYPE> M;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (a scalar: the K slice, the loop counters and the buffer loads' scalar offsets derive from it)
-    const int nsb = p.K / 256, npairs = (nsb + 1) >> 1;
+    constexpr bool Q80 = TYPE == PM_Q8_0;                         // 32-value blocks: "super-block" = 4 blocks, no scale table in LDS (scales travel with the operands)
+    const int nsb = Q80 ? (p.K + 127) / 128 : p.K / 256, npairs = (nsb + 1) >> 1;
+    const int nbw = Q80 ? p.K / 32 : nsb;                         // what the tile loader counts in: blocks of the row
     float * dTl = (float *) smem;                                 // activation scales [nsb + 1][32] (0 for token slots >= T; last row all 0)
-    uint8_t * stage = smem + (size_t) (nsb + 1) * 128;            // NWAVE x WAVE_LDS; afterwards the 32 KB reduction buffer
+    uint8_t * stage = smem + (Q80 ? 0 : (size_t) (nsb + 1) * 128);   // NWAVE x WAVE_LDS; afterwards the 32 KB reduction buffer
     const int G = (int) gridDim.x, w = (int) blockIdx.x;
     const int r0 = (int) ((long) p.N * w / G), r1 = (int) ((long) p.N * (w + 1) / G);      // (MJ: virtual rows over all jobs)
     const int nrg = (r1 - r0 + 31) >> 5;
@@ -351,10 +412,10 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     const int r = lane & 31, g = lane >> 5;
     const bool act = NV == 16 ? true : r < p.T;                                     // token slots >= T: operand bytes are don't-care (scale row 0, never stored)
     ActSrc xs;
-    xs.rx = __builtin_amdgcn_make_buffer_rsrc((void *) p.qT, 0, nsb * 8192, 0x00020000);
-    xs.rb = __builtin_amdgcn_make_buffer_rsrc((void *) p.bsT, 0, nsb * 1024 + 512, 0x00020000);      // (+ t_off slots of the last super-block: inside the table allocation)
+    xs.rx = __builtin_amdgcn_make_buffer_rsrc((void *) p.qT, 0, Q80 ? nbw * 1024 : nsb * 8192, 0x00020000);
+    xs.rb = __builtin_amdgcn_make_buffer_rsrc((void *) p.bsT, 0, Q80 ? nbw * 128 : nsb * 1024 + 512, 0x00020000);   // (+ t_off slots of the last super-block: inside the table allocation)
     xs.xo = act ? (uint32_t) ((32 * g + r + p.t_off) * 16) : 0x80000000u;
-    xs.bo = act ? (uint32_t) ((lane + p.t_off) * 16) : 0x80000000u;
+    xs.bo = Q80 ? (uint32_t) (16 * g + 4 * p.t_off) : act ? (uint32_t) ((lane + p.t_off) * 16) : 0x80000000u;   // (Q8_0: the scales of the RESULT tokens 8 q + 4 g .. + 3 - every lane)
     Rows<MJ> rw;
     typename M::B R;
     typename M::A A0 = {}, A1 = {};                              // (inactive token lanes keep these zeros)
@@ -363,7 +424,7 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     // (ffn_down Q6_K, 8 tokens: 41 us stream + 19 us compute + 12 fixed = 70). One part in front of every quarter of the first super-block's
     // products keeps both busy.
     auto issue_b_part = [&](int pr, int n) __attribute__((always_inline)) {
-        M::issue_b_part(R, rw, nsb, pr, lane, n);
+        M::issue_b_part(R, rw, nbw, pr, lane, n);
         if constexpr (TYPE == PM_Q6_K) if (n == 0) R.d = *(const PM_G uint16_t *) rw.at_d((uint32_t) nsb * 208u + (uint32_t) min(2 * pr + g, nsb - 1) * 2u);   // cached: 32 steps share the line
     };
     auto issue_b = [&](int pr) __attribute__((always_inline)) {
@@ -388,15 +449,17 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
             rw.rph = rowptr(rbase + (lane >> 1)); rw.rpd = rowptr(rbase + r);
         }
         issue_b(pb);
-        M::issue_a(A0, xs, 2 * pb);
-        if constexpr (ABL & 1) M::issue_a(A1, xs, 2 * pb);
+        M::template issue_a<NV>(A0, xs, 2 * pb);
+        if constexpr (ABL & 1) M::template issue_a<NV>(A1, xs, 2 * pb);
     };
     if (rgi < nrg && pb < pe) first(rgi);                         // ... including the staging of the scale table:
-    for (int i = tid; i < nsb * 32; i += BLOCK) {                 // (slots >= T masked here: a quantizer that writes the table itself fills rows < T only)
-        const int t = i & 31;
-        dTl[i] = t < p.T ? *((const PM_G float *) p.dT + (i + p.t_off)) : 0.0f;
+    if constexpr (!Q80) {
+        for (int i = tid; i < nsb * 32; i += BLOCK) {             // (slots >= T masked here: a quantizer that writes the table itself fills rows < T only)
+            const int t = i & 31;
+            dTl[i] = t < p.T ? *((const PM_G float *) p.dT + (i + p.t_off)) : 0.0f;
+        }
+        if (tid < 32) dTl[nsb * 32 + tid] = 0.0f;
     }
-    if (tid < 32) dTl[nsb * 32 + tid] = 0.0f;
     __syncthreads();
     for (int rg0 = 0; rg0 < nrg; rg0 += RGB) {
         const int rg = rg0 + rgi;
@@ -405,11 +468,11 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
             if (rg0 > 0) first(rg);
             for (int pr = pb; pr < pe; pr += pstep) {
                 M::stash(R, L, lane);                                  // waits for this step's weights only
-                const int sb0 = 2 * pr, sb1 = min(2 * pr + 1, nsb - 1);
+                const int sb0 = 2 * pr, sb1 = Q80 ? 2 * pr + 1 : min(2 * pr + 1, nsb - 1);   // (Q8_0: blocks past the row read as zeros - no clamp, no double count)
                 // Issue order is the design (VMEM returns in order): the compiler's schedulers must not sink the prefetches towards
                 // their uses - no conditional code in the step (an odd tail super-block is computed on clamped data with the all-zero
                 // scale row) and scheduling barriers around the issue points.
-                if constexpr (!(ABL & 1)) M::issue_a(A1, xs, sb1);
+                if constexpr (!(ABL & 1)) M::template issue_a<NV>(A1, xs, sb1);
                 const int prn = min(pr + pstep, pe - pstep);             // the wave's next pair (clamped: the last step re-loads its own)
                 __builtin_amdgcn_sched_barrier(0);
                 // (the 32-token Q6_K form has no registers for it - 404 B of spills, 88 -> 205 us: its tile still goes out in one burst)
@@ -421,7 +484,7 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
                 if constexpr (!(ABL & 4)) M::template compute<NV>(A0, L, 0, r, g, dTl + sb0 * 32, out, part);
                 else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A0.q[s_])); asm volatile("" :: "v"(A0.bs)); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane))); }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(ABL & 1)) M::issue_a(A0, xs, min(2 * prn, nsb - 1));
+                if constexpr (!(ABL & 1)) M::template issue_a<NV>(A0, xs, min(2 * prn, nsb - 1));
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(ABL & 4)) M::template compute<NV>(A1, L, 1, r, g, dTl + (2 * pr + 1 < nsb ? sb1 : nsb) * 32, out, [](int) {});
                 else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A1.q[s_])); asm volatile("" :: "v"(A1.bs)); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane + 1024))); }
@@ -475,25 +538,37 @@ __global__ __launch_bounds__(64) void mmq_prep_kernel(const uint8_t * xq, long x
     if (g == 0) dT[sb * 32 + t] = t < T ? ((const float *) (row + K))[sb] : 0.0f;
 }
 
+// Q8_0 activations (row-SoA: int8 qs[K] | f16 d[K / 32], quantize.hip) -> per block the values in A-operand order [blk][64 lanes][16 B] and the
+// scales as f32 [blk][32 token slots] (0 for slots >= T)
+__global__ __launch_bounds__(64) void mmq_prep_q80_kernel(const uint8_t * xq, long xq_stride, int K, int T, uint8_t * qT, float * dT) {
+    const int blk = (int) blockIdx.x, l = (int) threadIdx.x, t = l & 31, g = l >> 5;
+    const uint8_t * row = xq + (long) min(t, T - 1) * xq_stride;
+    if (t < T) *(u32x4 *) (qT + (size_t) blk * 1024 + l * 16) = *(const u32x4 *) (row + blk * 32 + 16 * g);
+    if (g == 0) dT[blk * 32 + t] = t < T ? h2f(((const uint16_t *) (row + K))[blk]) : 0.0f;
+}
+
 // per-device scratch (grown on demand, like mmq.hip's f16 activation copy): quantized activations of an f32 call + the two tables
 // scratch per (device, stream): the tables of a pass and the quantized copy of an f32 call are written and read in stream order, so two
 // streams of one device (two ggml backends, the engine next to the plug-in) must not share them
 struct Scr { hipStream_t st; uint8_t * p; size_t bytes; uint64_t use; int tab_K; };   // tab_K: the K the tables in p were last written for (0: none)
 constexpr int NSCR = 8;
 Scr g_scr[16][NSCR] = {};
+Scr g_scr80[16][NSCR] = {};             // Q8_0 launches: their own tables (never share bytes with the Q8_K tables a later launch may re-use)
 uint64_t g_tick = 0;
 std::mutex g_scr_mu;
 
 }  // namespace
 
 size_t pm_mmq_i8_lds_bytes(int type, int K) {
+    if (type == PM_Q8_0) return (size_t) NWAVE * MT<PM_Q8_0>::WAVE_LDS;
     const size_t w = type == PM_Q4_K ? MT<PM_Q4_K>::WAVE_LDS : type == PM_Q5_K ? MT<PM_Q5_K>::WAVE_LDS : MT<PM_Q6_K>::WAVE_LDS;
     return (size_t) (K / 256 + 1) * 128 + NWAVE * w;
 }
 
 // 0 when pm_launch_mmq_i8 serves this shape
 int pm_mmq_i8_check(int type, int K, int N, int T) {
-    if (type != PM_Q4_K && type != PM_Q5_K && type != PM_Q6_K) return -1;
+    if (type != PM_Q4_K && type != PM_Q5_K && type != PM_Q6_K && type != PM_Q8_0) return -1;
+    if (type == PM_Q8_0) return (T < 1 || T > 64 || K % 32 || K < 512 || N < 1) ? -2 : 0;
     if (T < 1 || T > 64 || K % 256 || K < 512 || N < 1) return -2;
     if (pm_mmq_i8_lds_bytes(type, K) > 150 * 1024) return -4;
     return 0;
@@ -542,6 +617,63 @@ void launch_prep(const Scr * sc, const void * xq, int K, int T, hipStream_t st) 
 }
 }  // namespace
 
+namespace {
+// Q8_0 weights x Q8_0 activations, passes of up to 16 tokens. xq: row-SoA Q8_0 rows (quantize.hip) or null and x_f32 is quantized first. Its tables
+// (operand-ordered values + f32 scales of both 32-slot halves, then a quantized copy of 64 f32 rows) are written by a prologue launch per call.
+int launch_q80(const void * W, const void * xq, const float * x_f32, float * Y, int K, int N, int T, const float * bias, const float * resid, hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
+    const int nb = K / 32;
+    const size_t xrow = pm_q80_row_bytes(K), qtab = (size_t) nb * 1024, dtab = (size_t) nb * 128;
+    const size_t need = 2 * (qtab + dtab) + (size_t) 64 * xrow + 512;
+    Scr * e = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_scr_mu);
+        Scr * lru = &g_scr80[dev][0];
+        for (Scr & c : g_scr80[dev]) {
+            if (c.p && c.st == st) { e = &c; break; }
+            if (!c.p) { if (lru->p) lru = &c; } else if (lru->p && c.use < lru->use) lru = &c;
+        }
+        if (!e || e->bytes < need) {
+            if (!e) e = lru;
+            if (e->p) { (void) hipDeviceSynchronize(); (void) hipFree(e->p); e->p = nullptr; e->bytes = 0; }
+            if (hipMalloc((void **) &e->p, need) != hipSuccess) { e->p = nullptr; return -3; }
+            e->st = st; e->bytes = need;
+        }
+        e->use = ++g_tick;
+    }
+    uint8_t * base = e->p;
+    if (!xq) {
+        uint8_t * q = base + 2 * (qtab + dtab) + 256;
+        pm_launch_quantize_q80(x_f32, q, K, T, st);
+        xq = q;
+    }
+    for (int t0 = 0, c = 0; t0 < T; t0 += 32, ++c)
+        hipLaunchKernelGGL(mmq_prep_q80_kernel, dim3(nb), dim3(64), 0, st, (const uint8_t *) xq + (size_t) t0 * xrow, (long) xrow, K, T - t0 < 32 ? T - t0 : 32,
+                           base + c * (qtab + dtab), (float *) (base + c * (qtab + dtab) + qtab));
+    const int cus = pm_device_cus();
+    const int grid = N / 32 >= cus ? cus : (N + 31) / 32;
+    const int rows = (N + grid - 1) / grid, nrg = (rows + 31) / 32;
+    const size_t lds = pm_mmq_i8_lds_bytes(PM_Q8_0, K);
+    for (int t0 = 0; t0 < T; t0 += 16) {
+        const int tn = T - t0 < 16 ? T - t0 : 16;
+        uint8_t * tab = base + (t0 / 32) * (qtab + dtab);
+        MmqP p = {};
+        p.t_off = t0 % 32;
+        p.W = (const uint8_t *) W; p.row_stride = (long) pm_weight_row_stride(PM_Q8_0, K); p.N = N; p.K = K; p.T = tn;
+        p.qT = tab; p.bsT = tab + qtab;                            // (bsT: here the f32 activation scales [blk][32])
+        p.y = Y + (size_t) t0 * N; p.y_stride = N; p.bias = bias; p.resid = resid ? resid + (size_t) t0 * N : nullptr;
+        p.rgb_log2 = nrg >= 8 ? 3 : nrg >= 3 ? 2 : nrg == 2 ? 1 : 0;
+        auto go = [&](auto kern) {
+            pm_allow_big_lds((const void *) kern, 150 * 1024);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, st, p);
+        };
+        if (tn <= 8) go(mmq_i8_kernel<PM_Q8_0, 4>); else go(mmq_i8_kernel<PM_Q8_0, 8>);
+    }
+    return 0;
+}
+}  // namespace
+
 // Where the tables for K live: pm_launch_quantize_q8k / pm_launch_rmsnorm_q8k write them as a second output (<= 64 rows), the mat-mul is
 // then launched with reuse_prep = 1 and no prologue launch at all.
 int pm_mmq_i8_tables(int K, hipStream_t st, pm_q8k_tables * out) {
@@ -573,6 +705,7 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
                      const float * bias, const float * resid, int reuse_prep, hipStream_t st) {
     const int rc = pm_mmq_i8_check(type, K, N, T);
     if (rc) return rc;
+    if (type == PM_Q8_0) return launch_q80(W, xq, x_f32, Y, K, N, T, bias, resid, st);      // (its tables are per call: reuse_prep does not apply)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
     const int nsb = K / 256;

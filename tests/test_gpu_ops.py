@@ -189,6 +189,32 @@ def test_gemv_epilogues_and_columns(P, oracle, t, C):
     assert np.allclose(y, oracle.silu_mul(want1, want2), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("T", [1, 3, 8, 9, 16, 17, 33, 64])
+def test_small_batch_matmul_q8_0_blocks(P, oracle, T):
+    """mmq_i8.hip, Q8_0 weights x Q8_0 activations (ggml_vec_dot_q8_0_q8_0: integer block sums times d_w * d_a, f32): one 32-k matrix instruction per
+    block. Shapes: K not a multiple of 128 or 256 (Qwen2.5-72B's ffn_down fallback, K = 29568 = 924 blocks: the last step holds 4 of 8 blocks), ragged rows,
+    several row groups; passes of 16 tokens over 32-slot tables (T = 17, 33: second half / second table)."""
+    rng = np.random.default_rng(4000 + T)
+    for K, N in ((4096, 70), (608, 600), (1184, 9000), (29568, 40)):
+        if (N == 9000 or K == 29568) and T not in (3, 17, 64): continue
+        b = rand_blocks(Q8_0, N, K, rng)
+        x = rng.normal(0, 1, (T, K)).astype(np.float32)
+        bias = rng.normal(0, 1, N).astype(np.float32)
+        resid = rng.normal(0, 1, (T, N)).astype(np.float32)
+        w = P.upload_weight(Q8_0, b, K, N)
+        want = oracle.mul_mat(Q8_0, b, K, N, x)
+        tol = dict(rtol=2e-5, atol=2e-5 * np.sqrt(K / 4096))
+        y = P.mul_mat_small(w, x=_dev(P, x)).cpu().numpy()
+        assert np.isfinite(y).all()
+        assert np.allclose(y, want, **tol), (K, N, np.abs(y - want).max())
+        xq = P.quantize_act(_dev(P, x), P.vec_dot_act_type(Q8_0))
+        y2 = P.mul_mat_small(w, xq=xq, n_tokens=T, bias=_dev(P, bias), resid=_dev(P, resid)).cpu().numpy()
+        assert np.allclose(y2, want + bias[None] + resid, **tol)
+        if T <= 8:
+            y1 = P.mul_mat_vec(w, xq=xq, ncols=T).cpu().numpy()
+            assert np.allclose(y, y1, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("T", [1, 2, 5, 8, 16, 17, 32, 33, 64])
 @pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K])
 def test_small_batch_matmul_on_integer_matrix_cores(P, oracle, t, T):

@@ -7,9 +7,10 @@ import prima_cpp_amd.engine as E  # noqa: E402
 
 Ts = [int(v) for v in sys.argv[1:]] or [1, 2, 3, 4, 8, 16]
 NL = 16
-hp = dict(E.LLAMA3_70B); hp["n_layer"] = NL
+QWEN = os.environ.get("PROBE_MODEL") == "qwen"                 # Qwen2.5-72B "Q6_K" file type: every matrix Q6_K, ffn_down (K = 29568) Q8_0
+hp = dict(E.QWEN25_72B if QWEN else E.LLAMA3_70B); hp["n_layer"] = NL
 win = E.Window(hp, lo=0, hi=NL, flags=0, n_ctx=1024)
-win.fill_synthetic(E.q4_k_m_types, seed=7)
+win.fill_synthetic(E.q6_k_types if QWEN else E.q4_k_m_types, seed=7)
 win.finalize(max_tokens=max(Ts), n_seq=1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for T in Ts:
