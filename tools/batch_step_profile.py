@@ -8,9 +8,10 @@ import prima_cpp_amd.engine as E  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-hp = dict(E.LLAMA3_70B); hp["n_layer"] = 8
+QWEN = os.environ.get("PROBE_MODEL") == "qwen"
+hp = dict(E.QWEN25_72B if QWEN else E.LLAMA3_70B); hp["n_layer"] = 8
 win = E.Window(hp, lo=0, hi=8, flags=0, n_ctx=1024)
-win.fill_synthetic(E.q4_k_m_types, seed=7)
+win.fill_synthetic(E.q6_k_types if QWEN else E.q4_k_m_types, seed=7)
 win.finalize(max_tokens=T, n_seq=1)
 x = torch.randn(T, hp["n_embd"], device="cuda") * 0.1
 for i in range(steps + 1):
