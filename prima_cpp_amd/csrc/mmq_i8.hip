@@ -137,7 +137,7 @@ template <> struct MT<PM_Q4_K> {
         a.bs = x.ld_bs(sb);
     }
     template <int NV, class F>
-    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out, F && between) {
+    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, int /*t_off*/, f32x16 & out, F && between) {
         const u32x4 hd = *(const u32x4 *) (L + HD + r * PITCH_H + sbi * 16);
         const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         i32x16 isum = zero;
@@ -204,7 +204,7 @@ template <> struct MT<PM_Q5_K> {
         a.bs = x.ld_bs(sb);
     }
     template <int NV, class F>
-    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out, F && between) {
+    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, int /*t_off*/, f32x16 & out, F && between) {
         const uint8_t * blk = L + r * RP + sbi * 176;
         const u32x4 hd = *(const u32x4 *) blk;
         const u32x4 qh = *(const u32x4 *) (blk + 16 + 16 * g);       // bit s of byte l: fifth bit of weight l of sub-block s (l = 16 g + i)
@@ -284,7 +284,7 @@ template <> struct MT<PM_Q6_K> {
         }
     }
     template <int NV, class F>
-    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, f32x16 & out, F && between) {
+    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float * yd_lds, int /*t_off*/, f32x16 & out, F && between) {
         const u32x4 s16 = *(const u32x4 *) (L + SC + r * PITCH_H + sbi * 16);
         const float d = h2f(*(const uint16_t *) (L + DD + (sbi * 32 + r) * 2));
         const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -339,9 +339,11 @@ template <> struct MT<PM_Q6_K> {
 // and its LDS image are Q4_K's. K need not be a multiple of 256 (Qwen2.5-72B's ffn_down, K = 29568, falls back to this type: src/llama.cpp:19447):
 // blocks past the row are clamped weight bytes against out-of-range (= zero) activations and scales.
 template <> struct MT<PM_Q8_0> {
-    static constexpr int QA = 0, QB = 32 * PITCH, HD = 64 * PITCH, WAVE_LDS = 64 * PITCH + 32 * PITCH_H;
-    struct B { u32x4 qa[4], qb[4], h; };
-    struct A { u32x4 q[4]; f32x4 da[4][2]; };
+    static constexpr int QA = 0, QB = 32 * PITCH, HD = 64 * PITCH, DS = HD + 32 * PITCH_H, WAVE_LDS = DS + 1024;
+    struct B { u32x4 qa[4], qb[4], h, ds; };
+    struct A { u32x4 q[4]; };
+    // (ds: the ACTIVATION scales of the step's 8 blocks, [block][32 token slots] f32 = 1 KiB per wave and step, travel with the weight tile into the wave's
+    //  LDS image - held in registers per result token they cost 32 VGPRs per operand set and the 16-token form spilled)
     template <class RW>
     static __device__ __forceinline__ void issue_b_part(B & b, const RW & rw, int nb /*blocks per row*/, int pr, int lane, int n) {
         const uint32_t u = (uint32_t) min(8 * pr + (lane & 7), nb - 1);
@@ -349,6 +351,7 @@ template <> struct MT<PM_Q8_0> {
         b.qb[n] = ld_nt16(rw.at(n, (uint32_t) nb * 16u + u * 16u));
         if (n == 0) b.h = ld_c16(rw.at_h((uint32_t) nb * 32u + (uint32_t) pr * 16u));   // the step's 8 block scales (row padding keeps the last piece inside the row)
     }
+    static __device__ __forceinline__ void issue_ds(B & b, const ActSrc & x, int pr) { b.ds = __builtin_bit_cast(u32x4, x.ld_d4(8 * pr, 0)); }   // (bo = 16 * lane; blocks past the row: 0)
     static __device__ __forceinline__ void stash(const B & b, uint8_t * L, int lane) {
         const int rr = lane >> 3, c = lane & 7;
 #pragma unroll
@@ -357,21 +360,18 @@ template <> struct MT<PM_Q8_0> {
             *(u32x4 *) (L + QB + (rr + 8 * n) * PITCH + c * 16) = b.qb[n];
         }
         if ((lane & 1) == 0) *(u32x4 *) (L + HD + (lane >> 1) * PITCH_H) = b.h;
+        *(u32x4 *) (L + DS + lane * 16) = b.ds;
     }
     template <int NV>
     static __device__ __forceinline__ void issue_a(A & a, const ActSrc & x, int sb) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a.q[j] = x.ld_blk(4 * sb + j);
-#pragma unroll
-            for (int q = 0; q < NV / 4; ++q) a.da[j][q] = x.ld_d4(4 * sb + j, q);
-        }
+        for (int j = 0; j < 4; ++j) a.q[j] = x.ld_blk(4 * sb + j);
     }
     template <int NV, class F>
-    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float *, f32x16 & out, F && between) {
-        static_assert(NV <= 8, "Q8_0: up to 16 tokens per pass");
+    static __device__ __forceinline__ void compute(const A & a, const uint8_t * L, int sbi, int r, int g, const float *, int t_off, f32x16 & out, F && between) {
         const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const u32x2 d4 = *(const u32x2 *) (L + HD + r * PITCH_H + sbi * 8);              // this row's four block scales (f16)
+        const float * ds = (const float *) (L + DS) + t_off;                             // (16-token passes over a 32-slot table start at slot t_off)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             between(j);
@@ -380,7 +380,11 @@ template <> struct MT<PM_Q8_0> {
             const float dw = (hb & 0x7C00u) == 0x7C00u ? 0.0f : h2f((uint16_t) hb);       // (a block past the row: whatever the padding holds, times zero)
             const i32x16 acc = mfma_i8x32(a.q[j], w, zero);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) out[v] = fmaf((float) acc[v], dw * a.da[j][v >> 2][v & 3], out[v]);
+            for (int q = 0; q < NV / 4; ++q) {
+                const f32x4 yd = *(const f32x4 *) (ds + (4 * sbi + j) * 32 + 8 * q + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) out[4 * q + i] = fmaf((float) acc[4 * q + i], dw * yd[i], out[4 * q + i]);
+            }
         }
     }
 };
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     xs.rx = __builtin_amdgcn_make_buffer_rsrc((void *) p.qT, 0, Q80 ? nbw * 1024 : nsb * 8192, 0x00020000);
     xs.rb = __builtin_amdgcn_make_buffer_rsrc((void *) p.bsT, 0, Q80 ? nbw * 128 : nsb * 1024 + 512, 0x00020000);   // (+ t_off slots of the last super-block: inside the table allocation)
     xs.xo = act ? (uint32_t) ((32 * g + r + p.t_off) * 16) : 0x80000000u;
-    xs.bo = Q80 ? (uint32_t) (16 * g + 4 * p.t_off) : act ? (uint32_t) ((lane + p.t_off) * 16) : 0x80000000u;   // (Q8_0: the scales of the RESULT tokens 8 q + 4 g .. + 3 - every lane)
+    xs.bo = Q80 ? (uint32_t) (16 * lane) : act ? (uint32_t) ((lane + p.t_off) * 16) : 0x80000000u;   // (Q8_0: lane l carries 16 bytes of the step's [8 blocks][32 slots] activation scales)
     Rows<MJ> rw;
     typename M::B R;
     typename M::A A0 = {}, A1 = {};                              // (inactive token lanes keep these zeros)
@@ -426,6 +430,7 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     auto issue_b_part = [&](int pr, int n) __attribute__((always_inline)) {
         M::issue_b_part(R, rw, nbw, pr, lane, n);
         if constexpr (TYPE == PM_Q6_K) if (n == 0) R.d = *(const PM_G uint16_t *) rw.at_d((uint32_t) nsb * 208u + (uint32_t) min(2 * pr + g, nsb - 1) * 2u);   // cached: 32 steps share the line
+        if constexpr (Q80) if (n == 0) M::issue_ds(R, xs, pr);
     };
     auto issue_b = [&](int pr) __attribute__((always_inline)) {
 #pragma unroll
@@ -481,12 +486,12 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
                 auto part = [&](int n) __attribute__((always_inline)) {   // next tile, part n: unconditional, pinned between the quarters
                     if constexpr (SPREAD && !(ABL & 2)) { __builtin_amdgcn_sched_barrier(0); issue_b_part(prn, n); __builtin_amdgcn_sched_barrier(0); }
                 };
-                if constexpr (!(ABL & 4)) M::template compute<NV>(A0, L, 0, r, g, dTl + sb0 * 32, out, part);
+                if constexpr (!(ABL & 4)) M::template compute<NV>(A0, L, 0, r, g, dTl + sb0 * 32, p.t_off, out, part);
                 else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A0.q[s_])); asm volatile("" :: "v"(A0.bs)); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane))); }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(ABL & 1)) M::template issue_a<NV>(A0, xs, min(2 * prn, nsb - 1));
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(ABL & 4)) M::template compute<NV>(A1, L, 1, r, g, dTl + (2 * pr + 1 < nsb ? sb1 : nsb) * 32, out, [](int) {});
+                if constexpr (!(ABL & 4)) M::template compute<NV>(A1, L, 1, r, g, dTl + (2 * pr + 1 < nsb ? sb1 : nsb) * 32, p.t_off, out, [](int) {});
                 else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A1.q[s_])); asm volatile("" :: "v"(A1.bs)); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane + 1024))); }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -655,8 +660,9 @@ int launch_q80(const void * W, const void * xq, const float * x_f32, float * Y, 
     const int grid = N / 32 >= cus ? cus : (N + 31) / 32;
     const int rows = (N + grid - 1) / grid, nrg = (rows + 31) / 32;
     const size_t lds = pm_mmq_i8_lds_bytes(PM_Q8_0, K);
-    for (int t0 = 0; t0 < T; t0 += 16) {
-        const int tn = T - t0 < 16 ? T - t0 : 16;
+    constexpr int tmax = 16;                         // (the 32-token form spills 236 B: 502 vs 422 us per Qwen2.5-72B layer at 32 tokens - two passes of 16 it is)
+    for (int t0 = 0; t0 < T; t0 += tmax) {
+        const int tn = T - t0 < tmax ? T - t0 : tmax;
         uint8_t * tab = base + (t0 / 32) * (qtab + dtab);
         MmqP p = {};
         p.t_off = t0 % 32;
