@@ -13,7 +13,7 @@ from prima_cpp_amd.lib import Q6_K  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 shape = sys.argv[2] if len(sys.argv) > 2 else "gate"
-K, N, t = {"gate": (8192, 28672, Q4_K), "down": (28672, 8192, Q6_K), "down4": (28672, 8192, Q4_K), "wo": (8192, 8192, Q4_K), "wk": (8192, 1024, Q4_K)}[shape]
+K, N, t = {"gate": (8192, 28672, Q4_K), "gate6": (8192, 28672, Q6_K), "down": (28672, 8192, Q6_K), "down4": (28672, 8192, Q4_K), "wo": (8192, 8192, Q4_K), "wk": (8192, 1024, Q4_K)}[shape]
 w = rand_weight(t, K, N)
 x = torch.randn(T, K, device="cuda") * 0.5
 iters = int(os.environ.get("PMC_ITERS", "10"))
