@@ -1,0 +1,105 @@
+"""Index arithmetic of the round-4 small-batch path, restated in Python and checked exhaustively (no GPU): the producers and consumers of the
+operand-ordered activation table agree on every byte, the K slices interleaved over the waves cover every step pair exactly once, the Q8_0
+tail never counts a block twice, and the multi-column mat-vec's idle slot repeats a column without storing it. The formulas are the ones in
+prima_cpp_amd/csrc/quantize.hip (q8k_block_from_regs), mmq_i8.hip (mmq_prep_kernel, mmq_prep_q80_kernel, ActSrc, MT<Q6_K>::operands, the
+kernel's pb / pe / pstep) and mmvq_device.h (stage_finish, write_out); tests/test_gpu_ops.py runs the kernels themselves against the oracle."""
+import itertools
+
+import pytest
+
+
+def table_offset_producer(row, blk, lane, i):
+    """quantize.hip: lane `lane` of the wave that quantizes 256-block `blk` of activation row `row` holds values 4 lane .. 4 lane + 3 (byte i)."""
+    return (row >> 5, blk * 8192 + (lane >> 3) * 1024 + ((((lane >> 2) & 1) * 32 + (row & 31)) * 16) + 4 * (lane & 3) + i)
+
+
+def table_offset_prep(t, sb, s, g, b):
+    """mmq_i8.hip mmq_prep_kernel: thread (t, g) copies the 16 bytes k = 32 s + 16 g .. of super-block sb."""
+    return sb * 8192 + s * 1024 + (g * 32 + t) * 16 + b
+
+
+def consumer_k(sb, s, t, g, b):
+    """ActSrc::ld_sub(sb, s) of operand lane (t, g), byte b: the k index the matrix instruction of sub-block s expects there (A operand of
+    v_mfma_i32_32x32x32_i8: lane (t, g) = 16 consecutive int8, k = 16 g .. 16 g + 15 of the 32-k slice)."""
+    return 256 * sb + 32 * s + 16 * g + b
+
+
+def test_quantizers_and_prologue_write_the_table_the_kernel_reads():
+    for row in (0, 5, 31, 32, 40, 63):
+        for blk in (0, 3):
+            seen = {}
+            for lane, i in itertools.product(range(64), range(4)):
+                k = 256 * blk + 4 * lane + i
+                pas, off = table_offset_producer(row, blk, lane, i)
+                assert pas == row // 32
+                seen[off] = k
+            assert len(seen) == 256                                   # a row's block lands on 256 distinct bytes ...
+            t = row & 31
+            for s, g, b in itertools.product(range(8), range(2), range(16)):
+                off = table_offset_prep(t, blk, s, g, b)              # ... the prologue kernel's and the quantizers' images coincide ...
+                assert seen[off] == consumer_k(blk, s, t, g, b)       # ... and every byte is the k the operand lane wants
+    # different rows of a pass never collide
+    offs = {table_offset_producer(r, 0, lane, i)[1] for r in range(32) for lane in range(64) for i in range(4)}
+    assert len(offs) == 32 * 256
+
+
+def test_q6k_halves_come_out_of_the_16_byte_loads_by_the_lane_swap():
+    """MT<Q6_K>::operands: lane (t, 0) / (t, 1) hold groups 2 s / 2 s + 1 whole; swapping the upper dwords of lane group 0 with the lower dwords of lane
+    group 1 (v_permlane32_swap vdst = LO, src0 = HI) leaves, per 16-k product over group G, bytes 8 g .. 8 g + 7 of G in lane (t, g)."""
+    for s in range(8):
+        held = {g: [32 * s + 16 * g + b for b in range(16)] for g in (0, 1)}          # k indices of the 16 loaded bytes, per lane group
+        lo = {g: held[g][:8] for g in (0, 1)}
+        hi = {g: held[g][8:] for g in (0, 1)}
+        # swap(vdst = LO, src0 = HI): vdst of group 1 <- src0 of group 0; src0 of group 0 <- vdst of group 1
+        vdst = {0: lo[0], 1: hi[0]}
+        src0 = {0: lo[1], 1: hi[1]}
+        for g in (0, 1):
+            even, odd = vdst[g], src0[g]
+            assert even == [16 * (2 * s) + 8 * g + b for b in range(8)]
+            assert odd == [16 * (2 * s + 1) + 8 * g + b for b in range(8)]
+
+
+@pytest.mark.parametrize("ks_log2", [0, 1, 2, 3])
+def test_interleaved_k_slices_cover_every_step_pair_once(ks_log2):
+    KS = 1 << ks_log2
+    for npairs in range(1, 70):
+        seen = []
+        for ks in range(KS):
+            pb, pstep = ks, KS
+            pe = ks if npairs <= ks else ks + ((npairs - ks + KS - 1) // KS) * KS
+            pr = pb
+            while pr < pe:
+                prn = min(pr + pstep, pe - pstep)                      # the prefetch target stays one of the wave's own pairs
+                assert pb <= prn < pe and (prn - pb) % KS == 0 and prn < npairs
+                seen.append(pr)
+                pr += pstep
+        assert sorted(seen) == list(range(npairs)), (npairs, KS)
+
+
+@pytest.mark.parametrize("K", [512, 608, 1184, 4096, 29568])
+def test_q8_0_blocks_are_counted_once_also_past_the_row(K):
+    """Q8_0: a step = 8 blocks, a "super-block" = 4; the second half of the last step may lie past the row - its blocks read as zeros (out-of-range
+    buffer loads), they are never a clamped copy of real ones."""
+    nb = K // 32
+    nsb = (K + 127) // 128
+    npairs = (nsb + 1) // 2
+    counted = []
+    for pr in range(npairs):
+        for sb in (2 * pr, 2 * pr + 1):                                # (sb1 is NOT clamped for this type)
+            for j in range(4):
+                blk = 4 * sb + j
+                in_range = blk * 1024 < nb * 1024 and blk * 128 < nb * 128     # the two buffer resources' bounds
+                if in_range:
+                    counted.append(blk)
+    assert sorted(counted) == list(range(nb))
+    # the table the prologue writes is the Q8_K one at block granularity: byte (blk, lane = 32 g + t, b) = k 32 blk + 16 g + b
+    for blk, g, b in itertools.product((0, nb - 1), (0, 1), (0, 15)):
+        assert table_offset_prep(7, blk // 8, blk % 8, g, b) == blk * 1024 + (g * 32 + 7) * 16 + b
+
+
+@pytest.mark.parametrize("ncols,slots", [(2, 2), (3, 4), (4, 4), (8, 8)])
+def test_idle_column_slot_repeats_a_column_and_is_not_stored(ncols, slots):
+    read = [min(c, ncols - 1) for c in range(slots)]                    # stage_finish: column index a slot is filled from
+    stored = [c for c in range(slots) if c < ncols]                     # write_out: slots that reach memory
+    assert read[:ncols] == list(range(ncols)) and all(r == ncols - 1 for r in read[ncols:])
+    assert stored == list(range(ncols))
