@@ -39,7 +39,8 @@ def test_small_batch_matmul_shape_check_is_host_logic():
         for K, N in ((8192, 28672), (28672, 8192), (8192, 1024), (4096, 128256), (768, 70)):
             for T in (1, 8, 16, 32, 33, 64):
                 assert chk(t, K, N, T) == 0, (t, K, N, T)
-    assert chk(Q8_0, 8192, 8192, 8) != 0            # Q8_0 weights pair with Q8_0 activations: not served
+    # Q8_0 weights pair with Q8_0 activations (32-value blocks): served since round 4, K a multiple of 32 (Qwen2.5-72B's ffn_down: 29568)
+    assert chk(Q8_0, 8192, 8192, 8) == 0 and chk(Q8_0, 29568, 8192, 33) == 0 and chk(Q8_0, 29568 + 16, 8192, 8) != 0 and chk(Q8_0, 256, 64, 8) != 0
     assert chk(Q4_K, 8192, 8192, 65) != 0 and chk(Q4_K, 8192, 8192, 0) != 0
     assert chk(Q4_K, 256, 8192, 8) != 0             # K < 512
     assert chk(Q4_K, 8192 + 64, 8192, 8) != 0       # K % 256
