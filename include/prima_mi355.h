@@ -294,9 +294,10 @@ PM355_API int pm355_attn_cached(const float * q_rot, void * k_cache, void * v_ca
                                 int max_keys, int flags, pm355_stream_t stream);
 /* The same (llm_build_kqv's MUL_MAT(k, q) -> SOFT_MAX_EXT -> MUL_MAT(v, kq), src/llama.cpp:10032-10095; CUDA plug-in: fattn-vec-f16.cuh) over LONG
  * contexts (cells attended >= the caller's split threshold): the GQA group's scores and the P.V product on the matrix
- * cores, keys split over workgroups, partials merged in the launch (attn_flash_mfma.hip). Transposed F16 V cache (no flash-attention
- * layout), head_dim 64 / 128, <= 16 query heads per KV head. scratch = pm355_attn_split_scratch_floats() floats, zeroed once by the
- * caller; max_cells sizes the grid (>= cells attended; 0 = n_ctx). flags: PM355_ATTN_MASK_F16 only. */
+ * cores, keys split over workgroups, partials merged in the launch (attn_flash_mfma.hip). F16 caches: transposed V (default graphs) or, with
+ * PM355_ATTN_V_ROWMAJOR, the row-major V of the flash-attention graphs (the kernel transposes a wave's tile through LDS: ds_read_b64_tr_b16);
+ * head_dim 64 / 128, <= 16 query heads per KV head. scratch = pm355_attn_split_scratch_floats() floats, zeroed once by the
+ * caller; max_cells sizes the grid (>= cells attended; 0 = n_ctx). flags: PM355_ATTN_MASK_F16 | PM355_ATTN_V_ROWMAJOR. */
 PM355_API int pm355_attn_cached_long(const float * q_rot, void * k_cache, void * v_cache, const int32_t * d_pos, const int32_t * d_cell_nkv,
                                      const void * mask, float * out, float * scratch, int n_head, int n_head_kv, int head_dim, int n_ctx,
                                      float kq_scale, int max_cells, int flags, pm355_stream_t stream);

@@ -55,12 +55,24 @@ __device__ __forceinline__ void st_coh4(float * p, float4v v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
 }
 
-template <int DH>
+// VROW: the V cache is ROW-major ([cell][n_head_kv * head_dim], the --flash-attn layout of the reference: llm_build_kv, src/llama.cpp:9705) - the 8 keys
+// of an operand's k-slots are 8 cache rows apart. A wave then fetches its 32-key tile as whole rows (coalesced 16-byte pieces, same register count as the
+// transposed operands), parks it in a private LDS image of DH / 16 sub-tiles [32 keys][16 dims] and reads the operands back with the transposing LDS read
+// (ds_read_b64_tr_b16: lane c of a 16-lane group receives column c of the [4 keys][16 dims] block whose rows the group's lanes address - checked on the hardware by
+// tools/tr16_probe.py). Keys 8 g .. 8 g + 3 of lane group g sit in block g, keys 8 g + 4 .. + 7 in block 4 + g: each of the two reads of an operand covers 512
+// contiguous bytes; sub-tiles are 32 bytes apart from a multiple of 1 KiB so that the 16 lanes that write one key's row hit different banks.
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) short4v * lds_s4;
+template <int DH, bool VROW>
 __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
     constexpr int KK = DH / 32;                      // k-steps of the S^T product
     constexpr int DT = DH / 16;                      // 16-row tiles of O^T
+    constexpr int SUB = 32 * 32 + 32, VW = DT * SUB; // bytes of a V sub-tile image / of a wave's staging area (VROW)
+    constexpr int OBYTES = 4 * RMAXM * DH * 4, SBYTES = VROW ? 4 * VW : 0;
     __shared__ float wm[4][16], wl[4][16];
-    __shared__ __attribute__((aligned(16))) float ored[4][RMAXM][DH];    // the four waves' O^T columns, scaled to the workgroup maximum
+    // the four waves' O^T columns, scaled to the workgroup maximum (after the key loop) / VROW: the waves' V staging images (during it)
+    __shared__ __attribute__((aligned(16))) uint8_t obuf[OBYTES > SBYTES ? OBYTES : SBYTES];
+    float (* ored)[RMAXM][DH] = (float (*)[RMAXM][DH]) obuf;
     __shared__ float msc[RMAXM][64], lsc[RMAXM][64]; // merge of the spans (<= 64 per KV head)
     __shared__ int last_flag;
     unsigned long long tsv[6] = {PM_TS_NOW(), 0, 0, 0, 0, 0};
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
     const int k_begin = c * p.span;
     const long krow = (long) p.Hkv * DH;
     const uint16_t * kc = p.kc + (long) seq * p.seq_stride + (long) g * DH;
-    const uint16_t * vc = p.vc + (long) seq * p.seq_stride + (long) g * DH * p.n_ctx;
+    const uint16_t * vc = p.vc + (long) seq * p.seq_stride + (VROW ? (long) g * DH : (long) g * DH * p.n_ctx);
     // Everything below up to the first use of n_kv is issued BEFORE the position arrives (addresses are clamped into the cache): the
     // scalar round trip for the position overlaps the first tile's loads instead of preceding them.
     // Q^T as B operand: lane (col = head, lg) holds q[head][32 kk + 8 lg .. +8] (already rotated and F16-rounded by the QKV epilogue)
@@ -98,9 +110,19 @@ __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) ka[t][kk] = *(const half8 *) (kr + 32 * kk);
         }
-        const uint16_t * vr = vc + (long) col * p.n_ctx + min(kt + 8 * lg, p.n_ctx - 8);
+        if constexpr (!VROW) {
+            const uint16_t * vr = vc + (long) col * p.n_ctx + min(kt + 8 * lg, p.n_ctx - 8);
 #pragma unroll
-        for (int d = 0; d < DT; ++d) va[d] = *(const half8 *) (vr + (long) 16 * d * p.n_ctx);
+            for (int d = 0; d < DT; ++d) va[d] = *(const half8 *) (vr + (long) 16 * d * p.n_ctx);
+        } else {
+            // raw rows: load n covers 64 / CPK keys, lane l = (key l / CPK, 16-byte piece l % CPK of the head's DH halves)
+            constexpr int CPK = DH / 8;
+#pragma unroll
+            for (int n = 0; n < DT; ++n) {
+                const int key = n * (64 / CPK) + lane / CPK;
+                va[n] = *(const half8 *) (vc + (long) min(kt + key, p.n_ctx - 1) * krow + 8 * (lane % CPK));
+            }
+        }
     };
     constexpr int KSTEP = 128;                        // (a wave's tiles interleave with the other waves': contiguous quarter spans measured 3 % slower)
     int kt = k_begin + 32 * wave;
@@ -148,8 +170,28 @@ __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
             }
             pf = half8{(_Float16) e[0], (_Float16) e[1], (_Float16) e[2], (_Float16) e[3], (_Float16) e[4], (_Float16) e[5], (_Float16) e[6], (_Float16) e[7]};
         }
+        if constexpr (!VROW) {
 #pragma unroll
-        for (int d = 0; d < DT; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vc_[d], pf, o[d], 0, 0, 0);
+            for (int d = 0; d < DT; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vc_[d], pf, o[d], 0, 0, 0);
+        } else {
+            constexpr int CPK = DH / 8;
+            uint8_t * wb = obuf + wave * VW;
+#pragma unroll
+            for (int n = 0; n < DT; ++n) {
+                const int kl = n * (64 / CPK) + lane / CPK, ch = lane % CPK;                 // key inside the tile, 16-byte piece of its row
+                const int pos = ((kl & 4) ? 16 + 4 * (kl >> 3) : 4 * (kl >> 3)) + (kl & 3);    // row of the sub-tile image: block (k / 8 or 4 + k / 8), row k % 4
+                *(half8 *) (wb + (ch >> 1) * SUB + pos * 32 + (ch & 1) * 16) = vc_[n];
+            }
+            const uint8_t * rb = wb + (4 * lg + (col >> 2)) * 32 + (col & 3) * 8;             // block lg, the lane's 4 halves of it
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4) (rb + d * SUB));          // keys 8 lg .. + 3 of dim 16 d + col
+                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4) (rb + d * SUB + 512));    // keys 8 lg + 4 .. + 7
+                typedef short short8v __attribute__((ext_vector_type(8)));
+                const short8v v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, v8), pf, o[d], 0, 0, 0);
+            }
+        }
     };
     for (; kt < k_end; kt += 2 * KSTEP) {
         tile(kt, ka0, va0, ka1, va1);
@@ -309,7 +351,7 @@ int pm_attn_flash_cached_ok(int H, int Hkv, int dh, int n_ctx) {
 
 int pm_launch_attn_flash_cached(const float * q, void * kc, void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride, float * out,
                                 float * scratch, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st, const int32_t * dyn,
-                                const void * mask, int mask_f16, int max_cells) {
+                                const void * mask, int mask_f16, int max_cells, int v_rowmajor) {
     if (!scratch || pm_attn_flash_cached_ok(H, Hkv, dh, n_ctx)) return -1;
     if (!pos0) pos0 = dyn;
     if (!pos0) return -1;
@@ -327,7 +369,12 @@ int pm_launch_attn_flash_cached(const float * q, void * kc, void * vc, const int
     p.H = H; p.Hkv = Hkv; p.n_ctx = n_ctx; p.nspan = nspan_max; p.span = span; p.scale = scale;
     p.dyn = dyn; p.mask = mask; p.mask_f16 = mask_f16; p.ts = pm_ts_next_slot();
     const dim3 grid(Hkv, (cells + span - 1) / span);
-    if (dh == 128) hipLaunchKernelGGL(attn_flash_mfma_kernel<128>, grid, dim3(256), 0, st, p);
-    else           hipLaunchKernelGGL(attn_flash_mfma_kernel<64>, grid, dim3(256), 0, st, p);
+    if (v_rowmajor) {
+        if (dh == 128) hipLaunchKernelGGL((attn_flash_mfma_kernel<128, true>), grid, dim3(256), 0, st, p);
+        else           hipLaunchKernelGGL((attn_flash_mfma_kernel<64, true>), grid, dim3(256), 0, st, p);
+    } else {
+        if (dh == 128) hipLaunchKernelGGL((attn_flash_mfma_kernel<128, false>), grid, dim3(256), 0, st, p);
+        else           hipLaunchKernelGGL((attn_flash_mfma_kernel<64, false>), grid, dim3(256), 0, st, p);
+    }
     return 0;
 }

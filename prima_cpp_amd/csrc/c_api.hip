@@ -362,9 +362,9 @@ int pm355_attn_cached(const float * q_rot, void * kc, void * vc, const int32_t *
 int pm355_attn_cached_long(const float * q_rot, void * kc, void * vc, const int32_t * d_pos, const int32_t * d_cell_nkv, const void * mask,
                            float * out, float * scratch, int H, int Hkv, int dh, int n_ctx, float kq_scale, int max_cells, int flags, pm355_stream_t st) {
     if (!q_rot || !kc || !vc || !out || !scratch || (!d_pos && !d_cell_nkv)) return fail(PM355_E_SHAPE, "attn_cached_long: null pointer");
-    if (flags & ~PM355_ATTN_MASK_F16) return fail(PM355_E_UNSUPPORTED, "attn_cached_long: transposed F16 V cache only");
+    if (flags & ~(PM355_ATTN_MASK_F16 | PM355_ATTN_V_ROWMAJOR)) return fail(PM355_E_UNSUPPORTED, "attn_cached_long: F16 K / V caches only");
     if (pm_launch_attn_flash_cached(q_rot, kc, vc, d_pos, nullptr, 0, out, scratch, H, Hkv, dh, n_ctx, kq_scale, S(st), d_cell_nkv, mask,
-                                    flags & PM355_ATTN_MASK_F16, max_cells))
+                                    flags & PM355_ATTN_MASK_F16, max_cells, (flags & PM355_ATTN_V_ROWMAJOR) ? 1 : 0))
         return fail(PM355_E_UNSUPPORTED, "attn_cached_long: head_dim must be 64/128, <= 16 query heads per KV head, n_ctx % 8 == 0");
     HIP_TRY(hipGetLastError());
     return 0;

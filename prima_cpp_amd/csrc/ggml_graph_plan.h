@@ -448,7 +448,7 @@ private:
         // the same cos / sin table as the layers planned before (same parameters, positions and frequency factors)
         pm355_rope_params rp_; rope_params_of(rq, rp_);
         const float * ff_ = rq->src[2] ? (const float *) rq->src[2]->data : nullptr;
-        bool epi = c_.rope_tab && one_launch && !q8 && (!split || (!fa && c_.attn_mfma && pm355_attn_cached_long_check((int) H, (int) Hkv, (int) dh, (int) n_ctx) == 0)) && (rp_.mode == 0 || rp_.mode == 2) && rp_.n_dims <= 256 &&
+        bool epi = c_.rope_tab && one_launch && !q8 && (!split || (c_.attn_mfma && pm355_attn_cached_long_check((int) H, (int) Hkv, (int) dh, (int) n_ctx) == 0)) && (rp_.mode == 0 || rp_.mode == 2) && rp_.n_dims <= 256 &&
                    pm355_mul_mat_vec_qkv_check_ex(jobs, E, (int) Hkv, (int) dh, rp_.n_dims, rp_.mode & 2) == 0;
         if (epi && tab_set_) {
             const bool same_ff = ff_ == tab_ff_ || (ff_ && tab_ff_ && c_.same_bytes && c_.same_bytes(c_.user, ff_, tab_ff_, (size_t) rp_.n_dims / 2 * 4));

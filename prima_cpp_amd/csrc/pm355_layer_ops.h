@@ -32,7 +32,7 @@ size_t pm_attn_flash_scratch_floats(int H, int Hkv, int dh, int n_ctx);
 int  pm_attn_flash_cached_ok(int H, int Hkv, int dh, int n_ctx);      // 0: served by the matrix-core long-context kernel
 int  pm_launch_attn_flash_cached(const float * q_rot, void * kc, void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride, float * out,
                                  float * scratch, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st, const int32_t * dyn,
-                                 const void * mask, int mask_f16, int max_cells);
+                                 const void * mask, int mask_f16, int max_cells, int v_rowmajor = 0);
 int  pm_launch_attn_flash(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos0, const int32_t * seq,
                           long seq_stride, const float * freq_factors, float * out, float * scratch, int H, int Hkv, int dh, int n_ctx,
                           float scale, const pm_rope_cfg & c, hipStream_t st, const int32_t * dyn = nullptr, const void * mask = nullptr,

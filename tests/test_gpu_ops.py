@@ -704,6 +704,49 @@ def _attn_refs(kc, vt, q, n_kv, H, Hkv, dh, scale):
     return ref64, ref16
 
 
+@pytest.mark.parametrize("dh,H,Hkv", [(128, 64, 8), (64, 12, 4)])
+@pytest.mark.parametrize("n_kv", [700, 8192])
+def test_long_context_attention_on_a_row_major_v_cache(P, n_kv, dh, H, Hkv):
+    """--flash-attn layout (V cache [cell][n_head_kv * head_dim], F16 mask; llm_build_kv, src/llama.cpp:9705, :10075-10095) on the matrix-core kernel: the wave's
+    V rows go through its LDS image and come back as operands through the transposing LDS read. Same cache VALUES as the transposed layout -> the two layouts'
+    results must be bitwise equal; and both against float64. A sparse F16 mask (-inf on every 7th cell) checks the masked path on the way."""
+    torch = P.torch
+    ATTN_V_ROWMAJOR, ATTN_MASK_F16 = 1, 2                                    # include/prima_mi355.h: PM355_ATTN_V_ROWMAJOR, PM355_ATTN_MASK_F16
+    rng = np.random.default_rng(7000 + n_kv + dh)
+    n_ctx = 8192 + 256
+    Nkv = Hkv * dh
+    kc = rng.normal(0, 1, (n_ctx, Nkv)).astype(np.float16)
+    vt = rng.normal(0, 1, (Nkv, n_ctx)).astype(np.float16)
+    vrow = np.ascontiguousarray(vt.T)                                        # [cell][Hkv * dh]
+    kcd = torch.from_numpy(kc.view(np.int16)).cuda().reshape(-1)
+    vtd = torch.from_numpy(vt.view(np.int16)).cuda().reshape(-1)
+    vrd = torch.from_numpy(vrow.view(np.int16)).cuda().reshape(-1)
+    scale = 1.0 / np.sqrt(dh)
+    q = (rng.normal(0, 1, (H, dh)) * 1.5).astype(np.float16).astype(np.float32)
+    qd = torch.from_numpy(q.reshape(1, -1)).cuda()
+    pd = torch.tensor([n_kv - 1], dtype=torch.int32, device="cuda")
+    mnp = np.zeros(n_ctx, dtype=np.float16); mnp[::7] = -np.inf
+    md = torch.from_numpy(mnp.view(np.int16)).cuda()
+    cells = 1024
+    while cells < n_kv: cells *= 2
+    cells = min(cells, n_ctx)
+    for mask, flags in ((None, 0), (md, ATTN_MASK_F16)):
+        s_t, s_r = P.attn_split_scratch(H, dh, n_ctx), P.attn_split_scratch(H, dh, n_ctx)
+        out_t = P.attn_cached(qd, kcd, vtd, pd, H, Hkv, dh, n_ctx, scale, mask=mask, max_keys=cells, flags=flags, scratch=s_t).cpu().numpy().reshape(H, dh)
+        out_r = P.attn_cached(qd, kcd, vrd, pd, H, Hkv, dh, n_ctx, scale, mask=mask, max_keys=cells, flags=flags | ATTN_V_ROWMAJOR, scratch=s_r).cpu().numpy().reshape(H, dh)
+        assert np.isfinite(out_r).all()
+        assert np.array_equal(out_t, out_r), np.abs(out_t - out_r).max()
+        R = H // Hkv
+        for h in range(H):
+            g = h // R
+            Kh = kc[:n_kv, g * dh:(g + 1) * dh].astype(np.float64)
+            Vh = vt[g * dh:(g + 1) * dh, :n_kv].astype(np.float64)
+            sc = Kh @ q[h].astype(np.float64) * scale + (mnp[:n_kv].astype(np.float64) if mask is not None else 0.0)
+            pr = np.exp(sc - sc.max()); pr /= pr.sum()
+            ref = Vh @ pr
+            assert np.abs(out_r[h] - ref).max() / max(1e-3, np.abs(ref).max()) < 2e-3, (n_kv, h)
+
+
 @pytest.mark.parametrize("n_kv", [8192, 32700])
 def test_long_context_attention_at_the_70b_head_shape(P, n_kv):
     """The shape the long-context numbers are quoted on - 64 query heads, 8 KV heads, head_dim 128, 8k and 32.7k cells (grid = 8 x 32 spans: every

@@ -130,16 +130,17 @@ def test_round3_attention_block_rope_in_the_qkv_epilogue(fa, tmp_path):
 
 def test_round3_long_context_attention_lowers_to_the_matrix_core_kernel(tmp_path):
     """Beyond the split threshold (640 cells attended) the round-3 form keeps its QKV epilogue and the attention step becomes the
-    matrix-core kernel over cached cells ("cached-split"); with --flash-attn (row-major V cache) the round-2 flash-decoding form stays."""
+    matrix-core kernel over cached cells ("cached-split") - since round 4 also with --flash-attn (row-major V cache: the kernel's transposing LDS
+    read); GGML_MI355_ATTN_MFMA=0 keeps the round-2 flash-decoding form for both."""
     from _bind import Ref, best_ref_flavour
     import _fixtures8d as F
     ref = Ref(best_ref_flavour())
     path = str(tmp_path / "m.gguf")
     F.write_model(path, ref, n_layer=2, n_embd=1024, n_head=8, n_head_kv=4, n_ff=1024, n_vocab=512, tag="planlc")
     prompt = [int(t) for t in F.prompt_tokens(512, 700)]
-    for fa, want, never in ((False, "cached-split", " split mask"), (True, " split mask", "cached-split")):
+    for fa, mfma, want, never in ((False, "1", "cached-split", " split mask"), (True, "1", "cached-split", " split mask"), (True, "0", " split mask", "cached-split")):
         _, _, st = run_llama_driver(path, prompt, 3, ngl=99, n_ctx=1024, threads=1, extra_args=["--keep-out-in-cuda"] + (["-fa"] if fa else []),
-                                    env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1"}, flavour="avx2", timeout=300)
+                                    env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1", "GGML_MI355_ATTN_MFMA": mfma}, flavour="avx2", timeout=300)
         segs = [g for g in st["stderr"].split("ggml-mi355 plan:") if "single_token=1" in g and "attention H=8" in g]
         assert segs, st["stderr"][-3000:]
         body = segs[-1]

@@ -17,6 +17,7 @@ extern "C" {
 /* streams `bytes` from HBM exactly once with the mat-vec's access pattern (one 1024-thread workgroup per CU x wg_per_cu, every wave
  * reads its own contiguous span with `unroll` (4 or 8) 16-byte non-temporal loads in flight per lane); `sink` = 4 writable bytes */
 __attribute__((visibility("default"))) int pm355_probe_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, void * stream);
+__attribute__((visibility("default"))) int pm355_probe_tr16(const uint16_t * in, uint16_t * out, void * stream);    /* ds_read_b64_tr_b16 semantics (tools/tr16_probe.py) */
 /* strided-chunk read (probe.hip): n_wg workgroups of 4 waves; see tools/access_pattern_probe.py */
 __attribute__((visibility("default"))) int pm355_probe_chunk_read(const void * src, int n_wg, int nx, int64_t wgx_stride, int64_t wgy_stride, int64_t wave_stride,
                        int64_t outer_stride, int64_t inner_stride, int64_t piece_stride, int chunk, int n_outer, void * sink, void * stream);

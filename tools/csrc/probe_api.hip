@@ -3,6 +3,18 @@
 
 static inline hipStream_t S(void * s) { return (hipStream_t) s; }
 
+typedef short pm_short4v __attribute__((ext_vector_type(4)));
+__global__ void pm_probe_tr16_kernel(const uint16_t * in, uint16_t * out) {
+    __shared__ __attribute__((aligned(16))) uint16_t t[256];
+    const int l = threadIdx.x;
+    for (int e = 0; e < 4; ++e) t[l * 4 + e] = in[l * 4 + e];
+    __syncthreads();
+    const int i = l & 15, g = l >> 4;
+    typedef __attribute__((address_space(3))) pm_short4v * lp;
+    const pm_short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp) (t + g * 64 + (i / 4) * 16 + 4 * (i % 4)));
+    for (int e = 0; e < 4; ++e) out[l * 4 + e] = (uint16_t) v[e];
+}
+
 extern "C" {
 
 int pm355_probe_stream_read(const void * src, size_t bytes, int wg_per_cu, int unroll, void * sink, void * st) {
@@ -42,5 +54,12 @@ int pm355_probe_engine(const void * w, int64_t region_stride, int n_regions, int
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+
+// ds_read_b64_tr_b16 semantics check (tools/tr16_probe.py): every 16-lane group holds a [4][16] block of halves; lane i supplies the address of the 4
+// contiguous halves (row i / 4, columns 4 (i % 4) ..); out[lane][e] = what the instruction returns
+int pm355_probe_tr16(const uint16_t * in, uint16_t * out, void * st) {
+    hipLaunchKernelGGL(pm_probe_tr16_kernel, dim3(1), dim3(64), 0, S(st), in, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 } // extern "C"
