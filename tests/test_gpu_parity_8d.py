@@ -169,7 +169,7 @@ def test_peaked_fixture_greedy_tokens_identical(gpu, files, size, mode):
     assert _nmse(lg, ls) < max(1e-6, 3 * nm_ref) * (10 if mode == "plugin-fa" else 1), (_nmse(lg, ls), nm_ref)
 
 
-@pytest.mark.parametrize("mode", ["plugin", "engine", "plugin-i8", "engine-i8"])
+@pytest.mark.parametrize("mode", ["plugin", "plugin-fa", "engine", "plugin-i8", "engine-i8"])
 def test_peaked_fixture_long_context_tokens_identical(gpu, files, mode, monkeypatch):
     """The same equality beyond the long-context threshold (640 cells): a 700-token prompt, then 24 greedy tokens whose attention runs on
     the matrix-core kernel over cached cells (attn_flash_mfma.hip: rope + KV store in the QKV epilogue, keys split over workgroups,
@@ -194,7 +194,8 @@ def test_peaked_fixture_long_context_tokens_identical(gpu, files, mode, monkeypa
         env = {"GGML_MI355_DEBUG_PLAN": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1"}
         if i8:
             env["GGML_MI355_PROMPT_I8"] = "1"
-        tg, lg, st = run_llama_driver(path, prompt, n_gen, ngl=99, n_ctx=n_ctx, threads=_threads(), timeout=1800, extra_args=GPU_ARGS, env=env)
+        # (plugin-fa: --flash-attn graphs - row-major V cache, F16 mask - on the same matrix-core kernel since round 4)
+        tg, lg, st = run_llama_driver(path, prompt, n_gen, ngl=99, n_ctx=n_ctx, threads=_threads(), timeout=1800, extra_args=GPU_ARGS + (["-fa"] if mode == "plugin-fa" else []), env=env)
         assert "cached-split" in st["stderr"], st["stderr"][-2000:]
     print(f"\n[8d small peaked, 700-token prompt, {mode}] tokens {(tg == ts).sum()}/{n_gen} identical to the reference CPU; logits NMSE {_nmse(lg, ls):.2e}")
     assert tg.tolist() == ts.tolist()
