@@ -103,3 +103,33 @@ def test_idle_column_slot_repeats_a_column_and_is_not_stored(ncols, slots):
     stored = [c for c in range(slots) if c < ncols]                     # write_out: slots that reach memory
     assert read[:ncols] == list(range(ncols)) and all(r == ncols - 1 for r in read[ncols:])
     assert stored == list(range(ncols))
+
+
+@pytest.mark.parametrize("dh", [64, 128])
+def test_row_major_v_image_feeds_the_transposing_read(dh):
+    """attn_flash_mfma.hip, VROW: a wave writes its 32-key tile of row-major V into DH / 16 sub-tiles [32 rows][16 dims] (row = permuted key) and reads operand
+    d of lane (col, lg) with two ds_read_b64_tr_b16 (lane i of a 16-lane group addresses row i / 4, columns 4 (i % 4) .. of a [4][16] block and RECEIVES column i,
+    rows 0..3 - tools/tr16_probe.py). Modelled here: every (key, dim) is written once, and the operand comes out as keys 8 lg .. 8 lg + 7 of dim 16 d + col."""
+    SUB, CPK, DT = 32 * 32 + 32, dh // 8, dh // 16
+    image = {}
+    for n in range(DT):                                               # the writer: load n, lane -> (key, 16-byte piece)
+        for lane in range(64):
+            kl, ch = n * (64 // CPK) + lane // CPK, lane % CPK
+            pos = (16 + 4 * (kl >> 3) if kl & 4 else 4 * (kl >> 3)) + (kl & 3)
+            base = (ch >> 1) * SUB + pos * 32 + (ch & 1) * 16
+            for b in range(8):                                        # 8 halves of the piece: dims 8 ch .. 8 ch + 7
+                assert base + 2 * b not in image
+                image[base + 2 * b] = (kl, 8 * ch + b)
+    assert len(image) == 32 * dh and sorted(k for k, _ in image.values()) == sorted(list(range(32)) * dh)
+    for lg in range(4):
+        for d in range(DT):
+            for half, off in ((0, 0), (1, 512)):
+                # addresses the 16 lanes of group lg supply, and the [4][16] block they describe
+                block = {}
+                for i in range(16):
+                    a = d * SUB + (4 * lg + (i >> 2)) * 32 + (i & 3) * 8 + off
+                    for e in range(4):
+                        block[(i >> 2, 4 * (i & 3) + e)] = image[a + 2 * e]
+                for col in range(16):                                 # lane `col` receives column col, rows 0..3
+                    got = [block[(r, col)] for r in range(4)]
+                    assert got == [(8 * lg + 4 * half + r, 16 * d + col) for r in range(4)], (lg, d, half, col, got)
