@@ -172,7 +172,7 @@ PM355_API int pm355_mul_mat_q_small(int type, const void * W, int64_t K, int64_t
                                     float * y, const float * bias, const float * resid, pm355_stream_t stream);
 PM355_API int pm355_mul_mat_q_small_check(int type, int64_t K, int64_t N, int64_t n_tokens);
 /* 2 or 3 matrices of ONE type and K that share the activations (wq | wk | wv, ffn_gate | ffn_up of build_llama, src/llama.cpp:11085-11160) in
- * one launch, n_tokens <= 32, xq = rows quantized by pm355_quantize_q8_K; y[j]: [n_tokens][N[j]]; bias[j] may be NULL (bias may be NULL). */
+ * one launch per 32 tokens, n_tokens <= 64, xq = rows quantized by pm355_quantize_q8_K; y[j]: [n_tokens][N[j]]; bias[j] may be NULL (bias may be NULL). */
 PM355_API int pm355_mul_mat_q_small_multi(int type, int njobs, const void * const * W, const int64_t * N, float * const * y,
                                           const float * const * bias, const void * xq, int64_t K, int64_t n_tokens, pm355_stream_t stream);
 /* test hook: additionally writes, per (row, unit), the exact int32 pair {sum scale*q_w*q_a, sum min*bsum} */

@@ -219,7 +219,7 @@ int pm355_mul_mat_q_small_multi(int type, int njobs, const void * const * W, con
     int n32[3];
     for (int j = 0; j < njobs; ++j) n32[j] = (int) N[j];
     const int rc = pm_launch_mmq_i8_multi(type, njobs, W, n32, y, bias, xq, (int) K, (int) n_tokens, 0, S(st));
-    if (rc == -5) return fail(PM355_E_UNSUPPORTED, "mul_mat_q_small_multi: Q4_K / Q6_K, n_tokens <= 32, K % 256 == 0 required");
+    if (rc == -5) return fail(PM355_E_UNSUPPORTED, "mul_mat_q_small_multi: Q4_K / Q6_K, n_tokens <= 64, K % 256 == 0 required");
     if (rc) return fail(PM355_E_HIP, "mul_mat_q_small_multi: scratch allocation");
     HIP_TRY(hipGetLastError());
     return 0;

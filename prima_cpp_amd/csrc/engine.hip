@@ -559,7 +559,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         int rc = 0;
         bool prepped = false;
         const bool small = T >= MMQ_MULTI_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && a.k != nullptr;   // (single launches: from MMQ_MIN_TOKENS, in matmul_small)
-        // matrices of one type that share the activations go out as ONE small-batch launch (<= 32 tokens = one pass): wq | wk (| wv), ffn_gate | ffn_up
+        // matrices of one type that share the activations go out as ONE small-batch launch per 32 tokens: wq | wk (| wv), ffn_gate | ffn_up
         auto multi = [&](std::initializer_list<const Tensor *> ws, std::initializer_list<float *> ys, std::initializer_list<const float *> bs) {
             const void * W[3]; int N[3]; float * Y[3]; const float * B[3]; int n = 0;
             for (const Tensor * w : ws) { W[n] = w->d; N[n] = (int) w->N; ++n; }
@@ -571,7 +571,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         const Tensor & wq_ = L.t[PM355_T_WQ], & wk_ = L.t[PM355_T_WK], & wv_ = L.t[PM355_T_WV];
         const float * bq_ = (const float *) L.t[PM355_T_BQ].d, * bk_ = (const float *) L.t[PM355_T_BK].d, * bv_ = (const float *) L.t[PM355_T_BV].d;
         bool qkv_done = false;
-        if (small && T <= 32 && !m->no_multi && wq_.type == wk_.type) {
+        if (small && T <= MMQ_MAX_TOKENS && !m->no_multi && wq_.type == wk_.type) {
             if (wv_.type == wq_.type) {
                 if (multi({&wq_, &wk_, &wv_}, {m->q, m->k, m->v}, {bq_, bk_, bv_}) == 0) qkv_done = true;
             } else if (multi({&wq_, &wk_}, {m->q, m->k}, {bq_, bk_}) == 0) {
@@ -616,7 +616,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         if (!pair_cols && small && m->h2 && pm_mmq_i8_check(wg.type, (int) wg.K, (int) wg.N, T) == 0) {
             // gate and up: one weight pass each for all tokens, then silu(gate) * up (the pair mat-vec would take one launch per token)
             prepped = false;
-            if (T <= 32 && !m->no_multi && wg.type == wu.type && multi({&wg, &wu}, {m->h, m->h2}, {nullptr, nullptr}) == 0) gu_done = true;
+            if (T <= MMQ_MAX_TOKENS && !m->no_multi && wg.type == wu.type && multi({&wg, &wu}, {m->h, m->h2}, {nullptr, nullptr}) == 0) gu_done = true;
             else if (T >= MMQ_MIN_TOKENS) {
                 if (matmul_small(m, wg, a, T, m->h, nullptr, nullptr, prepped, st) || matmul_small(m, wu, a, T, m->h2, nullptr, nullptr, prepped, st))
                     return seterr(m, PM355_E_UNSUPPORTED, "decode: gate/up small-batch mat-mul");

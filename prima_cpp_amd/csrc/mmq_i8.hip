@@ -763,11 +763,11 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
 }
 
 // Up to 3 matrices of ONE type and K sharing the activations (wq | wk | wv, ffn_gate | ffn_up) in one launch: one fill / drain of the
-// step pipeline instead of two or three (~10 us each). T <= 32 = one pass (round 4: with the operand-ordered activation table the 32-token
+// step pipeline instead of two or three (~10 us each). T <= 64 in passes of 32 (round 4: with the operand-ordered activation table the 32-token
 // instantiations have the registers for per-lane row pointers: 238 / 250 VGPRs); -5: not served, launch the jobs one by one. y[j]: [T][N[j]].
 int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const int * N, float * const * Y, const float * const * bias, const void * xq,
                            int K, int T, int reuse_prep, hipStream_t st) {
-    if (njobs < 2 || njobs > 3 || T > 32 || (type != PM_Q4_K && type != PM_Q6_K)) return -5;
+    if (njobs < 2 || njobs > 3 || T > 64 || (type != PM_Q4_K && type != PM_Q6_K)) return -5;
     long total = 0;
     for (int j = 0; j < njobs; ++j) { if (pm_mmq_i8_check(type, K, N[j], T)) return -5; total += N[j]; }
     int dev = 0;
@@ -797,7 +797,14 @@ int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const in
         pm_allow_big_lds((const void *) kern, 150 * 1024);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, st, p);
     };
-    if (type == PM_Q4_K) { if (T <= 8) go(mmq_i8_kernel<PM_Q4_K, 4, 0, true>); else if (T <= 16) go(mmq_i8_kernel<PM_Q4_K, 8, 0, true>); else go(mmq_i8_kernel<PM_Q4_K, 16, 0, true>); }
-    else                 { if (T <= 8) go(mmq_i8_kernel<PM_Q6_K, 4, 0, true>); else if (T <= 16) go(mmq_i8_kernel<PM_Q6_K, 8, 0, true>); else go(mmq_i8_kernel<PM_Q6_K, 16, 0, true>); }
+    const size_t tab = (size_t) nsb * (1024 + 128);
+    for (int t0 = 0, c = 0; t0 < T; t0 += 32, ++c) {                 // passes of 32 tokens, each with its own tables
+        const int tn = T - t0 < 32 ? T - t0 : 32;
+        p.T = tn;
+        p.bsT = sc->p + c * tab; p.dT = (const float *) (p.bsT + (size_t) nsb * 1024); p.qT = sc->p + scr_q_off(K) + (size_t) c * nsb * 8192;
+        for (int j = 0; j < 3; ++j) { const int jj = j < njobs ? j : njobs - 1; p.yj[j] = Y[jj] + (size_t) t0 * N[jj]; }
+        if (type == PM_Q4_K) { if (tn <= 8) go(mmq_i8_kernel<PM_Q4_K, 4, 0, true>); else if (tn <= 16) go(mmq_i8_kernel<PM_Q4_K, 8, 0, true>); else go(mmq_i8_kernel<PM_Q4_K, 16, 0, true>); }
+        else                 { if (tn <= 8) go(mmq_i8_kernel<PM_Q6_K, 4, 0, true>); else if (tn <= 16) go(mmq_i8_kernel<PM_Q6_K, 8, 0, true>); else go(mmq_i8_kernel<PM_Q6_K, 16, 0, true>); }
+    }
     return 0;
 }

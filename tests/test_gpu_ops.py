@@ -272,7 +272,7 @@ def test_small_batch_matmul_multi_job_launch(P, oracle, t):
     """wq | wk | wv and ffn_gate | ffn_up as ONE launch over a virtual row space: every job equals its own single-job launch (same integers; the
     K split over waves may differ) and the oracle; row groups straddle the job boundaries (N not a multiple of 32)."""
     rng = np.random.default_rng(300 + t)
-    for K, Ns, T in ((1024, (300, 70, 75), 5), (768, (2100, 2100), 16), (4096, (515, 40), 9), (1024, (300, 70, 75), 20), (2048, (2100, 2100), 32)):
+    for K, Ns, T in ((1024, (300, 70, 75), 5), (768, (2100, 2100), 16), (4096, (515, 40), 9), (1024, (300, 70, 75), 20), (2048, (2100, 2100), 32), (1024, (300, 70), 45), (768, (600, 600, 90), 64)):
         blocks = [rand_blocks(t, N, K, rng) for N in Ns]
         ws = [P.upload_weight(t, b, K, N) for b, N in zip(blocks, Ns)]
         x = rng.normal(0, 1, (T, K)).astype(np.float32)
