@@ -146,6 +146,15 @@ typedef struct {
 } pm355_matvec_job;
 PM355_API int pm355_mul_mat_vec_fused(const pm355_matvec_job * jobs, int njobs, int64_t K, const float * x_f32,
                                       const float * norm_w, float eps, pm355_stream_t stream);
+/* Producer-side sum of squares (round 5). The rms_norm in front of wq | wk | wv and of ffn_gate | ffn_up reads a row that the preceding wo / ffn_down
+ * launch has just written: sumsq_out != NULL (ONE job, W2 == NULL) makes every workgroup of that launch store the f64 sum of the f32-rounded squares
+ * of the output rows it wrote - the terms of ggml_compute_forward_rms_norm_f32's `sum += (ggml_float)(x[i] * x[i])`, ggml.c:11975-11980 - into
+ * sumsq_out[workgroup], pm355_mul_mat_vec_fused_grid() partials in all; sumsq_in != NULL (with norm_w) makes the consuming launch add those
+ * n_sumsq_in (<= 256) partials instead of reducing the row in its prologue. Same Q8_K blocks as the plain form (tests: bit for bit). */
+PM355_API int pm355_mul_mat_vec_fused_ss(const pm355_matvec_job * jobs, int njobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
+                                         double * sumsq_out, const double * sumsq_in, int n_sumsq_in, pm355_stream_t stream);
+/* workgroups (= sumsq_out partials) of the launch pm355_mul_mat_vec_fused(_ss) issues for this job list, or a negative PM355_E_* */
+PM355_API int pm355_mul_mat_vec_fused_grid(const pm355_matvec_job * jobs, int njobs, int64_t K);
 /* 0 when pm355_mul_mat_vec_fused can serve this job list in ONE launch (type mix, K, LDS), else the error it would return */
 PM355_API int pm355_mul_mat_vec_fused_check(const pm355_matvec_job * jobs, int njobs, int64_t K);
 /* Batched (prefill) path, n_tokens >= 16: Y[t][n] = sum_k W[n][k] x[t][k] (+bias[n]) (+resid[t][n]) on the MFMA matrix cores

@@ -173,6 +173,32 @@ int pm355_mul_mat_vec_fused(const pm355_matvec_job * jobs, int njobs, int64_t K,
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_mul_mat_vec_fused_ss(const pm355_matvec_job * jobs, int njobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
+                               double * sumsq_out, const double * sumsq_in, int n_sumsq_in, pm355_stream_t st) {
+    if (njobs < 1 || njobs > 3 || !jobs || !x_f32) return fail(PM355_E_RANGE, "mul_mat_vec_fused_ss: 1..3 jobs and an f32 activation");
+    pm_gemv_fused f = {};
+    f.K = (int) K; f.njobs = njobs; f.xf = x_f32; f.norm_w = norm_w; f.eps = eps;
+    f.ss_out = sumsq_out; f.ss_in = sumsq_in; f.n_ss = n_sumsq_in;
+    for (int j = 0; j < njobs; ++j) {
+        f.job[j].type = jobs[j].type; f.job[j].N = (int) jobs[j].N; f.job[j].W = jobs[j].W; f.job[j].W2 = jobs[j].W2;
+        f.job[j].y = jobs[j].y; f.job[j].bias = jobs[j].bias; f.job[j].resid = jobs[j].resid;
+    }
+    (void) hipGetLastError();
+    const int lrc = pm_launch_gemv_fused(f, S(st));
+    if (lrc == -6) return fail(PM355_E_UNSUPPORTED, "mul_mat_vec_fused_ss: sumsq_out needs ONE plain job; sumsq_in needs norm_w and 1..256 partials");
+    const int rc = gemv_rc(lrc);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pm355_mul_mat_vec_fused_grid(const pm355_matvec_job * jobs, int njobs, int64_t K) {
+    if (njobs < 1 || njobs > 3 || !jobs) return fail(PM355_E_RANGE, "mul_mat_vec_fused_grid: 1..3 jobs");
+    pm_gemv_fused f = {};
+    f.K = (int) K; f.njobs = njobs; f.xf = (const float *) 16;
+    for (int j = 0; j < njobs; ++j) { f.job[j].type = jobs[j].type; f.job[j].N = (int) jobs[j].N; f.job[j].W = jobs[j].W; f.job[j].W2 = jobs[j].W2; }
+    const int g = pm_gemv_fused_grid(f);
+    return g > 0 ? g : gemv_rc(g);
+}
 int pm355_mul_mat_vec_fused_check(const pm355_matvec_job * jobs, int njobs, int64_t K) {
     if (njobs < 1 || njobs > 3 || !jobs) return fail(PM355_E_RANGE, "mul_mat_vec_fused: 1..3 jobs");
     pm_gemv_fused f = {};

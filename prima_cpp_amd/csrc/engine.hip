@@ -52,6 +52,10 @@ struct pm355_model {
     // table `rope_tab`), the attention launch reads everything from the cache (attn_cached.hip). PM355_QKV_EPI=0: the round-2 form (raw q / k / v,
     // rope + store inside the attention kernel)
     bool qkv_epi = true; float * rope_tab = nullptr;
+    // producer-side sum of squares (round 5): the wo / ffn_down launches leave the per-workgroup partials of the NEXT rms_norm's sum of squares
+    // in ss[0] / ss[1] (256 doubles each); the consuming wq | wk | wv, ffn_gate | ffn_up and lm_head launches add them instead of reducing the row.
+    // PM355_SS=0: every norm prologue reduces its own row (the round-4 form)
+    bool use_ss = true; double * ss = nullptr;
     // PM355_PROMPT_I8=1: prompts (> 64 tokens) run their Q4_K / Q6_K matrices on the integer matrix cores over Q8_K activations (mmq_big.hip) - the CPU
     // reference's own arithmetic, at 0.6-0.75 of the F16 GEMMs' rate (mmq.hip, the default); tab_big = the activation tables of the current
     // activation set (pm_q8k_tables)
@@ -304,26 +308,36 @@ int matmul_small(pm355_model * m, const Tensor & w, const ActQ & a, int T, float
 }
 
 // single-token fused GEMV launch helper: jobs share the f32 activation `xf` (rms_norm'ed with norm_w when given)
+// ss_out: this launch leaves its per-workgroup sum-of-squares partials there and *n_ss_out receives their number (0: not served - the consumer
+// then reduces the row itself); ss_in / n_ss_in: partials of xf's sum of squares left by the producing launch
 int gemv_f32(pm355_model * m, const Tensor * const * ws, const Tensor * const * w2s, float * const * ys,
              const float * const * biases, const float * const * resids, int nj,
-             const float * xf, const float * norm_w, hipStream_t st, const pm_qkv_epi * epi = nullptr) {
+             const float * xf, const float * norm_w, hipStream_t st, const pm_qkv_epi * epi = nullptr,
+             double * ss_out = nullptr, int * n_ss_out = nullptr, const double * ss_in = nullptr, int n_ss_in = 0) {
     pm_gemv_fused f = {};
     f.K = (int) ws[0]->K; f.njobs = nj; f.xf = xf; f.norm_w = norm_w; f.eps = m->hp.rms_eps; f.epi = epi;
     for (int j = 0; j < nj; ++j) {
         f.job[j].type = ws[j]->type; f.job[j].N = (int) ws[j]->N; f.job[j].W = ws[j]->d; f.job[j].W2 = w2s ? (w2s[j] ? w2s[j]->d : nullptr) : nullptr;
         f.job[j].y = ys[j]; f.job[j].bias = biases ? biases[j] : nullptr; f.job[j].resid = resids ? resids[j] : nullptr;
     }
+    if (n_ss_out) *n_ss_out = 0;
+    if (ss_out && n_ss_out) {
+        const int g = pm_gemv_fused_grid(f);
+        if (g > 0 && g <= 256) { f.ss_out = ss_out; *n_ss_out = g; }
+    }
+    if (ss_in && n_ss_in > 0 && norm_w) { f.ss_in = ss_in; f.n_ss = n_ss_in; }
     return pm_launch_gemv_fused(f, st);
 }
 
 // result_norm + lm_head (+ greedy argmax) on ONE hidden row (build_llama's last sub-graph, src/llama.cpp:11191-11215)
-int run_head(pm355_model * m, const float * x_row, float * d_logits, int32_t * d_argmax, hipStream_t st) {
+int run_head(pm355_model * m, const float * x_row, float * d_logits, int32_t * d_argmax, hipStream_t st, const double * ss_in = nullptr, int n_ss_in = 0) {
     if (!m->output.d || !m->out_norm.d) return seterr(m, PM355_E_UNSUPPORTED, "head: output / output_norm missing");
     const Tensor * ow[1] = {&m->output};
     float * lg = d_logits ? d_logits : m->logits;
     if (!m->no_fuse) {
         float * y[1] = {lg};
-        if (gemv_f32(m, ow, nullptr, y, nullptr, nullptr, 1, x_row, (const float *) m->out_norm.d, st)) return seterr(m, PM355_E_UNSUPPORTED, "head: fused lm_head gemv");
+        if (gemv_f32(m, ow, nullptr, y, nullptr, nullptr, 1, x_row, (const float *) m->out_norm.d, st, nullptr, nullptr, nullptr, ss_in, n_ss_in))
+            return seterr(m, PM355_E_UNSUPPORTED, "head: fused lm_head gemv");
     } else {
         ActQ a = norm_quantize_for(m, x_row, (const float *) m->out_norm.d, m->hp.n_embd, 1, ow, 1, st);
         if (gemv(m->output, nullptr, a, 1, lg, nullptr, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "head: lm_head gemv");
@@ -343,7 +357,8 @@ int attn_regime(const pm355_model * m) {
 }
 
 // the single-token layer sequence (5 launches per layer)
-int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const float ** cur_out, hipStream_t st) {
+// *n_ss_end: number of partials the LAST layer's ffn_down left in m->ss + 256 for the sum of squares of the window's output row (0: none)
+int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const float ** cur_out, hipStream_t st, int * n_ss_end = nullptr) {
     const pm355_hparams & hp = m->hp;
     const int H = hp.n_head, Hkv = hp.n_head_kv, dh = hp.head_dim;
     const float kq_scale = 1.0f / sqrtf((float) dh);
@@ -353,6 +368,8 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
     bool epi = m->qkv_epi && m->rope_tab && (m->rope.mode == 0 || m->rope.mode == 2) &&
                (!m->long_ctx || (m->use_flash && m->attn_mfma && H / Hkv <= 8 && pm_attn_flash_cached_ok(H, Hkv, dh, hp.n_ctx) == 0));
     if (epi) pm_launch_rope_table(m->rope, m->d_pos, m->d_ctl, (const float *) m->rope_freqs.d, m->rope_tab, st);
+    double * ss_wo = (m->use_ss && m->ss) ? m->ss : nullptr, * ss_dn = ss_wo ? m->ss + 256 : nullptr;
+    int n_wo = 0, n_dn = 0;                           // partials the previous wo / ffn_down launch left (0: the consumer reduces the row itself)
     for (int il = m->lo; il < m->hi; ++il) {
         Layer Lv = layer_acquire(m, il, st); Layer & L = Lv;
         float * q = m->q, * k = m->k, * v = m->v, * att = m->att, * hbuf = m->h;
@@ -367,13 +384,13 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
             const pm_qkv_epi qe = {m->rope_tab, m->d_pos, m->d_ctl, nullptr, kvs_e, L.kc, L.vc, Hkv, dh, hp.n_ctx, m->rope.n_dims, 0, (m->rope.mode & 2) ? 1 : 0};
             bool qkv_done = false;
             if (epi) {
-                qkv_done = gemv_f32(m, ws, nullptr, ys, bs, nullptr, 3, cur, nw, st, &qe) == 0;
+                qkv_done = gemv_f32(m, ws, nullptr, ys, bs, nullptr, 3, cur, nw, st, &qe, nullptr, nullptr, ss_dn, n_dn) == 0;
                 if (!qkv_done) {
                     if (il != m->lo) return seterr(m, PM355_E_UNSUPPORTED, "decode: QKV epilogue served for some layers only");
                     epi = false;                       // (shape / type mix without the epilogue kernel: the whole window takes the round-2 form)
                 }
             }
-            if (!qkv_done && gemv_f32(m, ws, nullptr, ys, bs, nullptr, 3, cur, nw, st)) {
+            if (!qkv_done && gemv_f32(m, ws, nullptr, ys, bs, nullptr, 3, cur, nw, st, nullptr, nullptr, nullptr, ss_dn, n_dn)) {
                 for (int j = 0; j < 3; ++j)               // type mix without a 3-job kernel: one launch per matrix
                     if (gemv_f32(m, ws + j, nullptr, ys + j, bs + j, nullptr, 1, cur, nw, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused qkv gemv");
             }
@@ -406,24 +423,25 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
             return seterr(m, PM355_E_RANGE, "decode: fused attention unsupported for this head_dim / n_ctx");
         {
             const Tensor * w[1] = {&L.t[PM355_T_WO]}; float * y[1] = {x_mid}; const float * r[1] = {cur};
-            if (gemv_f32(m, w, nullptr, y, nullptr, r, 1, att, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused wo gemv");
+            if (gemv_f32(m, w, nullptr, y, nullptr, r, 1, att, nullptr, st, nullptr, ss_wo, &n_wo)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused wo gemv");
         }
         if (L.t[PM355_T_FFN_GATE].type != L.t[PM355_T_FFN_UP].type)
             return seterr(m, PM355_E_UNSUPPORTED, "decode: ffn_gate and ffn_up of different types");
         {
             const Tensor * w[1] = {&L.t[PM355_T_FFN_GATE]}; const Tensor * w2[1] = {&L.t[PM355_T_FFN_UP]}; float * y[1] = {hbuf};
-            if (gemv_f32(m, w, w2, y, nullptr, nullptr, 1, x_mid, (const float *) L.t[PM355_T_FFN_NORM].d, st))
+            if (gemv_f32(m, w, w2, y, nullptr, nullptr, 1, x_mid, (const float *) L.t[PM355_T_FFN_NORM].d, st, nullptr, nullptr, nullptr, ss_wo, n_wo))
                 return seterr(m, PM355_E_UNSUPPORTED, "decode: fused gate/up gemv");
         }
         float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : x_nxt;
         {
             const Tensor * w[1] = {&L.t[PM355_T_FFN_DOWN]}; float * y[1] = {x_next}; const float * r[1] = {x_mid};
-            if (gemv_f32(m, w, nullptr, y, nullptr, r, 1, hbuf, nullptr, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused down gemv");
+            if (gemv_f32(m, w, nullptr, y, nullptr, r, 1, hbuf, nullptr, st, nullptr, ss_dn, &n_dn)) return seterr(m, PM355_E_UNSUPPORTED, "decode: fused down gemv");
         }
         layer_release(m, il, st);
         cur = x_next;
     }
     *cur_out = cur;
+    if (n_ss_end) *n_ss_end = n_dn;
     return 0;
 }
 
@@ -443,11 +461,12 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
     }
     if (!cur) return seterr(m, PM355_E_SHAPE, "decode: neither tokens nor x_in");
     float * bufs[2] = {m->x, m->x1};
+    int n_ss_head = 0;                                // partials of the output row's sum of squares left by the last ffn_down (single-token path)
     if (T == 1 && !m->no_fuse) {
         m->flash_cells = attn_regime(m); m->long_ctx = m->flash_cells != 0;
         // ---- single token: every activation transform is fused into a mat-vec prologue / epilogue, 5 launches per layer
         const float * end = nullptr;
-        int rc = run_layers_fused(m, cur, d_x_out, &end, st);
+        int rc = run_layers_fused(m, cur, d_x_out, &end, st, &n_ss_head);
         if (rc) return rc;
         cur = end;
     } else
@@ -644,7 +663,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
     }
     if (d_x_out && cur != d_x_out) (void) hipMemcpyAsync(d_x_out, cur, (size_t) T * E * 4, hipMemcpyDeviceToDevice, st);
     if ((d_logits || d_argmax) && (m->flags & PM355_HAS_HEAD)) {
-        int rc = run_head(m, cur + (size_t) (T - 1) * E, d_logits, d_argmax, st);
+        int rc = run_head(m, cur + (size_t) (T - 1) * E, d_logits, d_argmax, st, n_ss_head ? m->ss + 256 : nullptr, n_ss_head);
         if (rc) return rc;
     }
     return hip_ok() ? 0 : seterr(m, PM355_E_HIP, "decode: kernel launch failed");
@@ -671,6 +690,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     { const char * e = getenv("PM355_NO_MMQ_I8"); m->no_mmq = e && e[0] == '1'; }     // 4..64-token batches: mat-vec columns / F16 GEMM from 16 (the round-1 paths)
     { const char * e = getenv("PM355_QKV_EPI"); m->qkv_epi = !(e && e[0] == '0'); }
     { const char * e = getenv("PM355_PROMPT_I8"); m->no_big = !(e && e[0] == '1'); }
+    { const char * e = getenv("PM355_SS"); m->use_ss = !(e && e[0] == '0'); }
     return m;
 }
 
@@ -684,7 +704,7 @@ void pm355_model_free(pm355_model * m) {
     for (auto & L : m->layers) { for (auto & t : L.t) if (t.d) (void) hipFree(t.d); if (L.kc) (void) hipFree(L.kc); if (L.vc) (void) hipFree(L.vc); }
     Tensor * g[4] = {&m->tok_embd, &m->out_norm, &m->output, &m->rope_freqs};
     for (auto t : g) if (t->d) (void) hipFree(t->d);
-    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->h2, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->split_scratch, m->rope_tab, m->tab_big};
+    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->h2, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->split_scratch, m->rope_tab, m->tab_big, m->ss};
     for (auto p : s) if (p) (void) hipFree(p);
     pm355_uploader_free(m->up);
     if (m->cap_stream) (void) hipStreamDestroy(m->cap_stream);
@@ -780,7 +800,7 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
               A((void **) &m->aq_k, T * pm_q8k_row_bytes((int) ((maxK + 255) / 256 * 256))) &&
               A((void **) &m->aq_0, T * pm_q80_row_bytes((int) ((maxK + 31) / 32 * 32))) &&
               A((void **) &m->d_pos, 64 * 4) && A((void **) &m->d_ctl, 64) && A((void **) &m->d_tok, 64 + T * 4) &&
-              A((void **) &m->rope_tab, (size_t) hp.head_dim * 4);
+              A((void **) &m->rope_tab, (size_t) hp.head_dim * 4) && A((void **) &m->ss, 2 * 256 * sizeof(double));
     if (ok && T > MMQ_MAX_TOKENS && !m->no_big) ok = A((void **) &m->tab_big, pm_mmq_big_table_bytes((int) ((maxK + 255) / 256 * 256), (int) T));
     if (!ok) return seterr(m, PM355_E_NOMEM, "finalize: scratch");
     if (hp.n_head / hp.n_head_kv <= 8 && (hp.head_dim == 64 || hp.head_dim == 128) &&

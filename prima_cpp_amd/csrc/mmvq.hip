@@ -108,7 +108,10 @@ int pmv::gemv_fill(const pm_gemv_fused & a, int grid_fixed, GemvP & p, int & ta_
     if (a.njobs < 1 || a.njobs > 3) return -4;
     p = GemvP{};
     p.K = a.K; p.xq = (const uint8_t *) a.xq; p.xf = a.xf; p.norm_w = a.norm_w; p.eps = a.eps; p.dbg = a.dbg_int;
-    p.xmode = a.xq ? 0 : (a.norm_w ? 2 : 1);
+    p.xmode = a.xq ? 0 : (a.norm_w ? (a.ss_in ? 3 : 2) : 1);
+    if (a.ss_in && (!a.norm_w || a.xq || a.n_ss < 1 || a.n_ss > 256)) return -6;
+    if (a.ss_out && (a.njobs != 1 || a.job[0].W2 || a.epi || a.dbg_int)) return -6;
+    p.ss_out = a.ss_out; p.ss_in = a.ss_in; p.n_ss = a.n_ss;
     int ta = a.job[0].type, tb = ta;
     const bool pair = a.job[0].W2 != nullptr;
     for (int j = 0; j < a.njobs; ++j) {
@@ -179,6 +182,12 @@ int pm_device_cus() { return num_cus(); }
 int pm_gemv_fused_check(const pm_gemv_fused & a) {
     GemvP p; int ta, tb, grid; bool pair; size_t lds;
     return gemv_fill(a, 0, p, ta, tb, pair, lds, grid);
+}
+
+int pm_gemv_fused_grid(const pm_gemv_fused & a) {
+    GemvP p; int ta, tb, grid; bool pair; size_t lds;
+    const int rc = gemv_fill(a, 0, p, ta, tb, pair, lds, grid);
+    return rc ? (rc < 0 ? rc : -rc) : grid;
 }
 
 // Fused launch: up to 3 matrices sharing one activation row.

@@ -39,8 +39,14 @@ struct QkvEpi {
 struct GemvP {
     GemvJob job[3];
     const uint8_t * xq;                     // xmode 0: pre-quantized activation row (row-SoA Q8_K / Q8_0)
-    const float * xf; const float * norm_w; // xmode 1: f32 activation; xmode 2: rms_norm(xf) * norm_w first
+    const float * xf; const float * norm_w; // xmode 1: f32 activation; xmode 2: rms_norm(xf) * norm_w first; xmode 3: the same with the
+                                            // sum of squares of xf taken from the PRODUCER's per-workgroup partials (ss_in[n_ss], see ss_out)
     float eps;
+    // producer-side sum of squares (round 5): a single-job launch whose output row is the next launch's rms_norm input stores, per workgroup,
+    // the f64 sum of the f32-rounded squares of the rows it wrote (ss_out[blockIdx.x]); the consuming launch (xmode 3) adds the n_ss partials
+    // instead of reducing the row itself - its prologue loses the reduction pass and one workgroup barrier (ggml.c:11975-11980: the reference
+    // sums (ggml_float)(x[i] * x[i]) in f64; any order of these <= 2^15 terms agrees after the final rounding to f32, as for xmode 2)
+    double * ss_out; const double * ss_in; int n_ss;
     int xmode, K;
     int32_t * dbg;
     int ncols;                              // activation columns served by one launch (xmode 0 only when > 1)
@@ -318,17 +324,21 @@ __device__ __forceinline__ void q80_block_to_lds(const float v[4], int i4 /*inde
 //                      are loaded ONCE and stay in registers between the sum-of-squares and the quantization.
 //   ABLK = 32  (Q8_0): thread t owns the float4s t, t + 1024, ... (8 lanes = one 32-block); K <= 16384 held in registers.
 // f[0] / f[1]: the two passes of a row of up to 128 blocks; with norm weights (held for <= 64 blocks = one pass) f[1] carries the weights
-struct ActRegs { float4 f[2][4]; };
+struct ActRegs { float4 f[2][4]; double ssp[4]; };      // ssp: xmode 3, this lane's share of the producer's partial sums (n_ss <= 256)
 
 template <int ABLK>
 __device__ __forceinline__ bool act_held(const GemvP & p) {
     if (p.xmode == 0) return false;
-    if (ABLK == 256) return p.K / 256 <= (p.xmode == 2 ? 64 : 128);
+    if (ABLK == 256) return p.K / 256 <= (p.xmode >= 2 ? 64 : 128);
     return p.K / 4 <= 4 * PM_GEMV_BLOCK;
 }
 
 template <int ABLK, bool COH>
 __device__ __forceinline__ void stage_issue(const GemvP & p, ActRegs & a, int wave, int lane) {
+    if (p.xmode == 3) {                      // the producer's partial sums: four 8-byte loads per lane, in front of everything else of this wave
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a.ssp[i] = lane + 64 * i < p.n_ss ? ld_g(p.ss_in + lane + 64 * i) : 0.0;
+    }
     if (!act_held<ABLK>(p)) return;
     const float4 * xf4 = (const float4 *) p.xf, * nw4 = (const float4 *) p.norm_w;
     if (ABLK == 256) {
@@ -339,7 +349,7 @@ __device__ __forceinline__ void stage_issue(const GemvP & p, ActRegs & a, int wa
 #pragma unroll
             for (int k = 0; k < 4; ++k) a.f[t][k] = ld_act4<false>(xf4 + (B * 64 + 16 * k + j));
         }
-        if (p.xmode == 2) {
+        if (p.xmode >= 2) {
             const int B = min(4 * wave + r, nblk - 1);
 #pragma unroll
             for (int k = 0; k < 4; ++k) a.f[1][k] = ld_g(nw4 + (B * 64 + 16 * k + j));
@@ -350,7 +360,7 @@ __device__ __forceinline__ void stage_issue(const GemvP & p, ActRegs & a, int wa
         for (int k = 0; k < 4; ++k) {
             const int i = tid + k * PM_GEMV_BLOCK;
             a.f[0][k] = ld_act4<false>(xf4 + (i < n4 ? i : 0));
-            if (p.xmode == 2) a.f[1][k] = ld_g(nw4 + (i < n4 ? i : 0));
+            if (p.xmode >= 2) a.f[1][k] = ld_g(nw4 + (i < n4 ? i : 0));
         }
     }
 }
@@ -388,7 +398,13 @@ __device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_
     const bool held = act_held<ABLK>(p);
     const int nblk = K / 256, r = lane >> 4, j = lane & 15;
     float scale = 1.0f;
-    if (p.xmode == 2) {
+    if (p.xmode == 3) {
+        // every wave adds the producer's partials for itself: no reduction over the row, no LDS, no workgroup barrier
+        const double tot = wave_sum_f64((a.ssp[0] + a.ssp[1]) + (a.ssp[2] + a.ssp[3]));
+        if (t_norm) *t_norm = PM_TS_NOW();
+        const float mean = (float) (tot / K);
+        scale = 1.0f / sqrtf(mean + p.eps);
+    } else if (p.xmode == 2) {
         // sum of the f32-rounded squares in f64 like the reference (ggml.c:11975-11980); any summation order of <= 2^15
         // f64 terms agrees with the sequential one after the final rounding to f32
         double ss = 0.0;
@@ -419,7 +435,7 @@ __device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 v[k][0] = f[k].x; v[k][1] = f[k].y; v[k][2] = f[k].z; v[k][3] = f[k].w;
-                if (p.xmode == 2) { v[k][0] = v[k][0] * scale * g[k].x; v[k][1] = v[k][1] * scale * g[k].y; v[k][2] = v[k][2] * scale * g[k].z; v[k][3] = v[k][3] * scale * g[k].w; }
+                if (p.xmode >= 2) { v[k][0] = v[k][0] * scale * g[k].x; v[k][1] = v[k][1] * scale * g[k].y; v[k][2] = v[k][2] * scale * g[k].z; v[k][3] = v[k][3] * scale * g[k].w; }
             }
             q8k_rows_to_lds(v, j, B < nblk, xs_q, xs_gs, xs_d, B);
         };
@@ -430,7 +446,7 @@ __device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_
             for (int B0 = 4 * wave; B0 < nblk; B0 += 4 * PM_GEMV_NW) {
                 const int Bc = min(B0 + r, nblk - 1);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { a.f[0][k] = ld_act4<false>(xf4 + (Bc * 64 + 16 * k + j)); if (p.xmode == 2) a.f[1][k] = ld_g(nw4 + (Bc * 64 + 16 * k + j)); }
+                for (int k = 0; k < 4; ++k) { a.f[0][k] = ld_act4<false>(xf4 + (Bc * 64 + 16 * k + j)); if (p.xmode >= 2) a.f[1][k] = ld_g(nw4 + (Bc * 64 + 16 * k + j)); }
                 rows(a.f[0], a.f[1], B0 + r);
             }
         }
@@ -441,7 +457,7 @@ __device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_
                 for (int k = 0; k < 4; ++k) {
                     const int i = i0 + k * PM_GEMV_BLOCK;
                     a.f[0][k] = ld_act4<false>(xf4 + (i < n4 ? i : 0));
-                    if (p.xmode == 2) a.f[1][k] = ld_g(nw4 + (i < n4 ? i : 0));
+                    if (p.xmode >= 2) a.f[1][k] = ld_g(nw4 + (i < n4 ? i : 0));
                 }
             }
 #pragma unroll
@@ -450,7 +466,7 @@ __device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_
                 if (i - lane < n4) {                 // wave-uniform (n4 is a multiple of 8 = one 32-block)
                     const float4 f = a.f[0][k], g = a.f[1][k];
                     float v[4] = {f.x, f.y, f.z, f.w};
-                    if (p.xmode == 2) { v[0] = v[0] * scale * g.x; v[1] = v[1] * scale * g.y; v[2] = v[2] * scale * g.z; v[3] = v[3] * scale * g.w; }
+                    if (p.xmode >= 2) { v[0] = v[0] * scale * g.x; v[1] = v[1] * scale * g.y; v[2] = v[2] * scale * g.z; v[3] = v[3] * scale * g.w; }
                     if (i < n4) q80_block_to_lds(v, i, xs_q, xs_gs, xs_d);
                 }
             }
@@ -664,8 +680,10 @@ __device__ __forceinline__ float row_result(const GemvJob & jb, const float * ou
     return o;
 }
 
+// returns this thread's share of sum (double)(out * out) over the values it stored (the producer-side partial of the next rms_norm, GemvP::ss_out)
 template <bool COH, int NC>
-__device__ __forceinline__ void write_out(const GemvJob & jb, const float * outbuf, int r0, int r1, int ob, int tid, long y_stride, int cpr = 1, int ncols = NC) {
+__device__ __forceinline__ double write_out(const GemvJob & jb, const float * outbuf, int r0, int r1, int ob, int tid, long y_stride, int cpr = 1, int ncols = NC) {
+    double ss = 0.0;
     for (int t = tid; t < (r1 - r0) * NC; t += PM_GEMV_BLOCK) {
         const int c = NC == 1 ? 0 : t / (r1 - r0), row = NC == 1 ? t : t - c * (r1 - r0);     // consecutive threads -> consecutive rows
         if (NC > 1 && c >= ncols) break;                                                        // (column slots past the batch)
@@ -673,7 +691,10 @@ __device__ __forceinline__ void write_out(const GemvJob & jb, const float * outb
         if (jb.bias)  out += ld_g(jb.bias + r0 + row);
         if (jb.resid) out += ld_act<false>(jb.resid + c * y_stride + r0 + row);
         st_act<COH>(jb.y + c * y_stride + r0 + row, out);
+        const float sq = out * out;                    // f32-rounded square, then widened: (ggml_float)(x[i] * x[i]), ggml.c:11977
+        ss += (double) sq;
     }
+    return ss;
 }
 
 // wq | wk | wv epilogue: RoPE on adjacent row pairs, q -> F16-rounded f32 in y, k -> F16 K-cache row of this token's cell, v -> F16 V cache
@@ -839,9 +860,26 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
         write_out_qkv(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off, ec2, es2);
     } else {
         const int ncw = NC > 1 && p.ncols > 0 ? p.ncols : NC;
-        write_out<MEGA, NC>(p.job[0], outbuf, r0_0, r1_0, 0, tid, p.y_stride, 1, ncw);
+        const double ss = write_out<MEGA, NC>(p.job[0], outbuf, r0_0, r1_0, 0, tid, p.y_stride, 1, ncw);
         write_out<MEGA, NC>(p.job[1], outbuf, r0_1, r1_1, ob_1, tid, p.y_stride, cpr_1, ncw);
         write_out<MEGA, NC>(p.job[2], outbuf, r0_2, r1_2, ob_2, tid, p.y_stride, cpr_2, ncw);
+        if (NC == 1 && !PAIR && !EPI) if (p.ss_out) {
+            // this workgroup's partial of the consumer's rms_norm (single-job launches: gemv_fill): rows sit in threads 0 .. r1 - r0 - 1
+            const double ws = wave_sum_f64(ss);
+            if (r1_0 - r0_0 <= 64) {                   // (every 70B / 8B / 72B shape: 16-32 rows per workgroup -> wave 0 alone, no barrier)
+                if (tid == 0) st_g(p.ss_out + b, ws);
+            } else {
+                __syncthreads();                       // (nred: the norm prologue's reads are long done, but not fenced by a barrier of THIS phase)
+                if (lane == 0) nred[wave] = ws;
+                __syncthreads();
+                if (tid == 0) {
+                    double tot = 0.0;
+#pragma unroll
+                    for (int k = 0; k < PM_GEMV_NW; ++k) tot += nred[k];
+                    st_g(p.ss_out + b, tot);
+                }
+            }
+        }
     }
     tsv[5] = PM_TS_NOW();
     pm_ts_store(p.ts, 1 | (PAIR ? 16 : 0) | (p.xmode << 8) | (p.K << 12), tsv);

@@ -85,9 +85,14 @@ struct pm_gemv_fused {
     const float * xf; const float * norm_w; float eps;
     int32_t * dbg_int;
     const pm_qkv_epi * epi;             // null: plain outputs
+    // producer-side sum of squares for the NEXT launch's rms_norm (round 5): ss_out != null (single job, no pair, no epilogue) - every workgroup
+    // stores the f64 sum of the f32-rounded squares of the output rows it wrote into ss_out[workgroup] (pm_gemv_fused_grid() of them);
+    // ss_in != null (with norm_w): the n_ss <= 256 partials a producer left for THIS launch's input row replace the in-kernel reduction
+    double * ss_out; const double * ss_in; int n_ss;
 };
 int pm_launch_gemv_fused(const pm_gemv_fused & a, hipStream_t st);
 int pm_gemv_fused_check(const pm_gemv_fused & a);      // the validation part of pm_launch_gemv_fused only
+int pm_gemv_fused_grid(const pm_gemv_fused & a);       // workgroups pm_launch_gemv_fused would launch (= partials written through ss_out), or < 0
 
 // batched (prefill) GEMM on MFMA: Y[T][N] = X[T][K] . W[N][K]^T (+bias[n]) (+resid[t][n]); W quantized (HBM layout), X f32
 int pm_launch_gemm_q(int type, const void * W, const float * X, float * Y, int K, int N, int T, const float * bias,

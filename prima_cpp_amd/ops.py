@@ -246,6 +246,32 @@ def mul_mat_vec_fused(ws, x, norm_w=None, eps=0.0, w2s=None, biases=None, resids
     return ys
 
 
+def mul_mat_vec_fused_ss(ws, x, norm_w=None, eps=0.0, resids=None, want_sumsq=False, sumsq_in=None):
+    """pm355_mul_mat_vec_fused_ss: like mul_mat_vec_fused; want_sumsq -> also returns the per-workgroup f64 partial sums of squares of the
+    (single) output row; sumsq_in (f64 tensor) -> the rms_norm takes its sum of squares from those partials."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_mul_mat_vec_fused_ss.restype = C.c_int
+    lib.pm355_mul_mat_vec_fused_ss.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.pm355_mul_mat_vec_fused_grid.restype = C.c_int
+    lib.pm355_mul_mat_vec_fused_grid.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+    n = len(ws)
+    jobs = (MatvecJob * n)()
+    ys = []
+    for j, w in enumerate(ws):
+        y = torch.empty(w.N, dtype=torch.float32, device=w.data.device)
+        ys.append(y)
+        jobs[j] = MatvecJob(w.type, 0, w.N, ptr(w.data), None, ptr(y), None, ptr(resids[j]) if resids and resids[j] is not None else None)
+    ss = None
+    if want_sumsq:
+        g = lib.pm355_mul_mat_vec_fused_grid(C.addressof(jobs), n, ws[0].K)
+        assert g > 0, g
+        ss = torch.zeros(g, dtype=torch.float64, device=x.device)
+    check(lib.pm355_mul_mat_vec_fused_ss(C.addressof(jobs), n, ws[0].K, ptr(x), ptr(norm_w), float(eps), ptr(ss), ptr(sumsq_in),
+                                         0 if sumsq_in is None else sumsq_in.numel(), stream_ptr()), "mul_mat_vec_fused_ss")
+    return (ys, ss) if want_sumsq else ys
+
+
 def mul_mat_small(w, x=None, xq=None, n_tokens=None, bias=None, resid=None):
     """1..32 tokens on the integer matrix cores (mmq_i8.hip): x f32 [T, K] (quantized to Q8_K on device) or pre-quantized xq -> f32 [T, N]."""
     import ctypes as C

@@ -353,3 +353,35 @@ def test_qkv_epilogue_decode_form_matches_round2_form(E, oracle, monkeypatch):
     oracle.model_free(ho)
     print(f"[QKV epilogue form vs oracle] worst per-step logits NMSE {worst:.2e}")
     assert worst < 1e-3, worst
+
+
+@pytest.mark.parametrize("arch", [0, 1])
+def test_producer_side_sum_of_squares_decode_is_bit_identical(E, monkeypatch, arch):
+    """PM355_SS=0 (every rms_norm prologue reduces its own row: the round-4 form) against the default (wo / ffn_down leave per-workgroup
+    partials, the wq | wk | wv, ffn_gate | ffn_up and lm_head launches add them): hidden rows and logits of 40 graph-replayed tokens must be
+    the same bits - the partial sums are exact in f64 for these magnitudes, and where they are not the f32 rounding of the mean hides it."""
+    torch = E.torch
+    rng = np.random.default_rng(321)
+    d = tiny_model(rng, arch=arch, n_layer=3, n_embd=1024, n_head=8, n_head_kv=4, n_ff=2048, n_vocab=320, n_ctx=128, rope_freqs=(arch == 0))
+    toks = rng.integers(0, d.n_vocab, 40).astype(np.int32)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("PM355_SS", flag)
+        w = E.Window(_hp(d), n_ctx=128)
+        w.load_desc(d)
+        w.finalize(max_tokens=1)
+        w.set_pos(0)
+        x_out = torch.empty((1, d.n_embd), dtype=torch.float32, device="cuda")
+        lg = torch.empty(d.n_vocab, dtype=torch.float32, device="cuda")
+        tok = torch.zeros(1, dtype=torch.int32, device="cuda")
+        res = []
+        for t in toks:
+            tok[0] = int(t)
+            w.step(token=tok, x_out=x_out, logits=lg, advance=1, use_graph=True)
+            torch.cuda.synchronize()
+            res.append((x_out.cpu().numpy().copy(), lg.cpu().numpy().copy()))
+        assert w.check() == 0
+        outs.append(res)
+        w.close()
+    for i, ((h0, l0), (h1, l1)) in enumerate(zip(*outs)):
+        assert np.array_equal(h0, h1) and np.array_equal(l0, l1), i

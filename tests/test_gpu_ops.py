@@ -502,6 +502,38 @@ def test_fused_prologue_equals_separate_kernels_bitexact(P, t, K, norm):
     assert torch.equal(got, want), (got - want).abs().max()
 
 
+@pytest.mark.parametrize("t", [Q4_K, Q6_K, Q8_0])
+@pytest.mark.parametrize("K_in,E", [(4096, 4096), (28672, 8192), (1024, 768)])
+def test_producer_side_sum_of_squares_gives_the_same_q8_K_blocks(P, oracle, t, K_in, E):
+    """Round 5: the wo / ffn_down launch leaves per-workgroup f64 partials of sum (f32 x^2) of the row it writes (+ residual); the next launch's
+    rms_norm prologue adds them instead of reducing the row (ggml_compute_forward_rms_norm_f32, ggml.c:11975-11980). Acceptance: the consumer's
+    outputs - i.e. its Q8_K / Q8_0 activation blocks and everything after them - are bit-identical to the plain form, and the partials add up to
+    the f64 sum of the f32-rounded squares."""
+    torch = P.torch
+    rng = np.random.default_rng(505 + K_in + E)
+    wp = P.upload_weight(Q4_K, rand_blocks(Q4_K, E, K_in, rng), K_in, E)                 # producer: E rows (wo / ffn_down), + residual
+    a = torch.from_numpy(rng.normal(0, 1.0, (1, K_in)).astype(np.float32)).cuda()
+    resid = torch.from_numpy(rng.normal(0, 2.0, E).astype(np.float32)).cuda()
+    (y_ss,), ss = P.mul_mat_vec_fused_ss([wp], a, resids=[resid], want_sumsq=True)
+    y_plain = P.mul_mat_vec_fused([wp], a, resids=[resid])[0]
+    assert torch.equal(y_ss, y_plain)                                                       # the producer's output itself is untouched
+    y64 = (y_ss.cpu().numpy().astype(np.float32) ** 2).astype(np.float32).astype(np.float64)   # f32-rounded squares, then widened
+    assert abs(float(ss.sum().cpu()) - y64.sum()) <= 1e-12 * y64.sum()
+    # per-workgroup slices: workgroup b owns rows [E b / G, E (b + 1) / G)
+    G = ss.numel()
+    for b in (0, G // 2, G - 1):
+        r0, r1 = E * b // G, E * (b + 1) // G
+        assert abs(float(ss[b].cpu()) - y64[r0:r1].sum()) <= 1e-12 * max(1.0, y64[r0:r1].sum())
+    # consumer: rms_norm(y) * w -> quantize -> mat-vec, with and without the partials
+    Nc = 70
+    wc = P.upload_weight(t, rand_blocks(t, Nc, E, rng), E, Nc)
+    nw = torch.from_numpy((1 + rng.normal(0, 0.05, E)).astype(np.float32)).cuda()
+    want = P.mul_mat_vec_fused([wc], y_ss.view(1, -1), norm_w=nw, eps=1e-5)[0]
+    got = P.mul_mat_vec_fused_ss([wc], y_ss.view(1, -1), norm_w=nw, eps=1e-5, sumsq_in=ss)[0]
+    assert torch.equal(got, want), (got - want).abs().max()
+    # and a pair launch (ffn_gate | ffn_up) as consumer is covered by the engine test (PM355_SS=0 vs default: identical logits)
+
+
 def test_fused_qkv_mixed_types_one_launch(P, oracle):
     """wq/wk (Q4_K) + wv (Q6_K or Q5_K) in one launch == three separate mat-vecs, and == the oracle's mul_mat."""
     torch = P.torch
