@@ -295,6 +295,9 @@ typedef struct {
 PM355_API int pm355_rope_table(const pm355_rope_params * rp, const int32_t * d_pos, const float * freq_factors, float * table, pm355_stream_t stream);
 PM355_API int pm355_mul_mat_vec_qkv(const pm355_matvec_job * jobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
                                     const pm355_qkv_store * s, pm355_stream_t stream);
+/* the same with the rms_norm's sum of squares taken from n_sumsq_in producer-side partials (pm355_mul_mat_vec_fused_ss) */
+PM355_API int pm355_mul_mat_vec_qkv_ss(const pm355_matvec_job * jobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
+                                       const pm355_qkv_store * s, const double * sumsq_in, int n_sumsq_in, pm355_stream_t stream);
 /* 0 when pm355_mul_mat_vec_qkv can serve this wq | wk | wv list (types, K, every workgroup's row slices hold whole rotation pairs) */
 PM355_API int pm355_mul_mat_vec_qkv_check(const pm355_matvec_job * jobs, int64_t K, int n_head_kv, int head_dim, int n_rot);
 PM355_API int pm355_mul_mat_vec_qkv_check_ex(const pm355_matvec_job * jobs, int64_t K, int n_head_kv, int head_dim, int n_rot, int rope_neox);

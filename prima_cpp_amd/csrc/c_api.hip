@@ -346,9 +346,14 @@ int pm355_rope_table(const pm355_rope_params * rp, const int32_t * d_pos, const 
 }
 int pm355_mul_mat_vec_qkv(const pm355_matvec_job * jobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
                           const pm355_qkv_store * s, pm355_stream_t st) {
+    return pm355_mul_mat_vec_qkv_ss(jobs, K, x_f32, norm_w, eps, s, nullptr, 0, st);
+}
+int pm355_mul_mat_vec_qkv_ss(const pm355_matvec_job * jobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
+                             const pm355_qkv_store * s, const double * sumsq_in, int n_sumsq_in, pm355_stream_t st) {
     if (!jobs || !x_f32 || !s || !s->rope_table || !s->k_cache || !s->v_cache || (!s->d_pos && !s->d_cell_nkv)) return fail(PM355_E_SHAPE, "mul_mat_vec_qkv: null pointer");
     pm_gemv_fused f = {};
     f.K = (int) K; f.njobs = 3; f.xf = x_f32; f.norm_w = norm_w; f.eps = eps;
+    if (sumsq_in && n_sumsq_in > 0 && norm_w) { f.ss_in = sumsq_in; f.n_ss = n_sumsq_in; }
     for (int j = 0; j < 3; ++j) {
         f.job[j].type = jobs[j].type; f.job[j].N = (int) jobs[j].N; f.job[j].W = jobs[j].W; f.job[j].W2 = nullptr;
         f.job[j].y = jobs[j].y; f.job[j].bias = jobs[j].bias; f.job[j].resid = nullptr;

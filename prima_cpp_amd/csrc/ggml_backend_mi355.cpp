@@ -125,6 +125,7 @@ struct backend_ctx {
     // graph lowering (ggml_graph_plan.h)
     int32_t * d_dyn = nullptr;                       // device int32[2]: {KV cell of the token, cells attended}
     float * rope_tab = nullptr;                      // device float[256]: this token's cos / sin per rotation pair (round-3 attention block)
+    double * ss_buf = nullptr; bool use_ss = true;   // producer-side sum-of-squares partials, double[2][256] (GGML_MI355_SS=0: off)
     bool attn_mfma = true;                           // GGML_MI355_ATTN_MFMA=0: long contexts keep the round-2 flash-decoding kernel
     bool qkv_epi = true;                             // GGML_MI355_QKV_EPI=0: rope + KV store inside the attention kernel (the round-2 form)
     float * qkv = nullptr; size_t qkv_floats = 0;    // raw q / k / v projections of one token
@@ -347,7 +348,7 @@ void backend_free(ggml_backend_t b) {
                 n, wall, d(0), d(5), d(6), d(7), d(8), d(1) + d(9), d(2) + d(10), d(3), wall - d(0) - d(1) - d(9) - d(2) - d(10) - d(3));
     }
     for (graph_entry * e : c->graphs) { if (e->exec) pm355_graph_free(e->exec); delete e; }
-    dfree(c->scratch); dfree(c->d_i32); dfree(c->d_dyn); dfree(c->rope_tab); dfree(c->qkv); dfree(c->split);
+    dfree(c->scratch); dfree(c->d_i32); dfree(c->d_dyn); dfree(c->rope_tab); dfree(c->ss_buf); dfree(c->qkv); dfree(c->split);
     if (c->null_ev) pm355_event_destroy(c->null_ev);
     if (!plan_only()) pm355_stream_destroy(c->stream);
     delete c; delete b;
@@ -618,7 +619,7 @@ bool run_plan(backend_ctx * c, struct ggml_cgraph * g, const mi355::plan & p) {
     for (const mi355::step & s : p.steps) {
         switch (s.kind) {
             case mi355::STEP_GEMV:
-                MI355_CHECK(pm355_mul_mat_vec_fused(s.job, s.njobs, s.K, s.x, s.norm_w, s.eps, c->stream));
+                MI355_CHECK(pm355_mul_mat_vec_fused_ss(s.job, s.njobs, s.K, s.x, s.norm_w, s.eps, s.ss_out, s.ss_in, s.n_ss, c->stream));
                 break;
             case mi355::STEP_ATTN:
                 MI355_CHECK(pm355_attn_token(&s.attn, &s.rope, c->stream));
@@ -627,7 +628,7 @@ bool run_plan(backend_ctx * c, struct ggml_cgraph * g, const mi355::plan & p) {
                 MI355_CHECK(pm355_rope_table(&s.rope, s.attn.d_pos, s.attn.freq_factors, (float *) s.qs.rope_table, c->stream));
                 break;
             case mi355::STEP_QKV:
-                MI355_CHECK(pm355_mul_mat_vec_qkv(s.job, s.K, s.x, s.norm_w, s.eps, &s.qs, c->stream));
+                MI355_CHECK(pm355_mul_mat_vec_qkv_ss(s.job, s.K, s.x, s.norm_w, s.eps, &s.qs, s.ss_in, s.n_ss, c->stream));
                 break;
             case mi355::STEP_ATTN_CACHED:
                 if (s.attn.split) {
@@ -664,7 +665,8 @@ void print_plan(const backend_ctx * c, struct ggml_cgraph * g, const mi355::plan
         if (s.kind == mi355::STEP_ROPE_TAB) {
             fprintf(stderr, "  [%d] rope table n_dims=%d mode=%d ff=%d\n", s.node_lo, s.rope.n_dims, s.rope.mode, s.attn.freq_factors != nullptr);
         } else if (s.kind == mi355::STEP_GEMV || s.kind == mi355::STEP_QKV) {
-            fprintf(stderr, "  [%d,%d) matvec%s K=%lld norm=%d jobs=%d:", s.node_lo, s.node_hi, s.kind == mi355::STEP_QKV ? " + rope + KV store" : "", (long long) s.K, s.norm_w != nullptr, s.njobs);
+            fprintf(stderr, "  [%d,%d) matvec%s K=%lld norm=%d%s%s jobs=%d:", s.node_lo, s.node_hi, s.kind == mi355::STEP_QKV ? " + rope + KV store" : "", (long long) s.K, s.norm_w != nullptr,
+                    s.ss_in ? " sumsq<-producer" : "", s.ss_out ? " sumsq->consumer" : "", s.njobs);
             for (int j = 0; j < s.njobs; ++j) fprintf(stderr, " {%s N=%lld%s%s%s}", ggml_type_name((enum ggml_type) s.job[j].type), (long long) s.job[j].N,
                                                      s.job[j].W2 ? " pair" : "", s.job[j].bias ? " +bias" : "", s.job[j].resid ? " +resid" : "");
             fprintf(stderr, "\n");
@@ -698,13 +700,14 @@ enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g)
     if (n_nodes == 0) return GGML_STATUS_SUCCESS;
     if (!c->d_dyn) { c->d_dyn = (int32_t *) dmalloc(64); GGML_ASSERT(c->d_dyn); }
     if (!c->rope_tab && c->qkv_epi) { c->rope_tab = (float *) dmalloc(1024 + 64); GGML_ASSERT(c->rope_tab); }
+    if (!c->ss_buf && c->use_ss) { c->ss_buf = (double *) dmalloc(2 * 256 * sizeof(double)); GGML_ASSERT(c->ss_buf); }
 
     { scoped_ns t1(g_ht.ns_fp); mi355::graph_fingerprint(g, c->fp_tmp); }
     graph_entry * e = nullptr;
     const auto t_plan0 = std::chrono::steady_clock::now();
     for (graph_entry * x : c->graphs) if (x->plan.fast_ok && mi355::fingerprint_equal(x->fp, c->fp_tmp)) { e = x; ++c->n_fp_hit; break; }
     if (!e) {
-        mi355::plan_ctx pc = { c, plan_qkv_scratch, plan_split_scratch, c->d_dyn, c->split_min, c->attn_mfma, c->fuse, c->qkv_epi ? c->rope_tab : nullptr, plan_same_bytes };
+        mi355::plan_ctx pc = { c, plan_qkv_scratch, plan_split_scratch, c->d_dyn, c->split_min, c->attn_mfma, c->fuse, c->qkv_epi ? c->rope_tab : nullptr, plan_same_bytes, c->use_ss ? c->ss_buf : nullptr };
         mi355::plan p;
         mi355::planner(g, pc).build(p);
         ++c->n_plan;
@@ -901,6 +904,7 @@ ggml_backend_t ggml_backend_mi355_init(int device) {
     c->fuse = !env_on("GGML_MI355_NO_FUSE");                          // node-by-node kernels only (debug / A-B)
     if (const char * am = getenv("GGML_MI355_ATTN_MFMA")) if (am[0] == '0') c->attn_mfma = false;
     if (const char * qe = getenv("GGML_MI355_QKV_EPI")) if (qe[0] == '0') c->qkv_epi = false;   // rope + KV store inside the attention kernel (round-2 form)
+    if (const char * se = getenv("GGML_MI355_SS")) if (se[0] == '0') c->use_ss = false;         // every rms_norm prologue reduces its own row (round-4 form)
     c->use_graphs = !env_on("GGML_MI355_NO_GRAPH") && !plan_only();   // no hipGraph capture / replay
     c->debug_plan = env_on("GGML_MI355_DEBUG_PLAN") || plan_only();
     if (const char * sm = getenv("GGML_MI355_ATTN_SPLIT_MIN")) if (sm[0]) c->split_min = atoi(sm);

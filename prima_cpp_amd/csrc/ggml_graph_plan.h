@@ -49,6 +49,9 @@ struct step {
     int32_t node_lo, node_hi;                        // graph nodes [lo, hi) this step stands for
     // STEP_GEMV
     int64_t K; int32_t njobs; float eps; const float * x; const float * norm_w; pm355_matvec_job job[3];
+    // producer-side sum of squares (pm355_mul_mat_vec_fused_ss): ss_out - this single-job launch leaves its per-workgroup partials there;
+    // ss_in / n_ss - the rms_norm of this launch (STEP_GEMV or STEP_QKV with norm_w) adds the n_ss partials the step right before it left
+    double * ss_out; const double * ss_in; int32_t n_ss; int32_t pad_ss_;
     // STEP_ATTN (STEP_ATTN_CACHED: the same arguments, q = rotated rows; STEP_ROPE_TAB: rope, attn.d_pos, attn.freq_factors, qs.rope_table)
     pm355_attn_token_args attn; pm355_rope_params rope;
     // STEP_QKV (with the STEP_GEMV fields)
@@ -84,6 +87,7 @@ struct plan_ctx {                                    // what the backend provide
     // (the per-layer copies of rope_freqs hold the same numbers: one table serves every layer)
     float * rope_tab = nullptr;
     bool (*same_bytes)(void * user, const void * a, const void * b, size_t n) = nullptr;
+    double * ss_buf = nullptr;                       // device double[2][256] for the producer-side sum-of-squares partials (null: off)
 };
 
 // ---- small pointer -> count map (open addressing; graphs have a few thousand nodes) ---------------------------------------
@@ -170,6 +174,24 @@ public:
             if (adv) { p.n_fused_nodes += adv; i += adv; continue; }
             emit_node(p, i);
             ++i;
+        }
+        wire_sumsq(p);
+    }
+
+    // Producer-side sum of squares: a fused mat-vec with rms_norm (wq | wk | wv, ffn_gate | ffn_up, lm_head) whose input row is exactly the output
+    // of the single-job mat-vec launched right before it (wo / ffn_down + residual) takes the sum of squares from that launch's per-workgroup
+    // partials. Adjacent steps only: nothing can have written the row in between.
+    void wire_sumsq(plan & p) {
+        if (!c_.ss_buf) return;
+        int flip = 0;
+        for (size_t i = 1; i < p.steps.size(); ++i) {
+            step & cs = p.steps[i]; step & pr = p.steps[i - 1];
+            if ((cs.kind != STEP_GEMV && cs.kind != STEP_QKV) || !cs.norm_w) continue;
+            if (pr.kind != STEP_GEMV || pr.njobs != 1 || pr.job[0].W2 || pr.job[0].y != cs.x || pr.job[0].N != cs.K) continue;
+            const int g = pm355_mul_mat_vec_fused_grid(pr.job, 1, pr.K);
+            if (g < 1 || g > 256) continue;
+            pr.ss_out = c_.ss_buf + 256 * flip; cs.ss_in = pr.ss_out; cs.n_ss = g;
+            flip ^= 1;
         }
     }
 

@@ -48,6 +48,26 @@ def test_decode_graph_lowers_to_five_launches_per_layer(name, nodes, tmp_path):
     assert f"{n_layer} multi-token attention chain(s) -> MFMA masked attention" in st["stderr"]
 
 
+@pytest.mark.parametrize("name", ["llama", "qwen2"])
+def test_rms_norm_sum_of_squares_is_wired_from_the_producing_launch(name, tmp_path):
+    """Round 5: wo / ffn_down (+ residual) leave per-workgroup partials of the next rms_norm's sum of squares; the planner wires every fused
+    norm + mat-vec whose input row is the output of the launch right before it (ffn_gate | ffn_up after wo in every layer; wq | wk | wv after
+    the previous layer's ffn_down). GGML_MI355_SS=0 turns the wiring off."""
+    z = np.load(os.path.join(HERE, "golden", f"tiny_{name}_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / f"tiny_{name}.gguf"), z)
+    n_layer = int(z["hp_n_layer"])
+    # (the LAST layer's wo output passes through GET_ROWS(inp_out_ids) + ADD nodes before its ffn_norm - src/llama.cpp:11141-11147 - so its
+    #  ffn_gate | ffn_up launch reduces the row itself, and the head is a graph of its own)
+    for ss, want in (("1", 2 * n_layer - 2), ("0", 0)):
+        _, _, st = run_llama_driver(path, z["prompt"][:3], 3, ngl=99, n_ctx=64, threads=1, extra_args=["--keep-out-in-cuda"],
+                                    env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1", "GGML_MI355_SS": ss}, flavour="avx2", timeout=120)
+        blocks = st["stderr"].split("ggml-mi355 plan: ")
+        decode = [b for b in blocks if "single_token=1" in b.split("\n")[0] and ") attention H=" in b]
+        assert decode, st["stderr"][-2000:]
+        for b in decode:
+            assert b.count("sumsq<-producer") == want and b.count("sumsq->consumer") == want, b[:3000]
+
+
 def test_flash_attn_decode_graph_lowers_to_five_launches_per_layer(tmp_path):
     """--flash-attn: CPY(V -> row of the row-major V cache), FLASH_ATTN_EXT(q, k, v, F16 mask) (llm_build_kv, src/llama.cpp:9705,
     :10075-10095) lower to the same five launches per layer; the once-per-graph F32 -> F16 cast of the KQ mask stays a node."""
