@@ -146,6 +146,9 @@ typedef struct {
 } pm355_matvec_job;
 PM355_API int pm355_mul_mat_vec_fused(const pm355_matvec_job * jobs, int njobs, int64_t K, const float * x_f32,
                                       const float * norm_w, float eps, pm355_stream_t stream);
+/* 1 when this build stores the tail of a Q6_K row per group of 8 blocks - scales[8][16] | d[8] - (round 5, csrc/pm355_device.h), 0 for the
+ * round-1..4 form scales[nb][16] | d[nb]; the streams in front of it (la | lb | qh) are the same. Tests build the expected HBM image from it. */
+PM355_API int pm355_q6k_tail_grouped(void);
 /* Producer-side sum of squares (round 5). The rms_norm in front of wq | wk | wv and of ffn_gate | ffn_up reads a row that the preceding wo / ffn_down
  * launch has just written: sumsq_out != NULL (ONE job, W2 == NULL) makes every workgroup of that launch store the f64 sum of the f32-rounded squares
  * of the output rows it wrote - the terms of ggml_compute_forward_rms_norm_f32's `sum += (ggml_float)(x[i] * x[i])`, ggml.c:11975-11980 - into

@@ -191,6 +191,7 @@ int pm355_mul_mat_vec_fused_ss(const pm355_matvec_job * jobs, int njobs, int64_t
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_q6k_tail_grouped(void) { return PM_Q6K_SCD ? 1 : 0; }
 int pm355_mul_mat_vec_fused_grid(const pm355_matvec_job * jobs, int njobs, int64_t K) {
     if (njobs < 1 || njobs > 3 || !jobs) return fail(PM355_E_RANGE, "mul_mat_vec_fused_grid: 1..3 jobs");
     pm_gemv_fused f = {};

@@ -177,7 +177,7 @@ __global__ void fix_scales_kernel(int type, uint8_t * dst, long nb_total, long n
         h[0] = f2h(u * scale / (qmax * 32.f));
         h[1] = f2h(u * scale / 64.f);
     } else if (type == PM_Q6_K) {
-        ((uint16_t *) (r + nb_row * 208))[bi] = f2h(u * scale / 2048.f);
+        *(uint16_t *) (r + pm_q6k_d_off((uint32_t) nb_row, (uint32_t) bi)) = f2h(u * scale / 2048.f);
     } else if (type == PM_Q8_0) {
         ((uint16_t *) (r + nb_row * 32))[bi] = f2h(u * scale / 64.f);
     }

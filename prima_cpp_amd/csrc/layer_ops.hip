@@ -48,8 +48,8 @@ __device__ float pm_dequant_elem(int type, const uint8_t * row, int K, int i) {
         const uint8_t lq = row[(k & 1) * nb * 64 + 16 * (4 * (long) b + 2 * hh + (l >> 4)) + (l & 15)];
         const uint8_t hq = row[nb * 128 + (long) b * 64 + 32 * hh + l];
         const int q = (int) (((k & 2) ? (lq >> 4) : (lq & 0xF)) | (((hq >> (2 * k)) & 3) << 4)) - 32;
-        const int sc = (int) (int8_t) row[nb * 192 + (long) b * 16 + 8 * hh + 2 * k + (l >> 4)];
-        const float d = h2f(((const uint16_t *) (row + nb * 208))[b]);
+        const int sc = (int) (int8_t) row[pm_q6k_sc_off((uint32_t) nb, (uint32_t) b) + 8 * hh + 2 * k + (l >> 4)];
+        const float d = h2f(*(const uint16_t *) (row + pm_q6k_d_off((uint32_t) nb, (uint32_t) b)));
         return d * (float) sc * (float) q;
     }
     }

@@ -52,7 +52,8 @@ __device__ __forceinline__ void fetch_w(const uint8_t * row, int K, int k0, int 
     const int hh = s >> 2, kq = s & 3;
     w.r[0] = *(const u32x4 *) (row + (kq & 1) * nb * 64 + 16 * (4 * (long) b + 2 * hh + part));
     w.r[1] = *(const u32x4 *) (row + nb * 128 + (long) b * 64 + 32 * hh + 16 * part);
-    w.s = (uint32_t) ((const uint8_t *) (row + nb * 192 + (long) b * 16 + 8 * hh + 2 * kq))[part] | ((uint32_t) ((const uint16_t *) (row + nb * 208))[b] << 16);
+    w.s = (uint32_t) ((const uint8_t *) (row + pm_q6k_sc_off((uint32_t) nb, (uint32_t) b) + 8 * hh + 2 * kq))[part] |
+          ((uint32_t) *(const uint16_t *) (row + pm_q6k_d_off((uint32_t) nb, (uint32_t) b)) << 16);
 }
 
 template <int TYPE>
@@ -395,8 +396,8 @@ __global__ __launch_bounds__(512) void gemm_q_f16_kernel2(GemmP p) {
                     R.w[0].r[0] = *(const u32x4 *) (wptr + (long) ahalf * nb * 64 + 16 * (4 * (long) b + 2 * hh));
                     R.w[0].r[1] = *(const u32x4 *) (wptr + (long) ahalf * nb * 64 + 16 * (4 * (long) b + 2 * hh + 1));
                     R.w[0].r[2] = *(const u32x4 *) (wptr + nb * 128 + (long) b * 64 + 32 * hh + 16 * ahalf);
-                    if (ahalf == 0) { const u32x2 s8 = *(const u32x2 *) (wptr + nb * 192 + (long) b * 16 + 8 * hh); R.w[1].r[0][0] = s8[0]; R.w[1].r[0][1] = s8[1]; }
-                    else R.w[1].r[0][0] = (uint32_t) ((const uint16_t *) (wptr + nb * 208))[b];
+                    if (ahalf == 0) { const u32x2 s8 = *(const u32x2 *) (wptr + pm_q6k_sc_off((uint32_t) nb, (uint32_t) b) + 8 * hh); R.w[1].r[0][0] = s8[0]; R.w[1].r[0][1] = s8[1]; }
+                    else R.w[1].r[0][0] = (uint32_t) *(const uint16_t *) (wptr + pm_q6k_d_off((uint32_t) nb, (uint32_t) b));
                 }
             } else {
                 fetch_w<TYPE>(wptr, p.K, k0 + 32 * ahalf, 0, R.w[0]);

@@ -60,11 +60,11 @@ __device__ __forceinline__ void dma16(const uint8_t * src, uint8_t * dst) {
 template <int TYPE> struct BT;
 template <> struct BT<PM_Q4_K> {
     static constexpr int NTN = 2, TN = 4 * 32 * NTN, NSTREAM = 2;          // row tiles per wave, rows per workgroup, 64-byte nibble streams per row
-    static constexpr int HDR_OFF = 128;                                    // hdr stream at nb * 128 + b * 16
+    static __device__ __forceinline__ long hdr_off(int nsb, int b) { return (long) nsb * 128 + (long) b * 16; }      // hdr stream at nb * 128 + b * 16
 };
 template <> struct BT<PM_Q6_K> {
     static constexpr int NTN = 1, TN = 4 * 32 * NTN, NSTREAM = 3;
-    static constexpr int HDR_OFF = 192;                                    // int8 scales at nb * 192 + b * 16 (d: nb * 208 + 2 b, read by the lanes)
+    static __device__ __forceinline__ long hdr_off(int nsb, int b) { return (long) pm_q6k_sc_off((uint32_t) nsb, (uint32_t) b); }   // int8 scales (d: pm_q6k_d_off, read by the lanes)
 };
 
 // LDS stage layout
@@ -85,7 +85,7 @@ __device__ __forceinline__ void issue_stage(const BigP & p, int b, uint8_t * buf
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const uint8_t * xb = p.xq + (long) b * 256, * tbs = p.tab + (long) b * 1024, * tdd = p.tab + (long) nsb * 1024 + (long) b * 128;
-    const uint8_t * wb = p.W + (long) b * 64, * hb = p.W + (long) nsb * B::HDR_OFF + (long) b * 16;
+    const uint8_t * wb = p.W + (long) b * 64, * hb = p.W + B::hdr_off(nsb, b);
     for (int q = wave; q < NQ; q += 8) {
         if (q < NQ_ACT) {                                   // 4 tokens x 256 bytes
             const int t = 4 * q + (ln >> 4), c = (ln & 15) ^ (t & 15);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NTHR, 2) void mmq_big_kernel(BigP p) {
 #pragma unroll
             for (int a = 0; a < NTN; ++a) {
                 const int ng = min(N0 + (wn * NTN + a) * 32 + r_, p.N - 1);
-                d[a] = *(const PM_G uint16_t *) (p.W + (long) ng * p.row_stride + (long) nsb * 208 + (long) b * 2);
+                d[a] = *(const PM_G uint16_t *) (p.W + (long) ng * p.row_stride + (long) pm_q6k_d_off((uint32_t) nsb, (uint32_t) b));
             }
         }
     };

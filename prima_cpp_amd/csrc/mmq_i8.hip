@@ -253,7 +253,7 @@ template <> struct MT<PM_Q6_K> {
         b.la[n] = ld_nt16(rw.at(n, u * 16u));
         b.lb[n] = ld_nt16(rw.at(n, (uint32_t) nb * 64u + u * 16u));
         b.qh[n] = ld_nt16(rw.at(n, (uint32_t) nb * 128u + u * 16u));
-        if (n == 0) b.s = ld_c16(rw.at_h((uint32_t) nb * 192u + sb * 16u));   // cached, like Q4_K's header
+        if (n == 0) b.s = ld_c16(rw.at_h(pm_q6k_sc_off((uint32_t) nb, sb)));   // cached, like Q4_K's header
         // (d: one 2-byte load per lane (row lane % 32, super-block 2 pr + lane / 32), issued by the kernel with its own row offset)
     }
     static __device__ __forceinline__ void stash(const B & b, uint8_t * L, int lane) {
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     // products keeps both busy.
     auto issue_b_part = [&](int pr, int n) __attribute__((always_inline)) {
         M::issue_b_part(R, rw, nbw, pr, lane, n);
-        if constexpr (TYPE == PM_Q6_K) if (n == 0) R.d = *(const PM_G uint16_t *) rw.at_d((uint32_t) nsb * 208u + (uint32_t) min(2 * pr + g, nsb - 1) * 2u);   // cached: 32 steps share the line
+        if constexpr (TYPE == PM_Q6_K) if (n == 0) R.d = *(const PM_G uint16_t *) rw.at_d(pm_q6k_d_off((uint32_t) nsb, (uint32_t) min(2 * pr + g, nsb - 1)));   // cached: 32 steps share the line
         if constexpr (Q80) if (n == 0) M::issue_ds(R, xs, pr);
     };
     auto issue_b = [&](int pr) __attribute__((always_inline)) {

@@ -96,7 +96,7 @@ size_t pm_weight_row_bytes(int type, int64_t K) {
 size_t pm_weight_row_stride(int type, int64_t K) {
     switch (type) {
         case PM_Q8_0: { const size_t nb = K / 32;  return nb * 32 + ((nb * 2 + 15) & ~(size_t) 15); }
-        case PM_Q6_K: { const size_t nb = K / 256; return nb * 208 + ((nb * 2 + 15) & ~(size_t) 15); }
+        case PM_Q6_K: return pm_q6k_row_stride((size_t) (K / 256));
     }
     return pm_weight_row_bytes(type, K);
 }

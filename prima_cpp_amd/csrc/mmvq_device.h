@@ -130,7 +130,7 @@ template <> struct QT<PM_Q5_K> {
 };
 
 // ---------------------------------------------------------------- Q6_K (row-SoA) --------------------
-// row: la[U][16] | lb[U][16] | qh[U][16] | scales[nb][16] | d[nb]      unit u = 4b + 2hh + v = (block b, half hh, 16-col slice v)
+// row: la[U][16] | lb[U][16] | qh[U][16] | per 8 blocks: scales[8][16] d[8] (pm355_device.h)   unit u = 4b + 2hh + v = (block b, half hh, 16-col slice v)
 //      la = ql[64hh+16v, +16), lb = ql[64hh+32+16v, +16), qh = qh[32hh+16v, +16): every load is one contiguous span per wave
 template <> struct QT<PM_Q6_K> {
     static constexpr int NV = 64, LPB = 4, ABLK = 256;
@@ -143,8 +143,16 @@ template <> struct QT<PM_Q6_K> {
         w.l0 = ld_nt16(row + (uint32_t) u * 16u);
         w.l1 = ld_nt16(row + nb * 64 + (uint32_t) u * 16u);
         w.h  = ld_nt16(row + nb * 128 + (uint32_t) u * 16u);
-        w.s  = ld_nt8(row + nb * 192 + (b * 16 + 8 * hh));
-        w.d  = ld_nt2(row + nb * 208 + b * 2);
+        // scales and d through the caches (round 5): a non-temporal load does not leave its line behind (mmq_i8.hip measured +29 % traffic for a
+        // header line shared by four nt loads) - with the round-4 tail streams the 128-byte line of d was fetched from HBM again by each of the four
+        // steps that share it; cached, the 2-byte load hits the line the scale load (or an earlier step) brought in. -DPM_Q6K_TAIL_NT=1: the round-4 loads
+#if defined(PM_Q6K_TAIL_NT) && PM_Q6K_TAIL_NT
+        w.s  = ld_nt8(row + (pm_q6k_sc_off(nb, b) + 8 * hh));
+        w.d  = ld_nt2(row + pm_q6k_d_off(nb, b));
+#else
+        w.s  = *(const PM_G u32x2 *) (row + (pm_q6k_sc_off(nb, b) + 8 * hh));
+        w.d  = *(const PM_G uint16_t *) (row + pm_q6k_d_off(nb, b));
+#endif
     }
     static __device__ __forceinline__ float consume(const Wr & w, const X & x, int u, float facc, int & isum, int & msum) {
         const int v = u & 1;

@@ -22,6 +22,21 @@ enum pm_type : int { PM_F32 = 0, PM_F16 = 1, PM_Q8_0 = 8, PM_Q4_K = 12, PM_Q5_K 
 #define PM_BS_Q6_K 210
 #define PM_BS_Q8_K 292
 
+// Q6_K row-SoA tail (round 5): after the three 64-byte-per-block streams (la | lb | qh: nb * 192 bytes) come, per GROUP of 8 blocks, the 8 x 16 int8
+// scales followed by the 8 fp16 super-block scales d (144 bytes): the 2-byte d a mat-vec lane loads sits in the cache lines its scale load has just
+// requested (separate `scales[nb][16] | d[nb]` streams: the 32 bytes of d a wave step needs were a line of their own, requested again by each of the
+// next three steps). -DPM_Q6K_SCD=0 keeps the separate streams (A/B). Same bytes per row whenever K % 2048 == 0.
+#ifndef PM_Q6K_SCD
+#define PM_Q6K_SCD 1
+#endif
+// (a last group of r < 8 blocks is scales[r][16] | d[r]: the row is 210 bytes per block rounded up to 16 in both forms)
+__host__ __device__ inline uint32_t pm_q6k_sc_off(uint32_t nb, uint32_t b) { return PM_Q6K_SCD ? nb * 192u + (b >> 3) * 144u + (b & 7u) * 16u : nb * 192u + b * 16u; }
+__host__ __device__ inline uint32_t pm_q6k_d_off(uint32_t nb, uint32_t b) {
+    const uint32_t left = nb - (b & ~7u), cnt = left < 8u ? left : 8u;                 // blocks in b's group
+    return PM_Q6K_SCD ? nb * 192u + (b >> 3) * 144u + cnt * 16u + (b & 7u) * 2u : nb * 208u + b * 2u;
+}
+__host__ __device__ inline size_t pm_q6k_row_stride(size_t nb) { return (nb * 210 + 15) & ~(size_t) 15; }
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 

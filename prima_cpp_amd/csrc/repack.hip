@@ -12,7 +12,8 @@
 // with native Q4_K blocks (header + 8 data pieces per 144 B). So each 16-byte "piece" a lane loads is its own stream
 // (U = units per row, a unit = the 64 weights (Q4_K/Q6_K) or 32 weights (Q8_0) one lane decodes at a time):
 //   Q4_K row (nb blocks, U = 4 nb): qa[U][16] | qb[U][16] | hdr[nb][16]           unit (b, j): qs[32j, +16) | qs[32j+16, +16)
-//   Q6_K row (nb blocks, U = 4 nb): la[U][16] | lb[U][16] | qh[U][16] | scales[nb][16] | d[nb]
+//   Q6_K row (nb blocks, U = 4 nb): la[U][16] | lb[U][16] | qh[U][16] | per group of 8 blocks: scales[8][16] | d[8]   (round 5, pm355_device.h;
+//                                   rounds 1-4 and -DPM_Q6K_SCD=0: scales[nb][16] | d[nb])
 //                                   unit (b, hh, v): ql[64hh+16v, +16) | ql[64hh+32+16v, +16) | qh[32hh+16v, +16)
 //   Q8_0 row (nb blocks, U = nb)  : qa[U][16] | qb[U][16] | d[nb]
 // Q5_K (176 = 11x16 B) stays native (identity): it only serves attn_v of the 70B mixture (2 % of the bytes).
@@ -35,8 +36,8 @@ __global__ __launch_bounds__(256) void repack_kernel(const uint16_t * __restrict
             so = second * nb * 64 + (4 * b + 2 * hh + v) * 16 + (r & 15);
         }
         else if (f < 192) so = nb * 128 + b * 64 + (f - 128);
-        else if (f < 208) so = nb * 192 + b * 16 + (f - 192);
-        else              so = nb * 208 + b * 2;
+        else if (f < 208) so = pm_q6k_sc_off((uint32_t) nb, (uint32_t) b) + (f - 192);
+        else              so = pm_q6k_d_off((uint32_t) nb, (uint32_t) b);
     } else if (type == PM_Q4_K) {
         const long b = o / PM_BS_Q4_K, f = o - b * PM_BS_Q4_K;
         if (f < 16) so = nb * 128 + b * 16 + f;                       // header: d, dmin, scales[12]

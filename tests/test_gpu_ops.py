@@ -90,8 +90,11 @@ def test_repack_roundtrip_bitexact(P, t, K):
             ql = b[:, :, :128].reshape(N, nb, 2, 2, 2, 16)          # [block][half hh][second][v][16]
             la = ql[:, :, :, 0].reshape(N, -1)                       # unit order (b, hh, v)
             lb = ql[:, :, :, 1].reshape(N, -1)
-            want = np.concatenate([la, lb, b[:, :, 128:192].reshape(N, -1),
-                                   b[:, :, 192:208].reshape(N, -1), b[:, :, 208:].reshape(N, -1)], axis=1)
+            if P.L.load().pm355_q6k_tail_grouped():                  # round 5: per group of <= 8 blocks scales[r][16] | d[r]
+                tail = [np.concatenate([b[:, g0:g0 + 8, 192:208].reshape(N, -1), b[:, g0:g0 + 8, 208:].reshape(N, -1)], axis=1) for g0 in range(0, nb, 8)]
+            else:
+                tail = [b[:, :, 192:208].reshape(N, -1), b[:, :, 208:].reshape(N, -1)]
+            want = np.concatenate([la, lb, b[:, :, 128:192].reshape(N, -1)] + tail, axis=1)
         elif t == Q4_K:
             nb = K // 256
             b = src.reshape(N, nb, 144)
