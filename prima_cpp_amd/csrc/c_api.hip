@@ -37,23 +37,28 @@ int pm355_device_info(int d, char * name, size_t name_len, size_t * free_b, size
     }
     return 0;
 }
-// Is `p` page-locked host memory? Asked for every small upload of a token (positions, mask, ...): the driver call (and, for pageable memory,
-// the error it returns) is paid once per 4 KiB page - a direct-mapped cache of verdicts, flushed whenever this library allocates or frees
-// pinned memory itself (pm355_host_malloc / pm355_host_free: the plug-in's host buffer type), the one way a page's status changes under it.
-// (A "pinned" verdict that has gone stale only costs a wait; a page the application pins later by other means is seen after the next flush.)
-namespace { struct PinE { uintptr_t page; int pinned; }; PinE g_pin[256] = {}; std::atomic<unsigned> g_pin_gen{1}; unsigned g_pin_seen = 0; std::mutex g_pin_mu; }
+// Is `p` page-locked host memory? Asked for every small upload of a token (positions, mask, ...). Only POSITIVE verdicts are cached (per 4 KiB page,
+// direct-mapped, flushed whenever this library allocates or frees pinned memory itself - pm355_host_malloc / pm355_host_free, the plug-in's host
+// buffer type): a stale "pinned" costs one wait, but a cached "pageable" for a page somebody pins later (hipHostRegister, another library's pinned
+// allocator) would let set_tensor return while the DMA still reads the source - pageable pages ask the runtime every time.
+namespace { struct PinE { uintptr_t page; }; PinE g_pin[256] = {}; std::atomic<unsigned> g_pin_gen{1}; unsigned g_pin_seen = 0; std::mutex g_pin_mu; }
 int pm355_host_is_pinned(const void * p) {
     const uintptr_t page = ((uintptr_t) p >> 12) + 1;                 // (+1: 0 marks an empty slot)
-    std::lock_guard<std::mutex> lk(g_pin_mu);
-    const unsigned gen = g_pin_gen.load(std::memory_order_acquire);
-    if (gen != g_pin_seen) { memset(g_pin, 0, sizeof(g_pin)); g_pin_seen = gen; }
-    PinE & e = g_pin[page & 255];
-    if (e.page == page) return e.pinned;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        const unsigned gen = g_pin_gen.load(std::memory_order_acquire);
+        if (gen != g_pin_seen) { memset(g_pin, 0, sizeof(g_pin)); g_pin_seen = gen; }
+        if (g_pin[page & 255].page == page) return 1;
+    }
+    const unsigned gen0 = g_pin_gen.load(std::memory_order_acquire);
     hipPointerAttribute_t a;
     int pinned = 0;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) (void) hipGetLastError();                   // unknown to the runtime: pageable
     else pinned = a.type == hipMemoryTypeHost ? 1 : 0;
-    e.page = page; e.pinned = pinned;
+    if (pinned) {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        if (g_pin_gen.load(std::memory_order_acquire) == gen0 && g_pin_seen == gen0) g_pin[page & 255].page = page;   // (an allocation raced the query: do not cache)
+    }
     return pinned;
 }
 int pm355_sync_null_stream(void) { HIP_TRY(hipStreamSynchronize(nullptr)); return 0; }
@@ -69,8 +74,9 @@ int pm355_event_sync(pm355_event_t e) { HIP_TRY(hipEventSynchronize((hipEvent_t)
 
 void * pm355_malloc(size_t n) { void * p = nullptr; return hipMalloc(&p, n) == hipSuccess ? p : nullptr; }
 void   pm355_free(void * p) { if (p) (void) hipFree(p); }
-void * pm355_host_malloc(size_t n) { void * p = nullptr; g_pin_gen.fetch_add(1, std::memory_order_release); return hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
-void   pm355_host_free(void * p) { g_pin_gen.fetch_add(1, std::memory_order_release); if (p) (void) hipHostFree(p); }
+// (the generation moves AFTER the runtime has changed the status of the pages: a query that overlaps the call re-asks the runtime next time)
+void * pm355_host_malloc(size_t n) { void * p = nullptr; const bool ok = hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess; g_pin_gen.fetch_add(1, std::memory_order_release); return ok ? p : nullptr; }
+void   pm355_host_free(void * p) { if (p) (void) hipHostFree(p); g_pin_gen.fetch_add(1, std::memory_order_release); }
 int pm355_memcpy_h2d(void * d, const void * s, size_t n, pm355_stream_t st) { HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, S(st))); return 0; }
 int pm355_memcpy_d2h(void * d, const void * s, size_t n, pm355_stream_t st) { HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, S(st))); return 0; }
 int pm355_memcpy_d2d(void * d, const void * s, size_t n, pm355_stream_t st) { HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, S(st))); return 0; }

@@ -143,10 +143,9 @@ template <> struct QT<PM_Q6_K> {
         w.l0 = ld_nt16(row + (uint32_t) u * 16u);
         w.l1 = ld_nt16(row + nb * 64 + (uint32_t) u * 16u);
         w.h  = ld_nt16(row + nb * 128 + (uint32_t) u * 16u);
-        // scales and d through the caches (round 5): a non-temporal load does not leave its line behind (mmq_i8.hip measured +29 % traffic for a
-        // header line shared by four nt loads) - with the round-4 tail streams the 128-byte line of d was fetched from HBM again by each of the four
-        // steps that share it; cached, the 2-byte load hits the line the scale load (or an earlier step) brought in. -DPM_Q6K_TAIL_NT=1: the round-4 loads
-#if defined(PM_Q6K_TAIL_NT) && PM_Q6K_TAIL_NT
+        // (round 5, measured: scales and d through the caches instead of non-temporal - so that the four steps sharing the 128-byte line of d hit it -
+        //  is 2.1 % SLOWER on the 70B token, with either tail layout: profiles/r05_ab_sumsq_q6k_tail.txt. -DPM_Q6K_TAIL_NT=0 builds the cached loads)
+#if !defined(PM_Q6K_TAIL_NT) || PM_Q6K_TAIL_NT
         w.s  = ld_nt8(row + (pm_q6k_sc_off(nb, b) + 8 * hh));
         w.d  = ld_nt2(row + pm_q6k_d_off(nb, b));
 #else

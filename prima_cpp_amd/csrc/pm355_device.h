@@ -26,8 +26,10 @@ enum pm_type : int { PM_F32 = 0, PM_F16 = 1, PM_Q8_0 = 8, PM_Q4_K = 12, PM_Q5_K 
 // scales followed by the 8 fp16 super-block scales d (144 bytes): the 2-byte d a mat-vec lane loads sits in the cache lines its scale load has just
 // requested (separate `scales[nb][16] | d[nb]` streams: the 32 bytes of d a wave step needs were a line of their own, requested again by each of the
 // next three steps). -DPM_Q6K_SCD=0 keeps the separate streams (A/B). Same bytes per row whenever K % 2048 == 0.
+// Measured (profiles/r05_ab_sumsq_q6k_tail.txt): the grouped tail changes nothing and tail loads through the caches cost 2 % of the 70B token
+// (the nt loads' re-fetch of the d line is the cheaper evil) - the default stays the round-4 form; -DPM_Q6K_SCD=1 builds the grouped tail.
 #ifndef PM_Q6K_SCD
-#define PM_Q6K_SCD 1
+#define PM_Q6K_SCD 0
 #endif
 // (a last group of r < 8 blocks is scales[r][16] | d[r]: the row is 210 bytes per block rounded up to 16 in both forms)
 __host__ __device__ inline uint32_t pm_q6k_sc_off(uint32_t nb, uint32_t b) { return PM_Q6K_SCD ? nb * 192u + (b >> 3) * 144u + (b & 7u) * 16u : nb * 192u + b * 16u; }
