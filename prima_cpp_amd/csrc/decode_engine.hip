@@ -1,0 +1,750 @@
+// decode_engine.hip — the single-token layer stack as ONE persistent launch on a run-ahead LDS-DMA weight loader (round 5).
+//
+// What it replaces: the five launches per layer of engine.hip's run_layers_fused (mmvq.hip + attn_cached.hip), i.e. the same reference
+// nodes - ggml_compute_forward_mul_mat over ggml_vec_dot_q4_K/q5_K/q6_K_q8_K with quantize_row_q8_K and rms_norm fused in front
+// (ggml.c:12377, ggml-quants.c:7713 / 8281 / 8918 / 3785, ggml.c:11950), rope + F16 KV store (ggml.c:14143, src/llama.cpp:9673-9718),
+// attention over cached cells (ggml.c:12445-12473, :13783-13879), silu * mul, residual adds - with the SAME device arithmetic (QT<>::consume,
+// q8k_rows_to_lds, write_out, write_out_qkv, the attn_cached / attn_rope_body bodies): outputs are bit-identical to the five-launch path except
+// for ffn_down, whose K = 28672 rows are summed chunk by chunk here (ring capacity) and lane by lane there (summation order, ~1e-7 relative).
+//
+// Why (profiles/r05_engine_seam_cost.txt, r05_seam_anatomy_sumsq.txt): a 70B layer is 75 us of weight streaming plus five dependent all-to-all
+// seams. As kernel boundaries each seam costs ~6.2 us (boundary 2.5 + activation fetch + quantizing prologue + ramp and tail) during which HBM
+// idles: 110 us per layer. Inside one launch a seam is a device-wide barrier + the same fetch / quantize (2-5 us), and a DEDICATED loader wave
+// keeps streaming the NEXT phase's weights into an LDS ring while the consumers sit in the seam - weights do not depend on activations: the
+// skeleton of this structure measured 92 us per layer on the box whose five launches take 110 (MI355X_MICROARCH.md "engine-vs-launches",
+// "prefetch-credit").
+//
+// Structure: one 1024-thread workgroup per CU (all resident: the device-wide barrier needs that), wave 15 = loader, waves 0-14 = consumers.
+//   * loader: walks every mat-vec phase of the launch in order; the rows of this workgroup are cut into ITEMS (a whole row of <= 2 steps, or one
+//     step of a long / split row; a step = 64 units = what a wave consumes with one instruction stream); an item's bytes are gathered with
+//     global_load_lds_dwordx4 ... nt into a ring-resident image [stream pieces of the step, lane-major] (the per-lane source addresses do the
+//     row-SoA -> step-major permutation), at most 48 DMA instructions in flight; item offsets and a monotonic `landed` counter live in LDS.
+//   * consumers: item n of the launch goes to wave n % 15; a wave waits for landed > n, reads the image with ds_read_b128 (conflict-free), runs the
+//     mat-vec's own consume() against the LDS-resident Q8_K activation, parks the row result, retires the item (done[wave]).
+//   * seam: results -> epilogue (bias / residual / silu*mul / RoPE + KV store, all write-through sc1 stores) -> consumer barrier -> two-level
+//     device-wide arrival -> wait -> consumers fetch the next activation row with sc1 loads and quantize it (rms_norm from the producer-side
+//     partial sums of squares: no reduction, no extra barrier).
+// Every wait is bounded; a time-out raises the launch's watchdog word and every later wait of that workgroup returns at once.
+#include "mmvq_device.h"
+#include "attn_device.h"
+#include "pm355_engine.h"
+#include <vector>
+#include <stdio.h>
+
+using namespace pmv;
+
+namespace {
+
+constexpr int ENG_NW = 16, ENG_NC = 15, ENG_THREADS = ENG_NW * 64;
+constexpr int ENG_RING = 120 * 1024;                       // bytes of weight images in flight per CU
+constexpr int ENG_ACT = 36864;                             // Q8_K activation row: q[K] | group sums[K/16] | d[K/256], K <= 28672 (also the attention scratch)
+constexpr int ENG_OUTF = 640;                              // parked results per workgroup (floats)
+constexpr int ENG_LDS = ENG_RING + ENG_ACT + ENG_OUTF * 4;
+constexpr int ENG_VMAX = 48;                               // DMA instructions in flight (the counter has 6 bits)
+constexpr int ENG_MAXG = 1024;
+
+struct EngPhase {
+    int kind;                                              // 0 = mat-vec, 1 = attention over cached cells
+    int ta, tb, pair, epi;
+    GemvP g;
+    const float * aq; uint16_t * akc, * avc; const int32_t * apos, * aseq; long aseq_stride; float * aout;
+    int aH, aHkv, adh, an_ctx, amax_keys; float ascale;
+};
+struct EngArgs { const EngPhase * ph; int n_ph; unsigned * ctr; int * err; };
+
+typedef __attribute__((address_space(3))) void * lds_vp;
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+
+// LDS control block. Accessed ONLY through LDS-typed pointers (a generic access is FLAT: it waits on vmcnt too and would drain the loader's queue);
+// the loader's own accesses are inline asm (a compiler-visible LDS access after global_load_lds gets an s_waitcnt vmcnt(0) in front of it).
+struct Ctl { unsigned landed, cbar, abar, giveup; unsigned done[16]; unsigned item_off[64]; };
+
+__device__ __forceinline__ lds_u32 * L(unsigned * p) { return (lds_u32 *) p; }
+__device__ __forceinline__ unsigned lds_ld(unsigned * p) { return __hip_atomic_load(L(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(unsigned * p, unsigned v) { __hip_atomic_store(L(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st_asm(unsigned * p, unsigned v) { asm volatile("ds_write_b32 %0, %1" :: "v"((unsigned) (uintptr_t) L(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ unsigned lds_ld_asm(unsigned * p) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned) (uintptr_t) L(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ void give_up(Ctl * c, int * err, int code, bool asm_path) {
+    if (asm_path) lds_st_asm(&c->giveup, 1); else lds_st(&c->giveup, 1);
+    __hip_atomic_store((PM_G int *) err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// consumers: wait until *word >= target (one poll per wave instruction; every lane reads the same address)
+__device__ __forceinline__ bool spin_ge(unsigned * word, unsigned target, Ctl * c, int * err, int code) {
+    int spins = 0;
+    while ((int) (lds_ld(word) - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (lds_ld(&c->giveup)) return false;
+        if (++spins > (1 << 22)) { give_up(c, err, code, false); return false; }
+    }
+    return true;
+}
+// barrier of `n` waves on a monotonic LDS counter (gen-th use completes at gen * n arrivals)
+__device__ __forceinline__ void wbar(unsigned * ctr, unsigned & gen, int n, int lane, Ctl * c, int * err, int code) {
+    ++gen;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): this wave's LDS writes are done
+    if (lane == 0) {
+        __hip_atomic_fetch_add(L(ctr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        spin_ge(ctr, gen * (unsigned) n, c, err, code);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- device-wide barrier: groups of 16 workgroups count on their own line, the last of a group counts on the top line, the last of all publishes
+// the phase number on every group's flag line (256 atomics on ONE counter cost 20 us; two levels 2.1 us: DESIGN_HISTORY.md section 6) -------------
+__device__ __forceinline__ void g_arrive(unsigned * ctr, unsigned phase, unsigned ngroups, unsigned gsize, bool last) {
+    unsigned * g = ctr + 32 * (1 + blockIdx.x / gsize);
+    const unsigned old = __hip_atomic_fetch_add((PM_G unsigned *) g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((old + 1) % gsize == 0) {
+        const unsigned t = __hip_atomic_fetch_add((PM_G unsigned *) ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1 == ngroups * (phase + 1)) {
+            if (last) {                                    // the launch's last arrival re-arms the counters (nobody waits on the last phase)
+                __hip_atomic_store((PM_G unsigned *) ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (unsigned k = 0; k < ngroups; ++k) {
+                    __hip_atomic_store((PM_G unsigned *) (ctr + 32 * (1 + k)), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store((PM_G unsigned *) (ctr + 32 * (1 + ENG_MAXG / 16 + k)), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                for (unsigned k = 0; k < ngroups; ++k)
+                    __hip_atomic_store((PM_G unsigned *) (ctr + 32 * (1 + ENG_MAXG / 16 + k)), phase + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void g_wait(unsigned * ctr, unsigned phase, unsigned gsize, Ctl * c, int * err) {   // phases 0 .. phase - 1 complete
+    const unsigned * flag = ctr + 32 * (1 + ENG_MAXG / 16 + blockIdx.x / gsize);
+    int spins = 0;
+    while (__hip_atomic_load((const PM_G unsigned *) flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase) {
+        __builtin_amdgcn_s_sleep(2);
+        if (lds_ld(&c->giveup)) return;
+        if (++spins > (1 << 21)) { give_up(c, err, 3, false); return; }
+    }
+}
+
+// ---- coherent (agent-scope, sc1) buffer accesses: tracked by the compiler's waitcnt logic, 16 bytes per instruction ---------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t coh_rsrc(const void * base) { return __builtin_amdgcn_make_buffer_rsrc((void *) base, 0, 0x7FFFFFF0, 0x00020000); }
+__device__ __forceinline__ float4 coh_ld16(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    const u32x4 t = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int) off, 0, 16));
+    return make_float4(__builtin_bit_cast(float, t[0]), __builtin_bit_cast(float, t[1]), __builtin_bit_cast(float, t[2]), __builtin_bit_cast(float, t[3]));
+}
+__device__ __forceinline__ u32x4 coh_ld16u(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int) off, 0, 16)); }
+__device__ __forceinline__ float coh_ld4(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int) off, 0, 16)); }
+
+// ---- ring image of one STEP of a row: the pieces a wave reads with one instruction each, lane-major ------------------------------------------
+//   Q4_K (2304 B): qa[64][16] | qb[64][16] | hdr[16][16]                    Q6_K (3360 B): la[64][16] | lb[64][16] | qh[64][16] | scales[16][16] | d[16]
+//   Q5_K (2816 B): the step's 16 native 176-byte blocks (two 32-weight units per lane and step)
+template <int TYPE> struct ST;
+template <> struct ST<PM_Q4_K> { static constexpr int BYTES = 2304, NDMA = 3; };
+template <> struct ST<PM_Q6_K> { static constexpr int BYTES = 3360, NDMA = 5; };
+template <> struct ST<PM_Q5_K> { static constexpr int BYTES = 2816, NDMA = 3; };
+
+__device__ __forceinline__ void dma16(const uint8_t * src, char * dst /*wave-uniform*/) {
+    __builtin_amdgcn_global_load_lds((const PM_G void *) src, (lds_vp) dst, 16, 0, 2);        // aux 2 = nt: streamed once (nt-weights)
+}
+__device__ __forceinline__ void dma4(const uint8_t * src, char * dst) {
+    __builtin_amdgcn_global_load_lds((const PM_G void *) src, (lds_vp) dst, 4, 0, 2);
+}
+// gather step `c` of `row` into the ring at dst (unit / block indices clamped into the row: a tail step repeats the last unit, whose products the
+// consumer zeroes exactly like the mat-vec's clamped loads)
+template <int TYPE>
+__device__ __forceinline__ void dma_step(char * dst, const uint8_t * row, int K, int U, int c, int lane) {
+    const uint32_t nb = (uint32_t) K / 256;
+    if (TYPE == PM_Q4_K) {
+        const uint32_t u = (uint32_t) min(64 * c + lane, U - 1);
+        dma16(row + u * 16u, dst);
+        dma16(row + nb * 64 + u * 16u, dst + 1024);
+        if (lane < 16) dma16(row + nb * 128 + (uint32_t) min(16 * c + lane, (int) nb - 1) * 16u, dst + 2048);
+    } else if (TYPE == PM_Q6_K) {
+        static_assert(PM_Q6K_SCD == 0, "the engine's d gather assumes the contiguous d[nb] stream");
+        const uint32_t u = (uint32_t) min(64 * c + lane, U - 1);
+        dma16(row + u * 16u, dst);
+        dma16(row + nb * 64 + u * 16u, dst + 1024);
+        dma16(row + nb * 128 + u * 16u, dst + 2048);
+        if (lane < 16) dma16(row + pm_q6k_sc_off(nb, (uint32_t) min(16 * c + lane, (int) nb - 1)), dst + 3072);
+        if (lane < 8) dma4(row + pm_q6k_d_off(nb, (uint32_t) min(16 * c + 2 * lane, ((int) nb - 1) & ~1)), dst + 3328);      // (two d per lane: an even block index keeps the 4-byte source aligned)
+    } else {                                               // Q5_K: 16 native blocks = 2816 contiguous bytes
+        const uint32_t b0 = 16u * (uint32_t) c, lim = nb * PM_BS_Q5_K - 16u;
+        const uint32_t o = b0 * PM_BS_Q5_K + (uint32_t) lane * 16u;
+        dma16(row + min(o, lim), dst);
+        dma16(row + min(o + 1024u, lim), dst + 1024);
+        if (lane < 48) dma16(row + min(o + 2048u, lim), dst + 2048);
+    }
+}
+// the step's weight registers of this lane, from the ring image
+template <int TYPE> struct LW;
+template <> struct LW<PM_Q4_K> {
+    static __device__ __forceinline__ void get(typename QT<PM_Q4_K>::Wr (&w)[1], const char * b, int lane) {
+        w[0].q0 = *(const u32x4 *) (b + lane * 16); w[0].q1 = *(const u32x4 *) (b + 1024 + lane * 16); w[0].h = *(const u32x4 *) (b + 2048 + (lane >> 2) * 16);
+    }
+};
+template <> struct LW<PM_Q6_K> {
+    static __device__ __forceinline__ void get(typename QT<PM_Q6_K>::Wr (&w)[1], const char * b, int lane) {
+        w[0].l0 = *(const u32x4 *) (b + lane * 16); w[0].l1 = *(const u32x4 *) (b + 1024 + lane * 16); w[0].h = *(const u32x4 *) (b + 2048 + lane * 16);
+        w[0].s = *(const u32x2 *) (b + 3072 + (lane >> 2) * 16 + 8 * ((lane >> 1) & 1));
+        w[0].d = *(const uint16_t *) (b + 3328 + (lane >> 2) * 2);
+    }
+};
+template <> struct LW<PM_Q5_K> {
+    static __device__ __forceinline__ void get(typename QT<PM_Q5_K>::Wr (&w)[2], const char * b, int lane) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ul = lane + 64 * i, hb = (ul >> 3) * PM_BS_Q5_K;
+            w[i].q = *(const u32x4 *) (b + hb + 48 + 16 * (ul & 7)); w[i].qh = *(const u32x4 *) (b + hb + 16 + 16 * (ul & 1)); w[i].h = *(const u32x4 *) (b + hb);
+        }
+    }
+};
+
+// items of a job inside one workgroup, as both the loader and the consumers count them
+struct JobGeo { int r0, r1, cpr, split, items, steps /*per item*/, bytes /*per item*/, ob /*first result slot*/, nres /*result slots*/; };
+__device__ __forceinline__ int type_cpr(int type, int U) { const int upl = (U + 63) >> 6, ch = (type == PM_Q4_K || type == PM_Q6_K) ? PM_CH64 : PM_CH32; return (upl + ch - 1) / ch; }
+__device__ __forceinline__ int type_step_bytes(int type) { return type == PM_Q4_K ? ST<PM_Q4_K>::BYTES : type == PM_Q6_K ? ST<PM_Q6_K>::BYTES : ST<PM_Q5_K>::BYTES; }
+__device__ __forceinline__ JobGeo job_geo(const GemvJob & jb, int type, int pair, int b, int G, int ob) {
+    JobGeo g;
+    g.r0 = (int) ((long) jb.N * b / G); g.r1 = (int) ((long) jb.N * (b + 1) / G);
+    g.cpr = type_cpr(type, jb.U);
+    g.split = jb.split;
+    g.items = g.split ? (g.r1 - g.r0) * g.cpr : (g.r1 - g.r0);
+    g.steps = g.split ? 1 : g.cpr;
+    g.bytes = g.steps * type_step_bytes(type) * (pair ? 2 : 1);
+    g.ob = ob; g.nres = g.items;
+    return g;
+}
+
+// v = value in lane `idx` (both wave-uniform), the other lanes keep theirs (v_writelane with two SGPR operands violates the constant-bus rule on
+// gfx9 and M0 belongs to the DMA instructions: a compare + select does it)
+__device__ __forceinline__ void write_lane(int & v, int value, int idx, int lane) { v = lane == idx ? value : v; }
+
+// ---- loader wave ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void loader_wave(const EngArgs & A, Ctl * c, char * ring, int lane) {
+    const int b = blockIdx.x, G = gridDim.x;
+    unsigned n = 0;                                        // items issued so far (launch-wide, this CU)
+    unsigned cur = 0, U_ = 0;                              // ring cursor; the same unwrapped (skipped tails included)
+    unsigned cum = 0;                                      // DMA instructions issued
+    unsigned tail = 0, m_landed = 0;                       // oldest item not yet retired (cached); items published as landed
+    int fifoU = 0, fifoC = 0;                              // lane (i % 64): unwrapped start / instruction count after item i
+    auto refresh_tail = [&]() __attribute__((always_inline)) {
+        unsigned v = lane < ENG_NC ? (unsigned) lane + lds_ld_asm(&c->done[lane < ENG_NC ? lane : 0]) * (unsigned) ENG_NC : 0xFFFFFFFFu;
+        unsigned t = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < ENG_NC; ++i) t = min(t, (unsigned) __builtin_amdgcn_readlane((int) v, i));
+        tail = min(t, n);
+    };
+    auto publish = [&]() __attribute__((always_inline)) {     // items whose last instruction is older than the ENG_VMAX newest have landed
+        while (m_landed < n && (unsigned) __builtin_amdgcn_readlane(fifoC, (int) (m_landed & 63)) + (unsigned) ENG_VMAX <= cum) ++m_landed;
+        if (lane == 0) lds_st_asm(&c->landed, m_landed);
+    };
+    const EngPhase * phs = uniform_const_ptr(A.ph);
+    for (int pi = 0; pi < A.n_ph; ++pi) {
+        const EngPhase * ph = phs + pi;
+        if (ph->kind != 0) continue;
+        const int K = ph->g.K, pair = ph->pair, ta = ph->ta, tb = ph->tb;
+        for (int j = 0; j < 3; ++j) {
+            const int N = ph->g.job[j].N;
+            if (N <= 0) continue;
+            GemvJob jb = ph->g.job[j];
+            const int type = jb.is_b ? tb : ta;
+            const JobGeo jg = job_geo(jb, type, pair, b, G, 0);
+            const int sb = type_step_bytes(type);
+            for (int it = 0; it < jg.items; ++it) {
+                const int lrow = jg.r0 + (jg.split ? it / jg.cpr : it), c0 = jg.split ? it % jg.cpr : 0;
+                // ---- place: the image may not overlap an item that has not been retired (live window [start of `tail`, end of this item) <= ring)
+                if (cur + (unsigned) jg.bytes > (unsigned) ENG_RING) { U_ += (unsigned) ENG_RING - cur; cur = 0; }
+                auto fits = [&]() __attribute__((always_inline)) {
+                    return tail >= n || U_ + (unsigned) jg.bytes - (unsigned) __builtin_amdgcn_readlane(fifoU, (int) (tail & 63)) <= (unsigned) ENG_RING;
+                };
+                int spins = 0;
+                while (!fits()) {
+                    refresh_tail();
+                    if (fits()) break;
+                    // ring full: nothing can be issued anyway -> drain and publish everything in flight, then wait for a retirement
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    m_landed = n;
+                    if (lane == 0) lds_st_asm(&c->landed, n);
+                    __builtin_amdgcn_s_sleep(1);
+                    if (lds_ld_asm(&c->giveup)) return;
+                    if (++spins > (1 << 22)) { give_up(c, A.err, 1, true); return; }
+                }
+                // ---- issue
+                char * dst = ring + cur;
+                const uint8_t * row = jb.W + (long) job_row(jb, lrow) * jb.row_stride;
+                int ndma;
+                if (type == PM_Q4_K) {
+                    for (int s = 0; s < jg.steps; ++s) dma_step<PM_Q4_K>(dst + s * sb, row, K, jb.U, c0 + s, lane);
+                    if (pair) { const uint8_t * row2 = jb.W2 + (long) lrow * jb.row_stride; for (int s = 0; s < jg.steps; ++s) dma_step<PM_Q4_K>(dst + (jg.steps + s) * sb, row2, K, jb.U, c0 + s, lane); }
+                    ndma = ST<PM_Q4_K>::NDMA;
+                } else if (type == PM_Q6_K) {
+                    for (int s = 0; s < jg.steps; ++s) dma_step<PM_Q6_K>(dst + s * sb, row, K, jb.U, c0 + s, lane);
+                    if (pair) { const uint8_t * row2 = jb.W2 + (long) lrow * jb.row_stride; for (int s = 0; s < jg.steps; ++s) dma_step<PM_Q6_K>(dst + (jg.steps + s) * sb, row2, K, jb.U, c0 + s, lane); }
+                    ndma = ST<PM_Q6_K>::NDMA;
+                } else {
+                    for (int s = 0; s < jg.steps; ++s) dma_step<PM_Q5_K>(dst + s * sb, row, K, jb.U, c0 + s, lane);
+                    if (pair) { const uint8_t * row2 = jb.W2 + (long) lrow * jb.row_stride; for (int s = 0; s < jg.steps; ++s) dma_step<PM_Q5_K>(dst + (jg.steps + s) * sb, row2, K, jb.U, c0 + s, lane); }
+                    ndma = ST<PM_Q5_K>::NDMA;
+                }
+                cum += (unsigned) (ndma * jg.steps * (pair ? 2 : 1));
+                write_lane(fifoU, (int) U_, (int) (n & 63), lane);
+                write_lane(fifoC, (int) cum, (int) (n & 63), lane);
+                if (lane == 0) lds_st_asm(&c->item_off[n & 63], cur);
+                cur += (unsigned) jg.bytes; U_ += (unsigned) jg.bytes;
+                ++n;
+                asm volatile("s_waitcnt vmcnt(48)" ::: "memory");            // (ENG_VMAX)
+                publish();
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) lds_st_asm(&c->landed, n);
+}
+
+// ---- consumers ---------------------------------------------------------------------------------------------------------------------------------
+// one item: `steps` steps of a row (both matrices of a pair), products against the LDS activation row; the wave's sum goes to out[slot]
+template <int TYPE, bool PAIR>
+__device__ __forceinline__ void eat_item(const char * img, int U, const XLds & xs, int c0, int steps, int lane, float * out_slot) {
+    typedef QT<TYPE> T;
+    constexpr int CH = T::NV == 64 ? PM_CH64 : PM_CH32, NM = PAIR ? 2 : 1;
+    float acc[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) acc[m] = 0.0f;
+    for (int s = 0; s < steps; ++s) {
+        typename T::Wr w[NM][CH];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) LW<TYPE>::get(w[m], img + (m * steps + s) * ST<TYPE>::BYTES, lane);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int uu = lane + 64 * ((c0 + s) * CH + i);
+            const bool uv = uu < U;
+            const int u = min(uu, U - 1);
+            typename T::X x;
+            load_x_lds<TYPE>(x, xs, u, 0);
+            x.yd = uv ? x.yd : 0.0f;                       // a clamped (out-of-row) unit contributes exactly 0
+#pragma unroll
+            for (int m = 0; m < NM; ++m) { int isum, msum; acc[m] = T::consume(w[m][i], x, u, acc[m], isum, msum); }
+        }
+    }
+    float o[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) o[m] = wave_sum(acc[m]);
+    if (lane == 0) *out_slot = PAIR ? silu_f(o[0]) * o[NM - 1] : o[0];
+}
+
+// the activation row of a mat-vec phase -> Q8_K in LDS (quantize_row_q8_K_ref bits: q8k_rows_to_lds), after an optional rms_norm whose sum of
+// squares comes from the producing phase's partials. 15 waves, 4 blocks per wave and pass, <= 2 passes (<= 1 with norm weights).
+__device__ __forceinline__ void eng_prologue(const GemvP & p, int8_t * xs_q, int * xs_gs, float * xs_d, int wave, int lane) {
+    const int K = p.K, nblk = K / 256, r = lane >> 4, j = lane & 15;
+    const __amdgpu_buffer_rsrc_t rx = coh_rsrc(p.xf);
+    const bool norm = p.xmode == 3;
+    double ssp[4] = {0.0, 0.0, 0.0, 0.0};
+    if (norm) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (lane + 64 * i < p.n_ss) ssp[i] = __hip_atomic_load((const PM_G double *) (p.ss_in + lane + 64 * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float4 f[2][4], g[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) if (4 * ENG_NC * t < nblk) {
+        const int B = min(4 * (wave + ENG_NC * t) + r, nblk - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f[t][k] = coh_ld16(rx, (uint32_t) (B * 64 + 16 * k + j) * 16u);
+    }
+    if (norm) {
+        const int B = min(4 * wave + r, nblk - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = ld_g((const float4 *) p.norm_w + (B * 64 + 16 * k + j));
+    }
+    float scale = 1.0f;
+    if (norm) {
+        const double tot = wave_sum_f64((ssp[0] + ssp[1]) + (ssp[2] + ssp[3]));
+        const float mean = (float) (tot / K);
+        scale = 1.0f / sqrtf(mean + p.eps);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) if (4 * (wave + ENG_NC * t) < nblk) {
+        float v[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k][0] = f[t][k].x; v[k][1] = f[t][k].y; v[k][2] = f[t][k].z; v[k][3] = f[t][k].w;
+            if (norm) { v[k][0] = v[k][0] * scale * g[k].x; v[k][1] = v[k][1] * scale * g[k].y; v[k][2] = v[k][2] * scale * g[k].z; v[k][3] = v[k][3] * scale * g[k].w; }
+        }
+        const int B = 4 * (wave + ENG_NC * t) + r;
+        q8k_rows_to_lds(v, j, B < nblk, xs_q, xs_gs, xs_d, B);
+    }
+}
+
+// attention of head h over cached cells by waves 0-3 (256 threads): attn_cached.hip's short path (<= 64 cells, one 4-wave barrier) and the
+// cached form of attn_rope_body beyond, same arithmetic and rounding points; every load of q / K / V is an agent-scope load (q and this token's
+// cell were written by other CUs in this launch)
+template <int DH>
+__device__ __forceinline__ void eng_attention(const EngPhase * ph, int h, char * smem, Ctl * c, unsigned & agen, int * err) {
+    // (the thread id goes through an opaque asm: everything derived from it - dozens of LDS / cache offsets - is then recomputed per phase instead
+    //  of being hoisted out of the phase loop and kept alive, i.e. spilled, across the mat-vec phases)
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = ph->aH, Hkv = ph->aHkv, n_ctx = ph->an_ctx;
+    const int hk = h / (H / Hkv);
+    const float scale = ph->ascale;
+    const int seq = ph->aseq ? uniform_const_ptr(ph->aseq)[0] : 0;
+    const int n_kv = uniform_const_ptr(ph->apos)[seq] + 1;
+    const long soff = (long) seq * ph->aseq_stride;
+    const __amdgpu_buffer_rsrc_t rk = coh_rsrc(ph->akc + soff), rv = coh_rsrc(ph->avc + soff), rq = coh_rsrc(ph->aq);
+    float * part = (float *) smem;                         // [4][64]
+    float * pw = part + 256;                               // [4][64]
+    float * redf = pw + 256;                               // [8]
+    double * redd = (double *) (redf + 8);                 // [4]
+    float * body = (float *) (redd + 4);                   // general path: qs[DH] | part[256] | sc[max_keys]
+    auto bar = [&]() __attribute__((always_inline)) { wbar(&c->abar, agen, 4, lane, c, err, 6); };
+    if (n_kv <= 64 && n_ctx >= 64) {
+        constexpr int DPW = DH / 4, NK = DPW / 8, KP = 64 / DPW, KPP = 64 / KP, NV = KPP / 8;
+        const int key = lane < n_ctx ? lane : 0;
+        u32x4 kreg[NK], vreg[NV];
+#pragma unroll
+        for (int j = 0; j < NK; ++j) kreg[j] = coh_ld16u(rk, (uint32_t) (((long) key * Hkv * DH + (long) hk * DH + DPW * wave + 8 * j) * 2));
+        const int e = lane % DPW, kp = lane / DPW;
+        const long vrow = (long) (hk * DH + DPW * wave + e) * n_ctx + (KPP * kp + KPP <= n_ctx ? KPP * kp : 0);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) vreg[j] = coh_ld16u(rv, (uint32_t) ((vrow + 8 * j) * 2));
+        // this wave's q slice -> its own LDS strip, read back as broadcasts (a scalar load could hit a stale scalar-cache line: the rows were written by
+        // other CUs in this launch; DPW values in registers next to the K / V pieces spill)
+        float * qw = body + wave * DPW;
+        if (lane < DPW) qw[lane] = coh_ld4(rq, (uint32_t) (((long) h * DH + DPW * wave + lane) * 4));
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NK; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc = fmaf(h2f((uint16_t) (kreg[j][t] & 0xFFFF)), qw[8 * j + 2 * t], acc);
+                acc = fmaf(h2f((uint16_t) (kreg[j][t] >> 16)), qw[8 * j + 2 * t + 1], acc);
+            }
+        part[wave * 64 + lane] = acc;
+        bar();
+        const bool valid = lane < n_kv;
+        const float s_ = valid ? ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane])) * scale : -INFINITY;
+        float mx = s_;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        const float ex = valid ? expf(s_ - mx) : 0.0f;
+        double tot = (double) ex;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        const float inv = (float) (1.0 / tot);
+        pw[wave * 64 + lane] = h2f(f2h(ex * inv));         // p rounded to F16 (src1 of the V^T.p product)
+        __builtin_amdgcn_wave_barrier();
+        float o = 0.0f;
+        const bool chunk_ok = KPP * kp + KPP <= n_ctx;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                o = fmaf(h2f((uint16_t) (vreg[j][t] & 0xFFFF)), pw[wave * 64 + KPP * kp + 8 * j + 2 * t], o);
+                o = fmaf(h2f((uint16_t) (vreg[j][t] >> 16)), pw[wave * 64 + KPP * kp + 8 * j + 2 * t + 1], o);
+            }
+        if (!chunk_ok) o = 0.0f;
+#pragma unroll
+        for (int off = DPW; off < 64; off <<= 1) o += __shfl_xor(o, off);
+        if (lane < DPW) st_act<true>(ph->aout + (long) h * DH + DPW * wave + lane, o);
+        return;
+    }
+    // ---- general cached body (attn_rope_body<DH, COH, 0, true>): thread per key, three 4-wave reductions
+    constexpr int PARTS = 256 / DH, KQ = DH / 8;
+    float * qs = body, * part2 = qs + DH, * sc = part2 + 256;
+    if (tid < DH) qs[tid] = coh_ld4(rq, (uint32_t) (((long) h * DH + tid) * 4));
+    const int ve = tid % DH, vpt = tid / DH;
+    const int n_pad = (n_kv + 7) & ~7;
+    bar();
+    float lmax = -INFINITY;
+#pragma unroll 1
+    for (int i = tid; i < n_kv; i += 256) {
+        // (the key's row in two halves: same accumulation order as one pass, half the registers)
+        float acc = 0.0f;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            u32x4 kk[KQ / 2];
+#pragma unroll
+            for (int j = 0; j < KQ / 2; ++j) kk[j] = coh_ld16u(rk, (uint32_t) (((long) i * Hkv * DH + (long) hk * DH + 8 * (hf * (KQ / 2) + j)) * 2));
+#pragma unroll
+            for (int jj = 0; jj < KQ / 2; ++jj)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc += h2f((uint16_t) (kk[jj][j] & 0xFFFF)) * qs[8 * (hf * (KQ / 2) + jj) + 2 * j];
+                    acc += h2f((uint16_t) (kk[jj][j] >> 16)) * qs[8 * (hf * (KQ / 2) + jj) + 2 * j + 1];
+                }
+        }
+        const float s_ = acc * scale;
+        sc[i] = s_;
+        lmax = fmaxf(lmax, s_);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    if (lane == 0) redf[wave] = lmax;
+    bar();
+    const float mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    double lsum = 0.0;
+    for (int i = tid; i < n_kv; i += 256) {
+        const float e = expf(sc[i] - mx);
+        sc[i] = e;
+        lsum += (double) e;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+    if (lane == 0) redd[wave] = lsum;
+    bar();
+    const double tot = (redd[0] + redd[1]) + (redd[2] + redd[3]);
+    const float inv = (float) (1.0 / tot);
+    bar();
+    for (int i = tid; i < n_pad; i += 256) sc[i] = i < n_kv ? h2f(f2h(sc[i] * inv)) : 0.0f;
+    bar();
+    {
+        float acc = 0.0f;
+        const long vrow = (long) (hk * DH + ve) * n_ctx;
+#pragma unroll 1
+        for (int i = vpt * 8; i < n_pad; i += PARTS * 8) {
+            const u32x4 vv = coh_ld16u(rv, (uint32_t) ((vrow + i) * 2));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc += h2f((uint16_t) (vv[j] & 0xFFFF)) * sc[i + 2 * j];
+                acc += h2f((uint16_t) (vv[j] >> 16)) * sc[i + 2 * j + 1];
+            }
+        }
+        part2[tid] = acc;
+    }
+    bar();
+    if (tid < DH) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) acc += part2[pt * DH + tid];
+        st_act<true>(ph->aout + (long) h * DH + tid, acc);
+    }
+}
+
+__global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ Ctl ctl;
+    Ctl * c = &ctl;
+    char * ring = smem;
+    char * acts = smem + ENG_RING;
+    float * outbuf = (float *) (smem + ENG_RING + ENG_ACT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < (int) (sizeof(Ctl) / 4)) ((unsigned *) c)[tid] = 0;
+    __syncthreads();                                       // the only workgroup-wide barrier: before the roles split
+    if (tid == 0 && __hip_atomic_load((PM_G int *) A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) lds_st(&c->giveup, 1);   // an earlier launch gave up: the counters are not trustworthy
+#ifndef ENG_NO_LOADER
+    if (wave == ENG_NW - 1) { loader_wave(A, c, ring, lane); return; }
+#endif
+
+    const int b = blockIdx.x, G = gridDim.x;
+    const unsigned NGR = (G % 16 == 0 && G / 16 <= ENG_MAXG / 16) ? 16 : 1, GS = G / NGR;
+    unsigned cgen = 0, agen = 0;                           // generations of the consumer / attention barriers
+    unsigned nbase = 0;                                    // launch-wide index of the current phase's first item
+    const EngPhase * phs = uniform_const_ptr(A.ph);
+    for (int pi = 0; pi < A.n_ph; ++pi) {
+        const EngPhase * ph = phs + pi;
+        // ---- seam: every workgroup's outputs of the previous phase are in memory
+        if (pi > 0) {
+            if (wave == 0 && lane == 0) g_wait(A.ctr, (unsigned) pi, GS, c, A.err);
+            wbar(&c->cbar, cgen, ENG_NC, lane, c, A.err, 2);
+        }
+        if (ph->kind == 1) {
+#ifndef ENG_NO_ATTN
+            if (b < ph->aH && wave < 4) {
+                if (ph->adh == 128) eng_attention<128>(ph, b, acts, c, agen, A.err);
+#ifndef ENG_NO_ATTN64
+                else eng_attention<64>(ph, b, acts, c, agen, A.err);
+#endif
+            }
+#endif
+        } else {
+            // (the phase block stays in constant memory: a local copy whose members are selected at run time would live in scratch)
+            const GemvP & p = ph->g;
+            const int ta = ph->ta, tb = ph->tb, pair = ph->pair;
+            const int K = p.K;
+            int8_t * xs_q = (int8_t *) acts; int * xs_gs = (int *) (acts + ((K + 15) & ~15)); float * xs_d = (float *) (xs_gs + K / 16);
+#ifndef ENG_NO_PRO
+            eng_prologue(p, xs_q, xs_gs, xs_d, wave, lane);
+#endif
+            wbar(&c->cbar, cgen, ENG_NC, lane, c, A.err, 2);
+            const XLds xs = {xs_q, xs_gs, xs_d, 0};
+            // ---- this workgroup's items, launch-wide index n -> wave n % 15
+            const int t0 = p.job[0].is_b ? tb : ta, t1 = p.job[1].is_b ? tb : ta, t2 = p.job[2].is_b ? tb : ta;
+            const int U0 = p.job[0].U, U1 = p.job[1].U, U2 = p.job[2].U;
+            JobGeo g0 = JobGeo(), g1 = JobGeo(), g2 = JobGeo();
+            if (p.job[0].N > 0) g0 = job_geo(p.job[0], t0, pair, b, G, 0);
+            g1.ob = g0.nres; if (p.job[1].N > 0) g1 = job_geo(p.job[1], t1, pair, b, G, g0.nres);
+            g2.ob = g1.ob + g1.nres; if (p.job[2].N > 0) g2 = job_geo(p.job[2], t2, pair, b, G, g1.ob + g1.nres);
+            const int nit = g0.items + g1.items + g2.items;
+            const unsigned first = nbase + (unsigned) ((wave + ENG_NC - (int) (nbase % ENG_NC)) % ENG_NC);
+            unsigned k_done = lds_ld(&c->done[wave]);
+            for (unsigned n = first; n < nbase + (unsigned) nit; n += ENG_NC) {
+                const int li = (int) (n - nbase);
+                const int j = li < g0.items ? 0 : (li < g0.items + g1.items ? 1 : 2);
+                const int id = li - (j > 0 ? g0.items : 0) - (j > 1 ? g1.items : 0);
+                const int q_cpr = j == 0 ? g0.cpr : (j == 1 ? g1.cpr : g2.cpr), q_split = j == 0 ? g0.split : (j == 1 ? g1.split : g2.split);
+                const int q_steps = j == 0 ? g0.steps : (j == 1 ? g1.steps : g2.steps), q_ob = j == 0 ? g0.ob : (j == 1 ? g1.ob : g2.ob);
+                const int type = j == 0 ? t0 : (j == 1 ? t1 : t2), U = j == 0 ? U0 : (j == 1 ? U1 : U2);
+                const int c0 = q_split ? id % q_cpr : 0;
+                spin_ge(&c->landed, n + 1, c, A.err, 4);
+                const char * img = ring + lds_ld(&c->item_off[n & 63]);
+                float * slot = outbuf + q_ob + id;
+                if (type == PM_Q4_K) { if (pair) eat_item<PM_Q4_K, true>(img, U, xs, c0, q_steps, lane, slot); else eat_item<PM_Q4_K, false>(img, U, xs, c0, q_steps, lane, slot); }
+#ifndef ENG_NO_Q6
+                else if (type == PM_Q6_K) { if (pair) eat_item<PM_Q6_K, true>(img, U, xs, c0, q_steps, lane, slot); else eat_item<PM_Q6_K, false>(img, U, xs, c0, q_steps, lane, slot); }
+#endif
+#ifndef ENG_NO_Q5
+                else eat_item<PM_Q5_K, false>(img, U, xs, c0, q_steps, lane, slot);
+#endif
+                ++k_done;
+                __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): the image has been read (and the result parked)
+                if (lane == 0) lds_st(&c->done[wave], k_done);
+            }
+            nbase += (unsigned) nit;
+            float ec0 = 1.0f, es0 = 0.0f, ec1 = 1.0f, es1 = 0.0f, ec2 = 1.0f, es2 = 0.0f;
+            int epi_slot = 0; long epi_off = 0;
+            if (ph->epi) {
+                const int seq = p.epi.seq_ptr ? uniform_const_ptr(p.epi.seq_ptr)[0] : 0;
+                epi_slot = uniform_const_ptr(p.epi.pos_ptr)[seq];
+                epi_off = (long) seq * p.epi.seq_stride;
+                qkv_cs(p.job[0], p.epi, g0.r0, g0.r1, tid, ec0, es0);
+                qkv_cs(p.job[1], p.epi, g1.r0, g1.r1, tid, ec1, es1);
+                qkv_cs(p.job[2], p.epi, g2.r0, g2.r1, tid, ec2, es2);
+            }
+            wbar(&c->cbar, cgen, ENG_NC, lane, c, A.err, 2);              // every row result of the workgroup is parked
+            // ---- epilogue: coalesced, write-through
+            if (ph->epi) {
+                write_out_qkv<true>(p.job[0], p.epi, outbuf, g0.r0, g0.r1, g0.ob, tid, g0.split ? g0.cpr : 1, epi_slot, epi_off, ec0, es0);
+                write_out_qkv<true>(p.job[1], p.epi, outbuf, g1.r0, g1.r1, g1.ob, tid, g1.split ? g1.cpr : 1, epi_slot, epi_off, ec1, es1);
+                write_out_qkv<true>(p.job[2], p.epi, outbuf, g2.r0, g2.r1, g2.ob, tid, g2.split ? g2.cpr : 1, epi_slot, epi_off, ec2, es2);
+            } else {
+                const double ss = write_out<true, 1>(p.job[0], outbuf, g0.r0, g0.r1, g0.ob, tid, 0, g0.split ? g0.cpr : 1);
+                write_out<true, 1>(p.job[1], outbuf, g1.r0, g1.r1, g1.ob, tid, 0, g1.split ? g1.cpr : 1);
+                write_out<true, 1>(p.job[2], outbuf, g2.r0, g2.r1, g2.ob, tid, 0, g2.split ? g2.cpr : 1);
+                if (p.ss_out && wave == 0) {               // (rows <= 64 per workgroup: checked by the host)
+                    const double ws = wave_sum_f64(ss);
+                    if (lane == 0) __hip_atomic_store((PM_G double *) (p.ss_out + b), ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        // ---- publish: this wave's stores have left, then the workgroup arrives
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wbar(&c->cbar, cgen, ENG_NC, lane, c, A.err, 2);
+        if (wave == 0 && lane == 0) g_arrive(A.ctr, (unsigned) pi, NGR, GS, pi == A.n_ph - 1);
+    }
+}
+
+// f64 sum of the f32-rounded squares of a row (the rms_norm input of the launch's FIRST phase has no producing phase: embedding row or ring hand-off)
+__global__ __launch_bounds__(256) void sumsq_row_kernel(const float * x, int K, double * out) {
+    __shared__ double red[4];
+    double ss = 0.0;
+    for (int i = threadIdx.x; i < K; i += 256) { const float v = x[i]; const float sq = v * v; ss += (double) sq; }
+    ss = wave_sum_f64(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+} // namespace
+
+void pm_launch_sumsq_row(const float * x, int K, double * out, hipStream_t st) { hipLaunchKernelGGL(sumsq_row_kernel, dim3(1), dim3(256), 0, st, x, K, out); }
+
+// ---- host side -----------------------------------------------------------------------------------------------------------------------------------
+struct pm_eng_plan {
+    std::vector<EngPhase> ph;
+    EngPhase * d_ph = nullptr; unsigned * d_ctr = nullptr; int * d_err = nullptr;
+    int grid = 0; bool finished = false;
+};
+
+pm_eng_plan * pm_eng_plan_new() { return new pm_eng_plan(); }
+void pm_eng_plan_free(pm_eng_plan * p) {
+    if (!p) return;
+    if (p->d_ph) (void) hipFree(p->d_ph);
+    if (p->d_ctr) (void) hipFree(p->d_ctr);
+    delete p;
+}
+int pm_eng_plan_phases(const pm_eng_plan * p) { return p ? (int) p->ph.size() : 0; }
+
+int pm_eng_plan_add_matvec(pm_eng_plan * pl, const pm_gemv_fused & f) {
+    if (!pl || pl->finished) return -1;
+    EngPhase e = {};
+    int ta, tb, grid; bool pair; size_t lds;
+    const int rc = gemv_fill(f, 0, e.g, ta, tb, pair, lds, grid);
+    if (rc) return rc < 0 ? rc : -rc;
+    auto served = [](int t) { return t == PM_Q4_K || t == PM_Q5_K || t == PM_Q6_K; };
+    if (!served(ta) || !served(tb)) return -10;                                   // (Q8_0 weights take Q8_0 activations: not in the engine yet)
+    if (pair && ta == PM_Q5_K) return -10;
+    if (e.g.xmode == 0 || e.g.xmode == 2) return -11;                             // f32 rows only; rms_norm only from producer-side partials
+    if (f.dbg_int) return -11;
+    const int nblk = f.K / 256;
+    if (f.K % 256 || nblk > (e.g.xmode == 3 ? 4 * ENG_NC : 8 * ENG_NC)) return -12;
+    if ((size_t) ((f.K + 15) & ~15) + (size_t) (f.K / 16) * 4 + (size_t) ((nblk + 3) & ~3) * 4 > (size_t) ENG_ACT) return -12;
+    if (pl->grid && pl->grid != grid) return -13;
+    if (grid > ENG_MAXG) return -13;
+    pl->grid = grid;
+    // items: rows whose image exceeds what 15 waves can hold in the ring next to the run-ahead are consumed step by step
+    int nres = 0;
+    for (int j = 0; j < 3; ++j) {
+        GemvJob & jb = e.g.job[j];
+        if (jb.N <= 0) continue;
+        const int type = jb.is_b ? tb : ta;
+        const int ch = (type == PM_Q4_K || type == PM_Q6_K) ? PM_CH64 : PM_CH32, cpr = (((jb.U + 63) >> 6) + ch - 1) / ch;
+        const int sb = type == PM_Q4_K ? ST<PM_Q4_K>::BYTES : type == PM_Q6_K ? ST<PM_Q6_K>::BYTES : ST<PM_Q5_K>::BYTES;
+        if (!jb.split && cpr * sb * (pair ? 2 : 1) > 10 * 1024) { if (pair) return -14; jb.split = 1; }
+        if (jb.split && cpr == 1) jb.split = 0;
+        const int rows = (jb.N + grid - 1) / grid + 1;
+        nres += rows * (jb.split ? cpr : 1);
+        if (f.ss_out && rows > 64) return -15;
+    }
+    if (nres > ENG_OUTF) return -15;
+    e.kind = 0; e.ta = ta; e.tb = tb; e.pair = pair ? 1 : 0; e.epi = f.epi ? 1 : 0;
+    pl->ph.push_back(e);
+    return 0;
+}
+
+int pm_eng_plan_add_attention(pm_eng_plan * pl, const float * q, void * kc, void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride, float * out,
+                              int H, int Hkv, int dh, int n_ctx, float scale, int max_keys) {
+    if (!pl || pl->finished) return -1;
+    if ((dh != 64 && dh != 128) || n_ctx % 8 || !pos0 || H % Hkv) return -10;
+    if (max_keys <= 0 || max_keys > n_ctx) max_keys = n_ctx;
+    // LDS of the general path inside the activation area: part / pw / reductions (2 KiB + 64) | qs[dh] | part[256] | sc[max_keys + 8]
+    if ((size_t) (512 + 8 + 8) * 4 + (size_t) (dh + 256 + ((max_keys + 15) & ~7)) * 4 > (size_t) ENG_ACT) return -12;
+    EngPhase e = {};
+    e.kind = 1; e.aq = q; e.akc = (uint16_t *) kc; e.avc = (uint16_t *) vc; e.apos = pos0; e.aseq = seq; e.aseq_stride = seq_stride; e.aout = out;
+    e.aH = H; e.aHkv = Hkv; e.adh = dh; e.an_ctx = n_ctx; e.amax_keys = max_keys; e.ascale = scale;
+    pl->ph.push_back(e);
+    return 0;
+}
+
+int pm_eng_plan_finish(pm_eng_plan * pl) {
+    if (!pl || pl->ph.empty() || pl->grid <= 0) return -1;
+    for (const EngPhase & e : pl->ph) if (e.kind == 1 && e.aH > pl->grid) return -13;
+    hipDeviceProp_t pr; int dev = 0; (void) hipGetDevice(&dev);
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess || pl->grid > pr.multiProcessorCount) return -13;        // every workgroup must be resident
+    if ((size_t) pr.sharedMemPerBlock < 64 * 1024) return -13;
+    const size_t ctr_bytes = (size_t) 32 * 4 * (1 + 2 * (ENG_MAXG / 16)) + 64;
+    if (hipMalloc((void **) &pl->d_ph, pl->ph.size() * sizeof(EngPhase)) != hipSuccess || hipMalloc((void **) &pl->d_ctr, ctr_bytes) != hipSuccess) return -3;
+    if (hipMemcpy(pl->d_ph, pl->ph.data(), pl->ph.size() * sizeof(EngPhase), hipMemcpyHostToDevice) != hipSuccess) return -3;
+    if (hipMemset(pl->d_ctr, 0, ctr_bytes) != hipSuccess) return -3;
+    pl->d_err = (int *) ((char *) pl->d_ctr + ctr_bytes - 64);
+    if (hipFuncSetAttribute((const void *) decode_engine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ENG_LDS) != hipSuccess) { (void) hipGetLastError(); return -3; }
+    pl->finished = true;
+    return 0;
+}
+
+int pm_eng_plan_launch(pm_eng_plan * pl, hipStream_t st) {
+    if (!pl || !pl->finished) return -1;
+    EngArgs a = {pl->d_ph, (int) pl->ph.size(), pl->d_ctr, pl->d_err};
+    hipLaunchKernelGGL(decode_engine_kernel, dim3(pl->grid), dim3(ENG_THREADS), ENG_LDS, st, a);
+    return 0;
+}
+
+int pm_eng_plan_status(pm_eng_plan * pl) {
+    if (!pl || !pl->finished) return -1;
+    int err = 0;
+    if (hipMemcpy(&err, pl->d_err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    if (err) {
+        const size_t ctr_bytes = (size_t) 32 * 4 * (1 + 2 * (ENG_MAXG / 16)) + 64;
+        (void) hipMemset(pl->d_ctr, 0, ctr_bytes);
+    }
+    return err;
+}

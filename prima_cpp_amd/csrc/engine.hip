@@ -12,6 +12,7 @@
 #include "pm355_device.h"
 #include "pm355_kernels.h"
 #include "pm355_layer_ops.h"
+#include "pm355_engine.h"
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -56,6 +57,10 @@ struct pm355_model {
     // in ss[0] / ss[1] (256 doubles each); the consuming wq | wk | wv, ffn_gate | ffn_up and lm_head launches add them instead of reducing the row.
     // PM355_SS=0: every norm prologue reduces its own row (the round-4 form)
     bool use_ss = true; double * ss = nullptr;
+    // the persistent decode engine (decode_engine.hip, round 5): the whole layer stack of a single-token step as ONE launch. Plans are keyed on the
+    // activation pointers baked into their phase tables. PM355_ENGINE=0: five launches per layer (run_layers_fused)
+    struct EnginePlan { const float * in; float * out; pm_eng_plan * plan; int n_ss_end; };
+    bool use_engine = true; std::vector<EnginePlan> eng_plans; bool eng_refused = false;
     // PM355_PROMPT_I8=1: prompts (> 64 tokens) run their Q4_K / Q6_K matrices on the integer matrix cores over Q8_K activations (mmq_big.hip) - the CPU
     // reference's own arithmetic, at 0.6-0.75 of the F16 GEMMs' rate (mmq.hip, the default); tab_big = the activation tables of the current
     // activation set (pm_q8k_tables)
@@ -346,6 +351,80 @@ int run_head(pm355_model * m, const float * x_row, float * d_logits, int32_t * d
     return 0;
 }
 
+// The single-token layer stack as ONE persistent launch: the same launches run_layers_fused issues, appended as phases (decode_engine.hip).
+// nullptr: this window is not served (types, shapes, streaming, long-context regime) - the caller takes the five-launch path.
+pm_eng_plan * engine_plan_for(pm355_model * m, const float * cur, float * d_x_out, int * n_ss_end) {
+    for (auto & e : m->eng_plans) if (e.in == cur && e.out == d_x_out) { *n_ss_end = e.n_ss_end; return e.plan; }
+    if (m->eng_refused) return nullptr;
+    const float * in0 = cur;
+    const pm355_hparams & hp = m->hp;
+    const int H = hp.n_head, Hkv = hp.n_head_kv, dh = hp.head_dim;
+    const float kq_scale = 1.0f / sqrtf((float) dh);
+    float * bufs[2] = {m->x, m->x1};
+    pm_eng_plan * pl = pm_eng_plan_new();
+    auto refuse = [&](const char * why, int rc) -> pm_eng_plan * {
+        if (getenv("PM355_ENGINE_VERBOSE")) fprintf(stderr, "prima_mi355 engine: not served (%s, rc %d) - five launches per layer\n", why, rc);
+        pm_eng_plan_free(pl); m->eng_refused = true; return nullptr;
+    };
+    const int max_keys = (m->split_scratch && m->split_min + 8 < hp.n_ctx) ? m->split_min + 8 : hp.n_ctx;
+    double * ss_wo = m->ss, * ss_dn = m->ss + 256;
+    int n_wo = 0, n_dn = 1;                              // the first rms_norm takes the one-partial sum the sumsq launch in front of the engine leaves
+    auto job = [](pm_gemv_fused & f, int j, const Tensor & w, const Tensor * w2, float * y, const float * bias, const float * resid) {
+        f.job[j].type = w.type; f.job[j].N = (int) w.N; f.job[j].W = w.d; f.job[j].W2 = w2 ? w2->d : nullptr; f.job[j].y = y; f.job[j].bias = bias; f.job[j].resid = resid;
+    };
+    for (int il = m->lo; il < m->hi; ++il) {
+        Layer & L = m->layers[il - m->lo];
+        float * x_mid = (cur == bufs[0]) ? bufs[1] : bufs[0];
+        float * x_nxt = (x_mid == bufs[0]) ? bufs[1] : bufs[0];
+        float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : x_nxt;
+        const long kvs = m->n_seq > 1 ? (long) hp.n_ctx * Hkv * dh : 0;
+        int rc;
+        {   // wq | wk | wv + rope + KV store
+            pm_gemv_fused f = {};
+            f.K = hp.n_embd; f.njobs = 3; f.xf = cur; f.norm_w = (const float *) L.t[PM355_T_ATTN_NORM].d; f.eps = hp.rms_eps;
+            job(f, 0, L.t[PM355_T_WQ], nullptr, m->q, (const float *) L.t[PM355_T_BQ].d, nullptr);
+            job(f, 1, L.t[PM355_T_WK], nullptr, m->k, (const float *) L.t[PM355_T_BK].d, nullptr);
+            job(f, 2, L.t[PM355_T_WV], nullptr, m->v, (const float *) L.t[PM355_T_BV].d, nullptr);
+            const pm_qkv_epi qe = {m->rope_tab, m->d_pos, m->d_ctl, nullptr, kvs, L.kc, L.vc, Hkv, dh, hp.n_ctx, m->rope.n_dims, 0, (m->rope.mode & 2) ? 1 : 0};
+            f.epi = &qe; f.ss_in = ss_dn; f.n_ss = n_dn;
+            if ((rc = pm_eng_plan_add_matvec(pl, f))) return refuse("wq | wk | wv", rc);
+        }
+        if ((rc = pm_eng_plan_add_attention(pl, m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, m->att, H, Hkv, dh, hp.n_ctx, kq_scale, max_keys))) return refuse("attention", rc);
+        {   // wo + residual, leaves the partials of ffn_norm
+            pm_gemv_fused f = {};
+            f.K = (int) L.t[PM355_T_WO].K; f.njobs = 1; f.xf = m->att; f.eps = hp.rms_eps;
+            job(f, 0, L.t[PM355_T_WO], nullptr, x_mid, nullptr, cur);
+            n_wo = pm_gemv_fused_grid(f);
+            if (n_wo < 1 || n_wo > 256) return refuse("wo grid", n_wo);
+            f.ss_out = ss_wo;
+            if ((rc = pm_eng_plan_add_matvec(pl, f))) return refuse("wo", rc);
+        }
+        if (L.t[PM355_T_FFN_GATE].type != L.t[PM355_T_FFN_UP].type) return refuse("ffn_gate / ffn_up types", -1);
+        {   // ffn_gate | ffn_up + silu * mul
+            pm_gemv_fused f = {};
+            f.K = hp.n_embd; f.njobs = 1; f.xf = x_mid; f.norm_w = (const float *) L.t[PM355_T_FFN_NORM].d; f.eps = hp.rms_eps;
+            job(f, 0, L.t[PM355_T_FFN_GATE], &L.t[PM355_T_FFN_UP], m->h, nullptr, nullptr);
+            f.ss_in = ss_wo; f.n_ss = n_wo;
+            if ((rc = pm_eng_plan_add_matvec(pl, f))) return refuse("ffn_gate | ffn_up", rc);
+        }
+        {   // ffn_down + residual, leaves the partials of the next attn_norm / output_norm
+            pm_gemv_fused f = {};
+            f.K = (int) L.t[PM355_T_FFN_DOWN].K; f.njobs = 1; f.xf = m->h; f.eps = hp.rms_eps;
+            job(f, 0, L.t[PM355_T_FFN_DOWN], nullptr, x_next, nullptr, x_mid);
+            n_dn = pm_gemv_fused_grid(f);
+            if (n_dn < 1 || n_dn > 256) return refuse("ffn_down grid", n_dn);
+            f.ss_out = ss_dn;
+            if ((rc = pm_eng_plan_add_matvec(pl, f))) return refuse("ffn_down", rc);
+        }
+        cur = x_next;
+    }
+    const int rc = pm_eng_plan_finish(pl);
+    if (rc) return refuse("finish", rc);
+    m->eng_plans.push_back({in0, d_x_out, pl, n_dn});
+    *n_ss_end = n_dn;
+    return pl;
+}
+
 // which single-token attention path the current sequence takes: 0 = one workgroup per head; else the cells the long-context grid is
 // sized for (power-of-two bucket >= position + 1, capped at n_ctx) - also the key of the captured step graph
 int attn_regime(const pm355_model * m) {
@@ -466,8 +545,26 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         m->flash_cells = attn_regime(m); m->long_ctx = m->flash_cells != 0;
         // ---- single token: every activation transform is fused into a mat-vec prologue / epilogue, 5 launches per layer
         const float * end = nullptr;
-        int rc = run_layers_fused(m, cur, d_x_out, &end, st, &n_ss_head);
-        if (rc) return rc;
+        pm_eng_plan * eng = nullptr;
+        const bool eng_ok = m->use_engine && !m->long_ctx && !m->n_slots && m->use_ss && m->ss && m->qkv_epi && m->rope_tab && (m->rope.mode == 0 || m->rope.mode == 2) && m->hi > m->lo;
+        if (eng_ok) eng = engine_plan_for(m, cur, d_x_out, &n_ss_head);
+        if (eng) {
+            // ---- ... or, where served, ALL layers as one persistent launch (decode_engine.hip): cos / sin table, the first norm's sum of squares, the engine
+            pm_launch_rope_table(m->rope, m->d_pos, m->d_ctl, (const float *) m->rope_freqs.d, m->rope_tab, st);
+            pm_launch_sumsq_row(cur, E, m->ss + 256, st);
+            if (pm_eng_plan_launch(eng, st)) return seterr(m, PM355_E_HIP, "decode: engine launch");
+            // where the stack's output row ends up: the same buffer rotation as run_layers_fused
+            const float * c2 = cur;
+            for (int il = m->lo; il < m->hi; ++il) {
+                float * x_mid = (c2 == bufs[0]) ? bufs[1] : bufs[0];
+                float * x_nxt = (x_mid == bufs[0]) ? bufs[1] : bufs[0];
+                c2 = (il == m->hi - 1 && d_x_out) ? d_x_out : x_nxt;
+            }
+            end = c2;
+        } else {
+            int rc = run_layers_fused(m, cur, d_x_out, &end, st, &n_ss_head);
+            if (rc) return rc;
+        }
         cur = end;
     } else
     for (int il = m->lo; il < m->hi; ++il) {
@@ -691,6 +788,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     { const char * e = getenv("PM355_QKV_EPI"); m->qkv_epi = !(e && e[0] == '0'); }
     { const char * e = getenv("PM355_PROMPT_I8"); m->no_big = !(e && e[0] == '1'); }
     { const char * e = getenv("PM355_SS"); m->use_ss = !(e && e[0] == '0'); }
+    { const char * e = getenv("PM355_ENGINE"); m->use_engine = !(e && e[0] == '0'); }
     return m;
 }
 
@@ -698,6 +796,7 @@ void pm355_model_free(pm355_model * m) {
     if (!m) return;
     (void) hipDeviceSynchronize();
     for (auto & g : m->graphs) (void) hipGraphExecDestroy(g.exec);
+    for (auto & e : m->eng_plans) pm_eng_plan_free(e.plan);
     if (m->copy_stream) { (void) hipStreamSynchronize(m->copy_stream); (void) hipStreamDestroy(m->copy_stream); }
     for (auto & S : m->slots) { for (auto p : S.d) if (p) (void) hipFree(p); if (S.ready) (void) hipEventDestroy(S.ready); if (S.free_) (void) hipEventDestroy(S.free_); }
     for (auto & L : m->layers) for (auto p : L.host) if (p) (void) hipHostFree(p);
@@ -985,6 +1084,10 @@ int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * 
 int pm355_model_check(pm355_model * m) {
     if (!m) return PM355_E_SHAPE;
     if (hipDeviceSynchronize() != hipSuccess) return seterr(m, PM355_E_HIP, "check: device error");
+    for (auto & e : m->eng_plans) {
+        const int w = pm_eng_plan_status(e.plan);
+        if (w) { snprintf(m->err, sizeof(m->err), "check: the decode engine's watchdog fired (code %d: 1 loader, 2 consumer barrier, 3 device-wide barrier, 4 item wait, 6 attention barrier)", w); return PM355_E_HIP; }
+    }
     return 0;
 }
 

@@ -722,6 +722,7 @@ __device__ __forceinline__ void qkv_cs(const GemvJob & jb, const QkvEpi & e, int
         }
     }
 }
+template <bool COH = false>
 __device__ __forceinline__ void write_out_qkv(const GemvJob & jb, const QkvEpi & e, const float * outbuf, int r0, int r1, int ob, int tid, int cpr,
                                               int slot, long kv_off, float c, float s_) {
     const int np = (r1 - r0) >> 1;
@@ -737,8 +738,8 @@ __device__ __forceinline__ void write_out_qkv(const GemvJob & jb, const QkvEpi &
             const float x0 = o0, x1 = o1;
             o0 = x0 * c - x1 * s_; o1 = x0 * s_ + x1 * c;
             const uint16_t h0 = f2h(o0), h1 = f2h(o1);
-            if (jb.role == 2) { st_g(e.kc + kv_off + (long) slot * e.kv_dim + p0, h0); st_g(e.kc + kv_off + (long) slot * e.kv_dim + p1, h1); }
-            else { st_g(jb.y + p0, h2f(h0)); st_g(jb.y + p1, h2f(h1)); }
+            if (jb.role == 2) { st_any<COH>(e.kc + kv_off + (long) slot * e.kv_dim + p0, h0); st_any<COH>(e.kc + kv_off + (long) slot * e.kv_dim + p1, h1); }
+            else { st_any<COH>(jb.y + p0, h2f(h0)); st_any<COH>(jb.y + p1, h2f(h1)); }
             return;
         }
         const int row = r0 + 2 * pr;
@@ -746,8 +747,8 @@ __device__ __forceinline__ void write_out_qkv(const GemvJob & jb, const QkvEpi &
         if (jb.bias) { o0 += ld_g(jb.bias + row); o1 += ld_g(jb.bias + row + 1); }
         if (jb.role == 3) {
             const uint16_t h0 = f2h(o0), h1 = f2h(o1);
-            if (e.v_rowmajor) st_g((uint32_t *) (e.vc + kv_off + (long) slot * e.kv_dim + row), (uint32_t) h0 | ((uint32_t) h1 << 16));
-            else { st_g(e.vc + kv_off + (long) row * e.n_ctx + slot, h0); st_g(e.vc + kv_off + (long) (row + 1) * e.n_ctx + slot, h1); }
+            if (e.v_rowmajor) st_any<COH>((uint32_t *) (e.vc + kv_off + (long) slot * e.kv_dim + row), (uint32_t) h0 | ((uint32_t) h1 << 16));
+            else { st_any<COH>(e.vc + kv_off + (long) row * e.n_ctx + slot, h0); st_any<COH>(e.vc + kv_off + (long) (row + 1) * e.n_ctx + slot, h1); }
             return;
         }
         if (row % e.dh < e.n_rot) {                                // (even row: pair (row % dh) / 2 of its head)
@@ -755,8 +756,8 @@ __device__ __forceinline__ void write_out_qkv(const GemvJob & jb, const QkvEpi &
             o0 = x0 * c - x1 * s_; o1 = x0 * s_ + x1 * c;
         }
         const uint16_t h0 = f2h(o0), h1 = f2h(o1);
-        if (jb.role == 2) st_g((uint32_t *) (e.kc + kv_off + (long) slot * e.kv_dim + row), (uint32_t) h0 | ((uint32_t) h1 << 16));
-        else { st_g(jb.y + row, h2f(h0)); st_g(jb.y + row + 1, h2f(h1)); }
+        if (jb.role == 2) st_any<COH>((uint32_t *) (e.kc + kv_off + (long) slot * e.kv_dim + row), (uint32_t) h0 | ((uint32_t) h1 << 16));
+        else { st_any<COH>(jb.y + row, h2f(h0)); st_any<COH>(jb.y + row + 1, h2f(h1)); }
     }
 }
 

@@ -192,6 +192,11 @@ template <bool COH> __device__ __forceinline__ float4 ld_act4(const float4 * p) 
     }
     return ld_g(p);
 }
+// the same for the 2- and 4-byte stores of the QKV epilogue (K / V cache cells, F16 pairs): COH = agent-scope write-through (global_store ... sc1)
+template <bool COH, typename T> __device__ __forceinline__ void st_any(T * p, T v) {
+    if (COH) __hip_atomic_store((PM_G T *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else st_g(p, v);
+}
 template <bool COH> __device__ __forceinline__ void st_act(float * p, float v) {
     if (COH) __hip_atomic_store((PM_G float *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else st_g(p, v);
