@@ -353,9 +353,10 @@ int run_head(pm355_model * m, const float * x_row, float * d_logits, int32_t * d
 
 // The single-token layer stack as ONE persistent launch: the same launches run_layers_fused issues, appended as phases (decode_engine.hip).
 // nullptr: this window is not served (types, shapes, streaming, long-context regime) - the caller takes the five-launch path.
-pm_eng_plan * engine_plan_for(pm355_model * m, const float * cur, float * d_x_out, int * n_ss_end) {
+// may_build = false (the stream is being captured: no allocation, no synchronous copy): only a plan that exists already is returned.
+pm_eng_plan * engine_plan_for(pm355_model * m, const float * cur, float * d_x_out, int * n_ss_end, bool may_build = true) {
     for (auto & e : m->eng_plans) if (e.in == cur && e.out == d_x_out) { *n_ss_end = e.n_ss_end; return e.plan; }
-    if (m->eng_refused) return nullptr;
+    if (m->eng_refused || !may_build) return nullptr;
     const float * in0 = cur;
     const pm355_hparams & hp = m->hp;
     const int H = hp.n_head, Hkv = hp.n_head_kv, dh = hp.head_dim;
@@ -364,6 +365,7 @@ pm_eng_plan * engine_plan_for(pm355_model * m, const float * cur, float * d_x_ou
     pm_eng_plan * pl = pm_eng_plan_new();
     auto refuse = [&](const char * why, int rc) -> pm_eng_plan * {
         if (getenv("PM355_ENGINE_VERBOSE")) fprintf(stderr, "prima_mi355 engine: not served (%s, rc %d) - five launches per layer\n", why, rc);
+        (void) hipGetLastError();
         pm_eng_plan_free(pl); m->eng_refused = true; return nullptr;
     };
     const int max_keys = (m->split_scratch && m->split_min + 8 < hp.n_ctx) ? m->split_min + 8 : hp.n_ctx;
@@ -423,6 +425,10 @@ pm_eng_plan * engine_plan_for(pm355_model * m, const float * cur, float * d_x_ou
     m->eng_plans.push_back({in0, d_x_out, pl, n_dn});
     *n_ss_end = n_dn;
     return pl;
+}
+
+bool engine_eligible(const pm355_model * m) {
+    return m->use_engine && !m->no_fuse && !m->long_ctx && !m->n_slots && m->use_ss && m->ss && m->qkv_epi && m->rope_tab && (m->rope.mode == 0 || m->rope.mode == 2) && m->hi > m->lo;
 }
 
 // which single-token attention path the current sequence takes: 0 = one workgroup per head; else the cells the long-context grid is
@@ -546,8 +552,11 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         // ---- single token: every activation transform is fused into a mat-vec prologue / epilogue, 5 launches per layer
         const float * end = nullptr;
         pm_eng_plan * eng = nullptr;
-        const bool eng_ok = m->use_engine && !m->long_ctx && !m->n_slots && m->use_ss && m->ss && m->qkv_epi && m->rope_tab && (m->rope.mode == 0 || m->rope.mode == 2) && m->hi > m->lo;
-        if (eng_ok) eng = engine_plan_for(m, cur, d_x_out, &n_ss_head);
+        if (engine_eligible(m)) {
+            hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(st, &cst) == hipSuccess && cst == hipStreamCaptureStatusActive;
+            eng = engine_plan_for(m, cur, d_x_out, &n_ss_head, !capturing);
+        }
         if (eng) {
             // ---- ... or, where served, ALL layers as one persistent launch (decode_engine.hip): cos / sin table, the first norm's sum of squares, the engine
             pm_launch_rope_table(m->rope, m->d_pos, m->d_ctl, (const float *) m->rope_freqs.d, m->rope_tab, st);
@@ -1052,6 +1061,8 @@ int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * 
         const int rc = step_body(m, d_token, d_x_in, d_x_out, d_logits, d_argmax, advance, rotate, head_first, st);
         return rc ? rc : commit();
     }
+    // the engine's phase table is allocated and uploaded outside the capture (keyed on the activation pointers of this step)
+    if (engine_eligible(m)) { int n_; (void) engine_plan_for(m, d_token ? m->x : d_x_in, d_x_out, &n_); }
     hipGraphExec_t exec = nullptr;
     for (auto & g : m->graphs)
         if (g.in == d_x_in && g.tok == d_token && g.out == d_x_out && g.logits == d_logits && g.argmax == d_argmax &&
