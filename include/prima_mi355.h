@@ -301,6 +301,24 @@ PM355_API int pm355_mul_mat_vec_qkv(const pm355_matvec_job * jobs, int64_t K, co
 /* the same with the rms_norm's sum of squares taken from n_sumsq_in producer-side partials (pm355_mul_mat_vec_fused_ss) */
 PM355_API int pm355_mul_mat_vec_qkv_ss(const pm355_matvec_job * jobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
                                        const pm355_qkv_store * s, const double * sumsq_in, int n_sumsq_in, pm355_stream_t stream);
+/* The persistent decode engine (round 5, prima_cpp_amd/csrc/decode_engine.hip): a list of PHASES - the launches above, in order - executed as ONE
+ * launch: one workgroup per CU, a loader wave that streams every phase's weights into an LDS ring ahead of the consumers, a device-wide barrier
+ * and write-through hand-offs between phases. pm355_model_step uses it for the whole layer stack of a single-token step; this entry runs an
+ * arbitrary phase list (tests: every phase kind against the launch it stands for, bit for bit; ffn_down-sized rows to summation order).
+ *   kind 0: pm355_mul_mat_vec_fused_ss (qkv == NULL) or pm355_mul_mat_vec_qkv_ss (qkv != NULL; d_cell_nkv must be NULL: engine mode); an rms_norm
+ *           (norm_w != NULL) needs sumsq_in - the engine never reduces a row itself
+ *   kind 1: pm355_attn_cached over cells [0, d_pos[0]] (no mask), transposed V cache
+ * Returns 0, PM355_E_UNSUPPORTED when a phase is not served (types Q4_K / Q5_K / Q6_K, K % 256, rows per workgroup), PM355_E_HIP when the launch's
+ * watchdog fired (a bounded wait gave up). Synchronizes the stream. */
+typedef struct {
+    int32_t kind, njobs; int64_t K;
+    const pm355_matvec_job * jobs; const float * x_f32; const float * norm_w; float eps; int32_t n_sumsq_in;
+    double * sumsq_out; const double * sumsq_in;
+    const pm355_qkv_store * qkv;
+    const float * q_rot; void * k_cache; void * v_cache; const int32_t * d_pos; float * out;
+    int32_t n_head, n_head_kv, head_dim, n_ctx, max_keys; float kq_scale;
+} pm355_engine_phase;
+PM355_API int pm355_engine_run(const pm355_engine_phase * phases, int n_phases, pm355_stream_t stream);
 /* 0 when pm355_mul_mat_vec_qkv can serve this wq | wk | wv list (types, K, every workgroup's row slices hold whole rotation pairs) */
 PM355_API int pm355_mul_mat_vec_qkv_check(const pm355_matvec_job * jobs, int64_t K, int n_head_kv, int head_dim, int n_rot);
 PM355_API int pm355_mul_mat_vec_qkv_check_ex(const pm355_matvec_job * jobs, int64_t K, int n_head_kv, int head_dim, int n_rot, int rope_neox);

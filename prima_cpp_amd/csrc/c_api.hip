@@ -2,6 +2,7 @@
 #include "../../include/prima_mi355.h"
 #include "pm355_device.h"
 #include "pm355_kernels.h"
+#include "pm355_engine.h"
 #include "pm355_layer_ops.h"
 #include <stdio.h>
 #include <string.h>
@@ -373,6 +374,46 @@ int pm355_mul_mat_vec_qkv_ss(const pm355_matvec_job * jobs, int64_t K, const flo
     if (rc == -5) return fail(PM355_E_UNSUPPORTED, "mul_mat_vec_qkv: every workgroup's row slices must hold whole rotation pairs (N % (2 * CUs) == 0), N_k == N_v == n_head_kv * head_dim");
     if (rc) return gemv_rc(rc);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pm355_engine_run(const pm355_engine_phase * phs, int n, pm355_stream_t st) {
+    if (!phs || n < 1) return fail(PM355_E_SHAPE, "engine_run: phases");
+    pm_eng_plan * pl = pm_eng_plan_new();
+    int rc = 0;
+    for (int i = 0; i < n && !rc; ++i) {
+        const pm355_engine_phase & e = phs[i];
+        if (e.kind == 0) {
+            if (e.njobs < 1 || e.njobs > 3 || !e.jobs || !e.x_f32) { rc = -100; break; }
+            pm_gemv_fused f = {};
+            f.K = (int) e.K; f.njobs = e.njobs; f.xf = e.x_f32; f.norm_w = e.norm_w; f.eps = e.eps;
+            f.ss_out = e.sumsq_out; f.ss_in = e.sumsq_in; f.n_ss = e.n_sumsq_in;
+            for (int j = 0; j < e.njobs; ++j) {
+                f.job[j].type = e.jobs[j].type; f.job[j].N = (int) e.jobs[j].N; f.job[j].W = e.jobs[j].W; f.job[j].W2 = e.jobs[j].W2;
+                f.job[j].y = e.jobs[j].y; f.job[j].bias = e.jobs[j].bias; f.job[j].resid = e.jobs[j].resid;
+            }
+            pm_qkv_epi qe = {};
+            if (e.qkv) {
+                const pm355_qkv_store * s = e.qkv;
+                if (s->d_cell_nkv || !s->d_pos || e.njobs != 3) { rc = -100; break; }
+                qe = pm_qkv_epi{s->rope_table, s->d_pos, nullptr, nullptr, 0, s->k_cache, s->v_cache, s->n_head_kv, s->head_dim, s->n_ctx, s->n_rot, s->v_rowmajor, s->rope_neox};
+                f.epi = &qe;
+            }
+            rc = pm_eng_plan_add_matvec(pl, f);
+        } else if (e.kind == 1) {
+            rc = pm_eng_plan_add_attention(pl, e.q_rot, e.k_cache, e.v_cache, e.d_pos, nullptr, 0, e.out, e.n_head, e.n_head_kv, e.head_dim, e.n_ctx, e.kq_scale, e.max_keys);
+        } else rc = -100;
+    }
+    if (!rc) rc = pm_eng_plan_finish(pl);
+    if (rc) { pm_eng_plan_free(pl); (void) hipGetLastError(); char msg[96]; snprintf(msg, sizeof(msg), "engine_run: phase list not served (code %d)", rc); return fail(PM355_E_UNSUPPORTED, msg); }
+    (void) hipGetLastError();
+    pm_eng_plan_launch(pl, S(st));
+    const hipError_t le = hipGetLastError();
+    const hipError_t se = hipStreamSynchronize(S(st));
+    const int w = pm_eng_plan_status(pl);
+    pm_eng_plan_free(pl);
+    if (le != hipSuccess) return fail(PM355_E_HIP, "engine_run: launch", le);
+    if (se != hipSuccess) return fail(PM355_E_HIP, "engine_run: synchronize", se);
+    if (w) { char msg[96]; snprintf(msg, sizeof(msg), "engine_run: watchdog code %d", w); return fail(PM355_E_HIP, msg); }
     return 0;
 }
 int pm355_mul_mat_vec_qkv_check_ex(const pm355_matvec_job * jobs, int64_t K, int n_head_kv, int head_dim, int n_rot, int rope_neox) {

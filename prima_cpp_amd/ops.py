@@ -384,3 +384,58 @@ def attn_cached(q_rot, k_cache, v_cache, pos, n_head, n_head_kv, head_dim, n_ctx
     check(lib.pm355_attn_cached(ptr(q_rot), ptr(k_cache), ptr(v_cache), ptr(pos), ptr(cell_nkv), ptr(mask), ptr(out), n_head, n_head_kv,
                                 head_dim, n_ctx, float(scale), max_keys, flags, stream_ptr()), "attn_cached")
     return out
+
+
+class EnginePhase(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("kind", _C.c_int32), ("njobs", _C.c_int32), ("K", _C.c_int64),
+                ("jobs", _C.c_void_p), ("x_f32", _C.c_void_p), ("norm_w", _C.c_void_p), ("eps", _C.c_float), ("n_sumsq_in", _C.c_int32),
+                ("sumsq_out", _C.c_void_p), ("sumsq_in", _C.c_void_p), ("qkv", _C.c_void_p),
+                ("q_rot", _C.c_void_p), ("k_cache", _C.c_void_p), ("v_cache", _C.c_void_p), ("d_pos", _C.c_void_p), ("out", _C.c_void_p),
+                ("n_head", _C.c_int32), ("n_head_kv", _C.c_int32), ("head_dim", _C.c_int32), ("n_ctx", _C.c_int32), ("max_keys", _C.c_int32),
+                ("kq_scale", _C.c_float)]
+
+
+class EngineRun:
+    """A phase list for pm355_engine_run (the persistent decode engine, csrc/decode_engine.hip). matvec() / attention() append phases and return the
+    output tensors; run() executes them as ONE launch."""
+
+    def __init__(self):
+        self.phases, self.keep = [], []
+
+    def matvec(self, ws, x, norm_w=None, eps=0.0, w2s=None, biases=None, resids=None, sumsq_in=None, want_sumsq=False, qkv=None):
+        """qkv = dict(tab=, pos=, k_cache=, v_cache=, n_head_kv=, head_dim=, n_ctx=, n_rot=, neox=) for the wq | wk | wv phase with RoPE + KV store."""
+        import ctypes as C
+        n = len(ws)
+        jobs = (MatvecJob * n)()
+        ys = []
+        for j, w in enumerate(ws):
+            y = torch.zeros(w.N, dtype=torch.float32, device=w.data.device)
+            ys.append(y)
+            jobs[j] = MatvecJob(w.type, 0, w.N, ptr(w.data), ptr(w2s[j].data) if w2s else None, ptr(y),
+                                ptr(biases[j]) if biases and biases[j] is not None else None, ptr(resids[j]) if resids and resids[j] is not None else None)
+        ss = torch.zeros(256, dtype=torch.float64, device=x.device) if want_sumsq else None
+        st = None
+        if qkv is not None:
+            st = QkvStore(ptr(qkv["tab"]), ptr(qkv["pos"]), None, ptr(qkv["k_cache"]), ptr(qkv["v_cache"]), qkv["n_head_kv"], qkv["head_dim"], qkv["n_ctx"],
+                          qkv.get("n_rot") or qkv["head_dim"], 0, int(qkv.get("neox", False)))
+        ph = EnginePhase(0, n, ws[0].K, C.addressof(jobs), ptr(x), ptr(norm_w), float(eps), 0 if sumsq_in is None else sumsq_in.numel(), ptr(ss), ptr(sumsq_in),
+                         C.addressof(st) if st is not None else None, None, None, None, None, None, 0, 0, 0, 0, 0, 0.0)
+        self.phases.append(ph)
+        self.keep += [jobs, ys, ss, st, x, norm_w, sumsq_in, biases, resids]
+        return (ys, ss) if want_sumsq else ys
+
+    def attention(self, q_rot, k_cache, v_cache, pos, n_head, n_head_kv, head_dim, n_ctx, scale, max_keys=0):
+        out = torch.zeros(n_head * head_dim, dtype=torch.float32, device=q_rot.device)
+        self.phases.append(EnginePhase(1, 0, 0, None, None, None, 0.0, 0, None, None, None, ptr(q_rot), ptr(k_cache), ptr(v_cache), ptr(pos), ptr(out),
+                                       n_head, n_head_kv, head_dim, n_ctx, max_keys, float(scale)))
+        self.keep += [out, q_rot, k_cache, v_cache, pos]
+        return out
+
+    def run(self):
+        import ctypes as C
+        lib = L.load()
+        lib.pm355_engine_run.restype = C.c_int
+        lib.pm355_engine_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        arr = (EnginePhase * len(self.phases))(*self.phases)
+        check(lib.pm355_engine_run(C.addressof(arr), len(self.phases), stream_ptr()), "engine_run")

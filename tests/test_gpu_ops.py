@@ -921,3 +921,89 @@ def test_native_q8_0_cache_view_matmul_and_dequantizing_copy(P, oracle):
     torch.cuda.synchronize()
     want = np.stack([oracle.dequantize_row(Q8_0, blocks[i * row_b:(i + 1) * row_b], Ekv) for i in range(n_ctx)]).reshape(n_ctx, Hkv, dh)
     assert np.array_equal(deq.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("t", [Q4_K, Q6_K, Q5_K])
+@pytest.mark.parametrize("K,N", [(1024, 512), (8192, 8192), (4096, 1024), (5120, 2560)])
+def test_engine_matvec_phase_is_bit_identical_to_the_launch(P, t, K, N):
+    """Persistent decode engine, one mat-vec phase (+ residual, + producer-side partials) against pm355_mul_mat_vec_fused_ss on the same operands: whole-row
+    items, same consume() arithmetic -> the same bits; then a two-phase list (wo-like phase -> rms_norm + pair phase fed through the in-launch seam)."""
+    torch = P.torch
+    rng = np.random.default_rng(900 + K + N)
+    w = P.upload_weight(t, rand_blocks(t, N, K, rng), K, N)
+    x = torch.from_numpy(rng.normal(0, 1.0, (1, K)).astype(np.float32)).cuda()
+    resid = torch.from_numpy(rng.normal(0, 2.0, N).astype(np.float32)).cuda()
+    (want,), ss_want = P.mul_mat_vec_fused_ss([w], x, resids=[resid], want_sumsq=True)
+    e = P.EngineRun()
+    (got,), ss = e.matvec([w], x, resids=[resid], want_sumsq=True)
+    e.run()
+    assert torch.equal(got, want), (got - want).abs().max()
+    assert torch.equal(ss[:ss_want.numel()], ss_want)
+    if t == Q5_K or N % 256:
+        return
+    # two phases: y = W x + resid, then h = silu(G n(y)) * (U n(y)) with the sum of squares handed over inside the launch
+    F = 768
+    g = P.upload_weight(t, rand_blocks(t, F, N, rng), N, F)
+    u = P.upload_weight(t, rand_blocks(t, F, N, rng), N, F)
+    nw = torch.from_numpy((1 + rng.normal(0, 0.05, N)).astype(np.float32)).cuda()
+    want_h = P.mul_mat_vec_fused([g], want.view(1, -1), norm_w=nw, eps=1e-5, w2s=[u])[0]
+    e = P.EngineRun()
+    (y1,), ss1 = e.matvec([w], x, resids=[resid], want_sumsq=True)
+    (h,) = e.matvec([g], y1, norm_w=nw, eps=1e-5, w2s=[u], sumsq_in=ss1[:ss_want.numel()])
+    e.run()
+    assert torch.equal(y1, want)
+    assert torch.equal(h, want_h), (h - want_h).abs().max()
+
+
+@pytest.mark.parametrize("t", [Q4_K, Q6_K])
+def test_engine_long_rows_are_summed_chunk_by_chunk(P, oracle, t):
+    """ffn_down-sized rows (K = 28672: seven steps per row) do not fit the ring as whole rows next to the run-ahead: the engine deals them out step by
+    step and adds the seven wave sums in chunk order - summation order only against the launch (and the oracle)."""
+    torch = P.torch
+    rng = np.random.default_rng(77)
+    K, N = 28672, 8192
+    blocks = rand_blocks(t, N, K, rng)
+    w = P.upload_weight(t, blocks, K, N)
+    x = torch.from_numpy(rng.normal(0, 1.0, (1, K)).astype(np.float32)).cuda()
+    resid = torch.from_numpy(rng.normal(0, 2.0, N).astype(np.float32)).cuda()
+    want = P.mul_mat_vec_fused([w], x, resids=[resid])[0]
+    e = P.EngineRun()
+    (got,) = e.matvec([w], x, resids=[resid])
+    e.run()
+    d = (got - want).abs().max().item()
+    assert d <= 2e-5 * max(1.0, want.abs().max().item()), d
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("n_past", [0, 5, 63, 64, 200])
+def test_engine_qkv_and_attention_phases_equal_the_launches(P, mode, n_past):
+    """wq | wk | wv + RoPE + KV store, then attention over the cached cells, as two phases of one engine launch (q and the token's cell cross the
+    in-launch seam) against pm355_mul_mat_vec_qkv + pm355_attn_cached: same bits in q, in the caches and in the attention output, below and above the
+    64-cell short path."""
+    torch = P.torch
+    rng = np.random.default_rng(31 + n_past + mode)
+    E_, H, Hkv, dh, n_ctx = 2048, 16, 4, 128, 256
+    ws = [P.upload_weight(Q4_K, rand_blocks(Q4_K, H * dh, E_, rng), E_, H * dh), P.upload_weight(Q4_K, rand_blocks(Q4_K, Hkv * dh, E_, rng), E_, Hkv * dh),
+          P.upload_weight(Q6_K, rand_blocks(Q6_K, Hkv * dh, E_, rng), E_, Hkv * dh)]
+    x = torch.from_numpy(rng.normal(0, 1.0, (1, E_)).astype(np.float32)).cuda()
+    nw = torch.from_numpy((1 + rng.normal(0, 0.05, E_)).astype(np.float32)).cuda()
+    pos = torch.tensor([n_past], dtype=torch.int32, device="cuda")
+    tab = P.rope_table(pos, dh, mode=mode, freq_base=500000.0)
+    kc0 = torch.from_numpy(rng.normal(0, 1, (n_ctx, Hkv * dh)).astype(np.float16)).cuda()
+    vc0 = torch.from_numpy(rng.normal(0, 1, (Hkv * dh, n_ctx)).astype(np.float16)).cuda()
+    scale = 1.0 / np.sqrt(dh)
+    ssx = (x.double() ** 2).float().double().sum().view(1)          # one-partial sum of squares of the input row (f32-rounded squares)
+    # launches
+    kc1, vc1 = kc0.clone(), vc0.clone()
+    q1 = P.mul_mat_vec_qkv(ws, x, tab, pos, kc1, vc1, Hkv, dh, n_ctx, norm_w=nw, eps=1e-5, neox=bool(mode & 2))
+    a1 = P.attn_cached(q1, kc1, vc1, pos, H, Hkv, dh, n_ctx, scale)
+    # engine
+    kc2, vc2 = kc0.clone(), vc0.clone()
+    e = P.EngineRun()
+    ys = e.matvec(ws, x, norm_w=nw, eps=1e-5, sumsq_in=ssx,
+                  qkv=dict(tab=tab, pos=pos, k_cache=kc2, v_cache=vc2, n_head_kv=Hkv, head_dim=dh, n_ctx=n_ctx, neox=bool(mode & 2)))
+    a2 = e.attention(ys[0], kc2, vc2, pos, H, Hkv, dh, n_ctx, scale)
+    e.run()
+    assert torch.equal(ys[0], q1), (ys[0] - q1).abs().max()
+    assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
+    assert torch.equal(a2, a1), (a2 - a1).abs().max()
