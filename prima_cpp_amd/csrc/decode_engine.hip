@@ -50,7 +50,7 @@ struct EngPhase {
     const float * aq; uint16_t * akc, * avc; const int32_t * apos, * aseq; long aseq_stride; float * aout;
     int aH, aHkv, adh, an_ctx, amax_keys; float ascale;
 };
-struct EngArgs { const EngPhase * ph; int n_ph; unsigned * ctr; int * err; };
+struct EngArgs { const EngPhase * ph; int n_ph; unsigned * ctr; int * err; float * dbg; };
 
 typedef __attribute__((address_space(3))) void * lds_vp;
 typedef __attribute__((address_space(3))) unsigned lds_u32;
@@ -127,8 +127,10 @@ __device__ __forceinline__ void g_wait(unsigned * ctr, unsigned phase, unsigned 
 // ---- coherent (agent-scope, sc1) buffer accesses: tracked by the compiler's waitcnt logic, 16 bytes per instruction ---------------------------
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t coh_rsrc(const void * base) { return __builtin_amdgcn_make_buffer_rsrc((void *) base, 0, 0x7FFFFFF0, 0x00020000); }
 __device__ __forceinline__ float4 coh_ld16(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-    const u32x4 t = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int) off, 0, 16));
-    return make_float4(__builtin_bit_cast(float, t[0]), __builtin_bit_cast(float, t[1]), __builtin_bit_cast(float, t[2]), __builtin_bit_cast(float, t[3]));
+    // (the whole vector is re-typed at once: element-wise __builtin_bit_cast(float, t[i]) of the loaded vector compiles to a ONE-dword load that
+    //  feeds all four components - ROCm 7.2 clang; found on the hardware, tools/r5)
+    const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int) off, 0, 16));
+    return make_float4(t.x, t.y, t.z, t.w);
 }
 __device__ __forceinline__ u32x4 coh_ld16u(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int) off, 0, 16)); }
 __device__ __forceinline__ float coh_ld4(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int) off, 0, 16)); }
@@ -301,6 +303,9 @@ __device__ __forceinline__ void loader_wave(const EngArgs & A, Ctl * c, char * r
 
 // ---- consumers ---------------------------------------------------------------------------------------------------------------------------------
 // one item: `steps` steps of a row (both matrices of a pair), products against the LDS activation row; the wave's sum goes to out[slot]
+#ifdef ENG_DEBUG
+__device__ float * g_dbg_lane = nullptr;      // (debug builds: per-lane record of the item being consumed, set by the kernel for item 0 of workgroup 0)
+#endif
 template <int TYPE, bool PAIR>
 __device__ __forceinline__ void eat_item(const char * img, int U, const XLds & xs, int c0, int steps, int lane, float * out_slot) {
     typedef QT<TYPE> T;
@@ -321,7 +326,12 @@ __device__ __forceinline__ void eat_item(const char * img, int U, const XLds & x
             load_x_lds<TYPE>(x, xs, u, 0);
             x.yd = uv ? x.yd : 0.0f;                       // a clamped (out-of-row) unit contributes exactly 0
 #pragma unroll
-            for (int m = 0; m < NM; ++m) { int isum, msum; acc[m] = T::consume(w[m][i], x, u, acc[m], isum, msum); }
+            for (int m = 0; m < NM; ++m) {
+                int isum, msum; acc[m] = T::consume(w[m][i], x, u, acc[m], isum, msum);
+#ifdef ENG_DEBUG
+                if (g_dbg_lane && s == 0 && i == 0 && m == 0) { float * o = g_dbg_lane + 8 * lane; o[0] = (float) isum; o[1] = (float) msum; o[2] = x.yd; o[3] = acc[m]; o[4] = (float) x.q[0]; o[5] = (float) x.gs[0]; o[6] = (float) u; o[7] = (float) uv; }
+#endif
+            }
         }
     }
     float o[NM];
@@ -588,6 +598,9 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
                 spin_ge(&c->landed, n + 1, c, A.err, 4);
                 const char * img = ring + lds_ld(&c->item_off[n & 63]);
                 float * slot = outbuf + q_ob + id;
+#ifdef ENG_DEBUG
+                g_dbg_lane = (A.dbg && b == 0 && n == 0) ? A.dbg + 64 * 16 : nullptr;
+#endif
                 if (type == PM_Q4_K) { if (pair) eat_item<PM_Q4_K, true>(img, U, xs, c0, q_steps, lane, slot); else eat_item<PM_Q4_K, false>(img, U, xs, c0, q_steps, lane, slot); }
 #ifndef ENG_NO_Q6
                 else if (type == PM_Q6_K) { if (pair) eat_item<PM_Q6_K, true>(img, U, xs, c0, q_steps, lane, slot); else eat_item<PM_Q6_K, false>(img, U, xs, c0, q_steps, lane, slot); }
@@ -597,6 +610,15 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
 #endif
                 ++k_done;
                 __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): the image has been read (and the result parked)
+#ifdef ENG_DEBUG
+                if (A.dbg && b == 0 && lane == 0 && n < 64) {
+                    float * o = A.dbg + 16 * n;
+                    o[0] = (float) n; o[1] = (float) (img - ring); o[2] = (float) (q_ob + id); o[3] = *slot; o[4] = (float) lds_ld(&c->landed); o[5] = (float) U; o[6] = (float) q_steps; o[7] = (float) type;
+                    o[8] = __builtin_bit_cast(float, *(const uint32_t *) img); o[9] = __builtin_bit_cast(float, *(const uint32_t *) (img + 2048)); o[10] = (float) xs_q[0]; o[11] = xs_d[0];
+                    o[12] = (float) wave; o[13] = (float) c0; o[14] = (float) pi; o[15] = 1.0f;
+                    if (n == 0) { float * o2 = A.dbg + 64 * 16 + 64 * 8; for (int i = 0; i < 32; ++i) o2[i] = (float) xs_q[i]; for (int i = 0; i < 4; ++i) o2[32 + i] = xs_d[i]; for (int i = 0; i < 8; ++i) o2[36 + i] = (float) xs_gs[i]; }
+                }
+#endif
                 if (lane == 0) lds_st(&c->done[wave], k_done);
             }
             nbase += (unsigned) nit;
@@ -651,7 +673,7 @@ void pm_launch_sumsq_row(const float * x, int K, double * out, hipStream_t st) {
 // ---- host side -----------------------------------------------------------------------------------------------------------------------------------
 struct pm_eng_plan {
     std::vector<EngPhase> ph;
-    EngPhase * d_ph = nullptr; unsigned * d_ctr = nullptr; int * d_err = nullptr;
+    EngPhase * d_ph = nullptr; unsigned * d_ctr = nullptr; int * d_err = nullptr; float * d_dbg = nullptr;
     int grid = 0; bool finished = false;
 };
 
@@ -733,13 +755,29 @@ int pm_eng_plan_finish(pm_eng_plan * pl) {
 
 int pm_eng_plan_launch(pm_eng_plan * pl, hipStream_t st) {
     if (!pl || !pl->finished) return -1;
-    EngArgs a = {pl->d_ph, (int) pl->ph.size(), pl->d_ctr, pl->d_err};
+#ifdef ENG_DEBUG
+    if (!pl->d_dbg) { (void) hipMalloc((void **) &pl->d_dbg, (64 * 16 + 64 * 8 + 64) * 4); (void) hipMemset(pl->d_dbg, 0, (64 * 16 + 64 * 8 + 64) * 4); }
+#endif
+    EngArgs a = {pl->d_ph, (int) pl->ph.size(), pl->d_ctr, pl->d_err, pl->d_dbg};
     hipLaunchKernelGGL(decode_engine_kernel, dim3(pl->grid), dim3(ENG_THREADS), ENG_LDS, st, a);
     return 0;
 }
 
 int pm_eng_plan_status(pm_eng_plan * pl) {
     if (!pl || !pl->finished) return -1;
+#ifdef ENG_DEBUG
+    if (pl->d_dbg) {
+        std::vector<float> h(64 * 16 + 64 * 8 + 64);
+        (void) hipMemcpy(h.data(), pl->d_dbg, h.size() * 4, hipMemcpyDeviceToHost);
+        { const float * o = &h[64 * 16 + 64 * 8]; fprintf(stderr, "eng xs_q[0..31]:"); for (int i = 0; i < 32; ++i) fprintf(stderr, " %g", o[i]); fprintf(stderr, "\neng xs_d[0..3]: %g %g %g %g  gs[0..7]:", o[32], o[33], o[34], o[35]); for (int i = 0; i < 8; ++i) fprintf(stderr, " %g", o[36 + i]); fprintf(stderr, "\n"); }
+        for (int l = 0; l < 20; ++l) { const float * o = &h[64 * 16 + 8 * l]; fprintf(stderr, "eng lane %2d: isum=%g msum=%g yd=%g acc=%g xq0=%g gs0=%g u=%g uv=%g\n", l, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]); }
+        for (int i = 0; i < 64; ++i) if (h[16 * i + 15] != 0.0f) {
+            const float * o = &h[16 * i];
+            fprintf(stderr, "eng item n=%g off=%g slot=%g val=%g landed=%g U=%g steps=%g type=%g w0=%08x hdr0=%08x xq0=%g xd0=%g wave=%g c0=%g phase=%g\n", o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7],
+                    __builtin_bit_cast(uint32_t, o[8]), __builtin_bit_cast(uint32_t, o[9]), o[10], o[11], o[12], o[13], o[14]);
+        }
+    }
+#endif
     int err = 0;
     if (hipMemcpy(&err, pl->d_err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -2;
     if (err) {
