@@ -57,7 +57,7 @@ typedef __attribute__((address_space(3))) unsigned lds_u32;
 
 // LDS control block. Accessed ONLY through LDS-typed pointers (a generic access is FLAT: it waits on vmcnt too and would drain the loader's queue);
 // the loader's own accesses are inline asm (a compiler-visible LDS access after global_load_lds gets an s_waitcnt vmcnt(0) in front of it).
-struct Ctl { unsigned landed, cbar, abar, giveup; unsigned done[16]; unsigned item_off[64]; };
+struct Ctl { unsigned landed, cbar, abar, giveup; unsigned done[16]; unsigned item_off[64]; unsigned item_U[64]; };      // (item_U right behind item_off: one ds_write2st64 per item)
 
 __device__ __forceinline__ lds_u32 * L(unsigned * p) { return (lds_u32 *) p; }
 __device__ __forceinline__ unsigned lds_ld(unsigned * p) { return __hip_atomic_load(L(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -124,16 +124,19 @@ __device__ __forceinline__ void g_wait(unsigned * ctr, unsigned phase, unsigned 
     }
 }
 
-// ---- coherent (agent-scope, sc1) buffer accesses: tracked by the compiler's waitcnt logic, 16 bytes per instruction ---------------------------
+// ---- coherent buffer loads: tracked by the compiler's waitcnt logic, 16 bytes per instruction. `sc0 sc1` (aux 17), not `sc1` alone: a buffer that is
+// handed over more than once per launch (the residual stream, q, the attention output, the ffn activation, the partial sums - every layer re-uses
+// them) may still sit in THIS XCD's L2 from the previous layer's read, and an sc1 load is served from there: two 70B layers differed by 1e-4 from
+// the five launches, one layer by 1e-14 (found on the hardware). The write side stays sc1 write-through (st_act<true>). --------------------------
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t coh_rsrc(const void * base) { return __builtin_amdgcn_make_buffer_rsrc((void *) base, 0, 0x7FFFFFF0, 0x00020000); }
 __device__ __forceinline__ float4 coh_ld16(__amdgpu_buffer_rsrc_t r, uint32_t off) {
     // (the whole vector is re-typed at once: element-wise __builtin_bit_cast(float, t[i]) of the loaded vector compiles to a ONE-dword load that
     //  feeds all four components - ROCm 7.2 clang; found on the hardware, tools/r5)
-    const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int) off, 0, 16));
+    const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int) off, 0, 17));
     return make_float4(t.x, t.y, t.z, t.w);
 }
-__device__ __forceinline__ u32x4 coh_ld16u(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int) off, 0, 16)); }
-__device__ __forceinline__ float coh_ld4(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int) off, 0, 16)); }
+__device__ __forceinline__ u32x4 coh_ld16u(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int) off, 0, 17)); }
+__device__ __forceinline__ float coh_ld4(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int) off, 0, 17)); }
 
 // ---- ring image of one STEP of a row: the pieces a wave reads with one instruction each, lane-major ------------------------------------------
 //   Q4_K (2304 B): qa[64][16] | qb[64][16] | hdr[16][16]                    Q6_K (3360 B): la[64][16] | lb[64][16] | qh[64][16] | scales[16][16] | d[16]
@@ -177,23 +180,25 @@ __device__ __forceinline__ void dma_step(char * dst, const uint8_t * row, int K,
 }
 // the step's weight registers of this lane, from the ring image
 template <int TYPE> struct LW;
+// (ulast = last valid unit of the row relative to the step's first: Q4_K / Q6_K images hold clamped copies per lane already, the Q5_K image is a
+//  plain copy of the row's bytes - its reader clamps, or the f16 scales of a tail step would be whatever follows the row)
 template <> struct LW<PM_Q4_K> {
-    static __device__ __forceinline__ void get(typename QT<PM_Q4_K>::Wr (&w)[1], const char * b, int lane) {
+    static __device__ __forceinline__ void get(typename QT<PM_Q4_K>::Wr (&w)[1], const char * b, int lane, int) {
         w[0].q0 = *(const u32x4 *) (b + lane * 16); w[0].q1 = *(const u32x4 *) (b + 1024 + lane * 16); w[0].h = *(const u32x4 *) (b + 2048 + (lane >> 2) * 16);
     }
 };
 template <> struct LW<PM_Q6_K> {
-    static __device__ __forceinline__ void get(typename QT<PM_Q6_K>::Wr (&w)[1], const char * b, int lane) {
+    static __device__ __forceinline__ void get(typename QT<PM_Q6_K>::Wr (&w)[1], const char * b, int lane, int) {
         w[0].l0 = *(const u32x4 *) (b + lane * 16); w[0].l1 = *(const u32x4 *) (b + 1024 + lane * 16); w[0].h = *(const u32x4 *) (b + 2048 + lane * 16);
         w[0].s = *(const u32x2 *) (b + 3072 + (lane >> 2) * 16 + 8 * ((lane >> 1) & 1));
         w[0].d = *(const uint16_t *) (b + 3328 + (lane >> 2) * 2);
     }
 };
 template <> struct LW<PM_Q5_K> {
-    static __device__ __forceinline__ void get(typename QT<PM_Q5_K>::Wr (&w)[2], const char * b, int lane) {
+    static __device__ __forceinline__ void get(typename QT<PM_Q5_K>::Wr (&w)[2], const char * b, int lane, int ulast) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int ul = lane + 64 * i, hb = (ul >> 3) * PM_BS_Q5_K;
+            const int ul = min(lane + 64 * i, ulast), hb = (ul >> 3) * PM_BS_Q5_K;
             w[i].q = *(const u32x4 *) (b + hb + 48 + 16 * (ul & 7)); w[i].qh = *(const u32x4 *) (b + hb + 16 + 16 * (ul & 1)); w[i].h = *(const u32x4 *) (b + hb);
         }
     }
@@ -215,90 +220,96 @@ __device__ __forceinline__ JobGeo job_geo(const GemvJob & jb, int type, int pair
     return g;
 }
 
-// v = value in lane `idx` (both wave-uniform), the other lanes keep theirs (v_writelane with two SGPR operands violates the constant-bus rule on
-// gfx9 and M0 belongs to the DMA instructions: a compare + select does it)
-__device__ __forceinline__ void write_lane(int & v, int value, int idx, int lane) { v = lane == idx ? value : v; }
-
 // ---- loader wave ------------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void loader_wave(const EngArgs & A, Ctl * c, char * ring, int lane) {
-    const int b = blockIdx.x, G = gridDim.x;
-    unsigned n = 0;                                        // items issued so far (launch-wide, this CU)
-    unsigned cur = 0, U_ = 0;                              // ring cursor; the same unwrapped (skipped tails included)
-    unsigned cum = 0;                                      // DMA instructions issued
-    unsigned tail = 0, m_landed = 0;                       // oldest item not yet retired (cached); items published as landed
-    int fifoU = 0, fifoC = 0;                              // lane (i % 64): unwrapped start / instruction count after item i
-    auto refresh_tail = [&]() __attribute__((always_inline)) {
-        unsigned v = lane < ENG_NC ? (unsigned) lane + lds_ld_asm(&c->done[lane < ENG_NC ? lane : 0]) * (unsigned) ENG_NC : 0xFFFFFFFFu;
+// One wave runs EVERYTHING the weights need - its instruction stream is the engine's bandwidth: a single wave issues one instruction every
+// 5-8 cycles, a 2304-byte step has to leave every ~180 cycles, so an item may cost ~40 instructions besides its DMA. Hence: every cursor lives in
+// SGPRs (no lane-indexed FIFOs, no per-item loops), the type / pair dispatch is per JOB, and `landed` follows from arithmetic - all items of a
+// job carry the same number of DMA instructions, so after s_waitcnt vmcnt(48) everything but the job's newest ceil(48 / k) items has landed.
+struct LoaderState {
+    unsigned n, cur, U, tail, tailU, landed;               // items issued | ring cursor | the same unwrapped | oldest unretired item (cached) and its unwrapped start | published
+};
+__device__ __forceinline__ void lds_st2_asm(unsigned * p, unsigned a, unsigned b) {       // p[0] = a, p[64] = b (item_off / item_U of one FIFO slot)
+    asm volatile("ds_write2st64_b32 %0, %1, %2 offset1:1" :: "v"((unsigned) (uintptr_t) L(p)), "v"(a), "v"(b) : "memory");
+}
+// room for `bytes` at the cursor? (the live window [start of the oldest unretired item, end of this item) may not exceed the ring)
+__device__ __forceinline__ bool loader_make_room(const EngArgs & A, Ctl * c, LoaderState & S, unsigned bytes, int lane) {
+    if (S.cur + bytes > (unsigned) ENG_RING) { S.U += (unsigned) ENG_RING - S.cur; S.cur = 0; }
+    if (S.U + bytes - S.tailU <= (unsigned) ENG_RING) return true;
+    int spins = 0;
+    for (;;) {
+        // refresh the tail: wave w has retired done[w] of its items (w, w + 15, ...): the oldest unretired item of the launch is the minimum
+        const unsigned v = lane < ENG_NC ? (unsigned) lane + lds_ld_asm(&c->done[lane < ENG_NC ? lane : 0]) * (unsigned) ENG_NC : 0xFFFFFFFFu;
         unsigned t = 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < ENG_NC; ++i) t = min(t, (unsigned) __builtin_amdgcn_readlane((int) v, i));
-        tail = min(t, n);
-    };
-    auto publish = [&]() __attribute__((always_inline)) {     // items whose last instruction is older than the ENG_VMAX newest have landed
-        while (m_landed < n && (unsigned) __builtin_amdgcn_readlane(fifoC, (int) (m_landed & 63)) + (unsigned) ENG_VMAX <= cum) ++m_landed;
-        if (lane == 0) lds_st_asm(&c->landed, m_landed);
-    };
+        S.tail = min(t, S.n);
+        S.tailU = S.tail >= S.n ? S.U : (unsigned) __builtin_amdgcn_readfirstlane((int) lds_ld_asm(&c->item_U[S.tail & 63]));
+        if (S.U + bytes - S.tailU <= (unsigned) ENG_RING) return true;
+        // ring full: nothing can be issued anyway -> drain, publish everything in flight, wait for a retirement
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (S.landed != S.n) { S.landed = S.n; if (lane == 0) lds_st_asm(&c->landed, S.n); }
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_readfirstlane((int) lds_ld_asm(&c->giveup))) return false;     // (made scalar: a divergent exit would turn every cursor into a VGPR)
+        if (++spins > (1 << 22)) { give_up(c, A.err, 1, true); return false; }
+    }
+}
+template <int TYPE, bool PAIR>
+__device__ __forceinline__ bool loader_job(const EngArgs & A, Ctl * c, char * ring, LoaderState & S, const GemvJob & jb, int K, int b, int G, int lane) {
+    const JobGeo jg = job_geo(jb, TYPE, PAIR, b, G, 0);
+    constexpr int SB = ST<TYPE>::BYTES;
+    const unsigned k_item = (unsigned) (ST<TYPE>::NDMA * jg.steps * (PAIR ? 2 : 1));      // DMA instructions per item
+    const unsigned lag = ((unsigned) ENG_VMAX + k_item - 1) / k_item;                    // items the newest ENG_VMAX instructions may belong to
+    const unsigned job_n0 = S.n;
+    const int rows = jg.r1 - jg.r0, chunks = jg.split ? jg.cpr : 1;
+    for (int r = 0; r < rows; ++r) {
+        const int lrow = jg.r0 + r;
+        const uint8_t * row = jb.W + (long) job_row(jb, lrow) * jb.row_stride;
+        const uint8_t * row2 = PAIR ? jb.W2 + (long) lrow * jb.row_stride : nullptr;
+        for (int cc = 0; cc < chunks; ++cc) {
+            if (!loader_make_room(A, c, S, (unsigned) jg.bytes, lane)) return false;
+            char * dst = ring + S.cur;
+            for (int s_ = 0; s_ < jg.steps; ++s_) {
+                dma_step<TYPE>(dst + s_ * SB, row, K, jb.U, cc + s_, lane);
+                if (PAIR) dma_step<TYPE>(dst + (jg.steps + s_) * SB, row2, K, jb.U, cc + s_, lane);
+            }
+            if (lane == 0) lds_st2_asm(&c->item_off[S.n & 63], S.cur, S.U);
+            S.cur += (unsigned) jg.bytes; S.U += (unsigned) jg.bytes; ++S.n;
+            asm volatile("s_waitcnt vmcnt(48)" ::: "memory");                             // (ENG_VMAX)
+            const unsigned in_job = S.n - job_n0;
+            const unsigned pub = in_job > lag ? S.n - lag : (in_job * k_item >= (unsigned) ENG_VMAX ? job_n0 : S.landed);
+            if (pub != S.landed) { S.landed = pub; if (lane == 0) lds_st_asm(&c->landed, pub); }
+        }
+    }
+    return true;
+}
+__device__ __forceinline__ void loader_wave(const EngArgs & A, Ctl * c, char * ring, int lane) {
+    const int b = blockIdx.x, G = gridDim.x;
+    __builtin_amdgcn_s_setprio(3);                         // the youngest wave of its SIMD would otherwise lose every arbitration to the consumers
+    LoaderState S = {0, 0, 0, 0, 0, 0};
+#ifdef ENG_DEBUG
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const EngPhase * phs = uniform_const_ptr(A.ph);
     for (int pi = 0; pi < A.n_ph; ++pi) {
         const EngPhase * ph = phs + pi;
         if (ph->kind != 0) continue;
         const int K = ph->g.K, pair = ph->pair, ta = ph->ta, tb = ph->tb;
         for (int j = 0; j < 3; ++j) {
-            const int N = ph->g.job[j].N;
-            if (N <= 0) continue;
-            GemvJob jb = ph->g.job[j];
+            if (ph->g.job[j].N <= 0) continue;
+            const GemvJob & jb = ph->g.job[j];
             const int type = jb.is_b ? tb : ta;
-            const JobGeo jg = job_geo(jb, type, pair, b, G, 0);
-            const int sb = type_step_bytes(type);
-            for (int it = 0; it < jg.items; ++it) {
-                const int lrow = jg.r0 + (jg.split ? it / jg.cpr : it), c0 = jg.split ? it % jg.cpr : 0;
-                // ---- place: the image may not overlap an item that has not been retired (live window [start of `tail`, end of this item) <= ring)
-                if (cur + (unsigned) jg.bytes > (unsigned) ENG_RING) { U_ += (unsigned) ENG_RING - cur; cur = 0; }
-                auto fits = [&]() __attribute__((always_inline)) {
-                    return tail >= n || U_ + (unsigned) jg.bytes - (unsigned) __builtin_amdgcn_readlane(fifoU, (int) (tail & 63)) <= (unsigned) ENG_RING;
-                };
-                int spins = 0;
-                while (!fits()) {
-                    refresh_tail();
-                    if (fits()) break;
-                    // ring full: nothing can be issued anyway -> drain and publish everything in flight, then wait for a retirement
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    m_landed = n;
-                    if (lane == 0) lds_st_asm(&c->landed, n);
-                    __builtin_amdgcn_s_sleep(1);
-                    if (lds_ld_asm(&c->giveup)) return;
-                    if (++spins > (1 << 22)) { give_up(c, A.err, 1, true); return; }
-                }
-                // ---- issue
-                char * dst = ring + cur;
-                const uint8_t * row = jb.W + (long) job_row(jb, lrow) * jb.row_stride;
-                int ndma;
-                if (type == PM_Q4_K) {
-                    for (int s = 0; s < jg.steps; ++s) dma_step<PM_Q4_K>(dst + s * sb, row, K, jb.U, c0 + s, lane);
-                    if (pair) { const uint8_t * row2 = jb.W2 + (long) lrow * jb.row_stride; for (int s = 0; s < jg.steps; ++s) dma_step<PM_Q4_K>(dst + (jg.steps + s) * sb, row2, K, jb.U, c0 + s, lane); }
-                    ndma = ST<PM_Q4_K>::NDMA;
-                } else if (type == PM_Q6_K) {
-                    for (int s = 0; s < jg.steps; ++s) dma_step<PM_Q6_K>(dst + s * sb, row, K, jb.U, c0 + s, lane);
-                    if (pair) { const uint8_t * row2 = jb.W2 + (long) lrow * jb.row_stride; for (int s = 0; s < jg.steps; ++s) dma_step<PM_Q6_K>(dst + (jg.steps + s) * sb, row2, K, jb.U, c0 + s, lane); }
-                    ndma = ST<PM_Q6_K>::NDMA;
-                } else {
-                    for (int s = 0; s < jg.steps; ++s) dma_step<PM_Q5_K>(dst + s * sb, row, K, jb.U, c0 + s, lane);
-                    if (pair) { const uint8_t * row2 = jb.W2 + (long) lrow * jb.row_stride; for (int s = 0; s < jg.steps; ++s) dma_step<PM_Q5_K>(dst + (jg.steps + s) * sb, row2, K, jb.U, c0 + s, lane); }
-                    ndma = ST<PM_Q5_K>::NDMA;
-                }
-                cum += (unsigned) (ndma * jg.steps * (pair ? 2 : 1));
-                write_lane(fifoU, (int) U_, (int) (n & 63), lane);
-                write_lane(fifoC, (int) cum, (int) (n & 63), lane);
-                if (lane == 0) lds_st_asm(&c->item_off[n & 63], cur);
-                cur += (unsigned) jg.bytes; U_ += (unsigned) jg.bytes;
-                ++n;
-                asm volatile("s_waitcnt vmcnt(48)" ::: "memory");            // (ENG_VMAX)
-                publish();
-            }
+            bool ok;
+            if (type == PM_Q4_K) ok = pair ? loader_job<PM_Q4_K, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q4_K, false>(A, c, ring, S, jb, K, b, G, lane);
+            else if (type == PM_Q6_K) ok = pair ? loader_job<PM_Q6_K, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q6_K, false>(A, c, ring, S, jb, K, b, G, lane);
+            else ok = loader_job<PM_Q5_K, false>(A, c, ring, S, jb, K, b, G, lane);
+            if (!ok) return;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) lds_st_asm(&c->landed, n);
+    if (lane == 0) lds_st_asm(&c->landed, S.n);
+#ifdef ENG_DEBUG
+    if (A.dbg && b == 0 && lane == 0) { float * Ld = A.dbg + 64 * 16 + 64 * 8 + 64 + 32 * 16; Ld[0] = (float) S.n; Ld[1] = 0.0f; Ld[2] = 0.0f; Ld[3] = (float) (__builtin_amdgcn_s_memrealtime() - dbg_t0) / 100.0f; }
+#endif
 }
 
 // ---- consumers ---------------------------------------------------------------------------------------------------------------------------------
@@ -316,7 +327,7 @@ __device__ __forceinline__ void eat_item(const char * img, int U, const XLds & x
     for (int s = 0; s < steps; ++s) {
         typename T::Wr w[NM][CH];
 #pragma unroll
-        for (int m = 0; m < NM; ++m) LW<TYPE>::get(w[m], img + (m * steps + s) * ST<TYPE>::BYTES, lane);
+        for (int m = 0; m < NM; ++m) LW<TYPE>::get(w[m], img + (m * steps + s) * ST<TYPE>::BYTES, lane, U - 1 - 64 * CH * (c0 + s));
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int uu = lane + 64 * ((c0 + s) * CH + i);
@@ -349,7 +360,7 @@ __device__ __forceinline__ void eng_prologue(const GemvP & p, int8_t * xs_q, int
     double ssp[4] = {0.0, 0.0, 0.0, 0.0};
     if (norm) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (lane + 64 * i < p.n_ss) ssp[i] = __hip_atomic_load((const PM_G double *) (p.ss_in + lane + 64 * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 4; ++i) if (lane + 64 * i < p.n_ss) ssp[i] = __hip_atomic_load((const PM_G double *) (p.ss_in + lane + 64 * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     float4 f[2][4], g[4];
 #pragma unroll
@@ -550,6 +561,12 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
     unsigned cgen = 0, agen = 0;                           // generations of the consumer / attention barriers
     unsigned nbase = 0;                                    // launch-wide index of the current phase's first item
     const EngPhase * phs = uniform_const_ptr(A.ph);
+#ifdef ENG_DEBUG
+    unsigned long long * tsd = (A.dbg && b == 0 && tid == 0) ? (unsigned long long *) (A.dbg + 64 * 16 + 64 * 8 + 64) : nullptr;
+#define ENG_STAMP(k) do { if (tsd && pi < 32) tsd[8 * pi + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ENG_STAMP(k) do { } while (0)
+#endif
     for (int pi = 0; pi < A.n_ph; ++pi) {
         const EngPhase * ph = phs + pi;
         // ---- seam: every workgroup's outputs of the previous phase are in memory
@@ -557,6 +574,7 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
             if (wave == 0 && lane == 0) g_wait(A.ctr, (unsigned) pi, GS, c, A.err);
             wbar(&c->cbar, cgen, ENG_NC, lane, c, A.err, 2);
         }
+        ENG_STAMP(0);
         if (ph->kind == 1) {
 #ifndef ENG_NO_ATTN
             if (b < ph->aH && wave < 4) {
@@ -576,6 +594,7 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
             eng_prologue(p, xs_q, xs_gs, xs_d, wave, lane);
 #endif
             wbar(&c->cbar, cgen, ENG_NC, lane, c, A.err, 2);
+            ENG_STAMP(1);
             const XLds xs = {xs_q, xs_gs, xs_d, 0};
             // ---- this workgroup's items, launch-wide index n -> wave n % 15
             const int t0 = p.job[0].is_b ? tb : ta, t1 = p.job[1].is_b ? tb : ta, t2 = p.job[2].is_b ? tb : ta;
@@ -622,6 +641,7 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
                 if (lane == 0) lds_st(&c->done[wave], k_done);
             }
             nbase += (unsigned) nit;
+            ENG_STAMP(2);
             float ec0 = 1.0f, es0 = 0.0f, ec1 = 1.0f, es1 = 0.0f, ec2 = 1.0f, es2 = 0.0f;
             int epi_slot = 0; long epi_off = 0;
             if (ph->epi) {
@@ -633,6 +653,7 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
                 qkv_cs(p.job[2], p.epi, g2.r0, g2.r1, tid, ec2, es2);
             }
             wbar(&c->cbar, cgen, ENG_NC, lane, c, A.err, 2);              // every row result of the workgroup is parked
+            ENG_STAMP(3);
             // ---- epilogue: coalesced, write-through
             if (ph->epi) {
                 write_out_qkv<true>(p.job[0], p.epi, outbuf, g0.r0, g0.r1, g0.ob, tid, g0.split ? g0.cpr : 1, epi_slot, epi_off, ec0, es0);
@@ -651,7 +672,9 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
         // ---- publish: this wave's stores have left, then the workgroup arrives
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wbar(&c->cbar, cgen, ENG_NC, lane, c, A.err, 2);
+        ENG_STAMP(4);
         if (wave == 0 && lane == 0) g_arrive(A.ctr, (unsigned) pi, NGR, GS, pi == A.n_ph - 1);
+        ENG_STAMP(5);
     }
 }
 
@@ -711,7 +734,8 @@ int pm_eng_plan_add_matvec(pm_eng_plan * pl, const pm_gemv_fused & f) {
         const int type = jb.is_b ? tb : ta;
         const int ch = (type == PM_Q4_K || type == PM_Q6_K) ? PM_CH64 : PM_CH32, cpr = (((jb.U + 63) >> 6) + ch - 1) / ch;
         const int sb = type == PM_Q4_K ? ST<PM_Q4_K>::BYTES : type == PM_Q6_K ? ST<PM_Q6_K>::BYTES : ST<PM_Q5_K>::BYTES;
-        if (!jb.split && cpr * sb * (pair ? 2 : 1) > 10 * 1024) { if (pair) return -14; jb.split = 1; }
+        // (a pair item holds the steps of both matrices: ffn_gate | ffn_up rows of 8192 Q6_K weights - Qwen2.5-72B - are 13 KiB, still one item)
+        if (!jb.split && cpr * sb * (pair ? 2 : 1) > (pair ? 16 : 10) * 1024) { if (pair) return -14; jb.split = 1; }
         if (jb.split && cpr == 1) jb.split = 0;
         const int rows = (jb.N + grid - 1) / grid + 1;
         nres += rows * (jb.split ? cpr : 1);
@@ -749,15 +773,15 @@ int pm_eng_plan_finish(pm_eng_plan * pl) {
     if (hipMemset(pl->d_ctr, 0, ctr_bytes) != hipSuccess) return -3;
     pl->d_err = (int *) ((char *) pl->d_ctr + ctr_bytes - 64);
     if (hipFuncSetAttribute((const void *) decode_engine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ENG_LDS) != hipSuccess) { (void) hipGetLastError(); return -3; }
+#ifdef ENG_DEBUG
+    if (!pl->d_dbg) { (void) hipMalloc((void **) &pl->d_dbg, (64 * 16 + 64 * 8 + 64 + 32 * 16 + 16) * 4); (void) hipMemset(pl->d_dbg, 0, (64 * 16 + 64 * 8 + 64 + 32 * 16 + 16) * 4); }
+#endif
     pl->finished = true;
     return 0;
 }
 
 int pm_eng_plan_launch(pm_eng_plan * pl, hipStream_t st) {
     if (!pl || !pl->finished) return -1;
-#ifdef ENG_DEBUG
-    if (!pl->d_dbg) { (void) hipMalloc((void **) &pl->d_dbg, (64 * 16 + 64 * 8 + 64) * 4); (void) hipMemset(pl->d_dbg, 0, (64 * 16 + 64 * 8 + 64) * 4); }
-#endif
     EngArgs a = {pl->d_ph, (int) pl->ph.size(), pl->d_ctr, pl->d_err, pl->d_dbg};
     hipLaunchKernelGGL(decode_engine_kernel, dim3(pl->grid), dim3(ENG_THREADS), ENG_LDS, st, a);
     return 0;
@@ -767,10 +791,18 @@ int pm_eng_plan_status(pm_eng_plan * pl) {
     if (!pl || !pl->finished) return -1;
 #ifdef ENG_DEBUG
     if (pl->d_dbg) {
-        std::vector<float> h(64 * 16 + 64 * 8 + 64);
+        std::vector<float> h(64 * 16 + 64 * 8 + 64 + 32 * 16 + 16);
         (void) hipMemcpy(h.data(), pl->d_dbg, h.size() * 4, hipMemcpyDeviceToHost);
         { const float * o = &h[64 * 16 + 64 * 8]; fprintf(stderr, "eng xs_q[0..31]:"); for (int i = 0; i < 32; ++i) fprintf(stderr, " %g", o[i]); fprintf(stderr, "\neng xs_d[0..3]: %g %g %g %g  gs[0..7]:", o[32], o[33], o[34], o[35]); for (int i = 0; i < 8; ++i) fprintf(stderr, " %g", o[36 + i]); fprintf(stderr, "\n"); }
-        for (int l = 0; l < 20; ++l) { const float * o = &h[64 * 16 + 8 * l]; fprintf(stderr, "eng lane %2d: isum=%g msum=%g yd=%g acc=%g xq0=%g gs0=%g u=%g uv=%g\n", l, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]); }
+        {
+            const unsigned long long * t = (const unsigned long long *) &h[64 * 16 + 64 * 8 + 64];
+            for (int ph = 0; ph < 32 && t[8 * ph]; ++ph)
+                fprintf(stderr, "eng phase %2d (wg 0, us since launch entry): seam-in %.2f | prologue done %.2f | items done (wave 0) %.2f | all waves %.2f | epilogue + stores %.2f | arrived %.2f\n", ph,
+                        (t[8 * ph] - t[0]) / 100.0, (t[8 * ph + 1] - t[0]) / 100.0, (t[8 * ph + 2] - t[0]) / 100.0, (t[8 * ph + 3] - t[0]) / 100.0, (t[8 * ph + 4] - t[0]) / 100.0, (t[8 * ph + 5] - t[0]) / 100.0);
+            const float * L = &h[64 * 16 + 64 * 8 + 64 + 32 * 16];
+            fprintf(stderr, "eng loader (wg 0): items %g, ring-full waits %g (drains), tail refreshes %g, done at %.2f us\n", L[0], L[1], L[2], L[3]);
+        }
+        for (int l = 0; l < 4; ++l) { const float * o = &h[64 * 16 + 8 * l]; fprintf(stderr, "eng lane %2d: isum=%g msum=%g yd=%g acc=%g xq0=%g gs0=%g u=%g uv=%g\n", l, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]); }
         for (int i = 0; i < 64; ++i) if (h[16 * i + 15] != 0.0f) {
             const float * o = &h[16 * i];
             fprintf(stderr, "eng item n=%g off=%g slot=%g val=%g landed=%g U=%g steps=%g type=%g w0=%08x hdr0=%08x xq0=%g xd0=%g wave=%g c0=%g phase=%g\n", o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7],

@@ -176,18 +176,20 @@ __device__ __forceinline__ void pm_ts_store(unsigned long long * ts, int tag, co
 // Activations written by one workgroup and read by another INSIDE one kernel (attn_wo.hip) go through agent-scope
 // relaxed atomics: global_load / global_store ... sc1, which are coherent across the 8 XCD L2s without any cache
 // write-back / invalidate. COH = false: plain accesses (stand-alone launches: kernel boundaries do the maintenance).
+// (loads: SYSTEM scope = `sc0 sc1` - an `sc1` load may be served from a line this XCD's L2 kept from an earlier read of the same buffer in the same
+//  launch; the persistent decode engine re-uses every hand-off buffer once per layer, round 5)
 template <bool COH> __device__ __forceinline__ float ld_act(const float * p) {
-    if (COH) return __hip_atomic_load((const PM_G float *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (COH) return __hip_atomic_load((const PM_G float *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return ld_g(p);
 }
 template <bool COH> __device__ __forceinline__ float4 ld_act4(const float4 * p) {
     if (COH) {
         const PM_G float * f = (const PM_G float *) p;
         float4 r;
-        r.x = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.y = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.z = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.w = __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.x = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        r.y = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        r.z = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        r.w = __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return r;
     }
     return ld_g(p);
