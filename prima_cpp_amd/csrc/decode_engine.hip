@@ -152,30 +152,61 @@ __device__ __forceinline__ void dma16(const uint8_t * src, char * dst /*wave-uni
 __device__ __forceinline__ void dma4(const uint8_t * src, char * dst) {
     __builtin_amdgcn_global_load_lds((const PM_G void *) src, (lds_vp) dst, 4, 0, 2);
 }
+// the same with the piece's place inside the step as the INSTRUCTION offset (it is added to the global and to the LDS address alike: the source
+// pointer is biased by -OFF): every piece of a step then shares one M0 value - one s_mov m0 per step instead of a readfirstlane + s_mov + s_nop in
+// front of every DMA instruction of the loader's one-wave instruction stream
+template <int OFF> __device__ __forceinline__ void dma16o(const uint8_t * row /*uniform*/, uint32_t voff /*>= OFF*/, char * dst) {
+    __builtin_amdgcn_global_load_lds((const PM_G void *) (row + (voff - (uint32_t) OFF)), (lds_vp) dst, 16, OFF, 2);
+}
+template <int OFF> __device__ __forceinline__ void dma4o(const uint8_t * row, uint32_t voff, char * dst) {
+    __builtin_amdgcn_global_load_lds((const PM_G void *) (row + (voff - (uint32_t) OFF)), (lds_vp) dst, 4, OFF, 2);
+}
 // gather step `c` of `row` into the ring at dst (unit / block indices clamped into the row: a tail step repeats the last unit, whose products the
-// consumer zeroes exactly like the mat-vec's clamped loads)
-template <int TYPE>
+// consumer zeroes exactly like the mat-vec's clamped loads). FAST (K >= 4096: every stream starts at least its piece offset into the row; Q5_K: whole
+// steps only): instruction-offset form.
+template <int TYPE, bool FAST>
 __device__ __forceinline__ void dma_step(char * dst, const uint8_t * row, int K, int U, int c, int lane) {
     const uint32_t nb = (uint32_t) K / 256;
     if (TYPE == PM_Q4_K) {
-        const uint32_t u = (uint32_t) min(64 * c + lane, U - 1);
-        dma16(row + u * 16u, dst);
-        dma16(row + nb * 64 + u * 16u, dst + 1024);
-        if (lane < 16) dma16(row + nb * 128 + (uint32_t) min(16 * c + lane, (int) nb - 1) * 16u, dst + 2048);
+        const uint32_t u = (uint32_t) min(64 * c + lane, U - 1), hb = (uint32_t) min(16 * c + lane, (int) nb - 1);
+        if (FAST) {
+            dma16o<0>(row, u * 16u, dst);
+            dma16o<1024>(row, nb * 64 + u * 16u, dst);
+            if (lane < 16) dma16o<2048>(row, nb * 128 + hb * 16u, dst);
+        } else {
+            dma16(row + u * 16u, dst);
+            dma16(row + nb * 64 + u * 16u, dst + 1024);
+            if (lane < 16) dma16(row + nb * 128 + hb * 16u, dst + 2048);
+        }
     } else if (TYPE == PM_Q6_K) {
         static_assert(PM_Q6K_SCD == 0, "the engine's d gather assumes the contiguous d[nb] stream");
-        const uint32_t u = (uint32_t) min(64 * c + lane, U - 1);
-        dma16(row + u * 16u, dst);
-        dma16(row + nb * 64 + u * 16u, dst + 1024);
-        dma16(row + nb * 128 + u * 16u, dst + 2048);
-        if (lane < 16) dma16(row + pm_q6k_sc_off(nb, (uint32_t) min(16 * c + lane, (int) nb - 1)), dst + 3072);
-        if (lane < 8) dma4(row + pm_q6k_d_off(nb, (uint32_t) min(16 * c + 2 * lane, ((int) nb - 1) & ~1)), dst + 3328);      // (two d per lane: an even block index keeps the 4-byte source aligned)
+        const uint32_t u = (uint32_t) min(64 * c + lane, U - 1), sb = (uint32_t) min(16 * c + lane, (int) nb - 1);
+        const uint32_t db = (uint32_t) min(16 * c + 2 * lane, ((int) nb - 1) & ~1);      // (two d per lane: an even block index keeps the 4-byte source aligned)
+        if (FAST) {
+            dma16o<0>(row, u * 16u, dst);
+            dma16o<1024>(row, nb * 64 + u * 16u, dst);
+            dma16o<2048>(row, nb * 128 + u * 16u, dst);
+            if (lane < 16) dma16o<3072>(row, pm_q6k_sc_off(nb, sb), dst);
+            if (lane < 8) dma4o<3328>(row, pm_q6k_d_off(nb, db), dst);
+        } else {
+            dma16(row + u * 16u, dst);
+            dma16(row + nb * 64 + u * 16u, dst + 1024);
+            dma16(row + nb * 128 + u * 16u, dst + 2048);
+            if (lane < 16) dma16(row + pm_q6k_sc_off(nb, sb), dst + 3072);
+            if (lane < 8) dma4(row + pm_q6k_d_off(nb, db), dst + 3328);
+        }
     } else {                                               // Q5_K: 16 native blocks = 2816 contiguous bytes
-        const uint32_t b0 = 16u * (uint32_t) c, lim = nb * PM_BS_Q5_K - 16u;
-        const uint32_t o = b0 * PM_BS_Q5_K + (uint32_t) lane * 16u;
-        dma16(row + min(o, lim), dst);
-        dma16(row + min(o + 1024u, lim), dst + 1024);
-        if (lane < 48) dma16(row + min(o + 2048u, lim), dst + 2048);
+        const uint32_t o = 16u * (uint32_t) c * PM_BS_Q5_K + (uint32_t) lane * 16u;
+        if (FAST) {
+            dma16o<0>(row, o, dst);
+            dma16o<1024>(row, o + 1024u, dst);
+            if (lane < 48) dma16o<2048>(row, o + 2048u, dst);
+        } else {
+            const uint32_t lim = nb * PM_BS_Q5_K - 16u;
+            dma16(row + min(o, lim), dst);
+            dma16(row + min(o + 1024u, lim), dst + 1024);
+            if (lane < 48) dma16(row + min(o + 2048u, lim), dst + 2048);
+        }
     }
 }
 // the step's weight registers of this lane, from the ring image
@@ -253,7 +284,7 @@ __device__ __forceinline__ bool loader_make_room(const EngArgs & A, Ctl * c, Loa
         if (++spins > (1 << 22)) { give_up(c, A.err, 1, true); return false; }
     }
 }
-template <int TYPE, bool PAIR>
+template <int TYPE, bool PAIR, bool FAST>
 __device__ __forceinline__ bool loader_job(const EngArgs & A, Ctl * c, char * ring, LoaderState & S, const GemvJob & jb, int K, int b, int G, int lane) {
     const JobGeo jg = job_geo(jb, TYPE, PAIR, b, G, 0);
     constexpr int SB = ST<TYPE>::BYTES;
@@ -261,16 +292,15 @@ __device__ __forceinline__ bool loader_job(const EngArgs & A, Ctl * c, char * ri
     const unsigned lag = ((unsigned) ENG_VMAX + k_item - 1) / k_item;                    // items the newest ENG_VMAX instructions may belong to
     const unsigned job_n0 = S.n;
     const int rows = jg.r1 - jg.r0, chunks = jg.split ? jg.cpr : 1;
-    for (int r = 0; r < rows; ++r) {
-        const int lrow = jg.r0 + r;
-        const uint8_t * row = jb.W + (long) job_row(jb, lrow) * jb.row_stride;
-        const uint8_t * row2 = PAIR ? jb.W2 + (long) lrow * jb.row_stride : nullptr;
+    const uint8_t * row_lin = jb.W + (long) jg.r0 * jb.row_stride, * row2 = PAIR ? jb.W2 + (long) jg.r0 * jb.row_stride : nullptr;
+    for (int r = 0; r < rows; ++r, row_lin += jb.row_stride, row2 += PAIR ? jb.row_stride : 0) {
+        const uint8_t * row = jb.nx_s ? jb.W + (long) job_row(jb, jg.r0 + r) * jb.row_stride : row_lin;      // (NEOX rope: permuted rows)
         for (int cc = 0; cc < chunks; ++cc) {
             if (!loader_make_room(A, c, S, (unsigned) jg.bytes, lane)) return false;
             char * dst = ring + S.cur;
             for (int s_ = 0; s_ < jg.steps; ++s_) {
-                dma_step<TYPE>(dst + s_ * SB, row, K, jb.U, cc + s_, lane);
-                if (PAIR) dma_step<TYPE>(dst + (jg.steps + s_) * SB, row2, K, jb.U, cc + s_, lane);
+                dma_step<TYPE, FAST>(dst + s_ * SB, row, K, jb.U, cc + s_, lane);
+                if (PAIR) dma_step<TYPE, FAST>(dst + (jg.steps + s_) * SB, row2, K, jb.U, cc + s_, lane);
             }
             if (lane == 0) lds_st2_asm(&c->item_off[S.n & 63], S.cur, S.U);
             S.cur += (unsigned) jg.bytes; S.U += (unsigned) jg.bytes; ++S.n;
@@ -298,10 +328,15 @@ __device__ __forceinline__ void loader_wave(const EngArgs & A, Ctl * c, char * r
             if (ph->g.job[j].N <= 0) continue;
             const GemvJob & jb = ph->g.job[j];
             const int type = jb.is_b ? tb : ta;
+            // the instruction-offset DMA form needs every stream of a row to start at least its piece's offset into the row (K >= 4096) and, for the
+            // plain-copy Q5_K image, whole steps
+            const bool fast = K >= 4096 && (type != PM_Q5_K || (K / 256) % 16 == 0);
             bool ok;
-            if (type == PM_Q4_K) ok = pair ? loader_job<PM_Q4_K, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q4_K, false>(A, c, ring, S, jb, K, b, G, lane);
-            else if (type == PM_Q6_K) ok = pair ? loader_job<PM_Q6_K, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q6_K, false>(A, c, ring, S, jb, K, b, G, lane);
-            else ok = loader_job<PM_Q5_K, false>(A, c, ring, S, jb, K, b, G, lane);
+            if (type == PM_Q4_K) ok = pair ? (fast ? loader_job<PM_Q4_K, true, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q4_K, true, false>(A, c, ring, S, jb, K, b, G, lane))
+                                           : (fast ? loader_job<PM_Q4_K, false, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q4_K, false, false>(A, c, ring, S, jb, K, b, G, lane));
+            else if (type == PM_Q6_K) ok = pair ? (fast ? loader_job<PM_Q6_K, true, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q6_K, true, false>(A, c, ring, S, jb, K, b, G, lane))
+                                                : (fast ? loader_job<PM_Q6_K, false, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q6_K, false, false>(A, c, ring, S, jb, K, b, G, lane));
+            else ok = fast ? loader_job<PM_Q5_K, false, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q5_K, false, false>(A, c, ring, S, jb, K, b, G, lane);
             if (!ok) return;
         }
     }

@@ -59,7 +59,10 @@ struct pm355_model {
     bool use_ss = true; double * ss = nullptr;
     // the persistent decode engine (decode_engine.hip, round 5): the whole layer stack of a single-token step as ONE launch. Plans are keyed on the
     // activation pointers baked into their phase tables. PM355_ENGINE=0: five launches per layer (run_layers_fused)
-    struct EnginePlan { const float * in; float * out; pm_eng_plan * plan; int n_ss_end; };
+    // Hand-off buffers are WRITE-ONCE per launch: every layer has its own q / attention output / ffn activation / residual rows / partial sums
+    // (eng_act, ~250 KB per 70B layer). A buffer re-used by the next layer was served stale from the reading XCD's L2 whatever the load's scope
+    // bits (two 70B layers differed from the launches by 1e-4, one by 1e-14: found on the hardware; round 1's persistent kernel had met the same).
+    struct EnginePlan { const float * in; float * out; pm_eng_plan * plan; int n_ss_end; const double * ss_end; const float * end; float * act; double * ss_in0; };
     bool use_engine = true; std::vector<EnginePlan> eng_plans; bool eng_refused = false;
     // PM355_PROMPT_I8=1: prompts (> 64 tokens) run their Q4_K / Q6_K matrices on the integer matrix cores over Q8_K activations (mmq_big.hip) - the CPU
     // reference's own arithmetic, at 0.6-0.75 of the F16 GEMMs' rate (mmq.hip, the default); tab_big = the activation tables of the current
@@ -354,47 +357,54 @@ int run_head(pm355_model * m, const float * x_row, float * d_logits, int32_t * d
 // The single-token layer stack as ONE persistent launch: the same launches run_layers_fused issues, appended as phases (decode_engine.hip).
 // nullptr: this window is not served (types, shapes, streaming, long-context regime) - the caller takes the five-launch path.
 // may_build = false (the stream is being captured: no allocation, no synchronous copy): only a plan that exists already is returned.
-pm_eng_plan * engine_plan_for(pm355_model * m, const float * cur, float * d_x_out, int * n_ss_end, bool may_build = true) {
-    for (auto & e : m->eng_plans) if (e.in == cur && e.out == d_x_out) { *n_ss_end = e.n_ss_end; return e.plan; }
+pm355_model::EnginePlan * engine_plan_for(pm355_model * m, const float * cur, float * d_x_out, bool may_build = true) {
+    for (auto & e : m->eng_plans) if (e.in == cur && e.out == d_x_out) return &e;
     if (m->eng_refused || !may_build) return nullptr;
     const float * in0 = cur;
     const pm355_hparams & hp = m->hp;
     const int H = hp.n_head, Hkv = hp.n_head_kv, dh = hp.head_dim;
+    const size_t E = hp.n_embd, Eq = (size_t) dh * H, F = hp.n_ff;
     const float kq_scale = 1.0f / sqrtf((float) dh);
-    float * bufs[2] = {m->x, m->x1};
+    const int nl = m->hi - m->lo;
+    // per layer: q[Eq] | att[Eq] | h[F] | x_mid[E] | x_next[E] floats, then ss_wo[256] | ss_dn[256] doubles (the first layer's attn_norm reads the
+    // one-partial sum the launch in front of the engine leaves in ss_in0)
+    const size_t per_f = 2 * Eq + F + 2 * E, per_bytes = ((per_f * 4 + 255) & ~(size_t) 255) + 2 * 256 * sizeof(double);
+    float * act = nullptr;
+    if (hipMalloc((void **) &act, per_bytes * (size_t) nl + 256 * sizeof(double) + 256) != hipSuccess) { (void) hipGetLastError(); m->eng_refused = true; return nullptr; }
     pm_eng_plan * pl = pm_eng_plan_new();
-    auto refuse = [&](const char * why, int rc) -> pm_eng_plan * {
+    auto refuse = [&](const char * why, int rc) -> pm355_model::EnginePlan * {
         if (getenv("PM355_ENGINE_VERBOSE")) fprintf(stderr, "prima_mi355 engine: not served (%s, rc %d) - five launches per layer\n", why, rc);
         (void) hipGetLastError();
-        pm_eng_plan_free(pl); m->eng_refused = true; return nullptr;
+        pm_eng_plan_free(pl); (void) hipFree(act); m->eng_refused = true; return nullptr;
     };
     const int max_keys = (m->split_scratch && m->split_min + 8 < hp.n_ctx) ? m->split_min + 8 : hp.n_ctx;
-    double * ss_wo = m->ss, * ss_dn = m->ss + 256;
-    int n_wo = 0, n_dn = 1;                              // the first rms_norm takes the one-partial sum the sumsq launch in front of the engine leaves
+    double * ss_in0 = (double *) ((char *) act + per_bytes * (size_t) nl);
+    const double * ss_prev = ss_in0; int n_prev = 1;          // partials of the sum of squares of `cur`
     auto job = [](pm_gemv_fused & f, int j, const Tensor & w, const Tensor * w2, float * y, const float * bias, const float * resid) {
         f.job[j].type = w.type; f.job[j].N = (int) w.N; f.job[j].W = w.d; f.job[j].W2 = w2 ? w2->d : nullptr; f.job[j].y = y; f.job[j].bias = bias; f.job[j].resid = resid;
     };
     for (int il = m->lo; il < m->hi; ++il) {
         Layer & L = m->layers[il - m->lo];
-        float * x_mid = (cur == bufs[0]) ? bufs[1] : bufs[0];
-        float * x_nxt = (x_mid == bufs[0]) ? bufs[1] : bufs[0];
-        float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : x_nxt;
+        char * base = (char *) act + per_bytes * (size_t) (il - m->lo);
+        float * q = (float *) base, * att = q + Eq, * hbuf = att + Eq, * x_mid = hbuf + F, * x_own = x_mid + E;
+        double * ss_wo = (double *) (base + ((per_f * 4 + 255) & ~(size_t) 255)), * ss_dn = ss_wo + 256;
+        float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : x_own;
         const long kvs = m->n_seq > 1 ? (long) hp.n_ctx * Hkv * dh : 0;
-        int rc;
+        int rc, n_wo, n_dn;
         {   // wq | wk | wv + rope + KV store
             pm_gemv_fused f = {};
             f.K = hp.n_embd; f.njobs = 3; f.xf = cur; f.norm_w = (const float *) L.t[PM355_T_ATTN_NORM].d; f.eps = hp.rms_eps;
-            job(f, 0, L.t[PM355_T_WQ], nullptr, m->q, (const float *) L.t[PM355_T_BQ].d, nullptr);
+            job(f, 0, L.t[PM355_T_WQ], nullptr, q, (const float *) L.t[PM355_T_BQ].d, nullptr);
             job(f, 1, L.t[PM355_T_WK], nullptr, m->k, (const float *) L.t[PM355_T_BK].d, nullptr);
             job(f, 2, L.t[PM355_T_WV], nullptr, m->v, (const float *) L.t[PM355_T_BV].d, nullptr);
             const pm_qkv_epi qe = {m->rope_tab, m->d_pos, m->d_ctl, nullptr, kvs, L.kc, L.vc, Hkv, dh, hp.n_ctx, m->rope.n_dims, 0, (m->rope.mode & 2) ? 1 : 0};
-            f.epi = &qe; f.ss_in = ss_dn; f.n_ss = n_dn;
+            f.epi = &qe; f.ss_in = ss_prev; f.n_ss = n_prev;
             if ((rc = pm_eng_plan_add_matvec(pl, f))) return refuse("wq | wk | wv", rc);
         }
-        if ((rc = pm_eng_plan_add_attention(pl, m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, m->att, H, Hkv, dh, hp.n_ctx, kq_scale, max_keys))) return refuse("attention", rc);
+        if ((rc = pm_eng_plan_add_attention(pl, q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, att, H, Hkv, dh, hp.n_ctx, kq_scale, max_keys))) return refuse("attention", rc);
         {   // wo + residual, leaves the partials of ffn_norm
             pm_gemv_fused f = {};
-            f.K = (int) L.t[PM355_T_WO].K; f.njobs = 1; f.xf = m->att; f.eps = hp.rms_eps;
+            f.K = (int) L.t[PM355_T_WO].K; f.njobs = 1; f.xf = att; f.eps = hp.rms_eps;
             job(f, 0, L.t[PM355_T_WO], nullptr, x_mid, nullptr, cur);
             n_wo = pm_gemv_fused_grid(f);
             if (n_wo < 1 || n_wo > 256) return refuse("wo grid", n_wo);
@@ -405,26 +415,25 @@ pm_eng_plan * engine_plan_for(pm355_model * m, const float * cur, float * d_x_ou
         {   // ffn_gate | ffn_up + silu * mul
             pm_gemv_fused f = {};
             f.K = hp.n_embd; f.njobs = 1; f.xf = x_mid; f.norm_w = (const float *) L.t[PM355_T_FFN_NORM].d; f.eps = hp.rms_eps;
-            job(f, 0, L.t[PM355_T_FFN_GATE], &L.t[PM355_T_FFN_UP], m->h, nullptr, nullptr);
+            job(f, 0, L.t[PM355_T_FFN_GATE], &L.t[PM355_T_FFN_UP], hbuf, nullptr, nullptr);
             f.ss_in = ss_wo; f.n_ss = n_wo;
             if ((rc = pm_eng_plan_add_matvec(pl, f))) return refuse("ffn_gate | ffn_up", rc);
         }
         {   // ffn_down + residual, leaves the partials of the next attn_norm / output_norm
             pm_gemv_fused f = {};
-            f.K = (int) L.t[PM355_T_FFN_DOWN].K; f.njobs = 1; f.xf = m->h; f.eps = hp.rms_eps;
+            f.K = (int) L.t[PM355_T_FFN_DOWN].K; f.njobs = 1; f.xf = hbuf; f.eps = hp.rms_eps;
             job(f, 0, L.t[PM355_T_FFN_DOWN], nullptr, x_next, nullptr, x_mid);
             n_dn = pm_gemv_fused_grid(f);
             if (n_dn < 1 || n_dn > 256) return refuse("ffn_down grid", n_dn);
             f.ss_out = ss_dn;
             if ((rc = pm_eng_plan_add_matvec(pl, f))) return refuse("ffn_down", rc);
         }
-        cur = x_next;
+        cur = x_next; ss_prev = ss_dn; n_prev = n_dn;
     }
     const int rc = pm_eng_plan_finish(pl);
     if (rc) return refuse("finish", rc);
-    m->eng_plans.push_back({in0, d_x_out, pl, n_dn});
-    *n_ss_end = n_dn;
-    return pl;
+    m->eng_plans.push_back({in0, d_x_out, pl, n_prev, ss_prev, cur, act, ss_in0});
+    return &m->eng_plans.back();
 }
 
 bool engine_eligible(const pm355_model * m) {
@@ -546,30 +555,23 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
     }
     if (!cur) return seterr(m, PM355_E_SHAPE, "decode: neither tokens nor x_in");
     float * bufs[2] = {m->x, m->x1};
-    int n_ss_head = 0;                                // partials of the output row's sum of squares left by the last ffn_down (single-token path)
+    int n_ss_head = 0; const double * ss_head = m->ss ? m->ss + 256 : nullptr;   // partials of the output row's sum of squares left by the last ffn_down (single-token path)
     if (T == 1 && !m->no_fuse) {
         m->flash_cells = attn_regime(m); m->long_ctx = m->flash_cells != 0;
         // ---- single token: every activation transform is fused into a mat-vec prologue / epilogue, 5 launches per layer
         const float * end = nullptr;
-        pm_eng_plan * eng = nullptr;
+        pm355_model::EnginePlan * eng = nullptr;
         if (engine_eligible(m)) {
             hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
             const bool capturing = hipStreamIsCapturing(st, &cst) == hipSuccess && cst == hipStreamCaptureStatusActive;
-            eng = engine_plan_for(m, cur, d_x_out, &n_ss_head, !capturing);
+            eng = engine_plan_for(m, cur, d_x_out, !capturing);
         }
         if (eng) {
             // ---- ... or, where served, ALL layers as one persistent launch (decode_engine.hip): cos / sin table, the first norm's sum of squares, the engine
             pm_launch_rope_table(m->rope, m->d_pos, m->d_ctl, (const float *) m->rope_freqs.d, m->rope_tab, st);
-            pm_launch_sumsq_row(cur, E, m->ss + 256, st);
-            if (pm_eng_plan_launch(eng, st)) return seterr(m, PM355_E_HIP, "decode: engine launch");
-            // where the stack's output row ends up: the same buffer rotation as run_layers_fused
-            const float * c2 = cur;
-            for (int il = m->lo; il < m->hi; ++il) {
-                float * x_mid = (c2 == bufs[0]) ? bufs[1] : bufs[0];
-                float * x_nxt = (x_mid == bufs[0]) ? bufs[1] : bufs[0];
-                c2 = (il == m->hi - 1 && d_x_out) ? d_x_out : x_nxt;
-            }
-            end = c2;
+            pm_launch_sumsq_row(cur, E, eng->ss_in0, st);
+            if (pm_eng_plan_launch(eng->plan, st)) return seterr(m, PM355_E_HIP, "decode: engine launch");
+            end = eng->end; n_ss_head = eng->n_ss_end; ss_head = eng->ss_end;
         } else {
             int rc = run_layers_fused(m, cur, d_x_out, &end, st, &n_ss_head);
             if (rc) return rc;
@@ -769,7 +771,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
     }
     if (d_x_out && cur != d_x_out) (void) hipMemcpyAsync(d_x_out, cur, (size_t) T * E * 4, hipMemcpyDeviceToDevice, st);
     if ((d_logits || d_argmax) && (m->flags & PM355_HAS_HEAD)) {
-        int rc = run_head(m, cur + (size_t) (T - 1) * E, d_logits, d_argmax, st, n_ss_head ? m->ss + 256 : nullptr, n_ss_head);
+        int rc = run_head(m, cur + (size_t) (T - 1) * E, d_logits, d_argmax, st, n_ss_head ? ss_head : nullptr, n_ss_head);
         if (rc) return rc;
     }
     return hip_ok() ? 0 : seterr(m, PM355_E_HIP, "decode: kernel launch failed");
@@ -805,7 +807,7 @@ void pm355_model_free(pm355_model * m) {
     if (!m) return;
     (void) hipDeviceSynchronize();
     for (auto & g : m->graphs) (void) hipGraphExecDestroy(g.exec);
-    for (auto & e : m->eng_plans) pm_eng_plan_free(e.plan);
+    for (auto & e : m->eng_plans) { pm_eng_plan_free(e.plan); if (e.act) (void) hipFree(e.act); }
     if (m->copy_stream) { (void) hipStreamSynchronize(m->copy_stream); (void) hipStreamDestroy(m->copy_stream); }
     for (auto & S : m->slots) { for (auto p : S.d) if (p) (void) hipFree(p); if (S.ready) (void) hipEventDestroy(S.ready); if (S.free_) (void) hipEventDestroy(S.free_); }
     for (auto & L : m->layers) for (auto p : L.host) if (p) (void) hipHostFree(p);
@@ -1062,7 +1064,7 @@ int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * 
         return rc ? rc : commit();
     }
     // the engine's phase table is allocated and uploaded outside the capture (keyed on the activation pointers of this step)
-    if (engine_eligible(m)) { int n_; (void) engine_plan_for(m, d_token ? m->x : d_x_in, d_x_out, &n_); }
+    if (engine_eligible(m)) (void) engine_plan_for(m, d_token ? m->x : d_x_in, d_x_out);
     hipGraphExec_t exec = nullptr;
     for (auto & g : m->graphs)
         if (g.in == d_x_in && g.tok == d_token && g.out == d_x_out && g.logits == d_logits && g.argmax == d_argmax &&
