@@ -35,7 +35,7 @@ using namespace pmv;
 
 namespace {
 
-constexpr int ENG_NW = 16, ENG_NC = 15, ENG_THREADS = ENG_NW * 64;
+constexpr int ENG_NW = 16, ENG_NL = 2, ENG_NC = ENG_NW - ENG_NL, ENG_THREADS = ENG_NW * 64;      // waves: consumers 0 .. 13, loaders 14 and 15
 constexpr int ENG_RING = 120 * 1024;                       // bytes of weight images in flight per CU
 constexpr int ENG_ACT = 36864;                             // Q8_K activation row: q[K] | group sums[K/16] | d[K/256], K <= 28672 (also the attention scratch)
 constexpr int ENG_OUTF = 640;                              // parked results per workgroup (floats)
@@ -57,7 +57,7 @@ typedef __attribute__((address_space(3))) unsigned lds_u32;
 
 // LDS control block. Accessed ONLY through LDS-typed pointers (a generic access is FLAT: it waits on vmcnt too and would drain the loader's queue);
 // the loader's own accesses are inline asm (a compiler-visible LDS access after global_load_lds gets an s_waitcnt vmcnt(0) in front of it).
-struct Ctl { unsigned landed, cbar, abar, giveup; unsigned done[16]; unsigned item_off[64]; unsigned item_U[64]; };      // (item_U right behind item_off: one ds_write2st64 per item)
+struct Ctl { unsigned landed[2], cbar, abar, giveup, pad_[3]; unsigned done[16]; unsigned item_off[64]; unsigned item_U[64]; };      // (item_U right behind item_off: one ds_write2st64 per item)
 
 __device__ __forceinline__ lds_u32 * L(unsigned * p) { return (lds_u32 *) p; }
 __device__ __forceinline__ unsigned lds_ld(unsigned * p) { return __hip_atomic_load(L(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -257,18 +257,22 @@ __device__ __forceinline__ JobGeo job_geo(const GemvJob & jb, int type, int pair
 // SGPRs (no lane-indexed FIFOs, no per-item loops), the type / pair dispatch is per JOB, and `landed` follows from arithmetic - all items of a
 // job carry the same number of DMA instructions, so after s_waitcnt vmcnt(48) everything but the job's newest ceil(48 / k) items has landed.
 struct LoaderState {
-    unsigned n, cur, U, tail, tailU, landed;               // items issued | ring cursor | the same unwrapped | oldest unretired item (cached) and its unwrapped start | published
+    unsigned n, cur, U, tail, tailU;                       // items WALKED (both loaders place every item) | ring cursor | the same unwrapped | oldest unretired item (cached), its start
+    unsigned m, landed;                                    // OWN items issued | own items published as landed
 };
 __device__ __forceinline__ void lds_st2_asm(unsigned * p, unsigned a, unsigned b) {       // p[0] = a, p[64] = b (item_off / item_U of one FIFO slot)
     asm volatile("ds_write2st64_b32 %0, %1, %2 offset1:1" :: "v"((unsigned) (uintptr_t) L(p)), "v"(a), "v"(b) : "memory");
 }
-// room for `bytes` at the cursor? (the live window [start of the oldest unretired item, end of this item) may not exceed the ring)
-__device__ __forceinline__ bool loader_make_room(const EngArgs & A, Ctl * c, LoaderState & S, unsigned bytes, int lane) {
+// the cursor of the next item (a tail of the ring too short for it is skipped: both loaders and nobody else follow this rule)
+__device__ __forceinline__ void loader_place(LoaderState & S, unsigned bytes) {
     if (S.cur + bytes > (unsigned) ENG_RING) { S.U += (unsigned) ENG_RING - S.cur; S.cur = 0; }
+}
+// room for `bytes` at the cursor? (the live window [start of the oldest unretired item, end of this item) may not exceed the ring)
+__device__ __forceinline__ bool loader_make_room(const EngArgs & A, Ctl * c, LoaderState & S, unsigned bytes, int lane, int LD) {
     if (S.U + bytes - S.tailU <= (unsigned) ENG_RING) return true;
     int spins = 0;
     for (;;) {
-        // refresh the tail: wave w has retired done[w] of its items (w, w + 15, ...): the oldest unretired item of the launch is the minimum
+        // refresh the tail: wave w has retired done[w] of its items (w, w + NC, ...): the oldest unretired item of the launch is the minimum
         const unsigned v = lane < ENG_NC ? (unsigned) lane + lds_ld_asm(&c->done[lane < ENG_NC ? lane : 0]) * (unsigned) ENG_NC : 0xFFFFFFFFu;
         unsigned t = 0xFFFFFFFFu;
 #pragma unroll
@@ -276,46 +280,50 @@ __device__ __forceinline__ bool loader_make_room(const EngArgs & A, Ctl * c, Loa
         S.tail = min(t, S.n);
         S.tailU = S.tail >= S.n ? S.U : (unsigned) __builtin_amdgcn_readfirstlane((int) lds_ld_asm(&c->item_U[S.tail & 63]));
         if (S.U + bytes - S.tailU <= (unsigned) ENG_RING) return true;
-        // ring full: nothing can be issued anyway -> drain, publish everything in flight, wait for a retirement
+        // ring full: nothing can be issued anyway -> drain, publish everything of this loader in flight, wait for a retirement
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (S.landed != S.n) { S.landed = S.n; if (lane == 0) lds_st_asm(&c->landed, S.n); }
+        if (S.landed != S.m) { S.landed = S.m; if (lane == 0) lds_st_asm(&c->landed[LD], S.m); }
         __builtin_amdgcn_s_sleep(1);
         if (__builtin_amdgcn_readfirstlane((int) lds_ld_asm(&c->giveup))) return false;     // (made scalar: a divergent exit would turn every cursor into a VGPR)
         if (++spins > (1 << 22)) { give_up(c, A.err, 1, true); return false; }
     }
 }
 template <int TYPE, bool PAIR, bool FAST>
-__device__ __forceinline__ bool loader_job(const EngArgs & A, Ctl * c, char * ring, LoaderState & S, const GemvJob & jb, int K, int b, int G, int lane) {
+__device__ __forceinline__ bool loader_job(const EngArgs & A, Ctl * c, char * ring, LoaderState & S, const GemvJob & jb, int K, int b, int G, int lane, int LD) {
     const JobGeo jg = job_geo(jb, TYPE, PAIR, b, G, 0);
     constexpr int SB = ST<TYPE>::BYTES;
     const unsigned k_item = (unsigned) (ST<TYPE>::NDMA * jg.steps * (PAIR ? 2 : 1));      // DMA instructions per item
-    const unsigned lag = ((unsigned) ENG_VMAX + k_item - 1) / k_item;                    // items the newest ENG_VMAX instructions may belong to
-    const unsigned job_n0 = S.n;
+    const unsigned lag = ((unsigned) ENG_VMAX + k_item - 1) / k_item;                    // OWN items the newest ENG_VMAX instructions may belong to
+    const unsigned job_m0 = S.m;
     const int rows = jg.r1 - jg.r0, chunks = jg.split ? jg.cpr : 1;
     const uint8_t * row_lin = jb.W + (long) jg.r0 * jb.row_stride, * row2 = PAIR ? jb.W2 + (long) jg.r0 * jb.row_stride : nullptr;
     for (int r = 0; r < rows; ++r, row_lin += jb.row_stride, row2 += PAIR ? jb.row_stride : 0) {
         const uint8_t * row = jb.nx_s ? jb.W + (long) job_row(jb, jg.r0 + r) * jb.row_stride : row_lin;      // (NEOX rope: permuted rows)
         for (int cc = 0; cc < chunks; ++cc) {
-            if (!loader_make_room(A, c, S, (unsigned) jg.bytes, lane)) return false;
-            char * dst = ring + S.cur;
-            for (int s_ = 0; s_ < jg.steps; ++s_) {
-                dma_step<TYPE, FAST>(dst + s_ * SB, row, K, jb.U, cc + s_, lane);
-                if (PAIR) dma_step<TYPE, FAST>(dst + (jg.steps + s_) * SB, row2, K, jb.U, cc + s_, lane);
-            }
-            if (lane == 0) lds_st2_asm(&c->item_off[S.n & 63], S.cur, S.U);
+            loader_place(S, (unsigned) jg.bytes);
+            if ((int) (S.n & 1u) == LD) {                  // items alternate between the two loader waves; both walk (place) every item
+                if (!loader_make_room(A, c, S, (unsigned) jg.bytes, lane, LD)) return false;
+                char * dst = ring + S.cur;
+                for (int s_ = 0; s_ < jg.steps; ++s_) {
+                    dma_step<TYPE, FAST>(dst + s_ * SB, row, K, jb.U, cc + s_, lane);
+                    if (PAIR) dma_step<TYPE, FAST>(dst + (jg.steps + s_) * SB, row2, K, jb.U, cc + s_, lane);
+                }
+                if (lane == 0) lds_st2_asm(&c->item_off[S.n & 63], S.cur, S.U);
+                ++S.m;
+                asm volatile("s_waitcnt vmcnt(48)" ::: "memory");                         // (ENG_VMAX)
+                const unsigned in_job = S.m - job_m0;
+                const unsigned pub = in_job > lag ? S.m - lag : (in_job * k_item >= (unsigned) ENG_VMAX ? job_m0 : S.landed);
+                if (pub != S.landed) { S.landed = pub; if (lane == 0) lds_st_asm(&c->landed[LD], pub); }
+            } else if (lane == 0) lds_st2_asm(&c->item_off[S.n & 63], S.cur, S.U);       // (the same values its issuer writes: this wave may need the entry first)
             S.cur += (unsigned) jg.bytes; S.U += (unsigned) jg.bytes; ++S.n;
-            asm volatile("s_waitcnt vmcnt(48)" ::: "memory");                             // (ENG_VMAX)
-            const unsigned in_job = S.n - job_n0;
-            const unsigned pub = in_job > lag ? S.n - lag : (in_job * k_item >= (unsigned) ENG_VMAX ? job_n0 : S.landed);
-            if (pub != S.landed) { S.landed = pub; if (lane == 0) lds_st_asm(&c->landed, pub); }
         }
     }
     return true;
 }
-__device__ __forceinline__ void loader_wave(const EngArgs & A, Ctl * c, char * ring, int lane) {
+__device__ __forceinline__ void loader_wave(const EngArgs & A, Ctl * c, char * ring, int lane, int LD) {
     const int b = blockIdx.x, G = gridDim.x;
-    __builtin_amdgcn_s_setprio(3);                         // the youngest wave of its SIMD would otherwise lose every arbitration to the consumers
-    LoaderState S = {0, 0, 0, 0, 0, 0};
+    __builtin_amdgcn_s_setprio(3);                         // the youngest waves of their SIMDs would otherwise lose every arbitration to the consumers
+    LoaderState S = {0, 0, 0, 0, 0, 0, 0};
 #ifdef ENG_DEBUG
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -332,18 +340,18 @@ __device__ __forceinline__ void loader_wave(const EngArgs & A, Ctl * c, char * r
             // plain-copy Q5_K image, whole steps
             const bool fast = K >= 4096 && (type != PM_Q5_K || (K / 256) % 16 == 0);
             bool ok;
-            if (type == PM_Q4_K) ok = pair ? (fast ? loader_job<PM_Q4_K, true, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q4_K, true, false>(A, c, ring, S, jb, K, b, G, lane))
-                                           : (fast ? loader_job<PM_Q4_K, false, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q4_K, false, false>(A, c, ring, S, jb, K, b, G, lane));
-            else if (type == PM_Q6_K) ok = pair ? (fast ? loader_job<PM_Q6_K, true, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q6_K, true, false>(A, c, ring, S, jb, K, b, G, lane))
-                                                : (fast ? loader_job<PM_Q6_K, false, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q6_K, false, false>(A, c, ring, S, jb, K, b, G, lane));
-            else ok = fast ? loader_job<PM_Q5_K, false, true>(A, c, ring, S, jb, K, b, G, lane) : loader_job<PM_Q5_K, false, false>(A, c, ring, S, jb, K, b, G, lane);
+#define ENG_LJ(T_, P_, F_) loader_job<T_, P_, F_>(A, c, ring, S, jb, K, b, G, lane, LD)
+            if (type == PM_Q4_K) ok = pair ? (fast ? ENG_LJ(PM_Q4_K, true, true) : ENG_LJ(PM_Q4_K, true, false)) : (fast ? ENG_LJ(PM_Q4_K, false, true) : ENG_LJ(PM_Q4_K, false, false));
+            else if (type == PM_Q6_K) ok = pair ? (fast ? ENG_LJ(PM_Q6_K, true, true) : ENG_LJ(PM_Q6_K, true, false)) : (fast ? ENG_LJ(PM_Q6_K, false, true) : ENG_LJ(PM_Q6_K, false, false));
+            else ok = fast ? ENG_LJ(PM_Q5_K, false, true) : ENG_LJ(PM_Q5_K, false, false);
+#undef ENG_LJ
             if (!ok) return;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) lds_st_asm(&c->landed, S.n);
+    if (lane == 0) lds_st_asm(&c->landed[LD], S.m);
 #ifdef ENG_DEBUG
-    if (A.dbg && b == 0 && lane == 0) { float * Ld = A.dbg + 64 * 16 + 64 * 8 + 64 + 32 * 16; Ld[0] = (float) S.n; Ld[1] = 0.0f; Ld[2] = 0.0f; Ld[3] = (float) (__builtin_amdgcn_s_memrealtime() - dbg_t0) / 100.0f; }
+    if (A.dbg && b == 0 && lane == 0 && LD == 0) { float * Ld = A.dbg + 64 * 16 + 64 * 8 + 64 + 32 * 16; Ld[0] = (float) S.n; Ld[1] = 0.0f; Ld[2] = 0.0f; Ld[3] = (float) (__builtin_amdgcn_s_memrealtime() - dbg_t0) / 100.0f; }
 #endif
 }
 
@@ -588,7 +596,7 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
     __syncthreads();                                       // the only workgroup-wide barrier: before the roles split
     if (tid == 0 && __hip_atomic_load((PM_G int *) A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) lds_st(&c->giveup, 1);   // an earlier launch gave up: the counters are not trustworthy
 #ifndef ENG_NO_LOADER
-    if (wave == ENG_NW - 1) { loader_wave(A, c, ring, lane); return; }
+    if (wave >= ENG_NC) { loader_wave(A, c, ring, lane, wave - ENG_NC); return; }
 #endif
 
     const int b = blockIdx.x, G = gridDim.x;
@@ -649,7 +657,7 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
                 const int q_steps = j == 0 ? g0.steps : (j == 1 ? g1.steps : g2.steps), q_ob = j == 0 ? g0.ob : (j == 1 ? g1.ob : g2.ob);
                 const int type = j == 0 ? t0 : (j == 1 ? t1 : t2), U = j == 0 ? U0 : (j == 1 ? U1 : U2);
                 const int c0 = q_split ? id % q_cpr : 0;
-                spin_ge(&c->landed, n + 1, c, A.err, 4);
+                spin_ge(&c->landed[n & 1u], (n >> 1) + 1, c, A.err, 4);          // (item n is the (n / 2)-th item of loader n % 2)
                 const char * img = ring + lds_ld(&c->item_off[n & 63]);
                 float * slot = outbuf + q_ob + id;
 #ifdef ENG_DEBUG
@@ -667,7 +675,7 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
 #ifdef ENG_DEBUG
                 if (A.dbg && b == 0 && lane == 0 && n < 64) {
                     float * o = A.dbg + 16 * n;
-                    o[0] = (float) n; o[1] = (float) (img - ring); o[2] = (float) (q_ob + id); o[3] = *slot; o[4] = (float) lds_ld(&c->landed); o[5] = (float) U; o[6] = (float) q_steps; o[7] = (float) type;
+                    o[0] = (float) n; o[1] = (float) (img - ring); o[2] = (float) (q_ob + id); o[3] = *slot; o[4] = (float) lds_ld(&c->landed[n & 1u]); o[5] = (float) U; o[6] = (float) q_steps; o[7] = (float) type;
                     o[8] = __builtin_bit_cast(float, *(const uint32_t *) img); o[9] = __builtin_bit_cast(float, *(const uint32_t *) (img + 2048)); o[10] = (float) xs_q[0]; o[11] = xs_d[0];
                     o[12] = (float) wave; o[13] = (float) c0; o[14] = (float) pi; o[15] = 1.0f;
                     if (n == 0) { float * o2 = A.dbg + 64 * 16 + 64 * 8; for (int i = 0; i < 32; ++i) o2[i] = (float) xs_q[i]; for (int i = 0; i < 4; ++i) o2[32 + i] = xs_d[i]; for (int i = 0; i < 8; ++i) o2[36 + i] = (float) xs_gs[i]; }

@@ -72,6 +72,7 @@ def main():
     tokens = rng.integers(0, hp["n_vocab"], a.tokens)
     ref, rc0, us0 = run(hp, mix, a.layers, tokens, False, a.time_steps, a.n_ctx, a.start_pos)
     eng, rc1, us1 = run(hp, mix, a.layers, tokens, True, a.time_steps, a.n_ctx, a.start_pos)
+    print("per-token hidden NMSE:", " ".join(f"{nmse(e[0], r[0]):.1e}" for e, r in zip(eng, ref)))
     worst_h = max(nmse(e[0], r[0]) for e, r in zip(eng, ref))
     worst_l = max(nmse(e[1], r[1]) for e, r in zip(eng, ref))
     same = sum(int(np.array_equal(e[1], r[1])) for e, r in zip(eng, ref))
