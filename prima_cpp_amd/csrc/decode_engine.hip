@@ -25,6 +25,7 @@
 //     device-wide arrival -> wait -> consumers fetch the next activation row with sc1 loads and quantize it (rms_norm from the producer-side
 //     partial sums of squares: no reduction, no extra barrier).
 // Every wait is bounded; a time-out raises the launch's watchdog word and every later wait of that workgroup returns at once.
+#define PM_GEMV_BLOCK 960                  // the mat-vec row loops of mmvq_device.h run on the engine's 15 CONSUMER waves (rows are dealt wave, wave + 15, ...)
 #include "mmvq_device.h"
 #include "attn_device.h"
 #include "pm355_engine.h"
@@ -35,7 +36,9 @@ using namespace pmv;
 
 namespace {
 
-constexpr int ENG_NW = 16, ENG_NL = 2, ENG_NC = ENG_NW - ENG_NL, ENG_THREADS = ENG_NW * 64;      // waves: consumers 0 .. 13, loaders 14 and 15
+constexpr int ENG_NW = 16, ENG_NL = 1, ENG_NC = ENG_NW - ENG_NL, ENG_THREADS = ENG_NW * 64;      // waves: consumers 0 .. 14, loader 15
+static_assert(ENG_NC == PM_GEMV_NW, "consumer waves == the row loops' wave count");
+constexpr int ENG_HEAD = 96 * 1024;                        // bytes of a phase's FIRST rows that go through the ring (what the loader has in LDS when the seam ends)
 constexpr int ENG_RING = 120 * 1024;                       // bytes of weight images in flight per CU
 constexpr int ENG_ACT = 36864;                             // Q8_K activation row: q[K] | group sums[K/16] | d[K/256], K <= 28672 (also the attention scratch)
 constexpr int ENG_OUTF = 640;                              // parked results per workgroup (floats)
@@ -251,11 +254,23 @@ __device__ __forceinline__ JobGeo job_geo(const GemvJob & jb, int type, int pair
     return g;
 }
 
+// How many of job 0's items take the ring (whole rows; the rest of the phase is read HBM -> registers by the consumers themselves, like the mat-vec
+// kernel): measured, LDS-DMA instructions issue at ~150 cycles each into a CU whose consumers are busy - one KiB per 150 cycles is 14 GB/s per
+// loader wave, two loader waves reached 20 of the 26.5 GB/s a CU's share of HBM is. The ring therefore carries only what hides the seam.
+__device__ __forceinline__ int ring_items(const JobGeo & jg) {
+    int n = ENG_HEAD / jg.bytes;
+    if (jg.split) n -= n % jg.cpr;
+    return n < jg.items ? n : jg.items;
+}
+
 // ---- loader wave ------------------------------------------------------------------------------------------------------------------------------
 // One wave runs EVERYTHING the weights need - its instruction stream is the engine's bandwidth: a single wave issues one instruction every
 // 5-8 cycles, a 2304-byte step has to leave every ~180 cycles, so an item may cost ~40 instructions besides its DMA. Hence: every cursor lives in
 // SGPRs (no lane-indexed FIFOs, no per-item loops), the type / pair dispatch is per JOB, and `landed` follows from arithmetic - all items of a
 // job carry the same number of DMA instructions, so after s_waitcnt vmcnt(48) everything but the job's newest ceil(48 / k) items has landed.
+#ifdef ENG_DEBUG
+__device__ unsigned long long g_ld_room = 0, g_ld_issue = 0, g_ld_wait = 0, g_cs_spin = 0, g_cs_eat = 0;      // (debug builds: cycle accounts of workgroup 0 - races between its waves are harmless noise: one wave each writes)
+#endif
 struct LoaderState {
     unsigned n, cur, U, tail, tailU;                       // items WALKED (both loaders place every item) | ring cursor | the same unwrapped | oldest unretired item (cached), its start
     unsigned m, landed;                                    // OWN items issued | own items published as landed
@@ -295,14 +310,21 @@ __device__ __forceinline__ bool loader_job(const EngArgs & A, Ctl * c, char * ri
     const unsigned k_item = (unsigned) (ST<TYPE>::NDMA * jg.steps * (PAIR ? 2 : 1));      // DMA instructions per item
     const unsigned lag = ((unsigned) ENG_VMAX + k_item - 1) / k_item;                    // OWN items the newest ENG_VMAX instructions may belong to
     const unsigned job_m0 = S.m;
-    const int rows = jg.r1 - jg.r0, chunks = jg.split ? jg.cpr : 1;
+    const int chunks = jg.split ? jg.cpr : 1, rows = ring_items(jg) / chunks;
     const uint8_t * row_lin = jb.W + (long) jg.r0 * jb.row_stride, * row2 = PAIR ? jb.W2 + (long) jg.r0 * jb.row_stride : nullptr;
     for (int r = 0; r < rows; ++r, row_lin += jb.row_stride, row2 += PAIR ? jb.row_stride : 0) {
         const uint8_t * row = jb.nx_s ? jb.W + (long) job_row(jb, jg.r0 + r) * jb.row_stride : row_lin;      // (NEOX rope: permuted rows)
         for (int cc = 0; cc < chunks; ++cc) {
             loader_place(S, (unsigned) jg.bytes);
-            if ((int) (S.n & 1u) == LD) {                  // items alternate between the two loader waves; both walk (place) every item
+            if ((int) (S.n % (unsigned) ENG_NL) == LD) {          // (with more than one loader wave the items alternate; every loader walks - places - every item)
+#ifdef ENG_DEBUG
+                const unsigned long long t_a = __builtin_amdgcn_s_memtime();
+#endif
                 if (!loader_make_room(A, c, S, (unsigned) jg.bytes, lane, LD)) return false;
+#ifdef ENG_DEBUG
+                const unsigned long long t_b = __builtin_amdgcn_s_memtime();
+                if (blockIdx.x == 0 && LD == 0) g_ld_room += t_b - t_a;
+#endif
                 char * dst = ring + S.cur;
                 for (int s_ = 0; s_ < jg.steps; ++s_) {
                     dma_step<TYPE, FAST>(dst + s_ * SB, row, K, jb.U, cc + s_, lane);
@@ -310,7 +332,14 @@ __device__ __forceinline__ bool loader_job(const EngArgs & A, Ctl * c, char * ri
                 }
                 if (lane == 0) lds_st2_asm(&c->item_off[S.n & 63], S.cur, S.U);
                 ++S.m;
+#ifdef ENG_DEBUG
+                const unsigned long long t_c = __builtin_amdgcn_s_memtime();
+                if (blockIdx.x == 0 && LD == 0) g_ld_issue += t_c - t_b;
+#endif
                 asm volatile("s_waitcnt vmcnt(48)" ::: "memory");                         // (ENG_VMAX)
+#ifdef ENG_DEBUG
+                if (blockIdx.x == 0 && LD == 0) g_ld_wait += __builtin_amdgcn_s_memtime() - t_c;
+#endif
                 const unsigned in_job = S.m - job_m0;
                 const unsigned pub = in_job > lag ? S.m - lag : (in_job * k_item >= (unsigned) ENG_VMAX ? job_m0 : S.landed);
                 if (pub != S.landed) { S.landed = pub; if (lane == 0) lds_st_asm(&c->landed[LD], pub); }
@@ -332,7 +361,7 @@ __device__ __forceinline__ void loader_wave(const EngArgs & A, Ctl * c, char * r
         const EngPhase * ph = phs + pi;
         if (ph->kind != 0) continue;
         const int K = ph->g.K, pair = ph->pair, ta = ph->ta, tb = ph->tb;
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < 1; ++j) {                     // (job 0's first rows only: ring_items())
             if (ph->g.job[j].N <= 0) continue;
             const GemvJob & jb = ph->g.job[j];
             const int type = jb.is_b ? tb : ta;
@@ -351,7 +380,10 @@ __device__ __forceinline__ void loader_wave(const EngArgs & A, Ctl * c, char * r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) lds_st_asm(&c->landed[LD], S.m);
 #ifdef ENG_DEBUG
-    if (A.dbg && b == 0 && lane == 0 && LD == 0) { float * Ld = A.dbg + 64 * 16 + 64 * 8 + 64 + 32 * 16; Ld[0] = (float) S.n; Ld[1] = 0.0f; Ld[2] = 0.0f; Ld[3] = (float) (__builtin_amdgcn_s_memrealtime() - dbg_t0) / 100.0f; }
+    if (A.dbg && b == 0 && lane == 0 && LD == 0) {
+        float * Ld = A.dbg + 64 * 16 + 64 * 8 + 64 + 32 * 16; Ld[0] = (float) S.n; Ld[1] = (float) g_ld_room; Ld[2] = (float) g_ld_issue; Ld[3] = (float) (__builtin_amdgcn_s_memrealtime() - dbg_t0) / 100.0f; Ld[4] = (float) g_ld_wait;
+        g_ld_room = g_ld_issue = g_ld_wait = 0;
+    }
 #endif
 }
 
@@ -584,6 +616,70 @@ __device__ __forceinline__ void eng_attention(const EngPhase * ph, int h, char *
     }
 }
 
+// The rows of one mat-vec phase in one workgroup. Returns the number of ring items of the phase (launch-wide item counter).
+template <int TA, int TB, bool PAIR, bool EPI>
+__device__ __forceinline__ int phase_rows(const EngArgs & A, const EngPhase * ph, Ctl * c, char * ring, const XLds & xs, float * outbuf, unsigned nbase, int wave, int lane, int b, int G,
+                                          JobGeo & g0, JobGeo & g1, JobGeo & g2) {
+    typedef Item<TA, PAIR, 1> IA;
+    typedef Item<TB, PAIR, 1> IB;
+    constexpr int R = IA::R;
+    static_assert(R == 1, "one row per item");
+    constexpr int NPRE = (PAIR || TA == PM_Q5_K) ? 1 : 2;   // register sets in flight before the ring items are consumed (as the launches: mmvq.hip)
+    GemvP pl = GemvP();                                    // what the row loops read of the argument block
+    pl.K = ph->g.K;
+    const GemvJob j0 = ph->g.job[0], j1 = ph->g.job[1], j2 = ph->g.job[2];
+    g0 = job_geo(j0, TA, PAIR, b, G, 0);
+    g1.ob = g0.nres; if (j1.N > 0) g1 = job_geo(j1, j1.is_b ? TB : TA, false, b, G, g0.nres);
+    g2.ob = g1.ob + g1.nres; if (j2.N > 0) g2 = job_geo(j2, j2.is_b ? TB : TA, false, b, G, g1.ob + g1.nres);
+    const int P = ring_items(g0), Prow = g0.split ? P / g0.cpr : P, r0r = g0.r0 + Prow;
+    // ---- this wave's first register-path steps of job 0 go out now: they travel while the ring items are consumed
+    typename IA::Regs ga, gb;
+    if (!g0.split) {
+        const int cpr0 = (((j0.U + 63) >> 6) + IA::CH - 1) / IA::CH;
+        int prow = r0r + wave * R, pc = 0;
+        auto adv = [&]() __attribute__((always_inline)) { if (++pc == cpr0) { pc = 0; prow += PM_GEMV_NW * R; } };
+        IA::issue(ga, pl, j0, prow, g0.r1, pc * IA::CH, lane); adv();
+        if (NPRE >= 2) { IA::issue(gb, pl, j0, prow, g0.r1, pc * IA::CH, lane); adv(); }
+    }
+    // ---- ring items (launch-wide index n -> wave n % 15)
+    {
+        const unsigned first = nbase + (unsigned) ((wave + ENG_NC - (int) (nbase % ENG_NC)) % ENG_NC);
+        unsigned k_done = lds_ld(&c->done[wave]);
+        for (unsigned n = first; n < nbase + (unsigned) P; n += ENG_NC) {
+            const int id = (int) (n - nbase);
+            const int c0 = g0.split ? id % g0.cpr : 0;
+            spin_ge(&c->landed[n % (unsigned) ENG_NL], n / (unsigned) ENG_NL + 1, c, A.err, 4);
+            const char * img = ring + lds_ld(&c->item_off[n & 63]);
+            eat_item<TA, PAIR>(img, j0.U, xs, c0, g0.steps, lane, outbuf + id);
+            ++k_done;
+            __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the image has been read (and the result parked)
+            if (lane == 0) lds_st(&c->done[wave], k_done);
+        }
+    }
+    // ---- the rest of job 0, then jobs 1 and 2 (wk / wv next to wq): HBM -> registers
+    const int ni_0 = g0.split ? (g0.r1 - r0r) * g0.cpr : (g0.r1 - r0r + R - 1) / R;
+    if (!g0.split) IA::template run_job<false, NPRE>(ga, gb, pl, j0, xs, outbuf + Prow, wave, ni_0, r0r, g0.r1, lane);
+    else if constexpr (!PAIR) IA::template run_job_split<false>(ga, gb, pl, j0, xs, outbuf + P, wave, ni_0, r0r, g0.r1, lane);
+    if constexpr (EPI) {
+        const int w1 = (wave + PM_GEMV_NW - ni_0 % PM_GEMV_NW) % PM_GEMV_NW;
+        const int w2 = (wave + 2 * PM_GEMV_NW - (ni_0 + g1.items) % PM_GEMV_NW) % PM_GEMV_NW;
+        typename IB::Regs gB, gB1;
+        if (g1.items > 0) {
+            if (g1.split) { if (TA != TB && j1.is_b) IB::template run_job_split<false>(gB, gB1, pl, j1, xs, outbuf + g1.ob, w1, g1.items, g1.r0, g1.r1, lane);
+                            else                      IA::template run_job_split<false>(ga, gb, pl, j1, xs, outbuf + g1.ob, w1, g1.items, g1.r0, g1.r1, lane); }
+            else          { if (TA != TB && j1.is_b) IB::template run_job<false, 0>(gB, gB1, pl, j1, xs, outbuf + g1.ob, w1, g1.items, g1.r0, g1.r1, lane);
+                            else                      IA::template run_job<false, 0>(ga, gb, pl, j1, xs, outbuf + g1.ob, w1, g1.items, g1.r0, g1.r1, lane); }
+        }
+        if (g2.items > 0) {
+            if (g2.split) { if (TA != TB && j2.is_b) IB::template run_job_split<false>(gB, gB1, pl, j2, xs, outbuf + g2.ob, w2, g2.items, g2.r0, g2.r1, lane);
+                            else                      IA::template run_job_split<false>(ga, gb, pl, j2, xs, outbuf + g2.ob, w2, g2.items, g2.r0, g2.r1, lane); }
+            else          { if (TA != TB && j2.is_b) IB::template run_job<false, 0>(gB, gB1, pl, j2, xs, outbuf + g2.ob, w2, g2.items, g2.r0, g2.r1, lane);
+                            else                      IA::template run_job<false, 0>(ga, gb, pl, j2, xs, outbuf + g2.ob, w2, g2.items, g2.r0, g2.r1, lane); }
+        }
+    }
+    return P;
+}
+
 __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ Ctl ctl;
@@ -610,8 +706,14 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
 #else
 #define ENG_STAMP(k) do { } while (0)
 #endif
+    const int wave_k = wave;                               // (scalar: lives in an SGPR across the phases; the lane id is re-derived with mbcnt)
     for (int pi = 0; pi < A.n_ph; ++pi) {
         const EngPhase * ph = phs + pi;
+        // (the thread id is re-derived through an opaque asm in every phase: what the row loops, prologues and epilogues compute from it - lane offsets, row
+        //  pointers - would otherwise be hoisted out of the phase loop and kept alive, i.e. spilled, across all eight instantiations of the phase body)
+        int lane_o = (int) __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_o));
+        const int lane = lane_o, wave = wave_k, tid = wave * 64 + lane;
         // ---- seam: every workgroup's outputs of the previous phase are in memory
         if (pi > 0) {
             if (wave == 0 && lane == 0) g_wait(A.ctr, (unsigned) pi, GS, c, A.err);
@@ -628,7 +730,6 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
             }
 #endif
         } else {
-            // (the phase block stays in constant memory: a local copy whose members are selected at run time would live in scratch)
             const GemvP & p = ph->g;
             const int ta = ph->ta, tb = ph->tb, pair = ph->pair;
             const int K = p.K;
@@ -639,50 +740,26 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
             wbar(&c->cbar, cgen, ENG_NC, lane, c, A.err, 2);
             ENG_STAMP(1);
             const XLds xs = {xs_q, xs_gs, xs_d, 0};
-            // ---- this workgroup's items, launch-wide index n -> wave n % 15
-            const int t0 = p.job[0].is_b ? tb : ta, t1 = p.job[1].is_b ? tb : ta, t2 = p.job[2].is_b ? tb : ta;
-            const int U0 = p.job[0].U, U1 = p.job[1].U, U2 = p.job[2].U;
+            // ---- rows: the head of job 0 out of the ring, everything else HBM -> registers (the mat-vec kernel's own row loops)
             JobGeo g0 = JobGeo(), g1 = JobGeo(), g2 = JobGeo();
-            if (p.job[0].N > 0) g0 = job_geo(p.job[0], t0, pair, b, G, 0);
-            g1.ob = g0.nres; if (p.job[1].N > 0) g1 = job_geo(p.job[1], t1, pair, b, G, g0.nres);
-            g2.ob = g1.ob + g1.nres; if (p.job[2].N > 0) g2 = job_geo(p.job[2], t2, pair, b, G, g1.ob + g1.nres);
-            const int nit = g0.items + g1.items + g2.items;
-            const unsigned first = nbase + (unsigned) ((wave + ENG_NC - (int) (nbase % ENG_NC)) % ENG_NC);
-            unsigned k_done = lds_ld(&c->done[wave]);
-            for (unsigned n = first; n < nbase + (unsigned) nit; n += ENG_NC) {
-                const int li = (int) (n - nbase);
-                const int j = li < g0.items ? 0 : (li < g0.items + g1.items ? 1 : 2);
-                const int id = li - (j > 0 ? g0.items : 0) - (j > 1 ? g1.items : 0);
-                const int q_cpr = j == 0 ? g0.cpr : (j == 1 ? g1.cpr : g2.cpr), q_split = j == 0 ? g0.split : (j == 1 ? g1.split : g2.split);
-                const int q_steps = j == 0 ? g0.steps : (j == 1 ? g1.steps : g2.steps), q_ob = j == 0 ? g0.ob : (j == 1 ? g1.ob : g2.ob);
-                const int type = j == 0 ? t0 : (j == 1 ? t1 : t2), U = j == 0 ? U0 : (j == 1 ? U1 : U2);
-                const int c0 = q_split ? id % q_cpr : 0;
-                spin_ge(&c->landed[n & 1u], (n >> 1) + 1, c, A.err, 4);          // (item n is the (n / 2)-th item of loader n % 2)
-                const char * img = ring + lds_ld(&c->item_off[n & 63]);
-                float * slot = outbuf + q_ob + id;
-#ifdef ENG_DEBUG
-                g_dbg_lane = (A.dbg && b == 0 && n == 0) ? A.dbg + 64 * 16 : nullptr;
+            int nit = 0;
+#define ENG_PH(TA_, TB_, P_, E_) nit = phase_rows<TA_, TB_, P_, E_>(A, ph, c, ring, xs, outbuf, nbase, wave, lane, b, G, g0, g1, g2)
+            if (ph->epi) {
+                if (ta == PM_Q4_K && tb == PM_Q4_K) ENG_PH(PM_Q4_K, PM_Q4_K, false, true);
+                else if (ta == PM_Q4_K && tb == PM_Q6_K) ENG_PH(PM_Q4_K, PM_Q6_K, false, true);
+                else if (ta == PM_Q4_K && tb == PM_Q5_K) ENG_PH(PM_Q4_K, PM_Q5_K, false, true);
+#ifndef ENG_NO_Q6EPI
+                else ENG_PH(PM_Q6_K, PM_Q6_K, false, true);
 #endif
-                if (type == PM_Q4_K) { if (pair) eat_item<PM_Q4_K, true>(img, U, xs, c0, q_steps, lane, slot); else eat_item<PM_Q4_K, false>(img, U, xs, c0, q_steps, lane, slot); }
-#ifndef ENG_NO_Q6
-                else if (type == PM_Q6_K) { if (pair) eat_item<PM_Q6_K, true>(img, U, xs, c0, q_steps, lane, slot); else eat_item<PM_Q6_K, false>(img, U, xs, c0, q_steps, lane, slot); }
+            } else if (pair) {
+                if (ta == PM_Q4_K) ENG_PH(PM_Q4_K, PM_Q4_K, true, false);
+#ifndef ENG_NO_Q6PAIR
+                else ENG_PH(PM_Q6_K, PM_Q6_K, true, false);
 #endif
-#ifndef ENG_NO_Q5
-                else eat_item<PM_Q5_K, false>(img, U, xs, c0, q_steps, lane, slot);
-#endif
-                ++k_done;
-                __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): the image has been read (and the result parked)
-#ifdef ENG_DEBUG
-                if (A.dbg && b == 0 && lane == 0 && n < 64) {
-                    float * o = A.dbg + 16 * n;
-                    o[0] = (float) n; o[1] = (float) (img - ring); o[2] = (float) (q_ob + id); o[3] = *slot; o[4] = (float) lds_ld(&c->landed[n & 1u]); o[5] = (float) U; o[6] = (float) q_steps; o[7] = (float) type;
-                    o[8] = __builtin_bit_cast(float, *(const uint32_t *) img); o[9] = __builtin_bit_cast(float, *(const uint32_t *) (img + 2048)); o[10] = (float) xs_q[0]; o[11] = xs_d[0];
-                    o[12] = (float) wave; o[13] = (float) c0; o[14] = (float) pi; o[15] = 1.0f;
-                    if (n == 0) { float * o2 = A.dbg + 64 * 16 + 64 * 8; for (int i = 0; i < 32; ++i) o2[i] = (float) xs_q[i]; for (int i = 0; i < 4; ++i) o2[32 + i] = xs_d[i]; for (int i = 0; i < 8; ++i) o2[36 + i] = (float) xs_gs[i]; }
-                }
-#endif
-                if (lane == 0) lds_st(&c->done[wave], k_done);
+            } else {
+                if (ta == PM_Q4_K) ENG_PH(PM_Q4_K, PM_Q4_K, false, false); else ENG_PH(PM_Q6_K, PM_Q6_K, false, false);
             }
+#undef ENG_PH
             nbase += (unsigned) nit;
             ENG_STAMP(2);
             float ec0 = 1.0f, es0 = 0.0f, ec1 = 1.0f, es1 = 0.0f, ec2 = 1.0f, es2 = 0.0f;
@@ -719,6 +796,9 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
         if (wave == 0 && lane == 0) g_arrive(A.ctr, (unsigned) pi, NGR, GS, pi == A.n_ph - 1);
         ENG_STAMP(5);
     }
+#ifdef ENG_DEBUG
+    if (A.dbg && b == 0 && tid == 0) { float * Ld = A.dbg + 64 * 16 + 64 * 8 + 64 + 32 * 16; Ld[5] = (float) g_cs_spin; Ld[6] = (float) g_cs_eat; g_cs_spin = g_cs_eat = 0; }
+#endif
 }
 
 // f64 sum of the f32-rounded squares of a row (the rms_norm input of the launch's FIRST phase has no producing phase: embedding row or ring hand-off)
@@ -758,9 +838,10 @@ int pm_eng_plan_add_matvec(pm_eng_plan * pl, const pm_gemv_fused & f) {
     int ta, tb, grid; bool pair; size_t lds;
     const int rc = gemv_fill(f, 0, e.g, ta, tb, pair, lds, grid);
     if (rc) return rc < 0 ? rc : -rc;
-    auto served = [](int t) { return t == PM_Q4_K || t == PM_Q5_K || t == PM_Q6_K; };
-    if (!served(ta) || !served(tb)) return -10;                                   // (Q8_0 weights take Q8_0 activations: not in the engine yet)
-    if (pair && ta == PM_Q5_K) return -10;
+    // the row loops compiled into the engine kernel (phase_rows<>): wq | wk | wv with the rope / KV-store epilogue in the type mixtures of the Q4_K_M and
+    // Q6_K files, single Q4_K / Q6_K matrices (wo, ffn_down), Q4_K / Q6_K pairs (ffn_gate | ffn_up). (Q8_0 weights take Q8_0 activations: not yet)
+    if (f.epi) { if (!((ta == PM_Q4_K && (tb == PM_Q4_K || tb == PM_Q6_K || tb == PM_Q5_K)) || (ta == PM_Q6_K && tb == PM_Q6_K))) return -10; }
+    else if (f.njobs != 1 || ta != tb || (ta != PM_Q4_K && ta != PM_Q6_K)) return -10;
     if (e.g.xmode == 0 || e.g.xmode == 2) return -11;                             // f32 rows only; rms_norm only from producer-side partials
     if (f.dbg_int) return -11;
     const int nblk = f.K / 256;
@@ -843,7 +924,8 @@ int pm_eng_plan_status(pm_eng_plan * pl) {
                 fprintf(stderr, "eng phase %2d (wg 0, us since launch entry): seam-in %.2f | prologue done %.2f | items done (wave 0) %.2f | all waves %.2f | epilogue + stores %.2f | arrived %.2f\n", ph,
                         (t[8 * ph] - t[0]) / 100.0, (t[8 * ph + 1] - t[0]) / 100.0, (t[8 * ph + 2] - t[0]) / 100.0, (t[8 * ph + 3] - t[0]) / 100.0, (t[8 * ph + 4] - t[0]) / 100.0, (t[8 * ph + 5] - t[0]) / 100.0);
             const float * L = &h[64 * 16 + 64 * 8 + 64 + 32 * 16];
-            fprintf(stderr, "eng loader (wg 0): items %g, ring-full waits %g (drains), tail refreshes %g, done at %.2f us\n", L[0], L[1], L[2], L[3]);
+            fprintf(stderr, "eng loader 0 (wg 0): walked %g items, done at %.2f us; shader cycles waiting for ring room %g | issuing %g | in s_waitcnt vmcnt %g\n", L[0], L[3], L[1], L[2], L[4]);
+            fprintf(stderr, "eng consumer wave 0 (wg 0): shader cycles waiting for items %g | consuming %g\n", L[5], L[6]);
         }
         for (int l = 0; l < 4; ++l) { const float * o = &h[64 * 16 + 8 * l]; fprintf(stderr, "eng lane %2d: isum=%g msum=%g yd=%g acc=%g xq0=%g gs0=%g u=%g uv=%g\n", l, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]); }
         for (int i = 0; i < 64; ++i) if (h[16 * i + 15] != 0.0f) {
