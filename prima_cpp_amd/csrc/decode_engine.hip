@@ -641,25 +641,29 @@ __device__ __forceinline__ int phase_rows(const EngArgs & A, const EngPhase * ph
         IA::issue(ga, pl, j0, prow, g0.r1, pc * IA::CH, lane); adv();
         if (NPRE >= 2) { IA::issue(gb, pl, j0, prow, g0.r1, pc * IA::CH, lane); adv(); }
     }
-    // ---- ring items (launch-wide index n -> wave n % 15)
-    {
-        const unsigned first = nbase + (unsigned) ((wave + ENG_NC - (int) (nbase % ENG_NC)) % ENG_NC);
+    // ---- ring items (launch-wide index n -> wave n % 15), then the rest of job 0 HBM -> registers. An item that has not landed yet (the loader shares the
+    // CU's address path with fifteen streaming waves) is left for a second pass behind the register rows: waiting for it would hold back this wave's share
+    // of the stream.
+    const int ni_0 = g0.split ? (g0.r1 - r0r) * g0.cpr : (g0.r1 - r0r + R - 1) / R;
+    unsigned n = nbase + (unsigned) ((wave + ENG_NC - (int) (nbase % ENG_NC)) % ENG_NC);
+    auto ring_pass = [&](bool wait) __attribute__((always_inline)) {
         unsigned k_done = lds_ld(&c->done[wave]);
-        for (unsigned n = first; n < nbase + (unsigned) P; n += ENG_NC) {
+        for (; n < nbase + (unsigned) P; n += ENG_NC) {
             const int id = (int) (n - nbase);
             const int c0 = g0.split ? id % g0.cpr : 0;
-            spin_ge(&c->landed[n % (unsigned) ENG_NL], n / (unsigned) ENG_NL + 1, c, A.err, 4);
+            if (!wait) { if ((int) (lds_ld(&c->landed[n % (unsigned) ENG_NL]) - (n / (unsigned) ENG_NL + 1)) < 0) break; }
+            else spin_ge(&c->landed[n % (unsigned) ENG_NL], n / (unsigned) ENG_NL + 1, c, A.err, 4);
             const char * img = ring + lds_ld(&c->item_off[n & 63]);
             eat_item<TA, PAIR>(img, j0.U, xs, c0, g0.steps, lane, outbuf + id);
             ++k_done;
             __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the image has been read (and the result parked)
             if (lane == 0) lds_st(&c->done[wave], k_done);
         }
-    }
-    // ---- the rest of job 0, then jobs 1 and 2 (wk / wv next to wq): HBM -> registers
-    const int ni_0 = g0.split ? (g0.r1 - r0r) * g0.cpr : (g0.r1 - r0r + R - 1) / R;
+    };
+    ring_pass(false);
     if (!g0.split) IA::template run_job<false, NPRE>(ga, gb, pl, j0, xs, outbuf + Prow, wave, ni_0, r0r, g0.r1, lane);
     else if constexpr (!PAIR) IA::template run_job_split<false>(ga, gb, pl, j0, xs, outbuf + P, wave, ni_0, r0r, g0.r1, lane);
+    ring_pass(true);
     if constexpr (EPI) {
         const int w1 = (wave + PM_GEMV_NW - ni_0 % PM_GEMV_NW) % PM_GEMV_NW;
         const int w2 = (wave + 2 * PM_GEMV_NW - (ni_0 + g1.items) % PM_GEMV_NW) % PM_GEMV_NW;
@@ -748,12 +752,12 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
                 if (ta == PM_Q4_K && tb == PM_Q4_K) ENG_PH(PM_Q4_K, PM_Q4_K, false, true);
                 else if (ta == PM_Q4_K && tb == PM_Q6_K) ENG_PH(PM_Q4_K, PM_Q6_K, false, true);
                 else if (ta == PM_Q4_K && tb == PM_Q5_K) ENG_PH(PM_Q4_K, PM_Q5_K, false, true);
-#ifndef ENG_NO_Q6EPI
+#ifdef ENG_ALL_TYPES
                 else ENG_PH(PM_Q6_K, PM_Q6_K, false, true);
 #endif
             } else if (pair) {
                 if (ta == PM_Q4_K) ENG_PH(PM_Q4_K, PM_Q4_K, true, false);
-#ifndef ENG_NO_Q6PAIR
+#ifdef ENG_ALL_TYPES
                 else ENG_PH(PM_Q6_K, PM_Q6_K, true, false);
 #endif
             } else {
@@ -840,8 +844,10 @@ int pm_eng_plan_add_matvec(pm_eng_plan * pl, const pm_gemv_fused & f) {
     if (rc) return rc < 0 ? rc : -rc;
     // the row loops compiled into the engine kernel (phase_rows<>): wq | wk | wv with the rope / KV-store epilogue in the type mixtures of the Q4_K_M and
     // Q6_K files, single Q4_K / Q6_K matrices (wo, ffn_down), Q4_K / Q6_K pairs (ffn_gate | ffn_up). (Q8_0 weights take Q8_0 activations: not yet)
-    if (f.epi) { if (!((ta == PM_Q4_K && (tb == PM_Q4_K || tb == PM_Q6_K || tb == PM_Q5_K)) || (ta == PM_Q6_K && tb == PM_Q6_K))) return -10; }
-    else if (f.njobs != 1 || ta != tb || (ta != PM_Q4_K && ta != PM_Q6_K)) return -10;
+    // (all-Q6_K wq | wk | wv and Q6_K pairs - the Q6_K file type - are written (-DENG_ALL_TYPES) but not compiled in: eight instantiations of the phase body
+    //  in one kernel spill; the Q6_K models carry Q8_0 ffn_down rows anyway and stay on the launches)
+    if (f.epi) { if (!(ta == PM_Q4_K && (tb == PM_Q4_K || tb == PM_Q6_K || tb == PM_Q5_K))) return -10; }
+    else if (f.njobs != 1 || ta != tb || (ta != PM_Q4_K && ta != PM_Q6_K) || (pair && ta != PM_Q4_K)) return -10;
     if (e.g.xmode == 0 || e.g.xmode == 2) return -11;                             // f32 rows only; rms_norm only from producer-side partials
     if (f.dbg_int) return -11;
     const int nblk = f.K / 256;
