@@ -1,31 +1,41 @@
-// decode_engine.hip — the single-token layer stack as ONE persistent launch on a run-ahead LDS-DMA weight loader (round 5).
+// decode_engine.hip — the single-token layer stack as ONE persistent launch (round 5).
 //
 // What it replaces: the five launches per layer of engine.hip's run_layers_fused (mmvq.hip + attn_cached.hip), i.e. the same reference
 // nodes - ggml_compute_forward_mul_mat over ggml_vec_dot_q4_K/q5_K/q6_K_q8_K with quantize_row_q8_K and rms_norm fused in front
 // (ggml.c:12377, ggml-quants.c:7713 / 8281 / 8918 / 3785, ggml.c:11950), rope + F16 KV store (ggml.c:14143, src/llama.cpp:9673-9718),
-// attention over cached cells (ggml.c:12445-12473, :13783-13879), silu * mul, residual adds - with the SAME device arithmetic (QT<>::consume,
-// q8k_rows_to_lds, write_out, write_out_qkv, the attn_cached / attn_rope_body bodies): outputs are bit-identical to the five-launch path except
-// for ffn_down, whose K = 28672 rows are summed chunk by chunk here (ring capacity) and lane by lane there (summation order, ~1e-7 relative).
+// attention over cached cells (ggml.c:12445-12473, :13783-13879), silu * mul, residual adds - with the SAME device code (the row loops
+// Item<>::run_job / run_job_split, QT<>::consume, q8k_rows_to_lds, write_out, write_out_qkv of mmvq_device.h, the attn_cached / attn_rope_body
+// arithmetic): every phase's output is bit-identical to the launch it stands for (tests/test_gpu_ops.py, test_gpu_engine.py).
 //
-// Why (profiles/r05_engine_seam_cost.txt, r05_seam_anatomy_sumsq.txt): a 70B layer is 75 us of weight streaming plus five dependent all-to-all
-// seams. As kernel boundaries each seam costs ~6.2 us (boundary 2.5 + activation fetch + quantizing prologue + ramp and tail) during which HBM
-// idles: 110 us per layer. Inside one launch a seam is a device-wide barrier + the same fetch / quantize (2-5 us), and a DEDICATED loader wave
-// keeps streaming the NEXT phase's weights into an LDS ring while the consumers sit in the seam - weights do not depend on activations: the
-// skeleton of this structure measured 92 us per layer on the box whose five launches take 110 (MI355X_MICROARCH.md "engine-vs-launches",
-// "prefetch-credit").
+// Status: OPT-IN (PM355_ENGINE=1). Correct - every phase the same bits as its launch, 80 70B-shape layers bit-identical in hidden rows and logits, watchdog
+// clean - and SLOWER than the five launches it replaces: 10.15-10.4 ms against 8.55 ms per 70B token, 2.23 against 1.67 ms on the 8B shape
+// (profiles/r05_engine_measured.txt). The default path stays run_layers_fused. What was learnt, in the order it was measured:
+//   1. The skeleton that motivated it (tools/csrc/engine_probe.hip, profiles/r05_engine_seam_cost.txt: 92 us against 110 us per layer) streams the real
+//      bytes through the real barriers but consumes them with a token amount of arithmetic. With the real consume() the row loops are not a pure
+//      stream: a CU needs most of its issue slots to keep its share of HBM busy, so nothing that "runs ahead" is free.
+//   2. A dedicated loader wave filling an LDS ring for 15 consumers (all weights, or only the head of each phase): an LDS-DMA instruction issues every
+//      ~150-190 cycles in a CU whose other waves stream - 14-20 GB/s per CU with one or two loader waves against the 26.5 GB/s a CU's share of HBM is;
+//      as a head-only prefetcher next to 15 register-streaming waves the loader got 4 GB/s and its items arrived after the phase they were meant to
+//      start. 13.8 / 10.6 ms per token.
+//   3. This file's form - no loader, every wave prefetches the first steps of its OWN next rows into a private LDS slot before it goes to the barrier:
+//      the prefetch does stream (37 MB in ~5 us, DMA issue blocks on the queue) but the token time is the same with slots of 0, 2304, 4608 or 9216 bytes
+//      per wave (10.35 / 10.32 / 10.15 / 10.42 ms): what is prefetched has to be consumed afterwards at the same rate the registers would have
+//      delivered it. The in-launch seam itself (timeline in r05_engine_measured.txt) is write-through stores + s_waitcnt 0.7-3.4 us, arrival 1 us,
+//      waiting for the slowest workgroup 2-9 us, system-scope activation fetch + quantize 2.6-3.8 us: ~8 us against the 6.2 us a kernel boundary
+//      costs, six of them per layer (the attention is a phase of its own) against five.
 //
-// Structure: one 1024-thread workgroup per CU (all resident: the device-wide barrier needs that), wave 15 = loader, waves 0-14 = consumers.
-//   * loader: walks every mat-vec phase of the launch in order; the rows of this workgroup are cut into ITEMS (a whole row of <= 2 steps, or one
-//     step of a long / split row; a step = 64 units = what a wave consumes with one instruction stream); an item's bytes are gathered with
-//     global_load_lds_dwordx4 ... nt into a ring-resident image [stream pieces of the step, lane-major] (the per-lane source addresses do the
-//     row-SoA -> step-major permutation), at most 48 DMA instructions in flight; item offsets and a monotonic `landed` counter live in LDS.
-//   * consumers: item n of the launch goes to wave n % 15; a wave waits for landed > n, reads the image with ds_read_b128 (conflict-free), runs the
-//     mat-vec's own consume() against the LDS-resident Q8_K activation, parks the row result, retires the item (done[wave]).
-//   * seam: results -> epilogue (bias / residual / silu*mul / RoPE + KV store, all write-through sc1 stores) -> consumer barrier -> two-level
-//     device-wide arrival -> wait -> consumers fetch the next activation row with sc1 loads and quantize it (rms_norm from the producer-side
-//     partial sums of squares: no reduction, no extra barrier).
+// Structure: one 1024-thread workgroup per CU (all resident: the device-wide barrier needs that), 16 waves that all do the same thing.
+//   * rows: exactly the mat-vec kernel's row loops, HBM -> registers (global_load_dwordx4 nt, two register sets software-pipelined, no LDS staging).
+//   * seam cover: a wave that has stored its results issues, BEFORE it waits at the barrier, LDS-DMA loads (global_load_lds_dwordx4) of the first
+//     steps of ITS OWN rows of the next mat-vec phase into a wave-private LDS slot (ENG_SLOT_BYTES: one 8192-weight Q4_K row); they need no
+//     registers and are consumed from LDS (ds_read_b128, same consume() calls, same order, the per-lane partial sums handed to the register row
+//     loop: Item::run_job's c_start / acc0) while the wave's first register loads travel. Nobody waits for anybody else's prefetch.
+//     (Wave 0 polls the device-wide barrier and every poll waits on vmcnt: it issues its prefetch after the barrier.)
+//   * seam: results -> epilogue (bias / residual / silu*mul / RoPE + KV store, write-through sc1 stores) -> prefetch -> workgroup barrier ->
+//     two-level device-wide arrival -> wait -> fetch the next activation row (sc0 sc1 loads) and quantize it (rms_norm from the producer-side
+//     partial sums of squares: no reduction pass).
+//   * hand-off buffers are write-once per launch (engine.hip gives every layer its own q / attention output / ffn activation / residual rows).
 // Every wait is bounded; a time-out raises the launch's watchdog word and every later wait of that workgroup returns at once.
-#define PM_GEMV_BLOCK 960                  // the mat-vec row loops of mmvq_device.h run on the engine's 15 CONSUMER waves (rows are dealt wave, wave + 15, ...)
 #include "mmvq_device.h"
 #include "attn_device.h"
 #include "pm355_engine.h"
@@ -36,14 +46,15 @@ using namespace pmv;
 
 namespace {
 
-constexpr int ENG_NW = 16, ENG_NL = 1, ENG_NC = ENG_NW - ENG_NL, ENG_THREADS = ENG_NW * 64;      // waves: consumers 0 .. 14, loader 15
-static_assert(ENG_NC == PM_GEMV_NW, "consumer waves == the row loops' wave count");
-constexpr int ENG_HEAD = 96 * 1024;                        // bytes of a phase's FIRST rows that go through the ring (what the loader has in LDS when the seam ends)
-constexpr int ENG_RING = 120 * 1024;                       // bytes of weight images in flight per CU
-constexpr int ENG_ACT = 36864;                             // Q8_K activation row: q[K] | group sums[K/16] | d[K/256], K <= 28672 (also the attention scratch)
-constexpr int ENG_OUTF = 640;                              // parked results per workgroup (floats)
-constexpr int ENG_LDS = ENG_RING + ENG_ACT + ENG_OUTF * 4;
-constexpr int ENG_VMAX = 48;                               // DMA instructions in flight (the counter has 6 bits)
+constexpr int ENG_NW = PM_GEMV_NW, ENG_THREADS = ENG_NW * 64;
+static_assert(ENG_NW == 16, "one 1024-thread workgroup per CU");
+constexpr int ENG_LDS = 163328;                            // dynamic LDS: activation row | 16 prefetch slots | parked results (+ the small static control block)
+constexpr int ENG_OUTF = 640;                              // parked results per workgroup (floats), at the top of the dynamic LDS
+constexpr int ENG_OUT_OFF = ENG_LDS - ENG_OUTF * 4;
+#ifndef ENG_SLOT_BYTES
+#define ENG_SLOT_BYTES 4608
+#endif
+constexpr int ENG_SLOT_MAX = ENG_SLOT_BYTES;                         // bytes a wave prefetches at most (two Q4_K rows of 8192 weights / one gate + up pair)
 constexpr int ENG_MAXG = 1024;
 
 struct EngPhase {
@@ -58,40 +69,44 @@ struct EngArgs { const EngPhase * ph; int n_ph; unsigned * ctr; int * err; float
 typedef __attribute__((address_space(3))) void * lds_vp;
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 
-// LDS control block. Accessed ONLY through LDS-typed pointers (a generic access is FLAT: it waits on vmcnt too and would drain the loader's queue);
-// the loader's own accesses are inline asm (a compiler-visible LDS access after global_load_lds gets an s_waitcnt vmcnt(0) in front of it).
-struct Ctl { unsigned landed[2], cbar, abar, giveup, pad_[3]; unsigned done[16]; unsigned item_off[64]; unsigned item_U[64]; };      // (item_U right behind item_off: one ds_write2st64 per item)
+// LDS control block. Between a wave's prefetch and the first use of its slot the seam's own LDS traffic is inline asm with explicit lgkmcnt waits, and the
+// workgroup barrier is a bare s_barrier: __syncthreads() carries a fence that drains vmcnt - the prefetch would be waited for AT the barrier instead
+// of travelling through it.
+struct Ctl { unsigned abar, giveup, pad_[2]; };
 
 __device__ __forceinline__ lds_u32 * L(unsigned * p) { return (lds_u32 *) p; }
-__device__ __forceinline__ unsigned lds_ld(unsigned * p) { return __hip_atomic_load(L(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_st(unsigned * p, unsigned v) { __hip_atomic_store(L(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st_asm(unsigned * p, unsigned v) { asm volatile("ds_write_b32 %0, %1" :: "v"((unsigned) (uintptr_t) L(p)), "v"(v) : "memory"); }
 __device__ __forceinline__ unsigned lds_ld_asm(unsigned * p) {
     unsigned v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned) (uintptr_t) L(p)) : "memory");
     return v;
 }
-__device__ __forceinline__ void give_up(Ctl * c, int * err, int code, bool asm_path) {
-    if (asm_path) lds_st_asm(&c->giveup, 1); else lds_st(&c->giveup, 1);
+__device__ __forceinline__ unsigned lds_inc_asm(unsigned * p) {      // returns the old value
+    unsigned v;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned) (uintptr_t) L(p)), "v"(1u) : "memory");
+    return v;
+}
+__device__ __forceinline__ void give_up(Ctl * c, int * err, int code) {
+    lds_st_asm(&c->giveup, 1);
     __hip_atomic_store((PM_G int *) err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// consumers: wait until *word >= target (one poll per wave instruction; every lane reads the same address)
-__device__ __forceinline__ bool spin_ge(unsigned * word, unsigned target, Ctl * c, int * err, int code) {
-    int spins = 0;
-    while ((int) (lds_ld(word) - target) < 0) {
-        __builtin_amdgcn_s_sleep(1);
-        if (lds_ld(&c->giveup)) return false;
-        if (++spins > (1 << 22)) { give_up(c, err, code, false); return false; }
-    }
-    return true;
+// workgroup barrier WITHOUT the fence __syncthreads() carries (that one drains vmcnt - and with it the prefetch): this wave's LDS traffic is done
+// (lgkmcnt), then s_barrier
+__device__ __forceinline__ void wg_bar() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-// barrier of `n` waves on a monotonic LDS counter (gen-th use completes at gen * n arrivals)
+// barrier of `n` waves (the attention's four) on a monotonic LDS counter (gen-th use completes at gen * n arrivals)
 __device__ __forceinline__ void wbar(unsigned * ctr, unsigned & gen, int n, int lane, Ctl * c, int * err, int code) {
     ++gen;
-    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): this wave's LDS writes are done
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) {
-        __hip_atomic_fetch_add(L(ctr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        spin_ge(ctr, gen * (unsigned) n, c, err, code);
+        lds_inc_asm(ctr);
+        int spins = 0;
+        while ((int) (lds_ld_asm(ctr) - gen * (unsigned) n) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (lds_ld_asm(&c->giveup)) break;
+            if (++spins > (1 << 22)) { give_up(c, err, code); break; }
+        }
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -122,8 +137,8 @@ __device__ __forceinline__ void g_wait(unsigned * ctr, unsigned phase, unsigned 
     int spins = 0;
     while (__hip_atomic_load((const PM_G unsigned *) flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase) {
         __builtin_amdgcn_s_sleep(2);
-        if (lds_ld(&c->giveup)) return;
-        if (++spins > (1 << 21)) { give_up(c, err, 3, false); return; }
+        if (lds_ld_asm(&c->giveup)) return;
+        if (++spins > (1 << 21)) { give_up(c, err, 3); return; }
     }
 }
 
@@ -238,196 +253,81 @@ template <> struct LW<PM_Q5_K> {
     }
 };
 
-// items of a job inside one workgroup, as both the loader and the consumers count them
-struct JobGeo { int r0, r1, cpr, split, items, steps /*per item*/, bytes /*per item*/, ob /*first result slot*/, nres /*result slots*/; };
+// the prefetch of one wave for one mat-vec phase: the first steps of its own items of job 0 (rows wave, wave + 16, ... of the workgroup's slice), whole rows
+// first, then the leading steps of one more row, as many as its slot holds
+struct PfGeo { int r0, r1, cpr, rows_full, steps_part, slot_bytes; };
 __device__ __forceinline__ int type_cpr(int type, int U) { const int upl = (U + 63) >> 6, ch = (type == PM_Q4_K || type == PM_Q6_K) ? PM_CH64 : PM_CH32; return (upl + ch - 1) / ch; }
 __device__ __forceinline__ int type_step_bytes(int type) { return type == PM_Q4_K ? ST<PM_Q4_K>::BYTES : type == PM_Q6_K ? ST<PM_Q6_K>::BYTES : ST<PM_Q5_K>::BYTES; }
-__device__ __forceinline__ JobGeo job_geo(const GemvJob & jb, int type, int pair, int b, int G, int ob) {
-    JobGeo g;
+__device__ __forceinline__ int acts_bytes(int K) { return (((K + 15) & ~15) + (K / 16) * 4 + (((K / 256) + 3) & ~3) * 4 + 255) & ~255; }
+__device__ __forceinline__ PfGeo pf_geo(const GemvJob & jb, int type, int pair, int K, int b, int G, int wave) {
+    PfGeo g;
     g.r0 = (int) ((long) jb.N * b / G); g.r1 = (int) ((long) jb.N * (b + 1) / G);
     g.cpr = type_cpr(type, jb.U);
-    g.split = jb.split;
-    g.items = g.split ? (g.r1 - g.r0) * g.cpr : (g.r1 - g.r0);
-    g.steps = g.split ? 1 : g.cpr;
-    g.bytes = g.steps * type_step_bytes(type) * (pair ? 2 : 1);
-    g.ob = ob; g.nres = g.items;
+    const int sb = type_step_bytes(type) * (pair ? 2 : 1);
+    int slot = ((ENG_OUT_OFF - acts_bytes(K)) / ENG_NW) & ~255;
+    g.slot_bytes = slot < ENG_SLOT_MAX ? slot : ENG_SLOT_MAX;
+    const int own = g.r1 - g.r0 > wave ? (g.r1 - g.r0 - wave + ENG_NW - 1) / ENG_NW : 0;      // rows of this wave
+    int steps = g.slot_bytes / sb;                          // steps the slot holds
+    if (jb.split) steps = 0;                                // (a few long rows spread over all waves as (row, chunk) items: not prefetched)
+    g.rows_full = steps / g.cpr; g.steps_part = steps - g.rows_full * g.cpr;
+    if (g.rows_full >= own) { g.rows_full = own; g.steps_part = 0; }
     return g;
 }
-
-// How many of job 0's items take the ring (whole rows; the rest of the phase is read HBM -> registers by the consumers themselves, like the mat-vec
-// kernel): measured, LDS-DMA instructions issue at ~150 cycles each into a CU whose consumers are busy - one KiB per 150 cycles is 14 GB/s per
-// loader wave, two loader waves reached 20 of the 26.5 GB/s a CU's share of HBM is. The ring therefore carries only what hides the seam.
-__device__ __forceinline__ int ring_items(const JobGeo & jg) {
-    int n = ENG_HEAD / jg.bytes;
-    if (jg.split) n -= n % jg.cpr;
-    return n < jg.items ? n : jg.items;
-}
-
-// ---- loader wave ------------------------------------------------------------------------------------------------------------------------------
-// One wave runs EVERYTHING the weights need - its instruction stream is the engine's bandwidth: a single wave issues one instruction every
-// 5-8 cycles, a 2304-byte step has to leave every ~180 cycles, so an item may cost ~40 instructions besides its DMA. Hence: every cursor lives in
-// SGPRs (no lane-indexed FIFOs, no per-item loops), the type / pair dispatch is per JOB, and `landed` follows from arithmetic - all items of a
-// job carry the same number of DMA instructions, so after s_waitcnt vmcnt(48) everything but the job's newest ceil(48 / k) items has landed.
-#ifdef ENG_DEBUG
-__device__ unsigned long long g_ld_room = 0, g_ld_issue = 0, g_ld_wait = 0, g_cs_spin = 0, g_cs_eat = 0;      // (debug builds: cycle accounts of workgroup 0 - races between its waves are harmless noise: one wave each writes)
-#endif
-struct LoaderState {
-    unsigned n, cur, U, tail, tailU;                       // items WALKED (both loaders place every item) | ring cursor | the same unwrapped | oldest unretired item (cached), its start
-    unsigned m, landed;                                    // OWN items issued | own items published as landed
-};
-__device__ __forceinline__ void lds_st2_asm(unsigned * p, unsigned a, unsigned b) {       // p[0] = a, p[64] = b (item_off / item_U of one FIFO slot)
-    asm volatile("ds_write2st64_b32 %0, %1, %2 offset1:1" :: "v"((unsigned) (uintptr_t) L(p)), "v"(a), "v"(b) : "memory");
-}
-// the cursor of the next item (a tail of the ring too short for it is skipped: both loaders and nobody else follow this rule)
-__device__ __forceinline__ void loader_place(LoaderState & S, unsigned bytes) {
-    if (S.cur + bytes > (unsigned) ENG_RING) { S.U += (unsigned) ENG_RING - S.cur; S.cur = 0; }
-}
-// room for `bytes` at the cursor? (the live window [start of the oldest unretired item, end of this item) may not exceed the ring)
-__device__ __forceinline__ bool loader_make_room(const EngArgs & A, Ctl * c, LoaderState & S, unsigned bytes, int lane, int LD) {
-    if (S.U + bytes - S.tailU <= (unsigned) ENG_RING) return true;
-    int spins = 0;
-    for (;;) {
-        // refresh the tail: wave w has retired done[w] of its items (w, w + NC, ...): the oldest unretired item of the launch is the minimum
-        const unsigned v = lane < ENG_NC ? (unsigned) lane + lds_ld_asm(&c->done[lane < ENG_NC ? lane : 0]) * (unsigned) ENG_NC : 0xFFFFFFFFu;
-        unsigned t = 0xFFFFFFFFu;
-#pragma unroll
-        for (int i = 0; i < ENG_NC; ++i) t = min(t, (unsigned) __builtin_amdgcn_readlane((int) v, i));
-        S.tail = min(t, S.n);
-        S.tailU = S.tail >= S.n ? S.U : (unsigned) __builtin_amdgcn_readfirstlane((int) lds_ld_asm(&c->item_U[S.tail & 63]));
-        if (S.U + bytes - S.tailU <= (unsigned) ENG_RING) return true;
-        // ring full: nothing can be issued anyway -> drain, publish everything of this loader in flight, wait for a retirement
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (S.landed != S.m) { S.landed = S.m; if (lane == 0) lds_st_asm(&c->landed[LD], S.m); }
-        __builtin_amdgcn_s_sleep(1);
-        if (__builtin_amdgcn_readfirstlane((int) lds_ld_asm(&c->giveup))) return false;     // (made scalar: a divergent exit would turn every cursor into a VGPR)
-        if (++spins > (1 << 22)) { give_up(c, A.err, 1, true); return false; }
-    }
-}
 template <int TYPE, bool PAIR, bool FAST>
-__device__ __forceinline__ bool loader_job(const EngArgs & A, Ctl * c, char * ring, LoaderState & S, const GemvJob & jb, int K, int b, int G, int lane, int LD) {
-    const JobGeo jg = job_geo(jb, TYPE, PAIR, b, G, 0);
+__device__ __forceinline__ void pf_issue(char * slot, const GemvJob & jb, int K, const PfGeo & g, int wave, int lane) {
     constexpr int SB = ST<TYPE>::BYTES;
-    const unsigned k_item = (unsigned) (ST<TYPE>::NDMA * jg.steps * (PAIR ? 2 : 1));      // DMA instructions per item
-    const unsigned lag = ((unsigned) ENG_VMAX + k_item - 1) / k_item;                    // OWN items the newest ENG_VMAX instructions may belong to
-    const unsigned job_m0 = S.m;
-    const int chunks = jg.split ? jg.cpr : 1, rows = ring_items(jg) / chunks;
-    const uint8_t * row_lin = jb.W + (long) jg.r0 * jb.row_stride, * row2 = PAIR ? jb.W2 + (long) jg.r0 * jb.row_stride : nullptr;
-    for (int r = 0; r < rows; ++r, row_lin += jb.row_stride, row2 += PAIR ? jb.row_stride : 0) {
-        const uint8_t * row = jb.nx_s ? jb.W + (long) job_row(jb, jg.r0 + r) * jb.row_stride : row_lin;      // (NEOX rope: permuted rows)
-        for (int cc = 0; cc < chunks; ++cc) {
-            loader_place(S, (unsigned) jg.bytes);
-            if ((int) (S.n % (unsigned) ENG_NL) == LD) {          // (with more than one loader wave the items alternate; every loader walks - places - every item)
-#ifdef ENG_DEBUG
-                const unsigned long long t_a = __builtin_amdgcn_s_memtime();
-#endif
-                if (!loader_make_room(A, c, S, (unsigned) jg.bytes, lane, LD)) return false;
-#ifdef ENG_DEBUG
-                const unsigned long long t_b = __builtin_amdgcn_s_memtime();
-                if (blockIdx.x == 0 && LD == 0) g_ld_room += t_b - t_a;
-#endif
-                char * dst = ring + S.cur;
-                for (int s_ = 0; s_ < jg.steps; ++s_) {
-                    dma_step<TYPE, FAST>(dst + s_ * SB, row, K, jb.U, cc + s_, lane);
-                    if (PAIR) dma_step<TYPE, FAST>(dst + (jg.steps + s_) * SB, row2, K, jb.U, cc + s_, lane);
-                }
-                if (lane == 0) lds_st2_asm(&c->item_off[S.n & 63], S.cur, S.U);
-                ++S.m;
-#ifdef ENG_DEBUG
-                const unsigned long long t_c = __builtin_amdgcn_s_memtime();
-                if (blockIdx.x == 0 && LD == 0) g_ld_issue += t_c - t_b;
-#endif
-                asm volatile("s_waitcnt vmcnt(48)" ::: "memory");                         // (ENG_VMAX)
-#ifdef ENG_DEBUG
-                if (blockIdx.x == 0 && LD == 0) g_ld_wait += __builtin_amdgcn_s_memtime() - t_c;
-#endif
-                const unsigned in_job = S.m - job_m0;
-                const unsigned pub = in_job > lag ? S.m - lag : (in_job * k_item >= (unsigned) ENG_VMAX ? job_m0 : S.landed);
-                if (pub != S.landed) { S.landed = pub; if (lane == 0) lds_st_asm(&c->landed[LD], pub); }
-            } else if (lane == 0) lds_st2_asm(&c->item_off[S.n & 63], S.cur, S.U);       // (the same values its issuer writes: this wave may need the entry first)
-            S.cur += (unsigned) jg.bytes; S.U += (unsigned) jg.bytes; ++S.n;
+    char * dst = slot;
+    for (int i = 0; i <= g.rows_full; ++i) {
+        const int ns = i < g.rows_full ? g.cpr : g.steps_part;
+        if (ns == 0) break;
+        const int lrow = g.r0 + wave + ENG_NW * i;
+        const uint8_t * row = jb.W + (long) job_row(jb, lrow) * jb.row_stride;
+        for (int s_ = 0; s_ < ns; ++s_) {
+            dma_step<TYPE, FAST>(dst, row, K, jb.U, s_, lane); dst += SB;
+            if (PAIR) { dma_step<TYPE, FAST>(dst, jb.W2 + (long) lrow * jb.row_stride, K, jb.U, s_, lane); dst += SB; }
         }
     }
-    return true;
 }
-__device__ __forceinline__ void loader_wave(const EngArgs & A, Ctl * c, char * ring, int lane, int LD) {
-    const int b = blockIdx.x, G = gridDim.x;
-    __builtin_amdgcn_s_setprio(3);                         // the youngest waves of their SIMDs would otherwise lose every arbitration to the consumers
-    LoaderState S = {0, 0, 0, 0, 0, 0, 0};
-#ifdef ENG_DEBUG
-    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    const EngPhase * phs = uniform_const_ptr(A.ph);
-    for (int pi = 0; pi < A.n_ph; ++pi) {
-        const EngPhase * ph = phs + pi;
-        if (ph->kind != 0) continue;
-        const int K = ph->g.K, pair = ph->pair, ta = ph->ta, tb = ph->tb;
-        for (int j = 0; j < 1; ++j) {                     // (job 0's first rows only: ring_items())
-            if (ph->g.job[j].N <= 0) continue;
-            const GemvJob & jb = ph->g.job[j];
-            const int type = jb.is_b ? tb : ta;
-            // the instruction-offset DMA form needs every stream of a row to start at least its piece's offset into the row (K >= 4096) and, for the
-            // plain-copy Q5_K image, whole steps
-            const bool fast = K >= 4096 && (type != PM_Q5_K || (K / 256) % 16 == 0);
-            bool ok;
-#define ENG_LJ(T_, P_, F_) loader_job<T_, P_, F_>(A, c, ring, S, jb, K, b, G, lane, LD)
-            if (type == PM_Q4_K) ok = pair ? (fast ? ENG_LJ(PM_Q4_K, true, true) : ENG_LJ(PM_Q4_K, true, false)) : (fast ? ENG_LJ(PM_Q4_K, false, true) : ENG_LJ(PM_Q4_K, false, false));
-            else if (type == PM_Q6_K) ok = pair ? (fast ? ENG_LJ(PM_Q6_K, true, true) : ENG_LJ(PM_Q6_K, true, false)) : (fast ? ENG_LJ(PM_Q6_K, false, true) : ENG_LJ(PM_Q6_K, false, false));
-            else ok = fast ? ENG_LJ(PM_Q5_K, false, true) : ENG_LJ(PM_Q5_K, false, false);
-#undef ENG_LJ
-            if (!ok) return;
-        }
+// issue the prefetch of mat-vec phase `ph` (its job 0) for this wave
+__device__ __forceinline__ void prefetch_phase(const EngPhase * ph, char * smem, int b, int G, int wave, int lane) {
+    const int K = ph->g.K, pair = ph->pair, ta = ph->ta;
+    const GemvJob & jb = ph->g.job[0];
+    const PfGeo g = pf_geo(jb, ta, pair, K, b, G, wave);
+    char * slot = smem + ENG_OUT_OFF - (wave + 1) * g.slot_bytes;
+    const bool fast = K >= 4096;                            // (instruction-offset DMA form: dma_step)
+    if (ta == PM_Q4_K) {
+        if (pair) { if (fast) pf_issue<PM_Q4_K, true, true>(slot, jb, K, g, wave, lane); else pf_issue<PM_Q4_K, true, false>(slot, jb, K, g, wave, lane); }
+        else      { if (fast) pf_issue<PM_Q4_K, false, true>(slot, jb, K, g, wave, lane); else pf_issue<PM_Q4_K, false, false>(slot, jb, K, g, wave, lane); }
+    } else if (ta == PM_Q6_K) {
+        if (fast) pf_issue<PM_Q6_K, false, true>(slot, jb, K, g, wave, lane); else pf_issue<PM_Q6_K, false, false>(slot, jb, K, g, wave, lane);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) lds_st_asm(&c->landed[LD], S.m);
-#ifdef ENG_DEBUG
-    if (A.dbg && b == 0 && lane == 0 && LD == 0) {
-        float * Ld = A.dbg + 64 * 16 + 64 * 8 + 64 + 32 * 16; Ld[0] = (float) S.n; Ld[1] = (float) g_ld_room; Ld[2] = (float) g_ld_issue; Ld[3] = (float) (__builtin_amdgcn_s_memrealtime() - dbg_t0) / 100.0f; Ld[4] = (float) g_ld_wait;
-        g_ld_room = g_ld_issue = g_ld_wait = 0;
-    }
-#endif
 }
 
-// ---- consumers ---------------------------------------------------------------------------------------------------------------------------------
-// one item: `steps` steps of a row (both matrices of a pair), products against the LDS activation row; the wave's sum goes to out[slot]
-#ifdef ENG_DEBUG
-__device__ float * g_dbg_lane = nullptr;      // (debug builds: per-lane record of the item being consumed, set by the kernel for item 0 of workgroup 0)
-#endif
+// `steps` prefetched steps of one row (both matrices of a pair: [m0 s0 | m1 s0 | m0 s1 | ...]) against the LDS activation row: per-lane partial sums
 template <int TYPE, bool PAIR>
-__device__ __forceinline__ void eat_item(const char * img, int U, const XLds & xs, int c0, int steps, int lane, float * out_slot) {
+__device__ __forceinline__ void eat_steps(const char * img, int U, const XLds & xs, int steps, int lane, float (&acc)[PAIR ? 2 : 1]) {
     typedef QT<TYPE> T;
     constexpr int CH = T::NV == 64 ? PM_CH64 : PM_CH32, NM = PAIR ? 2 : 1;
-    float acc[NM];
-#pragma unroll
-    for (int m = 0; m < NM; ++m) acc[m] = 0.0f;
     for (int s = 0; s < steps; ++s) {
         typename T::Wr w[NM][CH];
 #pragma unroll
-        for (int m = 0; m < NM; ++m) LW<TYPE>::get(w[m], img + (m * steps + s) * ST<TYPE>::BYTES, lane, U - 1 - 64 * CH * (c0 + s));
+        for (int m = 0; m < NM; ++m) LW<TYPE>::get(w[m], img + (s * NM + m) * ST<TYPE>::BYTES, lane, U - 1 - 64 * CH * s);
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const int uu = lane + 64 * ((c0 + s) * CH + i);
+            const int uu = lane + 64 * (s * CH + i);
             const bool uv = uu < U;
             const int u = min(uu, U - 1);
             typename T::X x;
             load_x_lds<TYPE>(x, xs, u, 0);
             x.yd = uv ? x.yd : 0.0f;                       // a clamped (out-of-row) unit contributes exactly 0
 #pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                int isum, msum; acc[m] = T::consume(w[m][i], x, u, acc[m], isum, msum);
-#ifdef ENG_DEBUG
-                if (g_dbg_lane && s == 0 && i == 0 && m == 0) { float * o = g_dbg_lane + 8 * lane; o[0] = (float) isum; o[1] = (float) msum; o[2] = x.yd; o[3] = acc[m]; o[4] = (float) x.q[0]; o[5] = (float) x.gs[0]; o[6] = (float) u; o[7] = (float) uv; }
-#endif
-            }
+            for (int m = 0; m < NM; ++m) { int isum, msum; acc[m] = T::consume(w[m][i], x, u, acc[m], isum, msum); }
         }
     }
-    float o[NM];
-#pragma unroll
-    for (int m = 0; m < NM; ++m) o[m] = wave_sum(acc[m]);
-    if (lane == 0) *out_slot = PAIR ? silu_f(o[0]) * o[NM - 1] : o[0];
 }
 
 // the activation row of a mat-vec phase -> Q8_K in LDS (quantize_row_q8_K_ref bits: q8k_rows_to_lds), after an optional rms_norm whose sum of
-// squares comes from the producing phase's partials. 15 waves, 4 blocks per wave and pass, <= 2 passes (<= 1 with norm weights).
+// squares comes from the producing phase's partials. 16 waves, 4 blocks per wave and pass, <= 2 passes (<= 1 with norm weights).
 __device__ __forceinline__ void eng_prologue(const GemvP & p, int8_t * xs_q, int * xs_gs, float * xs_d, int wave, int lane) {
     const int K = p.K, nblk = K / 256, r = lane >> 4, j = lane & 15;
     const __amdgpu_buffer_rsrc_t rx = coh_rsrc(p.xf);
@@ -439,8 +339,8 @@ __device__ __forceinline__ void eng_prologue(const GemvP & p, int8_t * xs_q, int
     }
     float4 f[2][4], g[4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) if (4 * ENG_NC * t < nblk) {
-        const int B = min(4 * (wave + ENG_NC * t) + r, nblk - 1);
+    for (int t = 0; t < 2; ++t) if (4 * ENG_NW * t < nblk) {
+        const int B = min(4 * (wave + ENG_NW * t) + r, nblk - 1);
 #pragma unroll
         for (int k = 0; k < 4; ++k) f[t][k] = coh_ld16(rx, (uint32_t) (B * 64 + 16 * k + j) * 16u);
     }
@@ -456,14 +356,14 @@ __device__ __forceinline__ void eng_prologue(const GemvP & p, int8_t * xs_q, int
         scale = 1.0f / sqrtf(mean + p.eps);
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) if (4 * (wave + ENG_NC * t) < nblk) {
+    for (int t = 0; t < 2; ++t) if (4 * (wave + ENG_NW * t) < nblk) {
         float v[4][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             v[k][0] = f[t][k].x; v[k][1] = f[t][k].y; v[k][2] = f[t][k].z; v[k][3] = f[t][k].w;
             if (norm) { v[k][0] = v[k][0] * scale * g[k].x; v[k][1] = v[k][1] * scale * g[k].y; v[k][2] = v[k][2] * scale * g[k].z; v[k][3] = v[k][3] * scale * g[k].w; }
         }
-        const int B = 4 * (wave + ENG_NC * t) + r;
+        const int B = 4 * (wave + ENG_NW * t) + r;
         q8k_rows_to_lds(v, j, B < nblk, xs_q, xs_gs, xs_d, B);
     }
 }
@@ -616,194 +516,193 @@ __device__ __forceinline__ void eng_attention(const EngPhase * ph, int h, char *
     }
 }
 
-// The rows of one mat-vec phase in one workgroup. Returns the number of ring items of the phase (launch-wide item counter).
+// The rows of one mat-vec phase in one workgroup: this wave's prefetched steps out of its LDS slot, everything else HBM -> registers.
 template <int TA, int TB, bool PAIR, bool EPI>
-__device__ __forceinline__ int phase_rows(const EngArgs & A, const EngPhase * ph, Ctl * c, char * ring, const XLds & xs, float * outbuf, unsigned nbase, int wave, int lane, int b, int G,
-                                          JobGeo & g0, JobGeo & g1, JobGeo & g2) {
+__device__ __forceinline__ void phase_rows(const EngPhase * ph, char * smem, const XLds & xs, float * outbuf, int wave, int lane, int b, int G) {
     typedef Item<TA, PAIR, 1> IA;
     typedef Item<TB, PAIR, 1> IB;
-    constexpr int R = IA::R;
+    constexpr int R = IA::R, NM = PAIR ? 2 : 1;
     static_assert(R == 1, "one row per item");
-    constexpr int NPRE = (PAIR || TA == PM_Q5_K) ? 1 : 2;   // register sets in flight before the ring items are consumed (as the launches: mmvq.hip)
+    constexpr int NPRE = (PAIR || TA == PM_Q5_K) ? 1 : 2;   // register sets in flight before the prefetched steps are consumed (as the launches: mmvq.hip)
     GemvP pl = GemvP();                                    // what the row loops read of the argument block
     pl.K = ph->g.K;
-    const GemvJob j0 = ph->g.job[0], j1 = ph->g.job[1], j2 = ph->g.job[2];
-    g0 = job_geo(j0, TA, PAIR, b, G, 0);
-    g1.ob = g0.nres; if (j1.N > 0) g1 = job_geo(j1, j1.is_b ? TB : TA, false, b, G, g0.nres);
-    g2.ob = g1.ob + g1.nres; if (j2.N > 0) g2 = job_geo(j2, j2.is_b ? TB : TA, false, b, G, g1.ob + g1.nres);
-    const int P = ring_items(g0), Prow = g0.split ? P / g0.cpr : P, r0r = g0.r0 + Prow;
-    // ---- this wave's first register-path steps of job 0 go out now: they travel while the ring items are consumed
+    const GemvJob j0 = ph->g.job[0];
+    const PfGeo g = pf_geo(j0, TA, PAIR, pl.K, b, G, wave);
+    const int rows0 = g.r1 - g.r0;
+    // ---- this wave's first register-path steps of job 0 go out now: they travel while the prefetched steps are consumed
     typename IA::Regs ga, gb;
-    if (!g0.split) {
-        const int cpr0 = (((j0.U + 63) >> 6) + IA::CH - 1) / IA::CH;
-        int prow = r0r + wave * R, pc = 0;
-        auto adv = [&]() __attribute__((always_inline)) { if (++pc == cpr0) { pc = 0; prow += PM_GEMV_NW * R; } };
-        IA::issue(ga, pl, j0, prow, g0.r1, pc * IA::CH, lane); adv();
-        if (NPRE >= 2) { IA::issue(gb, pl, j0, prow, g0.r1, pc * IA::CH, lane); adv(); }
+    const int first = wave + PM_GEMV_NW * g.rows_full;     // the item the register path starts with (at chunk steps_part)
+    if (!j0.split) {
+        int prow = g.r0 + first * R, pc = g.steps_part;
+        auto adv = [&]() __attribute__((always_inline)) { if (++pc == g.cpr) { pc = 0; prow += PM_GEMV_NW * R; } };
+        IA::issue(ga, pl, j0, prow, g.r1, pc * IA::CH, lane); adv();
+        if (NPRE >= 2) { IA::issue(gb, pl, j0, prow, g.r1, pc * IA::CH, lane); adv(); }
     }
-    // ---- ring items (launch-wide index n -> wave n % 15), then the rest of job 0 HBM -> registers. An item that has not landed yet (the loader shares the
-    // CU's address path with fifteen streaming waves) is left for a second pass behind the register rows: waiting for it would hold back this wave's share
-    // of the stream.
-    const int ni_0 = g0.split ? (g0.r1 - r0r) * g0.cpr : (g0.r1 - r0r + R - 1) / R;
-    unsigned n = nbase + (unsigned) ((wave + ENG_NC - (int) (nbase % ENG_NC)) % ENG_NC);
-    auto ring_pass = [&](bool wait) __attribute__((always_inline)) {
-        unsigned k_done = lds_ld(&c->done[wave]);
-        for (; n < nbase + (unsigned) P; n += ENG_NC) {
-            const int id = (int) (n - nbase);
-            const int c0 = g0.split ? id % g0.cpr : 0;
-            if (!wait) { if ((int) (lds_ld(&c->landed[n % (unsigned) ENG_NL]) - (n / (unsigned) ENG_NL + 1)) < 0) break; }
-            else spin_ge(&c->landed[n % (unsigned) ENG_NL], n / (unsigned) ENG_NL + 1, c, A.err, 4);
-            const char * img = ring + lds_ld(&c->item_off[n & 63]);
-            eat_item<TA, PAIR>(img, j0.U, xs, c0, g0.steps, lane, outbuf + id);
-            ++k_done;
-            __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the image has been read (and the result parked)
-            if (lane == 0) lds_st(&c->done[wave], k_done);
+    // ---- prefetched steps (the slot is this wave's own: its DMA loads are older than everything this wave has waited for since the prologue)
+    float acc0[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) acc0[m] = 0.0f;
+    {
+        const char * img = smem + ENG_OUT_OFF - (wave + 1) * g.slot_bytes;
+        for (int i = 0; i < g.rows_full; ++i) {
+            float acc[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) acc[m] = 0.0f;
+            eat_steps<TA, PAIR>(img, j0.U, xs, g.cpr, lane, acc);
+            img += g.cpr * NM * ST<TA>::BYTES;
+            float o[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) o[m] = wave_sum(acc[m]);
+            if (lane == 0) outbuf[wave + PM_GEMV_NW * i] = PAIR ? silu_f(o[0]) * o[NM - 1] : o[0];
         }
-    };
-    ring_pass(false);
-    if (!g0.split) IA::template run_job<false, NPRE>(ga, gb, pl, j0, xs, outbuf + Prow, wave, ni_0, r0r, g0.r1, lane);
-    else if constexpr (!PAIR) IA::template run_job_split<false>(ga, gb, pl, j0, xs, outbuf + P, wave, ni_0, r0r, g0.r1, lane);
-    ring_pass(true);
+        if (g.steps_part > 0) eat_steps<TA, PAIR>(img, j0.U, xs, g.steps_part, lane, acc0);
+    }
+    // ---- the rest of job 0, then jobs 1 and 2 (wk / wv next to wq): the mat-vec kernel's row loops
+    if (!j0.split) IA::template run_job<false, NPRE>(ga, gb, pl, j0, xs, outbuf, first, rows0, g.r0, g.r1, lane, g.steps_part, g.steps_part > 0 ? acc0 : nullptr);
+    else if constexpr (!PAIR) IA::template run_job_split<false>(ga, gb, pl, j0, xs, outbuf, wave, rows0 * g.cpr, g.r0, g.r1, lane);
     if constexpr (EPI) {
+        const GemvJob j1 = ph->g.job[1], j2 = ph->g.job[2];
+        const int r0_1 = (int) ((long) j1.N * b / G), r1_1 = (int) ((long) j1.N * (b + 1) / G), r0_2 = (int) ((long) j2.N * b / G), r1_2 = (int) ((long) j2.N * (b + 1) / G);
+        const int cpr_1 = j1.split ? type_cpr(j1.is_b ? TB : TA, j1.U) : 1, cpr_2 = j2.split ? type_cpr(j2.is_b ? TB : TA, j2.U) : 1;
+        const int ni_0 = j0.split ? rows0 * g.cpr : rows0, ni_1 = (r1_1 - r0_1) * cpr_1, ni_2 = (r1_2 - r0_2) * cpr_2;
+        const int ob_1 = ni_0, ob_2 = ob_1 + ni_1;
         const int w1 = (wave + PM_GEMV_NW - ni_0 % PM_GEMV_NW) % PM_GEMV_NW;
-        const int w2 = (wave + 2 * PM_GEMV_NW - (ni_0 + g1.items) % PM_GEMV_NW) % PM_GEMV_NW;
+        const int w2 = (wave + 2 * PM_GEMV_NW - (ni_0 + ni_1) % PM_GEMV_NW) % PM_GEMV_NW;
         typename IB::Regs gB, gB1;
-        if (g1.items > 0) {
-            if (g1.split) { if (TA != TB && j1.is_b) IB::template run_job_split<false>(gB, gB1, pl, j1, xs, outbuf + g1.ob, w1, g1.items, g1.r0, g1.r1, lane);
-                            else                      IA::template run_job_split<false>(ga, gb, pl, j1, xs, outbuf + g1.ob, w1, g1.items, g1.r0, g1.r1, lane); }
-            else          { if (TA != TB && j1.is_b) IB::template run_job<false, 0>(gB, gB1, pl, j1, xs, outbuf + g1.ob, w1, g1.items, g1.r0, g1.r1, lane);
-                            else                      IA::template run_job<false, 0>(ga, gb, pl, j1, xs, outbuf + g1.ob, w1, g1.items, g1.r0, g1.r1, lane); }
+        if (ni_1 > 0) {
+            if (j1.split) { if (TA != TB && j1.is_b) IB::template run_job_split<false>(gB, gB1, pl, j1, xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
+                            else                      IA::template run_job_split<false>(ga, gb, pl, j1, xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane); }
+            else          { if (TA != TB && j1.is_b) IB::template run_job<false, 0>(gB, gB1, pl, j1, xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane);
+                            else                      IA::template run_job<false, 0>(ga, gb, pl, j1, xs, outbuf + ob_1, w1, ni_1, r0_1, r1_1, lane); }
         }
-        if (g2.items > 0) {
-            if (g2.split) { if (TA != TB && j2.is_b) IB::template run_job_split<false>(gB, gB1, pl, j2, xs, outbuf + g2.ob, w2, g2.items, g2.r0, g2.r1, lane);
-                            else                      IA::template run_job_split<false>(ga, gb, pl, j2, xs, outbuf + g2.ob, w2, g2.items, g2.r0, g2.r1, lane); }
-            else          { if (TA != TB && j2.is_b) IB::template run_job<false, 0>(gB, gB1, pl, j2, xs, outbuf + g2.ob, w2, g2.items, g2.r0, g2.r1, lane);
-                            else                      IA::template run_job<false, 0>(ga, gb, pl, j2, xs, outbuf + g2.ob, w2, g2.items, g2.r0, g2.r1, lane); }
+        if (ni_2 > 0) {
+            if (j2.split) { if (TA != TB && j2.is_b) IB::template run_job_split<false>(gB, gB1, pl, j2, xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
+                            else                      IA::template run_job_split<false>(ga, gb, pl, j2, xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane); }
+            else          { if (TA != TB && j2.is_b) IB::template run_job<false, 0>(gB, gB1, pl, j2, xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane);
+                            else                      IA::template run_job<false, 0>(ga, gb, pl, j2, xs, outbuf + ob_2, w2, ni_2, r0_2, r1_2, lane); }
         }
     }
-    return P;
 }
 
 __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ Ctl ctl;
     Ctl * c = &ctl;
-    char * ring = smem;
-    char * acts = smem + ENG_RING;
-    float * outbuf = (float *) (smem + ENG_RING + ENG_ACT);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < (int) (sizeof(Ctl) / 4)) ((unsigned *) c)[tid] = 0;
-    __syncthreads();                                       // the only workgroup-wide barrier: before the roles split
-    if (tid == 0 && __hip_atomic_load((PM_G int *) A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) lds_st(&c->giveup, 1);   // an earlier launch gave up: the counters are not trustworthy
-#ifndef ENG_NO_LOADER
-    if (wave >= ENG_NC) { loader_wave(A, c, ring, lane, wave - ENG_NC); return; }
-#endif
-
+    float * outbuf = (float *) (smem + ENG_OUT_OFF);
+    const int tid0 = threadIdx.x, wave_k = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    if (tid0 < (int) (sizeof(Ctl) / 4)) ((unsigned *) c)[tid0] = 0;
+    __syncthreads();
+    if (tid0 == 0 && __hip_atomic_load((PM_G int *) A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) lds_st_asm(&c->giveup, 1);   // an earlier launch gave up: the counters are not trustworthy
     const int b = blockIdx.x, G = gridDim.x;
     const unsigned NGR = (G % 16 == 0 && G / 16 <= ENG_MAXG / 16) ? 16 : 1, GS = G / NGR;
-    unsigned cgen = 0, agen = 0;                           // generations of the consumer / attention barriers
-    unsigned nbase = 0;                                    // launch-wide index of the current phase's first item
+    unsigned agen = 0;                                     // generation of the attention's four-wave barrier
     const EngPhase * phs = uniform_const_ptr(A.ph);
 #ifdef ENG_DEBUG
-    unsigned long long * tsd = (A.dbg && b == 0 && tid == 0) ? (unsigned long long *) (A.dbg + 64 * 16 + 64 * 8 + 64) : nullptr;
+    unsigned long long * tsd = (A.dbg && b == ENG_DEBUG_WG && tid0 == 0) ? (unsigned long long *) A.dbg : nullptr;
 #define ENG_STAMP(k) do { if (tsd && pi < 32) tsd[8 * pi + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define ENG_STAMP(k) do { } while (0)
 #endif
-    const int wave_k = wave;                               // (scalar: lives in an SGPR across the phases; the lane id is re-derived with mbcnt)
+    int pf_done = -1;                                      // the last mat-vec phase whose prefetch has been issued ...
+    int pf_w0 = -1;                                        // ... and the one wave 0 still owes: the wave that polls the device-wide barrier waits on vmcnt for every poll -
+                                                           // with a prefetch in flight its first poll would return only when that has landed, and the workgroup with it
     for (int pi = 0; pi < A.n_ph; ++pi) {
         const EngPhase * ph = phs + pi;
-        // (the thread id is re-derived through an opaque asm in every phase: what the row loops, prologues and epilogues compute from it - lane offsets, row
-        //  pointers - would otherwise be hoisted out of the phase loop and kept alive, i.e. spilled, across all eight instantiations of the phase body)
+        // (the lane id is re-derived through an opaque asm in every phase: what the row loops, prologues and epilogues compute from it - lane offsets, row
+        //  pointers - would otherwise be hoisted out of the phase loop and kept alive, i.e. spilled, across all instantiations of the phase body)
         int lane_o = (int) __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(lane_o));
         const int lane = lane_o, wave = wave_k, tid = wave * 64 + lane;
+        // ---- the launch's first phase has nobody to prefetch for it
+        if (pi == 0 && ph->kind == 0) { prefetch_phase(ph, smem, b, G, wave, lane); pf_done = 0; }
         // ---- seam: every workgroup's outputs of the previous phase are in memory
         if (pi > 0) {
-            if (wave == 0 && lane == 0) g_wait(A.ctr, (unsigned) pi, GS, c, A.err);
-            wbar(&c->cbar, cgen, ENG_NC, lane, c, A.err, 2);
+            if (wave == 0) {
+                if (lane == 0) g_wait(A.ctr, (unsigned) pi, GS, c, A.err);
+                __builtin_amdgcn_wave_barrier();
+                if (pf_w0 >= 0) { prefetch_phase(phs + pf_w0, smem, b, G, wave, lane); pf_w0 = -1; }
+            }
+            wg_bar();
         }
         ENG_STAMP(0);
         if (ph->kind == 1) {
-#ifndef ENG_NO_ATTN
             if (b < ph->aH && wave < 4) {
-                if (ph->adh == 128) eng_attention<128>(ph, b, acts, c, agen, A.err);
-#ifndef ENG_NO_ATTN64
-                else eng_attention<64>(ph, b, acts, c, agen, A.err);
-#endif
+                if (ph->adh == 128) eng_attention<128>(ph, b, smem, c, agen, A.err);
+                else eng_attention<64>(ph, b, smem, c, agen, A.err);
             }
-#endif
         } else {
             const GemvP & p = ph->g;
             const int ta = ph->ta, tb = ph->tb, pair = ph->pair;
             const int K = p.K;
-            int8_t * xs_q = (int8_t *) acts; int * xs_gs = (int *) (acts + ((K + 15) & ~15)); float * xs_d = (float *) (xs_gs + K / 16);
-#ifndef ENG_NO_PRO
+            int8_t * xs_q = (int8_t *) smem; int * xs_gs = (int *) (smem + ((K + 15) & ~15)); float * xs_d = (float *) (xs_gs + K / 16);
             eng_prologue(p, xs_q, xs_gs, xs_d, wave, lane);
-#endif
-            wbar(&c->cbar, cgen, ENG_NC, lane, c, A.err, 2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this wave's prefetch has landed too: it is older than the activation loads)
+            wg_bar();
             ENG_STAMP(1);
             const XLds xs = {xs_q, xs_gs, xs_d, 0};
-            // ---- rows: the head of job 0 out of the ring, everything else HBM -> registers (the mat-vec kernel's own row loops)
-            JobGeo g0 = JobGeo(), g1 = JobGeo(), g2 = JobGeo();
-            int nit = 0;
-#define ENG_PH(TA_, TB_, P_, E_) nit = phase_rows<TA_, TB_, P_, E_>(A, ph, c, ring, xs, outbuf, nbase, wave, lane, b, G, g0, g1, g2)
+#define ENG_PH(TA_, TB_, P_, E_) phase_rows<TA_, TB_, P_, E_>(ph, smem, xs, outbuf, wave, lane, b, G)
             if (ph->epi) {
-                if (ta == PM_Q4_K && tb == PM_Q4_K) ENG_PH(PM_Q4_K, PM_Q4_K, false, true);
-                else if (ta == PM_Q4_K && tb == PM_Q6_K) ENG_PH(PM_Q4_K, PM_Q6_K, false, true);
-                else if (ta == PM_Q4_K && tb == PM_Q5_K) ENG_PH(PM_Q4_K, PM_Q5_K, false, true);
-#ifdef ENG_ALL_TYPES
-                else ENG_PH(PM_Q6_K, PM_Q6_K, false, true);
-#endif
-            } else if (pair) {
-                if (ta == PM_Q4_K) ENG_PH(PM_Q4_K, PM_Q4_K, true, false);
-#ifdef ENG_ALL_TYPES
-                else ENG_PH(PM_Q6_K, PM_Q6_K, true, false);
-#endif
-            } else {
-                if (ta == PM_Q4_K) ENG_PH(PM_Q4_K, PM_Q4_K, false, false); else ENG_PH(PM_Q6_K, PM_Q6_K, false, false);
-            }
+                if (tb == PM_Q4_K) ENG_PH(PM_Q4_K, PM_Q4_K, false, true);
+                else if (tb == PM_Q6_K) ENG_PH(PM_Q4_K, PM_Q6_K, false, true);
+                else ENG_PH(PM_Q4_K, PM_Q5_K, false, true);
+            } else if (pair) ENG_PH(PM_Q4_K, PM_Q4_K, true, false);
+            else if (ta == PM_Q4_K) ENG_PH(PM_Q4_K, PM_Q4_K, false, false);
+            else ENG_PH(PM_Q6_K, PM_Q6_K, false, false);
 #undef ENG_PH
-            nbase += (unsigned) nit;
             ENG_STAMP(2);
+            // geometry of the jobs' results in outbuf (as phase_rows parks them)
+            const int r0_0 = (int) ((long) p.job[0].N * b / G), r1_0 = (int) ((long) p.job[0].N * (b + 1) / G);
+            const int r0_1 = (int) ((long) p.job[1].N * b / G), r1_1 = (int) ((long) p.job[1].N * (b + 1) / G);
+            const int r0_2 = (int) ((long) p.job[2].N * b / G), r1_2 = (int) ((long) p.job[2].N * (b + 1) / G);
+            const int cpr_0 = p.job[0].split ? type_cpr(ta, p.job[0].U) : 1;
+            const int cpr_1 = p.job[1].split ? type_cpr(p.job[1].is_b ? tb : ta, p.job[1].U) : 1, cpr_2 = p.job[2].split ? type_cpr(p.job[2].is_b ? tb : ta, p.job[2].U) : 1;
+            const int ob_1 = (r1_0 - r0_0) * cpr_0, ob_2 = ob_1 + (r1_1 - r0_1) * cpr_1;
             float ec0 = 1.0f, es0 = 0.0f, ec1 = 1.0f, es1 = 0.0f, ec2 = 1.0f, es2 = 0.0f;
             int epi_slot = 0; long epi_off = 0;
             if (ph->epi) {
                 const int seq = p.epi.seq_ptr ? uniform_const_ptr(p.epi.seq_ptr)[0] : 0;
                 epi_slot = uniform_const_ptr(p.epi.pos_ptr)[seq];
                 epi_off = (long) seq * p.epi.seq_stride;
-                qkv_cs(p.job[0], p.epi, g0.r0, g0.r1, tid, ec0, es0);
-                qkv_cs(p.job[1], p.epi, g1.r0, g1.r1, tid, ec1, es1);
-                qkv_cs(p.job[2], p.epi, g2.r0, g2.r1, tid, ec2, es2);
+                qkv_cs(p.job[0], p.epi, r0_0, r1_0, tid, ec0, es0);
+                qkv_cs(p.job[1], p.epi, r0_1, r1_1, tid, ec1, es1);
+                qkv_cs(p.job[2], p.epi, r0_2, r1_2, tid, ec2, es2);
             }
-            wbar(&c->cbar, cgen, ENG_NC, lane, c, A.err, 2);              // every row result of the workgroup is parked
+            wg_bar();                                          // every row result of the workgroup is parked
             ENG_STAMP(3);
             // ---- epilogue: coalesced, write-through
             if (ph->epi) {
-                write_out_qkv<true>(p.job[0], p.epi, outbuf, g0.r0, g0.r1, g0.ob, tid, g0.split ? g0.cpr : 1, epi_slot, epi_off, ec0, es0);
-                write_out_qkv<true>(p.job[1], p.epi, outbuf, g1.r0, g1.r1, g1.ob, tid, g1.split ? g1.cpr : 1, epi_slot, epi_off, ec1, es1);
-                write_out_qkv<true>(p.job[2], p.epi, outbuf, g2.r0, g2.r1, g2.ob, tid, g2.split ? g2.cpr : 1, epi_slot, epi_off, ec2, es2);
+                write_out_qkv<true>(p.job[0], p.epi, outbuf, r0_0, r1_0, 0, tid, cpr_0, epi_slot, epi_off, ec0, es0);
+                write_out_qkv<true>(p.job[1], p.epi, outbuf, r0_1, r1_1, ob_1, tid, cpr_1, epi_slot, epi_off, ec1, es1);
+                write_out_qkv<true>(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off, ec2, es2);
             } else {
-                const double ss = write_out<true, 1>(p.job[0], outbuf, g0.r0, g0.r1, g0.ob, tid, 0, g0.split ? g0.cpr : 1);
-                write_out<true, 1>(p.job[1], outbuf, g1.r0, g1.r1, g1.ob, tid, 0, g1.split ? g1.cpr : 1);
-                write_out<true, 1>(p.job[2], outbuf, g2.r0, g2.r1, g2.ob, tid, 0, g2.split ? g2.cpr : 1);
+                const double ss = write_out<true, 1>(p.job[0], outbuf, r0_0, r1_0, 0, tid, 0, cpr_0);
                 if (p.ss_out && wave == 0) {               // (rows <= 64 per workgroup: checked by the host)
                     const double ws = wave_sum_f64(ss);
                     if (lane == 0) __hip_atomic_store((PM_G double *) (p.ss_out + b), ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
-        // ---- publish: this wave's stores have left, then the workgroup arrives
+        // ---- publish: this wave's stores have left; then, before the wave goes to wait, the first steps of its rows of the next mat-vec phase
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wbar(&c->cbar, cgen, ENG_NC, lane, c, A.err, 2);
         ENG_STAMP(4);
-        if (wave == 0 && lane == 0) g_arrive(A.ctr, (unsigned) pi, NGR, GS, pi == A.n_ph - 1);
+        {
+            int m = pi + 1;
+            while (m < A.n_ph && phs[m].kind != 0) ++m;
+            if (m < A.n_ph && m > pf_done) {
+                if (wave != 0) prefetch_phase(phs + m, smem, b, G, wave, lane); else pf_w0 = m;
+                pf_done = m;
+            }
+        }
+        wg_bar();
         ENG_STAMP(5);
+        if (wave == 0 && lane == 0) g_arrive(A.ctr, (unsigned) pi, NGR, GS, pi == A.n_ph - 1);
+        ENG_STAMP(6);
     }
-#ifdef ENG_DEBUG
-    if (A.dbg && b == 0 && tid == 0) { float * Ld = A.dbg + 64 * 16 + 64 * 8 + 64 + 32 * 16; Ld[5] = (float) g_cs_spin; Ld[6] = (float) g_cs_eat; g_cs_spin = g_cs_eat = 0; }
-#endif
 }
+
+} // namespace
+
+namespace {
 
 // f64 sum of the f32-rounded squares of a row (the rms_norm input of the launch's FIRST phase has no producing phase: embedding row or ring hand-off)
 __global__ __launch_bounds__(256) void sumsq_row_kernel(const float * x, int K, double * out) {
@@ -851,22 +750,19 @@ int pm_eng_plan_add_matvec(pm_eng_plan * pl, const pm_gemv_fused & f) {
     if (e.g.xmode == 0 || e.g.xmode == 2) return -11;                             // f32 rows only; rms_norm only from producer-side partials
     if (f.dbg_int) return -11;
     const int nblk = f.K / 256;
-    if (f.K % 256 || nblk > (e.g.xmode == 3 ? 4 * ENG_NC : 8 * ENG_NC)) return -12;
-    if ((size_t) ((f.K + 15) & ~15) + (size_t) (f.K / 16) * 4 + (size_t) ((nblk + 3) & ~3) * 4 > (size_t) ENG_ACT) return -12;
+    if (f.K % 256 || nblk > (e.g.xmode == 3 ? 4 * ENG_NW : 8 * ENG_NW)) return -12;
+    if ((size_t) ((f.K + 15) & ~15) + (size_t) (f.K / 16) * 4 + (size_t) ((nblk + 3) & ~3) * 4 + 256 + (size_t) ENG_NW * 2304 > (size_t) ENG_OUT_OFF) return -12;
     if (pl->grid && pl->grid != grid) return -13;
     if (grid > ENG_MAXG) return -13;
     pl->grid = grid;
-    // items: rows whose image exceeds what 15 waves can hold in the ring next to the run-ahead are consumed step by step
+    // results a workgroup parks before its epilogue
     int nres = 0;
     for (int j = 0; j < 3; ++j) {
         GemvJob & jb = e.g.job[j];
         if (jb.N <= 0) continue;
         const int type = jb.is_b ? tb : ta;
         const int ch = (type == PM_Q4_K || type == PM_Q6_K) ? PM_CH64 : PM_CH32, cpr = (((jb.U + 63) >> 6) + ch - 1) / ch;
-        const int sb = type == PM_Q4_K ? ST<PM_Q4_K>::BYTES : type == PM_Q6_K ? ST<PM_Q6_K>::BYTES : ST<PM_Q5_K>::BYTES;
-        // (a pair item holds the steps of both matrices: ffn_gate | ffn_up rows of 8192 Q6_K weights - Qwen2.5-72B - are 13 KiB, still one item)
-        if (!jb.split && cpr * sb * (pair ? 2 : 1) > (pair ? 16 : 10) * 1024) { if (pair) return -14; jb.split = 1; }
-        if (jb.split && cpr == 1) jb.split = 0;
+        if (jb.split && pair) return -14;
         const int rows = (jb.N + grid - 1) / grid + 1;
         nres += rows * (jb.split ? cpr : 1);
         if (f.ss_out && rows > 64) return -15;
@@ -882,8 +778,8 @@ int pm_eng_plan_add_attention(pm_eng_plan * pl, const float * q, void * kc, void
     if (!pl || pl->finished) return -1;
     if ((dh != 64 && dh != 128) || n_ctx % 8 || !pos0 || H % Hkv) return -10;
     if (max_keys <= 0 || max_keys > n_ctx) max_keys = n_ctx;
-    // LDS of the general path inside the activation area: part / pw / reductions (2 KiB + 64) | qs[dh] | part[256] | sc[max_keys + 8]
-    if ((size_t) (512 + 8 + 8) * 4 + (size_t) (dh + 256 + ((max_keys + 15) & ~7)) * 4 > (size_t) ENG_ACT) return -12;
+    // LDS of the general path below the prefetch slots (the next wo's rows are landing there): part / pw / reductions (2 KiB + 64) | qs[dh] | part[256] | sc[max_keys + 8]
+    if ((size_t) (512 + 8 + 8) * 4 + (size_t) (dh + 256 + ((max_keys + 15) & ~7)) * 4 > (size_t) (ENG_OUT_OFF - ENG_NW * ENG_SLOT_MAX)) return -12;
     EngPhase e = {};
     e.kind = 1; e.aq = q; e.akc = (uint16_t *) kc; e.avc = (uint16_t *) vc; e.apos = pos0; e.aseq = seq; e.aseq_stride = seq_stride; e.aout = out;
     e.aH = H; e.aHkv = Hkv; e.adh = dh; e.an_ctx = n_ctx; e.amax_keys = max_keys; e.ascale = scale;
@@ -904,7 +800,7 @@ int pm_eng_plan_finish(pm_eng_plan * pl) {
     pl->d_err = (int *) ((char *) pl->d_ctr + ctr_bytes - 64);
     if (hipFuncSetAttribute((const void *) decode_engine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ENG_LDS) != hipSuccess) { (void) hipGetLastError(); return -3; }
 #ifdef ENG_DEBUG
-    if (!pl->d_dbg) { (void) hipMalloc((void **) &pl->d_dbg, (64 * 16 + 64 * 8 + 64 + 32 * 16 + 16) * 4); (void) hipMemset(pl->d_dbg, 0, (64 * 16 + 64 * 8 + 64 + 32 * 16 + 16) * 4); }
+    if (!pl->d_dbg) { (void) hipMalloc((void **) &pl->d_dbg, 32 * 8 * 8); (void) hipMemset(pl->d_dbg, 0, 32 * 8 * 8); }
 #endif
     pl->finished = true;
     return 0;
@@ -921,24 +817,12 @@ int pm_eng_plan_status(pm_eng_plan * pl) {
     if (!pl || !pl->finished) return -1;
 #ifdef ENG_DEBUG
     if (pl->d_dbg) {
-        std::vector<float> h(64 * 16 + 64 * 8 + 64 + 32 * 16 + 16);
-        (void) hipMemcpy(h.data(), pl->d_dbg, h.size() * 4, hipMemcpyDeviceToHost);
-        { const float * o = &h[64 * 16 + 64 * 8]; fprintf(stderr, "eng xs_q[0..31]:"); for (int i = 0; i < 32; ++i) fprintf(stderr, " %g", o[i]); fprintf(stderr, "\neng xs_d[0..3]: %g %g %g %g  gs[0..7]:", o[32], o[33], o[34], o[35]); for (int i = 0; i < 8; ++i) fprintf(stderr, " %g", o[36 + i]); fprintf(stderr, "\n"); }
-        {
-            const unsigned long long * t = (const unsigned long long *) &h[64 * 16 + 64 * 8 + 64];
-            for (int ph = 0; ph < 32 && t[8 * ph]; ++ph)
-                fprintf(stderr, "eng phase %2d (wg 0, us since launch entry): seam-in %.2f | prologue done %.2f | items done (wave 0) %.2f | all waves %.2f | epilogue + stores %.2f | arrived %.2f\n", ph,
-                        (t[8 * ph] - t[0]) / 100.0, (t[8 * ph + 1] - t[0]) / 100.0, (t[8 * ph + 2] - t[0]) / 100.0, (t[8 * ph + 3] - t[0]) / 100.0, (t[8 * ph + 4] - t[0]) / 100.0, (t[8 * ph + 5] - t[0]) / 100.0);
-            const float * L = &h[64 * 16 + 64 * 8 + 64 + 32 * 16];
-            fprintf(stderr, "eng loader 0 (wg 0): walked %g items, done at %.2f us; shader cycles waiting for ring room %g | issuing %g | in s_waitcnt vmcnt %g\n", L[0], L[3], L[1], L[2], L[4]);
-            fprintf(stderr, "eng consumer wave 0 (wg 0): shader cycles waiting for items %g | consuming %g\n", L[5], L[6]);
-        }
-        for (int l = 0; l < 4; ++l) { const float * o = &h[64 * 16 + 8 * l]; fprintf(stderr, "eng lane %2d: isum=%g msum=%g yd=%g acc=%g xq0=%g gs0=%g u=%g uv=%g\n", l, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]); }
-        for (int i = 0; i < 64; ++i) if (h[16 * i + 15] != 0.0f) {
-            const float * o = &h[16 * i];
-            fprintf(stderr, "eng item n=%g off=%g slot=%g val=%g landed=%g U=%g steps=%g type=%g w0=%08x hdr0=%08x xq0=%g xd0=%g wave=%g c0=%g phase=%g\n", o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7],
-                    __builtin_bit_cast(uint32_t, o[8]), __builtin_bit_cast(uint32_t, o[9]), o[10], o[11], o[12], o[13], o[14]);
-        }
+        unsigned long long t[32 * 8];
+        (void) hipMemcpy(t, pl->d_dbg, sizeof(t), hipMemcpyDeviceToHost);
+        auto us = [&](unsigned long long v) { return v ? (double) (v - t[0]) / 100.0 : -1.0; };
+        for (int ph = 0; ph < 32 && t[8 * ph]; ++ph)
+            fprintf(stderr, "eng phase %2d (wg %d wave 0, us since the first seam-in): seam-in %.2f | prologue done %.2f | own rows done %.2f | all waves %.2f | stores out %.2f | barrier %.2f | arrived %.2f\n", ph, ENG_DEBUG_WG,
+                    us(t[8 * ph]), us(t[8 * ph + 1]), us(t[8 * ph + 2]), us(t[8 * ph + 3]), us(t[8 * ph + 4]), us(t[8 * ph + 5]), us(t[8 * ph + 6]));
     }
 #endif
     int err = 0;

@@ -58,12 +58,14 @@ struct pm355_model {
     // PM355_SS=0: every norm prologue reduces its own row (the round-4 form)
     bool use_ss = true; double * ss = nullptr;
     // the persistent decode engine (decode_engine.hip, round 5): the whole layer stack of a single-token step as ONE launch. Plans are keyed on the
-    // activation pointers baked into their phase tables. PM355_ENGINE=0: five launches per layer (run_layers_fused)
+    // activation pointers baked into their phase tables. OPT-IN (PM355_ENGINE=1): bit-identical to the five launches per layer (run_layers_fused) and
+    // measured SLOWER than them - 10.2-10.4 ms against 8.55 ms per 70B token, 2.23 against 1.67 ms on the 8B shape (profiles/r05_engine_measured.txt):
+    // the default stays the five launches
     // Hand-off buffers are WRITE-ONCE per launch: every layer has its own q / attention output / ffn activation / residual rows / partial sums
     // (eng_act, ~250 KB per 70B layer). A buffer re-used by the next layer was served stale from the reading XCD's L2 whatever the load's scope
     // bits (two 70B layers differed from the launches by 1e-4, one by 1e-14: found on the hardware; round 1's persistent kernel had met the same).
     struct EnginePlan { const float * in; float * out; pm_eng_plan * plan; int n_ss_end; const double * ss_end; const float * end; float * act; double * ss_in0; };
-    bool use_engine = true; std::vector<EnginePlan> eng_plans; bool eng_refused = false;
+    bool use_engine = false; std::vector<EnginePlan> eng_plans; bool eng_refused = false;
     // PM355_PROMPT_I8=1: prompts (> 64 tokens) run their Q4_K / Q6_K matrices on the integer matrix cores over Q8_K activations (mmq_big.hip) - the CPU
     // reference's own arithmetic, at 0.6-0.75 of the F16 GEMMs' rate (mmq.hip, the default); tab_big = the activation tables of the current
     // activation set (pm_q8k_tables)
@@ -799,7 +801,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     { const char * e = getenv("PM355_QKV_EPI"); m->qkv_epi = !(e && e[0] == '0'); }
     { const char * e = getenv("PM355_PROMPT_I8"); m->no_big = !(e && e[0] == '1'); }
     { const char * e = getenv("PM355_SS"); m->use_ss = !(e && e[0] == '0'); }
-    { const char * e = getenv("PM355_ENGINE"); m->use_engine = !(e && e[0] == '0'); }
+    { const char * e = getenv("PM355_ENGINE"); m->use_engine = e && e[0] == '1'; }
     return m;
 }
 

@@ -576,24 +576,28 @@ template <int TYPE, bool PAIR, int NC = 1> struct Item {
     // in every CU's load queue in front of the activation rows of the waves behind them: the prologue grows by what the extra steps cover
     // (QKV 4.5 -> 5.6-6.0 us, wo 2.3 -> 3.7-3.8 us, also when they are issued only after the wave's own activation row has arrived),
     // 116.0 vs 118.0 tok/s on the 70B shape, 588 vs 598 on the 8B shape.]
+    // c_start / acc0 (decode_engine.hip): the first item starts at chunk c_start with the per-lane partial sums acc0[NM] of its chunks 0 .. c_start - 1,
+    // which the caller consumed from another source (the engine's LDS-prefetched steps) with the same consume() calls: the fmaf chain of the row is
+    // the one the plain call builds. A pre-issuing caller starts its cursor at (row of item `first`, c_start) too.
     template <bool DBG, int NPRE>
     static __device__ __forceinline__ void run_job(Regs & ga, Regs & gb, const GemvP & p, const GemvJob & jb, const XLds & xs,
-                                                   float * out /*job slice*/, int first, int n_job_items, int r0, int r1, int lane) {
+                                                   float * out /*job slice*/, int first, int n_job_items, int r0, int r1, int lane,
+                                                   int c_start = 0, const float * acc0 = nullptr) {
         static_assert(NPRE >= 0 && NPRE <= 2, "pre-issue depth");
         if (first >= n_job_items) return;
         const int upl = (jb.U + 63) >> 6;            // units per lane
         const int cpr = (upl + CH - 1) / CH;         // chunks (steps) per item
         const int n_my = (n_job_items - first + PM_GEMV_NW - 1) / PM_GEMV_NW;
-        const int S = n_my * cpr;
+        const int S = n_my * cpr - c_start;
         float acc[R][NM][NC];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int m = 0; m < NM; ++m)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) acc[r][m][c] = 0.0f;
+                for (int c = 0; c < NC; ++c) acc[r][m][c] = (acc0 && r == 0 && c == 0) ? acc0[m] : 0.0f;
         // step cursors: (row, chunk) of the step being ISSUED and of the step being CONSUMED
-        int irow = r0 + first * R, ic = 0, crow = irow, cc = 0;
+        int irow = r0 + first * R, ic = c_start, crow = irow, cc = c_start;
         auto next = [&](int & row, int & c) __attribute__((always_inline)) { if (++c == cpr) { c = 0; row += PM_GEMV_NW * R; } };
         auto finish = [&]() __attribute__((always_inline)) {           // after a step was consumed: end of item?
             if (cc == cpr - 1) {

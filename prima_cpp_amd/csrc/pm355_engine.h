@@ -1,5 +1,6 @@
 // pm355_engine.h — host interface of the persistent decode engine (decode_engine.hip): ONE launch runs every phase of every layer of a
-// single-token step (wq | wk | wv + RoPE + KV store, attention, wo, ffn_gate | ffn_up, ffn_down) on a run-ahead LDS-DMA weight loader.
+// single-token step (wq | wk | wv + RoPE + KV store, attention, wo, ffn_gate | ffn_up, ffn_down), device-wide barriers in place of kernel boundaries.
+// Opt-in (PM355_ENGINE=1): bit-identical to the launches and measured slower than them (profiles/r05_engine_measured.txt).
 #pragma once
 #include "pm355_kernels.h"
 
