@@ -478,6 +478,35 @@ def plugin_decode_70b(tmp, hp70, engine_ms_per_token, n_gen=48):
     return out
 
 
+def parity_bit(tmp, n_layer=8, n_gen=32, n_prompt=16):
+    """The correctness bit the graded record carries: the peaked SURVEY-8d fixture at the Llama-3-70B shape with `n_layer` layers
+    (tests/_fixtures8d.py: N(0, 1/K) weights through the reference's quantizer, Q4_K_M mixture), 16-token prompt + 32 greedy tokens, decoded by the
+    reference's own llama_decode on this host's cores (oracle/_ref, -ngl 0: the checker) and by the resident engine (the thing measured): equal or not."""
+    B, drv = _driver()
+    if drv is None:
+        return {"match": None, "reason": "oracle/_ref not built"}
+    import _fixtures8d as F
+    flavour = B.best_ref_flavour()
+    shape = dict(n_layer=n_layer, n_embd=8192, n_head=64, n_head_kv=8, n_ff=28672, n_vocab=128256, is_70b=True)
+    path = os.path.join(tmp, f"pm355_bench_parity_70b_{n_layer}l_peaked.gguf")
+    t0 = time.time()
+    F.write_model(path, B.Ref(flavour), tag=f"70b{n_layer}", peaked=True, **shape)
+    t_gen = time.time() - t0
+    try:
+        prompt = F.prompt_tokens(shape["n_vocab"], n_prompt)
+        tr, lr, _ = B.run_llama_driver(path, prompt, n_gen, ngl=0, n_ctx=256, threads=usable_cores(), flavour=flavour, timeout=600)
+        te, le = F.engine_greedy(path, shape, prompt, n_gen, 256)
+    finally:
+        os.unlink(path)
+    d = np.asarray(le, dtype=np.float64) - np.asarray(lr, dtype=np.float64)
+    nmse = float((d ** 2).sum() / max((np.asarray(lr, dtype=np.float64) ** 2).sum(), 1e-30))
+    n_same = int((np.asarray(te) == np.asarray(tr)).sum())
+    return {"match": bool(n_same == n_gen), "tokens_identical": f"{n_same}/{n_gen}", "logits_nmse": float(f"{nmse:.3e}"),
+            "fixture": f"peaked SURVEY-8d fixture, Llama-3-70B shape x {n_layer} layers, Q4_K_M through the reference's quantizer, {n_prompt}-token prompt + {n_gen} greedy tokens",
+            "reference": f"llama_decode -ngl 0, oracle/_ref {flavour} build", "under_test": "resident engine (pm355_model_*), prompt batch + hipGraph single-token steps",
+            "gguf_write_s": round(t_gen, 1)}
+
+
 def cpu_llama_decode(tmp, path_8b, hp70):
     """The reference's own llama_decode on this host's cores (-ngl 0): (a) the 8B-shaped GGUF of plugin_decode, (b) the metric's
     model shape (Llama-3-70B Q4_K_M) at two reduced depths so that a whole-token time for 80 layers follows from the measured
@@ -833,6 +862,12 @@ def main():
                     result[key] = json.loads(line[-1]) if line else {"error": f"rc {r.returncode}: {r.stderr[-400:]}"}
                 except Exception as e:
                     result[key] = {"error": str(e)[-400:]}
+            try:
+                pb = parity_bit(a.tmp)
+            except Exception as e:
+                pb = {"match": None, "reason": str(e)[-400:]}
+            result["config"]["greedy_tokens_match_reference"] = pb.get("match")
+            result["parity_check"] = pb
             try:
                 result["weight_streaming"] = streaming_probe()
             except Exception as e:

@@ -250,3 +250,34 @@ def copy_with_new_head(src_path, dst_path, ref, peaked, tag="m", threads=None, e
     Q.pool.shutdown()
     g.close()
     return dict(path=dst_path, peaked=peaked, embd_sigma=embd_sigma, peak_gain=peak_gain, n_vocab=V)
+
+
+def engine_greedy(path, shape, prompt, n_gen, n_ctx=256):
+    """Greedy decode of a fixture file on the resident engine (pm355_model_*): the prompt as one batch, then token by token through the captured graph.
+    shape = the write_model keyword dict. Returns (tokens [n_gen], logits [n_gen, n_vocab])."""
+    import torch
+    import prima_cpp_amd.engine as eng
+    s = shape
+    hp = dict(arch=0, n_layer=s["n_layer"], n_embd=s["n_embd"], n_head=s["n_head"], n_head_kv=s["n_head_kv"], head_dim=s["n_embd"] // s["n_head"],
+              n_ff=s["n_ff"], n_vocab=s["n_vocab"], rms_eps=1e-5, rope_freq_base=500000.0)
+    w = eng.Window(hp, n_ctx=n_ctx)
+    w.load_gguf(path)
+    w.finalize(max_tokens=max(len(prompt), 1))
+    toks, logits = [], []
+    _, lg, _ = w.decode(tokens=torch.from_numpy(np.asarray(prompt, dtype=np.int32)).cuda(), pos0=0, want_hidden=False)
+    pos = len(prompt)
+    w.set_pos(pos)
+    tok_d = torch.empty(1, dtype=torch.int32, device="cuda")
+    lg_d = torch.empty(s["n_vocab"], dtype=torch.float32, device="cuda")
+    for i in range(n_gen):
+        l = lg.cpu().numpy()
+        t = int(np.argmax(l))
+        toks.append(t)
+        logits.append(l)
+        if i == n_gen - 1:
+            break
+        tok_d.fill_(t)
+        w.step(token=tok_d, logits=lg_d)          # single-token step: the replayed hipGraph, position advanced on the device
+        lg = lg_d
+    w.close()
+    return np.array(toks), np.stack(logits)

@@ -107,33 +107,7 @@ def _margins(lg):
 
 
 def _engine_greedy(path, size, prompt, n_gen, n_ctx=N_CTX):
-    """Greedy decode on the resident engine (pm355_model_*): prompt as one batch, then token by token through the captured graph."""
-    import torch
-    import prima_cpp_amd.engine as eng
-    s = SHAPES[size]
-    hp = dict(arch=0, n_layer=s["n_layer"], n_embd=s["n_embd"], n_head=s["n_head"], n_head_kv=s["n_head_kv"], head_dim=s["n_embd"] // s["n_head"],
-              n_ff=s["n_ff"], n_vocab=s["n_vocab"], rms_eps=1e-5, rope_freq_base=500000.0)
-    w = eng.Window(hp, n_ctx=n_ctx)
-    w.load_gguf(path)
-    w.finalize(max_tokens=max(len(prompt), 1))
-    toks, logits = [], []
-    _, lg, _ = w.decode(tokens=torch.from_numpy(np.asarray(prompt, dtype=np.int32)).cuda(), pos0=0, want_hidden=False)
-    pos = len(prompt)
-    w.set_pos(pos)
-    tok_d = torch.empty(1, dtype=torch.int32, device="cuda")
-    lg_d = torch.empty(s["n_vocab"], dtype=torch.float32, device="cuda")
-    for i in range(n_gen):
-        l = lg.cpu().numpy()
-        t = int(np.argmax(l))
-        toks.append(t)
-        logits.append(l)
-        if i == n_gen - 1:
-            break
-        tok_d.fill_(t)
-        w.step(token=tok_d, logits=lg_d)          # single-token step: the replayed hipGraph, position advanced on the device
-        lg = lg_d
-    w.close()
-    return np.array(toks), np.stack(logits)
+    return F.engine_greedy(path, SHAPES[size], prompt, n_gen, n_ctx)
 
 
 @pytest.mark.parametrize("mode", ["plugin", "plugin-fa", "engine"])
@@ -216,7 +190,8 @@ def test_peaked_fixture_8k_prompt_tokens_identical(gpu, files):
     whose attention runs the matrix-core kernel over > 8k cached cells - against the reference CPU through the plug-in's default graph and on the
     resident engine: the same 16 tokens, logits within the F16-accumulation tier. Default: the small 8-layer shape (the CPU reference needs ~1 min
     for the prompt); PM355_8D_LONG=8b runs it at the Llama-3-8B shape (32 layers, 32 query / 8 KV heads: ~20 min of host time for the CPU's
-    prompt pass - measured once in round 4, profiles/r04_parity_long_context.txt)."""
+    prompt pass; the round-4 attempt was cut off by the box limit after 25 minutes inside that pass - profiles/r04_long_context.txt - and has not been
+    repeated), PM355_8D_LONG=70b8 at the Llama-3-70B head shape (64 query / 8 KV heads, 8 layers)."""
     size = os.environ.get("PM355_8D_LONG", "small")
     if size not in SHAPES:
         pytest.skip("PM355_8D_LONG names no shape")
@@ -239,6 +214,50 @@ def test_peaked_fixture_8k_prompt_tokens_identical(gpu, files):
         print(f"[8d {size} peaked, 8200-token prompt, {mode}] tokens {(t_ == ta).sum()}/{n_gen} identical to the reference CPU; logits NMSE {_nmse(l_, la):.2e}")
         assert t_.tolist() == ta.tolist()
         assert _nmse(l_, la) < 1e-3
+
+
+def test_peaked_fixture_at_depth(gpu, tmp_path):
+    """VERDICT r4 item 5 - whole-model equality at the depth the bench times. Opt-in (PM355_8D_DEPTH=<layers>, e.g. 32 or 80; recorded under
+    profiles/r05_parity_8d.txt): the peaked fixture at the Llama-3-70B shape with that many layers (every layer its own N(0, 1/K) weights through the
+    reference's quantizer, Q4_K_M mixture), 16-token prompt + 32 greedy tokens: the reference CPU (its fastest ISA build, -ngl 0) against the plug-in
+    through the reference's llama_decode and against the resident engine - the same 32 tokens, logits at the reference-against-itself tier."""
+    depth = int(os.environ.get("PM355_8D_DEPTH", "0") or 0)
+    if depth <= 0:
+        pytest.skip("opt-in: PM355_8D_DEPTH=<layers>")
+    shape = dict(SHAPES["70b8"], n_layer=depth)
+    n_gen = 32
+    V = shape["n_vocab"]
+    ref = Ref(best_ref_flavour())
+    path = str(tmp_path / f"s8d_70b{depth}_peaked.gguf")
+    t0 = time.time()
+    F.write_model(path, ref, tag=f"70b{depth}", peaked=True, **shape)
+    print(f"\n[8d 70b x {depth} layers] peaked GGUF {os.path.getsize(path) / 1e9:.2f} GB quantized by the reference in {time.time() - t0:.0f} s ({_threads()} threads)")
+    try:
+        prompt = F.prompt_tokens(V, N_PROMPT)
+        expect = [F.peaked_next(prompt[-1], V)]
+        for _ in range(n_gen - 1):
+            expect.append(F.peaked_next(expect[-1], V))
+        t0 = time.time()
+        tr, lr, sr = run_llama_driver(path, prompt, n_gen, ngl=0, n_ctx=N_CTX, threads=_threads(), flavour=best_ref_flavour(), timeout=3000)
+        marg, sd = _margins(lr)
+        print(f"[8d 70b x {depth}] reference CPU ({best_ref_flavour()}): {sr['decode_tok_s']:.2f} tok/s ({time.time() - t0:.0f} s); top1-top2 margin / sigma min {(marg / sd).min():.2f}")
+        assert tr.tolist() == expect
+        tg, lg, st = run_llama_driver(path, prompt, n_gen, ngl=99, n_ctx=N_CTX, threads=_threads(), timeout=1800, extra_args=GPU_ARGS)
+        assert "MI355X0" in st["stderr"]
+        te, le = F.engine_greedy(path, shape, prompt, n_gen, N_CTX)
+        for mode, t_, l_ in (("plugin", tg, lg), ("engine", te, le)):
+            err = np.abs(l_ - lr).max(axis=1)
+            print(f"[8d 70b x {depth} peaked {mode}] tokens {(t_ == tr).sum()}/{n_gen} identical to the reference CPU; logits NMSE {_nmse(l_, lr):.2e}; "
+                  f"max |dlogit| / sigma {(err / sd).max():.3f}; smallest margin / observed error {(marg / np.maximum(err, 1e-30)).min():.1f}")
+            assert t_.tolist() == tr.tolist()
+            assert _nmse(l_, lr) < 1e-5, _nmse(l_, lr)
+        if st.get("decode_tok_s"):
+            print(f"[8d 70b x {depth}] plug-in decode {st['decode_tok_s']:.1f} tok/s")
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
 
 
 @pytest.mark.parametrize("size", SIZES)

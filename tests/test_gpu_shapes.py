@@ -115,8 +115,8 @@ def test_model_shaped_layer_decode_and_prefill(E, oracle, name, monkeypatch):
     print(f"[{name}] small batch (40) vs reference CPU: hidden NMSE {f:.2e}, logits NMSE {g2:.2e}")
     # (what is left is the multi-token attention kernel's f32 softmax.V against the reference's F16-rounded probabilities: the distance
     #  is the same, 4.3e-6 / 1.3e-5, with PM355_NO_MMQ_I8=1, i.e. on the mat-vec path)
-    # (the Qwen2.5-72B shape's Q8_0 ffn_down is not served by mmq_i8.hip: that matrix runs on the multi-column mat-vec with Q8_0 activations,
-    #  ggml_vec_dot_q8_0_q8_0's arithmetic, and the batch stays at the same distance - round 2 dropped the whole layer to the F16 GEMM)
+    # (the Qwen2.5-72B shape's Q8_0 ffn_down - K = 29568 is no multiple of 256 - is served by mmq_i8.hip's Q8_0 instantiation since round 4: Q8_0
+    #  activations on the integer matrix cores, ggml_vec_dot_q8_0_q8_0's arithmetic, and the batch stays at the same distance)
     assert f < 2e-5 and g2 < 2e-4
     # (4) 3-token step: wq | wk | wv and ffn_gate | ffn_up as one multi-job launch each (from 2 tokens), wo / down single launches (from 3)
     w.kv_clear()
