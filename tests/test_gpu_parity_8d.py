@@ -242,6 +242,12 @@ def test_peaked_fixture_at_depth(gpu, tmp_path):
         marg, sd = _margins(lr)
         print(f"[8d 70b x {depth}] reference CPU ({best_ref_flavour()}): {sr['decode_tok_s']:.2f} tok/s ({time.time() - t0:.0f} s); top1-top2 margin / sigma min {(marg / sd).min():.2f}")
         assert tr.tolist() == expect
+        # yardstick: the reference against itself - its AVX2 build on the same file (another summation order of the same integer arithmetic)
+        nm_ref = None
+        if have_ref("avx2") and best_ref_flavour() != "avx2":
+            ta, la, _ = run_llama_driver(path, prompt, n_gen, ngl=0, n_ctx=N_CTX, threads=_threads(), flavour="avx2", timeout=3000)
+            nm_ref = _nmse(la, lr)
+            print(f"[8d 70b x {depth}] reference AVX2 vs {best_ref_flavour()}: tokens {(ta == tr).sum()}/{n_gen}, logits NMSE {nm_ref:.2e}")
         tg, lg, st = run_llama_driver(path, prompt, n_gen, ngl=99, n_ctx=N_CTX, threads=_threads(), timeout=1800, extra_args=GPU_ARGS)
         assert "MI355X0" in st["stderr"]
         te, le = F.engine_greedy(path, shape, prompt, n_gen, N_CTX)
@@ -250,7 +256,9 @@ def test_peaked_fixture_at_depth(gpu, tmp_path):
             print(f"[8d 70b x {depth} peaked {mode}] tokens {(t_ == tr).sum()}/{n_gen} identical to the reference CPU; logits NMSE {_nmse(l_, lr):.2e}; "
                   f"max |dlogit| / sigma {(err / sd).max():.3f}; smallest margin / observed error {(marg / np.maximum(err, 1e-30)).min():.1f}")
             assert t_.tolist() == tr.tolist()
-            assert _nmse(l_, lr) < 1e-5, _nmse(l_, lr)
+            # (the 16-token prompt runs the MFMA prefill path - F16 activations x dequantized F16 weights - and its cells stay in the cache of every
+            #  decoded token: north_star's 1e-3 tier for fp16 accumulation, at any depth)
+            assert _nmse(l_, lr) < 1e-3, _nmse(l_, lr)
         if st.get("decode_tok_s"):
             print(f"[8d 70b x {depth}] plug-in decode {st['decode_tok_s']:.1f} tok/s")
     finally:
