@@ -301,6 +301,15 @@ PM355_API int pm355_mul_mat_vec_qkv(const pm355_matvec_job * jobs, int64_t K, co
 /* the same with the rms_norm's sum of squares taken from n_sumsq_in producer-side partials (pm355_mul_mat_vec_fused_ss) */
 PM355_API int pm355_mul_mat_vec_qkv_ss(const pm355_matvec_job * jobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
                                        const pm355_qkv_store * s, const double * sumsq_in, int n_sumsq_in, pm355_stream_t stream);
+/* The same launch with the attention over the cached cells in its TAIL (round 5; replaces the pm355_attn_cached launch that would follow - the
+ * reference's MUL_MAT(k, q) -> SOFT_MAX_EXT -> MUL_MAT(v, kq) nodes, ggml.c:12445-12473 / :13783-13879 - same arithmetic, same bits): the workgroups
+ * that hold the rows of one KV-head group take a ticket after their stores; the last n_head / n_head_kv of them wait for their group only and compute
+ * one query head each over cells [0, d_pos[0]]. ticket: n_head_kv uint32 counters, zeroed once (monotonic across launches of one stream);
+ * watchdog: optional int32, set non-zero if a bounded wait gave up. Needs d_pos (d_cell_nkv == NULL), the transposed V cache, no mask.
+ * PM355_E_UNSUPPORTED when the grid does not split into power-of-two runs per KV head - then launch pm355_attn_cached as before. */
+typedef struct { float * out; uint32_t * ticket; int32_t * watchdog; float kq_scale; int32_t n_head, max_keys; } pm355_qkv_attn;
+PM355_API int pm355_mul_mat_vec_qkv_attn(const pm355_matvec_job * jobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
+                                         const pm355_qkv_store * s, const double * sumsq_in, int n_sumsq_in, const pm355_qkv_attn * attn, pm355_stream_t stream);
 /* The persistent decode engine (round 5, prima_cpp_amd/csrc/decode_engine.hip): a list of PHASES - the launches above, in order - executed as ONE
  * launch: one workgroup per CU, a loader wave that streams every phase's weights into an LDS ring ahead of the consumers, a device-wide barrier
  * and write-through hand-offs between phases. pm355_model_step uses it for the whole layer stack of a single-token step; this entry runs an

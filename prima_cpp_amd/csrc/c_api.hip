@@ -358,6 +358,10 @@ int pm355_mul_mat_vec_qkv(const pm355_matvec_job * jobs, int64_t K, const float 
 }
 int pm355_mul_mat_vec_qkv_ss(const pm355_matvec_job * jobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
                              const pm355_qkv_store * s, const double * sumsq_in, int n_sumsq_in, pm355_stream_t st) {
+    return pm355_mul_mat_vec_qkv_attn(jobs, K, x_f32, norm_w, eps, s, sumsq_in, n_sumsq_in, nullptr, st);
+}
+int pm355_mul_mat_vec_qkv_attn(const pm355_matvec_job * jobs, int64_t K, const float * x_f32, const float * norm_w, float eps,
+                               const pm355_qkv_store * s, const double * sumsq_in, int n_sumsq_in, const pm355_qkv_attn * at, pm355_stream_t st) {
     if (!jobs || !x_f32 || !s || !s->rope_table || !s->k_cache || !s->v_cache || (!s->d_pos && !s->d_cell_nkv)) return fail(PM355_E_SHAPE, "mul_mat_vec_qkv: null pointer");
     pm_gemv_fused f = {};
     f.K = (int) K; f.njobs = 3; f.xf = x_f32; f.norm_w = norm_w; f.eps = eps;
@@ -366,11 +370,16 @@ int pm355_mul_mat_vec_qkv_ss(const pm355_matvec_job * jobs, int64_t K, const flo
         f.job[j].type = jobs[j].type; f.job[j].N = (int) jobs[j].N; f.job[j].W = jobs[j].W; f.job[j].W2 = nullptr;
         f.job[j].y = jobs[j].y; f.job[j].bias = jobs[j].bias; f.job[j].resid = nullptr;
     }
-    const pm_qkv_epi e = {s->rope_table, s->d_pos, nullptr, s->d_cell_nkv, 0, s->k_cache, s->v_cache, s->n_head_kv, s->head_dim, s->n_ctx, s->n_rot,
-                          s->v_rowmajor, s->rope_neox};
+    pm_qkv_epi e = {s->rope_table, s->d_pos, nullptr, s->d_cell_nkv, 0, s->k_cache, s->v_cache, s->n_head_kv, s->head_dim, s->n_ctx, s->n_rot,
+                    s->v_rowmajor, s->rope_neox};
+    if (at) {
+        if (!at->out || !at->ticket) return fail(PM355_E_SHAPE, "mul_mat_vec_qkv_attn: null pointer");
+        e.att_out = at->out; e.att_ticket = at->ticket; e.att_err = at->watchdog; e.kq_scale = at->kq_scale; e.n_head = at->n_head; e.att_max_keys = at->max_keys;
+    }
     f.epi = &e;
     (void) hipGetLastError();
     const int rc = pm_launch_gemv_fused(f, S(st));
+    if (rc == -7) return fail(PM355_E_UNSUPPORTED, "mul_mat_vec_qkv_attn: the workgroups of a KV-head group must be a power-of-two run of the grid (CUs % n_head_kv == 0), head_dim 64 / 128, position-pointer mode, transposed V cache");
     if (rc == -5) return fail(PM355_E_UNSUPPORTED, "mul_mat_vec_qkv: every workgroup's row slices must hold whole rotation pairs (N % (2 * CUs) == 0), N_k == N_v == n_head_kv * head_dim");
     if (rc) return gemv_rc(rc);
     HIP_TRY(hipGetLastError());

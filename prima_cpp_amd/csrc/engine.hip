@@ -57,6 +57,11 @@ struct pm355_model {
     // in ss[0] / ss[1] (256 doubles each); the consuming wq | wk | wv, ffn_gate | ffn_up and lm_head launches add them instead of reducing the row.
     // PM355_SS=0: every norm prologue reduces its own row (the round-4 form)
     bool use_ss = true; double * ss = nullptr;
+    // attention in the tail of the wq | wk | wv launch (round 5, pm_qkv_epi::att_out): the short-context regime's attention launch and its boundary
+    // disappear - four launches per layer. att_tk: 64 per-KV-head ticket counters + the watchdog word. OPT-IN (PM355_ATTN_TAIL=1): the same bits as the
+    // separate launch and 1.6 % SLOWER per 70B token (8.955 against 8.817 ms, interleaved A/B, profiles/r05_attention_tail.txt) - q and the new cell
+    // cross XCDs inside the launch (write-through store, ticket, cache-bypassing loads: ~6 us) where the kernel boundary + attn_cached cost 4.5
+    bool attn_tail = false; unsigned * att_tk = nullptr;
     // the persistent decode engine (decode_engine.hip, round 5): the whole layer stack of a single-token step as ONE launch. Plans are keyed on the
     // activation pointers baked into their phase tables. OPT-IN (PM355_ENGINE=1): bit-identical to the five launches per layer (run_layers_fused) and
     // measured SLOWER than them - 10.2-10.4 ms against 8.55 ms per 70B token, 2.23 against 1.67 ms on the 8B shape (profiles/r05_engine_measured.txt):
@@ -464,6 +469,7 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
     bool epi = m->qkv_epi && m->rope_tab && (m->rope.mode == 0 || m->rope.mode == 2) &&
                (!m->long_ctx || (m->use_flash && m->attn_mfma && H / Hkv <= 8 && pm_attn_flash_cached_ok(H, Hkv, dh, hp.n_ctx) == 0));
     if (epi) pm_launch_rope_table(m->rope, m->d_pos, m->d_ctl, (const float *) m->rope_freqs.d, m->rope_tab, st);
+    bool tail = epi && !m->long_ctx && m->attn_tail && m->att_tk && Hkv <= 64;
     double * ss_wo = (m->use_ss && m->ss) ? m->ss : nullptr, * ss_dn = ss_wo ? m->ss + 256 : nullptr;
     int n_wo = 0, n_dn = 0;                           // partials the previous wo / ffn_down launch left (0: the consumer reduces the row itself)
     for (int il = m->lo; il < m->hi; ++il) {
@@ -477,9 +483,19 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
             const float * bs[3] = {(const float *) L.t[PM355_T_BQ].d, (const float *) L.t[PM355_T_BK].d, (const float *) L.t[PM355_T_BV].d};
             const float * nw = (const float *) L.t[PM355_T_ATTN_NORM].d;
             const long kvs_e = m->n_seq > 1 ? (long) hp.n_ctx * Hkv * dh : 0;
-            const pm_qkv_epi qe = {m->rope_tab, m->d_pos, m->d_ctl, nullptr, kvs_e, L.kc, L.vc, Hkv, dh, hp.n_ctx, m->rope.n_dims, 0, (m->rope.mode & 2) ? 1 : 0};
+            pm_qkv_epi qe = {m->rope_tab, m->d_pos, m->d_ctl, nullptr, kvs_e, L.kc, L.vc, Hkv, dh, hp.n_ctx, m->rope.n_dims, 0, (m->rope.mode & 2) ? 1 : 0};
             bool qkv_done = false;
-            if (epi) {
+            if (tail) {
+                qe.att_out = att; qe.att_ticket = m->att_tk; qe.att_err = (int *) (m->att_tk + 64); qe.kq_scale = kq_scale; qe.n_head = H;
+                qe.att_max_keys = (m->split_scratch && m->split_min + 8 < hp.n_ctx) ? m->split_min + 8 : 0;
+                qkv_done = gemv_f32(m, ws, nullptr, ys, bs, nullptr, 3, cur, nw, st, &qe, nullptr, nullptr, ss_dn, n_dn) == 0;
+                if (!qkv_done) {
+                    if (il != m->lo) return seterr(m, PM355_E_UNSUPPORTED, "decode: attention tail served for some layers only");
+                    tail = false; m->attn_tail = false;    // (grid does not split into power-of-two runs per KV head, head_dim: the separate launch)
+                    qe.att_out = nullptr;
+                }
+            }
+            if (epi && !qkv_done) {
                 qkv_done = gemv_f32(m, ws, nullptr, ys, bs, nullptr, 3, cur, nw, st, &qe, nullptr, nullptr, ss_dn, n_dn) == 0;
                 if (!qkv_done) {
                     if (il != m->lo) return seterr(m, PM355_E_UNSUPPORTED, "decode: QKV epilogue served for some layers only");
@@ -507,6 +523,8 @@ int run_layers_fused(pm355_model * m, const float * cur, float * d_x_out, const 
             if (pm_launch_attn_split(q, k, v, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, (const float *) m->rope_freqs.d, att, m->split_scratch,
                                      H, Hkv, dh, hp.n_ctx, kq_scale, &m->rope, st))
                 return seterr(m, PM355_E_RANGE, "decode: split attention unsupported for this shape");
+        } else if (epi && tail) {
+            // (the attention ran in the tail of the wq | wk | wv launch)
         } else if (epi) {
             if (pm_launch_attn_cached(q, L.kc, L.vc, m->d_pos, m->d_ctl, kvs, att, H, Hkv, dh, hp.n_ctx, kq_scale, st, nullptr, nullptr,
                                       (m->split_scratch && m->split_min + 8 < hp.n_ctx) ? m->split_min + 8 : 0))
@@ -802,6 +820,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     { const char * e = getenv("PM355_PROMPT_I8"); m->no_big = !(e && e[0] == '1'); }
     { const char * e = getenv("PM355_SS"); m->use_ss = !(e && e[0] == '0'); }
     { const char * e = getenv("PM355_ENGINE"); m->use_engine = e && e[0] == '1'; }
+    { const char * e = getenv("PM355_ATTN_TAIL"); m->attn_tail = e && e[0] == '1'; }
     return m;
 }
 
@@ -816,7 +835,7 @@ void pm355_model_free(pm355_model * m) {
     for (auto & L : m->layers) { for (auto & t : L.t) if (t.d) (void) hipFree(t.d); if (L.kc) (void) hipFree(L.kc); if (L.vc) (void) hipFree(L.vc); }
     Tensor * g[4] = {&m->tok_embd, &m->out_norm, &m->output, &m->rope_freqs};
     for (auto t : g) if (t->d) (void) hipFree(t->d);
-    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->h2, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->split_scratch, m->rope_tab, m->tab_big, m->ss};
+    void * s[] = {m->x, m->x1, m->q, m->k, m->v, m->att, m->h, m->h2, m->logits, m->xn, m->aq_k, m->aq_0, m->d_pos, m->d_tok, m->d_ctl, m->split_scratch, m->rope_tab, m->tab_big, m->ss, m->att_tk};
     for (auto p : s) if (p) (void) hipFree(p);
     pm355_uploader_free(m->up);
     if (m->cap_stream) (void) hipStreamDestroy(m->cap_stream);
@@ -912,7 +931,9 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
               A((void **) &m->aq_k, T * pm_q8k_row_bytes((int) ((maxK + 255) / 256 * 256))) &&
               A((void **) &m->aq_0, T * pm_q80_row_bytes((int) ((maxK + 31) / 32 * 32))) &&
               A((void **) &m->d_pos, 64 * 4) && A((void **) &m->d_ctl, 64) && A((void **) &m->d_tok, 64 + T * 4) &&
-              A((void **) &m->rope_tab, (size_t) hp.head_dim * 4) && A((void **) &m->ss, 2 * 256 * sizeof(double));
+              A((void **) &m->rope_tab, (size_t) hp.head_dim * 4) && A((void **) &m->ss, 2 * 256 * sizeof(double)) &&
+              A((void **) &m->att_tk, 65 * 4);
+    if (ok) (void) hipMemset(m->att_tk, 0, 65 * 4);
     if (ok && T > MMQ_MAX_TOKENS && !m->no_big) ok = A((void **) &m->tab_big, pm_mmq_big_table_bytes((int) ((maxK + 255) / 256 * 256), (int) T));
     if (!ok) return seterr(m, PM355_E_NOMEM, "finalize: scratch");
     if (hp.n_head / hp.n_head_kv <= 8 && (hp.head_dim == 64 || hp.head_dim == 128) &&
@@ -1099,6 +1120,14 @@ int pm355_model_step_ex(pm355_model * m, const int32_t * d_token, const float * 
 int pm355_model_check(pm355_model * m) {
     if (!m) return PM355_E_SHAPE;
     if (hipDeviceSynchronize() != hipSuccess) return seterr(m, PM355_E_HIP, "check: device error");
+    if (m->att_tk) {
+        int w = 0;
+        if (hipMemcpy(&w, m->att_tk + 64, 4, hipMemcpyDeviceToHost) == hipSuccess && w) {
+            (void) hipMemset(m->att_tk, 0, 65 * 4);
+            snprintf(m->err, sizeof(m->err), "check: a workgroup of the wq | wk | wv launch gave up waiting for its KV-head group (attention tail, code %d)", w);
+            return PM355_E_HIP;
+        }
+    }
     for (auto & e : m->eng_plans) {
         const int w = pm_eng_plan_status(e.plan);
         if (w) { snprintf(m->err, sizeof(m->err), "check: the decode engine's watchdog fired (code %d: 1 loader, 2 consumer barrier, 3 device-wide barrier, 4 item wait, 6 attention barrier)", w); return PM355_E_HIP; }

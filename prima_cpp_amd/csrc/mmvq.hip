@@ -162,16 +162,29 @@ int pmv::gemv_fill(const pm_gemv_fused & a, int grid_fixed, GemvP & p, int & ta_
             }
         }
     }
+    size_t att_lds = 0;
     if (a.epi) {
         const pm_qkv_epi & e = *a.epi;
         if (grid_fixed > 0 || e.dh % 2 || e.n_rot % 2 || e.n_rot > e.dh || a.job[0].N % e.dh || a.job[1].N != e.Hkv * e.dh || a.job[2].N != e.Hkv * e.dh) return -5;
         // (ggml-graph mode has no position pointer: the scalar loads of the un-taken branch may still be issued - give them a valid address)
-        p.epi = QkvEpi{e.tab, e.pos ? e.pos : e.dyn, e.seq, e.dyn, e.seq_stride, (uint16_t *) e.kc, (uint16_t *) e.vc, e.Hkv * e.dh, e.dh, e.n_ctx, e.n_rot, e.v_rowmajor, e.neox};
+        p.epi = QkvEpi{e.tab, e.pos ? e.pos : e.dyn, e.seq, e.dyn, e.seq_stride, (uint16_t *) e.kc, (uint16_t *) e.vc, e.Hkv * e.dh, e.dh, e.n_ctx, e.n_rot, e.v_rowmajor, e.neox,
+                       nullptr, nullptr, nullptr, nullptr, 0.0f, 0, 0};
+        if (e.att_out) {
+            // attention in the tail: the workgroups of a KV-head group must be a power-of-two run of the grid, at least one per query head of the group
+            const int wgs = e.Hkv > 0 && grid % e.Hkv == 0 ? grid / e.Hkv : 0, nh = e.Hkv > 0 ? e.n_head / e.Hkv : 0;
+            const int mk = e.att_max_keys > 0 && e.att_max_keys < e.n_ctx ? e.att_max_keys : e.n_ctx;
+            if (!e.pos || e.dyn || !e.att_ticket || e.v_rowmajor || wgs < 1 || (wgs & (wgs - 1)) || nh < 1 || nh > wgs || e.n_head != nh * e.Hkv || a.job[0].N != e.n_head * e.dh ||
+                (e.dh != 64 && e.dh != 128) || e.n_ctx % 8 || e.n_ctx < 64) return -7;
+            att_lds = 64 + attn_tail_lds(e.dh, mk);
+            p.epi.att_out = e.att_out; p.epi.att_q = a.job[0].y; p.epi.att_ticket = e.att_ticket; p.epi.att_err = e.att_err; p.epi.att_scale = e.kq_scale;
+            p.epi.att_H = e.n_head; p.epi.att_wgs = wgs;
+        }
     }
     if (p.job[0].is_b)                                // the kernel pre-issues job 0 with the TA code path: put a TA job first
         for (int j = 1; j < 3; ++j) if (p.job[j].N > 0 && !p.job[j].is_b) { const GemvJob t = p.job[0]; p.job[0] = p.job[j]; p.job[j] = t; break; }
     const int ablk = ta == PM_Q8_0 ? 32 : 256;
-    const size_t lds = (size_t) ((a.K + 15) & ~15) + (size_t) (a.K / 16) * 4 + (size_t) ((a.K / ablk + 3) & ~3) * 4 + (size_t) rows_cap * 4;
+    size_t lds = (size_t) ((a.K + 15) & ~15) + (size_t) (a.K / 16) * 4 + (size_t) ((a.K / ablk + 3) & ~3) * 4 + (size_t) rows_cap * 4;
+    if (att_lds > lds) lds = att_lds;
     if (lds > 150 * 1024) return -4;
     ta_out = ta; tb_out = tb; pair_out = pair; lds_out = lds; grid_out = grid;
     return 0;

@@ -3,6 +3,7 @@
 #pragma once
 #include "pm355_device.h"
 #include "pm355_kernels.h"
+#include "attn_tail_device.h"
 #include <limits.h>
 
 #define PM_MAX_ROWS_PER_WG 512
@@ -35,6 +36,8 @@ struct QkvEpi {
     const float * tab; const int32_t * pos_ptr, * seq_ptr, * dyn; long seq_stride;
     uint16_t * kc, * vc; int kv_dim /*Hkv * dh*/, dh, n_ctx, n_rot, v_rowmajor;
     int neox;    // rotation pairs (i, i + n_rot / 2) instead of (2 i, 2 i + 1): the q / k jobs carry the row mapping (GemvJob::nx_s)
+    // attention in the tail (pm_qkv_epi::att_out): q = the rotated query rows this launch stores, wgs = workgroups per KV-head group (power of two)
+    float * att_out; const float * att_q; unsigned * att_ticket; int * att_err; float att_scale; int att_H, att_wgs;
 };
 struct GemvP {
     GemvJob job[3];
@@ -765,6 +768,51 @@ __device__ __forceinline__ void write_out_qkv(const GemvJob & jb, const QkvEpi &
     }
 }
 
+// Attention in the tail of the wq | wk | wv launch (QkvEpi::att_out). The workgroups [g * wgs, (g + 1) * wgs) hold every row of KV-head group g - its
+// H / Hkv query heads, its K rows, its V rows - so the group's attention depends on THESE workgroups only: the one seam of the layer that is not
+// all-to-all. After its stores are out every workgroup takes a ticket of its group; the last H / Hkv arrivers wait until the group is complete (the
+// rest of the chip is not waited for) and compute one query head each on four waves; everybody else leaves.
+// The counters are monotonic (every launch adds exactly wgs per group, launches of a stream are serial): ticket mod wgs = arrival order in this launch.
+template <int DUMMY = 0>
+__device__ __forceinline__ void qkv_attention_tail(const GemvP & p, char * smem, int b, int tid, int wave, int lane) {
+    const QkvEpi & e = p.epi;
+    const int wgs = e.att_wgs, g = b / wgs, nh = e.att_H / (e.kv_dim / e.dh);
+    unsigned * lds_u = (unsigned *) smem;                  // [0] ticket, [1] four-wave barrier counter (the attention body starts 64 bytes further up)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have been acknowledged
+    __syncthreads();                                       // ... every wave's (and nobody reads the activation row any more)
+    if (tid == 0) {
+        lds_u[0] = __hip_atomic_fetch_add((PM_G unsigned *) (e.att_ticket + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds_u[1] = 0;
+    }
+    __syncthreads();
+    const unsigned t = lds_u[0], k = t & (unsigned) (wgs - 1);
+    if ((int) k < wgs - nh || wave >= 4) return;
+    if (tid == 0) {
+        const unsigned want = t - k + (unsigned) wgs;      // the counter's value once the whole group has arrived
+        int spins = 0;
+        while ((int) (__hip_atomic_load((const PM_G unsigned *) (e.att_ticket + g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) { if (e.att_err) __hip_atomic_store((PM_G int *) e.att_err, 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    unsigned gen = 0;
+    auto bar4 = [&]() __attribute__((always_inline)) {     // barrier of the four surviving waves (the other twelve have left: no s_barrier)
+        ++gen;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) {
+            __hip_atomic_fetch_add(lds_u + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(lds_u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * gen) __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    bar4();
+    const AttnTailP a = {e.att_q, e.kc, e.vc, e.pos_ptr, e.seq_ptr, e.seq_stride, e.att_out, e.att_H, e.kv_dim / e.dh, e.n_ctx, e.att_scale};
+    const int h = g * nh + ((int) k - (wgs - nh));
+    if (e.dh == 128) attn_tail_head<128>(a, h, smem + 64, bar4);
+    else attn_tail_head<64>(a, h, smem + 64, bar4);
+}
+
 // The whole mat-vec of one workgroup (body of gemv_q_kernel / gemv_q_cols_kernel).
 template <int TA, int TB, bool PAIR, bool DBG, int NC = 1, bool EPI = false, int NPRE = 2>
 __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double * nred) {
@@ -867,9 +915,17 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
     tsv[4] = PM_TS_NOW();                              // (all 16 waves have)
     // (4) coalesced write-out (+bias, +residual)
     if (EPI && p.epi.tab) {
-        write_out_qkv(p.job[0], p.epi, outbuf, r0_0, r1_0, 0, tid, 1, epi_slot, epi_off, ec0, es0);
-        write_out_qkv(p.job[1], p.epi, outbuf, r0_1, r1_1, ob_1, tid, cpr_1, epi_slot, epi_off, ec1, es1);
-        write_out_qkv(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off, ec2, es2);
+        if (p.epi.att_out) {
+            // write-through stores: other compute units read q and this token's cell in this launch
+            write_out_qkv<true>(p.job[0], p.epi, outbuf, r0_0, r1_0, 0, tid, 1, epi_slot, epi_off, ec0, es0);
+            write_out_qkv<true>(p.job[1], p.epi, outbuf, r0_1, r1_1, ob_1, tid, cpr_1, epi_slot, epi_off, ec1, es1);
+            write_out_qkv<true>(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off, ec2, es2);
+            if constexpr (EPI && !PAIR && NC == 1) qkv_attention_tail(p, smem, b, tid, wave, lane);
+        } else {
+            write_out_qkv(p.job[0], p.epi, outbuf, r0_0, r1_0, 0, tid, 1, epi_slot, epi_off, ec0, es0);
+            write_out_qkv(p.job[1], p.epi, outbuf, r0_1, r1_1, ob_1, tid, cpr_1, epi_slot, epi_off, ec1, es1);
+            write_out_qkv(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off, ec2, es2);
+        }
     } else {
         const int ncw = NC > 1 && p.ncols > 0 ? p.ncols : NC;
         const double ss = write_out<MEGA, NC>(p.job[0], outbuf, r0_0, r1_0, 0, tid, p.y_stride, 1, ncw);

@@ -77,6 +77,12 @@ struct pm_qkv_epi {
     const float * tab; const int32_t * pos, * seq, * dyn; long seq_stride;
     void * kc, * vc; int Hkv, dh, n_ctx, n_rot, v_rowmajor;
     int neox;                           // rope mode 2 (build_qwen2): pairs (i, i + n_rot / 2); needs n_rot == head_dim and power-of-two slices
+    // attention in the launch's tail (round 5): att_out != null - the workgroups of one KV-head group (its query rows, its K rows and its V rows all
+    // live in the same grid / Hkv workgroups) take a ticket after their RoPE / KV stores; the last n_head / Hkv of them wait for the group to be
+    // complete and compute one query head each over the cached cells (attn_tail_device.h: attn_cached.hip's arithmetic, the same bits) - the
+    // attention launch and its boundary disappear. att_ticket: Hkv counters (zeroed once, monotonic), att_err: watchdog word (a bounded wait gave up).
+    // Position-pointer mode only (pos != null, dyn == null); -7 when the shape is not served (then launch pm_launch_attn_cached as before)
+    float * att_out; unsigned * att_ticket; int * att_err; float kq_scale; int n_head, att_max_keys;
 };
 struct pm_gemv_fused {
     int K; int njobs;

@@ -366,6 +366,32 @@ def mul_mat_vec_qkv(ws, x, tab, pos, k_cache, v_cache, n_head_kv, head_dim, n_ct
     return q
 
 
+class QkvAttn(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("out", _C.c_void_p), ("ticket", _C.c_void_p), ("watchdog", _C.c_void_p), ("kq_scale", _C.c_float), ("n_head", _C.c_int32), ("max_keys", _C.c_int32)]
+
+
+def mul_mat_vec_qkv_attn(ws, x, tab, pos, k_cache, v_cache, n_head, n_head_kv, head_dim, n_ctx, scale, ticket, norm_w=None, eps=0.0, biases=None, n_rot=None,
+                         neox=False, max_keys=0, watchdog=None):
+    """mul_mat_vec_qkv with the attention over the cached cells in the launch's tail (pm355_mul_mat_vec_qkv_attn). ticket: zeroed uint32-sized int32 tensor
+    [n_head_kv] that lives across calls. Returns (q [N_q], attention output [N_q])."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_mul_mat_vec_qkv_attn.restype = C.c_int
+    lib.pm355_mul_mat_vec_qkv_attn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    jobs = (MatvecJob * 3)()
+    q = torch.empty(ws[0].N, dtype=torch.float32, device=x.device)
+    out = torch.empty(ws[0].N, dtype=torch.float32, device=x.device)
+    for j, w in enumerate(ws):
+        jobs[j] = MatvecJob(w.type, 0, w.N, ptr(w.data), None, ptr(q) if j == 0 else None,
+                            ptr(biases[j]) if biases and biases[j] is not None else None, None)
+    s = QkvStore(ptr(tab), ptr(pos), None, ptr(k_cache), ptr(v_cache), n_head_kv, head_dim, n_ctx, n_rot or head_dim, 0, int(neox))
+    at = QkvAttn(ptr(out), ptr(ticket), ptr(watchdog), float(scale), n_head, max_keys)
+    check(lib.pm355_mul_mat_vec_qkv_attn(C.addressof(jobs), ws[0].K, ptr(x), ptr(norm_w), float(eps), C.addressof(s), None, 0, C.addressof(at), stream_ptr()),
+          "mul_mat_vec_qkv_attn")
+    return q, out
+
+
 def attn_cached(q_rot, k_cache, v_cache, pos, n_head, n_head_kv, head_dim, n_ctx, scale, cell_nkv=None, mask=None, max_keys=0, flags=0, scratch=None):
     """Single-token attention over cells that are all in the cache (q rotated and F16-rounded). pos: int32 device tensor [1].
     scratch (zero-initialised f32 tensor of attn_split_scratch_floats): the long-context matrix-core kernel, max_keys = grid cells."""

@@ -427,3 +427,35 @@ def test_persistent_decode_engine_matches_the_five_launch_path(E, oracle, monkey
         worst = max(worst, _nmse(outs[1][i][1], l_ref))
     oracle.model_free(ho)
     assert worst < 1e-3, worst
+
+
+@pytest.mark.parametrize("arch", [0, 1])
+def test_attention_tail_decode_is_bit_identical(E, monkeypatch, arch):
+    """Round 5: PM355_ATTN_TAIL=1 - the attention computed in the tail of the wq | wk | wv launch by the last workgroups of each
+    KV-head group (four launches per layer) - against the default five launches: the same hidden rows and logits, bit for bit, across the 64-cell
+    boundary of the short attention path, NORM and NEOX rope, with the tail's watchdog clean."""
+    torch = E.torch
+    rng = np.random.default_rng(977 + arch)
+    d = tiny_model(rng, arch=arch, n_layer=3, n_embd=1024, n_head=16, n_head_kv=8, n_ff=2048, n_vocab=320, n_ctx=128, rope_freqs=(arch == 0))
+    toks = rng.integers(0, d.n_vocab, 80).astype(np.int32)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("PM355_ATTN_TAIL", flag)
+        w = E.Window(_hp(d), n_ctx=128)
+        w.load_desc(d)
+        w.finalize(max_tokens=1)
+        w.set_pos(0)
+        x_out = torch.empty((1, d.n_embd), dtype=torch.float32, device="cuda")
+        lg = torch.empty(d.n_vocab, dtype=torch.float32, device="cuda")
+        tok = torch.zeros(1, dtype=torch.int32, device="cuda")
+        res = []
+        for t in toks:
+            tok[0] = int(t)
+            w.step(token=tok, x_out=x_out, logits=lg, advance=1, use_graph=True)
+            torch.cuda.synchronize()
+            res.append((x_out.cpu().numpy().copy(), lg.cpu().numpy().copy()))
+        assert w.check() == 0
+        outs.append(res)
+        w.close()
+    for i, ((h0, l0), (h1, l1)) in enumerate(zip(*outs)):
+        assert np.array_equal(h0, h1) and np.array_equal(l0, l1), i

@@ -1009,3 +1009,39 @@ def test_engine_qkv_and_attention_phases_equal_the_launches(P, mode, n_past, tv)
     assert torch.equal(ys[0], q1), (ys[0] - q1).abs().max()
     assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
     assert torch.equal(a2, a1), (a2 - a1).abs().max()
+
+
+@pytest.mark.parametrize("shape", [(8192, 64, 8, 128), (4096, 32, 8, 128), (2048, 16, 4, 128), (1024, 16, 8, 64)])
+@pytest.mark.parametrize("tv", [Q6_K, Q4_K])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_attention_in_the_qkv_launch_tail_equals_the_two_launches(P, shape, tv, mode):
+    """Round 5: pm355_mul_mat_vec_qkv_attn - the attention over the cached cells computed in the TAIL of the wq | wk | wv launch by
+    the last workgroups of each KV-head group (per-group ticket; q and the token's cell are read back through write-through stores / cache-bypassing
+    loads) - against pm355_mul_mat_vec_qkv followed by pm355_attn_cached: the same bits in q, in both caches and in the attention output, at the
+    Llama-3-70B / 8B head shapes and two small ones, on both sides of the 64-cell short path, the launch repeated on one set of ticket counters
+    (they are monotonic across launches), NORM and NEOX rope."""
+    torch = P.torch
+    E_, H, Hkv, dh = shape
+    n_ctx = 1024
+    rng = np.random.default_rng(77 + E_ + mode)
+    ws = [P.upload_weight(Q4_K, rand_blocks(Q4_K, H * dh, E_, rng), E_, H * dh), P.upload_weight(Q4_K, rand_blocks(Q4_K, Hkv * dh, E_, rng), E_, Hkv * dh),
+          P.upload_weight(tv, rand_blocks(tv, Hkv * dh, E_, rng), E_, Hkv * dh)]
+    nw = torch.from_numpy((1 + rng.normal(0, 0.05, E_)).astype(np.float32)).cuda()
+    kc0 = torch.from_numpy(rng.normal(0, 1, (n_ctx, Hkv * dh)).astype(np.float16)).cuda()
+    vc0 = torch.from_numpy(rng.normal(0, 1, (Hkv * dh, n_ctx)).astype(np.float16)).cuda()
+    scale = 1.0 / np.sqrt(dh)
+    ticket = torch.zeros(Hkv, dtype=torch.int32, device="cuda")
+    dog = torch.zeros(1, dtype=torch.int32, device="cuda")
+    kc1, vc1, kc2, vc2 = kc0.clone(), vc0.clone(), kc0.clone(), vc0.clone()
+    for n_past in (0, 1, 17, 63, 64, 65, 200, 639):
+        x = torch.from_numpy(rng.normal(0, 1.0, (1, E_)).astype(np.float32)).cuda()
+        pos = torch.tensor([n_past], dtype=torch.int32, device="cuda")
+        tab = P.rope_table(pos, dh, mode=mode, freq_base=500000.0)
+        q1 = P.mul_mat_vec_qkv(ws, x, tab, pos, kc1, vc1, Hkv, dh, n_ctx, norm_w=nw, eps=1e-5, neox=bool(mode & 2))
+        a1 = P.attn_cached(q1, kc1, vc1, pos, H, Hkv, dh, n_ctx, scale, max_keys=648)
+        q2, a2 = P.mul_mat_vec_qkv_attn(ws, x, tab, pos, kc2, vc2, H, Hkv, dh, n_ctx, scale, ticket, norm_w=nw, eps=1e-5, neox=bool(mode & 2), max_keys=648, watchdog=dog)
+        torch.cuda.synchronize()
+        assert int(dog.item()) == 0
+        assert torch.equal(q2, q1), (n_past, (q2 - q1).abs().max())
+        assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1), n_past
+        assert torch.equal(a2, a1), (n_past, (a2 - a1).abs().max())
