@@ -432,6 +432,15 @@ def plugin_decode(tmp, n_gen=64, prompt_len=16):
            "prompt_tokens_per_s": round(st["prompt_tok_s"], 1), "load_ms": round(st["load_ms"], 1), "gguf_write_s": round(t_gen, 1),
            "hbm_roofline_tokens_per_s": round(roof, 1), "frac_of_hbm_roofline": round(st["decode_tok_s"] / roof, 4),
            "timing": "wall clock around llama_decode + llama_synchronize per token, first 5 tokens dropped (llama_perf convention)"}
+    # the same run with oracle/ref_patches/graph_reuse.patch switched on (LLAMA_MI355_GRAPH_REUSE=1: libllama keeps the previous single-token graph and
+    # scheduler allocation; the headline figure above is the reference's unpatched per-token graph build)
+    try:
+        _, _, sr = B.run_llama_driver(path, prompt, n_gen, ngl=99, n_ctx=4096, threads=usable_cores(), extra_args=["--keep-out-in-cuda"], timeout=150,
+                                      env={"LLAMA_MI355_GRAPH_REUSE": "1"})
+        out["graph_reuse_patch"] = {"tokens_per_s": round(sr["decode_tok_s"], 2), "ms_per_token": round(sr["decode_ms_avg"], 4), "best_ms_per_token": round(sr["decode_ms_min"], 4),
+                                    "frac_of_hbm_roofline": round(sr["decode_tok_s"] / roof, 4)}
+    except Exception as e:                       # noqa: BLE001 - a bench leg, never fatal
+        out["graph_reuse_patch"] = {"error": str(e)[:200]}
     # the same model with --flash-attn (FLASH_ATTN_EXT graphs: row-major V cache, F16 mask) - lowered to the same five launches
     try:
         _, _, sf = B.run_llama_driver(path, prompt, 32, ngl=99, n_ctx=4096, threads=usable_cores(), extra_args=["--keep-out-in-cuda", "-fa"], timeout=150)
@@ -451,7 +460,7 @@ def plugin_decode_70b(tmp, hp70, engine_ms_per_token, n_gen=48):
         return None
     prompt = np.random.default_rng(1234).integers(0, 128256, 16)
     prompt[0] = 128000
-    ms = {}
+    ms, ms_reuse = {}, {}
     depths = (8, 16, 32)
     for L in depths:
         p = os.path.join(tmp, f"pm355_bench_llama3_70b_shape_{L}l.gguf")
@@ -460,6 +469,12 @@ def plugin_decode_70b(tmp, hp70, engine_ms_per_token, n_gen=48):
         try:
             _, _, st = B.run_llama_driver(p, prompt, n_gen, ngl=99, n_ctx=4096, threads=usable_cores(), extra_args=["--keep-out-in-cuda"], timeout=300)
             ms[L] = (st["decode_ms_avg"], st["decode_ms_min"])
+            try:                                     # the same file with oracle/ref_patches/graph_reuse.patch switched on
+                _, _, sr = B.run_llama_driver(p, prompt, n_gen, ngl=99, n_ctx=4096, threads=usable_cores(), extra_args=["--keep-out-in-cuda"], timeout=300,
+                                              env={"LLAMA_MI355_GRAPH_REUSE": "1"})
+                ms_reuse[L] = sr["decode_ms_avg"]
+            except Exception:                        # noqa: BLE001
+                pass
         finally:
             os.unlink(p)
     # least-squares line through the depths (two points made the slope - and with it the 80-layer figure - swing by 10 % between boxes)
@@ -475,6 +490,15 @@ def plugin_decode_70b(tmp, hp70, engine_ms_per_token, n_gen=48):
     if engine_ms_per_token:
         out["engine_ms_per_token"] = round(engine_ms_per_token, 4)
         out["frac_of_engine"] = round(engine_ms_per_token / tok_ms, 4)
+    if len(ms_reuse) == len(depths):
+        (pl_r, fx_r), *_ = np.linalg.lstsq(A, np.array([ms_reuse[L] for L in depths]), rcond=None)
+        tok_r = float(fx_r) + hp70["n_layer"] * float(pl_r)
+        out["graph_reuse_patch"] = {"what": "the same files with oracle/ref_patches/graph_reuse.patch switched on (LLAMA_MI355_GRAPH_REUSE=1): libllama keeps the previous "
+                                            "single-token ggml_cgraph + scheduler allocation while the KV bucket is unchanged",
+                                    "ms_per_token_at_depth": {str(L): round(ms_reuse[L], 4) for L in depths}, "ms_per_layer": round(float(pl_r), 4), "ms_fixed": round(float(fx_r), 4),
+                                    "ms_per_token_80_layers": round(tok_r, 4), "tokens_per_s_80_layers": round(1e3 / tok_r, 2)}
+        if engine_ms_per_token:
+            out["graph_reuse_patch"]["frac_of_engine"] = round(engine_ms_per_token / tok_r, 4)
     return out
 
 

@@ -290,3 +290,35 @@ def test_llama_decode_plugin_defrag_on_a_q8_0_k_cache_moves_whole_blocks(gpu, tm
         d = np.abs(l1 - l0).max() / np.abs(l0).max()
         print(f"\n[defrag, K cache {'q8_0' if kv else 'f16'}] max |d logit| / max |logit| = {d:.2e}")
         assert d <= 1e-4, (kv, d)
+
+
+@pytest.mark.parametrize("name", ["llama", "qwen2"])
+@pytest.mark.parametrize("extra", [[], ["-fa"], ["-fa", "-ctk", "q8_0", "-ctv", "q8_0"]], ids=["default", "flash-attn", "q8_0-kv"])
+def test_llama_decode_plugin_under_the_graph_reuse_patch(gpu, name, extra, tmp_path):
+    """oracle/ref_patches/graph_reuse.patch (LLAMA_MI355_GRAPH_REUSE=1) - libllama keeps the previous single-token ggml_cgraph and
+    scheduler allocation while (n_kv bucket, outputs) are unchanged and only moves the KV-store views - with the plug-in underneath: the same tokens
+    and the same logits, bit for bit, as the same binary building the graph for every token, the hipGraph replayed for (almost) every token, and the
+    reuse actually taken."""
+    z = np.load(os.path.join(HERE, "golden", f"tiny_{name}_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / f"tiny_{name}.gguf"), z)
+    n_ctx = int(z["hp_n_ctx"])
+    n = min(40, n_ctx - len(z["prompt"]) - 1)
+    t0, l0, _ = run_llama_driver(path, z["prompt"], n, ngl=99, n_ctx=n_ctx, extra_args=GPU_ARGS + extra)
+    t1, l1, st = run_llama_driver(path, z["prompt"], n, ngl=99, n_ctx=n_ctx, extra_args=GPU_ARGS + extra, env={"LLAMA_MI355_GRAPH_REUSE": "1", "GGML_MI355_STATS": "1"})
+    assert "MI355X0" in st["stderr"]
+    m = re.search(r"graph-reuse patch\): (\d+) of (\d+) single-token decodes reused", st["stderr"])
+    assert m and int(m.group(1)) >= int(m.group(2)) - 3 and int(m.group(2)) >= n - 1, st["stderr"][-800:]
+    r = re.search(r"hipGraph replays (\d+)", st["stderr"])
+    assert r and int(r.group(1)) >= n - 6, st["stderr"][-800:]
+    assert t1.tolist() == t0.tolist()
+    assert np.array_equal(l1, l0), np.abs(l1 - l0).max()
+
+
+def test_llama_decode_plugin_context_shift_under_the_graph_reuse_patch(gpu, tmp_path, monkeypatch):
+    """A context shift in mid-generation (build_k_shift on the plug-in's KV buffer) drops the kept graphs: same logits as without the patch."""
+    z = np.load(os.path.join(HERE, "golden", "tiny_llama_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / "tiny.gguf"), z)
+    monkeypatch.setenv("REFDRV_SHIFT", "4,2,3")
+    t0, l0, _ = run_llama_driver(path, z["prompt"], 12, ngl=99, n_ctx=64, extra_args=GPU_ARGS)
+    t1, l1, _ = run_llama_driver(path, z["prompt"], 12, ngl=99, n_ctx=64, extra_args=GPU_ARGS, env={"LLAMA_MI355_GRAPH_REUSE": "1"})
+    assert t1.tolist() == t0.tolist() and np.array_equal(l1, l0)

@@ -41,3 +41,33 @@ def test_gguf_roundtrip(tmp_path):
     assert shape == (512, 256) and data.nbytes == G.tensor_nbytes(t, shape)
     assert "blk.0.attn_q.bias" in f.tensors and f.tensors["output.weight"][0] == G.Q6_K
     f.close()
+
+
+@pytest.mark.parametrize("name", ["llama", "qwen2"])
+@pytest.mark.parametrize("extra", [[], ["-fa"], ["-ctk", "q8_0"]], ids=["default", "flash-attn", "q8_0-k"])
+def test_graph_reuse_patch_leaves_the_reference_cpu_decode_unchanged(name, extra, tmp_path, monkeypatch):
+    """oracle/ref_patches/graph_reuse.patch, judged on the reference's OWN CPU backend: with LLAMA_MI355_GRAPH_REUSE=1 libllama keeps
+    the previous single-token graphs and scheduler allocations and only moves the KV-store views to the new cache head - 40 greedy tokens (the n_kv
+    bucket of 32 is crossed: a rebuild in the middle of the run) must give the same tokens and the same logits, bit for bit, as the unpatched path;
+    also with cells removed and a defragmentation queued mid-run (the reuse state must be dropped when the cache graph runs)."""
+    z = np.load(os.path.join(HERE, "golden", f"tiny_{name}_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / f"tiny_{name}.gguf"), z)
+    n_ctx = int(z["hp_n_ctx"])
+    n_gen = min(40, n_ctx - len(z["prompt"]) - 1)
+    monkeypatch.delenv("LLAMA_MI355_GRAPH_REUSE", raising=False)
+    t0, l0, _ = run_llama_driver(path, z["prompt"], n_gen, ngl=0, n_ctx=n_ctx, flavour="avx2", extra_args=extra)
+    monkeypatch.setenv("LLAMA_MI355_GRAPH_REUSE", "1")
+    t1, l1, st = run_llama_driver(path, z["prompt"], n_gen, ngl=0, n_ctx=n_ctx, flavour="avx2", extra_args=extra)
+    import re
+    m = re.search(r"graph-reuse patch\): (\d+) of (\d+) single-token decodes reused", st["stderr"])
+    assert m and int(m.group(1)) >= int(m.group(2)) - 3 and int(m.group(2)) >= n_gen - 1, st["stderr"][-500:]     # (rebuilt at the start and at each 32-cell bucket)
+    assert t1.tolist() == t0.tolist()
+    assert np.array_equal(l1, l0), np.abs(l1 - l0).max()
+    if extra:
+        return
+    monkeypatch.setenv("REFDRV_RM", "3,2,5")
+    monkeypatch.setenv("REFDRV_DEFRAG", "5")
+    t3, l3, _ = run_llama_driver(path, z["prompt"], 12, ngl=0, n_ctx=n_ctx, flavour="avx2")
+    monkeypatch.delenv("LLAMA_MI355_GRAPH_REUSE")
+    t2, l2, _ = run_llama_driver(path, z["prompt"], 12, ngl=0, n_ctx=n_ctx, flavour="avx2")
+    assert t3.tolist() == t2.tolist() and np.array_equal(l3, l2)
