@@ -272,6 +272,22 @@ def probe_prefill(hp, mixture, n_tok, small_batches=(2, 3, 4, 8, 16, 32, 64)):
            "gemm_tflops_whole_prompt": round(flop / (ms / 1e3) / 1e12, 1), "mfma_peak_tflops_f16_dense": 2500.0,
            "note": "token embedding + all layers (MFMA v_mfma_f32_32x32x16_f16 weight GEMMs with on-the-fly dequantization, MFMA causal "
                    "attention) + result_norm + lm_head on the last token; gemm_tflops_whole_prompt counts the weight-GEMM FLOPs over the whole time"}
+    # the same prompt handed over in the reference's default micro-batches (n_ubatch = 512, common/common.h:178: what llama_decode passes to a backend
+    # per graph when the prompt is longer) - every chunk a pass over all weights, the cells of the earlier chunks attended from the cache
+    try:
+        UB = 512
+        if n_tok > UB and n_tok % UB == 0:
+            win.kv_clear()
+            e0.record(st)
+            for c0 in range(0, n_tok, UB):
+                win.decode(tokens=toks[c0:c0 + UB], pos0=c0, want_hidden=False, want_logits=(c0 + UB == n_tok))
+            e1.record(st)
+            torch.cuda.synchronize()
+            ms_ub = e0.elapsed_time(e1)
+            out["n_ubatch_512"] = {"tokens_per_s": round(n_tok / (ms_ub / 1e3), 1), "ms": round(ms_ub, 2), "chunks": n_tok // UB,
+                                   "gemm_tflops_whole_prompt": round(flop / (ms_ub / 1e3) / 1e12, 1)}
+    except Exception as e:
+        out["n_ubatch_512"] = {"error": str(e)[:300]}
     # small batches through the same window (speculative decoding / parallel sequences / short prompts): 4..64 tokens per step take the
     # integer-matrix-core mat-mul (mmq_i8.hip: one weight pass per 32 tokens), whole model, KV positions advancing
     try:

@@ -525,7 +525,9 @@ PM355_API int pm355_ring_single_token(pm355_ring * r, pm355_model * m, int seq, 
  * micro-step: wait (device-side) for the previous exchange -> window step (rank 0: head on the returned activation -> argmax -> embed -> window,
  * one captured graph) -> grouped exchange. Nothing blocks the host. forced: host array [n_micro] for rank 0 (token to feed instead of the head's
  * argmax, < 0 = none; required for the first `world` micro-steps after a reset), else NULL. d_tokens_out: device int32 [n_micro] on rank 0
- * (token fed at each micro-step), or NULL. reset != 0 restarts the schedule at micro-step 0. Finish with pm355_ring_wait. */
+ * (token fed at each micro-step), or NULL. reset != 0 restarts the schedule at micro-step 0 AND sets the model's sequence counter back to sequence 0
+ * (pm355_model_set_seq(m, 0): the micro-step index selects the KV slab on every rank); positions are the caller's (pm355_model_set_seq_pos). Finish with
+ * pm355_ring_wait. */
 PM355_API int pm355_ring_decode_staggered(pm355_ring * ring, pm355_model * m, int n_micro, const int32_t * forced, int32_t * d_tokens_out, int reset,
                                           int use_graph, pm355_stream_t compute_stream);
 PM355_API const float * pm355_ring_decode_last_output(const pm355_ring * ring);

@@ -23,8 +23,27 @@ PROBE_SOURCES = ["probe.hip", "engine_probe.hip", "probe_api.hip", "overlap_prob
 EXTRA = os.environ.get("PM355_EXTRA_FLAGS", "").split()
 # -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs with the dispatch instead of through an s_load of the kernarg segment
 # (mmvq.hip hands the six values its prologue starts with that way: +0.4 % on the 70B decode step, +0.9 % on the 8B one, interleaved A/B on one box).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-mllvm", "-amdgpu-kernarg-preload-count=16",
+# The option is an internal LLVM one: it goes to mmvq.hip only, and only when this compiler accepts it (probed once; a ROCm / LLVM upgrade that renames it
+# builds without it instead of failing everything).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-const-variable", "-Wno-unused-value", "-Wno-unused-function", "-Wno-unused-result"]
+KERNARG_PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
+PER_SOURCE_FLAGS = {"mmvq.hip": KERNARG_PRELOAD}
+_probe_ok = {}
+
+
+def _flags_accepted(hipcc, flags):
+    key = (hipcc, tuple(flags))
+    if key not in _probe_ok:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "p.hip")
+            with open(src, "w") as f:
+                f.write("#include <hip/hip_runtime.h>\n__global__ void k(int * p, int v) { p[0] = v; }\n")
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-c", src, "-o", os.path.join(d, "p.o")] + list(flags),
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            _probe_ok[key] = r.returncode == 0
+    return _probe_ok[key]
 
 
 def _newer(target, deps):
@@ -42,7 +61,10 @@ def _compile(srcs, hdrs, objdir, lib, flags, force, verbose):
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            cmd = [hipcc] + flags + ["-c", s, "-o", o]
+            extra = PER_SOURCE_FLAGS.get(os.path.basename(s), [])
+            if extra and not _flags_accepted(hipcc, extra):
+                extra = []
+            cmd = [hipcc] + flags + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd)))

@@ -77,6 +77,7 @@ host_timers g_ht;
 // steady state: the counters at the first hipGraph replay (everything before it is model load, prompt, planning and capture) and the time of the last one
 struct host_snapshot { uint64_t v[12] = {}; std::chrono::steady_clock::time_point t0, t_last; bool taken = false; };
 host_snapshot g_snap;
+std::atomic<int> g_n_backends{0};        // backends created in this process (the steady-state statistics are meaningful for one)
 void host_counters(uint64_t (&v)[12]) {
     const uint64_t x[12] = {g_ht.ns_compute, g_ht.ns_set, g_ht.ns_get, g_ht.ns_sync, g_ht.ns_order, g_ht.ns_fp, g_ht.ns_plan, g_ht.ns_dyn, g_ht.ns_launch, g_ht.ns_seta, g_ht.ns_geta, 0};
     for (int i = 0; i < 12; ++i) v[i] = x[i];
@@ -337,7 +338,9 @@ void backend_free(ggml_backend_t b) {
         fprintf(stderr, "ggml-mi355 graph_compute phases, us per call: order behind uploads %.1f, fingerprint %.1f, plan lookup / build %.1f, KV cell lookup + patch %.1f, launch %.1f\n",
                 g_ht.ns_order / 1e3 / (double) c->n_compute, g_ht.ns_fp / 1e3 / (double) c->n_compute, g_ht.ns_plan / 1e3 / (double) c->n_compute,
                 g_ht.ns_dyn / 1e3 / (double) c->n_compute, g_ht.ns_launch / 1e3 / (double) c->n_compute);
-    if (env_on("GGML_MI355_STATS") && g_snap.taken && c->n_replay > g_snap.v[11] + 1) {
+    // (the snapshot and the phase timers are process-wide: with more than one backend they mix counters of different backends - the steady-state
+    //  split is printed only when this process had a single one)
+    if (env_on("GGML_MI355_STATS") && g_n_backends.load() == 1 && g_snap.taken && c->n_replay > g_snap.v[11] + 1) {
         // from the first replay to the last: one replay per token, so (last - first) spans n - 1 whole tokens
         uint64_t now[12]; host_counters(now);
         const double n = (double) (c->n_replay - g_snap.v[11] - 1);
@@ -900,6 +903,7 @@ ggml_backend_t ggml_backend_mi355_init(int device) {
     if (device < 0 || device >= ggml_backend_mi355_get_device_count()) { fprintf(stderr, "ggml-mi355: invalid device %d\n", device); return nullptr; }
     if (dsetdev(device)) return nullptr;
     backend_ctx * c = new backend_ctx{device, std::string(GGML_MI355_NAME "X") + std::to_string(device), plan_only() ? (pm355_stream_t) 1 : pm355_stream_create()};
+    ++g_n_backends;
     if (!c->stream) { delete c; return nullptr; }
     c->fuse = !env_on("GGML_MI355_NO_FUSE");                          // node-by-node kernels only (debug / A-B)
     if (const char * am = getenv("GGML_MI355_ATTN_MFMA")) if (am[0] == '0') c->attn_mfma = false;

@@ -88,6 +88,7 @@ static int ring_buffers(pm355_ring * r, size_t n_floats) {
     (void) hipDeviceSynchronize();
     for (int i = 0; i < 2; ++i) { if (r->pin[i]) (void) hipFree(r->pin[i]); if (r->pout[i]) (void) hipFree(r->pout[i]); r->pin[i] = r->pout[i] = nullptr; }
     r->buf_floats = 0;
+    r->stag_last = nullptr;                              // (it pointed into the rows just freed: the staggered loop starts from its forced tokens again)
     for (int i = 0; i < 2; ++i)
         if (hipMalloc((void **) &r->pin[i], n_floats * 4 + 256) != hipSuccess || hipMalloc((void **) &r->pout[i], n_floats * 4 + 256) != hipSuccess) return -1;
     r->buf_floats = n_floats;
@@ -329,7 +330,13 @@ int pm355_ring_decode_staggered(pm355_ring * r, pm355_model * m, int n_micro, co
     hipStream_t st = (hipStream_t) compute_stream;
     if (ring_buffers(r, (size_t) E)) return rfail(PM355_E_NOMEM, "ring_decode_staggered: buffers");
     if (!r->d_cur && hipMalloc((void **) &r->d_cur, 64) != hipSuccess) return rfail(PM355_E_NOMEM, "ring_decode_staggered: token slot");
-    if (reset) { r->stag_m = 0; r->stag_k = 0; r->stag_last = nullptr; }
+    if (reset) {
+        // the schedule restarts at micro-step 0 = sequence 0 on EVERY rank: the model's device-side sequence counter (it selects the KV slab and advances
+        // with every step) restarts with it - after n micro-steps the ranks sit at different sequence indices
+        r->stag_m = 0; r->stag_k = 0; r->stag_last = nullptr;
+        const int rs = pm355_model_set_seq(m, 0, compute_stream);
+        if (rs) return rfail(rs, pm355_model_error(m));
+    }
     auto need_recv = [&](long mm) { return W > 1 && (rank == 0 ? mm >= W : mm >= rank); };
     for (int i = 0; i < n_micro; ++i) {
         const long mm = r->stag_m++;
