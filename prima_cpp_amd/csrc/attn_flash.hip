@@ -331,7 +331,11 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(FlashP p) {
 // scratch floats: M, L [H][nspan_max], P [nspan_max][H][dh], tickets [Hkv] (the caller zeroes the scratch once after allocating it)
 size_t pm_attn_flash_scratch_floats(int H, int Hkv, int dh, int n_ctx) {
     const size_t nspan = (size_t) (n_ctx + CK - 1) / CK;
-    return 2 * (size_t) H * nspan + nspan * H * dh + (size_t) Hkv + 64;
+    return 2 * (size_t) H * nspan + nspan * H * dh + (size_t) Hkv + 64 + 64 + (size_t) H * dh;      // (+ the Q8_0 path's query rows: pm_attn_flash_qrot_offset)
+}
+size_t pm_attn_flash_qrot_offset(int H, int Hkv, int dh, int n_ctx) {
+    const size_t nspan = (size_t) (n_ctx + CK - 1) / CK;
+    return 2 * (size_t) H * nspan + nspan * H * dh + (size_t) Hkv + 64 + 64;      // behind the tickets of both flash kernels (attn_flash_mfma.hip: + Hkv + 16 .. + 48)
 }
 
 // q, k, v = the RAW projections of the token; RoPE, KV store and attention over cells [0, n_kv) happen in this one launch.

@@ -63,8 +63,42 @@ __device__ __forceinline__ void st_coh4(float * p, float4v v) {
 // contiguous bytes; sub-tiles are 32 bytes apart from a multiple of 1 KiB so that the 16 lanes that write one key's row hit different banks.
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) short4v * lds_s4;
-template <int DH, bool VROW>
+
+// ---- Q8_0 K / V (round 5): the caches are 1-D tensors of NATIVE 34-byte blocks (half d | 32 int8, attn_q8.hip) - a head's row is DH / 32 blocks. The
+// operands of the F16 matrix instructions are the DEQUANTIZED values q_i * d rounded to F16 (one rounding per value; the reference dequantizes V the
+// same way - v_to_float, ggml.c:15990 - and multiplies K block-wise with the Q8_0-quantized query: attn_q8.hip's prep kernel hands the query over as
+// q_i * d_q rounded to F16, so the only difference to ggml_vec_dot_q8_0_q8_0 is that rounding of the two factors, 2^-11 relative each).
+// An operand slice = 8 consecutive int8 of one block (8 bytes at a 2-byte-aligned address: gfx950 serves them, tools/r5/unaligned_probe) + the block's d.
+constexpr int QB8 = 34;
+typedef uint32_t u32x2q __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+struct Q8Piece { u32x2q q; uint32_t d; };                  // raw bytes + the F16 scale's bits (zero-extended)
+__device__ __forceinline__ Q8Piece q8_fetch(const uint8_t * blk, int off8) {
+    Q8Piece r;
+    r.q = *(const PM_G u32x2q *) (blk + 2 + off8);
+    r.d = *(const PM_G uint16_t *) blk;
+    return r;
+}
+__device__ __forceinline__ half8 q8_deq(const Q8Piece & r) {
+    // int8 b -> F16: (b ^ 0x80) is b + 128 as an unsigned byte; the F16 bit pattern 0x6400 | x is the number 1024 + x; minus 1152 leaves b, exactly
+    const uint32_t lo = r.q.x ^ 0x80808080u, hi = r.q.y ^ 0x80808080u;
+    const half2v off = {(_Float16) 1152.0f, (_Float16) 1152.0f};
+    const _Float16 dh_ = __builtin_bit_cast(_Float16, (uint16_t) r.d);
+    const half2v d2 = {dh_, dh_};
+    const half2v h0 = (__builtin_bit_cast(half2v, __builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u)) - off) * d2;
+    const half2v h1 = (__builtin_bit_cast(half2v, __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u)) - off) * d2;
+    const half2v h2 = (__builtin_bit_cast(half2v, __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u)) - off) * d2;
+    const half2v h3 = (__builtin_bit_cast(half2v, __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u)) - off) * d2;
+    return half8{h0.x, h0.y, h1.x, h1.y, h2.x, h2.y, h3.x, h3.y};
+}
+// one operand slice of a tile as it travels: F16 (16 bytes) or a Q8_0 piece (8 + 2 bytes)
+template <bool Q8> struct Opnd;
+template <> struct Opnd<false> { half8 v;   __device__ __forceinline__ half8 get() const { return v; } };
+template <> struct Opnd<true>  { Q8Piece v; __device__ __forceinline__ half8 get() const { return q8_deq(v); } };
+
+template <int DH, bool VROW, bool KQ8 = false, bool VQ8 = false>
 __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
+    static_assert(!VQ8 || VROW, "a quantized V cache is row-major (flash-attention graphs)");
     constexpr int KK = DH / 32;                      // k-steps of the S^T product
     constexpr int DT = DH / 16;                      // 16-row tiles of O^T
     constexpr int SUB = 32 * 32 + 32, VW = DT * SUB; // bytes of a V sub-tile image / of a wave's staging area (VROW)
@@ -87,6 +121,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
     const long krow = (long) p.Hkv * DH;
     const uint16_t * kc = p.kc + (long) seq * p.seq_stride + (long) g * DH;
     const uint16_t * vc = p.vc + (long) seq * p.seq_stride + (VROW ? (long) g * DH : (long) g * DH * p.n_ctx);
+    // Q8_0 caches: byte addressing, a cell row = n_head_kv * DH / 32 blocks
+    constexpr int HB8 = DH / 32 * QB8;                 // bytes of a head's row
+    const long krow8 = (long) p.Hkv * HB8;
+    const uint8_t * kc8 = (const uint8_t *) p.kc + (long) g * HB8, * vc8 = (const uint8_t *) p.vc + (long) g * HB8;
     // Everything below up to the first use of n_kv is issued BEFORE the position arrives (addresses are clamped into the cache): the
     // scalar round trip for the position overlaps the first tile's loads instead of preceding them.
     // Q^T as B operand: lane (col = head, lg) holds q[head][32 kk + 8 lg .. +8] (already rotated and F16-rounded by the QKV epilogue)
@@ -102,25 +140,36 @@ __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
     }
     // the key this lane's A-operand row stands for in score tile A (tile B: + 4), see the header
     const int krow_i = 8 * (col >> 2) + (col & 3);
-    half8 ka0[2][KK], ka1[2][KK], va0[DT], va1[DT];
-    auto fetch = [&](half8 (&ka)[2][KK], half8 (&va)[DT], int kt) __attribute__((always_inline)) {
+    typedef Opnd<KQ8> KOp;
+    typedef Opnd<VQ8> VOp;
+    KOp ka0[2][KK], ka1[2][KK]; VOp va0[DT], va1[DT];
+    auto fetch = [&](KOp (&ka)[2][KK], VOp (&va)[DT], int kt) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const uint16_t * kr = kc + (long) min(kt + krow_i + 4 * t, p.n_ctx - 1) * krow + 8 * lg;
+            const long cell = min(kt + krow_i + 4 * t, p.n_ctx - 1);
+            if constexpr (KQ8) {
+                const uint8_t * kr = kc8 + cell * krow8;                       // k-step kk of the S^T product = block kk of the head's row
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) ka[t][kk] = *(const half8 *) (kr + 32 * kk);
+                for (int kk = 0; kk < KK; ++kk) ka[t][kk].v = q8_fetch(kr + kk * QB8, 8 * lg);
+            } else {
+                const uint16_t * kr = kc + cell * krow + 8 * lg;
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) ka[t][kk].v = *(const half8 *) (kr + 32 * kk);
+            }
         }
         if constexpr (!VROW) {
             const uint16_t * vr = vc + (long) col * p.n_ctx + min(kt + 8 * lg, p.n_ctx - 8);
 #pragma unroll
-            for (int d = 0; d < DT; ++d) va[d] = *(const half8 *) (vr + (long) 16 * d * p.n_ctx);
+            for (int d = 0; d < DT; ++d) va[d].v = *(const half8 *) (vr + (long) 16 * d * p.n_ctx);
         } else {
             // raw rows: load n covers 64 / CPK keys, lane l = (key l / CPK, 16-byte piece l % CPK of the head's DH halves)
             constexpr int CPK = DH / 8;
 #pragma unroll
             for (int n = 0; n < DT; ++n) {
-                const int key = n * (64 / CPK) + lane / CPK;
-                va[n] = *(const half8 *) (vc + (long) min(kt + key, p.n_ctx - 1) * krow + 8 * (lane % CPK));
+                const int key = n * (64 / CPK) + lane / CPK, ch = lane % CPK;
+                const long cell = min(kt + key, p.n_ctx - 1);
+                if constexpr (VQ8) va[n].v = q8_fetch(vc8 + cell * krow8 + (ch >> 2) * QB8, 8 * (ch & 3));     // dims 8 ch .. + 7 = a quarter of block ch / 4
+                else va[n].v = *(const half8 *) (vc + cell * krow + 8 * ch);
             }
         }
     };
@@ -136,13 +185,13 @@ __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
 #pragma unroll
     for (int d = 0; d < DT; ++d) o[d] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
     // one 32-key tile whose K and V^T are in (kc_, vc_); the next tile's loads go to the other register set first
-    auto tile = [&](int kt_, half8 (&kc_)[2][KK], half8 (&vc_)[DT], half8 (&kn_)[2][KK], half8 (&vn_)[DT]) __attribute__((always_inline)) {
+    auto tile = [&](int kt_, KOp (&kc_)[2][KK], VOp (&vc_)[DT], KOp (&kn_)[2][KK], VOp (&vn_)[DT]) __attribute__((always_inline)) {
         if (kt_ + KSTEP < k_end) fetch(kn_, vn_, kt_ + KSTEP);
         float4v acc[2] = {float4v{0.0f, 0.0f, 0.0f, 0.0f}, float4v{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc_[0][kk], qf[kk], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc_[1][kk], qf[kk], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc_[0][kk].get(), qf[kk], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc_[1][kk].get(), qf[kk], acc[1], 0, 0, 0);
         }
         float s[8], mt = -INFINITY;
 #pragma unroll
@@ -172,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
         }
         if constexpr (!VROW) {
 #pragma unroll
-            for (int d = 0; d < DT; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vc_[d], pf, o[d], 0, 0, 0);
+            for (int d = 0; d < DT; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vc_[d].get(), pf, o[d], 0, 0, 0);
         } else {
             constexpr int CPK = DH / 8;
             uint8_t * wb = obuf + wave * VW;
@@ -180,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_mfma_kernel(FlashM p) {
             for (int n = 0; n < DT; ++n) {
                 const int kl = n * (64 / CPK) + lane / CPK, ch = lane % CPK;                 // key inside the tile, 16-byte piece of its row
                 const int pos = ((kl & 4) ? 16 + 4 * (kl >> 3) : 4 * (kl >> 3)) + (kl & 3);    // row of the sub-tile image: block (k / 8 or 4 + k / 8), row k % 4
-                *(half8 *) (wb + (ch >> 1) * SUB + pos * 32 + (ch & 1) * 16) = vc_[n];
+                *(half8 *) (wb + (ch >> 1) * SUB + pos * 32 + (ch & 1) * 16) = vc_[n].get();
             }
             const uint8_t * rb = wb + (4 * lg + (col >> 2)) * 32 + (col & 3) * 8;             // block lg, the lane's 4 halves of it
 #pragma unroll
@@ -351,8 +400,9 @@ int pm_attn_flash_cached_ok(int H, int Hkv, int dh, int n_ctx) {
 
 int pm_launch_attn_flash_cached(const float * q, void * kc, void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride, float * out,
                                 float * scratch, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st, const int32_t * dyn,
-                                const void * mask, int mask_f16, int max_cells, int v_rowmajor) {
+                                const void * mask, int mask_f16, int max_cells, int v_rowmajor, int k_q8, int v_q8) {
     if (!scratch || pm_attn_flash_cached_ok(H, Hkv, dh, n_ctx)) return -1;
+    if ((k_q8 || v_q8) && (!v_rowmajor || seq)) return -1;          // Q8_0 caches: flash-attention layout (row-major V), one sequence slab
     if (!pos0) pos0 = dyn;
     if (!pos0) return -1;
     const int CK = 128;
@@ -362,6 +412,9 @@ int pm_launch_attn_flash_cached(const float * q, void * kc, void * vc, const int
     // and 16 at 8k .. 32k cells), then longer spans; never more than 64 partials per head (the mergers' LDS tables)
     int span = CK, parts = 256 / Hkv;
     parts = parts < 16 ? 16 : parts > 64 ? 64 : parts;
+    // (measurement only: PM355_FLASH_PARTS = spans per KV head, 1 .. 64 - profiles/r05_long_context_spans.txt)
+    static const int parts_env = [] { const char * e = getenv("PM355_FLASH_PARTS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 0; }();
+    if (parts_env) parts = parts_env;
     while ((cells + span - 1) / span > parts) span *= 2;
     FlashM p = {};
     p.q = q; p.kc = (const uint16_t *) kc; p.vc = (const uint16_t *) vc; p.pos0_ptr = pos0; p.seq_ptr = seq; p.seq_stride = seq_stride; p.out = out;
@@ -369,7 +422,14 @@ int pm_launch_attn_flash_cached(const float * q, void * kc, void * vc, const int
     p.H = H; p.Hkv = Hkv; p.n_ctx = n_ctx; p.nspan = nspan_max; p.span = span; p.scale = scale;
     p.dyn = dyn; p.mask = mask; p.mask_f16 = mask_f16; p.ts = pm_ts_next_slot();
     const dim3 grid(Hkv, (cells + span - 1) / span);
-    if (v_rowmajor) {
+    if (k_q8 || v_q8) {
+#define PM_FQ8(DH_) do { \
+            if (k_q8 && v_q8) hipLaunchKernelGGL((attn_flash_mfma_kernel<DH_, true, true, true>), grid, dim3(256), 0, st, p); \
+            else if (k_q8)    hipLaunchKernelGGL((attn_flash_mfma_kernel<DH_, true, true, false>), grid, dim3(256), 0, st, p); \
+            else              hipLaunchKernelGGL((attn_flash_mfma_kernel<DH_, true, false, true>), grid, dim3(256), 0, st, p); } while (0)
+        if (dh == 128) PM_FQ8(128); else PM_FQ8(64);
+#undef PM_FQ8
+    } else if (v_rowmajor) {
         if (dh == 128) hipLaunchKernelGGL((attn_flash_mfma_kernel<128, true>), grid, dim3(256), 0, st, p);
         else           hipLaunchKernelGGL((attn_flash_mfma_kernel<64, true>), grid, dim3(256), 0, st, p);
     } else {

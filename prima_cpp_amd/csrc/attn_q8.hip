@@ -327,6 +327,63 @@ __global__ __launch_bounds__(256) void attn_q8_token_kernel(Q8TokP a) {
     }
 }
 
+// ---- 3b. long contexts: the same rotation + store alone (one launch), so that the attention can run on the matrix cores over cells that are ALL
+// in the cache (attn_flash_mfma.hip with Q8_0 K / V). q_out[h * DH + e] = what the K.q product multiplies the cache with: the F16-rounded rotated
+// query, or for a Q8_0 K cache its Q8_0 quantization (the reference quantizes the query row too: q_to_vec_dot, ggml.c:15905-15912) written as
+// the values q_i * d rounded to F16 (exactly representable operands for the F16 matrix instruction).
+template <int DH, bool KQ8, bool VQ8>
+__global__ __launch_bounds__(DH) void q8_token_prep_kernel(Q8TokP a, float * q_out) {
+    __shared__ float qf[DH], kf[DH];
+    constexpr int NB = DH / 32;
+    const int h = blockIdx.x, tid = threadIdx.x;
+    const int H = a.H, Hkv = a.Hkv;
+    const int hk = h / (H / Hkv);
+    const bool writer = h % (H / Hkv) == 0;
+    const int pos = a.pos[0], slot = a.dyn[0];
+    const RopeP r = a.r;
+    const bool neox = r.mode & 2;
+    const int half = r.n_dims / 2;
+    const long k_row = KQ8 ? (long) Hkv * NB * QB : (long) Hkv * DH * 2;
+    const long v_row = VQ8 ? (long) Hkv * NB * QB : (long) Hkv * DH * 2;
+    const long k_head = KQ8 ? (long) hk * NB * QB : (long) hk * DH * 2;
+    const long v_head = VQ8 ? (long) hk * NB * QB : (long) hk * DH * 2;
+    {   // rotate q (threads 0 .. DH/2-1) and k (DH/2 .. DH-1): attn_q8_token_kernel's arithmetic
+        const bool is_k = tid >= DH / 2;
+        const int pair = is_k ? tid - DH / 2 : tid;
+        const float * src = is_k ? a.k + (long) hk * DH : a.q + (long) h * DH;
+        int ia, ib;
+        if (pair < half) { ia = neox ? pair : 2 * pair; ib = neox ? pair + half : 2 * pair + 1; }
+        else             { ia = r.n_dims + 2 * (pair - half); ib = ia + 1; }
+        float o0 = src[ia], o1 = src[ib];
+        if (pair < half) {
+            float c, s_;
+            rope_cs(r, (float) pos, pair, a.ff, c, s_);
+            const float x0 = o0, x1 = o1;
+            o0 = x0 * c - x1 * s_; o1 = x0 * s_ + x1 * c;
+        }
+        float * dst = is_k ? kf : qf;
+        dst[ia] = o0; dst[ib] = o1;
+    }
+    __syncthreads();
+    const float xq = qf[tid], xk = kf[tid], xv = a.v[(long) hk * DH + tid];
+    uint8_t * kdst = a.kc + (long) slot * k_row + k_head, * vdst = a.vc + (long) slot * v_row + v_head;
+    if (KQ8) {
+        uint16_t d16;
+        const int qi = q8_quant32(xq, d16);
+        q_out[(long) h * DH + tid] = h2f(f2h((float) qi * h2f(d16)));
+        const int ki = q8_quant32(xk, d16);
+        if (writer) { uint8_t * o = kdst + (tid >> 5) * QB; if ((tid & 31) == 0) *(uint16_t *) o = d16; o[2 + (tid & 31)] = (uint8_t) (int8_t) ki; }
+    } else {
+        q_out[(long) h * DH + tid] = h2f(f2h(xq));
+        if (writer) ((uint16_t *) kdst)[tid] = f2h(xk);
+    }
+    if (VQ8) {
+        uint16_t d16;
+        const int vi = q8_quant32(xv, d16);
+        if (writer) { uint8_t * o = vdst + (tid >> 5) * QB; if ((tid & 31) == 0) *(uint16_t *) o = d16; o[2 + (tid & 31)] = (uint8_t) (int8_t) vi; }
+    } else if (writer) ((uint16_t *) vdst)[tid] = f2h(xv);
+}
+
 // > 48 KiB of dynamic LDS needs the function attribute once per (kernel, device); the kernels here share their pointer TYPE, so the
 // bookkeeping is keyed on the pointer value
 void set_lds(const void * kern, size_t lds) {
@@ -370,6 +427,24 @@ int pm_launch_flash_attn_ext_q8(const pm355_tensor * q, const pm355_tensor * k, 
     if (kq8 && vq8) go(flash_attn_ext_q8_kernel<true, true>);
     else if (kq8)   go(flash_attn_ext_q8_kernel<true, false>);
     else            go(flash_attn_ext_q8_kernel<false, true>);
+    return 0;
+}
+
+// one token, long context: RoPE + (quantizing) KV store in one small launch (q_rot receives the operand rows of the K.q product), then the caller
+// runs pm_launch_attn_flash_cached over the cached cells. Row-major caches. -1: unsupported
+int pm_launch_q8_token_prep(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos, const int32_t * dyn, const float * ff,
+                            float * q_rot, int H, int Hkv, int dh, int n_ctx, const pm_rope_cfg & c, int k_q8, int v_q8, hipStream_t st) {
+    if ((dh != 64 && dh != 128) || H % Hkv || (!k_q8 && !v_q8) || !dyn || !q_rot) return -1;
+    Q8TokP a = {};
+    a.q = q; a.k = k; a.v = v; a.kc = (uint8_t *) kc; a.vc = (uint8_t *) vc; a.pos = pos; a.dyn = dyn; a.ff = ff; a.H = H; a.Hkv = Hkv; a.n_ctx = n_ctx;
+    a.r.n_dims = c.n_dims; a.r.mode = c.mode; a.r.n_ctx_orig = c.n_ctx_orig; a.r.theta_scale = c.theta_scale; a.r.freq_scale = c.freq_scale;
+    a.r.ext_factor = c.ext_factor; a.r.attn_factor = c.attn_factor; a.r.corr0 = c.corr0; a.r.corr1 = c.corr1;
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(H), dim3(dh), 0, st, a, q_rot); };
+    if (dh == 128) {
+        if (k_q8 && v_q8) go(q8_token_prep_kernel<128, true, true>); else if (k_q8) go(q8_token_prep_kernel<128, true, false>); else go(q8_token_prep_kernel<128, false, true>);
+    } else {
+        if (k_q8 && v_q8) go(q8_token_prep_kernel<64, true, true>); else if (k_q8) go(q8_token_prep_kernel<64, true, false>); else go(q8_token_prep_kernel<64, false, true>);
+    }
     return 0;
 }
 

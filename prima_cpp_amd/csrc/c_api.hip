@@ -450,10 +450,11 @@ int pm355_attn_cached(const float * q_rot, void * kc, void * vc, const int32_t *
 int pm355_attn_cached_long(const float * q_rot, void * kc, void * vc, const int32_t * d_pos, const int32_t * d_cell_nkv, const void * mask,
                            float * out, float * scratch, int H, int Hkv, int dh, int n_ctx, float kq_scale, int max_cells, int flags, pm355_stream_t st) {
     if (!q_rot || !kc || !vc || !out || !scratch || (!d_pos && !d_cell_nkv)) return fail(PM355_E_SHAPE, "attn_cached_long: null pointer");
-    if (flags & ~(PM355_ATTN_MASK_F16 | PM355_ATTN_V_ROWMAJOR)) return fail(PM355_E_UNSUPPORTED, "attn_cached_long: F16 K / V caches only");
+    if (flags & ~(PM355_ATTN_MASK_F16 | PM355_ATTN_V_ROWMAJOR | PM355_ATTN_K_Q8_0 | PM355_ATTN_V_Q8_0)) return fail(PM355_E_UNSUPPORTED, "attn_cached_long: unknown flag");
     if (pm_launch_attn_flash_cached(q_rot, kc, vc, d_pos, nullptr, 0, out, scratch, H, Hkv, dh, n_ctx, kq_scale, S(st), d_cell_nkv, mask,
-                                    flags & PM355_ATTN_MASK_F16, max_cells, (flags & PM355_ATTN_V_ROWMAJOR) ? 1 : 0))
-        return fail(PM355_E_UNSUPPORTED, "attn_cached_long: head_dim must be 64/128, <= 16 query heads per KV head, n_ctx % 8 == 0");
+                                    flags & PM355_ATTN_MASK_F16, max_cells, (flags & PM355_ATTN_V_ROWMAJOR) ? 1 : 0,
+                                    (flags & PM355_ATTN_K_Q8_0) ? 1 : 0, (flags & PM355_ATTN_V_Q8_0) ? 1 : 0))
+        return fail(PM355_E_UNSUPPORTED, "attn_cached_long: head_dim must be 64/128, <= 16 query heads per KV head, n_ctx % 8 == 0; Q8_0 caches need row-major V");
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -467,7 +468,21 @@ int pm355_attn_token(const pm355_attn_token_args * a, const pm355_rope_params * 
     pm_rope_params(c);
     (void) hipGetLastError();
     if (a->flags & (PM355_ATTN_K_Q8_0 | PM355_ATTN_V_Q8_0)) {
-        if (!(a->flags & PM355_ATTN_V_ROWMAJOR) || a->split) return fail(PM355_E_UNSUPPORTED, "attn_token: a quantized KV cache needs row-major V and the one-workgroup-per-head path");
+        if (!(a->flags & PM355_ATTN_V_ROWMAJOR)) return fail(PM355_E_UNSUPPORTED, "attn_token: a quantized KV cache needs row-major V (flash-attention graphs)");
+        if (a->split) {
+            // long context: RoPE + quantizing KV store (one small launch), then scores and P.V on the matrix cores over the cached Q8_0 / F16 cells
+            // (attn_flash_mfma.hip); max_keys = cells the grid is sized for, scratch zeroed once after its allocation
+            if (!a->scratch) return fail(PM355_E_SHAPE, "attn_token(q8_0, long): scratch");
+            float * q_rot = a->scratch + pm_attn_flash_qrot_offset(a->n_head, a->n_head_kv, a->head_dim, a->n_ctx);
+            const int kq = (a->flags & PM355_ATTN_K_Q8_0) ? 1 : 0, vq = (a->flags & PM355_ATTN_V_Q8_0) ? 1 : 0;
+            if (pm_launch_q8_token_prep(a->q, a->k, a->v, a->k_cache, a->v_cache, a->d_pos, a->d_cell_nkv, a->freq_factors, q_rot, a->n_head, a->n_head_kv,
+                                        a->head_dim, a->n_ctx, c, kq, vq, S(st)) ||
+                pm_launch_attn_flash_cached(q_rot, a->k_cache, a->v_cache, nullptr, nullptr, 0, a->out, a->scratch, a->n_head, a->n_head_kv, a->head_dim, a->n_ctx,
+                                            a->kq_scale, S(st), a->d_cell_nkv, a->mask, a->flags & PM355_ATTN_MASK_F16, a->max_keys, 1, kq, vq))
+                return fail(PM355_E_UNSUPPORTED, "attn_token(q8_0, long): head_dim 64/128, <= 16 query heads per KV head, <= 16 KV heads, n_ctx % 8 == 0");
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         if (pm_launch_attn_q8_token(a->q, a->k, a->v, a->k_cache, a->v_cache, a->d_pos, a->d_cell_nkv, a->mask, a->flags & PM355_ATTN_MASK_F16,
                                     a->freq_factors, a->out, a->n_head, a->n_head_kv, a->head_dim, a->n_ctx, a->kq_scale, c,
                                     a->flags & PM355_ATTN_K_Q8_0, a->flags & PM355_ATTN_V_Q8_0, a->max_keys, S(st)))

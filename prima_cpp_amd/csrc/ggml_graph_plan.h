@@ -442,7 +442,9 @@ private:
         const int out_idx = hi - 1;                                  // the CONT node / the RESHAPE of the flash-attention result
         // supported by the kernels?
         const bool q8 = kq8 || vq8;                                   // quantized cache: one workgroup per head only, head_dim 64 / 128
-        const bool can_split = (dh == 64 || dh == 128) && H / Hkv <= 8 && !q8;
+        // long contexts: keys split over workgroups; a quantized cache takes the matrix-core kernel over cached cells behind a rope + store launch (round 5)
+        const bool can_split = (dh == 64 || dh == 128) && H / Hkv <= 8 &&
+                               (!q8 || (fa && c_.attn_mfma && pm355_attn_cached_long_check((int) H, (int) Hkv, (int) dh, (int) n_ctx) == 0));
         const bool can_fused = dh == 64 || dh == 128 || (dh == 256 && !q8);
         bool split = n_kv >= c_.split_min && can_split;
         float * split_mem = nullptr;

@@ -32,7 +32,9 @@ size_t pm_attn_flash_scratch_floats(int H, int Hkv, int dh, int n_ctx);
 int  pm_attn_flash_cached_ok(int H, int Hkv, int dh, int n_ctx);      // 0: served by the matrix-core long-context kernel
 int  pm_launch_attn_flash_cached(const float * q_rot, void * kc, void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride, float * out,
                                  float * scratch, int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st, const int32_t * dyn,
-                                 const void * mask, int mask_f16, int max_cells, int v_rowmajor = 0);
+                                 const void * mask, int mask_f16, int max_cells, int v_rowmajor = 0, int k_q8 = 0, int v_q8 = 0);
+// where the long-context Q8_0 path parks the token's rotated (and, for a Q8_0 K cache, Q8_0-quantized) query rows inside the attention scratch
+size_t pm_attn_flash_qrot_offset(int H, int Hkv, int dh, int n_ctx);
 int  pm_launch_attn_flash(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos0, const int32_t * seq,
                           long seq_stride, const float * freq_factors, float * out, float * scratch, int H, int Hkv, int dh, int n_ctx,
                           float scale, const pm_rope_cfg & c, hipStream_t st, const int32_t * dyn = nullptr, const void * mask = nullptr,
@@ -64,6 +66,8 @@ void pm_launch_set_i32x2(int32_t * p, int a, int b, hipStream_t st);
 int  pm_launch_cpy_f32_q8_0(const pm355_tensor * src, void * dst, hipStream_t st);
 int  pm_launch_flash_attn_ext_q8(const pm355_tensor * q, const pm355_tensor * k, const pm355_tensor * v, const pm355_tensor * mask,
                                  const pm355_tensor * dst, float scale, float softcap, hipStream_t st);
+int  pm_launch_q8_token_prep(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos, const int32_t * dyn, const float * ff,
+                             float * q_rot, int H, int Hkv, int dh, int n_ctx, const pm_rope_cfg & c, int k_q8, int v_q8, hipStream_t st);
 int  pm_launch_attn_q8_token(const float * q, const float * k, const float * v, void * kc, void * vc, const int32_t * pos, const int32_t * dyn,
                              const void * mask, int mask_f16, const float * ff, float * out, int H, int Hkv, int dh, int n_ctx, float scale,
                              const pm_rope_cfg & c, int k_q8, int v_q8, int max_keys, hipStream_t st);

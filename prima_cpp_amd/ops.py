@@ -366,6 +366,33 @@ def mul_mat_vec_qkv(ws, x, tab, pos, k_cache, v_cache, n_head_kv, head_dim, n_ct
     return q
 
 
+ATTN_V_ROWMAJOR, ATTN_MASK_F16, ATTN_K_Q8_0, ATTN_V_Q8_0 = 1, 2, 4, 8
+
+
+class AttnTokenArgs(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("q", _C.c_void_p), ("k", _C.c_void_p), ("v", _C.c_void_p), ("k_cache", _C.c_void_p), ("v_cache", _C.c_void_p), ("d_pos", _C.c_void_p),
+                ("d_cell_nkv", _C.c_void_p), ("mask", _C.c_void_p), ("freq_factors", _C.c_void_p), ("out", _C.c_void_p), ("scratch", _C.c_void_p),
+                ("n_head", _C.c_int32), ("n_head_kv", _C.c_int32), ("head_dim", _C.c_int32), ("n_ctx", _C.c_int32), ("split", _C.c_int32), ("max_keys", _C.c_int32),
+                ("kq_scale", _C.c_float), ("flags", _C.c_int32)]
+
+
+def attn_token(q, k, v, k_cache, v_cache, pos, cell_nkv, n_head, n_head_kv, head_dim, n_ctx, scale, flags=0, mask=None, freq_factors=None, scratch=None,
+               max_keys=0, mode=0, freq_base=10000.0, n_dims=None):
+    """pm355_attn_token: one token's RoPE + KV store + attention (the plug-in's ggml-graph mode: cell_nkv = int32 {cache cell, cells attended}); raw q / k / v
+    projections in, attention output [n_head * head_dim] out. scratch != None: the long-context (split) form."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_attn_token.restype = C.c_int
+    lib.pm355_attn_token.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    out = torch.empty(n_head * head_dim, dtype=torch.float32, device=q.device)
+    a = AttnTokenArgs(ptr(q), ptr(k), ptr(v), ptr(k_cache), ptr(v_cache), ptr(pos), ptr(cell_nkv), ptr(mask), ptr(freq_factors), ptr(out), ptr(scratch),
+                      n_head, n_head_kv, head_dim, n_ctx, 1 if scratch is not None else 0, max_keys, float(scale), flags)
+    rp = RopeParams(n_dims or head_dim, mode, 8192, freq_base, 1.0, 0.0, 1.0, 32.0, 1.0)
+    check(lib.pm355_attn_token(C.addressof(a), C.addressof(rp), stream_ptr()), "attn_token")
+    return out
+
+
 class QkvAttn(__import__("ctypes").Structure):
     import ctypes as _C
     _fields_ = [("out", _C.c_void_p), ("ticket", _C.c_void_p), ("watchdog", _C.c_void_p), ("kq_scale", _C.c_float), ("n_head", _C.c_int32), ("max_keys", _C.c_int32)]

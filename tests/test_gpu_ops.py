@@ -1045,3 +1045,93 @@ def test_attention_in_the_qkv_launch_tail_equals_the_two_launches(P, shape, tv, 
         assert torch.equal(q2, q1), (n_past, (q2 - q1).abs().max())
         assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1), n_past
         assert torch.equal(a2, a1), (n_past, (a2 - a1).abs().max())
+
+
+def _q8_cache(oracle, rng, n_ctx, Ekv):
+    f = rng.normal(0, 1, (n_ctx, Ekv)).astype(np.float32)
+    blocks = np.concatenate([oracle.quantize_row_q8_0(f[i]) for i in range(n_ctx)])
+    deq = np.stack([oracle.dequantize_row(Q8_0, blocks[i * (Ekv // 32 * 34):(i + 1) * (Ekv // 32 * 34)], Ekv) for i in range(n_ctx)])
+    return blocks, deq
+
+
+@pytest.mark.parametrize("kq8,vq8", [(True, True), (True, False), (False, True)])
+@pytest.mark.parametrize("shape", [(64, 8, 128), (32, 8, 128), (16, 4, 64)])
+@pytest.mark.parametrize("n_kv", [700, 2500, 8200])
+def test_long_context_attention_over_q8_0_caches_on_the_matrix_cores(P, oracle, kq8, vq8, shape, n_kv):
+    """Round 5: attn_flash_mfma.hip over Q8_0 K and / or V caches (native 34-byte blocks, row-major V: `-fa -ctk q8_0 -ctv q8_0`,
+    src/llama.cpp:3531-3560, :10075-10095) - the dequantizing operand fetch (q_i * d rounded to F16 per value) against float64 attention over the
+    dequantized cache values (dequantize_row_q8_0 / F16), 2e-3 of max |out| as for the F16 caches (probabilities are rounded to F16 as MFMA
+    operands), at the Llama-3-70B / 8B head shapes and a head_dim-64 one, 700 .. 8200 cells."""
+    torch = P.torch
+    H, Hkv, dh = shape
+    Ekv = Hkv * dh
+    n_ctx = ((n_kv + 300) // 256) * 256
+    rng = np.random.default_rng(n_kv + H + 2 * kq8 + vq8)
+    if kq8:
+        kb, kd = _q8_cache(oracle, rng, n_ctx, Ekv)
+        kc = torch.from_numpy(kb).cuda()
+    else:
+        kd = rng.normal(0, 1, (n_ctx, Ekv)).astype(np.float16).astype(np.float32)
+        kc = torch.from_numpy(kd.astype(np.float16)).cuda()
+    if vq8:
+        vb, vd = _q8_cache(oracle, rng, n_ctx, Ekv)
+        vc = torch.from_numpy(vb).cuda()
+    else:
+        vd = rng.normal(0, 1, (n_ctx, Ekv)).astype(np.float16).astype(np.float32)
+        vc = torch.from_numpy(vd.astype(np.float16)).cuda()
+    q = rng.normal(0, 1, (H, dh)).astype(np.float16).astype(np.float32)
+    scale = 1.0 / np.sqrt(dh)
+    dyn = torch.tensor([n_kv - 1, n_kv], dtype=torch.int32, device="cuda")
+    scratch = P.attn_split_scratch(H, dh, n_ctx)
+    grid = 1024
+    while grid < n_kv:
+        grid *= 2
+    flags = P.ATTN_V_ROWMAJOR | (P.ATTN_K_Q8_0 if kq8 else 0) | (P.ATTN_V_Q8_0 if vq8 else 0)
+    out = P.attn_cached(torch.from_numpy(q.reshape(1, -1)).cuda(), kc, vc, None, H, Hkv, dh, n_ctx, scale, cell_nkv=dyn, max_keys=min(grid, n_ctx), flags=flags, scratch=scratch)
+    got = out.cpu().numpy().reshape(H, dh)
+    want = np.zeros((H, dh))
+    for h in range(H):
+        hk = h // (H // Hkv)
+        K = kd[:n_kv, hk * dh:(hk + 1) * dh].astype(np.float64)
+        V = vd[:n_kv, hk * dh:(hk + 1) * dh].astype(np.float64)
+        s = K @ q[h].astype(np.float64) * scale
+        p = np.exp(s - s.max())
+        want[h] = (p / p.sum()) @ V
+    err = np.abs(got - want).max()
+    assert err <= 2e-3 * np.abs(want).max(), (err, np.abs(want).max())
+
+
+@pytest.mark.parametrize("kq8,vq8", [(True, True), (True, False), (False, True)])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_long_context_q8_0_token_step_matches_the_one_workgroup_per_head_kernel(P, oracle, kq8, vq8, mode):
+    """pm355_attn_token with Q8_0 caches beyond the long-context threshold: rope + quantizing KV store (attn_q8.hip q8_token_prep_kernel) + the matrix-core
+    kernel over the cached cells, against the one-workgroup-per-head kernel that serves short contexts (attn_q8_token_kernel: the reference's
+    block-wise integer K.q, f32 P.V): the same bytes in both caches (quantize_row_q8_0_ref of the rotated k / of v), outputs within the F16-operand
+    tier of each other and of float64."""
+    torch = P.torch
+    H, Hkv, dh, n_kv = 32, 8, 128, 1500
+    Ekv, n_ctx = Hkv * dh, 2048
+    rng = np.random.default_rng(500 + 2 * kq8 + vq8 + mode)
+    def cache(q8):
+        if q8:
+            b, _ = _q8_cache(oracle, rng, n_ctx, Ekv)
+            return torch.from_numpy(b).cuda()
+        return torch.from_numpy(rng.normal(0, 1, (n_ctx, Ekv)).astype(np.float16)).cuda()
+    kc0, vc0 = cache(kq8), cache(vq8)
+    q = torch.from_numpy(rng.normal(0, 1, (1, H * dh)).astype(np.float32)).cuda()
+    k = torch.from_numpy(rng.normal(0, 1, (1, Ekv)).astype(np.float32)).cuda()
+    v = torch.from_numpy(rng.normal(0, 1, (1, Ekv)).astype(np.float32)).cuda()
+    pos = torch.tensor([n_kv - 1], dtype=torch.int32, device="cuda")
+    dyn = torch.tensor([n_kv - 1, n_kv], dtype=torch.int32, device="cuda")
+    flags = P.ATTN_V_ROWMAJOR | (P.ATTN_K_Q8_0 if kq8 else 0) | (P.ATTN_V_Q8_0 if vq8 else 0)
+    scale = 1.0 / np.sqrt(dh)
+    kc1, vc1, kc2, vc2 = kc0.clone(), vc0.clone(), kc0.clone(), vc0.clone()
+    a1 = P.attn_token(q, k, v, kc1, vc1, pos, dyn, H, Hkv, dh, n_ctx, scale, flags=flags, mode=mode, freq_base=500000.0)
+    scratch = P.attn_split_scratch(H, dh, n_ctx)
+    a2 = P.attn_token(q, k, v, kc2, vc2, pos, dyn, H, Hkv, dh, n_ctx, scale, flags=flags, mode=mode, freq_base=500000.0, scratch=scratch, max_keys=2048)
+    torch.cuda.synchronize()
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
+    d = (a2 - a1).abs().max().item()
+    assert d <= 2e-3 * a1.abs().max().item(), (d, a1.abs().max().item())
+    nm = float(((a2 - a1).double() ** 2).sum() / (a1.double() ** 2).sum())
+    assert nm < 1e-5, nm

@@ -185,6 +185,40 @@ def test_peaked_fixture_long_context_tokens_identical(gpu, files, mode, monkeypa
         assert _nmse(lg, ls) < 1e-3
 
 
+@pytest.mark.parametrize("kv", [["-ctk", "q8_0", "-ctv", "q8_0"], ["-ctk", "q8_0"]], ids=["q8_0-kv", "q8_0-k"])
+def test_peaked_fixture_long_context_q8_0_cache_tokens_identical(gpu, files, kv):
+    """Round 5: `-fa -ctk q8_0 [-ctv q8_0]` beyond the long-context threshold - a 700-token prompt, then 24 greedy tokens whose attention
+    runs rope + quantizing KV store + the matrix-core kernel over the cached Q8_0 cells (attn_flash_mfma.hip) - against the reference CPU running the same
+    flash-attention graph on the same quantized cache types: the same 24 tokens, logits within the reference's tolerance for the flash-attention op."""
+    if "small" not in SIZES:
+        pytest.skip("PM355_8D_SIZES without 'small'")
+    size, n_prompt, n_gen, n_ctx = "small", 700, 24, 1024
+    V = SHAPES[size]["n_vocab"]
+    prompt = F.prompt_tokens(V, n_prompt)
+    path = files.path(size, True)
+    args = ["-fa"] + kv
+    ts, ls, _ = run_llama_driver(path, prompt, n_gen, ngl=0, n_ctx=n_ctx, threads=_threads(), flavour=best_ref_flavour(), timeout=3000, extra_args=args)
+    expect = [F.peaked_next(prompt[-1], V)]
+    for _ in range(n_gen - 1):
+        expect.append(F.peaked_next(expect[-1], V))
+    assert ts.tolist() == expect
+    tg, lg, st = run_llama_driver(path, prompt, n_gen, ngl=99, n_ctx=n_ctx, threads=_threads(), timeout=1800, extra_args=GPU_ARGS + args,
+                                  env={"GGML_MI355_DEBUG_PLAN": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1"})
+    assert "split" in st["stderr"], st["stderr"][-2000:]
+    # yardstick: the same run on the one-workgroup-per-head kernel that serves short contexts (GGML_MI355_ATTN_MFMA=0: the reference's block-wise integer
+    # K.q). Both see the same 700 prompt cells - stored by the F16 prompt GEMMs and then QUANTIZED, so they differ from the CPU's cells by whole Q8_0
+    # steps wherever a value sat near a rounding boundary: that, not the attention kernel, sets the distance to the CPU
+    to, lo, so = run_llama_driver(path, prompt, n_gen, ngl=99, n_ctx=n_ctx, threads=_threads(), timeout=1800, extra_args=GPU_ARGS + args,
+                                  env={"GGML_MI355_ATTN_MFMA": "0", "GGML_MI355_DEBUG_PLAN": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1"})
+    print(f"\n[8d small peaked, 700-token prompt, -fa {' '.join(kv)}] tokens {(tg == ts).sum()}/{n_gen} identical to the reference CPU; logits NMSE {_nmse(lg, ls):.2e} "
+          f"(one-workgroup-per-head kernel on the same cells: {_nmse(lo, ls):.2e}; the two kernels against each other: {_nmse(lg, lo):.2e})")
+    assert tg.tolist() == ts.tolist() and to.tolist() == ts.tolist()
+    # (kernel against kernel: the first token's logits are the same to 1e-7; from then on each run attends the cells IT stored - a rotated k that
+    #  differs in the last F16-operand bit moves a Q8_0 value by a whole step now and then: ~1e-4 after 24 tokens. The op test holds the kernels to 1e-5.)
+    assert _nmse(lg[0], lo[0]) < 1e-6 and _nmse(lg, lo) < 1e-3
+    assert _nmse(lg, ls) < max(1e-3, 1.5 * _nmse(lo, ls))
+
+
 def test_peaked_fixture_8k_prompt_tokens_identical(gpu, files):
     """whole-model equality beyond 8k cached cells. An 8200-token prompt - prompt chunks on the prefill path, then 16 greedy tokens
     whose attention runs the matrix-core kernel over > 8k cached cells - against the reference CPU through the plug-in's default graph and on the
