@@ -662,6 +662,47 @@ def section_long_context(name="llama3-70b", ctxs=(8192, 32768)):
         kvb = 2 * n_kv * Nkv * 2
         kern[str(ctx)] = {"us_per_launch": round(us, 2), "kv_bytes_per_launch": kvb,
                           "roofline": {"bound": "hbm", "achieved": round(kvb / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kvb / us / 1e3 / HBM_PEAK_GBS, 4)}}
+    # the same kernel over Q8_0 K / V caches (-fa -ctk q8_0 -ctv q8_0: native 34-byte blocks, row-major V; random valid blocks)
+    try:
+        del kcs, vcs
+        torch.cuda.empty_cache()
+        row_b = Nkv // 32 * 34
+        def q8_cache():
+            b = torch.randint(-127, 128, (n_ctx * Nkv // 32, 34), dtype=torch.int8, device="cuda", generator=g)
+            d = (torch.rand(n_ctx * Nkv // 32, device="cuda", generator=g) * 0.02 + 0.002).to(torch.float16).view(torch.int16)
+            b[:, 0] = (d & 0xFF).to(torch.int8)
+            b[:, 1] = ((d >> 8) & 0xFF).to(torch.int8)
+            return b.view(-1)
+        nb8 = max(2, int(600e6 / (n_ctx * row_b * 2)) + 1)
+        k8 = [q8_cache() for _ in range(nb8)]
+        v8 = [q8_cache() for _ in range(nb8)]
+        flags = P.ATTN_V_ROWMAJOR | P.ATTN_K_Q8_0 | P.ATTN_V_Q8_0
+        kern8 = {}
+        for ctx in ctxs:
+            n_kv = ctx - 7
+            dyn = torch.tensor([n_kv - 1, n_kv], dtype=torch.int32, device="cuda")
+            grid = 1024
+            while grid < n_kv:
+                grid *= 2
+            grid = min(grid, n_ctx)
+            run8 = lambda i: P.attn_cached(q, k8[i % nb8], v8[i % nb8], None, H, Hkv, dh, n_ctx, dh ** -0.5, cell_nkv=dyn, max_keys=grid, flags=flags, scratch=scratch)
+            for i in range(nb8):
+                run8(i)
+            torch.cuda.synchronize()
+            reps = 10 * nb8
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(reps):
+                run8(i)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            kvb = 2 * n_kv * row_b
+            kern8[str(ctx)] = {"us_per_launch": round(us, 2), "kv_bytes_per_launch": kvb,
+                               "roofline": {"bound": "hbm", "achieved": round(kvb / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kvb / us / 1e3 / HBM_PEAK_GBS, 4)}}
+        out["attention_kernel_q8_0_kv"] = {"kernel": "attn_flash_mfma_kernel<.., K Q8_0, V Q8_0> (operand slices dequantized on the fly: q * d rounded to F16)", "cells": kern8}
+    except Exception as e:
+        out["attention_kernel_q8_0_kv"] = {"error": str(e)[:300]}
     out["attention_kernel"] = {"kernel": "attn_flash_mfma_kernel (scores and P.V of a GQA group on v_mfma_f32_16x16x32_f16, keys split over workgroups, in-launch merge)",
                                "shape": f"H {H} Hkv {Hkv} head_dim {dh}", "timing": "HIP events over eager launches on torch's current stream (the launch stream), caches rotated out of the infinity cache",
                                "cells": kern}
