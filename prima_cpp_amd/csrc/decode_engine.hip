@@ -522,7 +522,7 @@ __global__ __launch_bounds__(ENG_THREADS, 4) void decode_engine_kernel(EngArgs A
                 write_out_qkv<true>(p.job[1], p.epi, outbuf, r0_1, r1_1, ob_1, tid, cpr_1, epi_slot, epi_off, ec1, es1);
                 write_out_qkv<true>(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off, ec2, es2);
             } else {
-                const double ss = write_out<true, 1>(p.job[0], outbuf, r0_0, r1_0, 0, tid, 0, cpr_0);
+                const double ss = write_out<true, 1, true>(p.job[0], outbuf, r0_0, r1_0, 0, tid, 0, cpr_0);
                 if (p.ss_out && wave == 0) {               // (rows <= 64 per workgroup: checked by the host)
                     const double ws = wave_sum_f64(ss);
                     if (lane == 0) __hip_atomic_store((PM_G double *) (p.ss_out + b), ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -55,8 +55,10 @@ struct pm355_model {
     bool qkv_epi = true; float * rope_tab = nullptr;
     // producer-side sum of squares (round 5): the wo / ffn_down launches leave the per-workgroup partials of the NEXT rms_norm's sum of squares
     // in ss[0] / ss[1] (256 doubles each); the consuming wq | wk | wv, ffn_gate | ffn_up and lm_head launches add them instead of reducing the row.
-    // PM355_SS=0: every norm prologue reduces its own row (the round-4 form)
-    bool use_ss = true; double * ss = nullptr;
+    // OPT-IN (PM355_SS=1): the same bits, and a net LOSS of 0.4 % on the 70B token - the partials cost the wo / ffn_down launches 0.8 us each and buy
+    // the consumers nothing measurable (their reduction pass hides behind the pre-issued weight loads): profiles/r05_ab_sumsq_q6k_tail.txt. The code
+    // lives in kernel instantiations of its own (PM_FEAT_SS) because its mere presence cost every launch 0.55 us. Default: every prologue reduces its row
+    bool use_ss = false; double * ss = nullptr;
     // attention in the tail of the wq | wk | wv launch (round 5, pm_qkv_epi::att_out): the short-context regime's attention launch and its boundary
     // disappear - four launches per layer. att_tk: 64 per-KV-head ticket counters + the watchdog word. OPT-IN (PM355_ATTN_TAIL=1): the same bits as the
     // separate launch and 1.6 % SLOWER per 70B token (8.955 against 8.817 ms, interleaved A/B, profiles/r05_attention_tail.txt) - q and the new cell
@@ -271,7 +273,10 @@ void layer_release(pm355_model * m, int il, hipStream_t st) {
 
 // quantize `src` [T][K] into the activation format(s) the given weights need; returns pointers
 struct ActQ { const void * k = nullptr; const void * z = nullptr; bool tab = false; };   // tab: the small-batch mat-mul's activation tables were written too
-const int MMQ_MIN_TOKENS = 3, MMQ_MAX_TOKENS = 64;      // (3 columns cost the multi-column mat-vec two passes: 57 vs 39 us on the ffn shape)
+const int MMQ_MIN_TOKENS = 3;                           // (3 columns cost the multi-column mat-vec two passes: 57 vs 39 us on the ffn shape)
+// largest batch on the integer matrix cores (mmq_i8.hip: the CPU's Q8_K arithmetic, one weight pass per 32 tokens); beyond it the F16 GEMMs (mmq.hip).
+// PM355_MMQ_MAX_TOKENS = 16 .. 64 moves the crossover (measurement: profiles/r05_small_batch_crossover.txt; 64 stays - the F16 path is another parity tier)
+const int MMQ_MAX_TOKENS = [] { const char * e = getenv("PM355_MMQ_MAX_TOKENS"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 64 ? v : 64; }();
 const int MMQ_MULTI_MIN_TOKENS = 2;       // the fused wq | wk | wv and ffn_gate | ffn_up launches already win at 2 tokens (3 / 4 mat-vec launches otherwise)
 // the table output of the Q8_K quantizers, when this batch size takes the small-batch mat-mul (mmq_i8.hip)
 pm_q8k_tables mmq_tables(const pm355_model * m, int K, int T, hipStream_t st) {
@@ -444,7 +449,7 @@ pm355_model::EnginePlan * engine_plan_for(pm355_model * m, const float * cur, fl
 }
 
 bool engine_eligible(const pm355_model * m) {
-    return m->use_engine && !m->no_fuse && !m->long_ctx && !m->n_slots && m->use_ss && m->ss && m->qkv_epi && m->rope_tab && (m->rope.mode == 0 || m->rope.mode == 2) && m->hi > m->lo;
+    return m->use_engine && !m->no_fuse && !m->long_ctx && !m->n_slots && m->ss && m->qkv_epi && m->rope_tab && (m->rope.mode == 0 || m->rope.mode == 2) && m->hi > m->lo;
 }
 
 // which single-token attention path the current sequence takes: 0 = one workgroup per head; else the cells the long-context grid is
@@ -818,7 +823,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     { const char * e = getenv("PM355_NO_MMQ_I8"); m->no_mmq = e && e[0] == '1'; }     // 4..64-token batches: mat-vec columns / F16 GEMM from 16 (the round-1 paths)
     { const char * e = getenv("PM355_QKV_EPI"); m->qkv_epi = !(e && e[0] == '0'); }
     { const char * e = getenv("PM355_PROMPT_I8"); m->no_big = !(e && e[0] == '1'); }
-    { const char * e = getenv("PM355_SS"); m->use_ss = !(e && e[0] == '0'); }
+    { const char * e = getenv("PM355_SS"); m->use_ss = e && e[0] == '1'; }
     { const char * e = getenv("PM355_ENGINE"); m->use_engine = e && e[0] == '1'; }
     { const char * e = getenv("PM355_ATTN_TAIL"); m->attn_tail = e && e[0] == '1'; }
     return m;

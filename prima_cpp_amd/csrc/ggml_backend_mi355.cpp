@@ -126,7 +126,7 @@ struct backend_ctx {
     // graph lowering (ggml_graph_plan.h)
     int32_t * d_dyn = nullptr;                       // device int32[2]: {KV cell of the token, cells attended}
     float * rope_tab = nullptr;                      // device float[256]: this token's cos / sin per rotation pair (round-3 attention block)
-    double * ss_buf = nullptr; bool use_ss = true;   // producer-side sum-of-squares partials, double[2][256] (GGML_MI355_SS=0: off)
+    double * ss_buf = nullptr; bool use_ss = false;  // producer-side sum-of-squares partials, double[2][256]: opt-in (GGML_MI355_SS=1; same bits, measured -0.4 %)
     bool attn_mfma = true;                           // GGML_MI355_ATTN_MFMA=0: long contexts keep the round-2 flash-decoding kernel
     bool qkv_epi = true;                             // GGML_MI355_QKV_EPI=0: rope + KV store inside the attention kernel (the round-2 form)
     float * qkv = nullptr; size_t qkv_floats = 0;    // raw q / k / v projections of one token
@@ -908,7 +908,7 @@ ggml_backend_t ggml_backend_mi355_init(int device) {
     c->fuse = !env_on("GGML_MI355_NO_FUSE");                          // node-by-node kernels only (debug / A-B)
     if (const char * am = getenv("GGML_MI355_ATTN_MFMA")) if (am[0] == '0') c->attn_mfma = false;
     if (const char * qe = getenv("GGML_MI355_QKV_EPI")) if (qe[0] == '0') c->qkv_epi = false;   // rope + KV store inside the attention kernel (round-2 form)
-    if (const char * se = getenv("GGML_MI355_SS")) if (se[0] == '0') c->use_ss = false;         // every rms_norm prologue reduces its own row (round-4 form)
+    if (const char * se = getenv("GGML_MI355_SS")) c->use_ss = se[0] == '1';                    // default: every rms_norm prologue reduces its own row
     c->use_graphs = !env_on("GGML_MI355_NO_GRAPH") && !plan_only();   // no hipGraph capture / replay
     c->debug_plan = env_on("GGML_MI355_DEBUG_PLAN") || plan_only();
     if (const char * sm = getenv("GGML_MI355_ATTN_SPLIT_MIN")) if (sm[0]) c->split_min = atoi(sm);

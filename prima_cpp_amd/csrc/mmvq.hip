@@ -34,7 +34,8 @@ namespace {
 // The first things a workgroup does - the activation loads and the pre-issued weight loads of job 0 - need six values of the argument block. They
 // travel as LEADING scalar kernel arguments as well, which the dispatcher preloads into SGPRs (-mllvm -amdgpu-kernarg-preload-count, build.py):
 // the wave starts issuing its loads without first waiting for an s_load of the kernarg segment (a by-value struct is never preloaded).
-template <int TA, int TB, bool PAIR, bool DBG, bool EPI = false, int NPRE = 2>
+// FEAT (mmvq_device.h): PM_FEAT_SS / PM_FEAT_TAIL code lives in instantiations of its own - a launch that uses neither runs the plain kernel
+template <int TA, int TB, bool PAIR, bool DBG, bool EPI = false, int NPRE = 2, int FEAT = 0>
 __global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(const float * xf, const float * norm_w, const uint8_t * W0, const uint8_t * W0b, long row_stride0,
                                                                   int K, int xmode, int N0, int U0, GemvP p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(const float * 
     p.xf = xf; p.norm_w = norm_w; p.K = K; p.xmode = xmode;
     p.job[0].W = W0; p.job[0].W2 = W0b; p.job[0].row_stride = row_stride0; p.job[0].N = N0; p.job[0].U = U0;
     // (Q5_K: two 32-weight units per lane and step = 24-VGPR sets with the high-bit plane; a second pre-issued set spills)
-    gemv_body<TA, TB, PAIR, DBG, 1, EPI, (TA == PM_Q5_K && NPRE == 2) ? 1 : NPRE>(p, smem, nred);
+    gemv_body<TA, TB, PAIR, DBG, 1, EPI, (TA == PM_Q5_K && NPRE == 2) ? 1 : NPRE, FEAT>(p, smem, nred);
 }
 template <int TA, int TB>
 int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, hipStream_t st, bool epi = false) {
@@ -52,15 +53,25 @@ int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, 
         pm_allow_big_lds((const void *) kern, lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(PM_GEMV_BLOCK), lds, st, p.xf, p.norm_w, p.job[0].W, p.job[0].W2, p.job[0].row_stride, p.K, p.xmode, p.job[0].N, p.job[0].U, p);
     };
+    const bool ss = p.ss_out != nullptr || p.xmode == 3;          // producer or consumer of per-workgroup partial sums of squares
+    const bool tail = epi && p.epi.att_out != nullptr;
     if (pair) {
         if (TA != TB) return -1;
         // (pair launches: one step of pre-issue - two sets of two matrices next to the activation registers spill)
-        if (dbg) go(gemv_q_kernel<TA, TA, true, true, false, 1>); else go(gemv_q_kernel<TA, TA, true, false, false, 1>);
+        if (dbg) { if (ss) return -6; go(gemv_q_kernel<TA, TA, true, true, false, 1>); }
+        else if (ss) go(gemv_q_kernel<TA, TA, true, false, false, 1, PM_FEAT_SS>);
+        else go(gemv_q_kernel<TA, TA, true, false, false, 1>);
     } else if (epi) {
         if (dbg) return -1;
-        go(gemv_q_kernel<TA, TB, false, false, true>);
+        if (tail) {
+            // the tail is compiled for the wq | wk | wv type mixtures of the Q4_K_M files only (wq Q4_K; wv Q4_K / Q5_K / Q6_K)
+            if constexpr (TA == PM_Q4_K) { if (ss) go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_SS | PM_FEAT_TAIL>); else go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_TAIL>); }
+            else return -7;
+        } else if (ss) go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_SS>);
+        else go(gemv_q_kernel<TA, TB, false, false, true>);
     } else {
-        if (dbg) go(gemv_q_kernel<TA, TB, false, true, false, 1>);     // (test hook: one pre-issued step - with two, the Q6_K form sat on the 128-VGPR cliff with a spilled register)
+        if (dbg) { if (ss) return -6; go(gemv_q_kernel<TA, TB, false, true, false, 1>); }     // (test hook: one pre-issued step - with two, the Q6_K form sat on the 128-VGPR cliff with a spilled register)
+        else if (ss) go(gemv_q_kernel<TA, TB, false, false, false, 2, PM_FEAT_SS>);
         else go(gemv_q_kernel<TA, TB, false, false>);
     }
     return 0;

@@ -334,7 +334,14 @@ __device__ __forceinline__ void q80_block_to_lds(const float v[4], int i4 /*inde
 //                      are loaded ONCE and stay in registers between the sum-of-squares and the quantization.
 //   ABLK = 32  (Q8_0): thread t owns the float4s t, t + 1024, ... (8 lanes = one 32-block); K <= 16384 held in registers.
 // f[0] / f[1]: the two passes of a row of up to 128 blocks; with norm weights (held for <= 64 blocks = one pass) f[1] carries the weights
-struct ActRegs { float4 f[2][4]; double ssp[4]; };      // ssp: xmode 3, this lane's share of the producer's partial sums (n_ss <= 256)
+// Kernel FEATURES that are compiled into their own instantiations (template parameter FEAT of gemv_body / gemv_q_kernel), because their mere presence
+// costs the kernels that do not use them (measured, profiles/r05_ab_sumsq_q6k_tail.txt: the sum-of-squares code +0.55 us on every launch, unused):
+//   PM_FEAT_SS    producer-side sum of squares: xmode 3 prologues and the ss_out epilogue
+//   PM_FEAT_TAIL  attention in the tail of the wq | wk | wv launch (QkvEpi::att_out)
+constexpr int PM_FEAT_SS = 1, PM_FEAT_TAIL = 2;
+template <bool SS> struct ActRegsT;
+template <> struct ActRegsT<false> { float4 f[2][4]; };
+template <> struct ActRegsT<true>  { float4 f[2][4]; double ssp[4]; };      // ssp: xmode 3, this lane's share of the producer's partial sums (n_ss <= 256)
 
 template <int ABLK>
 __device__ __forceinline__ bool act_held(const GemvP & p) {
@@ -343,9 +350,9 @@ __device__ __forceinline__ bool act_held(const GemvP & p) {
     return p.K / 4 <= 4 * PM_GEMV_BLOCK;
 }
 
-template <int ABLK, bool COH>
-__device__ __forceinline__ void stage_issue(const GemvP & p, ActRegs & a, int wave, int lane) {
-    if (p.xmode == 3) {                      // the producer's partial sums: four 8-byte loads per lane, in front of everything else of this wave
+template <int ABLK, bool COH, bool SS = false>
+__device__ __forceinline__ void stage_issue(const GemvP & p, ActRegsT<SS> & a, int wave, int lane) {
+    if constexpr (SS) if (p.xmode == 3) {    // the producer's partial sums: four 8-byte loads per lane, in front of everything else of this wave
 #pragma unroll
         for (int i = 0; i < 4; ++i) a.ssp[i] = lane + 64 * i < p.n_ss ? ld_g(p.ss_in + lane + 64 * i) : 0.0;
     }
@@ -380,8 +387,8 @@ __device__ __forceinline__ double sumsq4(const float4 & f) {
     return s;
 }
 
-template <int ABLK, bool COH>
-__device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_t * xs_q, int * xs_gs, float * xs_d, double * nred,
+template <int ABLK, bool COH, bool SS = false>
+__device__ __forceinline__ void stage_finish(const GemvP & p, ActRegsT<SS> & a, int8_t * xs_q, int * xs_gs, float * xs_d, double * nred,
                                              int wave, int lane, int ncols = 1, int col_bytes = 0, unsigned long long * t_norm = nullptr) {
     const int tid = threadIdx.x;
     const int K = p.K;
@@ -408,13 +415,16 @@ __device__ __forceinline__ void stage_finish(const GemvP & p, ActRegs & a, int8_
     const bool held = act_held<ABLK>(p);
     const int nblk = K / 256, r = lane >> 4, j = lane & 15;
     float scale = 1.0f;
-    if (p.xmode == 3) {
+    bool from_partials = false;
+    if constexpr (SS) if (p.xmode == 3) {
         // every wave adds the producer's partials for itself: no reduction over the row, no LDS, no workgroup barrier
         const double tot = wave_sum_f64((a.ssp[0] + a.ssp[1]) + (a.ssp[2] + a.ssp[3]));
         if (t_norm) *t_norm = PM_TS_NOW();
         const float mean = (float) (tot / K);
         scale = 1.0f / sqrtf(mean + p.eps);
-    } else if (p.xmode == 2) {
+        from_partials = true;
+    }
+    if (!from_partials && p.xmode == 2) {
         // sum of the f32-rounded squares in f64 like the reference (ggml.c:11975-11980); any summation order of <= 2^15
         // f64 terms agrees with the sequential one after the final rounding to f32
         double ss = 0.0;
@@ -695,7 +705,7 @@ __device__ __forceinline__ float row_result(const GemvJob & jb, const float * ou
 }
 
 // returns this thread's share of sum (double)(out * out) over the values it stored (the producer-side partial of the next rms_norm, GemvP::ss_out)
-template <bool COH, int NC>
+template <bool COH, int NC, bool SS = false>
 __device__ __forceinline__ double write_out(const GemvJob & jb, const float * outbuf, int r0, int r1, int ob, int tid, long y_stride, int cpr = 1, int ncols = NC) {
     double ss = 0.0;
     for (int t = tid; t < (r1 - r0) * NC; t += PM_GEMV_BLOCK) {
@@ -705,8 +715,10 @@ __device__ __forceinline__ double write_out(const GemvJob & jb, const float * ou
         if (jb.bias)  out += ld_g(jb.bias + r0 + row);
         if (jb.resid) out += ld_act<false>(jb.resid + c * y_stride + r0 + row);
         st_act<COH>(jb.y + c * y_stride + r0 + row, out);
-        const float sq = out * out;                    // f32-rounded square, then widened: (ggml_float)(x[i] * x[i]), ggml.c:11977
-        ss += (double) sq;
+        if constexpr (SS) {
+            const float sq = out * out;                // f32-rounded square, then widened: (ggml_float)(x[i] * x[i]), ggml.c:11977
+            ss += (double) sq;
+        }
     }
     return ss;
 }
@@ -814,8 +826,10 @@ __device__ __forceinline__ void qkv_attention_tail(const GemvP & p, char * smem,
 }
 
 // The whole mat-vec of one workgroup (body of gemv_q_kernel / gemv_q_cols_kernel).
-template <int TA, int TB, bool PAIR, bool DBG, int NC = 1, bool EPI = false, int NPRE = 2>
+template <int TA, int TB, bool PAIR, bool DBG, int NC = 1, bool EPI = false, int NPRE = 2, int FEAT = 0>
 __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double * nred) {
+    constexpr bool SS = (FEAT & PM_FEAT_SS) != 0, TAIL = (FEAT & PM_FEAT_TAIL) != 0;
+    static_assert(!TAIL || (EPI && !PAIR && NC == 1), "the attention tail belongs to the wq | wk | wv launch");
     constexpr bool MEGA = false;      // (outputs are plain stores: kernel boundaries do the cache maintenance)
     constexpr int ABLK = QT<TA>::ABLK;
     typedef Item<TA, PAIR, NC> IA;
@@ -860,8 +874,8 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
     //      the small wq/wo launches: the in-order VMEM return delays the prologue and the lines are fetched twice); and
     //      splitting the workgroup into 8 prologue waves + 8 waves that pre-issue their first step (-3 %, A/B on one box).]
     unsigned long long tsv[6] = {PM_TS_NOW(), 0, 0, 0, 0, 0};
-    ActRegs areg;
-    stage_issue<ABLK, MEGA>(p, areg, wave, lane);                             // activation loads go out first (they return first)
+    ActRegsT<SS> areg;
+    stage_issue<ABLK, MEGA, SS>(p, areg, wave, lane);                             // activation loads go out first (they return first)
     typename IA::Regs g0, g1;                                   // job 0 is always of type TA (host side orders the jobs)
     {   // the first NPRE steps of this wave in job 0 (same cursor sequence as run_job: chunks of a row, then the wave's next item)
         const int cpr0 = (((p.job[0].U + 63) >> 6) + IA::CH - 1) / IA::CH;
@@ -870,7 +884,7 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
         IA::issue(g0, p, p.job[0], prow, r1_0, pc * IA::CH, lane); adv();
         if (NPRE >= 2) { IA::issue(g1, p, p.job[0], prow, r1_0, pc * IA::CH, lane); adv(); }
     }
-    stage_finish<ABLK, MEGA>(p, areg, xs_q, xs_gs, xs_d, nred, wave, lane, NC, col_bytes, &tsv[1]);
+    stage_finish<ABLK, MEGA, SS>(p, areg, xs_q, xs_gs, xs_d, nred, wave, lane, NC, col_bytes, &tsv[1]);
     __syncthreads();
     tsv[2] = PM_TS_NOW();
     const XLds xs = {xs_q, xs_gs, xs_d, col_bytes};
@@ -915,12 +929,12 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
     tsv[4] = PM_TS_NOW();                              // (all 16 waves have)
     // (4) coalesced write-out (+bias, +residual)
     if (EPI && p.epi.tab) {
-        if (p.epi.att_out) {
-            // write-through stores: other compute units read q and this token's cell in this launch
+        if constexpr (TAIL) {
+            // (this instantiation is launched only with att_out set) write-through stores: other compute units read q and this token's cell in this launch
             write_out_qkv<true>(p.job[0], p.epi, outbuf, r0_0, r1_0, 0, tid, 1, epi_slot, epi_off, ec0, es0);
             write_out_qkv<true>(p.job[1], p.epi, outbuf, r0_1, r1_1, ob_1, tid, cpr_1, epi_slot, epi_off, ec1, es1);
             write_out_qkv<true>(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off, ec2, es2);
-            if constexpr (EPI && !PAIR && NC == 1) qkv_attention_tail(p, smem, b, tid, wave, lane);
+            qkv_attention_tail(p, smem, b, tid, wave, lane);
         } else {
             write_out_qkv(p.job[0], p.epi, outbuf, r0_0, r1_0, 0, tid, 1, epi_slot, epi_off, ec0, es0);
             write_out_qkv(p.job[1], p.epi, outbuf, r0_1, r1_1, ob_1, tid, cpr_1, epi_slot, epi_off, ec1, es1);
@@ -928,10 +942,10 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
         }
     } else {
         const int ncw = NC > 1 && p.ncols > 0 ? p.ncols : NC;
-        const double ss = write_out<MEGA, NC>(p.job[0], outbuf, r0_0, r1_0, 0, tid, p.y_stride, 1, ncw);
+        const double ss = write_out<MEGA, NC, SS>(p.job[0], outbuf, r0_0, r1_0, 0, tid, p.y_stride, 1, ncw);
         write_out<MEGA, NC>(p.job[1], outbuf, r0_1, r1_1, ob_1, tid, p.y_stride, cpr_1, ncw);
         write_out<MEGA, NC>(p.job[2], outbuf, r0_2, r1_2, ob_2, tid, p.y_stride, cpr_2, ncw);
-        if (NC == 1 && !PAIR && !EPI) if (p.ss_out) {
+        if constexpr (SS && NC == 1 && !PAIR && !EPI) if (p.ss_out) {
             // this workgroup's partial of the consumer's rms_norm (single-job launches: gemv_fill): rows sit in threads 0 .. r1 - r0 - 1
             const double ws = wave_sum_f64(ss);
             if (r1_0 - r0_0 <= 64) {                   // (every 70B / 8B / 72B shape: 16-32 rows per workgroup -> wave 0 alone, no barrier)
