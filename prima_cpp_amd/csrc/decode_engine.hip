@@ -366,8 +366,8 @@ __device__ __forceinline__ void eng_attention(const EngPhase * ph, int h, char *
 // The rows of one mat-vec phase in one workgroup: this wave's prefetched steps out of its LDS slot, everything else HBM -> registers.
 template <int TA, int TB, bool PAIR, bool EPI>
 __device__ __forceinline__ void phase_rows(const EngPhase * ph, char * smem, const XLds & xs, float * outbuf, int wave, int lane, int b, int G) {
-    typedef Item<TA, PAIR, 1> IA;
-    typedef Item<TB, PAIR, 1> IB;
+    typedef Item<TA, PAIR, 1, EPI> IA;                        // (wq | wk | wv phases carry the NEOX row mapping: runtime identity for NORM rope)
+    typedef Item<TB, PAIR, 1, EPI> IB;
     constexpr int R = IA::R, NM = PAIR ? 2 : 1;
     static_assert(R == 1, "one row per item");
     constexpr int NPRE = (PAIR || TA == PM_Q5_K) ? 1 : 2;   // register sets in flight before the prefetched steps are consumed (as the launches: mmvq.hip)

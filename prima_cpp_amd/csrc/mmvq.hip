@@ -36,6 +36,11 @@ namespace {
 // the wave starts issuing its loads without first waiting for an s_load of the kernarg segment (a by-value struct is never preloaded).
 // FEAT (mmvq_device.h): PM_FEAT_SS / PM_FEAT_TAIL code lives in instantiations of its own - a launch that uses neither runs the plain kernel
 template <int TA, int TB, bool PAIR, bool DBG, bool EPI = false, int NPRE = 2, int FEAT = 0>
+#ifdef PM_NO_PRELOAD_ARGS
+__global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(GemvP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double nred[PM_GEMV_NW];
+#else
 __global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(const float * xf, const float * norm_w, const uint8_t * W0, const uint8_t * W0b, long row_stride0,
                                                                   int K, int xmode, int N0, int U0, GemvP p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -43,6 +48,7 @@ __global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(const float * 
     GemvP p = p_in;
     p.xf = xf; p.norm_w = norm_w; p.K = K; p.xmode = xmode;
     p.job[0].W = W0; p.job[0].W2 = W0b; p.job[0].row_stride = row_stride0; p.job[0].N = N0; p.job[0].U = U0;
+#endif
     // (Q5_K: two 32-weight units per lane and step = 24-VGPR sets with the high-bit plane; a second pre-issued set spills)
     gemv_body<TA, TB, PAIR, DBG, 1, EPI, (TA == PM_Q5_K && NPRE == 2) ? 1 : NPRE, FEAT>(p, smem, nred);
 }
@@ -51,10 +57,15 @@ int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, 
     const GemvP & p = p_in;
     auto go = [&](auto kern) {
         pm_allow_big_lds((const void *) kern, lds);
+#ifdef PM_NO_PRELOAD_ARGS
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(PM_GEMV_BLOCK), lds, st, p);
+#else
         hipLaunchKernelGGL(kern, dim3(grid), dim3(PM_GEMV_BLOCK), lds, st, p.xf, p.norm_w, p.job[0].W, p.job[0].W2, p.job[0].row_stride, p.K, p.xmode, p.job[0].N, p.job[0].U, p);
+#endif
     };
     const bool ss = p.ss_out != nullptr || p.xmode == 3;          // producer or consumer of per-workgroup partial sums of squares
     const bool tail = epi && p.epi.att_out != nullptr;
+    const bool neox = epi && (p.job[0].nx_s > 0 || p.job[1].nx_s > 0 || p.job[2].nx_s > 0);
     if (pair) {
         if (TA != TB) return -1;
         // (pair launches: one step of pre-issue - two sets of two matrices next to the activation registers spill)
@@ -67,7 +78,8 @@ int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, 
             // the tail is compiled for the wq | wk | wv type mixtures of the Q4_K_M files only (wq Q4_K; wv Q4_K / Q5_K / Q6_K)
             if constexpr (TA == PM_Q4_K) { if (ss) go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_SS | PM_FEAT_TAIL>); else go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_TAIL>); }
             else return -7;
-        } else if (ss) go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_SS>);
+        } else if (neox) { if (ss) go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_NEOX | PM_FEAT_SS>); else go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_NEOX>); }
+        else if (ss) go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_SS>);
         else go(gemv_q_kernel<TA, TB, false, false, true>);
     } else {
         if (dbg) { if (ss) return -6; go(gemv_q_kernel<TA, TB, false, true, false, 1>); }     // (test hook: one pre-issued step - with two, the Q6_K form sat on the 128-VGPR cliff with a spilled register)

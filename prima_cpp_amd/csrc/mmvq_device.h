@@ -338,7 +338,8 @@ __device__ __forceinline__ void q80_block_to_lds(const float v[4], int i4 /*inde
 // costs the kernels that do not use them (measured, profiles/r05_ab_sumsq_q6k_tail.txt: the sum-of-squares code +0.55 us on every launch, unused):
 //   PM_FEAT_SS    producer-side sum of squares: xmode 3 prologues and the ss_out epilogue
 //   PM_FEAT_TAIL  attention in the tail of the wq | wk | wv launch (QkvEpi::att_out)
-constexpr int PM_FEAT_SS = 1, PM_FEAT_TAIL = 2;
+//   PM_FEAT_NEOX  logical -> matrix row mapping of the wq / wk jobs (NEOX rope pairs in the QKV epilogue: build_qwen2); the TAIL instantiations carry it too
+constexpr int PM_FEAT_SS = 1, PM_FEAT_TAIL = 2, PM_FEAT_NEOX = 4;
 template <bool SS> struct ActRegsT;
 template <> struct ActRegsT<false> { float4 f[2][4]; };
 template <> struct ActRegsT<true>  { float4 f[2][4]; double ssp[4]; };      // ssp: xmode 3, this lane's share of the producer's partial sums (n_ss <= 256)
@@ -513,7 +514,10 @@ __device__ __forceinline__ void load_x_lds(typename QT<TYPE>::X & x, const XLds 
 
 // A wave processes ITEMS: R consecutive rows of one job. Lanes stride over the row's units in chunks of CH units per
 // lane; the activation slice of every unit comes from LDS. No barrier and no cross-wave reduction inside an item.
-template <int TYPE, bool PAIR, int NC = 1> struct Item {
+// NX: the job's logical rows go through job_row() (NEOX rope in the QKV epilogue). A template parameter, not a runtime select: the dozen scalar
+// instructions in front of every weight-row address cost the NORM-rope models 1.25 % of the 70B token when they sat in every kernel (round 4 shipped
+// that; found in round 5 with the round-3 library beside it: profiles/r05_ab_sumsq_q6k_tail.txt, second correction)
+template <int TYPE, bool PAIR, int NC = 1, bool NX = false> struct Item {
     typedef QT<TYPE> T;
     static constexpr int NM = PAIR ? 2 : 1;
 #ifndef PM_CH32
@@ -545,7 +549,7 @@ template <int TYPE, bool PAIR, int NC = 1> struct Item {
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 const int u = min(lane + 64 * (c0 + i), jb.U - 1);
-                T::issue(g.w[r][0][i], jb.W + (long) job_row(jb, rr) * jb.row_stride, p.K, u);
+                T::issue(g.w[r][0][i], jb.W + (long) (NX ? job_row(jb, rr) : rr) * jb.row_stride, p.K, u);
                 if (PAIR) T::issue(g.w[r][NM - 1][i], jb.W2 + (long) rr * jb.row_stride, p.K, u);
             }
         }
@@ -828,12 +832,13 @@ __device__ __forceinline__ void qkv_attention_tail(const GemvP & p, char * smem,
 // The whole mat-vec of one workgroup (body of gemv_q_kernel / gemv_q_cols_kernel).
 template <int TA, int TB, bool PAIR, bool DBG, int NC = 1, bool EPI = false, int NPRE = 2, int FEAT = 0>
 __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double * nred) {
-    constexpr bool SS = (FEAT & PM_FEAT_SS) != 0, TAIL = (FEAT & PM_FEAT_TAIL) != 0;
+    constexpr bool SS = (FEAT & PM_FEAT_SS) != 0, TAIL = (FEAT & PM_FEAT_TAIL) != 0, NX = (FEAT & (PM_FEAT_NEOX | PM_FEAT_TAIL)) != 0;
+    static_assert(!NX || EPI, "row mapping: wq | wk | wv launches only");
     static_assert(!TAIL || (EPI && !PAIR && NC == 1), "the attention tail belongs to the wq | wk | wv launch");
     constexpr bool MEGA = false;      // (outputs are plain stores: kernel boundaries do the cache maintenance)
     constexpr int ABLK = QT<TA>::ABLK;
-    typedef Item<TA, PAIR, NC> IA;
-    typedef Item<TB, PAIR, NC> IB;
+    typedef Item<TA, PAIR, NC, NX> IA;
+    typedef Item<TB, PAIR, NC, NX> IB;
     constexpr int R = IA::R;
     // LDS: NC activation columns, each [q int8 K | gs int32 K/16 | d float K/ABLK] (16-byte aligned pieces), then the results
     const int col_bytes = ((p.K + 15) & ~15) + (p.K / 16) * 4 + ((p.K / ABLK + 3) & ~3) * 4;
