@@ -747,6 +747,8 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         // cached cells, one workgroup per (head, token) (attn_cached.hip: one barrier up to 64 cells; 11 -> ~4 us per layer at 2..8 tokens)
         pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride,
                                 (const float *) m->rope_freqs.d, T, H, Hkv, dh, hp.n_ctx, m->rope, st, 1);
+        // (a shape attn_cached refuses - head_dim other than 64 / 128 / 256, scores beyond 150 KiB of LDS - falls back to attn_decode, which rounds q to
+        //  F16 itself: the pre-rounded rows give it the same bits as raw ones, tests/test_gpu_ops.py::test_small_batch_attention_fallback_...)
         if (pm_launch_attn_cached(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride, m->att, H, Hkv, dh, hp.n_ctx, kq_scale, st, nullptr, nullptr, 0, 0, 0, T) &&
             pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
             return seterr(m, PM355_E_RANGE, "decode: n_ctx too large for the decode-attention kernel");

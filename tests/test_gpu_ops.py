@@ -1135,3 +1135,19 @@ def test_long_context_q8_0_token_step_matches_the_one_workgroup_per_head_kernel(
     assert d <= 2e-3 * a1.abs().max().item(), (d, a1.abs().max().item())
     nm = float(((a2 - a1).double() ** 2).sum() / (a1.double() ** 2).sum())
     assert nm < 1e-5, nm
+
+
+def test_small_batch_attention_fallback_is_indifferent_to_the_pre_rounded_query(P):
+    """small batches store q F16-rounded (rope + KV store with round_q) for pm355_attn_cached; when that kernel refuses a shape the older
+    pm355_attn_decode consumes the same rows. It rounds q to F16 itself (MUL_MAT's src1 conversion, ggml.c:12445-12473), so an already rounded q gives
+    the same bits as the raw one - shown here at head_dim 96, a shape attn_cached does not serve."""
+    torch = P.torch
+    rng = np.random.default_rng(9)
+    T, H, Hkv, dh, n_ctx, pos0 = 3, 8, 4, 96, 64, 20
+    q = torch.from_numpy(rng.normal(0, 1, (T, H * dh)).astype(np.float32)).cuda()
+    kc = torch.from_numpy(rng.normal(0, 1, (n_ctx, Hkv * dh)).astype(np.float16)).cuda().view(torch.int16)
+    vc = torch.from_numpy(rng.normal(0, 1, (Hkv * dh, n_ctx)).astype(np.float16)).cuda().view(torch.int16)
+    scale = 1.0 / np.sqrt(dh)
+    raw = P.attn_decode(q, kc, vc, pos0, H, Hkv, dh, n_ctx, scale)
+    rounded = P.attn_decode(q.half().float(), kc, vc, pos0, H, Hkv, dh, n_ctx, scale)
+    assert torch.equal(raw, rounded)
