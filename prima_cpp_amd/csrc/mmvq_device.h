@@ -733,10 +733,11 @@ __device__ __forceinline__ double write_out(const GemvJob & jb, const float * ou
 // (c, s_): this thread's (cos, sin) of pair `tid`, fetched by qkv_cs() BEFORE the barrier in front of the epilogue (a workgroup's slice
 // holds at most PM_MAX_ROWS_PER_WG / 2 pairs < PM_GEMV_BLOCK: one pair per thread) - loaded after the barrier the table's L2 latency
 // sat in the tail of every workgroup (store phase 1.6 us instead of 0.5).
+template <bool NX = true>      // NX = false: the NEOX pairing is compiled out (NORM-rope launches: gemv_body's FEAT)
 __device__ __forceinline__ void qkv_cs(const GemvJob & jb, const QkvEpi & e, int r0, int r1, int tid, float & c, float & s_) {
     c = 1.0f; s_ = 0.0f;
     if (jb.role == 1 || jb.role == 2) {
-        if (jb.nx_s) {                                                 // NEOX: pair `tid` of the slice = matrix rows (p0, p0 + n_rot / 2), table entry p0 % dh
+        if (NX && jb.nx_s) {                                           // NEOX: pair `tid` of the slice = matrix rows (p0, p0 + n_rot / 2), table entry p0 % dh
             const int ic = job_row(jb, r0 + tid) & (e.dh - 1);
             if (2 * tid < r1 - r0) { c = ld_g(e.tab + 2 * ic); s_ = ld_g(e.tab + 2 * ic + 1); }
         } else {
@@ -745,14 +746,14 @@ __device__ __forceinline__ void qkv_cs(const GemvJob & jb, const QkvEpi & e, int
         }
     }
 }
-template <bool COH = false>
+template <bool COH = false, bool NX = true>
 __device__ __forceinline__ void write_out_qkv(const GemvJob & jb, const QkvEpi & e, const float * outbuf, int r0, int r1, int ob, int tid, int cpr,
                                               int slot, long kv_off, float c, float s_) {
     const int np = (r1 - r0) >> 1;
     {
         const int pr = tid;
         if (pr >= np) return;
-        if (jb.nx_s) {
+        if (NX && jb.nx_s) {
             // NEOX (ggml_compute_forward_rope_f32, ggml.c:14238-14253): x0 = row p0, x1 = row p0 + n_rot / 2 of the same head; the slice holds both
             // (logical rows pr and pr + np). n_rot == head_dim here (gemv_fill): every row of a q / k head is rotated.
             const int p0 = job_row(jb, r0 + pr), p1 = p0 + jb.nx_hrot;
@@ -926,9 +927,9 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
     tsv[3] = PM_TS_NOW();                              // (wave 0 has finished its rows)
     float ec0 = 1.0f, es0 = 0.0f, ec1 = 1.0f, es1 = 0.0f, ec2 = 1.0f, es2 = 0.0f;
     if (EPI && p.epi.tab) {
-        qkv_cs(p.job[0], p.epi, r0_0, r1_0, tid, ec0, es0);
-        qkv_cs(p.job[1], p.epi, r0_1, r1_1, tid, ec1, es1);
-        qkv_cs(p.job[2], p.epi, r0_2, r1_2, tid, ec2, es2);
+        qkv_cs<NX>(p.job[0], p.epi, r0_0, r1_0, tid, ec0, es0);
+        qkv_cs<NX>(p.job[1], p.epi, r0_1, r1_1, tid, ec1, es1);
+        qkv_cs<NX>(p.job[2], p.epi, r0_2, r1_2, tid, ec2, es2);
     }
     __syncthreads();
     tsv[4] = PM_TS_NOW();                              // (all 16 waves have)
@@ -941,9 +942,9 @@ __device__ __forceinline__ void gemv_body(const GemvP & p, char * smem, double *
             write_out_qkv<true>(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off, ec2, es2);
             qkv_attention_tail(p, smem, b, tid, wave, lane);
         } else {
-            write_out_qkv(p.job[0], p.epi, outbuf, r0_0, r1_0, 0, tid, 1, epi_slot, epi_off, ec0, es0);
-            write_out_qkv(p.job[1], p.epi, outbuf, r0_1, r1_1, ob_1, tid, cpr_1, epi_slot, epi_off, ec1, es1);
-            write_out_qkv(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off, ec2, es2);
+            write_out_qkv<false, NX>(p.job[0], p.epi, outbuf, r0_0, r1_0, 0, tid, 1, epi_slot, epi_off, ec0, es0);
+            write_out_qkv<false, NX>(p.job[1], p.epi, outbuf, r0_1, r1_1, ob_1, tid, cpr_1, epi_slot, epi_off, ec1, es1);
+            write_out_qkv<false, NX>(p.job[2], p.epi, outbuf, r0_2, r1_2, ob_2, tid, cpr_2, epi_slot, epi_off, ec2, es2);
         }
     } else {
         const int ncw = NC > 1 && p.ncols > 0 ? p.ncols : NC;
