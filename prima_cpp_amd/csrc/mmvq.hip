@@ -38,8 +38,9 @@ namespace {
 // XM >= 0: the activation mode is a compile-time constant of the instantiation (the hot launches: 1 = f32 row, 2 = rms_norm of an f32 row) - the prologue
 // keeps one mode's code instead of four behind scalar branches
 // HOT: everything else the decode launches of the Llama-family layer never use is pinned too (no bias, one job outside wq | wk | wv, no residual on
-// the pair launch, position-pointer mode + transposed V cache in the QKV epilogue): launch_types() checks that the argument block really looks like that
-template <int TA, int TB, bool PAIR, bool DBG, bool EPI = false, int NPRE = 2, int FEAT = 0, int XM = -1, bool HOT = false>
+// the pair launch, transposed V cache and - HOT 1: the engine - position-pointer mode / HOT 2: the plug-in - ggml-graph mode in the QKV epilogue):
+// launch_types() checks that the argument block really looks like that
+template <int TA, int TB, bool PAIR, bool DBG, bool EPI = false, int NPRE = 2, int FEAT = 0, int XM = -1, int HOT = 0>
 #ifdef PM_NO_PRELOAD_ARGS
 __global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(GemvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(PM_GEMV_BLOCK, 4) void gemv_q_kernel(const float * 
     if constexpr (HOT) {
         p.dbg = nullptr; p.job[0].bias = nullptr;
         if constexpr (EPI) {
-            p.job[1].bias = nullptr; p.job[2].bias = nullptr; p.epi.dyn = nullptr; p.epi.v_rowmajor = 0;
+            p.job[1].bias = nullptr; p.job[2].bias = nullptr; p.epi.v_rowmajor = 0;
+            if constexpr (HOT == 1) p.epi.dyn = nullptr; else __builtin_assume(p.epi.dyn != nullptr);
             p.job[0].role = 1; p.job[1].role = 2; p.job[2].role = 3;                    // wq, wk, wv in this order (no TA-first swap happened)
             p.job[0].is_b = 0; p.job[1].is_b = 0; p.job[2].is_b = TA != TB ? 1 : 0;     // Q4_K_M: wq / wk of the first type, wv of the second (or all of one)
             p.job[0].split = 0; p.job[0].resid = nullptr; p.job[1].resid = nullptr; p.job[2].resid = nullptr;
@@ -90,7 +92,7 @@ int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, 
         // (pair launches: one step of pre-issue - two sets of two matrices next to the activation registers spill)
         if (dbg) { if (ss) return -6; go(gemv_q_kernel<TA, TA, true, true, false, 1>); }
         else if (ss) go(gemv_q_kernel<TA, TA, true, false, false, 1, PM_FEAT_SS>);
-        else if (p.xmode == 2 && hot_spec && one_job && !p.job[0].bias && !p.job[0].resid && !p.job[0].split) go(gemv_q_kernel<TA, TA, true, false, false, 1, 0, 2, true>);
+        else if (p.xmode == 2 && hot_spec && one_job && !p.job[0].bias && !p.job[0].resid && !p.job[0].split) go(gemv_q_kernel<TA, TA, true, false, false, 1, 0, 2, 1>);
         else if (p.xmode == 2 && xm_spec) go(gemv_q_kernel<TA, TA, true, false, false, 1, 0, 2>);
         else go(gemv_q_kernel<TA, TA, true, false, false, 1>);
     } else if (epi) {
@@ -101,15 +103,15 @@ int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, 
             else return -7;
         } else if (neox) { if (ss) go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_NEOX | PM_FEAT_SS>); else go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_NEOX>); }
         else if (ss) go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_SS>);
-        else if (p.xmode == 2 && hot_spec && !p.job[0].bias && !p.job[1].bias && !p.job[2].bias && !p.epi.dyn && !p.epi.v_rowmajor &&
+        else if (p.xmode == 2 && hot_spec && !p.job[0].bias && !p.job[1].bias && !p.job[2].bias && !p.epi.v_rowmajor &&
                  p.job[0].role == 1 && p.job[1].role == 2 && p.job[2].role == 3 && !p.job[0].is_b && !p.job[1].is_b && p.job[2].is_b == (TA != TB ? 1 : 0) &&
-                 !p.job[0].split && !p.job[0].resid && !p.job[1].resid && !p.job[2].resid) go(gemv_q_kernel<TA, TB, false, false, true, 2, 0, 2, true>);
+                 !p.job[0].split && !p.job[0].resid && !p.job[1].resid && !p.job[2].resid) { if (p.epi.dyn) go(gemv_q_kernel<TA, TB, false, false, true, 2, 0, 2, 2>); else go(gemv_q_kernel<TA, TB, false, false, true, 2, 0, 2, 1>); }
         else if (p.xmode == 2 && xm_spec) go(gemv_q_kernel<TA, TB, false, false, true, 2, 0, 2>);
         else go(gemv_q_kernel<TA, TB, false, false, true>);
     } else {
         if (dbg) { if (ss) return -6; go(gemv_q_kernel<TA, TB, false, true, false, 1>); }     // (test hook: one pre-issued step - with two, the Q6_K form sat on the 128-VGPR cliff with a spilled register)
         else if (ss) go(gemv_q_kernel<TA, TB, false, false, false, 2, PM_FEAT_SS>);
-        else if (p.xmode == 1 && hot_spec && one_job && !p.job[0].bias && p.job[0].resid && !p.job[0].split && !p.job[0].is_b) go(gemv_q_kernel<TA, TB, false, false, false, 2, 0, 1, true>);
+        else if (p.xmode == 1 && hot_spec && one_job && !p.job[0].bias && p.job[0].resid && !p.job[0].split && !p.job[0].is_b) go(gemv_q_kernel<TA, TB, false, false, false, 2, 0, 1, 1>);
         else if (p.xmode == 1 && xm_spec) go(gemv_q_kernel<TA, TB, false, false, false, 2, 0, 1>);
         else if (p.xmode == 2 && xm_spec) go(gemv_q_kernel<TA, TB, false, false, false, 2, 0, 2>);
         else go(gemv_q_kernel<TA, TB, false, false>);
