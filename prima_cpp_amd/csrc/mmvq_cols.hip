@@ -15,9 +15,13 @@ using namespace pmv;
 namespace {
 
 template <int T, int NC, bool PAIR>
-__global__ __launch_bounds__(PM_GEMV_BLOCK, 2) void gemv_q_cols_kernel(GemvP p) {
+__global__ __launch_bounds__(PM_GEMV_BLOCK, 2) void gemv_q_cols_kernel(GemvP p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double nred[PM_GEMV_NW];
+    // what a multi-column launch never uses is pinned at compile time (as the hot single-token instantiations of mmvq.hip: profiles/r05_kernel_specialization.txt):
+    // pre-quantized activation columns, one job, no debug output
+    GemvP p = p_in;
+    p.xmode = 0; p.dbg = nullptr; p.job[1].N = 0; p.job[2].N = 0; p.job[0].split = 0; p.job[0].is_b = 0; p.job[0].role = 0; p.ss_out = nullptr;
     gemv_body<T, T, PAIR, false, NC>(p, smem, nred);
 }
 
