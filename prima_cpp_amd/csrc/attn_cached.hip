@@ -14,6 +14,7 @@
 //     quarter of the output.
 //   * more cells (up to the long-context threshold): the per-head body of attn_device.h in its CACHED form.
 #include "attn_device.h"
+#include "attn_tail_device.h"
 #include "pm355_layer_ops.h"
 
 namespace {
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(256) void attn_cached_kernel(AttnP a_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float redf[8];
     __shared__ double redd[4];
-    __shared__ float part[4][64];
-    __shared__ float pw[4][64];
+    __shared__ float part[4][256];             // (short path: [4][64]; keys-in-lanes form up to 256 cells: [4][64 KPL])
+    __shared__ float pw[4][256];
     const int h = blockIdx.x;
     constexpr bool SHORT_OK = VM == 0 && (DH == 64 || DH == 128 || DH == 256);
     if (SHORT_OK) {
@@ -125,6 +126,19 @@ __global__ __launch_bounds__(256) void attn_cached_kernel(AttnP a_in) {
             tsv[5] = PM_TS_NOW();
             pm_ts_store(a.ts, 3, tsv);
             return;
+        }
+        // up to 256 cells: keys in the lanes, two / four per lane (attn_tail_device.h) instead of the general body's score buffer and three reductions
+        if constexpr (DH <= 128) {
+            const uint16_t * kc = a.kc + (long) seq * a.seq_stride, * vc = a.vc + (long) seq * a.seq_stride;
+            auto bar = [&]() __attribute__((always_inline)) { __syncthreads(); };
+            if (n_kv <= 128 && n_ctx >= 128) {
+                attn_keys_in_lanes<DH, 2, false>(a.q + (long) h * DH, kc, vc, a.out + (long) h * DH, hk, Hkv, n_ctx, n_kv, a.scale, a.mask, a.mask_f16, &part[0][0], &pw[0][0], nullptr, lane, wave, bar);
+                return;
+            }
+            if (n_kv <= 256 && n_ctx >= 256) {
+                attn_keys_in_lanes<DH, 4, false>(a.q + (long) h * DH, kc, vc, a.out + (long) h * DH, hk, Hkv, n_ctx, n_kv, a.scale, a.mask, a.mask_f16, &part[0][0], &pw[0][0], nullptr, lane, wave, bar);
+                return;
+            }
         }
     }
     attn_rope_body<DH, false, VM, true>(a, h, smem, redf, redd);

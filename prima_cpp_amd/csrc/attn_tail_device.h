@@ -21,12 +21,99 @@ __device__ __forceinline__ u32x4 coh_ld16u(__amdgpu_buffer_rsrc_t r, uint32_t of
 __device__ __forceinline__ float coh_ld4(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int) off, 0, 17)); }
 
 
+// ---- up to 64 * KPL cells with the KEYS IN THE LANES (round 5; KPL = 1 is attn_cached.hip's short path, one key per lane): lane l owns keys l, l + 64, ...,
+// wave w the head dimensions [DPW w, DPW w + DPW); every load is issued before anything is computed, ONE barrier of the four waves. The general body
+// (thread per key, three reductions, a score buffer) costs 7.1 us per launch at 65 cells and 9.1 at 256 where this form costs ~4 (tools/r5/attn_short_probe.py).
+// Rounding points as everywhere: q, K, V F16, the normalised probabilities rounded to F16, f32 accumulation. n_kv <= 64 * KPL <= n_ctx, DH 64 / 128.
+// COH: q / K / V through cache-bypassing loads, the output written through (callers inside a launch that produced them: attn_tail_head below).
+// part / pw: LDS [4][64 * KPL] floats each; qstrip: LDS [DH] floats (COH only); bar(): barrier of exactly the four waves.
+template <int DH, int KPL, bool COH, class Bar>
+__device__ __forceinline__ void attn_keys_in_lanes(const float * q_head, const uint16_t * kc, const uint16_t * vc, float * out_head, int hk, int Hkv, int n_ctx, int n_kv,
+                                                   float scale, const void * mask, int mask_f16, float * part, float * pw, float * qstrip, int lane, int wave, Bar && bar) {
+    constexpr int NKEY = 64 * KPL, DPW = DH / 4, NK = DPW / 8, KP = 64 / DPW, KPP = NKEY / KP, NV = KPP / 8;
+    u32x4 kreg[KPL][NK], vreg[NV];
+    const __amdgpu_buffer_rsrc_t rk = coh_rsrc(kc), rv = coh_rsrc(vc), rq = coh_rsrc(q_head);
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+        const long koff = (long) (lane + 64 * k) * Hkv * DH + (long) hk * DH + DPW * wave;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            if constexpr (COH) kreg[k][j] = coh_ld16u(rk, (uint32_t) ((koff + 8 * j) * 2));
+            else kreg[k][j] = *(const PM_G u32x4 *) (kc + koff + 8 * j);
+        }
+    }
+    const int e = lane % DPW, kp = lane / DPW;
+    const long vrow = (long) (hk * DH + DPW * wave + e) * n_ctx + KPP * kp;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if constexpr (COH) vreg[j] = coh_ld16u(rv, (uint32_t) ((vrow + 8 * j) * 2));
+        else vreg[j] = *(const PM_G u32x4 *) (vc + vrow + 8 * j);
+    }
+    const float * qw;
+    if constexpr (COH) {
+        float * qs = qstrip + wave * DPW;
+        if (lane < DPW) qs[lane] = coh_ld4(rq, (uint32_t) ((DPW * wave + lane) * 4));
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        qw = qs;
+    } else qw = uniform_const_ptr(q_head + DPW * wave);
+    float m_add[KPL];
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+        const int key = lane + 64 * k;
+        m_add[k] = (mask && key < n_kv) ? (mask_f16 ? h2f(((const PM_G uint16_t *) mask)[key]) : ((const PM_G float *) mask)[key]) : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NK; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc = fmaf(h2f((uint16_t) (kreg[k][j][t] & 0xFFFF)), qw[8 * j + 2 * t], acc);
+                acc = fmaf(h2f((uint16_t) (kreg[k][j][t] >> 16)), qw[8 * j + 2 * t + 1], acc);
+            }
+        part[wave * NKEY + lane + 64 * k] = acc;
+    }
+    bar();
+    float s_[KPL], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+        const int key = lane + 64 * k;
+        s_[k] = key < n_kv ? ((part[key] + part[NKEY + key]) + (part[2 * NKEY + key] + part[3 * NKEY + key])) * scale + m_add[k] : -INFINITY;
+        mx = fmaxf(mx, s_[k]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float ex[KPL];
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) { ex[k] = lane + 64 * k < n_kv ? expf(s_[k] - mx) : 0.0f; tot += (double) ex[k]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+    const float inv = (float) (1.0 / tot);
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) pw[wave * NKEY + lane + 64 * k] = h2f(f2h(ex[k] * inv));        // p rounded to F16 (src1 of the V^T.p product)
+    __builtin_amdgcn_wave_barrier();                       // (a wave's LDS accesses execute in order: its own copy needs no workgroup barrier)
+    float o = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            o = fmaf(h2f((uint16_t) (vreg[j][t] & 0xFFFF)), pw[wave * NKEY + KPP * kp + 8 * j + 2 * t], o);
+            o = fmaf(h2f((uint16_t) (vreg[j][t] >> 16)), pw[wave * NKEY + KPP * kp + 8 * j + 2 * t + 1], o);
+        }
+#pragma unroll
+    for (int off = DPW; off < 64; off <<= 1) o += __shfl_xor(o, off);
+    if (lane < DPW) st_act<COH>(out_head + DPW * wave + lane, o);
+}
+
 struct AttnTailP {
     const float * q; const uint16_t * kc, * vc; const int32_t * pos, * seq; long seq_stride; float * out;
     int H, Hkv, n_ctx; float scale;
 };
-// LDS bytes of the body for head_dim DH and up to max_keys cells: part / pw / reductions | qs[DH] | part[256] | sc[max_keys + 8]
-static inline __host__ __device__ size_t attn_tail_lds(int dh, int max_keys) { return (size_t) (512 + 8 + 8) * 4 + (size_t) (dh + 256 + ((max_keys + 15) & ~7)) * 4; }
+// LDS bytes of the body for head_dim DH and up to max_keys cells: part[4][256] / pw[4][256] / reductions | qs[DH] | part[256] | sc[max_keys + 8]
+static inline __host__ __device__ size_t attn_tail_lds(int dh, int max_keys) { return (size_t) (2048 + 8 + 8) * 4 + (size_t) (dh + 256 + ((max_keys + 15) & ~7)) * 4; }
 
 // head h by FOUR waves (threads 0 .. 255 of the caller's workgroup); bar() = a barrier of exactly those four waves that also orders their LDS traffic.
 // attn_cached.hip's short path (<= 64 cells, one barrier) and the cached form of attn_rope_body beyond.
@@ -44,9 +131,9 @@ __device__ __forceinline__ void attn_tail_head(const AttnTailP & a, int h, char 
     const int n_kv = uniform_const_ptr(a.pos)[seq] + 1;
     const long soff = (long) seq * a.seq_stride;
     const __amdgpu_buffer_rsrc_t rk = coh_rsrc(a.kc + soff), rv = coh_rsrc(a.vc + soff), rq = coh_rsrc(a.q);
-    float * part = (float *) smem;                         // [4][64]
-    float * pw = part + 256;                               // [4][64]
-    float * redf = pw + 256;                               // [8]
+    float * part = (float *) smem;                         // [4][256]
+    float * pw = part + 1024;                              // [4][256]
+    float * redf = pw + 1024;                              // [8]
     double * redd = (double *) (redf + 8);                 // [4]
     float * body = (float *) (redd + 4);                   // general path: qs[DH] | part[256] | sc[max_keys]
     if (n_kv <= 64 && n_ctx >= 64) {
@@ -101,6 +188,11 @@ __device__ __forceinline__ void attn_tail_head(const AttnTailP & a, int h, char 
         for (int off = DPW; off < 64; off <<= 1) o += __shfl_xor(o, off);
         if (lane < DPW) st_act<true>(a.out + (long) h * DH + DPW * wave + lane, o);
         return;
+    }
+    // ---- up to 256 cells: keys in the lanes, two / four per lane (the same function attn_cached.hip calls: same bits)
+    if constexpr (DH <= 128) {
+        if (n_kv <= 128 && n_ctx >= 128) { attn_keys_in_lanes<DH, 2, true>(a.q + (long) h * DH, a.kc + soff, a.vc + soff, a.out + (long) h * DH, hk, Hkv, n_ctx, n_kv, scale, nullptr, 0, part, pw, body, lane, wave, bar); return; }
+        if (n_kv <= 256 && n_ctx >= 256) { attn_keys_in_lanes<DH, 4, true>(a.q + (long) h * DH, a.kc + soff, a.vc + soff, a.out + (long) h * DH, hk, Hkv, n_ctx, n_kv, scale, nullptr, 0, part, pw, body, lane, wave, bar); return; }
     }
     // ---- general cached body (attn_rope_body<DH, COH, 0, true>): thread per key, three 4-wave reductions
     constexpr int PARTS = 256 / DH, KQ = DH / 8;

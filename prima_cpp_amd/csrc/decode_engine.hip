@@ -626,7 +626,7 @@ int pm_eng_plan_add_attention(pm_eng_plan * pl, const float * q, void * kc, void
     if ((dh != 64 && dh != 128) || n_ctx % 8 || !pos0 || H % Hkv) return -10;
     if (max_keys <= 0 || max_keys > n_ctx) max_keys = n_ctx;
     // LDS of the general path below the prefetch slots (the next wo's rows are landing there): part / pw / reductions (2 KiB + 64) | qs[dh] | part[256] | sc[max_keys + 8]
-    if ((size_t) (512 + 8 + 8) * 4 + (size_t) (dh + 256 + ((max_keys + 15) & ~7)) * 4 > (size_t) (ENG_OUT_OFF - ENG_NW * ENG_SLOT_MAX)) return -12;
+    if (attn_tail_lds(dh, max_keys) > (size_t) (ENG_OUT_OFF - ENG_NW * ENG_SLOT_MAX)) return -12;
     EngPhase e = {};
     e.kind = 1; e.aq = q; e.akc = (uint16_t *) kc; e.avc = (uint16_t *) vc; e.apos = pos0; e.aseq = seq; e.aseq_stride = seq_stride; e.aout = out;
     e.aH = H; e.aHkv = Hkv; e.adh = dh; e.an_ctx = n_ctx; e.amax_keys = max_keys; e.ascale = scale;
