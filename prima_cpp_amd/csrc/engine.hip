@@ -89,9 +89,10 @@ struct pm355_model {
     uint64_t streamed_bytes = 0, stream_step = 0;
     // long-context decode attention (attn_split.hip): the host mirrors the device position counters to choose, per step, between
     // the fused one-workgroup-per-head kernel and the keys-split-over-workgroups path (different launch sequences = different
-    // captured graphs). PM355_ATTN_SPLIT_MIN positions (default 640: measured crossover on the 70B head shape).
+    // captured graphs). PM355_ATTN_SPLIT_MIN positions (default 320: the crossover on the 70B head shape once the matrix-core kernel existed - one workgroup
+    // per head costs 12.8 / 15.4 / 18.1 us at 384 / 512 / 640 cells, the matrix-core kernel ~9; rounds 2-4 kept 640, measured against attn_flash.hip).
     float * split_scratch = nullptr;
-    std::vector<int> h_pos; int h_seq = 0; int split_min = 640; bool long_ctx = false;
+    std::vector<int> h_pos; int h_seq = 0; int split_min = 320; bool long_ctx = false;
     bool attn_mfma = true;                        // long contexts in the QKV-epilogue form: matrix-core attention (attn_flash_mfma.hip); PM355_ATTN_MFMA=0 = round-2 kernel
     int flash_cells = 0; bool use_flash = true;   // long contexts: one-launch flash-decoding (attn_flash.hip), grid sized for `flash_cells` (a power-of-two bucket of the position)
     // staging for set_tensor

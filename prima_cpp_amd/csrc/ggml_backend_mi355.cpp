@@ -135,7 +135,7 @@ struct backend_ctx {
     mi355::graph_fp fp_tmp;
     uint64_t tick = 0;
     bool fuse = true, use_graphs = true, debug_plan = false;
-    int split_min = 640;
+    int split_min = 320;                             // cells attended from which the keys are split over workgroups (engine.hip: measured crossover)
     // counters (GGML_MI355_STATS=1 prints them when the backend is freed; tests read them through the log)
     uint64_t n_compute = 0, n_replay = 0, n_capture = 0, n_eager = 0, n_plan = 0, n_fp_hit = 0;
     pm355_event_t null_ev = nullptr; uint64_t null_epoch = 0;   // orders this stream behind the null stream's pending small uploads

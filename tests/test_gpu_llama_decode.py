@@ -137,7 +137,7 @@ def test_llama_decode_plugin_quantized_kv_cache(gpu, name, ctk, ctv, tmp_path):
 
 @pytest.mark.parametrize("fa", [False, True])
 def test_llama_decode_plugin_long_context_split_attention(gpu, fa, tmp_path):
-    """Beyond GGML_MI355_ATTN_SPLIT_MIN cells (640) the single-token attention runs on the keys-split-over-workgroups kernels - the matrix-core
+    """Beyond GGML_MI355_ATTN_SPLIT_MIN cells (320 since round 5) the single-token attention runs on the keys-split-over-workgroups kernels - the matrix-core
     kernel over cached cells where the head shape allows (attn_flash_mfma.hip: transposed V by default, since round 4 also the row-major V + F16
     mask of --flash-attn), else attn_flash.hip. A 700-token prompt, then greedy decode:
     the lowered path against the node-by-node execution of the same graphs on the GPU (tight) and against the reference CPU run."""

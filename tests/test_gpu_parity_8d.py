@@ -145,7 +145,7 @@ def test_peaked_fixture_greedy_tokens_identical(gpu, files, size, mode):
 
 @pytest.mark.parametrize("mode", ["plugin", "plugin-fa", "engine", "plugin-i8", "engine-i8"])
 def test_peaked_fixture_long_context_tokens_identical(gpu, files, mode, monkeypatch):
-    """The same equality beyond the long-context threshold (640 cells): a 700-token prompt, then 24 greedy tokens whose attention runs on
+    """The same equality beyond the long-context threshold (320 cells since round 5): a 700-token prompt, then 24 greedy tokens whose attention runs on
     the matrix-core kernel over cached cells (attn_flash_mfma.hip: rope + KV store in the QKV epilogue, keys split over workgroups,
     spans merged in the launch) - through the plug-in's default graph and on the resident engine."""
     if "small" not in SIZES:

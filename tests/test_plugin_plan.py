@@ -149,7 +149,7 @@ def test_round3_attention_block_rope_in_the_qkv_epilogue(fa, tmp_path):
 
 
 def test_round3_long_context_attention_lowers_to_the_matrix_core_kernel(tmp_path):
-    """Beyond the split threshold (640 cells attended) the round-3 form keeps its QKV epilogue and the attention step becomes the
+    """Beyond the split threshold (320 cells attended since round 5) the round-3 form keeps its QKV epilogue and the attention step becomes the
     matrix-core kernel over cached cells ("cached-split") - since round 4 also with --flash-attn (row-major V cache: the kernel's transposing LDS
     read); GGML_MI355_ATTN_MFMA=0 keeps the round-2 flash-decoding form for both."""
     from _bind import Ref, best_ref_flavour
