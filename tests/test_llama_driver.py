@@ -71,3 +71,17 @@ def test_graph_reuse_patch_leaves_the_reference_cpu_decode_unchanged(name, extra
     monkeypatch.delenv("LLAMA_MI355_GRAPH_REUSE")
     t2, l2, _ = run_llama_driver(path, z["prompt"], 12, ngl=0, n_ctx=n_ctx, flavour="avx2")
     assert t3.tolist() == t2.tolist() and np.array_equal(l3, l2)
+
+
+def test_graph_reuse_patch_drops_the_kept_graphs_on_a_context_shift(tmp_path, monkeypatch):
+    """A context shift in mid-generation (llama_kv_cache_seq_rm + seq_add -> build_k_shift runs on the scheduler inside the next llama_decode): the
+    kept single-token graphs must be dropped and rebuilt - same tokens and logits as the unpatched path, on the reference's own CPU backend."""
+    z = np.load(os.path.join(HERE, "golden", "tiny_llama_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / "tiny_llama.gguf"), z)
+    monkeypatch.setenv("REFDRV_SHIFT", "4,2,3")
+    monkeypatch.delenv("LLAMA_MI355_GRAPH_REUSE", raising=False)
+    t0, l0, _ = run_llama_driver(path, z["prompt"], 14, ngl=0, n_ctx=64, flavour="avx2")
+    monkeypatch.setenv("LLAMA_MI355_GRAPH_REUSE", "1")
+    t1, l1, st = run_llama_driver(path, z["prompt"], 14, ngl=0, n_ctx=64, flavour="avx2")
+    assert "graph-reuse patch" in st["stderr"]
+    assert t1.tolist() == t0.tolist() and np.array_equal(l1, l0)
