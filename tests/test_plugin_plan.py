@@ -167,6 +167,26 @@ def test_round3_long_context_attention_lowers_to_the_matrix_core_kernel(tmp_path
         assert body.count(want) == 2 and never not in body, body[:3000]
 
 
+@pytest.mark.parametrize("kv", [["-ctk", "q8_0", "-ctv", "q8_0"], ["-ctk", "q8_0"]], ids=["q8_0-kv", "q8_0-k"])
+def test_round5_long_context_attention_over_q8_0_caches_is_split_over_workgroups(kv, tmp_path):
+    """Round 5: `-fa -ctk q8_0 [-ctv q8_0]` beyond the split threshold - the attention step of the fused plan is the split form (rope + quantizing KV
+    store launch, then the matrix-core kernel over the cached Q8_0 cells: pm355_attn_token with split = 1); GGML_MI355_ATTN_MFMA=0 keeps the
+    one-workgroup-per-head kernel of attn_q8.hip (its scores then have to fit LDS)."""
+    from _bind import Ref, best_ref_flavour
+    import _fixtures8d as F
+    ref = Ref(best_ref_flavour())
+    path = str(tmp_path / "m.gguf")
+    F.write_model(path, ref, n_layer=2, n_embd=1024, n_head=8, n_head_kv=4, n_ff=1024, n_vocab=512, tag="planlq")
+    prompt = [int(t) for t in F.prompt_tokens(512, 700)]
+    for mfma, split in (("1", True), ("0", False)):
+        _, _, st = run_llama_driver(path, prompt, 3, ngl=99, n_ctx=1024, threads=1, extra_args=["--keep-out-in-cuda", "-fa"] + kv,
+                                    env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_DEBUG_PLAN_STEPS": "1", "GGML_MI355_ATTN_MFMA": mfma}, flavour="avx2", timeout=300)
+        segs = [g for g in st["stderr"].split("ggml-mi355 plan:") if "single_token=1" in g and "attention H=8" in g]
+        assert segs, st["stderr"][-3000:]
+        body = segs[-1]
+        assert (body.count(" split") == 2) == split, body[:3000]
+
+
 @pytest.mark.parametrize("kv", [[], ["-ctk", "q8_0"]], ids=["f16", "k_q8_0"])
 def test_k_shift_graph_is_accepted_by_the_plugin(kv, tmp_path, monkeypatch):
     """build_k_shift (src/llama.cpp:10665) after a context shift: every node lands on the plug-in's pre-allocated KV buffer, so supports_op
