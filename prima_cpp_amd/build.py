@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libprima_mi355.so")
 PROBE_LIB = os.path.join(HERE, "libprima_mi355_probe.so")
-SOURCES = ["c_api.hip", "quantize.hip", "mmvq.hip", "mmvq_cols.hip", "repack.hip", "layer_ops.hip", "ggml_ops.hip", "engine.hip", "mmq.hip", "mmq_i8.hip", "mmq_big.hip",
+SOURCES = ["c_api.hip", "quantize.hip", "mmvq.hip", "mmvq_cols.hip", "repack.hip", "layer_ops.hip", "ggml_ops.hip", "engine.hip", "mmq.hip", "mmq_pf.hip", "mmq_i8.hip", "mmq_big.hip",
            "decode_engine.hip", "attn_prefill.hip", "attn_cached.hip", "attn_flash_mfma.hip", "attn_split.hip", "attn_flash.hip", "attn_q8.hip", "ring.hip", "upload.hip", "ts.hip"]
 PROBE_SOURCES = ["probe.hip", "engine_probe.hip", "probe_api.hip", "overlap_probe.hip"]
 # -ffp-contract=off: the quantizers must round exactly like the reference (no fused multiply-add where

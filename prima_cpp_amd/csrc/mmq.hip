@@ -595,6 +595,12 @@ int pm_launch_gemm_q_h(int type, const void * W, const float * X, const void * x
     _Float16 * xh = x_f16 ? (_Float16 *) x_f16 : g_xh[dev];
     if (!reuse_x && !x_f16) hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) ((need / 8 + 255) / 256)), dim3(256), 0, st, X, xh, (long) (need / 8));
     static const int exp_sw = [] { const char * e = getenv("PM355_GEMM_EXP"); return e ? atoi(e) : 0; }();
+    static const int force = [] { const char * e = getenv("PM355_GEMM_KERNEL"); return e ? atoi(e) : 0; }();
+    // third generation (mmq_pf.hip: LDS-DMA for every byte, weights dequantized in registers) wherever it serves the shape; PM355_GEMM_KERNEL=1 / 2 keep the older kernels (A/B)
+    if ((force == 0 || force == 3) && pm_gemm_pf_check(type, K, N, T) == 0) {
+        const pm_gemm_pf_job job = {type, N, W, Y, y_f16, bias, resid, silu_gate, (long) N};
+        return pm_launch_gemm_pf(&job, 1, xh, K, T, st);
+    }
     const long rs = (long) pm_weight_row_stride(type, K);
     // a launch over weight rows [r0, r0 + n): every per-column pointer is advanced, the token stride stays N
     auto params = [&](int r0, int n) {
@@ -633,7 +639,6 @@ int pm_launch_gemm_q_h(int type, const void * W, const float * X, const void * x
         }
     };
     // 256 x 256 tiles (gemm_q_f16_kernel2) when they still fill the chip; else the 128 x 256 kernel (more workgroups for small N)
-    static const int force = [] { const char * e = getenv("PM355_GEMM_KERNEL"); return e ? atoi(e) : 0; }();
     static const bool no_tail_split = [] { const char * e = getenv("PM355_GEMM_TAIL_SPLIT"); return e && e[0] == '0'; }();
     const int cus = pm_device_cus();
     const int tn = (N + BM2 - 1) / BM2, tt = (T + BN2 - 1) / BN2;

@@ -109,6 +109,13 @@ int pm_launch_gemm_q_ex(int type, const void * W, const float * X, float * Y, in
 int pm_launch_gemm_q_h(int type, const void * W, const float * X, const void * x_f16, float * Y, void * y_f16, int K, int N, int T,
                        const float * bias, const float * resid, const float * silu_gate, int reuse_x, hipStream_t st);
 
+// prompt GEMM, third generation (mmq_pf.hip): up to 4 matrices (Q4_K / Q6_K, at most two types per launch) that share the F16 activations xh [T][K]
+// go out as ONE launch. Job: Y[t * ldy + n] (f32) or, when Yh != null, Yh[t * ldy + n] (F16) = W . x (+ bias[n]) (+ resid[t * ldy + n]) (* silu(silu_gate[t * ldy + n]));
+// ldy == 0 means N. pm_gemm_pf_check: 0 when (type, K, N, T) is served, -1 type, -2 shape
+struct pm_gemm_pf_job { int type; int N; const void * W; float * Y; void * Yh; const float * bias; const float * resid; const float * silu_gate; long ldy; };
+int pm_gemm_pf_check(int type, int K, int N, int T);
+int pm_launch_gemm_pf(const pm_gemm_pf_job * jobs, int njobs, const void * xh, int K, int T, hipStream_t st);
+
 int pm_device_cus();
 struct pm_rope_cfg;
 

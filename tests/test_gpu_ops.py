@@ -558,7 +558,7 @@ def test_fused_qkv_mixed_types_one_launch(P, oracle):
 
 
 @pytest.mark.parametrize("t", QUANT_TYPES)
-@pytest.mark.parametrize("K,N,T", [(256, 132, 17), (1024, 256, 128), (768, 64, 200)])
+@pytest.mark.parametrize("K,N,T", [(256, 132, 17), (1024, 256, 128), (768, 64, 200), (2048, 516, 300), (1536, 260, 129)])
 def test_mfma_prefill_gemm_vs_oracle(P, oracle, t, K, N, T):
     """MFMA batched GEMM (F16 tiles, f32 accumulate, activations not re-quantized) against the reference arithmetic
     (activations quantized to Q8_K/Q8_0): the reference's own backend tolerance is NMSE <= 5e-4
