@@ -165,6 +165,17 @@ PM355_API int pm355_mul_mat_vec_fused_check(const pm355_matvec_job * jobs, int n
  * in for the reference CUDA plug-in's mul_mat_q / dequantize+cuBLAS large-batch path (ggml-cuda/mmq.cuh:2583). */
 PM355_API int pm355_mul_mat_q_mfma(int type, const void * W, int64_t K, int64_t N, const float * x, int64_t n_tokens, float * y,
                                    const float * bias, const float * resid, pm355_stream_t stream);
+/* Several matrices that share the activations (wq | wk | wv: the three MUL_MATs of build_llama, src/llama.cpp:11065-11092; ffn_gate | ffn_up, llm_build_ffn
+ * :9804) as ONE launch of the prompt GEMM (prima_cpp_amd/csrc/mmq_pf.hip), each job with its own quant type (at most two types per launch:
+ * Llama-3-70B Q4_K_M has Q4_K wq / wk next to Q5_K or Q6_K wv, src/llama.cpp:19360-19373) and its own output y[n_tokens][N], bias, residual. Jobs the
+ * kernel does not serve (Q8_0, K % 256 != 0) are launched one by one. njobs <= 4. */
+typedef struct pm355_gemm_job { int32_t type; int32_t N; const void * W; float * y; const float * bias; const float * resid; } pm355_gemm_job;
+PM355_API int pm355_mul_mat_q_mfma_multi(const pm355_gemm_job * jobs, int njobs, int64_t K, const float * x, int64_t n_tokens, pm355_stream_t stream);
+/* ffn_gate | ffn_up of a prompt batch as one launch of PAIR tiles: y[t][n] = silu(Wgate . x) * (Wup . x) (llm_build_ffn LLM_FFN_SILU + LLM_FFN_PAR,
+ * src/llama.cpp:9804-9890: MUL_MAT, MUL_MAT, SILU, MUL) - the gate result crosses from the waves that computed it to the waves that hold the matching
+ * ffn_up rows inside the workgroup. Same type and N for both matrices; PM355_E_UNSUPPORTED when the prompt kernel does not serve the shape. */
+PM355_API int pm355_mul_mat_q_mfma_pair(int type, const void * W_gate, const void * W_up, int64_t K, int64_t N, const float * x, int64_t n_tokens, float * y,
+                                        pm355_stream_t stream);
 /* Prompt-sized batches on the INTEGER matrix cores (v_mfma_i32_32x32x32_i8, prima_cpp_amd/csrc/mmq_big.hip): x is quantized to Q8_K
  * (quantize_row_q8_K, ggml-quants.c:3785) and multiplied with the CPU reference's own integer arithmetic (ggml_vec_dot_q4_K_q8_K /
  * ggml_vec_dot_q6_K_q8_K, ggml-quants.c:7713 / :8918): exact int32 sub-block sums, one f32 multiply-add per 256-weight super-block - the

@@ -223,6 +223,28 @@ int pm355_mul_mat_q_mfma(int type, const void * W, int64_t K, int64_t N, const f
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_mul_mat_q_mfma_multi(const pm355_gemm_job * jobs, int njobs, int64_t K, const float * x, int64_t n_tokens, pm355_stream_t st) {
+    (void) hipGetLastError();
+    if (!jobs || njobs < 1 || njobs > 4 || !x) return fail(PM355_E_RANGE, "mul_mat_q_mfma_multi: 1..4 jobs");
+    pm_gemm_pf_job jb[4];
+    for (int j = 0; j < njobs; ++j) jb[j] = {jobs[j].type, (int) jobs[j].N, jobs[j].W, jobs[j].y, nullptr, jobs[j].bias, jobs[j].resid, nullptr, 0};
+    const int rc = pm_launch_gemm_q_multi(jb, njobs, x, nullptr, (int) K, (int) n_tokens, S(st));
+    if (rc == -1) return fail(PM355_E_UNSUPPORTED, "mul_mat_q_mfma_multi: weight type");
+    if (rc == -2) return fail(PM355_E_SHAPE, "mul_mat_q_mfma_multi: K % 256 (K % 64 for Q8_0) and N % 4 required");
+    if (rc) return fail(PM355_E_HIP, "mul_mat_q_mfma_multi: scratch allocation");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int pm355_mul_mat_q_mfma_pair(int type, const void * W_gate, const void * W_up, int64_t K, int64_t N, const float * x, int64_t n_tokens, float * y, pm355_stream_t st) {
+    (void) hipGetLastError();
+    if (!W_gate || !W_up || !x || !y) return fail(PM355_E_SHAPE, "mul_mat_q_mfma_pair: null pointer");
+    if (pm_gemm_pf_check(type, (int) K, (int) N, (int) n_tokens)) return fail(PM355_E_UNSUPPORTED, "mul_mat_q_mfma_pair: type / shape not served by the prompt kernel");
+    const pm_gemm_pf_job jb[2] = {{type, (int) N, W_gate, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, {type, (int) N, W_up, y, nullptr, nullptr, nullptr, nullptr, 0}};
+    const int rc = pm_launch_gemm_q_pair(jb, x, (int) K, (int) n_tokens, S(st));
+    if (rc) return fail(PM355_E_HIP, "mul_mat_q_mfma_pair: launch");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 int pm355_mul_mat_q_i8(int type, const void * W, int64_t K, int64_t N, const float * x, int64_t n_tokens, float * y,
                        const float * bias, const float * resid, pm355_stream_t st) {
     if (!W || !x || !y) return fail(PM355_E_SHAPE, "mul_mat_q_i8: null pointer");

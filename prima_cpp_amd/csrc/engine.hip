@@ -670,19 +670,17 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
                 return pm_launch_gemm_q_h(w.type, w.d, nullptr, xh, y, yh, (int) w.K, (int) w.N, T, bias, resid, silu_gate, 0, s2 ? s2 : st);
             };
             pm_launch_rmsnorm_q8k(cur, (const float *) L.t[PM355_T_ATTN_NORM].d, nullptr, nullptr, E, T, hp.rms_eps, st, m->xn);
-            int rc = G(L.t[PM355_T_WQ], m->xn, m->q, nullptr, (const float *) L.t[PM355_T_BQ].d, nullptr);
-            // wk and wv (N = n_head_kv * head_dim: a fraction of the CUs each) run concurrently: wv on a side stream that forks
-            // after wq and joins before the rope
-            if (!m->side) {
-                if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->side_a, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&m->side_b, hipEventDisableTiming) != hipSuccess) return seterr(m, PM355_E_HIP, "prefill: side stream");
+            // wq | wk | wv: ONE launch over the shared activations, each matrix with its own quant type (mmq_pf.hip jobs; wk / wv alone - N = n_head_kv * head_dim -
+            // filled a fraction of the chip: 212 TFLOP/s as their own launches)
+            int rc;
+            {
+                const Tensor & wq = L.t[PM355_T_WQ], & wk = L.t[PM355_T_WK], & wv = L.t[PM355_T_WV];
+                const pm_gemm_pf_job qkvj[3] = {
+                    {wq.type, (int) wq.N, wq.d, m->q, nullptr, (const float *) L.t[PM355_T_BQ].d, nullptr, nullptr, 0},
+                    {wk.type, (int) wk.N, wk.d, m->k, nullptr, (const float *) L.t[PM355_T_BK].d, nullptr, nullptr, 0},
+                    {wv.type, (int) wv.N, wv.d, m->v, nullptr, (const float *) L.t[PM355_T_BV].d, nullptr, nullptr, 0}};
+                rc = pm_launch_gemm_q_multi(qkvj, 3, nullptr, m->xn, E, T, st);
             }
-            (void) hipEventRecord(m->side_a, st);
-            (void) hipStreamWaitEvent(m->side, m->side_a, 0);
-            rc |= G(L.t[PM355_T_WK], m->xn, m->k, nullptr, (const float *) L.t[PM355_T_BK].d, nullptr);
-            rc |= G(L.t[PM355_T_WV], m->xn, m->v, nullptr, (const float *) L.t[PM355_T_BV].d, nullptr, nullptr, m->side);
-            (void) hipEventRecord(m->side_b, m->side);
-            (void) hipStreamWaitEvent(st, m->side_b, 0);
             if (rc) return seterr(m, PM355_E_UNSUPPORTED, "prefill: qkv gemm");
             const long kvs = (long) hp.n_ctx * Hkv * dh;
             pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kvs,
@@ -698,8 +696,20 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
                       : pm_launch_gemm_q_ex(L.t[PM355_T_WO].type, L.t[PM355_T_WO].d, m->att, x_mid, (int) L.t[PM355_T_WO].K, (int) L.t[PM355_T_WO].N, T, nullptr, cur, nullptr, 0, st))
                 return seterr(m, PM355_E_UNSUPPORTED, "prefill: wo gemm");
             pm_launch_rmsnorm_q8k(x_mid, (const float *) L.t[PM355_T_FFN_NORM].d, nullptr, nullptr, E, T, hp.rms_eps, st, m->xn);
-            rc = G(L.t[PM355_T_FFN_GATE], m->xn, m->h, nullptr, nullptr, nullptr);
-            rc |= G(L.t[PM355_T_FFN_UP], m->xn, nullptr, m->h2, nullptr, nullptr, m->h);                // h2 = F16(silu(gate) * up), in the epilogue
+            {
+                // ffn_gate | ffn_up as ONE launch of pair tiles: h2 = F16(silu(gate) * up) comes out of the up waves' epilogue, the gate result crosses over inside
+                // the workgroup and never reaches HBM (two launches: gate as f32, read back by ffn_up's epilogue - 2 x T x n_ff x 4 bytes per layer)
+                const Tensor & wg = L.t[PM355_T_FFN_GATE], & wu = L.t[PM355_T_FFN_UP];
+                const pm_gemm_pf_job gu[2] = {{wg.type, (int) wg.N, wg.d, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
+                                              {wu.type, (int) wu.N, wu.d, nullptr, m->h2, nullptr, nullptr, nullptr, 0}};
+                static const bool no_pair = [] { const char * e = getenv("PM355_GEMM_PAIR"); return e && e[0] == '0'; }();
+                if (!no_pair && wg.type == wu.type && wg.N == wu.N && pm_gemm_pf_check(wg.type, E, (int) wg.N, T) == 0 && pm_gemm_pf_enabled())
+                    rc = pm_launch_gemm_pf_ex(gu, 2, m->xn, E, T, 1, st);
+                else {
+                    rc = G(wg, m->xn, m->h, nullptr, nullptr, nullptr);
+                    rc |= G(wu, m->xn, nullptr, m->h2, nullptr, nullptr, m->h);                          // h2 = F16(silu(gate) * up), in the epilogue
+                }
+            }
             if (rc) return seterr(m, PM355_E_UNSUPPORTED, "prefill: gate/up gemm");
             float * x_next = (il == m->hi - 1 && d_x_out) ? d_x_out : ((x_mid == bufs[0]) ? bufs[1] : bufs[0]);
             if (G(L.t[PM355_T_FFN_DOWN], m->h2, x_next, nullptr, nullptr, x_mid)) return seterr(m, PM355_E_UNSUPPORTED, "prefill: down gemm");

@@ -663,3 +663,53 @@ int pm_launch_gemm_q_h(int type, const void * W, const float * X, const void * x
     launch2(0, N);
     return 0;
 }
+
+// Several matrices over the same activations: f32 X is converted to F16 once (x_f16 != null: already F16, e.g. written by the producing kernel);
+// one launch of the third-generation kernel when it serves every job, else one launch per job.
+int pm_launch_gemm_q_multi(const pm_gemm_pf_job * jobs, int njobs, const float * X, const void * x_f16, int K, int T, hipStream_t st) {
+    if (njobs < 1 || njobs > 4 || !jobs || (!X && !x_f16)) return -2;
+    static const int force = [] { const char * e = getenv("PM355_GEMM_KERNEL"); return e ? atoi(e) : 0; }();
+    bool all_pf = force == 0 || force == 3;
+    int nty = 0, ty[4];
+    for (int j = 0; j < njobs; ++j) {
+        all_pf = all_pf && pm_gemm_pf_check(jobs[j].type, K, jobs[j].N, T) == 0;
+        bool seen = false;
+        for (int q = 0; q < nty; ++q) seen = seen || ty[q] == jobs[j].type;
+        if (!seen) ty[nty++] = jobs[j].type;
+    }
+    all_pf = all_pf && nty <= 2;
+    int rc = 0;
+    for (int j = 0; j < njobs; ++j) {
+        if (all_pf && j > 0) break;
+        const pm_gemm_pf_job & b = jobs[j];
+        if (all_pf) {
+            if (x_f16) return pm_launch_gemm_pf(jobs, njobs, x_f16, K, T, st);
+            // (the single-job entry converts X into the per-device scratch and launches job 0; the others follow on the same scratch)
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
+            const size_t need = (size_t) T * K;
+            if (need > g_xh_elems[dev]) {
+                if (g_xh[dev]) { (void) hipDeviceSynchronize(); (void) hipFree(g_xh[dev]); }
+                if (hipMalloc((void **) &g_xh[dev], need * 2) != hipSuccess) { g_xh[dev] = nullptr; g_xh_elems[dev] = 0; return -3; }
+                g_xh_elems[dev] = need;
+            }
+            hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) ((need / 8 + 255) / 256)), dim3(256), 0, st, X, g_xh[dev], (long) (need / 8));
+            return pm_launch_gemm_pf(jobs, njobs, g_xh[dev], K, T, st);
+        }
+        rc |= pm_launch_gemm_q_h(b.type, b.W, X, x_f16, b.Y, b.Yh, K, b.N, T, b.bias, b.resid, b.silu_gate, j > 0 ? 1 : 0, st);
+    }
+    return rc;
+}
+
+int pm_launch_gemm_q_pair(const pm_gemm_pf_job * gate_up, const float * X, int K, int T, hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
+    const size_t need = (size_t) T * K;
+    if (need > g_xh_elems[dev]) {
+        if (g_xh[dev]) { (void) hipDeviceSynchronize(); (void) hipFree(g_xh[dev]); }
+        if (hipMalloc((void **) &g_xh[dev], need * 2) != hipSuccess) { g_xh[dev] = nullptr; g_xh_elems[dev] = 0; return -3; }
+        g_xh_elems[dev] = need;
+    }
+    hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned) ((need / 8 + 255) / 256)), dim3(256), 0, st, X, g_xh[dev], (long) (need / 8));
+    return pm_launch_gemm_pf_ex(gate_up, 2, g_xh[dev], K, T, 1, st);
+}

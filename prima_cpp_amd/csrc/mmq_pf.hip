@@ -41,7 +41,7 @@ struct PfJob {
     const uint8_t * W; float * Y; _Float16 * Yh; const float * bias; const float * resid; const float * silu_gate;
     long row_stride, ldy; int type, N, tile0;      // tile0: this job's first row tile in the launch's numbering of row tiles
 };
-struct PfP { PfJob job[PF_MAX_JOBS]; int njobs, nt_n, nt_t; const _Float16 * Xh; int K, T; int grp; unsigned long long * trace; };
+struct PfP { PfJob job[PF_MAX_JOBS]; int njobs, nt_n, nt_t; const _Float16 * Xh; int K, T; int grp, pair; unsigned long long * trace; };
 // Ablations (measurement builds only: -DPM_GEMM_ABLATE=1 adds instantiations of the Q4_K 256-token kernel, PM355_GEMM_EXP=<bits> picks one; results are WRONG when set):
 // 1 no activation DMA, 2 no weight DMA, 4 no vmcnt wait / barrier, 8 no B fragment reads, 16 no dequantization, 32 no MFMA, 64 no stores;
 // 128: s_memtime stamps of super-block 5's second k-step (waves 0 and 4 of workgroup 0), printed by the launcher: the phase timeline
@@ -64,14 +64,20 @@ __device__ __forceinline__ uint32_t u2(half2v v) { return __builtin_bit_cast(uin
 __device__ __forceinline__ half2v pk_fma(half2v a, half2v b, half2v c) { return __builtin_elementwise_fma(a, b, c); }
 
 template <int TYPE> struct PfT;
-template <> struct PfT<PM_Q4_K> { static constexpr int NSTREAM = 2; };
-template <> struct PfT<PM_Q6_K> { static constexpr int NSTREAM = 3; };
+// NSTREAM: 1-KiB DMA pieces per 128-k slot (32 rows x 32 bytes each); EXTRA: bytes behind the two header slots (Q5_K: two super-blocks' qh, Q6_K: 8 super-blocks' d)
+template <> struct PfT<PM_Q4_K> { static constexpr int NSTREAM = 2, EXTRA = 0; };
+template <> struct PfT<PM_Q5_K> { static constexpr int NSTREAM = 2, EXTRA = 2048; };
+template <> struct PfT<PM_Q6_K> { static constexpr int NSTREAM = 3, EXTRA = 512; };
+template <int TYPE> constexpr int pf_wave_bytes() { return 2 * PfT<TYPE>::NSTREAM * 1024 + 1024 + PfT<TYPE>::EXTRA; }
 
 // the k loop + epilogue of one workgroup tile: rows [n0, n0 + 256) of job jb, tokens [t0, t0 + 32 NT)
+// role: 0 plain; 1 / 2 = the gate / up half of a PAIR tile (waves 0-3 multiply ffn_gate's rows [n0, n0 + 128), waves 4-7 the same rows of ffn_up; the gate
+// accumulators cross over through LDS after the k loop and the up waves store silu(gate) * up: ffn_gate's result never travels to HBM)
 template <int TYPE, int NT, int EXP>
-__device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const int n0, const int t0, uint8_t * smem) {
+__device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const int n0, const int t0, uint8_t * smem, const int role) {
     constexpr int BBUF = NT * 32 * 128;                       // one activation buffer: 32 NT tokens x 64 halfs
-    constexpr int NSTREAM = PfT<TYPE>::NSTREAM, SLOT = NSTREAM * 1024, AW = 2 * SLOT + 1024 + (TYPE == PM_Q6_K ? 512 : 0);   // per wave: two 128-k slots + two 512-byte header slots (+ Q6_K: 8 super-blocks' d)
+    constexpr int NSTREAM = PfT<TYPE>::NSTREAM, SLOT = NSTREAM * 1024, AW = pf_wave_bytes<TYPE>();   // per wave: two 128-k slots + two 512-byte header slots + EXTRA
+    constexpr bool K45 = TYPE == PM_Q4_K || TYPE == PM_Q5_K;
     constexpr int NQ = NT / 2;                                // activation DMA instructions per wave and k-step
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,7 +90,8 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
 
     // ---- DMA sources. weights: lane (row r, 16-byte piece h of the 32 bytes a 128-k slot holds per row and stream)
     const uint8_t * const Wg = jb.W;
-    const uint32_t wrow = (uint32_t) min(n0 + 32 * wave + r, jb.N - 1) * (uint32_t) jb.row_stride;
+    const int nw = n0 + 32 * (role ? wave & 3 : wave);         // first row of this wave
+    const uint32_t wrow = (uint32_t) min(nw + r, jb.N - 1) * (uint32_t) jb.row_stride;
     const uint32_t wsrc = wrow + 16u * (uint32_t) h;
     //      activations: instruction q of this wave = token rows 8 (wave + 8 q) .. + 8, lane (row lane / 8, LDS chunk lane % 8 <- global chunk ^ swizzle)
     const uint8_t * const Xg = (const uint8_t *) p.Xh;
@@ -107,28 +114,38 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
     };
     auto issue_A = [&](int m, int slot, int st) __attribute__((always_inline)) {    // 128-k piece m of the rows -> slot
         if (exp & 2) return;
-        dma16(Wg, wsrc + 32u * (uint32_t) min(m, 2 * nb - 1) + (uint32_t) st * (uint32_t) nb * 64u, aw_l + slot * SLOT + st * 1024);
+        const uint32_t mc = (uint32_t) min(m, 2 * nb - 1);
+        if (TYPE == PM_Q5_K)      // native 176-byte blocks: qs at + 48; lane (r, h) = bytes [16 st, + 16) of unit 2 (m % 2) + h
+            dma16(Wg, wrow + (mc >> 1) * 176u + 48u + (mc & 1u) * 64u + 32u * (uint32_t) h + 16u * (uint32_t) st, aw_l + slot * SLOT + st * 1024);
+        else
+            dma16(Wg, wsrc + 32u * mc + (uint32_t) st * (uint32_t) nb * 64u, aw_l + slot * SLOT + st * 1024);
     };
     auto issue_H = [&](int b) __attribute__((always_inline)) {                       // header (Q4_K) / int8 scales (Q6_K) of super-block b
         if (exp & 2) return;
         const uint32_t bc = (uint32_t) min(b, nb - 1);
-        const uint32_t off = TYPE == PM_Q4_K ? (uint32_t) nb * 128u + bc * 16u : pm_q6k_sc_off((uint32_t) nb, bc);
+        const uint32_t off = TYPE == PM_Q4_K ? (uint32_t) nb * 128u + bc * 16u : TYPE == PM_Q5_K ? bc * 176u : pm_q6k_sc_off((uint32_t) nb, bc);
         if (h == 0) dma16(Wg, wrow + off, aw_l + 2 * SLOT + (b & 1) * 512);
+    };
+    auto issue_QH = [&](int b) __attribute__((always_inline)) {                      // Q5_K: the 32 qh bytes of super-block b, lane (r, h) = bytes [16 h, + 16)
+        if (exp & 2) return;
+        dma16(Wg, wrow + (uint32_t) min(b, nb - 1) * 176u + 16u + 16u * (uint32_t) h, aw_l + 2 * SLOT + 1024 + (b & 1) * 1024);
     };
     auto issue_D = [&](int g) __attribute__((always_inline)) {                       // Q6_K: the fp16 d of super-blocks 8 g .. 8 g + 7 (16 bytes per row)
         if (exp & 2) return;
-        if (h == 0) dma16(Wg, wrow + pm_q6k_d_off((uint32_t) nb, (uint32_t) min(8 * g, nb - 8)), aw_l + 2 * SLOT + 1024);
+        // (16 bytes from the group's first d: a last group of fewer than 8 super-blocks ends exactly at the 16-byte-rounded row stride, pm_q6k_row_stride)
+        if (h == 0) dma16(Wg, wrow + pm_q6k_d_off((uint32_t) nb, (uint32_t) (8 * min(g, (nb - 1) >> 3))), aw_l + 2 * SLOT + 1024);
     };
 
     // ---- weight path, per 16-k slice i of a super-block (i = 0..15: k-step i / 4, slice j = i % 4; 128-k piece mm = i / 8, k-step ks = (i / 4) % 2 of it)
     struct Raw { u32x2 ql, qh; };
-    auto read_raw = [&](int i) __attribute__((always_inline)) {
+    auto read_raw = [&](int i, int b) __attribute__((always_inline)) {                // slice i of super-block b
         const int mm = (i >> 3) & 1, ks = (i >> 2) & 1, j = i & 3;
         Raw w;
-        if (TYPE == PM_Q4_K) {
+        if (K45) {
             // unit ks of the slot: qa = qs[0, 16) / qb = qs[16, 32) of its 64 weights; slices 0, 2 read qa, slices 1, 3 qb
             w.ql = *(const u32x2 *) (aw + mm * SLOT + (j & 1) * 1024 + ks * 512 + aoff);
             w.qh = u32x2{0, 0};
+            if (TYPE == PM_Q5_K) w.qh = *(const u32x2 *) (aw + 2 * SLOT + 1024 + (b & 1) * 1024 + (j & 1) * 512 + aoff);   // qh[16 (j & 1) + 8 h, + 8): bit s = 5th bit of sub-block s
         } else {
             // 32-weight group g = 2 ks + j / 2 of the 128-weight half: ql stream (g & 1), piece v = j & 1, nibble ks; qh piece v, bit pair g
             const int v = j & 1, st = j >> 1;
@@ -145,7 +162,7 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
     };
     half2v mul = {0, 0}, add = {0, 0}, muln = {0, 0}, addn = {0, 0};
     auto scales = [&](int i, half2v & mul, half2v & add) __attribute__((always_inline)) {   // multiplier / addend of slice i (constant per sub-block / 16-group)
-        if (TYPE == PM_Q4_K) {
+        if (K45) {
             const int s = i >> 1;                              // 32-weight sub-block of the super-block
             int sc, mn;
             k4_scale_min(hd[1], hd[2], hd[3], s, sc, mn);
@@ -164,14 +181,24 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
         const int ks = (i >> 2) & 1, j = i & 3;
         uint32_t v[2];
         half2v t[4];
-        if (TYPE == PM_Q4_K) {
+        if (K45) {
             const bool hi = j >> 1;                            // slices 2, 3: the unit's second sub-block = high nibbles
             const half2v bias = hi ? half2v{(_Float16) -64.0f, (_Float16) -64.0f} : half2v{(_Float16) -1024.0f, (_Float16) -1024.0f};
-            const uint32_t ex = hi ? 0x54545454u : 0x64646464u;                     // F16 exponent byte: 64 + m / 16 (m = nibble << 4) / 1024 + m
+            uint32_t ex[2] = {hi ? 0x54545454u : 0x64646464u, hi ? 0x54545454u : 0x64646464u};   // F16 exponent byte: 64 + m / 16 (m = nibble << 4) / 1024 + m
 #pragma unroll
             for (int c = 0; c < 2; ++c) v[c] = w.ql[c] & (hi ? 0xF0F0F0F0u : 0x0F0F0F0Fu);
+            if (TYPE == PM_Q5_K) {
+                // the 5th bit (bit s of the qh bytes, s = sub-block): low nibbles - bit 4 of the value byte; high nibbles (value byte = q << 4, ulp 1/16) - it is
+                // mantissa bit 8 = bit 0 of the half's HIGH byte, which v_perm takes from the exponent operand
+                const int sb = i >> 1;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) { t[2 * c] = h2(__builtin_amdgcn_perm(ex, v[c], 0x05010400u)); t[2 * c + 1] = h2(__builtin_amdgcn_perm(ex, v[c], 0x07030602u)); }
+                for (int c = 0; c < 2; ++c) {
+                    const uint32_t bit = (w.qh[c] >> sb) & 0x01010101u;
+                    if (hi) ex[c] |= bit; else v[c] |= bit << 4;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { t[2 * c] = h2(__builtin_amdgcn_perm(ex[c], v[c], 0x05010400u)); t[2 * c + 1] = h2(__builtin_amdgcn_perm(ex[c], v[c], 0x07030602u)); }
 #pragma unroll
             for (int c = 0; c < 4; ++c) t[c] = t[c] + bias;
 #pragma unroll
@@ -209,7 +236,7 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
 
     // ---- prologue: super-block 0's header, piece 0, k-steps 0 and 1
     uint32_t rd = 0, nx = BBUF, wr = 2 * BBUF;                 // ring: buffer of step s, s + 1, s + 2
-    issue_H(0); if (TYPE == PM_Q6_K) issue_D(0);
+    issue_H(0); if (TYPE == PM_Q6_K) issue_D(0); if (TYPE == PM_Q5_K) issue_QH(0);
 #pragma unroll
     for (int st = 0; st < NSTREAM; ++st) issue_A(0, 0, st);
 #pragma unroll
@@ -217,11 +244,11 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_hdr(0);
-    raw = read_raw(0);
+    raw = read_raw(0, 0);
     scales(0, mul, add);
     af[0] = dequant(raw, 0);
     if (TYPE == PM_Q6_K) scales(1, mul, add);
-    raw = read_raw(1);
+    raw = read_raw(1, 0);
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) bf[jt] = read_B(rd, 0, jt);
     // Two waves share a SIMD (waves w and w + 4): the second group runs HALF A SLICE behind the first, so that on every SIMD one wave is in the memory
@@ -255,7 +282,9 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
             if (NT == 8 || (j & 1) == 0) issue_B(4 * b + sq + 2, wr, NT == 8 ? j : j >> 1);
             if ((sq == 0 || sq == 2) && j >= 1 && j - 1 < NSTREAM) issue_A(2 * b + 1 + (sq >> 1), sq == 0 ? 1 : 0, j - 1);
             if (sq == 1 && j == 1) issue_H(b + 1);
-            if (TYPE == PM_Q6_K && sq == 0 && j == 3 && (b & 7) == 6) issue_D((b >> 3) + 1);
+            if (TYPE == PM_Q5_K && sq == 1 && j == 2) issue_QH(b + 1);
+            // (the slot's last reader - d of super-block 8 g + 7 - ran at slice 13 of super-block 8 g + 6; the first reader of the new group runs at slice 13 of 8 g + 7)
+            if (TYPE == PM_Q6_K && sq == 0 && j == 3 && (b & 7) == 7) issue_D((b >> 3) + 1);
             __builtin_amdgcn_sched_barrier(0);
             // the wave's vector work: the F16 operand of slice i + 1. HERE, not between the MFMAs: a packed-F16 instruction next to a wave's own MFMA costs its
             // full 8 cycles of issue (measured: 8 MFMAs + 22 vector instructions = 448 cycles, 56 per MFMA, while this half idled 250 cycles at its barrier)
@@ -288,7 +317,7 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            raw = read_raw((i + 2) & 15);                       // (consumed after two barriers: no exposed latency)
+            raw = read_raw((i + 2) & 15, b + ((i + 2) >> 4));                       // (consumed after two barriers: no exposed latency)
             if (i == 13) read_hdr(b + 1);
             if (sq == 1) stamp(4 * j + 3, b);
             if (!(exp & 4)) __builtin_amdgcn_s_barrier();
@@ -307,6 +336,21 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
 #pragma unroll
         for (int k = 0; k < 17; ++k) p.trace[(wave >> 2) * 17 + k] = ts[k];
     }
+    // ---- pair tiles: the gate waves park their accumulators in LDS (same lane, same register index as the up wave that needs them)
+    f32x4 * const xlds = (f32x4 *) smem;
+    if (role) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the last steps' look-ahead DMAs still land in the ring)
+        if (!late && !(exp & 4)) __builtin_amdgcn_s_barrier();  // (the first group is one barrier ahead of the second: level)
+        __builtin_amdgcn_s_barrier();                           // every wave is out of the k loop: the tile memory is free
+        if (role == 1) {
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xlds[(((wave & 3) * NT + jt) * 4 + g) * 64 + lane] = f32x4{acc[jt][4 * g], acc[jt][4 * g + 1], acc[jt][4 * g + 2], acc[jt][4 * g + 3]};
+        }
+        __syncthreads();
+        if (role == 1) return;
+    }
     // ---- epilogue: C[row = (e & 3) + 8 (e >> 2) + 4 h][col = r]; Y[t][n]: 4 consecutive n per float4
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
@@ -314,8 +358,13 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
         if (t >= p.T || (exp & 64)) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int n = n0 + 32 * wave + 8 * g + 4 * h;
+            const int n = nw + 8 * g + 4 * h;
             const long o = (long) t * jb.ldy + n;
+            if (role == 2) {                                    // silu(gate) * up, the arithmetic of the separate launches (silu_gate epilogue below)
+                const f32x4 gg = xlds[(((wave & 3) * NT + jt) * 4 + g) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[jt][4 * g + e] *= gg[e] / (1.0f + expf(-gg[e]));
+            }
             if (n + 3 < jb.N) {
                 float4 v = {acc[jt][4 * g], acc[jt][4 * g + 1], acc[jt][4 * g + 2], acc[jt][4 * g + 3]};
                 if (jb.bias)  { const float4 bb = ld_g((const float4 *) (jb.bias + n)); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
@@ -350,14 +399,22 @@ __global__ __launch_bounds__(PF_NTHR) void gemm_pf_kernel(PfP p) {
     if (slot >= per_x * p.nt_t) return;
     const int tile_n = x + 8 * (slot / p.nt_t), tile_t = slot % p.nt_t;
     PfJob jb = p.job[0];                                       // (selected field by field with static indices: a run-time index would put the table into scratch)
+    int n0, role = 0;
+    if (p.pair) {                                              // 128-row tiles of job 0 (waves 0-3) and job 1 (waves 4-7)
+        role = 1 + __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 8));
+        if (role == 2) jb = p.job[1];
+        n0 = tile_n * 128;
+    } else {
 #pragma unroll
-    for (int q = 1; q < PF_MAX_JOBS; ++q) if (q < p.njobs && tile_n >= p.job[q].tile0) jb = p.job[q];
-    const int n0 = (tile_n - jb.tile0) * 256, t0 = tile_t * 32 * NT;
-    if (TA == TB || jb.type == TA) pf_body<TA, NT, EXP>(p, jb, n0, t0, pf_smem);
-    else pf_body<TB, NT, EXP>(p, jb, n0, t0, pf_smem);
+        for (int q = 1; q < PF_MAX_JOBS; ++q) if (q < p.njobs && tile_n >= p.job[q].tile0) jb = p.job[q];
+        n0 = (tile_n - jb.tile0) * 256;
+    }
+    const int t0 = tile_t * 32 * NT;
+    if (TA == TB || jb.type == TA) pf_body<TA, NT, EXP>(p, jb, n0, t0, pf_smem, role);
+    else pf_body<TB, NT, EXP>(p, jb, n0, t0, pf_smem, role);
 }
 
-template <int TYPE, int NT> constexpr size_t pf_lds_bytes() { return (size_t) 3 * NT * 32 * 128 + (size_t) 8 * (2 * PfT<TYPE>::NSTREAM * 1024 + 1024 + (TYPE == PM_Q6_K ? 512 : 0)); }
+template <int TA, int TB, int NT> constexpr size_t pf_lds_bytes() { return (size_t) 3 * NT * 32 * 128 + (size_t) 8 * (pf_wave_bytes<TA>() > pf_wave_bytes<TB>() ? pf_wave_bytes<TA>() : pf_wave_bytes<TB>()); }
 
 void pf_allow_lds(const void * kern, size_t lds) {
     struct E { const void * k; int dev; };
@@ -370,20 +427,31 @@ void pf_allow_lds(const void * kern, size_t lds) {
 
 } // namespace
 
+bool pm_gemm_pf_enabled() {
+    static const int force = [] { const char * e = getenv("PM355_GEMM_KERNEL"); return e ? atoi(e) : 0; }();
+    return force == 0 || force == 3;
+}
+
 // 0 when pm_launch_gemm_pf serves (type, K, N, T)
 int pm_gemm_pf_check(int type, int K, int N, int T) {
-    if (type != PM_Q4_K && type != PM_Q6_K) return -1;
+    if (type != PM_Q4_K && type != PM_Q5_K && type != PM_Q6_K) return -1;
     if (K % 256 || K < 512 || N < 1 || N % 4 || T < 1) return -2;
-    if (type == PM_Q6_K && (K % 2048 || PM_Q6K_SCD)) return -2;   // (the d's travel as 16-byte pieces = 8 super-blocks of the separate-stream row tail)
+    if (type == PM_Q6_K && PM_Q6K_SCD) return -2;               // (the d's travel as 16-byte pieces = 8 super-blocks of the separate-stream row tail)
     if ((size_t) T * (size_t) K * 2 >= ((size_t) 1 << 32) || (size_t) N * pm_weight_row_stride(type, K) >= ((size_t) 1 << 32)) return -2;   // 32-bit lane offsets
     return 0;
 }
 
 // One launch over njobs <= 4 matrices that share the F16 activations xh [T][K]. Job j: Y_j[t][n] (f32, token stride ldy_j) or Yh_j (F16) =
 // W_j . x (+bias)(+resid)(x silu(gate)). 0, or -1 type / -2 shape
-int pm_launch_gemm_pf(const pm_gemm_pf_job * jobs, int njobs, const void * xh, int K, int T, hipStream_t st) {
+int pm_launch_gemm_pf(const pm_gemm_pf_job * jobs, int njobs, const void * xh, int K, int T, hipStream_t st) { return pm_launch_gemm_pf_ex(jobs, njobs, xh, K, T, 0, st); }
+
+// pair != 0: jobs[0] = ffn_gate, jobs[1] = ffn_up (same type, same N; jobs[0]'s outputs are ignored): jobs[1]'s output = silu(W0 . x) * (W1 . x) (+ its own bias / resid
+// before the product are NOT applied to the gate). One launch, the gate result stays on the chip.
+int pm_launch_gemm_pf_ex(const pm_gemm_pf_job * jobs, int njobs, const void * xh, int K, int T, int pair, hipStream_t st) {
     if (njobs < 1 || njobs > PF_MAX_JOBS || !jobs || !xh) return -2;
+    if (pair && (njobs != 2 || jobs[0].type != jobs[1].type || jobs[0].N != jobs[1].N || jobs[0].bias || jobs[0].resid || jobs[1].silu_gate)) return -2;
     PfP p = {};
+    p.pair = pair ? 1 : 0;
     int tiles = 0, ta = jobs[0].type, tb = jobs[0].type;
     for (int j = 0; j < njobs; ++j) {
         const int rc = pm_gemm_pf_check(jobs[j].type, K, jobs[j].N, T);
@@ -394,6 +462,7 @@ int pm_launch_gemm_pf(const pm_gemm_pf_job * jobs, int njobs, const void * xh, i
         o.row_stride = (long) pm_weight_row_stride(jobs[j].type, K); o.ldy = jobs[j].ldy ? jobs[j].ldy : jobs[j].N; o.type = jobs[j].type; o.N = jobs[j].N; o.tile0 = tiles;
         tiles += (jobs[j].N + 255) / 256;
     }
+    if (pair) tiles = (jobs[0].N + 127) / 128;
     if (ta > tb) { const int t = ta; ta = tb; tb = t; }       // (Q4_K, Q6_K) in that order
     static const int grp = [] { const char * e = getenv("PM355_GEMM_PF_GROUP"); return e ? atoi(e) : 0; }();
     p.grp = grp;
@@ -418,9 +487,9 @@ int pm_launch_gemm_pf(const pm_gemm_pf_job * jobs, int njobs, const void * xh, i
         if (!tr) (void) hipMalloc((void **) &tr, 42 * 8);
         p.trace = tr;
         switch (exp_sw) {
-#define PF_AB(E) case E: go(gemm_pf_kernel<PM_Q4_K, PM_Q4_K, 8, E>, pf_lds_bytes<PM_Q4_K, 8>()); return 0;
+#define PF_AB(E) case E: go(gemm_pf_kernel<PM_Q4_K, PM_Q4_K, 8, E>, pf_lds_bytes<PM_Q4_K, PM_Q4_K, 8>()); return 0;
             PF_AB(3) PF_AB(4) PF_AB(8) PF_AB(16) PF_AB(24) PF_AB(27)
-#define PF_TR(E) case 128 + E: go(gemm_pf_kernel<PM_Q4_K, PM_Q4_K, 8, 128 + E>, pf_lds_bytes<PM_Q4_K, 8>()); break;
+#define PF_TR(E) case 128 + E: go(gemm_pf_kernel<PM_Q4_K, PM_Q4_K, 8, 128 + E>, pf_lds_bytes<PM_Q4_K, PM_Q4_K, 8>()); break;
             PF_TR(0) PF_TR(3) PF_TR(8) PF_TR(16) PF_TR(24) PF_TR(27)
 #undef PF_TR
             default: return -2;
@@ -436,10 +505,11 @@ int pm_launch_gemm_pf(const pm_gemm_pf_job * jobs, int njobs, const void * xh, i
         return 0;
     }
 #endif
-#define PF_GO(A, B, LT) (nt == 8 ? go(gemm_pf_kernel<A, B, 8>, pf_lds_bytes<LT, 8>()) : go(gemm_pf_kernel<A, B, 4>, pf_lds_bytes<LT, 4>()))
-    if (ta == PM_Q4_K && tb == PM_Q4_K) PF_GO(PM_Q4_K, PM_Q4_K, PM_Q4_K);
-    else if (ta == PM_Q6_K && tb == PM_Q6_K) PF_GO(PM_Q6_K, PM_Q6_K, PM_Q6_K);
-    else PF_GO(PM_Q4_K, PM_Q6_K, PM_Q6_K);
+#define PF_GO(A, B) (nt == 8 ? go(gemm_pf_kernel<A, B, 8>, pf_lds_bytes<A, B, 8>()) : go(gemm_pf_kernel<A, B, 4>, pf_lds_bytes<A, B, 4>()))
+    if (ta == tb) { if (ta == PM_Q4_K) PF_GO(PM_Q4_K, PM_Q4_K); else if (ta == PM_Q5_K) PF_GO(PM_Q5_K, PM_Q5_K); else PF_GO(PM_Q6_K, PM_Q6_K); }
+    else if (ta == PM_Q4_K && tb == PM_Q5_K) PF_GO(PM_Q4_K, PM_Q5_K);
+    else if (ta == PM_Q4_K && tb == PM_Q6_K) PF_GO(PM_Q4_K, PM_Q6_K);
+    else PF_GO(PM_Q5_K, PM_Q6_K);
 #undef PF_GO
     return 0;
 }

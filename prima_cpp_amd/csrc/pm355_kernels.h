@@ -114,7 +114,15 @@ int pm_launch_gemm_q_h(int type, const void * W, const float * X, const void * x
 // ldy == 0 means N. pm_gemm_pf_check: 0 when (type, K, N, T) is served, -1 type, -2 shape
 struct pm_gemm_pf_job { int type; int N; const void * W; float * Y; void * Yh; const float * bias; const float * resid; const float * silu_gate; long ldy; };
 int pm_gemm_pf_check(int type, int K, int N, int T);
+bool pm_gemm_pf_enabled();      // false under PM355_GEMM_KERNEL=1 / 2 (A/B against the older prompt kernels)
 int pm_launch_gemm_pf(const pm_gemm_pf_job * jobs, int njobs, const void * xh, int K, int T, hipStream_t st);
+// pair != 0: jobs = {ffn_gate, ffn_up} (same type and N): jobs[1]'s output = silu(W0 . x) * (W1 . x) in one launch, the gate result never leaves the chip
+int pm_launch_gemm_pf_ex(const pm_gemm_pf_job * jobs, int njobs, const void * xh, int K, int T, int pair, hipStream_t st);
+
+// up to 4 matrices over the same activations (f32 X converted once, or x_f16 given): ONE launch of mmq_pf.hip when it serves all of them, else one launch each
+int pm_launch_gemm_q_multi(const pm_gemm_pf_job * jobs, int njobs, const float * X, const void * x_f16, int K, int T, hipStream_t st);
+
+int pm_launch_gemm_q_pair(const pm_gemm_pf_job * gate_up, const float * X, int K, int T, hipStream_t st);   // f32 X -> F16 scratch -> pair launch
 
 int pm_device_cus();
 struct pm_rope_cfg;

@@ -326,6 +326,42 @@ def mul_mat_mfma(w, x, bias=None, resid=None):
     return y
 
 
+class GemmJob(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("type", _C.c_int32), ("N", _C.c_int32), ("W", _C.c_void_p), ("y", _C.c_void_p), ("bias", _C.c_void_p), ("resid", _C.c_void_p)]
+
+
+def mul_mat_mfma_multi(ws, x, biases=None, resids=None):
+    """Several matrices over the same activations as ONE launch of the prompt GEMM (mmq_pf.hip): x f32 [T, K] -> list of f32 [T, N_j]."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_mul_mat_q_mfma_multi.restype = C.c_int
+    lib.pm355_mul_mat_q_mfma_multi.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    K = ws[0].K
+    x2 = x.contiguous().view(-1, K)
+    ys = [torch.empty((x2.shape[0], w.N), dtype=torch.float32, device=x.device) for w in ws]
+    jobs = (GemmJob * len(ws))()
+    for j, w in enumerate(ws):
+        jobs[j].type, jobs[j].N, jobs[j].W, jobs[j].y = w.type, w.N, ptr(w.data), ptr(ys[j])
+        jobs[j].bias = ptr(biases[j]) if biases else None
+        jobs[j].resid = ptr(resids[j]) if resids else None
+    check(lib.pm355_mul_mat_q_mfma_multi(C.addressof(jobs), len(ws), K, ptr(x2), x2.shape[0], stream_ptr()), "mul_mat_q_mfma_multi")
+    return ys
+
+
+def mul_mat_mfma_pair(w_gate, w_up, x):
+    """silu(W_gate . x) * (W_up . x) as one launch of pair tiles (mmq_pf.hip): x f32 [T, K] -> f32 [T, N]."""
+    import ctypes as C
+    lib = L.load()
+    lib.pm355_mul_mat_q_mfma_pair.restype = C.c_int
+    lib.pm355_mul_mat_q_mfma_pair.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    x2 = x.contiguous().view(-1, w_gate.K)
+    y = torch.empty((x2.shape[0], w_gate.N), dtype=torch.float32, device=x.device)
+    check(lib.pm355_mul_mat_q_mfma_pair(w_gate.type, ptr(w_gate.data), ptr(w_up.data), w_gate.K, w_gate.N, ptr(x2), x2.shape[0], ptr(y), stream_ptr()),
+          "mul_mat_q_mfma_pair")
+    return y
+
+
 class QkvStore(__import__("ctypes").Structure):
     import ctypes as _C
     _fields_ = [("rope_table", _C.c_void_p), ("d_pos", _C.c_void_p), ("d_cell_nkv", _C.c_void_p), ("k_cache", _C.c_void_p),

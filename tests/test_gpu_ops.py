@@ -558,7 +558,7 @@ def test_fused_qkv_mixed_types_one_launch(P, oracle):
 
 
 @pytest.mark.parametrize("t", QUANT_TYPES)
-@pytest.mark.parametrize("K,N,T", [(256, 132, 17), (1024, 256, 128), (768, 64, 200), (2048, 516, 300), (1536, 260, 129)])
+@pytest.mark.parametrize("K,N,T", [(256, 132, 17), (1024, 256, 128), (768, 64, 200), (2048, 516, 300), (1536, 260, 129), (6144, 64, 96)])
 def test_mfma_prefill_gemm_vs_oracle(P, oracle, t, K, N, T):
     """MFMA batched GEMM (F16 tiles, f32 accumulate, activations not re-quantized) against the reference arithmetic
     (activations quantized to Q8_K/Q8_0): the reference's own backend tolerance is NMSE <= 5e-4
@@ -578,6 +578,48 @@ def test_mfma_prefill_gemm_vs_oracle(P, oracle, t, K, N, T):
     ref = oracle.mul_mat(t, blocks, K, N, x) + bias + resid
     nm_ref = ((got - ref) ** 2).sum() / (ref ** 2).sum()
     assert nm_ref < 5e-4, nm_ref
+
+
+@pytest.mark.parametrize("types", [(Q4_K, Q4_K, Q6_K), (Q4_K, Q4_K, Q5_K), (Q6_K, Q6_K, Q6_K), (Q5_K, Q6_K), (Q4_K,)])
+@pytest.mark.parametrize("T", [77, 300])
+def test_prompt_gemm_jobs_one_launch(P, oracle, types, T):
+    """wq | wk | wv of a prompt batch as jobs of ONE launch (mmq_pf.hip), each with its own quant type, bias and row count (incl. a ragged last tile):
+    every job's output is bit-identical to its own single launch, and equals the f64 product of the dequantized weights to F16 operand rounding."""
+    torch = P.torch
+    rng = np.random.default_rng(81)
+    K = 1024
+    Ns = [520, 132, 256][:len(types)]
+    blocks = [rand_blocks(t, n, K, rng, scale=1.0) for t, n in zip(types, Ns)]
+    ws = [P.upload_weight(t, b, K, n) for t, b, n in zip(types, blocks, Ns)]
+    x = rng.normal(0, 1, (T, K)).astype(np.float32)
+    biases = [torch.from_numpy(rng.normal(0, 1, n).astype(np.float32)).cuda() for n in Ns]
+    xd = _dev(P, x)
+    ys = P.mul_mat_mfma_multi(ws, xd, biases=biases)
+    for w, t, b, bl, y in zip(ws, types, biases, blocks, ys):
+        single = P.mul_mat_mfma(w, xd, bias=b)
+        assert torch.equal(y, single)
+        rs = row_size(t, K)
+        Wf = np.stack([oracle.dequantize_row(t, bl[r * rs:(r + 1) * rs], K) for r in range(w.N)]).astype(np.float64)
+        exact = x.astype(np.float64) @ Wf.T + b.cpu().numpy()
+        nm = ((y.cpu().numpy() - exact) ** 2).sum() / (exact ** 2).sum()
+        assert nm < 1e-6, (t, nm)
+
+
+@pytest.mark.parametrize("t", [Q4_K, Q5_K, Q6_K])
+@pytest.mark.parametrize("K,N,T", [(1024, 384, 200), (2048, 132, 64), (512, 256, 257)])
+def test_prompt_gemm_pair_tiles_silu_gate_times_up(P, oracle, t, K, N, T):
+    """ffn_gate | ffn_up as one launch of pair tiles: silu(gate) * up formed inside the workgroup == the two separate launches followed by the product
+    (the reference's MUL_MAT, MUL_MAT, SILU, MUL: llm_build_ffn, src/llama.cpp:9804)."""
+    torch = P.torch
+    rng = np.random.default_rng(83)
+    wg = P.upload_weight(t, rand_blocks(t, N, K, rng, scale=1.0), K, N)
+    wu = P.upload_weight(t, rand_blocks(t, N, K, rng, scale=1.0), K, N)
+    x = _dev(P, rng.normal(0, 1, (T, K)).astype(np.float32))
+    got = P.mul_mat_mfma_pair(wg, wu, x)
+    g, u = P.mul_mat_mfma(wg, x), P.mul_mat_mfma(wu, x)
+    want = (g.double() / (1.0 + torch.exp(-g.double()))) * u.double()
+    err = (got.double() - want).abs().max().item()
+    assert err <= 2e-6 * want.abs().max().item(), err
 
 
 @pytest.mark.parametrize("mode", [0, 2])
