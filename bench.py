@@ -338,15 +338,50 @@ def probe_prefill(hp, mixture, n_tok, small_batches=(2, 3, 4, 8, 16, 32, 64)):
         e1.record(st)
         torch.cuda.synchronize()
         lib_tf = 2.0 * n_tok * Ed * F / (e0.elapsed_time(e1) * 1e3 / iters) / 1e6
+        tname = {Q4_K: "Q4_K", Q6_K: "Q6_K"}.get(ty.value, str(ty.value))
         out["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-                           "kernel": f"gemm_q_f16_kernel2<{'Q4_K' if ty.value == Q4_K else 'Q6_K' if ty.value == Q6_K else ty.value}> ffn_gate "
-                                     f"[{n_tok} x {Ed}] x [{F} x {Ed}]^T incl. the f32->f16 conversion of the activations",
+                           "kernel": f"gemm_pf_kernel<{tname}> (mmq_pf.hip) ffn_gate [{n_tok} x {Ed}] x [{F} x {Ed}]^T incl. the f32->f16 conversion of the activations",
                            "flops_per_launch": 2.0 * n_tok * Ed * F, "avg_launch_us": round(us, 1),
                            "library_f16_gemm_same_shape_tflops": round(lib_tf, 1), "frac_of_library_f16_gemm": round(tf / lib_tf, 4),
                            "traffic": None,
-                           "note": "peak = dense F16 MFMA at the nominal 2.4 GHz; under this load the chip runs at ~1.6 GHz (GRBM_GUI_ACTIVE / duration, "
-                                   "profiles/r02_prefill_pmc.txt), where rocprofv3 reports MfmaUtil 46 %; library_f16_gemm = torch.matmul (hipBLASLt) F16 x F16 "
-                                   "of the same shape on this box, measured here only as the practical ceiling"}
+                           "note": "peak = dense F16 MFMA at the nominal 2.4 GHz. With random operands the matrix pipe itself is power-throttled on this chip: "
+                                   "back-to-back v_mfma_f32_32x32x16_f16 on every SIMD and nothing else take 25.5 ns each = 1.3 PFLOP/s (tools/r6/mfma_valu_probe.hip, "
+                                   "profiles/r06_mfma_power_limit.txt); library_f16_gemm = torch.matmul (hipBLASLt) F16 x F16 of the same shape on this box, "
+                                   "measured here only as the practical ceiling"}
+        # the launches the layer really makes: wq | wk | wv as ONE launch of jobs, ffn_gate | ffn_up as ONE launch of pair tiles (silu(gate) * up inside the workgroup)
+        try:
+            class _Job(C.Structure):
+                _fields_ = [("type", C.c_int32), ("N", C.c_int32), ("W", C.c_void_p), ("y", C.c_void_p), ("bias", C.c_void_p), ("resid", C.c_void_p)]
+            jobs, outs, nq = (_Job * 3)(), [], 0
+            for j, k in enumerate((E.T_WQ, E.T_WK, E.T_WV)):
+                tj = C.c_int(0)
+                wj = lib.pm355_model_tensor_ptr(win.h, k, 0, C.byref(tj))
+                nj = Eq if k == E.T_WQ else Ekv
+                outs.append(torch.empty(n_tok, nj, device="cuda"))
+                jobs[j].type, jobs[j].N, jobs[j].W, jobs[j].y = tj.value, nj, wj, outs[-1].data_ptr()
+                nq += nj
+            lib.pm355_mul_mat_q_mfma_multi.restype = C.c_int
+            lib.pm355_mul_mat_q_mfma_multi.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+            runq = lambda: P.check(lib.pm355_mul_mat_q_mfma_multi(C.addressof(jobs), 3, Ed, x.data_ptr(), n_tok, st.cuda_stream), "qkv probe")
+            tu = C.c_int(0)
+            wu = lib.pm355_model_tensor_ptr(win.h, E.T_FFN_UP, 0, C.byref(tu))
+            lib.pm355_mul_mat_q_mfma_pair.restype = C.c_int
+            lib.pm355_mul_mat_q_mfma_pair.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+            runp = lambda: P.check(lib.pm355_mul_mat_q_mfma_pair(ty.value, wp, wu, Ed, F, x.data_ptr(), n_tok, y.data_ptr(), st.cuda_stream), "pair probe")
+            for nm, fn, fl in (("qkv_one_launch", runq, 2.0 * n_tok * Ed * nq), ("gate_up_pair_launch", runp, 4.0 * n_tok * Ed * F)):
+                if nm == "gate_up_pair_launch" and tu.value != ty.value:
+                    continue
+                fn(); torch.cuda.synchronize()
+                e0.record(st)
+                for _ in range(iters):
+                    fn()
+                e1.record(st)
+                torch.cuda.synchronize()
+                u2 = e0.elapsed_time(e1) * 1e3 / iters
+                out["roofline"][nm] = {"avg_launch_us": round(u2, 1), "tflops": round(fl / u2 / 1e6, 1), "frac": round(fl / u2 / 1e6 / 2500.0, 4),
+                                       "note": "incl. the f32->f16 conversion of the activations"}
+        except Exception as e:
+            out["roofline"]["launch_forms"] = {"error": str(e)[:300]}
     except Exception as e:
         out["roofline"] = {"error": str(e)[:300]}
     win.close()

@@ -26,6 +26,7 @@
 #include "pm355_kernels.h"
 #include <stdlib.h>
 #include <stdio.h>
+#include <mutex>
 
 namespace {
 
@@ -41,7 +42,7 @@ struct PfJob {
     const uint8_t * W; float * Y; _Float16 * Yh; const float * bias; const float * resid; const float * silu_gate;
     long row_stride, ldy; int type, N, tile0;      // tile0: this job's first row tile in the launch's numbering of row tiles
 };
-struct PfP { PfJob job[PF_MAX_JOBS]; int njobs, nt_n, nt_t; const _Float16 * Xh; int K, T; int grp, pair; unsigned long long * trace; };
+struct PfP { PfJob job[PF_MAX_JOBS]; int njobs, nt_n, nt_t; const _Float16 * Xh; int K, T; int grp, pair; int splitk; float * ws; unsigned * cnt; unsigned long long * trace; };
 // Ablations (measurement builds only: -DPM_GEMM_ABLATE=1 adds instantiations of the Q4_K 256-token kernel, PM355_GEMM_EXP=<bits> picks one; results are WRONG when set):
 // 1 no activation DMA, 2 no weight DMA, 4 no vmcnt wait / barrier, 8 no B fragment reads, 16 no dequantization, 32 no MFMA, 64 no stores;
 // 128: s_memtime stamps of super-block 5's second k-step (waves 0 and 4 of workgroup 0), printed by the launcher: the phase timeline
@@ -74,7 +75,7 @@ template <int TYPE> constexpr int pf_wave_bytes() { return 2 * PfT<TYPE>::NSTREA
 // role: 0 plain; 1 / 2 = the gate / up half of a PAIR tile (waves 0-3 multiply ffn_gate's rows [n0, n0 + 128), waves 4-7 the same rows of ffn_up; the gate
 // accumulators cross over through LDS after the k loop and the up waves store silu(gate) * up: ffn_gate's result never travels to HBM)
 template <int TYPE, int NT, int EXP>
-__device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const int n0, const int t0, uint8_t * smem, const int role) {
+__device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const int n0, const int t0, uint8_t * smem, const int role, const int ks, const int tile_id) {
     constexpr int BBUF = NT * 32 * 128;                       // one activation buffer: 32 NT tokens x 64 halfs
     constexpr int NSTREAM = PfT<TYPE>::NSTREAM, SLOT = NSTREAM * 1024, AW = pf_wave_bytes<TYPE>();   // per wave: two 128-k slots + two 512-byte header slots + EXTRA
     constexpr bool K45 = TYPE == PM_Q4_K || TYPE == PM_Q5_K;
@@ -236,19 +237,21 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
 
     // ---- prologue: super-block 0's header, piece 0, k-steps 0 and 1
     uint32_t rd = 0, nx = BBUF, wr = 2 * BBUF;                 // ring: buffer of step s, s + 1, s + 2
-    issue_H(0); if (TYPE == PM_Q6_K) issue_D(0); if (TYPE == PM_Q5_K) issue_QH(0);
+    // split K: slice ks of S takes the super-blocks [b0, b1); all indices below stay absolute (slot parities, look-ahead clamps)
+    const int S = p.splitk, b0 = (int) ((long) ks * nb / S), b1 = (int) ((long) (ks + 1) * nb / S);
+    issue_H(b0); if (TYPE == PM_Q6_K) issue_D(b0 >> 3); if (TYPE == PM_Q5_K) issue_QH(b0);
 #pragma unroll
-    for (int st = 0; st < NSTREAM; ++st) issue_A(0, 0, st);
+    for (int st = 0; st < NSTREAM; ++st) issue_A(2 * b0, 0, st);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { issue_B(0, rd, q); issue_B(1, nx, q); }
+    for (int q = 0; q < NQ; ++q) { issue_B(4 * b0, rd, q); issue_B(4 * b0 + 1, nx, q); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    read_hdr(0);
-    raw = read_raw(0, 0);
+    read_hdr(b0);
+    raw = read_raw(0, b0);
     scales(0, mul, add);
     af[0] = dequant(raw, 0);
     if (TYPE == PM_Q6_K) scales(1, mul, add);
-    raw = read_raw(1, 0);
+    raw = read_raw(1, b0);
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) bf[jt] = read_B(rd, 0, jt);
     // Two waves share a SIMD (waves w and w + 4): the second group runs HALF A SLICE behind the first, so that on every SIMD one wave is in the memory
@@ -259,9 +262,9 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
 
     unsigned long long ts[17] = {};
     auto stamp = [&](int k, int b) __attribute__((always_inline)) {
-        if ((exp & 128) && b == 5) asm volatile("s_memtime %0" : "=s"(ts[k]));
+        if ((exp & 128) && b == b0 + 5) asm volatile("s_memtime %0" : "=s"(ts[k]));
     };
-    for (int b = 0; b < nb; ++b) {
+    for (int b = b0; b < b1; ++b) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int j = i & 3, sq = i >> 2;                  // slice of the k-step, k-step of the super-block
@@ -336,12 +339,61 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
 #pragma unroll
         for (int k = 0; k < 17; ++k) p.trace[(wave >> 2) * 17 + k] = ts[k];
     }
-    // ---- pair tiles: the gate waves park their accumulators in LDS (same lane, same register index as the up wave that needs them)
     f32x4 * const xlds = (f32x4 *) smem;
-    if (role) {
+    if (role || S > 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the last steps' look-ahead DMAs still land in the ring)
-        if (!late && !(exp & 4)) __builtin_amdgcn_s_barrier();  // (the first group is one barrier ahead of the second: level)
+        if (!late && !(exp & 4)) __builtin_amdgcn_s_barrier();  // (the second group has passed one barrier more: level)
         __builtin_amdgcn_s_barrier();                           // every wave is out of the k loop: the tile memory is free
+    }
+    // ---- split K: every slice leaves its partial tile in a slab (lane-linear, 1 KiB per store instruction); the LAST arriver of a tile adds the S partials in
+    //      slice order, so the sum does not depend on who arrives when, and runs the epilogue. Hand-off = plain stores, one agent-scope
+    //      release before the ticket, one acquire behind it (cdna_hip_programming.md, Guideline 16 counter form); the counter returns to 0 for the next launch.
+    if (S > 1) {
+        f32x4 * const slab0 = (f32x4 *) p.ws + (size_t) tile_id * S * (8 * NT * 4 * 64);
+        f32x4 * const mine = slab0 + (size_t) ks * (8 * NT * 4 * 64);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(PM_G f32x4 *) (mine + ((wave * NT + jt) * 4 + g) * 64 + lane) = f32x4{acc[jt][4 * g], acc[jt][4 * g + 1], acc[jt][4 * g + 2], acc[jt][4 * g + 3]};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *(volatile unsigned *) smem = __hip_atomic_fetch_add(p.cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const unsigned ticket = *(volatile unsigned *) smem;
+        if (ticket != (unsigned) (S - 1)) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(p.cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        // (all S slabs from memory, the reducer's own included - a second register copy of the tile would not fit; one token tile at a time, fenced:
+        //  left alone the scheduler puts every load of the tile in flight and spills the accumulators)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[jt][e] = 0.0f;
+        for (int q = 0; q < S; ++q) {
+            const f32x4 * sl = slab0 + (size_t) q * (8 * NT * 4 * 64) + lane;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                f32x4 v[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v[g] = *(const PM_G f32x4 *) (sl + ((wave * NT + jt) * 4 + g) * 64);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[jt][4 * g + e] += v[g][e];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                                        // (the ticket word is tile memory: pair tiles write there next)
+    }
+    // ---- pair tiles: the gate waves park their accumulators in LDS (same lane, same register index as the up wave that needs them)
+    if (role) {
         if (role == 1) {
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt)
@@ -394,7 +446,8 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
 template <int TA, int TB, int NT, int EXP = 0>
 __global__ __launch_bounds__(PF_NTHR) void gemm_pf_kernel(PfP p) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t pf_smem[];
-    const int id = (int) blockIdx.x, x = id & 7, slot = id >> 3;
+    const int id = (int) blockIdx.x, x = id & 7;
+    const int ks = (id >> 3) % p.splitk, slot = (id >> 3) / p.splitk;   // (the K slices of a tile are neighbours on one XCD: the reducer reads their slabs out of its own L2)
     const int per_x = (p.nt_n + 7 - x) >> 3;
     if (slot >= per_x * p.nt_t) return;
     const int tile_n = x + 8 * (slot / p.nt_t), tile_t = slot % p.nt_t;
@@ -410,8 +463,9 @@ __global__ __launch_bounds__(PF_NTHR) void gemm_pf_kernel(PfP p) {
         n0 = (tile_n - jb.tile0) * 256;
     }
     const int t0 = tile_t * 32 * NT;
-    if (TA == TB || jb.type == TA) pf_body<TA, NT, EXP>(p, jb, n0, t0, pf_smem, role);
-    else pf_body<TB, NT, EXP>(p, jb, n0, t0, pf_smem, role);
+    const int tile_id = tile_n * p.nt_t + tile_t;
+    if (TA == TB || jb.type == TA) pf_body<TA, NT, EXP>(p, jb, n0, t0, pf_smem, role, ks, tile_id);
+    else pf_body<TB, NT, EXP>(p, jb, n0, t0, pf_smem, role, ks, tile_id);
 }
 
 template <int TA, int TB, int NT> constexpr size_t pf_lds_bytes() { return (size_t) 3 * NT * 32 * 128 + (size_t) 8 * (pf_wave_bytes<TA>() > pf_wave_bytes<TB>() ? pf_wave_bytes<TA>() : pf_wave_bytes<TB>()); }
@@ -423,6 +477,29 @@ void pf_allow_lds(const void * kern, size_t lds) {
     for (int i = 0; i < n_done && i < 64; ++i) if (done[i].k == kern && done[i].dev == dev) return;
     (void) hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (n_done < 64) { done[n_done].k = kern; done[n_done].dev = dev; ++n_done; }
+}
+
+// split-K workspace of a (device, stream): 64 KiB of tile counters (zero between launches: the reducer resets its own) + the partial-tile slabs
+struct PfWs { hipStream_t st; int dev; uint8_t * p; size_t bytes; uint64_t use; };
+PfWs g_pf_ws[16] = {};
+uint64_t g_pf_tick = 0;
+std::mutex g_pf_mu;
+uint8_t * pf_workspace(hipStream_t st, size_t need) {
+    std::lock_guard<std::mutex> lk(g_pf_mu);
+    const int dev = pm_cur_dev();
+    PfWs * e = nullptr, * lru = &g_pf_ws[0];
+    for (PfWs & c : g_pf_ws) {
+        if (c.p && c.st == st && c.dev == dev) { e = &c; break; }
+        if (!c.p) lru = &c; else if (lru->p && c.use < lru->use) lru = &c;
+    }
+    if (e && e->bytes >= need) { e->use = ++g_pf_tick; return e->p; }
+    if (!e) e = lru;
+    if (e->p) { (void) hipDeviceSynchronize(); (void) hipFree(e->p); e->p = nullptr; e->bytes = 0; }
+    need = (need + ((size_t) 32 << 20)) & ~(((size_t) 16 << 20) - 1);     // (grow in steps: a later, larger batch does not reallocate at once)
+    if (hipMalloc((void **) &e->p, need) != hipSuccess) { e->p = nullptr; return nullptr; }
+    (void) hipMemsetAsync(e->p, 0, 65536, st);
+    e->st = st; e->dev = dev; e->bytes = need; e->use = ++g_pf_tick;
+    return e->p;
 }
 
 } // namespace
@@ -469,13 +546,33 @@ int pm_launch_gemm_pf_ex(const pm_gemm_pf_job * jobs, int njobs, const void * xh
     p.njobs = njobs; p.nt_n = tiles; p.Xh = (const _Float16 *) xh; p.K = K; p.T = T;
     static const int force_nt = [] { const char * e = getenv("PM355_GEMM_PF_NT"); return e ? atoi(e) : 0; }();
     const int cus = pm_device_cus();
-    // 256-token tiles unless they leave more than half of the chip idle and 128-token tiles do better
-    const long wg8 = (long) tiles * ((T + 255) / 256), wg4 = (long) tiles * ((T + 127) / 128);
-    int nt = 8;
-    if (T <= 128 || (wg8 < cus && wg4 > wg8)) nt = 4;
+    // 256-token tiles (a dequantized operand serves 8 MFMAs; 128-token tiles only where the batch has no more tokens). Few tiles - wo / ffn_down / wq | wk | wv
+    // at the reference's default n_ubatch 512 (common/common.h:178) are 64-80 tiles for 256 CUs - are split along K: S slices per tile, the slice count that
+    // minimises  rounds of workgroups x (super-blocks per slice + ~3 for prologue, slab traffic and the reducer's pass)
+    int nt = T <= 128 ? 4 : 8;
     if (force_nt == 4 || force_nt == 8) nt = force_nt;
     p.nt_t = (T + 32 * nt - 1) / (32 * nt);
-    const int slots = ((tiles + 7) / 8) * p.nt_t;
+    const long wgs = (long) tiles * p.nt_t;
+    const int nb = K / 256;
+    static const int force_s = [] { const char * e = getenv("PM355_GEMM_PF_SPLITK"); return e ? atoi(e) : 0; }();
+    int S = 1;
+    {
+        double best = (double) ((wgs + cus - 1) / cus) * nb;
+        for (int q = 2; q <= 8; ++q) {
+            if (nb / q < 4 || wgs * q > 16384) break;
+            const double c = (double) ((wgs * q + cus - 1) / cus) * ((double) nb / q + 3.0);
+            if (c < best * 0.97) { best = c; S = q; }
+        }
+        if (force_s >= 1 && force_s <= 8 && nb / force_s >= 1) S = force_s;
+    }
+    p.splitk = S;
+    if (S > 1) {
+        const size_t slab = (size_t) 8 * nt * 4 * 64 * 16, need = 65536 + (size_t) wgs * S * slab;
+        uint8_t * w = pf_workspace(st, need);
+        if (!w) return -3;
+        p.cnt = (unsigned *) w; p.ws = (float *) (w + 65536);
+    }
+    const int slots = ((tiles + 7) / 8) * p.nt_t * S;
     auto go = [&](auto kern, size_t lds) {
         pf_allow_lds((const void *) kern, lds);
         hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(PF_NTHR), lds, st, p);
