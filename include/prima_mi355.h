@@ -226,7 +226,7 @@ PM355_API int pm355_attn_decode(const float * q, const void * k_cache, const voi
                                 float kq_scale, pm355_stream_t stream);
 /* single-token variant of pm355_attn_decode for LONG contexts: the keys are split over n_ctx/256 x n_head_kv workgroups,
  * each serving the whole group of query heads of its KV head (prima_cpp_amd/csrc/attn_split.hip; the engine uses it beyond
- * PM355_ATTN_SPLIT_MIN = 640 positions). q_rot = the token's rotated queries (pm355_rope_kv_store output), the caches
+ * PM355_ATTN_SPLIT_MIN = 320 positions). q_rot = the token's rotated queries (pm355_rope_kv_store output), the caches
  * already contain the token. scratch: pm355_attn_split_scratch_floats() floats of device memory. Position d_pos0[0] = index
  * of the token (it attends keys 0 .. d_pos0[0]). */
 PM355_API size_t pm355_attn_split_scratch_floats(int n_head, int head_dim, int n_ctx);

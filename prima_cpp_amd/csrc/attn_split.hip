@@ -11,7 +11,7 @@
 //   3. combine: out[h][e] = sum over chunks of the partial O, fixed order (deterministic)
 // RoPE and the KV store of the new token are done by the scores kernel (every workgroup rotates its group's queries; the one
 // whose chunk holds the token's position also rotates k, uses it from LDS and writes the K row / V column). 3 launches
-// instead of 1, so the engine switches to this path only beyond PM355_ATTN_SPLIT_MIN positions (default 640 = the measured
+// instead of 1, so the engine switches to this path only beyond PM355_ATTN_SPLIT_MIN positions (default 320 since round 5, engine.hip; 640 was the measured
 // crossover: the 3 launches cost ~25 us per layer whatever the context, the fused kernel 7 us + 27 ns per position; the host
 // mirrors the device position counters to pick the captured graph). Llama-3-70B decode at 3.8k context: 57.6 -> 92 tok/s. Rounding points as in the fused kernel: q and p -> F16, F16 K / V, f32 accumulation; differences to it are
 // summation order only (the sum of exponentials is assembled from per-chunk sums).

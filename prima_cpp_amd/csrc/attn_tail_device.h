@@ -1,7 +1,9 @@
 // attn_tail_device.h — single-token attention over cached cells for callers INSIDE a launch that also produced q and this token's cell
 // (the QKV launch's tail: mmvq.hip; the persistent engine's attention phase: decode_engine.hip). The arithmetic, its order and its rounding points are
 // attn_cached.hip's (ggml.c:12445-12473 K.q rows, :13783-13879 soft_max, F16-rounded probabilities against the F16 V rows: the reference's
-// ggml_compute_forward_mul_mat with an F16 src1 conversion) - the outputs are the same bits; what differs is how memory is read: q and the newest
+// ggml_compute_forward_mul_mat with an F16 src1 conversion) - the outputs are the same bits as attn_cached.hip's OF THE SAME ROUND (for 65-256 cells both take the
+// keys-in-the-lanes form of round 5, whose fmaf chains over 4-wave partial sums differ in the low-order bits from the per-head body the round-4 path ran there);
+// what differs is how memory is read: q and the newest
 // cell were written by OTHER compute units in this launch, so every load of q / K / V bypasses this XCD's caches (sc0 sc1).
 #pragma once
 #include "pm355_device.h"

@@ -863,7 +863,10 @@ const struct ggml_backend_reg_i reg_iface = { reg_name, reg_dev_count, reg_dev_g
 extern "C" {
 
 int ggml_backend_mi355_get_device_count(void) {
-    if (plan_only()) return 1;
+    if (plan_only()) {                                          // (GGML_MI355_PLAN_DEVICES=<n>: several pretend devices - libllama then builds its pipeline-parallel scheduler)
+        static const int n = [] { const char * e = getenv("GGML_MI355_PLAN_DEVICES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > GGML_MI355_MAX_DEVICES ? GGML_MI355_MAX_DEVICES : v; }();
+        return n;
+    }
     int n = pm355_device_count(); return n > GGML_MI355_MAX_DEVICES ? GGML_MI355_MAX_DEVICES : n;
 }
 

@@ -255,9 +255,11 @@ def test_peaked_fixture_at_depth(gpu, tmp_path):
     profiles/r05_parity_8d.txt): the peaked fixture at the Llama-3-70B shape with that many layers (every layer its own N(0, 1/K) weights through the
     reference's quantizer, Q4_K_M mixture), 16-token prompt + 32 greedy tokens: the reference CPU (its fastest ISA build, -ngl 0) against the plug-in
     through the reference's llama_decode and against the resident engine - the same 32 tokens, logits at the reference-against-itself tier."""
-    depth = int(os.environ.get("PM355_8D_DEPTH", "0") or 0)
+    # Round 6: 16 layers run by DEFAULT under `pytest -m gpu` (8.5 GB GGUF, about a minute), so the driver's GPU tier carries depth beyond the 8-layer fixture;
+    # PM355_8D_DEPTH=80 is the full model (profiles/r05_parity_8d.txt), PM355_8D_DEPTH=0 skips.
+    depth = int(os.environ.get("PM355_8D_DEPTH", "16") or 0)
     if depth <= 0:
-        pytest.skip("opt-in: PM355_8D_DEPTH=<layers>")
+        pytest.skip("PM355_8D_DEPTH=0")
     shape = dict(SHAPES["70b8"], n_layer=depth)
     n_gen = 32
     V = shape["n_vocab"]
@@ -293,6 +295,10 @@ def test_peaked_fixture_at_depth(gpu, tmp_path):
             # (the 16-token prompt runs the MFMA prefill path - F16 activations x dequantized F16 weights - and its cells stay in the cache of every
             #  decoded token: north_star's 1e-3 tier for fp16 accumulation, at any depth)
             assert _nmse(l_, lr) < 1e-3, _nmse(l_, lr)
+            # the DISCRIMINATING quantity (token equality on the peaked fixture is weak by construction: the margin is ~50 x the observed error): the logits
+            # may sit no further from the reference than 1.5 x the distance of the reference's own AVX2 build from its AVX512 build on this file
+            if nm_ref is not None:
+                assert _nmse(l_, lr) <= 1.5 * max(nm_ref, 2e-5), (mode, _nmse(l_, lr), nm_ref)
         if st.get("decode_tok_s"):
             print(f"[8d 70b x {depth}] plug-in decode {st['decode_tok_s']:.1f} tok/s")
     finally:

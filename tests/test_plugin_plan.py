@@ -52,7 +52,7 @@ def test_decode_graph_lowers_to_five_launches_per_layer(name, nodes, tmp_path):
 def test_rms_norm_sum_of_squares_is_wired_from_the_producing_launch(name, tmp_path):
     """Round 5: wo / ffn_down (+ residual) leave per-workgroup partials of the next rms_norm's sum of squares; the planner wires every fused
     norm + mat-vec whose input row is the output of the launch right before it (ffn_gate | ffn_up after wo in every layer; wq | wk | wv after
-    the previous layer's ffn_down). GGML_MI355_SS=0 turns the wiring off."""
+    the previous layer's ffn_down). Opt-in: GGML_MI355_SS=1 switches the wiring on (measured -1.0 %: the default is off, every rms_norm prologue reduces its own row)."""
     z = np.load(os.path.join(HERE, "golden", f"tiny_{name}_decode.npz"))
     path = write_gguf_from_arrays(str(tmp_path / f"tiny_{name}.gguf"), z)
     n_layer = int(z["hp_n_layer"])
@@ -282,3 +282,26 @@ def test_mha_models_keep_the_round2_long_context_kernel(tmp_path):
         for g in segs:
             assert f"Hkv={n_head_kv} dh=64 n_ctx=128 {want} " in g, (n_head_kv, g[-1500:])
             assert ("matvec + rope + KV store" in g) == (want == "cached-split"), g[-1500:]
+
+
+def test_graph_reuse_patch_with_two_devices_never_reuses_under_a_pipeline_parallel_scheduler(tmp_path):
+    """with more than one device libllama MAY build its scheduler with n_copies > 1 (src/llama.cpp:21328-21355) - split_graph then binds the
+    graph inputs to copy `cur_copy`, which advances after every compute, so a KEPT graph would read the copy its inputs were not uploaded into. The
+    patch's guard asks `ggml_backend_sched_get_n_copies == 1` of every scheduler. Two pretend devices (GGML_MI355_PLAN_DEVICES=2), LLAMA_MI355_GRAPH_REUSE=1:
+    whenever the run reports pipeline parallelism, no single-token decode may have reused a graph. (prima.cpp's loader clamps n_gpu_layers to its layer
+    window, :21330 `n_gpu_layers > n_layer` - on this reference the second device stays idle and the scheduler single-copy; the guard is what keeps the patch
+    safe on an upstream libllama.) With one copy the reuse must still work with both devices registered."""
+    z = np.load(os.path.join(HERE, "golden", "tiny_llama_decode.npz"))
+    path = write_gguf_from_arrays(str(tmp_path / "tiny_llama.gguf"), z)
+    pat = re.compile(r"graph-reuse patch\): (\d+) of (\d+) single-token decodes reused")
+    for ndev in (1, 2):
+        _, _, st = run_llama_driver(path, z["prompt"][:3], 6, ngl=99, n_ctx=64, threads=1, flavour="avx2", timeout=120, extra_args=["--keep-out-in-cuda"],
+                                    env={"GGML_MI355_PLAN_ONLY": "1", "GGML_MI355_PLAN_DEVICES": str(ndev), "LLAMA_MI355_GRAPH_REUSE": "1"})
+        m = pat.search(st["stderr"])
+        reused = int(m.group(1)) if m else 0
+        if ndev == 2:
+            assert "MI355X1" in st["stderr"], st["stderr"][-1500:]
+        if "pipeline parallelism enabled" in st["stderr"]:
+            assert reused == 0, st["stderr"][-800:]
+        else:
+            assert m and reused >= 3, st["stderr"][-800:]
