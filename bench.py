@@ -783,7 +783,11 @@ def main():
         win = E.Window(hp, lo=lo, hi=hi, flags=flags, n_ctx=a.n_ctx)
         win.fill_synthetic(mixture, seed=1234)
         RING_UBATCH = 512                                  # tokens per hop of the pipelined prompt pass (the reference's n_ubatch)
-        win.finalize(max_tokens=RING_UBATCH if world > 1 else 1, n_seq=world)
+        # sequences in flight: 2 per rank (round 6: the two-deep schedule of pm355_ring_decode_staggered - every hop travels under the other round's compute);
+        # PM355_RING_DEPTH=1 is the lock-step schedule of rounds 4-5 (one sequence per rank, every hop exposed)
+        ring_depth = 2 if (world > 1 and os.environ.get("PM355_RING_DEPTH", "2") != "1") else 1
+        n_seq = ring_depth * world
+        win.finalize(max_tokens=RING_UBATCH if world > 1 else 1, n_seq=n_seq)
         use_graph = not a.no_graph
         # N > 1 over RCCL: the transport is the C one (pm355_ring_*: ncclSend / ncclRecv on the library's communication stream, event
         # hand-off, no host wait per micro-step); PM355_RING_TRANSPORT=torch keeps torch.distributed's batch_isend_irecv instead
@@ -800,9 +804,13 @@ def main():
                 try:
                     c_ring = CRing(rank, world, transport="rccl")
                 except Exception as e:                       # every rank must take the same path: agree on it below
+                    if os.environ.get("PM355_REQUIRE_RCCL") == "1":     # the first run on real multi-GPU hardware: fail loudly, never measure a fall-back by accident
+                        raise RuntimeError(f"[rank {rank}] PM355_REQUIRE_RCCL=1 and the RCCL ring transport could not be created: {e}")
                     print(f"[rank {rank}] RCCL transport unavailable ({e}); falling back to torch.distributed", file=sys.stderr, flush=True)
                     ok.zero_()
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if ok.item() < 1 and os.environ.get("PM355_REQUIRE_RCCL") == "1":
+                    raise RuntimeError(f"[rank {rank}] PM355_REQUIRE_RCCL=1: another rank could not create the RCCL ring transport")
                 if ok.item() < 1:
                     if c_ring is not None:
                         c_ring.close()
@@ -814,7 +822,7 @@ def main():
             from prima_cpp_amd.ring import CRing
             c_ring = CRing(0, 1, transport="local")          # one window: the same C loop, no communicator
         rng = np.random.default_rng(1234)
-        prompt = rng.integers(0, hp["n_vocab"], size=(world, a.prompt))
+        prompt = rng.integers(0, hp["n_vocab"], size=(n_seq, a.prompt))
         prompt[:, 0] = 128000 % hp["n_vocab"]            # BOS first, like llama-bench
 
         # The decode loop is C (pm355_ring_decode_staggered): `world` sequences in flight one rank apart, a step = every sequence advances one
@@ -829,24 +837,26 @@ def main():
         # [n_tokens][n_embd] hand-offs, pipelined (pm355_ring_prefill), the last rank returns each prompt's last row to rank 0 for the head
         n_pre = a.prompt + a.warmup
         assert n_pre + 2 * a.steps + 2 <= a.n_ctx, "n_ctx too small for prompt+warmup+steps"
+        # a STEP = `world` micro-steps on every rank = `world` tokens leaving rank 0's head (with two sequences per rank in flight every sequence advances one
+        # token per two steps; the work per step and GPU is the same as with one)
         ring_prompt = None
         if world > 1:
             toks_d = torch.from_numpy(prompt.astype(np.int32)).cuda() if rank == 0 else None
-            rows = torch.zeros((world, hp["n_embd"]), dtype=torch.float32, device="cuda") if rank == 0 else None
+            rows = torch.zeros((n_seq, hp["n_embd"]), dtype=torch.float32, device="cuda") if rank == 0 else None
             sync()
             tp0 = time.perf_counter()
-            c_ring.prefill(win, toks_d, world, a.prompt, min(RING_UBATCH, a.prompt), rows)
+            c_ring.prefill(win, toks_d, n_seq, a.prompt, min(RING_UBATCH, a.prompt), rows)
             sync()
             ring_prompt = time.perf_counter() - tp0
-            first_tok = [None] * world                     # the token each sequence starts its decode with (after the prompt pass)
+            first_tok = [None] * n_seq                     # the token each sequence starts its decode with (after the prompt pass)
             if rank == 0:
                 am = torch.empty(1, dtype=torch.int32, device="cuda")
-                for q in range(world):
+                for q in range(n_seq):
                     win.head(rows[q], argmax=am)
                     first_tok[q] = int(am.item())
             win.set_seq(0)                                  # the staggered decode meets the sequences in the order 0, 1, ...
-            n_w = max(a.warmup, 1) * world
-            c_ring.decode_staggered(win, n_w, forced=(first_tok + [None] * (n_w - world)) if rank == 0 else None, reset=True, use_graph=use_graph)
+            n_w = max(a.warmup, ring_depth) * world          # (at least one micro-step per sequence in flight: their first tokens are forced)
+            c_ring.decode_staggered(win, n_w, forced=(first_tok + [None] * (n_w - n_seq)) if rank == 0 else None, reset=True, use_graph=use_graph)
         else:
             c_ring.decode_staggered(win, n_pre, forced=[int(prompt[0, s_]) if s_ < a.prompt else None for s_ in range(n_pre)], reset=True, use_graph=use_graph)
         sync()
@@ -912,9 +922,12 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8xint4->int32, f32 accumulate",
                 "data": "synthetic",
                 "config": {"workload": f"{model_name} batch-1 greedy decode, {a.prompt}-token synthetic prompt, "
-                                       f"{world} sequence(s) in flight, n_ctx {a.n_ctx}, F16 KV cache",
+                                       f"{n_seq} sequence(s) in flight, n_ctx {a.n_ctx}, F16 KV cache",
                            "parallelism": "single GPU" if world == 1 else f"piped-ring layer split pp{world} "
-                                          f"(windows {wins}), ring in C (pm355_ring_*), transport {'RCCL send/recv: comm stream + events, no host wait' if ring_transport == 'rccl' else 'torch.distributed ' + dist.get_backend() + ' through the transport callbacks'}",
+                                          f"(windows {wins}; window bytes per token and rank {[int(sum(lb[lo_:hi_]) + (head_b if i_ == 0 else 0)) for i_, (lo_, hi_) in enumerate(wins)]}; "
+                                          f"hop = {hp['n_embd'] * 4} bytes per micro-step and link), {n_seq} sequences in flight ({ring_depth} per rank: "
+                                          f"{'a hop is consumed two micro-steps after it was sent' if ring_depth == 2 else 'lock-step, every hop exposed'}), ring in C (pm355_ring_*), "
+                                          f"transport agreed on by all ranks: {'RCCL send/recv: comm stream + events, no host wait' if ring_transport == 'rccl' else 'torch.distributed ' + dist.get_backend() + ' through the transport callbacks'}",
                            "weights_bytes_per_token": total_w, "kv_bytes_per_token_mid_run": kv_b,
                            "hip_graph": use_graph, "activations_finite": finite},
                 "hbm_roofline_tokens_per_s": round(HBM_PEAK_GBS * 1e9 / total_w * world, 2),

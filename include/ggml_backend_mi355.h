@@ -49,6 +49,10 @@ __attribute__((visibility("default"))) ggml_backend_buffer_type_t ggml_backend_m
 __attribute__((visibility("default"))) ggml_backend_buffer_type_t ggml_backend_mi355_host_buffer_type(void);
 __attribute__((visibility("default"))) int                        ggml_backend_mi355_get_device_count(void);
 __attribute__((visibility("default"))) void                       ggml_backend_mi355_get_device_memory(int device, size_t * free, size_t * total);
+/* Optional hint, also reachable as ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355_set_graph_reused") (the CUDA plug-in keeps its graph on its own
+ * side of the boundary, ggml-cuda.cu:2513-2780; here a host that keeps its ggml_cgraph objects between tokens - oracle/ref_patches/graph_reuse.patch - says so
+ * and the plug-in skips the per-token fingerprint walk over the nodes). reused == 0 restores the default. */
+__attribute__((visibility("default"))) void                       ggml_backend_mi355_set_graph_reused(ggml_backend_t backend, int reused);
 
 #ifdef __cplusplus
 }

@@ -453,6 +453,7 @@ PM355_API int pm355_model_decode(pm355_model * m, const int32_t * d_tokens, cons
 PM355_API int pm355_model_decode_seq(pm355_model * m, int seq, const int32_t * d_tokens, const float * d_x_in, int n_tokens, int pos0,
                                      float * d_x_out, float * d_logits, int32_t * d_argmax, pm355_stream_t stream);
 PM355_API int pm355_model_n_embd(const pm355_model * m);
+PM355_API int pm355_model_n_seq(const pm355_model * m);          /* KV slabs the window was finalized for (pm355_model_finalize_seqs) */
 /* Device-resident greedy loop (needs HAS_EMBD|HAS_HEAD and the whole model in one window): starting from the token
  * in d_tokens_io[0] at position pos0, generate n_steps tokens; step i reads d_tokens_io[i], writes d_tokens_io[i+1].
  * One captured hipGraph per step, replayed; no host synchronisation inside. */
@@ -538,7 +539,11 @@ PM355_API int pm355_ring_single_token(pm355_ring * r, pm355_model * m, int seq, 
  * argmax, < 0 = none; required for the first `world` micro-steps after a reset), else NULL. d_tokens_out: device int32 [n_micro] on rank 0
  * (token fed at each micro-step), or NULL. reset != 0 restarts the schedule at micro-step 0 AND sets the model's sequence counter back to sequence 0
  * (pm355_model_set_seq(m, 0): the micro-step index selects the KV slab on every rank); positions are the caller's (pm355_model_set_seq_pos). Finish with
- * pm355_ring_wait. */
+ * pm355_ring_wait.
+ * Round 6 - two sequences per rank: a window finalized with n_seq == 2 * world runs the two-deep schedule: rank r works on sequence (m - 2 r) mod (2 world)
+ * at micro-step m, the row it sends after step m is consumed by its successor at step m + 2, so every hop travels under the other round's compute instead
+ * of in front of it (the exchange of step m signals its own event, the window of step m + 2 waits for that one only); the first 2 * world micro-steps of
+ * rank 0 need forced tokens. */
 PM355_API int pm355_ring_decode_staggered(pm355_ring * ring, pm355_model * m, int n_micro, const int32_t * forced, int32_t * d_tokens_out, int reset,
                                           int use_graph, pm355_stream_t compute_stream);
 PM355_API const float * pm355_ring_decode_last_output(const pm355_ring * ring);

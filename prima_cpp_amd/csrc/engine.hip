@@ -929,6 +929,11 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
     m->n_seq = n_seq;
     (void) pm355_uploader_sync(m->up);
     (void) hipDeviceSynchronize();
+    // (a re-finalize re-allocates the KV caches, the rope table and the split scratch that the kept engine plans and captured graphs have baked in)
+    for (auto & e : m->eng_plans) { pm_eng_plan_free(e.plan); if (e.act) (void) hipFree(e.act); }
+    m->eng_plans.clear(); m->eng_refused = false;
+    for (auto & g : m->graphs) (void) hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
     const pm355_hparams & hp = m->hp;
     const size_t E = hp.n_embd, Eq = (size_t) hp.head_dim * hp.n_head, Ekv = (size_t) hp.head_dim * hp.n_head_kv, F = hp.n_ff;
     const size_t T = max_tokens < 1 ? 1 : max_tokens;
@@ -1063,6 +1068,7 @@ int pm355_model_decode_seq(pm355_model * m, int seq, const int32_t * d_tokens, c
     return run_window(m, d_tokens, d_x_in, T, d_x_out, d_logits, d_argmax, (hipStream_t) st);
 }
 int pm355_model_n_embd(const pm355_model * m) { return m ? m->hp.n_embd : 0; }
+int pm355_model_n_seq(const pm355_model * m) { return m ? m->n_seq : 0; }
 
 // head_first != 0 (ring rank 0): d_x_in is the LAST rank's activation; apply the head to it (-> d_argmax / d_logits),
 // then embed the token found at d_token (which may be d_argmax itself) and run the window -> d_x_out.

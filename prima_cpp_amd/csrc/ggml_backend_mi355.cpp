@@ -132,6 +132,12 @@ struct backend_ctx {
     float * qkv = nullptr; size_t qkv_floats = 0;    // raw q / k / v projections of one token
     float * split = nullptr; size_t split_floats = 0;
     std::vector<graph_entry *> graphs;
+    // the host told us (ggml_backend_mi355_set_graph_reused, reached through get_proc_address by the graph-reuse patch) that the ggml_cgraph objects it hands to
+    // graph_compute are the SAME, un-rebuilt objects as last time: entries are then found by graph pointer + node count, no walk over the nodes
+    bool host_reuses = false;
+    struct by_ptr_t { const struct ggml_cgraph * g; int n_nodes; graph_entry * e; };
+    std::vector<by_ptr_t> by_ptr;
+    uint64_t n_ptr_hit = 0;
     mi355::graph_fp fp_tmp;
     uint64_t tick = 0;
     bool fuse = true, use_graphs = true, debug_plan = false;
@@ -326,8 +332,8 @@ void backend_free(ggml_backend_t b) {
     dsetdev(c->device);
     dsync(c->stream);
     if (env_on("GGML_MI355_STATS"))
-        fprintf(stderr, "ggml-mi355 stats: graph_compute %llu, fingerprint hits %llu, plans built %llu, hipGraph replays %llu, captures %llu, eager runs %llu\n",
-                (unsigned long long) c->n_compute, (unsigned long long) c->n_fp_hit, (unsigned long long) c->n_plan, (unsigned long long) c->n_replay,
+        fprintf(stderr, "ggml-mi355 stats: graph_compute %llu, fingerprint hits %llu, graph-pointer hits %llu, plans built %llu, hipGraph replays %llu, captures %llu, eager runs %llu\n",
+                (unsigned long long) c->n_compute, (unsigned long long) c->n_fp_hit, (unsigned long long) c->n_ptr_hit, (unsigned long long) c->n_plan, (unsigned long long) c->n_replay,
                 (unsigned long long) c->n_capture, (unsigned long long) c->n_eager);
     if (env_on("GGML_MI355_STATS"))
         fprintf(stderr, "ggml-mi355 host time: graph_compute %.3f ms total (%.1f us per call), set_tensor %.3f ms in %llu calls, get_tensor %.3f ms in %llu calls, "
@@ -705,10 +711,12 @@ enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g)
     if (!c->rope_tab && c->qkv_epi) { c->rope_tab = (float *) dmalloc(1024 + 64); GGML_ASSERT(c->rope_tab); }
     if (!c->ss_buf && c->use_ss) { c->ss_buf = (double *) dmalloc(2 * 256 * sizeof(double)); GGML_ASSERT(c->ss_buf); }
 
-    { scoped_ns t1(g_ht.ns_fp); mi355::graph_fingerprint(g, c->fp_tmp); }
     graph_entry * e = nullptr;
+    if (c->host_reuses) for (const auto & q : c->by_ptr) if (q.g == g && q.n_nodes == n_nodes && q.e->plan.fast_ok) { e = q.e; ++c->n_ptr_hit; break; }
+    if (!e) { scoped_ns t1(g_ht.ns_fp); mi355::graph_fingerprint(g, c->fp_tmp); }
     const auto t_plan0 = std::chrono::steady_clock::now();
-    for (graph_entry * x : c->graphs) if (x->plan.fast_ok && mi355::fingerprint_equal(x->fp, c->fp_tmp)) { e = x; ++c->n_fp_hit; break; }
+    const bool by_pointer = e != nullptr;
+    if (!e) for (graph_entry * x : c->graphs) if (x->plan.fast_ok && mi355::fingerprint_equal(x->fp, c->fp_tmp)) { e = x; ++c->n_fp_hit; break; }
     if (!e) {
         mi355::plan_ctx pc = { c, plan_qkv_scratch, plan_split_scratch, c->d_dyn, c->split_min, c->attn_mfma, c->fuse, c->qkv_epi ? c->rope_tab : nullptr, plan_same_bytes, c->use_ss ? c->ss_buf : nullptr };
         mi355::plan p;
@@ -722,6 +730,7 @@ enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g)
                 for (size_t i = 1; i < c->graphs.size(); ++i) if (c->graphs[i]->last_use < c->graphs[lru]->last_use) lru = i;
                 dsync(c->stream);                                // its hipGraph may still be in flight
                 if (c->graphs[lru]->exec) pm355_graph_free(c->graphs[lru]->exec);
+                for (size_t q = c->by_ptr.size(); q-- > 0;) if (c->by_ptr[q].e == c->graphs[lru]) c->by_ptr.erase(c->by_ptr.begin() + q);
                 delete c->graphs[lru];
                 c->graphs.erase(c->graphs.begin() + lru);
             }
@@ -731,6 +740,11 @@ enum ggml_status backend_graph_compute(ggml_backend_t b, struct ggml_cgraph * g)
         }
     }
     e->last_use = c->tick;
+    if (!by_pointer) {                                   // remember which entry this graph object lowered to (used only while the host vouches for its objects)
+        bool seen = false;
+        for (auto & q : c->by_ptr) if (q.g == g) { q.n_nodes = n_nodes; q.e = e; seen = true; break; }
+        if (!seen) { if (c->by_ptr.size() >= 32) c->by_ptr.erase(c->by_ptr.begin()); c->by_ptr.push_back({g, n_nodes, e}); }
+    }
     const auto t_dyn0 = std::chrono::steady_clock::now();
     g_ht.ns_plan += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(t_dyn0 - t_plan0).count();
     const mi355::plan & p = e->plan;
@@ -855,12 +869,25 @@ struct reg_ctx { std::vector<ggml_backend_dev_t> devices; };
 const char * reg_name(ggml_backend_reg_t) { return GGML_MI355_NAME; }
 size_t reg_dev_count(ggml_backend_reg_t r) { return ((reg_ctx *) r->context)->devices.size(); }
 ggml_backend_dev_t reg_dev_get(ggml_backend_reg_t r, size_t i) { reg_ctx * c = (reg_ctx *) r->context; GGML_ASSERT(i < c->devices.size()); return c->devices[i]; }
-void * reg_proc(ggml_backend_reg_t, const char *) { return nullptr; }    // no split buffers, no n_threads (llama.cpp:3772, :21261)
+extern "C" void ggml_backend_mi355_set_graph_reused(ggml_backend_t b, int reused);
+// no split buffers, no n_threads (llama.cpp:3772, :21261); the one name served is the graph-reuse patch's hint
+void * reg_proc(ggml_backend_reg_t, const char * name) {
+    if (name && strcmp(name, "ggml_backend_mi355_set_graph_reused") == 0) return (void *) ggml_backend_mi355_set_graph_reused;
+    return nullptr;
+}
 const struct ggml_backend_reg_i reg_iface = { reg_name, reg_dev_count, reg_dev_get, reg_proc };
 
 } // namespace
 
 extern "C" {
+
+// Hint of a host that keeps its graphs between tokens (the graph-reuse patch of INTEGRATION.md section 2b calls it before every compute): reused != 0 - the ggml_cgraph
+// objects passed to graph_compute until the next call are the un-rebuilt objects of the previous token (only the KV-store views moved), so the plug-in may
+// look its plan up by graph pointer instead of fingerprinting every node. reused == 0 (or never called): every graph is fingerprinted.
+void ggml_backend_mi355_set_graph_reused(ggml_backend_t b, int reused) {
+    if (!b || !ggml_backend_is_mi355(b)) return;
+    ((backend_ctx *) b->context)->host_reuses = reused != 0;
+}
 
 int ggml_backend_mi355_get_device_count(void) {
     if (plan_only()) {                                          // (GGML_MI355_PLAN_DEVICES=<n>: several pretend devices - libllama then builds its pipeline-parallel scheduler)

@@ -678,6 +678,7 @@ int pm_launch_gemm_q_multi(const pm_gemm_pf_job * jobs, int njobs, const float *
         if (!seen) ty[nty++] = jobs[j].type;
     }
     all_pf = all_pf && nty <= 2;
+    if (nty == 2 && (ty[0] == PM_Q8_0 || ty[1] == PM_Q8_0)) all_pf = false;      // (Q8_0 goes as a launch of its own)
     int rc = 0;
     for (int j = 0; j < njobs; ++j) {
         if (all_pf && j > 0) break;

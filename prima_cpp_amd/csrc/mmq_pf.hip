@@ -69,6 +69,8 @@ template <int TYPE> struct PfT;
 template <> struct PfT<PM_Q4_K> { static constexpr int NSTREAM = 2, EXTRA = 0; };
 template <> struct PfT<PM_Q5_K> { static constexpr int NSTREAM = 2, EXTRA = 2048; };
 template <> struct PfT<PM_Q6_K> { static constexpr int NSTREAM = 3, EXTRA = 512; };
+// Q8_0 (row-SoA qa[K/32][16] | qb[K/32][16] | half d[K/32]): slots of 64 k = one k-step (two blocks: 1 KiB of qa, 1 KiB of qb per wave), requested two steps ahead
+template <> struct PfT<PM_Q8_0> { static constexpr int NSTREAM = 2, EXTRA = 0; };
 template <int TYPE> constexpr int pf_wave_bytes() { return 2 * PfT<TYPE>::NSTREAM * 1024 + 1024 + PfT<TYPE>::EXTRA; }
 
 // the k loop + epilogue of one workgroup tile: rows [n0, n0 + 256) of job jb, tokens [t0, t0 + 32 NT)
@@ -78,12 +80,15 @@ template <int TYPE, int NT, int EXP>
 __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const int n0, const int t0, uint8_t * smem, const int role, const int ks, const int tile_id) {
     constexpr int BBUF = NT * 32 * 128;                       // one activation buffer: 32 NT tokens x 64 halfs
     constexpr int NSTREAM = PfT<TYPE>::NSTREAM, SLOT = NSTREAM * 1024, AW = pf_wave_bytes<TYPE>();   // per wave: two 128-k slots + two 512-byte header slots + EXTRA
-    constexpr bool K45 = TYPE == PM_Q4_K || TYPE == PM_Q5_K;
+    constexpr bool K45 = TYPE == PM_Q4_K || TYPE == PM_Q5_K, Q8 = TYPE == PM_Q8_0;
     constexpr int NQ = NT / 2;                                // activation DMA instructions per wave and k-step
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int K = p.K, nst = K / 64, nb = K / 256;
+    // nb = super-blocks of 256 k the loop walks; Q8_0 rows may end on half of one (K % 256 == 128: Qwen2.5-72B's ffn_down, K = 29568) - the weight operand of
+    // the missing half is zeroed, its look-ahead requests are clamped to the last real k-step
+    const int K = p.K, nst = K / 64, nb = (K + 255) / 256;
+    const bool half_tail = Q8 && (K & 255) != 0;
     constexpr int exp = EXP;
     uint8_t * const aw = smem + 3 * BBUF + wave * AW;
     const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) smem;     // LDS byte address of the tile memory
@@ -115,6 +120,11 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
     };
     auto issue_A = [&](int m, int slot, int st) __attribute__((always_inline)) {    // 128-k piece m of the rows -> slot
         if (exp & 2) return;
+        if (Q8) {                 // m = k-step: blocks 2 m + h of stream st (0 qa, 1 qb)
+            const uint32_t sc = (uint32_t) min(m, nst - 1);
+            dma16(Wg, wrow + (st ? (uint32_t) K / 2u : 0u) + (2u * sc + (uint32_t) h) * 16u, aw_l + slot * SLOT + st * 1024);
+            return;
+        }
         const uint32_t mc = (uint32_t) min(m, 2 * nb - 1);
         if (TYPE == PM_Q5_K)      // native 176-byte blocks: qs at + 48; lane (r, h) = bytes [16 st, + 16) of unit 2 (m % 2) + h
             dma16(Wg, wrow + (mc >> 1) * 176u + 48u + (mc & 1u) * 64u + 32u * (uint32_t) h + 16u * (uint32_t) st, aw_l + slot * SLOT + st * 1024);
@@ -124,7 +134,7 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
     auto issue_H = [&](int b) __attribute__((always_inline)) {                       // header (Q4_K) / int8 scales (Q6_K) of super-block b
         if (exp & 2) return;
         const uint32_t bc = (uint32_t) min(b, nb - 1);
-        const uint32_t off = TYPE == PM_Q4_K ? (uint32_t) nb * 128u + bc * 16u : TYPE == PM_Q5_K ? bc * 176u : pm_q6k_sc_off((uint32_t) nb, bc);
+        const uint32_t off = TYPE == PM_Q4_K ? (uint32_t) nb * 128u + bc * 16u : TYPE == PM_Q5_K ? bc * 176u : Q8 ? (uint32_t) K + bc * 16u /* 8 blocks' d */ : pm_q6k_sc_off((uint32_t) nb, bc);
         if (h == 0) dma16(Wg, wrow + off, aw_l + 2 * SLOT + (b & 1) * 512);
     };
     auto issue_QH = [&](int b) __attribute__((always_inline)) {                      // Q5_K: the 32 qh bytes of super-block b, lane (r, h) = bytes [16 h, + 16)
@@ -142,7 +152,11 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
     auto read_raw = [&](int i, int b) __attribute__((always_inline)) {                // slice i of super-block b
         const int mm = (i >> 3) & 1, ks = (i >> 2) & 1, j = i & 3;
         Raw w;
-        if (K45) {
+        if (Q8) {
+            // block j / 2 of the k-step (slot = the step's parity), its first (qa) or second (qb) sixteen values, bytes [8 h, + 8)
+            w.ql = *(const u32x2 *) (aw + ((i >> 2) & 1) * SLOT + (j & 1) * 1024 + (j >> 1) * 512 + aoff);
+            w.qh = u32x2{0, 0};
+        } else if (K45) {
             // unit ks of the slot: qa = qs[0, 16) / qb = qs[16, 32) of its 64 weights; slices 0, 2 read qa, slices 1, 3 qb
             w.ql = *(const u32x2 *) (aw + mm * SLOT + (j & 1) * 1024 + ks * 512 + aoff);
             w.qh = u32x2{0, 0};
@@ -163,7 +177,11 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
     };
     half2v mul = {0, 0}, add = {0, 0}, muln = {0, 0}, addn = {0, 0};
     auto scales = [&](int i, half2v & mul, half2v & add) __attribute__((always_inline)) {   // multiplier / addend of slice i (constant per sub-block / 16-group)
-        if (K45) {
+        if (Q8) {
+            const int q = i >> 1;                              // block of the super-block: its d is already an F16 number
+            const _Float16 dd = __builtin_bit_cast(_Float16, (uint16_t) (hd[q >> 1] >> (16 * (q & 1))));
+            mul = half2v{dd, dd};
+        } else if (K45) {
             const int s = i >> 1;                              // 32-weight sub-block of the super-block
             int sc, mn;
             k4_scale_min(hd[1], hd[2], hd[3], s, sc, mn);
@@ -182,7 +200,18 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
         const int ks = (i >> 2) & 1, j = i & 3;
         uint32_t v[2];
         half2v t[4];
-        if (K45) {
+        if (Q8) {
+            // int8 x -> byte x ^ 0x80 = x + 128 -> F16 1024 + 128 + x (exact) -> - 1152 -> * d: one rounding, dequantize_row_q8_0's d * x (ggml-quants.c:1616)
+            const half2v bias = half2v{(_Float16) -1152.0f, (_Float16) -1152.0f};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) v[c] = w.ql[c] ^ 0x80808080u;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { t[2 * c] = h2(__builtin_amdgcn_perm(0x64646464u, v[c], 0x05010400u)); t[2 * c + 1] = h2(__builtin_amdgcn_perm(0x64646464u, v[c], 0x07030602u)); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t[c] = t[c] + bias;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t[c] = t[c] * mul;
+        } else if (K45) {
             const bool hi = j >> 1;                            // slices 2, 3: the unit's second sub-block = high nibbles
             const half2v bias = hi ? half2v{(_Float16) -64.0f, (_Float16) -64.0f} : half2v{(_Float16) -1024.0f, (_Float16) -1024.0f};
             uint32_t ex[2] = {hi ? 0x54545454u : 0x64646464u, hi ? 0x54545454u : 0x64646464u};   // F16 exponent byte: 64 + m / 16 (m = nibble << 4) / 1024 + m
@@ -241,7 +270,7 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
     const int S = p.splitk, b0 = (int) ((long) ks * nb / S), b1 = (int) ((long) (ks + 1) * nb / S);
     issue_H(b0); if (TYPE == PM_Q6_K) issue_D(b0 >> 3); if (TYPE == PM_Q5_K) issue_QH(b0);
 #pragma unroll
-    for (int st = 0; st < NSTREAM; ++st) issue_A(2 * b0, 0, st);
+    for (int st = 0; st < NSTREAM; ++st) { if (Q8) { issue_A(4 * b0, 0, st); issue_A(4 * b0 + 1, 1, st); } else issue_A(2 * b0, 0, st); }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { issue_B(4 * b0, rd, q); issue_B(4 * b0 + 1, nx, q); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -276,14 +305,16 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
             // slice 2 begins: `vmcnt(N)` there, N = what slices 0 and 1 of step s + 1 issued. For the activations a barrier follows before their first
             // reader (slice 3 of step s + 1 reads the fragments of step s + 2's first slice); the weights are the wave's own.
             if (j == 2 && !(exp & 3)) {
-                constexpr int N8[4] = {3, 3, 3, 2}, N4[4] = {2, 2, 2, 1};
-                const int n = NT == 8 ? N8[sq] : N4[sq];
+                constexpr int N8[4] = {3, 3, 3, 2}, N4[4] = {2, 2, 2, 1}, Q8N8[4] = {2, 3, 2, 2}, Q8N4[4] = {1, 2, 1, 1};
+                const int n = Q8 ? (NT == 8 ? Q8N8[sq] : Q8N4[sq]) : NT == 8 ? N8[sq] : N4[sq];
                 if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             }
             if (NT == 8 || (j & 1) == 0) issue_B(4 * b + sq + 2, wr, NT == 8 ? j : j >> 1);
-            if ((sq == 0 || sq == 2) && j >= 1 && j - 1 < NSTREAM) issue_A(2 * b + 1 + (sq >> 1), sq == 0 ? 1 : 0, j - 1);
+            // (Q8_0: the 64-k slot of step s is free once its last slice has been read - behind slice 1 - and takes step s + 2's blocks in slices 2 and 3)
+            if (Q8) { if (j >= 2) issue_A(4 * b + sq + 2, sq & 1, j - 2); }
+            else if ((sq == 0 || sq == 2) && j >= 1 && j - 1 < NSTREAM) issue_A(2 * b + 1 + (sq >> 1), sq == 0 ? 1 : 0, j - 1);
             if (sq == 1 && j == 1) issue_H(b + 1);
             if (TYPE == PM_Q5_K && sq == 1 && j == 2) issue_QH(b + 1);
             // (the slot's last reader - d of super-block 8 g + 7 - ran at slice 13 of super-block 8 g + 6; the first reader of the new group runs at slice 13 of 8 g + 7)
@@ -295,6 +326,7 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
             const bool newgrp = TYPE == PM_Q6_K || (i & 1) == 0;
             if (newgrp && !(exp & 16)) scales((i + 2) & 15, muln, addn);
             if (!(exp & 16)) af[(i + 1) & 1] = dequant(raw, (i + 1) & 15);
+            if (Q8 && i >= 7 && i < 15 && half_tail && b == nb - 1) af[(i + 1) & 1] = half8{0, 0, 0, 0, 0, 0, 0, 0};      // (k >= K: the row has no such weights)
             if (newgrp) { mul = muln; add = addn; }
             __builtin_amdgcn_sched_barrier(0);
             if (sq == 1) stamp(4 * j + 1, b);
@@ -511,8 +543,8 @@ bool pm_gemm_pf_enabled() {
 
 // 0 when pm_launch_gemm_pf serves (type, K, N, T)
 int pm_gemm_pf_check(int type, int K, int N, int T) {
-    if (type != PM_Q4_K && type != PM_Q5_K && type != PM_Q6_K) return -1;
-    if (K % 256 || K < 512 || N < 1 || N % 4 || T < 1) return -2;
+    if (type != PM_Q4_K && type != PM_Q5_K && type != PM_Q6_K && type != PM_Q8_0) return -1;
+    if ((type == PM_Q8_0 ? K % 128 : K % 256) || K < 512 || N < 1 || N % 4 || T < 1) return -2;
     if (type == PM_Q6_K && PM_Q6K_SCD) return -2;               // (the d's travel as 16-byte pieces = 8 super-blocks of the separate-stream row tail)
     if ((size_t) T * (size_t) K * 2 >= ((size_t) 1 << 32) || (size_t) N * pm_weight_row_stride(type, K) >= ((size_t) 1 << 32)) return -2;   // 32-bit lane offsets
     return 0;
@@ -553,7 +585,7 @@ int pm_launch_gemm_pf_ex(const pm_gemm_pf_job * jobs, int njobs, const void * xh
     if (force_nt == 4 || force_nt == 8) nt = force_nt;
     p.nt_t = (T + 32 * nt - 1) / (32 * nt);
     const long wgs = (long) tiles * p.nt_t;
-    const int nb = K / 256;
+    const int nb = (K + 255) / 256;
     static const int force_s = [] { const char * e = getenv("PM355_GEMM_PF_SPLITK"); return e ? atoi(e) : 0; }();
     int S = 1;
     {
@@ -603,7 +635,8 @@ int pm_launch_gemm_pf_ex(const pm_gemm_pf_job * jobs, int njobs, const void * xh
     }
 #endif
 #define PF_GO(A, B) (nt == 8 ? go(gemm_pf_kernel<A, B, 8>, pf_lds_bytes<A, B, 8>()) : go(gemm_pf_kernel<A, B, 4>, pf_lds_bytes<A, B, 4>()))
-    if (ta == tb) { if (ta == PM_Q4_K) PF_GO(PM_Q4_K, PM_Q4_K); else if (ta == PM_Q5_K) PF_GO(PM_Q5_K, PM_Q5_K); else PF_GO(PM_Q6_K, PM_Q6_K); }
+    if (ta == tb) { if (ta == PM_Q4_K) PF_GO(PM_Q4_K, PM_Q4_K); else if (ta == PM_Q5_K) PF_GO(PM_Q5_K, PM_Q5_K); else if (ta == PM_Q8_0) PF_GO(PM_Q8_0, PM_Q8_0); else PF_GO(PM_Q6_K, PM_Q6_K); }
+    else if (ta == PM_Q8_0 || tb == PM_Q8_0) return -1;      // (Q8_0 only as a launch of its own: ffn_down of the files whose n_ff is no multiple of 256)
     else if (ta == PM_Q4_K && tb == PM_Q5_K) PF_GO(PM_Q4_K, PM_Q5_K);
     else if (ta == PM_Q4_K && tb == PM_Q6_K) PF_GO(PM_Q4_K, PM_Q6_K);
     else PF_GO(PM_Q5_K, PM_Q6_K);

@@ -73,7 +73,10 @@ struct pm355_ring {
     hipStream_t cs = nullptr;                 // communication stream
     hipEvent_t ready = nullptr;               // compute -> comm: the buffer to send is complete
     hipEvent_t done = nullptr;                // comm -> compute: the exchange (send left, input arrived) is complete
+    hipEvent_t done2[2] = {nullptr, nullptr}; // staggered loop with two sequences per rank in flight: exchange of micro-step m signals done2[m % 2]
+    int done_slot = -1;                       // >= 0: pm355_ring_exchange2 records done2[done_slot] instead of `done`
     bool pending = false;                     // an exchange was enqueued since the last wait
+    bool pending2[2] = {false, false};
     // caller-supplied transport (pm355_ring_init_cb) instead of RCCL
     pm355_ring_exchange_fn cb_exchange = nullptr; pm355_ring_wait_fn cb_wait = nullptr; void * cb_user = nullptr;
     // prompt pipeline / single-stream buffers: [2] inputs + [2] outputs of up to buf_floats f32
@@ -121,7 +124,8 @@ pm355_ring * pm355_ring_init(const void * id128, int rank, int world) {
     if (rc != ncclSuccess) { rfail(PM355_E_HIP, "ncclCommInitRank", rc); delete r; return nullptr; }
     if (hipStreamCreateWithFlags(&r->cs, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&r->ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&r->done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&r->done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->done2[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->done2[1], hipEventDisableTiming) != hipSuccess) {
         rfail(PM355_E_HIP, "ring_init: stream / events");
         pm355_ring_free(r);
         return nullptr;
@@ -153,6 +157,7 @@ void pm355_ring_free(pm355_ring * r) {
     if (r->cs) (void) hipStreamDestroy(r->cs);
     if (r->ready) (void) hipEventDestroy(r->ready);
     if (r->done) (void) hipEventDestroy(r->done);
+    for (int i = 0; i < 2; ++i) if (r->done2[i]) (void) hipEventDestroy(r->done2[i]);
     delete r;
 }
 
@@ -171,7 +176,7 @@ int pm355_ring_exchange2(pm355_ring * r, const float * send, int64_t n_send, flo
     if (r->cb_exchange) {
         const int rc = r->cb_exchange(r->cb_user, send, send ? n_send : 0, recv, recv ? n_recv : 0, compute_stream);
         if (rc) return rfail(PM355_E_HIP, "ring_exchange: transport callback failed");
-        r->pending = true;
+        if (r->done_slot >= 0) r->pending2[r->done_slot] = true; else r->pending = true;
         return 0;
     }
     Rccl & R = rccl();
@@ -183,14 +188,30 @@ int pm355_ring_exchange2(pm355_ring * r, const float * send, int64_t n_send, flo
     if (rc == ncclSuccess && recv) rc = R.Recv(recv, (size_t) n_recv, ncclFloat32, r->prev, r->comm, r->cs);
     const int rc2 = R.GroupEnd();
     if (rc != ncclSuccess || rc2 != ncclSuccess) return rfail(PM355_E_HIP, "ring_exchange: ncclSend / ncclRecv", rc != ncclSuccess ? rc : rc2);
-    if (hipEventRecord(r->done, r->cs) != hipSuccess) return rfail(PM355_E_HIP, "ring_exchange: event record");
-    r->pending = true;
+    if (hipEventRecord(r->done_slot >= 0 ? r->done2[r->done_slot] : r->done, r->cs) != hipSuccess) return rfail(PM355_E_HIP, "ring_exchange: event record");
+    if (r->done_slot >= 0) r->pending2[r->done_slot] = true; else r->pending = true;
+    return 0;
+}
+
+// the compute stream waits for the exchange that signalled done2[slot] (two-deep staggered loop). A caller-supplied transport knows only "everything
+// enqueued so far" - its wait also covers the younger exchange, which costs the overlap and nothing else.
+static int ring_wait_slot(pm355_ring * r, int slot, pm355_stream_t compute_stream) {
+    if (!r->pending2[slot]) return 0;
+    if (r->cb_wait) {
+        if (r->cb_wait(r->cb_user, compute_stream)) return rfail(PM355_E_HIP, "ring_wait: transport callback failed");
+        r->pending2[0] = r->pending2[1] = false;
+        return 0;
+    }
+    if (hipStreamWaitEvent((hipStream_t) compute_stream, r->done2[slot], 0) != hipSuccess) return rfail(PM355_E_HIP, "ring_wait");
+    r->pending2[slot] = false;
     return 0;
 }
 
 // The compute stream waits (on the device) for the last exchange: the previous send has left its buffer, the input has arrived.
+// (also for everything a two-deep staggered loop still has in flight)
 int pm355_ring_wait(pm355_ring * r, pm355_stream_t compute_stream) {
     if (!r) return rfail(PM355_E_SHAPE, "ring_wait: no ring");
+    for (int sl = 0; sl < 2; ++sl) { const int rc = ring_wait_slot(r, sl, compute_stream); if (rc) return rc; }
     if (!r->pending) return 0;
     if (r->cb_wait) {
         if (r->cb_wait(r->cb_user, compute_stream)) return rfail(PM355_E_HIP, "ring_wait: transport callback failed");
@@ -337,11 +358,18 @@ int pm355_ring_decode_staggered(pm355_ring * r, pm355_model * m, int n_micro, co
         const int rs = pm355_model_set_seq(m, 0, compute_stream);
         if (rs) return rfail(rs, pm355_model_error(m));
     }
-    auto need_recv = [&](long mm) { return W > 1 && (rank == 0 ? mm >= W : mm >= rank); };
+    // D = sequences per rank in flight = hop latency in micro-steps: a window finalized for n_seq = 2 x world runs TWO interleaved rounds of sequences - the row
+    // a rank sends after micro-step m is consumed by its successor at micro-step m + 2, so the exchange of step m travels while step m + 1 (the other round's
+    // sequence) computes and no hop is exposed (the reference has one batch in flight, src/llama.cpp:18509). D = 1: the lock-step schedule.
+    const int n_seq = pm355_model_n_seq(m);
+    const int D = (W > 1 && n_seq == 2 * W) ? 2 : 1;
+    if (n_seq != D * W && !(W == 1 && n_seq >= 1)) return rfail(PM355_E_SHAPE, "ring_decode_staggered: the window must be finalized for world or 2 x world sequences");
+    auto need_recv = [&](long mm) { return W > 1 && (rank == 0 ? mm >= (long) D * W : mm >= (long) D * rank); };
     for (int i = 0; i < n_micro; ++i) {
         const long mm = r->stag_m++;
-        const bool active = mm >= rank;
-        int rc = pm355_ring_wait(r, compute_stream);          // previous exchange: our last row has left, this step's input is here
+        const bool active = mm >= (long) D * rank;
+        // the exchange enqueued D micro-steps ago: our row of then has left its buffer, this step's input is here
+        int rc = D == 1 ? pm355_ring_wait(r, compute_stream) : ring_wait_slot(r, (int) (mm & 1), compute_stream);
         if (rc) return rc;
         float * out = nullptr;
         if (active) {
@@ -351,7 +379,7 @@ int pm355_ring_decode_staggered(pm355_ring * r, pm355_model * m, int n_micro, co
             if (rank == 0) {
                 const bool have_forced = forced && forced[i] >= 0;
                 if (have_forced || !x_in) {
-                    if (!have_forced && mm < W) return rfail(PM355_E_SHAPE, "ring_decode_staggered: the first `world` micro-steps of rank 0 need forced tokens");
+                    if (!have_forced && mm < (long) D * W) return rfail(PM355_E_SHAPE, "ring_decode_staggered: the first micro-steps of rank 0 (one per sequence in flight) need forced tokens");
                     if (have_forced && pm355_set_i32x2(r->d_cur, forced[i], 0, compute_stream)) return rfail(PM355_E_HIP, "ring_decode_staggered: token upload");
                     rc = pm355_model_step_ex(m, r->d_cur, nullptr, out, nullptr, nullptr, 1, 1, 0, use_graph, compute_stream);
                 } else {
@@ -366,7 +394,10 @@ int pm355_ring_decode_staggered(pm355_ring * r, pm355_model * m, int n_micro, co
             r->stag_last = out;
         }
         if (W > 1) {
-            rc = pm355_ring_exchange2(r, active ? out : nullptr, E, need_recv(mm + 1) ? r->pin[(mm + 1) & 1] : nullptr, E, compute_stream);
+            // send this step's row, receive the input of step mm + D (same buffer parity as this step's input, which the window has just consumed)
+            r->done_slot = D == 1 ? -1 : (int) (mm & 1);
+            rc = pm355_ring_exchange2(r, active ? out : nullptr, E, need_recv(mm + D) ? r->pin[(mm + D) & 1] : nullptr, E, compute_stream);
+            r->done_slot = -1;
             if (rc) return rc;
         }
     }

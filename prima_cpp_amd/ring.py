@@ -106,17 +106,23 @@ class RingDriver:
     next == previous) and the NCCL per-communicator ordering deadlock-free; a rank sends at micro-step m iff
     it is active (m >= rank) and its successor receives for m+1 under exactly the same condition."""
 
-    def __init__(self, compute, rank, world, group=None, c_ring=None):
+    def __init__(self, compute, rank, world, group=None, c_ring=None, depth=1):
         """c_ring: a prima_cpp_amd.ring.CRing (RCCL transport in C, pm355_ring_* of include/prima_mi355.h): the exchange is enqueued
         on the library's communication stream with event hand-off and the host never waits; without it the exchange goes through
-        torch.distributed (gloo in the CPU tests) and the host waits for the requests at the start of the next micro-step."""
+        torch.distributed (gloo in the CPU tests) and the host waits for the requests at the start of the next micro-step.
+        depth = 2 (round 6, world > 1): 2 x world sequences in flight - rank r works on sequence (m - 2 r) mod (2 world), the row sent after
+        micro-step m is consumed by the successor at m + 2, so the exchange of step m is only waited for before step m + 2 (the schedule
+        of pm355_ring_decode_staggered on a window finalized for 2 x world sequences)."""
         self.c, self.rank, self.world, self.group = compute, rank, world, group
+        self.depth = depth if world > 1 else 1
+        assert self.depth in (1, 2)
+        self.n_seq = self.depth * world
         self.c_ring = c_ring if world > 1 else None
         self.nxt, self.prv = (rank + 1) % world, (rank - 1) % world
-        # receive buffers alternate so the receive for m+1 never targets the buffer micro-step m reads
+        # receive buffers alternate so the receive for a later micro-step never targets the buffer micro-step m reads
         self.x_in = [torch.empty((1, compute.n_embd), dtype=torch.float32, device=compute.device) for _ in range(2)]
         self.m = 0
-        self.reqs = []
+        self.reqs = {}                                # micro-step -> requests of the exchange enqueued at its end
         self.last_out = None
         # gloo has no device-memory send/recv: when the transport is gloo and the buffers live on a GPU (single-GPU
         # tests only), stage through pinned host tensors. With nccl (= RCCL) the device buffers go on the wire directly.
@@ -130,23 +136,24 @@ class RingDriver:
     def _need_recv(self, m):
         if self.world == 1:
             return False
-        return m >= self.world if self.rank == 0 else m >= self.rank
+        return m >= self.depth * self.world if self.rank == 0 else m >= self.depth * self.rank
 
-    def _wait(self):
+    def _wait(self, upto):
+        """every exchange enqueued at a micro-step <= upto has completed (our row has left, the input it carried is here)"""
         if self.c_ring is not None:
             self.c_ring.wait()                        # device-side: the compute stream waits for the exchange's event
             return
-        for q in self.reqs:
-            q.wait()
-        self.reqs = []
+        for k in sorted(k for k in self.reqs if k <= upto):
+            for q in self.reqs.pop(k):
+                q.wait()
 
     def micro_step(self, forced_token=None):
         """One micro-step of this rank. Returns the sequence id processed, or None while the pipeline fills."""
-        m, r, W = self.m, self.rank, self.world
+        m, r, W, D = self.m, self.rank, self.world, self.depth
         self.m += 1
-        active = m >= r
-        seq = (m - r) % W if active else None
-        self._wait()                                  # previous exchange: our last send left, this step's input arrived
+        active = m >= D * r
+        seq = (m - D * r) % self.n_seq if active else None
+        self._wait(m - D)                             # the exchange of D micro-steps ago: that row has left, this step's input arrived
         out = None
         if active:
             if W == 1:
@@ -158,7 +165,7 @@ class RingDriver:
             out = self.c.first_rank_step(seq, x_in, forced_token) if r == 0 else self.c.rank_step(seq, x_in)
             self.last_out = out
         if W > 1 and self.c_ring is not None:
-            rcv = self.x_in[(m + 1) & 1] if self._need_recv(m + 1) else None
+            rcv = self.x_in[(m + D) & 1] if self._need_recv(m + D) else None
             self.c_ring.exchange(out if active else None, rcv)       # ncclGroupStart; ncclSend; ncclRecv; ncclGroupEnd on the comm stream
         elif W > 1:
             ops = []
@@ -169,17 +176,17 @@ class RingDriver:
                     torch.cuda.current_stream().synchronize()
                     snd = self.h_out[m & 1]
                 ops.append(dist.P2POp(dist.isend, snd, self.nxt, self.group))
-            if self._need_recv(m + 1):
-                rcv = self.h_in[(m + 1) & 1] if self.host_stage else self.x_in[(m + 1) & 1]
+            if self._need_recv(m + D):
+                rcv = self.h_in[(m + D) & 1] if self.host_stage else self.x_in[(m + D) & 1]
                 ops.append(dist.P2POp(dist.irecv, rcv, self.prv, self.group))
             if ops:
-                self.reqs = dist.batch_isend_irecv(ops)
+                self.reqs[m] = dist.batch_isend_irecv(ops)
         return seq
 
     def flush(self):
         """After the last micro-step: the receive posted for the never-executed next micro-step absorbs the
         predecessor's final send, so every send has been matched; wait for both."""
-        self._wait()
+        self._wait(self.m)
 
 
 class CRing:

@@ -97,7 +97,7 @@ def test_two_rank_ring_matches_single_window():
     w.close()
 
 
-def _worker_stag(rank, world, port, n_rounds, first, q):
+def _worker_stag(rank, world, port, n_rounds, first, q, depth=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -114,29 +114,32 @@ def _worker_stag(rank, world, port, n_rounds, first, q):
     with torch.cuda.stream(torch.cuda.Stream()):
         w = E.Window(_hp(d), lo=lo, hi=hi, flags=(E.HAS_EMBD | E.HAS_HEAD) if rank == 0 else 0, n_ctx=64)
         w.load_desc(d)
-        w.finalize(max_tokens=1, n_seq=world)
+        n_seq = depth * world                                                  # depth 2: two sequences per rank in flight (the two-deep schedule)
+        w.finalize(max_tokens=1, n_seq=n_seq)
         ring = CRing(rank, world, transport="torch")
-        total = world * (n_rounds + 1)
+        total = n_seq * (n_rounds + 1)
         out = torch.full((total,), -1, dtype=torch.int32, device="cuda") if rank == 0 else None
         # in two calls: the schedule's state (micro-step counter, buffer toggles) lives in the ring object
-        n1 = world + 3
-        ring.decode_staggered(w, n1, forced=(list(first) + [None] * (n1 - world)) if rank == 0 else None, tokens_out=out, reset=True)
+        n1 = n_seq + 3
+        ring.decode_staggered(w, n1, forced=(list(first) + [None] * (n1 - n_seq)) if rank == 0 else None, tokens_out=out, reset=True)
         ring.decode_staggered(w, total - n1, tokens_out=out[n1:] if rank == 0 else None)
         ring.wait()
         torch.cuda.synchronize()
         if rank == 0:
-            fed = out.cpu().numpy().tolist()                                   # token fed at micro-step m = generated for sequence m % world
-            q.put([[fed[m] for m in range(world + s_, total, world)] for s_ in range(world)])
+            fed = out.cpu().numpy().tolist()                                   # token fed at micro-step m = generated for sequence m % n_seq
+            q.put([[fed[m] for m in range(n_seq + s_, total, n_seq)] for s_ in range(n_seq)])
         ring.close()
         w.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_c_staggered_decode_loop_two_ranks_matches_single_window():
+@pytest.mark.parametrize("depth", [1, 2])
+def test_c_staggered_decode_loop_two_ranks_matches_single_window(depth):
     """pm355_ring_decode_staggered - the N-sequences-in-flight decode loop in C (was RingDriver.micro_step) - on two ranks sharing the test GPU over
     gloo (transport callbacks): every sequence's token stream equals the one a single full-model window generates for it. And the same loop
-    on a world-1 local ring against Window.generate."""
+    on a world-1 local ring against Window.generate. depth 2 (round 6): windows finalized for 2 x world sequences run the two-deep schedule - a hop
+    sent after micro-step m is consumed at m + 2, the exchange of step m travels under step m + 1's compute."""
     import torch
     import torch.multiprocessing as mp
     if not torch.cuda.is_available():
@@ -146,11 +149,11 @@ def test_c_staggered_decode_loop_two_ranks_matches_single_window():
     import prima_cpp_amd.engine as E
     from prima_cpp_amd.ring import CRing
     world, n_rounds = 2, 6
-    first = [17, 101]
+    first = [17, 101, 5, 230][:depth * world]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_stag, args=(r, world, port, n_rounds, first, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_stag, args=(r, world, port, n_rounds, first, q, depth)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=300)
@@ -162,7 +165,7 @@ def test_c_staggered_decode_loop_two_ranks_matches_single_window():
     w.load_desc(d)
     w.finalize(1)
     want = []
-    for s in range(world):
+    for s in range(depth * world):
         w.kv_clear()
         io = torch.zeros(n_rounds + 1, dtype=torch.int32, device="cuda")
         io[0] = first[s]

@@ -34,11 +34,11 @@ class FakeCompute:
     device = "cpu"
     n_embd = E
 
-    def __init__(self, lo, hi, world):
+    def __init__(self, lo, hi, n_seq):
         self.lo, self.hi = lo, hi
-        self.pos = [0] * world
-        self.tok = [None] * world
-        self.generated = [[] for _ in range(world)]
+        self.pos = [0] * n_seq
+        self.tok = [None] * n_seq
+        self.generated = [[] for _ in range(n_seq)]
 
     def _window(self, seq, x):
         for il in range(self.lo, self.hi):
@@ -73,20 +73,21 @@ def _serial(n_layer, world, first_tokens, n_rounds):
     return out
 
 
-def _worker(rank, world, port, n_layer, n_rounds, q):
+def _worker(rank, world, port, n_layer, n_rounds, q, depth=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from prima_cpp_amd.ring import RingDriver, partition_layers
     wins = partition_layers([10 + (i % 3) for i in range(n_layer)], 12, world)
     lo, hi = wins[rank]
-    comp = FakeCompute(lo, hi, world)
-    drv = RingDriver(comp, rank, world)
-    first = [11 + 3 * s for s in range(world)]
+    n_seq = depth * world
+    comp = FakeCompute(lo, hi, n_seq)
+    drv = RingDriver(comp, rank, world, depth=depth)
+    first = [11 + 3 * s for s in range(n_seq)]
     # n_rounds full rounds + one extra round on rank 0 so the last tokens are produced by the head
-    total = world * (n_rounds + 1)
+    total = n_seq * (n_rounds + 1)
     for m in range(total):
-        forced = first[m] if (rank == 0 and m < world) else None
+        forced = first[m] if (rank == 0 and m < n_seq) else None
         drv.micro_step(forced_token=forced)
     drv.flush()
     if rank == 0:
@@ -103,21 +104,24 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("depth", [1, 2])
 @pytest.mark.parametrize("world", [2, 3])
-def test_ring_schedule_matches_serial(world):
+def test_ring_schedule_matches_serial(world, depth):
+    """depth 2 (round 6): 2 x world sequences in flight, every hop consumed two micro-steps after it was sent - the same tokens as the serial run."""
     n_layer, n_rounds = 7, 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_layer, n_rounds, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_layer, n_rounds, q, depth)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    want = _serial(n_layer, world, [11 + 3 * s for s in range(world)], n_rounds)
-    for s in range(world):
+    n_seq = depth * world
+    want = _serial(n_layer, n_seq, [11 + 3 * s for s in range(n_seq)], n_rounds)
+    for s in range(n_seq):
         assert got[s][:n_rounds] == want[s], (s, got[s], want[s])
 
 
