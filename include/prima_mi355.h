@@ -149,6 +149,11 @@ PM355_API int pm355_mul_mat_vec_fused(const pm355_matvec_job * jobs, int njobs, 
 /* 1 when this build stores the tail of a Q6_K row per group of 8 blocks - scales[8][16] | d[8] - (round 5, csrc/pm355_device.h), 0 for the
  * round-1..4 form scales[nb][16] | d[nb]; the streams in front of it (la | lb | qh) are the same. Tests build the expected HBM image from it. */
 PM355_API int pm355_q6k_tail_grouped(void);
+/* 1 in prima_cpp_amd/libprima_mi355_exp.so (-DPM_EXPERIMENTS=1): round 5's measured-slower forms of the decode layer - producer-side sums of squares
+ * (pm355_mul_mat_vec_fused_ss with sumsq arguments), attention in the tail of the QKV launch (pm355_mul_mat_vec_qkv_attn), the persistent engine
+ * (pm355_engine_run; PM355_SS / PM355_ATTN_TAIL / PM355_ENGINE for the resident window) - exist only there; in the product library (0) those entry
+ * points return PM355_E_UNSUPPORTED and the switches do nothing. */
+PM355_API int pm355_experiments_built(void);
 /* Producer-side sum of squares (round 5). The rms_norm in front of wq | wk | wv and of ffn_gate | ffn_up reads a row that the preceding wo / ffn_down
  * launch has just written: sumsq_out != NULL (ONE job, W2 == NULL) makes every workgroup of that launch store the f64 sum of the f32-rounded squares
  * of the output rows it wrote - the terms of ggml_compute_forward_rms_norm_f32's `sum += (ggml_float)(x[i] * x[i])`, ggml.c:11975-11980 - into

@@ -2,6 +2,8 @@
 machinery: the .so travels with the repo snapshot to the GPU box.
 
 build()            the product library prima_cpp_amd/libprima_mi355.so
+build_experiments()  libprima_mi355_exp.so = the product sources + decode_engine.hip with -DPM_EXPERIMENTS=1: round 5's three measured-slower forms of the decode
+                   layer live only there (tests/test_gpu_experiments.py runs their tests against it)
 build_probe()      tools/csrc -> prima_cpp_amd/libprima_mi355_probe.so: measurement helpers (HBM streaming-read ceiling, persistent-layer
                    skeleton) that bench.py / tools/ load separately - nothing of them is inside the product library
 build(tag=, extra=)  an A/B or measurement variant of the product library with extra compiler flags -> ab/<tag>.so, objects under
@@ -16,7 +18,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libprima_mi355.so")
 PROBE_LIB = os.path.join(HERE, "libprima_mi355_probe.so")
 SOURCES = ["c_api.hip", "quantize.hip", "mmvq.hip", "mmvq_cols.hip", "repack.hip", "layer_ops.hip", "ggml_ops.hip", "engine.hip", "mmq.hip", "mmq_pf.hip", "mmq_i8.hip", "mmq_big.hip",
-           "decode_engine.hip", "attn_prefill.hip", "attn_cached.hip", "attn_flash_mfma.hip", "attn_split.hip", "attn_flash.hip", "attn_q8.hip", "ring.hip", "upload.hip", "ts.hip"]
+           "attn_prefill.hip", "attn_cached.hip", "attn_flash_mfma.hip", "attn_split.hip", "attn_flash.hip", "attn_q8.hip", "ring.hip", "upload.hip", "ts.hip"]
+# round 5's measured-slower forms of the decode layer (sum-of-squares partials, attention tail, persistent engine): a library of their own, loaded by their tests
+EXP_LIB = os.path.join(HERE, "libprima_mi355_exp.so")
+EXP_SOURCES = SOURCES + ["decode_engine.hip"]
 PROBE_SOURCES = ["probe.hip", "engine_probe.hip", "probe_api.hip", "overlap_probe.hip"]
 # -ffp-contract=off: the quantizers must round exactly like the reference (no fused multiply-add where
 # the reference has a separate multiply and add); FMAs we want are written as fmaf().
@@ -97,6 +102,14 @@ def build(force=False, verbose=False, tag=None, extra=()):
     return _compile(srcs, _headers(), CSRC, LIB, EXTRA + FLAGS, force, verbose)
 
 
+def build_experiments(force=False, verbose=False):
+    """prima_cpp_amd/libprima_mi355_exp.so: the product sources + decode_engine.hip with -DPM_EXPERIMENTS=1 (objects under csrc/obj_exp/)"""
+    srcs = [os.path.join(CSRC, s) for s in EXP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    for s_ in EXP_SOURCES:
+        PER_SOURCE_FLAGS.setdefault(s_, KERNARG_PRELOAD)
+    return _compile(srcs, _headers(), os.path.join(CSRC, "obj_exp"), EXP_LIB, EXTRA + ["-DPM_EXPERIMENTS=1"] + FLAGS, force, verbose)
+
+
 def build_probe(force=False, verbose=False):
     d = os.path.join(ROOT, "tools", "csrc")
     srcs = [os.path.join(d, s) for s in PROBE_SOURCES]
@@ -110,4 +123,5 @@ if __name__ == "__main__":
         print(build(force="--force" in sys.argv, verbose=True, tag=args[0], extra=[a for a in sys.argv[2:] if a.startswith("-D")]))
     else:
         print(build(force="--force" in sys.argv, verbose=True))
+        print(build_experiments(force="--force" in sys.argv, verbose=True))
         print(build_probe(force="--force" in sys.argv, verbose=True))

@@ -154,6 +154,7 @@ static int gemv_rc(int rc) {
         case -2: return fail(PM355_E_SHAPE, "mul_mat_vec_q: K not a multiple of the block size");
         case -3: return fail(PM355_E_ALIGN, "mul_mat_vec_q: K not a multiple of 32 for Q8_0");
         case -4: return fail(PM355_E_RANGE, "mul_mat_vec_q: K too large");
+        case -8: return fail(PM355_E_UNSUPPORTED, "mul_mat_vec_q: sum-of-squares partials / attention tail are built into libprima_mi355_exp.so only (PM_EXPERIMENTS)");
         default: return fail(PM355_E_HIP, "mul_mat_vec_q: launch", hipGetLastError());
     }
 }
@@ -192,6 +193,7 @@ int pm355_mul_mat_vec_fused_ss(const pm355_matvec_job * jobs, int njobs, int64_t
     }
     (void) hipGetLastError();
     const int lrc = pm_launch_gemv_fused(f, S(st));
+    if (lrc == -8) return gemv_rc(-8);
     if (lrc == -6) return fail(PM355_E_UNSUPPORTED, "mul_mat_vec_fused_ss: sumsq_out needs ONE plain job; sumsq_in needs norm_w and 1..256 partials");
     const int rc = gemv_rc(lrc);
     if (rc) return rc;
@@ -199,6 +201,7 @@ int pm355_mul_mat_vec_fused_ss(const pm355_matvec_job * jobs, int njobs, int64_t
     return 0;
 }
 int pm355_q6k_tail_grouped(void) { return PM_Q6K_SCD ? 1 : 0; }
+int pm355_experiments_built(void) { return PM_EXPERIMENTS ? 1 : 0; }
 int pm355_mul_mat_vec_fused_grid(const pm355_matvec_job * jobs, int njobs, int64_t K) {
     if (njobs < 1 || njobs > 3 || !jobs) return fail(PM355_E_RANGE, "mul_mat_vec_fused_grid: 1..3 jobs");
     pm_gemv_fused f = {};
@@ -401,12 +404,14 @@ int pm355_mul_mat_vec_qkv_attn(const pm355_matvec_job * jobs, int64_t K, const f
     f.epi = &e;
     (void) hipGetLastError();
     const int rc = pm_launch_gemv_fused(f, S(st));
+    if (rc == -8) return gemv_rc(-8);
     if (rc == -7) return fail(PM355_E_UNSUPPORTED, "mul_mat_vec_qkv_attn: the workgroups of a KV-head group must be a power-of-two run of the grid (CUs % n_head_kv == 0), head_dim 64 / 128, position-pointer mode, transposed V cache");
     if (rc == -5) return fail(PM355_E_UNSUPPORTED, "mul_mat_vec_qkv: every workgroup's row slices must hold whole rotation pairs (N % (2 * CUs) == 0), N_k == N_v == n_head_kv * head_dim");
     if (rc) return gemv_rc(rc);
     HIP_TRY(hipGetLastError());
     return 0;
 }
+#if PM_EXPERIMENTS
 int pm355_engine_run(const pm355_engine_phase * phs, int n, pm355_stream_t st) {
     if (!phs || n < 1) return fail(PM355_E_SHAPE, "engine_run: phases");
     pm_eng_plan * pl = pm_eng_plan_new();
@@ -447,6 +452,9 @@ int pm355_engine_run(const pm355_engine_phase * phs, int n, pm355_stream_t st) {
     if (w) { char msg[96]; snprintf(msg, sizeof(msg), "engine_run: watchdog code %d", w); return fail(PM355_E_HIP, msg); }
     return 0;
 }
+#else
+int pm355_engine_run(const pm355_engine_phase *, int, pm355_stream_t) { return fail(PM355_E_UNSUPPORTED, "engine_run: the persistent decode engine is built into libprima_mi355_exp.so only (PM_EXPERIMENTS)"); }
+#endif
 int pm355_mul_mat_vec_qkv_check_ex(const pm355_matvec_job * jobs, int64_t K, int n_head_kv, int head_dim, int n_rot, int rope_neox) {
     if (!jobs) return fail(PM355_E_SHAPE, "mul_mat_vec_qkv_check: jobs");
     pm_gemv_fused f = {};

@@ -370,6 +370,7 @@ int run_head(pm355_model * m, const float * x_row, float * d_logits, int32_t * d
 // The single-token layer stack as ONE persistent launch: the same launches run_layers_fused issues, appended as phases (decode_engine.hip).
 // nullptr: this window is not served (types, shapes, streaming, long-context regime) - the caller takes the five-launch path.
 // may_build = false (the stream is being captured: no allocation, no synchronous copy): only a plan that exists already is returned.
+#if PM_EXPERIMENTS
 pm355_model::EnginePlan * engine_plan_for(pm355_model * m, const float * cur, float * d_x_out, bool may_build = true) {
     for (auto & e : m->eng_plans) if (e.in == cur && e.out == d_x_out) return &e;
     if (m->eng_refused || !may_build) return nullptr;
@@ -449,6 +450,9 @@ pm355_model::EnginePlan * engine_plan_for(pm355_model * m, const float * cur, fl
     return &m->eng_plans.back();
 }
 
+#else
+pm355_model::EnginePlan * engine_plan_for(pm355_model *, const float *, float *, bool = true) { return nullptr; }      // (experiments library only)
+#endif
 bool engine_eligible(const pm355_model * m) {
     return m->use_engine && !m->no_fuse && !m->long_ctx && !m->n_slots && m->ss && m->qkv_epi && m->rope_tab && (m->rope.mode == 0 || m->rope.mode == 2) && m->hi > m->lo;
 }
@@ -596,7 +600,9 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
             // ---- ... or, where served, ALL layers as one persistent launch (decode_engine.hip): cos / sin table, the first norm's sum of squares, the engine
             pm_launch_rope_table(m->rope, m->d_pos, m->d_ctl, (const float *) m->rope_freqs.d, m->rope_tab, st);
             pm_launch_sumsq_row(cur, E, eng->ss_in0, st);
+#if PM_EXPERIMENTS
             if (pm_eng_plan_launch(eng->plan, st)) return seterr(m, PM355_E_HIP, "decode: engine launch");
+#endif
             end = eng->end; n_ss_head = eng->n_ss_end; ss_head = eng->ss_end;
         } else {
             int rc = run_layers_fused(m, cur, d_x_out, &end, st, &n_ss_head);
@@ -836,9 +842,11 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     { const char * e = getenv("PM355_NO_MMQ_I8"); m->no_mmq = e && e[0] == '1'; }     // 4..64-token batches: mat-vec columns / F16 GEMM from 16 (the round-1 paths)
     { const char * e = getenv("PM355_QKV_EPI"); m->qkv_epi = !(e && e[0] == '0'); }
     { const char * e = getenv("PM355_PROMPT_I8"); m->no_big = !(e && e[0] == '1'); }
+#if PM_EXPERIMENTS          // (round 5's measured-slower forms: libprima_mi355_exp.so only - the product library has no code behind these switches)
     { const char * e = getenv("PM355_SS"); m->use_ss = e && e[0] == '1'; }
     { const char * e = getenv("PM355_ENGINE"); m->use_engine = e && e[0] == '1'; }
     { const char * e = getenv("PM355_ATTN_TAIL"); m->attn_tail = e && e[0] == '1'; }
+#endif
     return m;
 }
 
@@ -846,7 +854,9 @@ void pm355_model_free(pm355_model * m) {
     if (!m) return;
     (void) hipDeviceSynchronize();
     for (auto & g : m->graphs) (void) hipGraphExecDestroy(g.exec);
+#if PM_EXPERIMENTS
     for (auto & e : m->eng_plans) { pm_eng_plan_free(e.plan); if (e.act) (void) hipFree(e.act); }
+#endif
     if (m->copy_stream) { (void) hipStreamSynchronize(m->copy_stream); (void) hipStreamDestroy(m->copy_stream); }
     for (auto & S : m->slots) { for (auto p : S.d) if (p) (void) hipFree(p); if (S.ready) (void) hipEventDestroy(S.ready); if (S.free_) (void) hipEventDestroy(S.free_); }
     for (auto & L : m->layers) for (auto p : L.host) if (p) (void) hipHostFree(p);
@@ -930,7 +940,9 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
     (void) pm355_uploader_sync(m->up);
     (void) hipDeviceSynchronize();
     // (a re-finalize re-allocates the KV caches, the rope table and the split scratch that the kept engine plans and captured graphs have baked in)
+#if PM_EXPERIMENTS
     for (auto & e : m->eng_plans) { pm_eng_plan_free(e.plan); if (e.act) (void) hipFree(e.act); }
+#endif
     m->eng_plans.clear(); m->eng_refused = false;
     for (auto & g : m->graphs) (void) hipGraphExecDestroy(g.exec);
     m->graphs.clear();
@@ -1152,10 +1164,12 @@ int pm355_model_check(pm355_model * m) {
             return PM355_E_HIP;
         }
     }
+#if PM_EXPERIMENTS
     for (auto & e : m->eng_plans) {
         const int w = pm_eng_plan_status(e.plan);
         if (w) { snprintf(m->err, sizeof(m->err), "check: the decode engine's watchdog fired (code %d: 1 loader, 2 consumer barrier, 3 device-wide barrier, 4 item wait, 6 attention barrier)", w); return PM355_E_HIP; }
     }
+#endif
     return 0;
 }
 

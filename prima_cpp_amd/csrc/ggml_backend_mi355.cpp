@@ -938,7 +938,7 @@ ggml_backend_t ggml_backend_mi355_init(int device) {
     c->fuse = !env_on("GGML_MI355_NO_FUSE");                          // node-by-node kernels only (debug / A-B)
     if (const char * am = getenv("GGML_MI355_ATTN_MFMA")) if (am[0] == '0') c->attn_mfma = false;
     if (const char * qe = getenv("GGML_MI355_QKV_EPI")) if (qe[0] == '0') c->qkv_epi = false;   // rope + KV store inside the attention kernel (round-2 form)
-    if (const char * se = getenv("GGML_MI355_SS")) c->use_ss = se[0] == '1';                    // default: every rms_norm prologue reduces its own row
+    if (const char * se = getenv("GGML_MI355_SS")) c->use_ss = se[0] == '1' && (plan_only() || pm355_experiments_built());   // (the partials' kernels live in the experiments library)                    // default: every rms_norm prologue reduces its own row
     c->use_graphs = !env_on("GGML_MI355_NO_GRAPH") && !plan_only();   // no hipGraph capture / replay
     c->debug_plan = env_on("GGML_MI355_DEBUG_PLAN") || plan_only();
     if (const char * sm = getenv("GGML_MI355_ATTN_SPLIT_MIN")) if (sm[0]) c->split_min = atoi(sm);

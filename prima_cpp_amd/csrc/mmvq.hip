@@ -82,27 +82,36 @@ int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, 
 #endif
     };
     const bool ss = p.ss_out != nullptr || p.xmode == 3;          // producer or consumer of per-workgroup partial sums of squares
+#if !PM_EXPERIMENTS
+    if (ss || (epi && p.epi.att_out != nullptr)) return -8;         // (sum-of-squares partials / attention tail: experiments library only)
+#endif
     static const bool xm_spec = [] { const char * e = getenv("PM355_XMODE_SPEC"); return !(e && e[0] == '0'); }();     // (A/B switches)
     static const bool hot_spec = xm_spec && [] { const char * e = getenv("PM355_HOT_SPEC"); return !(e && e[0] == '0'); }();
     const bool one_job = p.job[1].N == 0 && p.job[2].N == 0;
-    const bool tail = epi && p.epi.att_out != nullptr;
+    const bool tail = epi && p.epi.att_out != nullptr; (void) tail;
     const bool neox = epi && (p.job[0].nx_s > 0 || p.job[1].nx_s > 0 || p.job[2].nx_s > 0);
     if (pair) {
         if (TA != TB) return -1;
         // (pair launches: one step of pre-issue - two sets of two matrices next to the activation registers spill)
         if (dbg) { if (ss) return -6; go(gemv_q_kernel<TA, TA, true, true, false, 1>); }
+#if PM_EXPERIMENTS
         else if (ss) go(gemv_q_kernel<TA, TA, true, false, false, 1, PM_FEAT_SS>);
+#endif
         else if (p.xmode == 2 && hot_spec && one_job && !p.job[0].bias && !p.job[0].resid && !p.job[0].split) go(gemv_q_kernel<TA, TA, true, false, false, 1, 0, 2, 1>);
         else if (p.xmode == 2 && xm_spec) go(gemv_q_kernel<TA, TA, true, false, false, 1, 0, 2>);
         else go(gemv_q_kernel<TA, TA, true, false, false, 1>);
     } else if (epi) {
         if (dbg) return -1;
+#if PM_EXPERIMENTS
         if (tail) {
             // the tail is compiled for the wq | wk | wv type mixtures of the Q4_K_M files only (wq Q4_K; wv Q4_K / Q5_K / Q6_K)
             if constexpr (TA == PM_Q4_K) { if (ss) go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_SS | PM_FEAT_TAIL>); else go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_TAIL>); }
             else return -7;
-        } else if (neox) { if (ss) go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_NEOX | PM_FEAT_SS>); else go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_NEOX>); }
+        } else if (neox && ss) go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_NEOX | PM_FEAT_SS>);
         else if (ss) go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_SS>);
+        else
+#endif
+        if (neox) go(gemv_q_kernel<TA, TB, false, false, true, 2, PM_FEAT_NEOX>);
         else if (p.xmode == 2 && hot_spec && !p.job[0].bias && !p.job[1].bias && !p.job[2].bias && !p.epi.v_rowmajor &&
                  p.job[0].role == 1 && p.job[1].role == 2 && p.job[2].role == 3 && !p.job[0].is_b && !p.job[1].is_b && p.job[2].is_b == (TA != TB ? 1 : 0) &&
                  !p.job[0].split && !p.job[0].resid && !p.job[1].resid && !p.job[2].resid) { if (p.epi.dyn) go(gemv_q_kernel<TA, TB, false, false, true, 2, 0, 2, 2>); else go(gemv_q_kernel<TA, TB, false, false, true, 2, 0, 2, 1>); }
@@ -110,7 +119,9 @@ int launch_types(const GemvP & p_in, bool pair, int grid, size_t lds, bool dbg, 
         else go(gemv_q_kernel<TA, TB, false, false, true>);
     } else {
         if (dbg) { if (ss) return -6; go(gemv_q_kernel<TA, TB, false, true, false, 1>); }     // (test hook: one pre-issued step - with two, the Q6_K form sat on the 128-VGPR cliff with a spilled register)
+#if PM_EXPERIMENTS
         else if (ss) go(gemv_q_kernel<TA, TB, false, false, false, 2, PM_FEAT_SS>);
+#endif
         else if (p.xmode == 1 && hot_spec && one_job && !p.job[0].bias && p.job[0].resid && !p.job[0].split && !p.job[0].is_b) go(gemv_q_kernel<TA, TB, false, false, false, 2, 0, 1, 1>);
         else if (p.xmode == 1 && xm_spec) go(gemv_q_kernel<TA, TB, false, false, false, 2, 0, 1>);
         else if (p.xmode == 2 && xm_spec) go(gemv_q_kernel<TA, TB, false, false, false, 2, 0, 2>);

@@ -1,5 +1,11 @@
 // pm355_kernels.h — internal launcher prototypes (host side) for the gfx950 kernels.
 #pragma once
+// PM_EXPERIMENTS: round 5's three measured-slower forms of the decode layer - producer-side sums of squares, attention in the tail of the QKV launch, the persistent
+// engine (decode_engine.hip) - are compiled ONLY into prima_cpp_amd/libprima_mi355_exp.so (build.py build_experiments(), -DPM_EXPERIMENTS=1), which their tests load.
+// The product library libprima_mi355.so (what prima.cpp links) carries none of them: the entry points answer PM355_E_UNSUPPORTED there.
+#ifndef PM_EXPERIMENTS
+#define PM_EXPERIMENTS 0
+#endif
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>

@@ -355,6 +355,7 @@ def test_qkv_epilogue_decode_form_matches_round2_form(E, oracle, monkeypatch):
     assert worst < 1e-3, worst
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("arch", [0, 1])
 def test_producer_side_sum_of_squares_decode_is_bit_identical(E, monkeypatch, arch):
     """PM355_SS=0 (every rms_norm prologue reduces its own row: the round-4 form) against the default (wo / ffn_down leave per-workgroup
@@ -387,6 +388,7 @@ def test_producer_side_sum_of_squares_decode_is_bit_identical(E, monkeypatch, ar
         assert np.array_equal(h0, h1) and np.array_equal(l0, l1), i
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("arch,n_tok", [(0, 90), (1, 70)])
 def test_persistent_decode_engine_matches_the_five_launch_path(E, oracle, monkeypatch, arch, n_tok):
     """Round 5: csrc/decode_engine.hip (opt-in, PM355_ENGINE=1) - every phase of every layer of a single-token step as ONE persistent launch, device-wide
@@ -429,6 +431,7 @@ def test_persistent_decode_engine_matches_the_five_launch_path(E, oracle, monkey
     assert worst < 1e-3, worst
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("arch", [0, 1])
 def test_attention_tail_decode_is_bit_identical(E, monkeypatch, arch):
     """Round 5: PM355_ATTN_TAIL=1 - the attention computed in the tail of the wq | wk | wv launch by the last workgroups of each

@@ -505,6 +505,7 @@ def test_fused_prologue_equals_separate_kernels_bitexact(P, t, K, norm):
     assert torch.equal(got, want), (got - want).abs().max()
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("t", [Q4_K, Q6_K, Q8_0])
 @pytest.mark.parametrize("K_in,E", [(4096, 4096), (28672, 8192), (1024, 768)])
 def test_producer_side_sum_of_squares_gives_the_same_q8_K_blocks(P, oracle, t, K_in, E):
@@ -967,6 +968,7 @@ def test_native_q8_0_cache_view_matmul_and_dequantizing_copy(P, oracle):
     assert np.array_equal(deq.cpu().numpy(), want)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("t", [Q4_K, Q6_K])
 @pytest.mark.parametrize("K,N", [(1024, 512), (8192, 8192), (4096, 1024), (5120, 2560)])
 def test_engine_matvec_phase_is_bit_identical_to_the_launch(P, t, K, N):
@@ -1001,6 +1003,7 @@ def test_engine_matvec_phase_is_bit_identical_to_the_launch(P, t, K, N):
     assert torch.equal(h, want_h), (h - want_h).abs().max()
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("t", [Q4_K, Q6_K])
 def test_engine_long_rows_continue_from_the_prefetched_steps(P, oracle, t):
     """ffn_down-sized rows (K = 28672: seven steps per row) do not fit a wave's prefetch slot: the first two or three steps of a wave's first row come out
@@ -1019,6 +1022,7 @@ def test_engine_long_rows_continue_from_the_prefetched_steps(P, oracle, t):
     assert torch.equal(got, want), (got - want).abs().max().item()
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("tv", [Q6_K, Q5_K, Q4_K])
 @pytest.mark.parametrize("mode", [0, 2])
 @pytest.mark.parametrize("n_past", [0, 5, 63, 64, 200])
@@ -1055,6 +1059,7 @@ def test_engine_qkv_and_attention_phases_equal_the_launches(P, mode, n_past, tv)
     assert torch.equal(a2, a1), (a2 - a1).abs().max()
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("shape", [(8192, 64, 8, 128), (4096, 32, 8, 128), (2048, 16, 4, 128), (1024, 16, 8, 64)])
 @pytest.mark.parametrize("tv", [Q6_K, Q4_K])
 @pytest.mark.parametrize("mode", [0, 2])
