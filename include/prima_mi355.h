@@ -81,6 +81,11 @@ PM355_API int    pm355_memcpy_d2h(void * dst, const void * src, size_t bytes, pm
 PM355_API int    pm355_host_is_pinned(const void * p);
 PM355_API int    pm355_memcpy_d2d(void * dst, const void * src, size_t bytes, pm355_stream_t stream);
 PM355_API int    pm355_memset(void * dst, int value, size_t bytes, pm355_stream_t stream);
+/* One launch that copies up to 16 byte ranges out of ONE device staging block to their destinations: the per-token graph inputs of llama_set_inputs
+ * (src/llama.cpp:17276-17420: token / embedding, positions, KQ mask row, output ids - four buffer set_tensor calls per token) travel as one pinned block + one
+ * hipMemcpyAsync + this, instead of four pageable copies of ~19 us each. */
+typedef struct pm355_scatter_seg { void * dst; uint32_t src_off; uint32_t bytes; } pm355_scatter_seg;
+PM355_API int    pm355_scatter_bytes(const void * src_dev, const pm355_scatter_seg * segs, int n_segs, pm355_stream_t stream);
 
 /* Asynchronous weight staging from host DRAM (upload.hip): pageable / mmap'd GGUF bytes -> ring of pinned chunks (filled by
  * `copy_threads` copier threads; -1 = PM355_UPLOAD_THREADS or 4) -> hipMemcpyAsync on a private stream -> (row-SoA types) repack into

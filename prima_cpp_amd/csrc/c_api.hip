@@ -200,6 +200,28 @@ int pm355_mul_mat_vec_fused_ss(const pm355_matvec_job * jobs, int njobs, int64_t
     HIP_TRY(hipGetLastError());
     return 0;
 }
+namespace {
+struct ScatterP { pm355_scatter_seg seg[16]; };
+__global__ __launch_bounds__(256) void scatter_bytes_kernel(const uint8_t * __restrict__ src, ScatterP p) {
+    const pm355_scatter_seg sg = p.seg[blockIdx.x];
+    const uint8_t * s_ = src + sg.src_off;
+    uint8_t * d_ = (uint8_t *) sg.dst;
+    if ((((uintptr_t) d_ | (uintptr_t) s_ | sg.bytes) & 3) == 0) {
+        for (uint32_t i = threadIdx.x; i < sg.bytes / 4; i += 256) ((uint32_t *) d_)[i] = ((const uint32_t *) s_)[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < sg.bytes; i += 256) d_[i] = s_[i];
+    }
+}
+} // namespace
+int pm355_scatter_bytes(const void * src_dev, const pm355_scatter_seg * segs, int n, pm355_stream_t st) {
+    if (!src_dev || !segs || n < 1 || n > 16) return fail(PM355_E_RANGE, "scatter_bytes: 1..16 segments");
+    ScatterP p = {};
+    for (int i = 0; i < n; ++i) { if (!segs[i].dst) return fail(PM355_E_SHAPE, "scatter_bytes: null destination"); p.seg[i] = segs[i]; }
+    (void) hipGetLastError();
+    hipLaunchKernelGGL(scatter_bytes_kernel, dim3(n), dim3(256), 0, S(st), (const uint8_t *) src_dev, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 int pm355_q6k_tail_grouped(void) { return PM_Q6K_SCD ? 1 : 0; }
 int pm355_experiments_built(void) { return PM_EXPERIMENTS ? 1 : 0; }
 int pm355_mul_mat_vec_fused_grid(const pm355_matvec_job * jobs, int njobs, int64_t K) {

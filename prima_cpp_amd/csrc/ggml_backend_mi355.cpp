@@ -97,6 +97,51 @@ constexpr size_t UPLOAD_ASYNC_MIN = (size_t) 4 << 20;
 // their stream wait for an event recorded on the null stream, get_tensor and the other buffer functions run on the null stream
 // themselves, synchronize() drains it. Saves one host round trip (~10 us) per input tensor and token.
 std::atomic<uint64_t> g_null_epoch{0};             // bumped by every such upload; each backend remembers the epoch its stream is ordered after
+// Round 6: those uploads are BATCHED - set_tensor copies the bytes into a pinned staging block and returns (the caller's buffer is free); the batch leaves as ONE
+// hipMemcpyAsync into a device staging block + ONE scatter launch (pm355_scatter_bytes) on the null stream the next time anything could observe it: every
+// function of this file that touches device memory, orders a stream behind the null stream, or synchronizes calls small_flush() first. Four pageable copies
+// per token (token, positions, KQ mask row, output ids: ~77 us) become ~25 us. GGML_MI355_BATCH_UPLOADS=0 keeps the per-tensor copies.
+struct small_stage {
+    uint8_t * pinned[2] = {nullptr, nullptr}, * dev[2] = {nullptr, nullptr};
+    pm355_event_t done[2] = {nullptr, nullptr}; bool busy[2] = {false, false};
+    int slot = 0; size_t used = 0; int n = 0; pm355_scatter_seg seg[16];
+};
+constexpr size_t SMALL_CAP = (size_t) 256 << 10, SMALL_MAX = (size_t) 64 << 10;
+small_stage g_small[GGML_MI355_MAX_DEVICES];
+std::mutex g_small_mu;
+bool small_batching() { static const bool v = !plan_only() && !(getenv("GGML_MI355_BATCH_UPLOADS") && getenv("GGML_MI355_BATCH_UPLOADS")[0] == '0'); return v; }
+void small_flush_dev(int device) {
+    small_stage & s = g_small[device];
+    if (!s.n) return;
+    dsetdev(device);
+    MI355_CHECK(pm355_memcpy_h2d(s.dev[s.slot], s.pinned[s.slot], s.used, nullptr));
+    MI355_CHECK(pm355_scatter_bytes(s.dev[s.slot], s.seg, s.n, nullptr));
+    MI355_CHECK(pm355_event_record(s.done[s.slot], nullptr));
+    s.busy[s.slot] = true;
+    s.slot ^= 1; s.used = 0; s.n = 0;
+    g_null_epoch.fetch_add(1, std::memory_order_release);
+}
+void small_flush() {
+    if (!small_batching()) return;
+    std::lock_guard<std::mutex> lk(g_small_mu);
+    for (int d = 0; d < GGML_MI355_MAX_DEVICES; ++d) if (g_small[d].n) small_flush_dev(d);
+}
+void small_enqueue(int device, void * dst, const void * data, size_t size) {
+    std::lock_guard<std::mutex> lk(g_small_mu);
+    small_stage & s = g_small[device];
+    if (!s.pinned[0]) {
+        for (int i = 0; i < 2; ++i) {
+            s.pinned[i] = (uint8_t *) pm355_host_malloc(SMALL_CAP); s.dev[i] = (uint8_t *) pm355_malloc(SMALL_CAP); s.done[i] = pm355_event_create();
+            GGML_ASSERT(s.pinned[i] && s.dev[i] && s.done[i] && "small-upload staging");
+        }
+    }
+    size_t at = (s.used + 15) & ~(size_t) 15;
+    if (s.n == 16 || at + size > SMALL_CAP) { small_flush_dev(device); at = 0; }
+    if (s.busy[s.slot]) { MI355_CHECK(pm355_event_sync(s.done[s.slot])); s.busy[s.slot] = false; }      // (two batches ago: long done)
+    memcpy(s.pinned[s.slot] + at, data, size);
+    s.seg[s.n++] = {dst, (uint32_t) at, (uint32_t) size};
+    s.used = at + size;
+}
 void buf_drain(buf_ctx * c) {
     if (c->up_pending) { pm355_uploader_sync(c->up); c->up_pending = false; }
 }
@@ -149,6 +194,7 @@ struct backend_ctx {
 
 // make `c`'s stream wait (on the device) for everything enqueued on the null stream so far
 void order_after_null_stream(backend_ctx * c) {
+    small_flush();
     const uint64_t ep = g_null_epoch.load(std::memory_order_acquire);
     if (ep == c->null_epoch || plan_only()) return;
     if (!c->null_ev) { c->null_ev = pm355_event_create(); GGML_ASSERT(c->null_ev); }
@@ -169,6 +215,7 @@ const char * buf_get_name(ggml_backend_buffer_t b) { return ((buf_ctx *) b->cont
 bool buffer_is_mi355(ggml_backend_buffer_t b) { return b && b->iface.get_name == buf_get_name; }
 
 void buf_free(ggml_backend_buffer_t b) {
+    small_flush();
     buf_ctx * c = (buf_ctx *) b->context;
     dsetdev(c->device);
     if (c->up) {
@@ -185,6 +232,7 @@ void * buf_get_base(ggml_backend_buffer_t b) { return ((buf_ctx *) b->context)->
 void buf_init_tensor(ggml_backend_buffer_t, struct ggml_tensor *) {}
 
 void buf_memset_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, uint8_t v, size_t off, size_t size) {
+    small_flush();
     dsetdev(((buf_ctx *) b->context)->device);
     buf_drain((buf_ctx *) b->context);
     MI355_CHECK(dset((char *) t->data + off, v, size, nullptr));
@@ -202,6 +250,7 @@ void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void 
         GGML_ASSERT(off % rb == 0 && size % rb == 0 && "row-granular access to a row-SoA tensor");
         GGML_ASSERT(!t->view_src && "row-SoA tensors are addressed per allocated tensor, not through views");
     }
+    if (size >= UPLOAD_ASYNC_MIN) small_flush();
     if (size >= UPLOAD_ASYNC_MIN && !plan_only() && !env_on("GGML_MI355_SYNC_UPLOAD")) {
         // weights: pinned ring + copier threads + private stream, returns once the bytes have left `data`
         if (!c->up) {
@@ -217,6 +266,12 @@ void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void 
         return;
     }
     buf_drain(c);
+    if (!soa && small_batching() && size <= SMALL_MAX && !env_on("GGML_MI355_SYNC_UPLOAD")) {
+        // per-token graph inputs: into the pinned staging block (the caller's bytes are consumed here), on their way with the next flush
+        small_enqueue(c->device, (char *) t->data + off, data, size);
+        return;
+    }
+    small_flush();
     if (!soa && !plan_only() && size <= ((size_t) 1 << 20) && !env_on("GGML_MI355_SYNC_UPLOAD")) {
         // per-token graph inputs: enqueued on the null stream, the compute stream is ordered behind them on the device. The source bytes
         // have left `data` when hipMemcpyAsync returns ONLY for pageable memory (the runtime stages it); a page-locked source - e.g. a
@@ -239,6 +294,7 @@ void buf_set_tensor(ggml_backend_buffer_t b, struct ggml_tensor * t, const void 
 }
 void buf_get_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * t, void * data, size_t off, size_t size) {
     scoped_ns tm(g_ht.ns_get); ++g_ht.n_get;
+    small_flush();
     dsetdev(((buf_ctx *) b->context)->device);
     buf_drain((buf_ctx *) b->context);
     if (is_soa_tensor(t)) {
@@ -259,6 +315,7 @@ size_t hbm_bytes(const struct ggml_tensor * t) {
     return ggml_nbytes(t);
 }
 bool buf_cpy_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    small_flush();
     if (!buffer_is_mi355(src->buffer)) return false;                 // ggml falls back to get + set through the host
     buf_ctx * sc = (buf_ctx *) src->buffer->context, * dc = (buf_ctx *) b->context;
     if (sc->device != dc->device || src->type != dst->type || !ggml_is_contiguous(src) || !ggml_is_contiguous(dst)) return false;
@@ -269,6 +326,7 @@ bool buf_cpy_tensor(ggml_backend_buffer_t b, const struct ggml_tensor * src, str
     return true;
 }
 void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
+    small_flush();
     buf_ctx * c = (buf_ctx *) b->context;
     dsetdev(c->device);
     buf_drain(c);
