@@ -893,7 +893,9 @@ bool dev_supports_buft(ggml_backend_dev_t d, ggml_backend_buffer_type_t t) {
 }
 bool dev_offload_op(ggml_backend_dev_t, const struct ggml_tensor * op) {
     // weights left in host memory: worth shipping to the GPU only for batched work (cf. ggml-cuda.cu:3201-3208)
-    return op->op != GGML_OP_GET_ROWS && op->ne[1] >= 32;
+    // GGML_MI355_OFFLOAD=0: never (the parity tests' reference runs at -ngl 0 must be the host's arithmetic for prompt batches too, also on a machine with a GPU)
+    static const bool off = [] { const char * e = getenv("GGML_MI355_OFFLOAD"); return e && e[0] == '0'; }();
+    return !off && op->op != GGML_OP_GET_ROWS && op->ne[1] >= 32;
 }
 ggml_backend_event_t dev_event_new(ggml_backend_dev_t d) {
     dsetdev(((dev_ctx *) d->context)->device);

@@ -228,7 +228,7 @@ class CRing:
         elif transport == "torch":
             XF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p)
             WF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
-            self._pend = None
+            self._pend = []                      # exchanges enqueued and not yet waited for, oldest first (the two-deep decode loop keeps two)
             self._xf, self._wf = XF(self._cb_exchange), WF(self._cb_wait)      # (kept alive with the object)
             lib.pm355_ring_init_cb.argtypes = [C.c_int, C.c_int, XF, WF, C.c_void_p]
             self.h = lib.pm355_ring_init_cb(rank, world, self._xf, self._wf, None)
@@ -268,7 +268,7 @@ class CRing:
             if recv and n_recv:
                 hr = torch.empty(n_recv, dtype=torch.float32, device=dev if on_dev else "cpu")
                 ops.append(dist.P2POp(dist.irecv, hr, prv, self.group))
-            self._pend = (dist.batch_isend_irecv(ops) if ops else [], hs, hr, recv, n_recv, on_dev)
+            self._pend.append((dist.batch_isend_irecv(ops) if ops else [], hs, hr, recv, n_recv, on_dev))
             return 0
         except Exception as e:                         # never let an exception cross the C frames
             print(f"[ring transport] exchange failed: {e}", flush=True)
@@ -276,18 +276,16 @@ class CRing:
 
     def _cb_wait(self, user, stream):
         try:
-            if self._pend is None:
-                return 0
-            reqs, hs, hr, recv, n_recv, on_dev = self._pend
-            self._pend = None
-            for q in reqs:
-                q.wait()
-            if hr is not None:
-                if on_dev:
-                    torch.cuda.current_stream().synchronize()
-                cp = self.lib.pm355_memcpy_d2d if on_dev else self.lib.pm355_memcpy_h2d
-                if cp(recv, hr.data_ptr(), n_recv * 4, stream) or self.lib.pm355_sync(stream):
-                    return 1
+            while self._pend:                        # "everything enqueued so far", oldest first
+                reqs, hs, hr, recv, n_recv, on_dev = self._pend.pop(0)
+                for q in reqs:
+                    q.wait()
+                if hr is not None:
+                    if on_dev:
+                        torch.cuda.current_stream().synchronize()
+                    cp = self.lib.pm355_memcpy_d2d if on_dev else self.lib.pm355_memcpy_h2d
+                    if cp(recv, hr.data_ptr(), n_recv * 4, stream) or self.lib.pm355_sync(stream):
+                        return 1
             return 0
         except Exception as e:
             print(f"[ring transport] wait failed: {e}", flush=True)

@@ -558,6 +558,10 @@ def run_llama_driver(gguf_path, prompt, n_gen, ngl=0, n_ctx=64, threads=2, extra
         e["REFDRV_FORCE"] = ",".join(str(int(t)) for t in force)
     if chunk:
         e["REFDRV_CHUNK"] = str(chunk)
+    if ngl == 0:
+        # a reference run: the host's arithmetic for EVERY batch. With the plug-in linked in, ggml_backend_sched would ship the >= 32-token batches of a
+        # -ngl 0 run to the GPU (offload_op, as the CUDA plug-in does, ggml-cuda.cu:3201-3208) - round 6 found the 8200-token "CPU reference" doing that on the GPU box
+        e["GGML_MI355_OFFLOAD"] = "0"
     if env:
         e.update(env)
     cmd = [drv, "-m", gguf_path, "-c", str(n_ctx), "-t", str(threads), "-ngl", str(ngl)] + list(extra_args)

@@ -3,7 +3,7 @@
 # repo root:  bash tools/collect_profiles.sh r02
 # kernel-trace / stats passes and PMC passes are SEPARATE runs (never --pmc together with trace domains other than --kernel-trace).
 set -u
-R=${1:-r04}
+R=${1:-r06}
 OUT=$PWD/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -41,18 +41,21 @@ print("traffic/algorithmic", fr / alg)
 PY
 # (3) prefill GEMM: achieved TFLOP/s + MFMA / VALU / LDS utilisation and wait counters, one pass per counter (SKIP_PREFILL=1: leave it out)
 [ "${SKIP_PREFILL:-0}" = 1 ] || { echo "prefill GEMM (ffn_gate shape, T = 2048), tools/gemm_probe.py; counters: separate rocprofv3 --pmc <counter> --kernel-trace passes, 4 launches each";
-  echo "== default kernel selection (256 x 256 tiles + tail split); gate6 = the ffn_gate shape in Q6_K (Qwen2.5-72B file type)"
+  echo "== default kernel selection (mmq_pf.hip); gate6 = the ffn_gate shape in Q6_K (Qwen2.5-72B file type); then the second generation (PM355_GEMM_KERNEL=2) on the same box"
   for s in gate gate6 wo down wk; do python $OLDPWD/tools/gemm_probe.py 2048 $s 2>/dev/null; done
+  for s in gate gate6 wo down; do python $OLDPWD/tools/gemm_probe.py 512 $s 2>/dev/null; done
+  for s in gate gate6 wo down; do echo -n "kernel2: "; PM355_GEMM_KERNEL=2 python $OLDPWD/tools/gemm_probe.py 2048 $s 2>/dev/null; done
   python $OLDPWD/tools/torch_gemm_ref.py 2>/dev/null
-  for s in gate gate6; do echo "== counters, PM355_GEMM_KERNEL=2, $s shape";
-    for c in MfmaUtil VALUBusy LdsUtil GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS; do
-      rm -rf /tmp/pg_$c && PM355_GEMM_KERNEL=2 PMC_ITERS=3 timeout 120 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pg_$c -- python $OLDPWD/tools/gemm_probe.py 2048 $s > /dev/null 2>&1
+  echo "== the launches of the layer as the engine makes them (bench.py prefill.roofline measures the same): see BENCH / r06_bench_builder_run.json"
+  for s in gate gate6; do echo "== counters, default kernel (mmq_pf.hip gemm_pf_kernel), $s shape";
+    for c in MfmaUtil VALUBusy LdsUtil GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; do
+      rm -rf /tmp/pg_$c && PMC_ITERS=3 timeout 120 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pg_$c -- python $OLDPWD/tools/gemm_probe.py 2048 $s > /dev/null 2>&1
       python - <<PY
 import csv, glob
 try:
     f = glob.glob("/tmp/pg_$c/**/*counter_collection.csv", recursive=True)[0]; k = glob.glob("/tmp/pg_$c/**/*kernel_trace.csv", recursive=True)[0]
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "gemm_q_f16" in r["Kernel_Name"]]
-    t = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(k)) if "gemm_q_f16" in r["Kernel_Name"]]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "gemm_pf" in r["Kernel_Name"]]
+    t = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(k)) if "gemm_pf" in r["Kernel_Name"]]
     print(f"  $c: avg {sum(v) / len(v):.5g} over {len(v)} launches; kernel duration {sum(t) / len(t):.1f} us")
 except Exception as e:
     print("  $c: failed", e)
