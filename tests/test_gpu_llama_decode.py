@@ -159,14 +159,15 @@ def test_llama_decode_plugin_long_context_split_attention(gpu, fa, tmp_path):
         # (the reference's F16 V.p accumulator loses more over 768 cells than over a handful: 1.0e-3 observed for the two layers)
         _check("tiny_llama 700-token prompt -fa", toks, logits, path, prompt, n, 1024, cpu_args=["-fa"], nmse_floor=3e-3, err_floor=5e-2)
     else:
-        # A 700-token batch runs the MFMA prefill path: F16 activations x dequantized F16 weights, f32 accumulate - not the CPU's int8 x int8 over Q8_K
-        # activations. Round 6: the reference run is now the host's arithmetic for the PROMPT too (GGML_MI355_OFFLOAD=0; before, ggml_backend_sched shipped the
-        # -ngl 0 run's >= 32-token batches to this very plug-in), and the distance became visible: 1.6e-3 on this 256-wide model, where a row is ONE Q8_K block
-        # - it is the reference's activation quantization, not the kernels: the same prompt fed in 16-token chunks takes the plug-in's integer small-batch
-        # path (Q8_K activations, the CPU's arithmetic) and sits at the reference-against-itself tier.
-        _check("tiny_llama 700-token prompt", toks, logits, path, prompt, n, 1024, nmse_floor=5e-3, err_floor=8e-2)
+        # Round 6: the reference run is now the host's arithmetic for the PROMPT too (GGML_MI355_OFFLOAD=0; before, ggml_backend_sched shipped the -ngl 0 run's
+        # >= 32-token batches to this very plug-in, so both runs attended the SAME 700 cells). With honest cells the distance is 1.6e-3 on this toy model
+        # (256 wide, 64-dim heads, random weights: near-flat attention over 700 cells, every int8 re-quantization flip cascades) - and it is the SAME 1.6e-3 whether
+        # the prompt runs on the F16 prompt GEMMs or, fed in 16-token chunks, on the integer small-batch path (the CPU's arithmetic): it is not the prompt
+        # mat-muls, it is 700-cell attention at this size (rounding of the probabilities before / after normalisation; the `-fa` branch above has carried a
+        # 3e-3 floor for the same reason). At real shapes the same comparison gives 8e-5 over 8200 cells (profiles/r06_parity_long_context.txt).
+        _check("tiny_llama 700-token prompt", toks, logits, path, prompt, n, 1024, nmse_floor=3e-3, err_floor=8e-2)
         tq, lq, _ = run_llama_driver(path, prompt, n, ngl=99, n_ctx=1024, extra_args=args, chunk=16)
-        _check("tiny_llama 700-token prompt in 16-token chunks (integer small-batch path)", tq, lq, path, prompt, n, 1024, nmse_floor=1e-3, err_floor=5e-2)
+        _check("tiny_llama 700-token prompt in 16-token chunks (integer small-batch path)", tq, lq, path, prompt, n, 1024, nmse_floor=3e-3, err_floor=8e-2)
 
 
 def test_llama_decode_plugin_free_running_prefill_chunks(gpu, tmp_path):
