@@ -81,7 +81,7 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
     constexpr int BBUF = NT * 32 * 128;                       // one activation buffer: 32 NT tokens x 64 halfs
     constexpr int NSTREAM = PfT<TYPE>::NSTREAM, SLOT = NSTREAM * 1024, AW = pf_wave_bytes<TYPE>();   // per wave: two 128-k slots + two 512-byte header slots + EXTRA
     constexpr bool K45 = TYPE == PM_Q4_K || TYPE == PM_Q5_K, Q8 = TYPE == PM_Q8_0;
-    constexpr int NQ = NT / 2;                                // activation DMA instructions per wave and k-step
+    constexpr int NQ = NT >= 4 ? NT / 2 : 1;                  // activation DMA instructions per wave and k-step (NT = 2: 64 token rows = one per wave)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -311,7 +311,7 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
                 else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             }
-            if (NT == 8 || (j & 1) == 0) issue_B(4 * b + sq + 2, wr, NT == 8 ? j : j >> 1);
+            if (NT == 8 || (NT == 4 && (j & 1) == 0) || j == 0) issue_B(4 * b + sq + 2, wr, NT == 8 ? j : NT == 4 ? j >> 1 : 0);
             // (Q8_0: the 64-k slot of step s is free once its last slice has been read - behind slice 1 - and takes step s + 2's blocks in slices 2 and 3)
             if (Q8) { if (j >= 2) issue_A(4 * b + sq + 2, sq & 1, j - 2); }
             else if ((sq == 0 || sq == 2) && j >= 1 && j - 1 < NSTREAM) issue_A(2 * b + 1 + (sq >> 1), sq == 0 ? 1 : 0, j - 1);
@@ -581,8 +581,8 @@ int pm_launch_gemm_pf_ex(const pm_gemm_pf_job * jobs, int njobs, const void * xh
     // 256-token tiles (a dequantized operand serves 8 MFMAs; 128-token tiles only where the batch has no more tokens). Few tiles - wo / ffn_down / wq | wk | wv
     // at the reference's default n_ubatch 512 (common/common.h:178) are 64-80 tiles for 256 CUs - are split along K: S slices per tile, the slice count that
     // minimises  rounds of workgroups x (super-blocks per slice + ~3 for prologue, slab traffic and the reducer's pass)
-    int nt = T <= 128 ? 4 : 8;
-    if (force_nt == 4 || force_nt == 8) nt = force_nt;
+    int nt = T <= 64 ? 2 : T <= 128 ? 4 : 8;
+    if (force_nt == 2 || force_nt == 4 || force_nt == 8) nt = force_nt;
     p.nt_t = (T + 32 * nt - 1) / (32 * nt);
     const long wgs = (long) tiles * p.nt_t;
     const int nb = (K + 255) / 256;
@@ -634,7 +634,7 @@ int pm_launch_gemm_pf_ex(const pm_gemm_pf_job * jobs, int njobs, const void * xh
         return 0;
     }
 #endif
-#define PF_GO(A, B) (nt == 8 ? go(gemm_pf_kernel<A, B, 8>, pf_lds_bytes<A, B, 8>()) : go(gemm_pf_kernel<A, B, 4>, pf_lds_bytes<A, B, 4>()))
+#define PF_GO(A, B) (nt == 8 ? go(gemm_pf_kernel<A, B, 8>, pf_lds_bytes<A, B, 8>()) : nt == 4 ? go(gemm_pf_kernel<A, B, 4>, pf_lds_bytes<A, B, 4>()) : go(gemm_pf_kernel<A, B, 2>, pf_lds_bytes<A, B, 2>()))
     if (ta == tb) { if (ta == PM_Q4_K) PF_GO(PM_Q4_K, PM_Q4_K); else if (ta == PM_Q5_K) PF_GO(PM_Q5_K, PM_Q5_K); else if (ta == PM_Q8_0) PF_GO(PM_Q8_0, PM_Q8_0); else PF_GO(PM_Q6_K, PM_Q6_K); }
     else if (ta == PM_Q8_0 || tb == PM_Q8_0) return -1;      // (Q8_0 only as a launch of its own: ffn_down of the files whose n_ff is no multiple of 256)
     else if (ta == PM_Q4_K && tb == PM_Q5_K) PF_GO(PM_Q4_K, PM_Q5_K);
