@@ -208,6 +208,10 @@ PM355_API int pm355_mul_mat_q_small_check(int type, int64_t K, int64_t N, int64_
  * one launch per 32 tokens, n_tokens <= 64, xq = rows quantized by pm355_quantize_q8_K; y[j]: [n_tokens][N[j]]; bias[j] may be NULL (bias may be NULL). */
 PM355_API int pm355_mul_mat_q_small_multi(int type, int njobs, const void * const * W, const int64_t * N, float * const * y,
                                           const float * const * bias, const void * xq, int64_t K, int64_t n_tokens, pm355_stream_t stream);
+/* The same with the LAST job of another K-quant type - wq | wk (Q4_K) and wv (Q6_K: n_tokens <= 32; Q5_K: <= 16), the layer composition of the Q4_K_M files
+ * (llama_tensor_get_type, src/llama.cpp:19447) - as ONE grid whose workgroups are divided by weight bytes. PM355_E_UNSUPPORTED: launch the jobs separately. */
+PM355_API int pm355_mul_mat_q_small_mixed(const int * types, int njobs, const void * const * W, const int64_t * N, float * const * y,
+                                          const float * const * bias, const void * xq, int64_t K, int64_t n_tokens, pm355_stream_t stream);
 /* test hook: additionally writes, per (row, unit), the exact int32 pair {sum scale*q_w*q_a, sum min*bsum} */
 PM355_API int pm355_mul_mat_vec_q_dbg(int type, const void * W, int64_t K, int64_t N, const void * xq, float * y,
                                       int32_t * int_partials, int64_t * units_per_row, pm355_stream_t stream);
@@ -464,6 +468,9 @@ PM355_API int pm355_model_decode_seq(pm355_model * m, int seq, const int32_t * d
                                      float * d_x_out, float * d_logits, int32_t * d_argmax, pm355_stream_t stream);
 PM355_API int pm355_model_n_embd(const pm355_model * m);
 PM355_API int pm355_model_n_seq(const pm355_model * m);          /* KV slabs the window was finalized for (pm355_model_finalize_seqs) */
+/* Largest batch the library routes to the integer small-batch mat-mul (pm355_mul_mat_q_small: the CPU backend's Q8_K arithmetic, ggml/src/ggml.c:12377); larger
+ * batches take the F16 prompt GEMM (pm355_mul_mat_q_mfma). 32 unless PM355_MMQ_MAX_TOKENS = 16 .. 64 says otherwise. */
+PM355_API int pm355_small_batch_max_tokens(void);
 /* Device-resident greedy loop (needs HAS_EMBD|HAS_HEAD and the whole model in one window): starting from the token
  * in d_tokens_io[0] at position pos0, generate n_steps tokens; step i reads d_tokens_io[i], writes d_tokens_io[i+1].
  * One captured hipGraph per step, replayed; no host synchronisation inside. */

@@ -305,6 +305,20 @@ int pm355_mul_mat_q_small_multi(int type, int njobs, const void * const * W, con
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_mul_mat_q_small_mixed(const int * types, int njobs, const void * const * W, const int64_t * N, float * const * y, const float * const * bias,
+                                const void * xq, int64_t K, int64_t n_tokens, pm355_stream_t st) {
+    (void) hipGetLastError();
+    if (njobs < 2 || njobs > 3 || !types || !W || !N || !y || !xq) return fail(PM355_E_RANGE, "mul_mat_q_small_mixed: 2..3 jobs, pre-quantized activations");
+    int n32[3];
+    for (int j = 0; j < njobs; ++j) n32[j] = (int) N[j];
+    for (int j = 1; j < njobs - 1; ++j) if (types[j] != types[0]) return fail(PM355_E_UNSUPPORTED, "mul_mat_q_small_mixed: only the LAST job may be of another type");
+    const int na = njobs - 1;
+    const int rc = pm_launch_mmq_i8_dual(types[0], na, W, n32, y, bias, types[na], W[na], n32[na], y[na], bias ? bias[na] : nullptr, xq, (int) K, (int) n_tokens, 0, S(st));
+    if (rc == -5) return fail(PM355_E_UNSUPPORTED, "mul_mat_q_small_mixed: Q4_K jobs + one Q6_K (n_tokens <= 32) / Q5_K (<= 16) job, K % 256 == 0 required");
+    if (rc) return fail(PM355_E_HIP, "mul_mat_q_small_mixed: scratch allocation");
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 int pm355_mul_mat_q_small_check(int type, int64_t K, int64_t N, int64_t n_tokens) {
     return pm_mmq_i8_check(type, (int) K, (int) N, (int) n_tokens) == 0 ? 0 : PM355_E_UNSUPPORTED;
 }

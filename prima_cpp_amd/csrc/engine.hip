@@ -275,9 +275,14 @@ void layer_release(pm355_model * m, int il, hipStream_t st) {
 // quantize `src` [T][K] into the activation format(s) the given weights need; returns pointers
 struct ActQ { const void * k = nullptr; const void * z = nullptr; bool tab = false; };   // tab: the small-batch mat-mul's activation tables were written too
 const int MMQ_MIN_TOKENS = 3;                           // (3 columns cost the multi-column mat-vec two passes: 57 vs 39 us on the ffn shape)
-// largest batch on the integer matrix cores (mmq_i8.hip: the CPU's Q8_K arithmetic, one weight pass per 32 tokens); beyond it the F16 GEMMs (mmq.hip).
-// PM355_MMQ_MAX_TOKENS = 16 .. 64 moves the crossover (measurement: profiles/r05_small_batch_crossover.txt; 64 stays - the F16 path is another parity tier)
-const int MMQ_MAX_TOKENS = [] { const char * e = getenv("PM355_MMQ_MAX_TOKENS"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 64 ? v : 64; }();
+// largest batch on the integer matrix cores (mmq_i8.hip: the CPU's Q8_K arithmetic, one weight pass per 32 tokens); beyond it the F16 GEMMs (mmq_pf.hip).
+// Round 6: 32 (was 64) - with 64-token tiles the prompt GEMM takes 33..64 tokens through a 70B layer in 304-314 us against 378-447 for two passes of the
+// integer kernel (profiles/r06_small_batch.txt; round 5's 256-token tiles: 3 x slower, profiles/r05_small_batch_crossover.txt). PM355_MMQ_MAX_TOKENS = 16 .. 64
+// moves the crossover (the F16 path is the prompt's parity tier: activations not re-quantized)
+const int MMQ_MAX_TOKENS = [] { const char * e = getenv("PM355_MMQ_MAX_TOKENS"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= 64 ? v : 32; }();
+// small batches from this size on attend through the prompt path's matrix-core kernel (attn_prefill.hip: one workgroup per head, the same rounding points);
+// below it one workgroup per (head, token) (attn_cached.hip). 70B layer at 16 / 24 / 32 tokens: 190.1 / 219.1 / 229.9 -> 188.9 / 214.0 / 217.0 us
+const int SMALL_ATTN_MFMA_MIN = [] { const char * e = getenv("PM355_SMALL_ATTN_MFMA_MIN"); return e ? atoi(e) : 16; }();
 const int MMQ_MULTI_MIN_TOKENS = 2;       // the fused wq | wk | wv and ffn_gate | ffn_up launches already win at 2 tokens (3 / 4 mat-vec launches otherwise)
 // the table output of the Q8_K quantizers, when this batch size takes the small-batch mat-mul (mmq_i8.hip)
 pm_q8k_tables mmq_tables(const pm355_model * m, int K, int T, hipStream_t st) {
@@ -743,6 +748,11 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         if (small && T <= MMQ_MAX_TOKENS && !m->no_multi && wq_.type == wk_.type) {
             if (wv_.type == wq_.type) {
                 if (multi({&wq_, &wk_, &wv_}, {m->q, m->k, m->v}, {bq_, bk_, bv_}) == 0) qkv_done = true;
+            } else if ([&] {        // wv of another K-quant type (Q6_K / Q5_K in the Q4_K_M files): the same grid, its own workgroups (mmq_i8_dual_kernel)
+                           const void * W[2] = {wq_.d, wk_.d}; const int N[2] = {(int) wq_.N, (int) wk_.N}; float * Y[2] = {m->q, m->k}; const float * B[2] = {bq_, bk_};
+                           return wv_.K == wq_.K && pm_launch_mmq_i8_dual(wq_.type, 2, W, N, Y, B, wv_.type, wv_.d, (int) wv_.N, m->v, bv_, a.k, (int) wq_.K, T, (prepped || a.tab) ? 1 : 0, st) == 0;
+                       }()) {
+                qkv_done = true;
             } else if (multi({&wq_, &wk_}, {m->q, m->k}, {bq_, bk_}) == 0) {
                 prepped = true; qkv_done = true;
                 rc |= matmul_small(m, wv_, a, T, m->v, bv_, nullptr, prepped, st);
@@ -766,6 +776,8 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
                                 (const float *) m->rope_freqs.d, T, H, Hkv, dh, hp.n_ctx, m->rope, st, 1);
         // (a shape attn_cached refuses - head_dim other than 64 / 128 / 256, scores beyond 150 KiB of LDS - falls back to attn_decode, which rounds q to
         //  F16 itself: the pre-rounded rows give it the same bits as raw ones, tests/test_gpu_ops.py::test_small_batch_attention_fallback_...)
+        // (from SMALL_ATTN_MFMA_MIN tokens on: the prompt path's matrix-core kernel - 12 us per layer at 32 tokens against 26 for 2048 small workgroups)
+        if (!(T >= SMALL_ATTN_MFMA_MIN && pm_launch_attn_prefill(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st) == 0))
         if (pm_launch_attn_cached(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride, m->att, H, Hkv, dh, hp.n_ctx, kq_scale, st, nullptr, nullptr, 0, 0, 0, T) &&
             pm_launch_attn_decode(m->q, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride, m->att, T, H, Hkv, dh, hp.n_ctx, kq_scale, st))
             return seterr(m, PM355_E_RANGE, "decode: n_ctx too large for the decode-attention kernel");
@@ -1081,6 +1093,7 @@ int pm355_model_decode_seq(pm355_model * m, int seq, const int32_t * d_tokens, c
 }
 int pm355_model_n_embd(const pm355_model * m) { return m ? m->hp.n_embd : 0; }
 int pm355_model_n_seq(const pm355_model * m) { return m ? m->n_seq : 0; }
+int pm355_small_batch_max_tokens(void) { return MMQ_MAX_TOKENS; }
 
 // head_first != 0 (ring rank 0): d_x_in is the LAST rank's activation; apply the head to it (-> d_argmax / d_logits),
 // then embed the token found at d_token (which may be d_argmax itself) and run the window -> d_x_out.

@@ -543,10 +543,11 @@ bool compute_node(backend_ctx * c, struct ggml_tensor * op) {
             if (mul_mat_quant_ok(op)) {
                 // one fused launch per activation column: f32 -> vec_dot_type in the kernel prologue, then the mat-vec
                 const int64_t K = a->ne[0], N = a->ne[1], ncols = b->ne[1];
-                // 4..64 columns (parallel sequences, speculative batches, short prompts): one pass over the weights per 32 columns on the integer
+                // 3..32 columns (parallel sequences, speculative batches, short prompts; pm355_small_batch_max_tokens): one pass over the weights on the integer
                 // matrix cores; GGML_MI355_NO_MMQ_I8=1 restores the paths around it (one mat-vec per column / F16 GEMM from 16)
                 static const bool no_small = [] { const char * e = getenv("GGML_MI355_NO_MMQ_I8"); return e && e[0] == '1'; }();
-                if (!no_small && ncols >= 3 && ncols <= 64 && pm355_mul_mat_q_small_check((int) a->type, K, N, ncols) == 0) {
+                static const int small_max = pm355_small_batch_max_tokens();
+                if (!no_small && ncols >= 3 && ncols <= small_max && pm355_mul_mat_q_small_check((int) a->type, K, N, ncols) == 0) {
                     MI355_CHECK(pm355_mul_mat_q_small((int) a->type, a->data, K, N, nullptr, (const float *) b->data, ncols, (float *) op->data, nullptr, nullptr, st));
                     return true;
                 }

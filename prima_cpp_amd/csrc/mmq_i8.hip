@@ -75,18 +75,21 @@ __device__ __forceinline__ i32x16 mfma_i8x32(u32x4 a, u32x4 b, i32x16 c) {
 
 // where the loader lanes of a wave point: lane (rr = lane / 8, c = lane % 8) fetches 16-byte chunk c of rows rr, rr + 8, rr + 16, rr + 24
 template <bool MJ> struct Rows;
+// lm: all ones, or 0 for a look-ahead request past the wave's last step (the step code has no branches - the compiler's vmcnt bookkeeping stays exact - so
+// the request is issued anyway): every lane then asks for the same few addresses at the start of a row instead of re-loading the last tile (round 6: that
+// re-load was a third of wo's L2 -> CU traffic - two real tiles per wave and one for nothing)
 template <> struct Rows<false> {          // one matrix: wave-uniform base + 32-bit lane offsets
-    const uint8_t * base; uint32_t stride, off_d; int lim /*last valid row of the group, relative*/, rr, rh;
-    __device__ __forceinline__ const uint8_t * at(int n, uint32_t x) const { return base + ((uint32_t) min(rr + 8 * n, lim) * stride + x); }
-    __device__ __forceinline__ const uint8_t * at_h(uint32_t x) const { return base + ((uint32_t) min(rh, lim) * stride + x); }
-    __device__ __forceinline__ const uint8_t * at_d(uint32_t x) const { return base + (off_d + x); }
-    __device__ __forceinline__ const uint8_t * at_row(int row, uint32_t x) const { return base + ((uint32_t) min(row, lim) * stride + x); }   // any row of the group
+    const uint8_t * base; uint32_t stride, off_d, lm; int lim /*last valid row of the group, relative*/, rr, rh;
+    __device__ __forceinline__ const uint8_t * at(int n, uint32_t x) const { return base + (((uint32_t) min(rr + 8 * n, lim) * stride + x) & lm); }
+    __device__ __forceinline__ const uint8_t * at_h(uint32_t x) const { return base + (((uint32_t) min(rh, lim) * stride + x) & lm); }
+    __device__ __forceinline__ const uint8_t * at_d(uint32_t x) const { return base + ((off_d + x) & lm); }
+    __device__ __forceinline__ const uint8_t * at_row(int row, uint32_t x) const { return base + (((uint32_t) min(row, lim) * stride + x) & lm); }   // any row of the group
 };
 template <> struct Rows<true> {           // several matrices: a lane's rows may sit in different allocations -> 64-bit row pointers per lane
-    const uint8_t * rp[4], * rph, * rpd;
-    __device__ __forceinline__ const uint8_t * at(int n, uint32_t x) const { return rp[n] + x; }
-    __device__ __forceinline__ const uint8_t * at_h(uint32_t x) const { return rph + x; }
-    __device__ __forceinline__ const uint8_t * at_d(uint32_t x) const { return rpd + x; }
+    const uint8_t * rp[4], * rph, * rpd; uint32_t lm;
+    __device__ __forceinline__ const uint8_t * at(int n, uint32_t x) const { return rp[n] + (x & lm); }
+    __device__ __forceinline__ const uint8_t * at_h(uint32_t x) const { return rph + (x & lm); }
+    __device__ __forceinline__ const uint8_t * at_d(uint32_t x) const { return rpd + (x & lm); }
     __device__ __forceinline__ const uint8_t * at_row(int, uint32_t) const { return nullptr; }     // (native-layout types are single-job only)
 };
 
@@ -390,17 +393,16 @@ template <> struct MT<PM_Q8_0> {
 };
 
 // ABL (measurement only, PM355_MMQ_ABL): 1 = no activation loads in the loop, 2 = no weight loads in the loop, 4 = no MFMA / VALU work
-template <int TYPE, int NV, int ABL = 0, bool MJ = false>      // NV result registers per lane in use: 4 (<= 8 tokens), 8 (<= 16), 16 (<= 32)
-__global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
+// the work of workgroup w of G on the launch p (its own grid, or one part of a two-part launch)
+template <int TYPE, int NV, int ABL, bool MJ>                   // NV result registers per lane in use: 4 (<= 8 tokens), 8 (<= 16), 16 (<= 32)
+__device__ __forceinline__ void mmq_i8_body(const MmqP & p, const int w, const int G, uint8_t * smem) {
     typedef MT<TYPE> M;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (a scalar: the K slice, the loop counters and the buffer loads' scalar offsets derive from it)
     constexpr bool Q80 = TYPE == PM_Q8_0;                         // 32-value blocks: "super-block" = 4 blocks, no scale table in LDS (scales travel with the operands)
     const int nsb = Q80 ? (p.K + 127) / 128 : p.K / 256, npairs = (nsb + 1) >> 1;
     const int nbw = Q80 ? p.K / 32 : nsb;                         // what the tile loader counts in: blocks of the row
     float * dTl = (float *) smem;                                 // activation scales [nsb + 1][32] (0 for token slots >= T; last row all 0)
     uint8_t * stage = smem + (Q80 ? 0 : (size_t) (nsb + 1) * 128);   // NWAVE x WAVE_LDS; afterwards the 32 KB reduction buffer
-    const int G = (int) gridDim.x, w = (int) blockIdx.x;
     const int r0 = (int) ((long) p.N * w / G), r1 = (int) ((long) p.N * (w + 1) / G);      // (MJ: virtual rows over all jobs)
     const int nrg = (r1 - r0 + 31) >> 5;
     const int RGB = 1 << p.rgb_log2, KS = NWAVE >> p.rgb_log2;
@@ -421,20 +423,24 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     xs.xo = act ? (uint32_t) ((32 * g + r + p.t_off) * 16) : 0x80000000u;
     xs.bo = Q80 ? (uint32_t) (16 * lane) : act ? (uint32_t) ((lane + p.t_off) * 16) : 0x80000000u;   // (Q8_0: lane l carries 16 bytes of the step's [8 blocks][32 slots] activation scales)
     Rows<MJ> rw;
+    // (round 6, measured and rejected: TWO weight tiles in flight per wave - a second register set, the steps taking the sets alternately. The forms with the
+    //  registers for it, Q4_K up to 8 tokens, went from 170 to 248 VGPRs and - with the look-ahead past the last step made cheap - from 36.7 to 38.5 us on
+    //  ffn_gate, 16.5 to 17.6 on wq, 160.5 to 165.7 us per 70B layer: the streaming part of a launch already runs at 6.3 TB/s, what a launch pays is its
+    //  fixed ~8 us - profiles/r06_small_batch.txt)
     typename M::B R;
     typename M::A A0 = {}, A1 = {};                              // (inactive token lanes keep these zeros)
     // a step's weight tile goes out in FOUR parts. Issued in one burst (13 x 1 KiB per wave, 100 KB per CU) the wave sat in the issue itself until the
     // CU's miss queues had taken the whole tile - and only then started on the tile it holds: load time and compute time added up
     // (ffn_down Q6_K, 8 tokens: 41 us stream + 19 us compute + 12 fixed = 70). One part in front of every quarter of the first super-block's
     // products keeps both busy.
-    auto issue_b_part = [&](int pr, int n) __attribute__((always_inline)) {
+    auto issue_b_part = [&](typename M::B & R, int pr, int n) __attribute__((always_inline)) {
         M::issue_b_part(R, rw, nbw, pr, lane, n);
         if constexpr (TYPE == PM_Q6_K) if (n == 0) R.d = *(const PM_G uint16_t *) rw.at_d(pm_q6k_d_off((uint32_t) nsb, (uint32_t) min(2 * pr + g, nsb - 1)));   // cached: 32 steps share the line
         if constexpr (Q80) if (n == 0) M::issue_ds(R, xs, pr);
     };
-    auto issue_b = [&](int pr) __attribute__((always_inline)) {
+    auto issue_b = [&](typename M::B & R, int pr) __attribute__((always_inline)) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) issue_b_part(pr, n);
+        for (int n = 0; n < 4; ++n) issue_b_part(R, pr, n);
     };
     // the first weight tile and activation slice of a row group (in flight before anything waits)
     auto first = [&](int rg) __attribute__((always_inline)) {
@@ -453,15 +459,25 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
             for (int n = 0; n < 4; ++n) rw.rp[n] = rowptr(rbase + (lane >> 3) + 8 * n);
             rw.rph = rowptr(rbase + (lane >> 1)); rw.rpd = rowptr(rbase + r);
         }
-        issue_b(pb);
+        rw.lm = ~0u;
+        issue_b(R, pb);
         M::template issue_a<NV>(A0, xs, 2 * pb);
         if constexpr (ABL & 1) M::template issue_a<NV>(A1, xs, 2 * pb);
     };
     if (rgi < nrg && pb < pe) first(rgi);                         // ... including the staging of the scale table:
     if constexpr (!Q80) {
-        for (int i = tid; i < nsb * 32; i += BLOCK) {             // (slots >= T masked here: a quantizer that writes the table itself fills rows < T only)
-            const int t = i & 31;
-            dTl[i] = t < p.T ? *((const PM_G float *) p.dT + (i + p.t_off)) : 0.0f;
+        // (slots >= T masked here: a quantizer that writes the table itself fills rows < T only). Four loads per thread in flight: one load per trip made
+        // ffn_down's 112 super-blocks seven dependent round trips to L2 = 5 of the launch's ~18 fixed microseconds (empty-loop ablation 13.3 us at K = 8192,
+        // 18.4 at 28672, profiles/r06_small_batch.txt)
+        for (int i0 = tid; i0 < nsb * 32; i0 += 4 * BLOCK) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * BLOCK;
+                v[u] = (i < nsb * 32 && (i & 31) < p.T) ? *((const PM_G float *) p.dT + (i + p.t_off)) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * BLOCK; if (i < nsb * 32) dTl[i] = v[u]; }
         }
         if (tid < 32) dTl[nsb * 32 + tid] = 0.0f;
     }
@@ -471,20 +487,23 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
         f32x16 out = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (rg < nrg && pb < pe) {
             if (rg0 > 0) first(rg);
-            for (int pr = pb; pr < pe; pr += pstep) {
-                M::stash(R, L, lane);                                  // waits for this step's weights only
+            // one step: the tile in `Rc` -> LDS, its two super-blocks' products; on the way the requests for the wave's next tile (into the same registers)
+            // and for the next step's activations
+            auto step = [&](typename M::B & Rc, int pr) __attribute__((always_inline)) {
+                M::stash(Rc, L, lane);                                 // waits for this step's weights only
                 const int sb0 = 2 * pr, sb1 = Q80 ? 2 * pr + 1 : min(2 * pr + 1, nsb - 1);   // (Q8_0: blocks past the row read as zeros - no clamp, no double count)
                 // Issue order is the design (VMEM returns in order): the compiler's schedulers must not sink the prefetches towards
                 // their uses - no conditional code in the step (an odd tail super-block is computed on clamped data with the all-zero
                 // scale row) and scheduling barriers around the issue points.
                 if constexpr (!(ABL & 1)) M::template issue_a<NV>(A1, xs, sb1);
-                const int prn = min(pr + pstep, pe - pstep);             // the wave's next pair (clamped: the last step re-loads its own)
+                const int prn = min(pr + pstep, pe - pstep);             // the tile these registers take next
+                rw.lm = pr + pstep < pe ? ~0u : 0u;                      // (past the wave's last step: a request for nothing)
                 __builtin_amdgcn_sched_barrier(0);
                 // (the 32-token Q6_K form has no registers for it - 404 B of spills, 88 -> 205 us: its tile still goes out in one burst)
                 constexpr bool SPREAD = !(TYPE == PM_Q6_K && NV == 16) && !(ABL & 4);
-                if constexpr (!SPREAD && !(ABL & 2)) { issue_b(prn); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (!SPREAD && !(ABL & 2)) { issue_b(Rc, prn); __builtin_amdgcn_sched_barrier(0); }
                 auto part = [&](int n) __attribute__((always_inline)) {   // next tile, part n: unconditional, pinned between the quarters
-                    if constexpr (SPREAD && !(ABL & 2)) { __builtin_amdgcn_sched_barrier(0); issue_b_part(prn, n); __builtin_amdgcn_sched_barrier(0); }
+                    if constexpr (SPREAD && !(ABL & 2)) { __builtin_amdgcn_sched_barrier(0); issue_b_part(Rc, prn, n); __builtin_amdgcn_sched_barrier(0); }
                 };
                 if constexpr (!(ABL & 4)) M::template compute<NV>(A0, L, 0, r, g, dTl + sb0 * 32, p.t_off, out, part);
                 else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A0.q[s_])); asm volatile("" :: "v"(A0.bs)); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane))); }
@@ -494,7 +513,8 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
                 if constexpr (!(ABL & 4)) M::template compute<NV>(A1, L, 1, r, g, dTl + (2 * pr + 1 < nsb ? sb1 : nsb) * 32, p.t_off, out, [](int) {});
                 else { for (int s_ = 0; s_ < 8; ++s_) asm volatile("" :: "v"(A1.q[s_])); asm volatile("" :: "v"(A1.bs)); asm volatile("" :: "v"(*(const u32x4 *) (L + 16 * lane + 1024))); }
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            };
+            for (int pr = pb; pr < pe; pr += pstep) step(R, pr);
         }
         // fixed-order sum of the K slices through LDS, epilogue, store
         __syncthreads();
@@ -527,6 +547,23 @@ __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     }
 }
 
+template <int TYPE, int NV, int ABL = 0, bool MJ = false>
+__global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    mmq_i8_body<TYPE, NV, ABL, MJ>(p, (int) blockIdx.x, (int) gridDim.x, smem);
+}
+
+// Two launches that share the activations as ONE grid: workgroups [0, ga) are the multi-job launch `a` (wq | wk, type TA), the rest the single matrix `b` of
+// another type (wv: Q6_K or Q5_K in the Q4_K_M files, src/llama.cpp:19447 use_more_bits) - by itself a 7 MB matrix is a launch of ~14 us that 32 workgroups
+// spend mostly on their fixed costs (profiles/r06_small_batch.txt); here it rides in the shadow of the large part.
+struct MmqP2 { MmqP a, b; int ga; };
+template <int TA, int TB, int NV>
+__global__ __launch_bounds__(BLOCK, 2) void mmq_i8_dual_kernel(MmqP2 pp) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if ((int) blockIdx.x < pp.ga) mmq_i8_body<TA, NV, 0, true>(pp.a, (int) blockIdx.x, pp.ga, smem);
+    else mmq_i8_body<TB, NV, 0, false>(pp.b, (int) blockIdx.x - pp.ga, (int) gridDim.x - pp.ga, smem);
+}
+
 // prologue: per super-block, the activation group sums as F16 in A-operand order and the transposed activation scales
 __global__ __launch_bounds__(64) void mmq_prep_kernel(const uint8_t * xq, long xq_stride, int K, int T, uint8_t * bsT, float * dT, uint8_t * qT) {
     const int sb = (int) blockIdx.x, l = (int) threadIdx.x, t = l & 31, g = l >> 5;
@@ -550,6 +587,13 @@ __global__ __launch_bounds__(64) void mmq_prep_q80_kernel(const uint8_t * xq, lo
     const uint8_t * row = xq + (long) min(t, T - 1) * xq_stride;
     if (t < T) *(u32x4 *) (qT + (size_t) blk * 1024 + l * 16) = *(const u32x4 *) (row + blk * 32 + 16 * g);
     if (g == 0) dT[blk * 32 + t] = t < T ? h2f(((const uint16_t *) (row + K))[blk]) : 0.0f;
+}
+
+// row groups a workgroup works on side by side (the other waves split K): 5..7 groups take all 8 wave slots in ONE round (one fill / drain of the step
+// pipeline, no K split) instead of two rounds of 4 (ffn_gate | ffn_up of the 70B shape: 7 groups per workgroup); PM355_MMQ_RGB8_MIN=8: the round-5 rule
+int rgb_log2_for(int nrg) {
+    static const int rgb8_min = [] { const char * e = getenv("PM355_MMQ_RGB8_MIN"); const int v = e ? atoi(e) : 0; return v >= 3 && v <= 8 ? v : 5; }();
+    return nrg >= rgb8_min ? 3 : nrg >= 3 ? 2 : nrg == 2 ? 1 : 0;
 }
 
 // per-device scratch (grown on demand, like mmq.hip's f16 activation copy): quantized activations of an f32 call + the two tables
@@ -669,7 +713,7 @@ int launch_q80(const void * W, const void * xq, const float * x_f32, float * Y, 
         p.W = (const uint8_t *) W; p.row_stride = (long) pm_weight_row_stride(PM_Q8_0, K); p.N = N; p.K = K; p.T = tn;
         p.qT = tab; p.bsT = tab + qtab;                            // (bsT: here the f32 activation scales [blk][32])
         p.y = Y + (size_t) t0 * N; p.y_stride = N; p.bias = bias; p.resid = resid ? resid + (size_t) t0 * N : nullptr;
-        p.rgb_log2 = nrg >= 8 ? 3 : nrg >= 3 ? 2 : nrg == 2 ? 1 : 0;
+        p.rgb_log2 = rgb_log2_for(nrg);
         auto go = [&](auto kern) {
             pm_allow_big_lds((const void *) kern, 150 * 1024);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, st, p);
@@ -738,7 +782,7 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
         p.W = (const uint8_t *) W; p.row_stride = (long) pm_weight_row_stride(type, K); p.N = N; p.K = K; p.T = tn;
         p.xq = xc; p.xq_stride = (long) xrow; p.bsT = bsT; p.dT = dT; p.qT = sc->p + scr_q_off(K) + (size_t) (t0 / 32) * nsb * 8192;
         p.y = Y + (size_t) t0 * N; p.y_stride = N; p.bias = bias; p.resid = resid ? resid + (size_t) t0 * N : nullptr;
-        p.rgb_log2 = nrg >= 8 ? 3 : nrg >= 3 ? 2 : nrg == 2 ? 1 : 0;
+        p.rgb_log2 = rgb_log2_for(nrg);
         auto go = [&](auto kern) {
             pm_allow_big_lds((const void *) kern, 150 * 1024);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, st, p);
@@ -791,7 +835,7 @@ int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const in
         p.start[j] = j < njobs ? at : (int) total;
         if (j < njobs) at += N[j];
     }
-    p.rgb_log2 = nrg >= 8 ? 3 : nrg >= 3 ? 2 : nrg == 2 ? 1 : 0;
+    p.rgb_log2 = rgb_log2_for(nrg);
     const size_t lds = pm_mmq_i8_lds_bytes(type, K);
     auto go = [&](auto kern) {
         pm_allow_big_lds((const void *) kern, 150 * 1024);
@@ -806,5 +850,64 @@ int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const in
         if (type == PM_Q4_K) { if (tn <= 8) go(mmq_i8_kernel<PM_Q4_K, 4, 0, true>); else if (tn <= 16) go(mmq_i8_kernel<PM_Q4_K, 8, 0, true>); else go(mmq_i8_kernel<PM_Q4_K, 16, 0, true>); }
         else                 { if (tn <= 8) go(mmq_i8_kernel<PM_Q6_K, 4, 0, true>); else if (tn <= 16) go(mmq_i8_kernel<PM_Q6_K, 8, 0, true>); else go(mmq_i8_kernel<PM_Q6_K, 16, 0, true>); }
     }
+    return 0;
+}
+
+// wq | wk (na matrices of type ta = Q4_K, as in pm_launch_mmq_i8_multi) AND one matrix of another K-quant type (wv: Q6_K / Q5_K) over the same activations as
+// ONE grid (mmq_i8_dual_kernel): the device's workgroups are divided by weight bytes. T <= 32 (Q5_K: 16) - one pass; -5: not served, launch them separately.
+int pm_launch_mmq_i8_dual(int ta, int na, const void * const * Wa, const int * Na, float * const * Ya, const float * const * ba,
+                          int tb, const void * Wb, int Nb, float * Yb, const float * bb, const void * xq, int K, int T, int reuse_prep, hipStream_t st) {
+    static const bool off = [] { const char * e = getenv("PM355_MMQ_DUAL"); return e && e[0] == '0'; }();
+    if (off || ta != PM_Q4_K || (tb != PM_Q6_K && tb != PM_Q5_K) || na < 1 || na > 3 || T < 1 || T > (tb == PM_Q5_K ? 16 : 32)) return -5;
+    long total = 0;
+    for (int j = 0; j < na; ++j) { if (pm_mmq_i8_check(ta, K, Na[j], T)) return -5; total += Na[j]; }
+    if (pm_mmq_i8_check(tb, K, Nb, T)) return -5;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
+    const int nsb = K / 256;
+    const size_t xrow = pm_q8k_row_bytes(K);
+    const Scr * sc = scratch(dev, st, K, reuse_prep != 0);
+    if (!sc) return -3;
+    if (!reuse_prep) launch_prep(sc, xq, K, T, st);
+    const int cus = pm_device_cus();
+    const double bytes_a = (double) total * pm_weight_row_stride(ta, K), bytes_b = (double) Nb * pm_weight_row_stride(tb, K);
+    int gb = (int) (cus * bytes_b / (bytes_a + bytes_b) + 0.5);
+    gb = gb < 1 ? 1 : gb;
+    if (gb > (Nb + 31) / 32) gb = (Nb + 31) / 32;
+    int ga = cus - gb;
+    if (ga > (int) ((total + 31) / 32)) ga = (int) ((total + 31) / 32);
+    if (ga < 1) return -5;
+    MmqP2 pp = {};
+    {
+        MmqP & p = pp.a;
+        p.row_stride = (long) pm_weight_row_stride(ta, K); p.N = (int) total; p.K = K; p.T = T;
+        p.xq = (const uint8_t *) xq; p.xq_stride = (long) xrow; p.bsT = sc->p; p.dT = (const float *) (sc->p + (size_t) nsb * 1024); p.qT = sc->p + scr_q_off(K);
+        p.njobs = na;
+        int at = 0;
+        for (int j = 0; j < 3; ++j) {
+            const int jj = j < na ? j : na - 1;
+            p.Wj[j] = (const uint8_t *) Wa[jj]; p.yj[j] = Ya[jj]; p.bj[j] = ba ? ba[jj] : nullptr; p.nj[j] = Na[jj];
+            p.start[j] = j < na ? at : (int) total;
+            if (j < na) at += Na[j];
+        }
+        const int rows = (int) ((total + ga - 1) / ga);
+        p.rgb_log2 = rgb_log2_for((rows + 31) / 32);
+    }
+    {
+        MmqP & p = pp.b;
+        p.W = (const uint8_t *) Wb; p.row_stride = (long) pm_weight_row_stride(tb, K); p.N = Nb; p.K = K; p.T = T;
+        p.xq = (const uint8_t *) xq; p.xq_stride = (long) xrow; p.bsT = pp.a.bsT; p.dT = pp.a.dT; p.qT = pp.a.qT;
+        p.y = Yb; p.y_stride = Nb; p.bias = bb;
+        const int rows = (Nb + gb - 1) / gb;
+        p.rgb_log2 = rgb_log2_for((rows + 31) / 32);
+    }
+    pp.ga = ga;
+    const size_t la = pm_mmq_i8_lds_bytes(ta, K), lb = pm_mmq_i8_lds_bytes(tb, K), lds = la > lb ? la : lb;
+    auto go = [&](auto kern) {
+        pm_allow_big_lds((const void *) kern, 150 * 1024);
+        hipLaunchKernelGGL(kern, dim3(ga + gb), dim3(BLOCK), lds, st, pp);
+    };
+    if (tb == PM_Q6_K) { if (T <= 8) go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q6_K, 4>); else if (T <= 16) go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q6_K, 8>); else go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q6_K, 16>); }
+    else               { if (T <= 8) go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q5_K, 4>); else go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q5_K, 8>); }
     return 0;
 }

@@ -586,13 +586,16 @@ int pm_launch_gemm_pf_ex(const pm_gemm_pf_job * jobs, int njobs, const void * xh
     p.nt_t = (T + 32 * nt - 1) / (32 * nt);
     const long wgs = (long) tiles * p.nt_t;
     const int nb = (K + 255) / 256;
+    // (64-token tiles - 93-101 registers, 65 KB of LDS for Q4_K - with the K split sized for two workgroups per CU: measured 352 vs 312 us per 70B layer
+    //  at 33-64 tokens, profiles/r06_small_batch.txt; one workgroup per CU it stays)
+    const int slots_cu = cus;
     static const int force_s = [] { const char * e = getenv("PM355_GEMM_PF_SPLITK"); return e ? atoi(e) : 0; }();
     int S = 1;
     {
-        double best = (double) ((wgs + cus - 1) / cus) * nb;
+        double best = (double) ((wgs + slots_cu - 1) / slots_cu) * nb;
         for (int q = 2; q <= 8; ++q) {
             if (nb / q < 4 || wgs * q > 16384) break;
-            const double c = (double) ((wgs * q + cus - 1) / cus) * ((double) nb / q + 3.0);
+            const double c = (double) ((wgs * q + slots_cu - 1) / slots_cu) * ((double) nb / q + 3.0);
             if (c < best * 0.97) { best = c; S = q; }
         }
         if (force_s >= 1 && force_s <= 8 && nb / force_s >= 1) S = force_s;

@@ -301,6 +301,21 @@ def mul_mat_small_multi(ws, xq, n_tokens, biases=None):
     return ys
 
 
+def mul_mat_small_mixed(ws, xq, n_tokens, biases=None):
+    """wq | wk of one type and wv of another sharing the pre-quantized activations, one grid (mmq_i8.hip mmq_i8_dual_kernel) -> list of f32 [T, N_j]."""
+    import ctypes as C
+    lib = L.load()
+    n = len(ws)
+    lib.pm355_mul_mat_q_small_mixed.restype = C.c_int
+    lib.pm355_mul_mat_q_small_mixed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    ys = [torch.empty((n_tokens, w.N), dtype=torch.float32, device=w.data.device) for w in ws]
+    Tp = (C.c_int * n)(*[w.type for w in ws])
+    Wp = (C.c_void_p * n)(*[ptr(w.data) for w in ws]); Np = (C.c_int64 * n)(*[w.N for w in ws]); Yp = (C.c_void_p * n)(*[ptr(y) for y in ys])
+    Bp = (C.c_void_p * n)(*[ptr(b) for b in biases]) if biases else None
+    check(lib.pm355_mul_mat_q_small_mixed(Tp, n, Wp, Np, Yp, Bp, ptr(xq), ws[0].K, n_tokens, stream_ptr()), "mul_mat_q_small_mixed")
+    return ys
+
+
 def mul_mat_i8(w, x, bias=None, resid=None):
     """Prompt-sized batches on the integer matrix cores (mmq_big.hip): x f32 [T, K] -> Q8_K on device -> f32 [T, N]."""
     import ctypes as C

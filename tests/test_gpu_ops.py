@@ -290,6 +290,32 @@ def test_small_batch_matmul_multi_job_launch(P, oracle, t):
             assert np.allclose(got, one, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("tv", [Q6_K, Q5_K])
+def test_small_batch_matmul_wv_of_another_type_in_the_same_grid(P, oracle, tv):
+    """wq | wk (Q4_K) and wv (Q6_K / Q5_K: the Q4_K_M files' use_more_bits layers, src/llama.cpp:19447) as ONE grid - the device's workgroups divided by
+    weight bytes, every part with its own row split: each job equals its own single launch (same integers; the K split over waves may differ) and the oracle."""
+    rng = np.random.default_rng(330 + tv)
+    for K, Ns, T in ((1024, (300, 70, 75), 5), (8192, (1024, 128, 128), 8), (2048, (2100, 260, 300), 16), (4096, (515, 40, 33), 9)) + (((1024, (600, 64, 90), 32), (8192, (520, 130, 100), 24)) if tv == Q6_K else ()):
+        types = (Q4_K, Q4_K, tv)
+        blocks = [rand_blocks(t, N, K, rng) for t, N in zip(types, Ns)]
+        ws = [P.upload_weight(t, b, K, N) for t, b, N in zip(types, blocks, Ns)]
+        x = rng.normal(0, 1, (T, K)).astype(np.float32)
+        biases = [rng.normal(0, 1, N).astype(np.float32) for N in Ns]
+        xq = P.quantize_act(_dev(P, x), P.vec_dot_act_type(Q4_K))
+        ys = P.mul_mat_small_mixed(ws, xq, T, biases=[_dev(P, b) for b in biases])
+        for w, t, b, bias, y in zip(ws, types, blocks, biases, ys):
+            want = oracle.mul_mat(t, b, K, w.N, x) + bias[None]
+            got = y.cpu().numpy()
+            assert np.allclose(got, want, rtol=2e-5, atol=2e-5 * np.sqrt(K / 4096)), (K, w.N, np.abs(got - want).max())
+            one = P.mul_mat_small(w, xq=xq, n_tokens=T, bias=_dev(P, bias)).cpu().numpy()
+            assert np.allclose(got, one, rtol=1e-5, atol=1e-5)
+    # what the single grid does not serve is refused, not approximated
+    ws = [P.upload_weight(t, rand_blocks(t, 64, 1024, rng), 1024, 64) for t in (Q4_K, Q4_K, tv)]
+    xq = P.quantize_act(_dev(P, rng.normal(0, 1, (40, 1024)).astype(np.float32)), P.vec_dot_act_type(Q4_K))
+    with pytest.raises(Exception):
+        P.mul_mat_small_mixed(ws, xq, 40)
+
+
 def test_rms_norm_matches_oracle(P, oracle):
     rng = np.random.default_rng(26)
     for K, eps in ((4096, 1e-5), (8192, 1e-6)):
@@ -559,7 +585,7 @@ def test_fused_qkv_mixed_types_one_launch(P, oracle):
 
 
 @pytest.mark.parametrize("t", QUANT_TYPES)
-@pytest.mark.parametrize("K,N,T", [(256, 132, 17), (1024, 256, 128), (768, 64, 200), (2048, 516, 300), (1536, 260, 129), (6144, 64, 96)])
+@pytest.mark.parametrize("K,N,T", [(256, 132, 17), (1024, 256, 128), (768, 64, 200), (2048, 516, 300), (1536, 260, 129), (6144, 64, 96), (8192, 260, 33), (4096, 516, 64)])
 def test_mfma_prefill_gemm_vs_oracle(P, oracle, t, K, N, T):
     """MFMA batched GEMM (F16 tiles, f32 accumulate, activations not re-quantized) against the reference arithmetic
     (activations quantized to Q8_K/Q8_0): the reference's own backend tolerance is NMSE <= 5e-4

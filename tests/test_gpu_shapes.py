@@ -104,20 +104,30 @@ def test_model_shaped_layer_decode_and_prefill(E, oracle, name, monkeypatch):
     assert a < 5e-4 and b < 1e-3
     assert c < 5e-4 and e < 1e-3
 
-    # (3) 40-token batch (two passes, 32 + 8 tokens; up to 64 tokens take this path - speculative / parallel-sequence / short-prompt regime): mmq_i8.hip for the Q4_K / Q6_K matrices - the reference's integer
-    #     arithmetic on Q8_K activations, so it sits at mat-vec distance from the CPU backend, not at F16-GEMM distance
+    # (3) 24-token batch (up to 32 tokens take this path - speculative / parallel-sequence / short-prompt regime): mmq_i8.hip for the Q4_K / Q6_K matrices - the
+    #     reference's integer arithmetic on Q8_K activations, so it sits at mat-vec distance from the CPU backend, not at F16-GEMM distance
     w.kv_clear()
     hr = ref.model_new(d)
-    hid_s, lg_s, _ = w.decode(tokens=torch.from_numpy(toks[:40]).cuda(), pos0=0, want_argmax=True)
-    hs_ref, ls_ref = ref.model_eval(hr, d, tokens=toks[:40], pos0=0, n_threads=thr)
+    hid_s, lg_s, _ = w.decode(tokens=torch.from_numpy(toks[:24]).cuda(), pos0=0, want_argmax=True)
+    hs_ref, ls_ref = ref.model_eval(hr, d, tokens=toks[:24], pos0=0, n_threads=thr)
     ref.model_free(hr)
     f, g2 = _nmse(hid_s.cpu().numpy(), hs_ref), _nmse(lg_s.cpu().numpy(), ls_ref)
-    print(f"[{name}] small batch (40) vs reference CPU: hidden NMSE {f:.2e}, logits NMSE {g2:.2e}")
+    print(f"[{name}] small batch (24) vs reference CPU: hidden NMSE {f:.2e}, logits NMSE {g2:.2e}")
     # (what is left is the multi-token attention kernel's f32 softmax.V against the reference's F16-rounded probabilities: the distance
     #  is the same, 4.3e-6 / 1.3e-5, with PM355_NO_MMQ_I8=1, i.e. on the mat-vec path)
     # (the Qwen2.5-72B shape's Q8_0 ffn_down - K = 29568 is no multiple of 256 - is served by mmq_i8.hip's Q8_0 instantiation since round 4: Q8_0
     #  activations on the integer matrix cores, ggml_vec_dot_q8_0_q8_0's arithmetic, and the batch stays at the same distance)
     assert f < 2e-5 and g2 < 2e-4
+    # (3b) 40-token batch: since round 6 batches of 33..64 tokens take the prompt GEMM with 64-token tiles (mmq_pf.hip: 25 ms against 30-36 for two integer
+    #      passes on the 70B model) - F16 activations, the prompt's parity tier (the same bound as the 80-token prompt above)
+    w.kv_clear()
+    hr = ref.model_new(d)
+    hid_m, lg_m, _ = w.decode(tokens=torch.from_numpy(toks[:40]).cuda(), pos0=0, want_argmax=True)
+    hm_ref, lm_ref = ref.model_eval(hr, d, tokens=toks[:40], pos0=0, n_threads=thr)
+    ref.model_free(hr)
+    fm, gm = _nmse(hid_m.cpu().numpy(), hm_ref), _nmse(lg_m.cpu().numpy(), lm_ref)
+    print(f"[{name}] 40-token batch (prompt GEMM, 64-token tiles) vs reference CPU: hidden NMSE {fm:.2e}, logits NMSE {gm:.2e}")
+    assert fm < 5e-4 and gm < 1e-3
     # (4) 3-token step: wq | wk | wv and ffn_gate | ffn_up as one multi-job launch each (from 2 tokens), wo / down single launches (from 3)
     w.kv_clear()
     hr = ref.model_new(d)
