@@ -815,6 +815,19 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
             pm_launch_silu_mul_q8k(m->h, m->h2, m->aq_k, F, T, st, tb);
             a = ActQ(); a.k = m->aq_k; a.tab = tb.base != nullptr;
         } else {
+            // Q8_0 ffn_down (n_ff no multiple of 256) on the small-batch mat-mul: silu(gate) * up quantized straight into its activation tables - one launch
+            // instead of silu_mul, quantize_q80 and the mat-mul's table prologue
+            const Tensor & wd = L.t[PM355_T_FFN_DOWN];
+            void * tab = nullptr; size_t qb = 0, db = 0;
+            if (gu_done && T >= MMQ_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && !m->no_multi && pm_mmq_i8_check(wd.type, (int) wd.K, (int) wd.N, T) == 0 &&
+                pm_mmq_i8_q80_tables((int) wd.K, st, &tab, &qb, &db) == 0) {
+                pm_launch_silu_mul_q80_tab(m->h, m->h2, tab, qb, db, F, T, st);
+                float * x_nx = (il == m->hi - 1 && d_x_out) ? d_x_out : ((x_mid == bufs[0]) ? bufs[1] : bufs[0]);
+                if (pm_launch_mmq_i8(wd.type, wd.d, nullptr, nullptr, x_nx, (int) wd.K, (int) wd.N, T, nullptr, x_mid, 1, st)) return seterr(m, PM355_E_UNSUPPORTED, "decode: down mat-mul");
+                layer_release(m, il, st);
+                cur = x_nx;
+                continue;
+            }
             if (gu_done) pm_launch_silu_mul(m->h, m->h2, m->h, (long) T * F, st);
             a = quantize_for(m, m->h, F, T, dn, 1, st);
         }

@@ -150,6 +150,10 @@ template <> struct MT<PM_Q4_K> {
         f16x8 bm;
 #pragma unroll
         for (int sb = 0; sb < 8; ++sb) bm[sb] = (_Float16) (float) ((mn4[sb >> 2] >> (8 * (sb & 3))) & 0xFFu);
+        // (round 6, measured and rejected for 17..32 tokens, where the 16 v_mad_i32_i24 per sub-block are what the wave does: the scale INSIDE the weight operand -
+        //  sc = 8 hi + lo, q * lo and q * hi are bytes <= 105, four v_pk_mul_lo_u16 per operand, two MFMA chains that accumulate across the sub-blocks,
+        //  sum = lo-chain + 8 * hi-chain: the same integers, 8 instead of 16 vector instructions and 2 instead of 1 MFMA per sub-block. 52-100 B of spills,
+        //  ffn_gate 43.6 -> 49.8 us, 202.5 -> 229.8 us per 70B layer at 32 tokens: profiles/r06_small_batch.txt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             between(j);
@@ -539,6 +543,7 @@ __device__ __forceinline__ void mmq_i8_body(const MmqP & p, const int w, const i
                     const float * bj = j == 0 ? p.bj[0] : j == 1 ? p.bj[1] : p.bj[2];
                     float * yj = j == 0 ? p.yj[0] : j == 1 ? p.yj[1] : p.yj[2];
                     if (bj) s += ld_g(bj + lr);
+                    if (p.resid) s += ld_g(p.resid + (long) t * nj + lr);          // (one-job launches of this form: wo / ffn_down with their residual)
                     st_g(yj + (long) t * nj + lr, s);
                 }
             }
@@ -561,7 +566,7 @@ template <int TA, int TB, int NV>
 __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_dual_kernel(MmqP2 pp) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if ((int) blockIdx.x < pp.ga) mmq_i8_body<TA, NV, 0, true>(pp.a, (int) blockIdx.x, pp.ga, smem);
-    else mmq_i8_body<TB, NV, 0, false>(pp.b, (int) blockIdx.x - pp.ga, (int) gridDim.x - pp.ga, smem);
+    else mmq_i8_body<TB, NV, 0, TB == PM_Q6_K>(pp.b, (int) blockIdx.x - pp.ga, (int) gridDim.x - pp.ga, smem);   // (Q6_K: the one-job multi-job form - no spills at 16 tokens)
 }
 
 // prologue: per super-block, the activation group sums as F16 in A-operand order and the transposed activation scales
@@ -669,29 +674,34 @@ void launch_prep(const Scr * sc, const void * xq, int K, int T, hipStream_t st) 
 namespace {
 // Q8_0 weights x Q8_0 activations, passes of up to 16 tokens. xq: row-SoA Q8_0 rows (quantize.hip) or null and x_f32 is quantized first. Its tables
 // (operand-ordered values + f32 scales of both 32-slot halves, then a quantized copy of 64 f32 rows) are written by a prologue launch per call.
-int launch_q80(const void * W, const void * xq, const float * x_f32, float * Y, int K, int N, int T, const float * bias, const float * resid, hipStream_t st) {
+Scr * scratch80(int dev, hipStream_t st, size_t need) {
+    std::lock_guard<std::mutex> lk(g_scr_mu);
+    Scr * e = nullptr, * lru = &g_scr80[dev][0];
+    for (Scr & c : g_scr80[dev]) {
+        if (c.p && c.st == st) { e = &c; break; }
+        if (!c.p) { if (lru->p) lru = &c; } else if (lru->p && c.use < lru->use) lru = &c;
+    }
+    if (!e || e->bytes < need) {
+        if (!e) e = lru;
+        if (e->p) { (void) hipDeviceSynchronize(); (void) hipFree(e->p); e->p = nullptr; e->bytes = 0; }
+        if (hipMalloc((void **) &e->p, need) != hipSuccess) { e->p = nullptr; return nullptr; }
+        e->st = st; e->bytes = need;
+    }
+    e->use = ++g_tick;
+    return e;
+}
+size_t q80_need(int K) { return 2 * ((size_t) (K / 32) * 1024 + (size_t) (K / 32) * 128) + (size_t) 64 * pm_q80_row_bytes(K) + 512; }
+
+// reuse_prep: the tables of this (device, stream) already describe these activations (pm_launch_silu_mul_q80_tab wrote them): no quantizer, no prologue launch
+int launch_q80(const void * W, const void * xq, const float * x_f32, float * Y, int K, int N, int T, const float * bias, const float * resid, int reuse_prep, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
     const int nb = K / 32;
     const size_t xrow = pm_q80_row_bytes(K), qtab = (size_t) nb * 1024, dtab = (size_t) nb * 128;
-    const size_t need = 2 * (qtab + dtab) + (size_t) 64 * xrow + 512;
-    Scr * e = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_scr_mu);
-        Scr * lru = &g_scr80[dev][0];
-        for (Scr & c : g_scr80[dev]) {
-            if (c.p && c.st == st) { e = &c; break; }
-            if (!c.p) { if (lru->p) lru = &c; } else if (lru->p && c.use < lru->use) lru = &c;
-        }
-        if (!e || e->bytes < need) {
-            if (!e) e = lru;
-            if (e->p) { (void) hipDeviceSynchronize(); (void) hipFree(e->p); e->p = nullptr; e->bytes = 0; }
-            if (hipMalloc((void **) &e->p, need) != hipSuccess) { e->p = nullptr; return -3; }
-            e->st = st; e->bytes = need;
-        }
-        e->use = ++g_tick;
-    }
+    Scr * e = scratch80(dev, st, q80_need(K));
+    if (!e) return -3;
     uint8_t * base = e->p;
+    if (!reuse_prep) {
     if (!xq) {
         uint8_t * q = base + 2 * (qtab + dtab) + 256;
         pm_launch_quantize_q80(x_f32, q, K, T, st);
@@ -700,6 +710,7 @@ int launch_q80(const void * W, const void * xq, const float * x_f32, float * Y, 
     for (int t0 = 0, c = 0; t0 < T; t0 += 32, ++c)
         hipLaunchKernelGGL(mmq_prep_q80_kernel, dim3(nb), dim3(64), 0, st, (const uint8_t *) xq + (size_t) t0 * xrow, (long) xrow, K, T - t0 < 32 ? T - t0 : 32,
                            base + c * (qtab + dtab), (float *) (base + c * (qtab + dtab) + qtab));
+    }
     const int cus = pm_device_cus();
     const int grid = N / 32 >= cus ? cus : (N + 31) / 32;
     const int rows = (N + grid - 1) / grid, nrg = (rows + 31) / 32;
@@ -723,6 +734,17 @@ int launch_q80(const void * W, const void * xq, const float * x_f32, float * Y, 
     return 0;
 }
 }  // namespace
+
+// Q8_0 weights: where a producer (pm_launch_silu_mul_q80_tab) writes the activation tables of this (device, stream) for K; per 32-token pass qtab + dtab bytes
+int pm_mmq_i8_q80_tables(int K, hipStream_t st, void ** tab, size_t * qtab_bytes, size_t * dtab_bytes) {
+    if (K % 32 || K < 512) return -2;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
+    Scr * e = scratch80(dev, st, q80_need(K));
+    if (!e) return -3;
+    *tab = e->p; *qtab_bytes = (size_t) (K / 32) * 1024; *dtab_bytes = (size_t) (K / 32) * 128;
+    return 0;
+}
 
 // Where the tables for K live: pm_launch_quantize_q8k / pm_launch_rmsnorm_q8k write them as a second output (<= 64 rows), the mat-mul is
 // then launched with reuse_prep = 1 and no prologue launch at all.
@@ -755,7 +777,7 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
                      const float * bias, const float * resid, int reuse_prep, hipStream_t st) {
     const int rc = pm_mmq_i8_check(type, K, N, T);
     if (rc) return rc;
-    if (type == PM_Q8_0) return launch_q80(W, xq, x_f32, Y, K, N, T, bias, resid, st);      // (its tables are per call: reuse_prep does not apply)
+    if (type == PM_Q8_0) return launch_q80(W, xq, x_f32, Y, K, N, T, bias, resid, reuse_prep, st);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
     const int nsb = K / 256;
@@ -800,7 +822,13 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
         if (type == PM_Q4_K) { if (tn <= 8) go(mmq_i8_kernel<PM_Q4_K, 4>); else if (tn <= 16) go(mmq_i8_kernel<PM_Q4_K, 8>); else go(mmq_i8_kernel<PM_Q4_K, 16>); }
         else if (type == PM_Q5_K) { if (tn <= 8) go(mmq_i8_kernel<PM_Q5_K, 4>); else go(mmq_i8_kernel<PM_Q5_K, 8>); }
         else if (tn <= 8)    go(mmq_i8_kernel<PM_Q6_K, 4>);
-        else if (tn <= 16)   go(mmq_i8_kernel<PM_Q6_K, 8>);
+        else if (tn <= 16) {
+            // the 16-token Q6_K form with wave-uniform row addressing spills 44 B per lane; the one with per-lane row pointers (the multi-job form) does not
+            // (249 registers): a launch of ONE job in that form
+            p.njobs = 1; p.y_stride = N;
+            for (int j = 0; j < 3; ++j) { p.Wj[j] = p.W; p.yj[j] = p.y; p.bj[j] = p.bias; p.nj[j] = N; p.start[j] = j == 0 ? 0 : N; }
+            go(mmq_i8_kernel<PM_Q6_K, 8, 0, true>);
+        }
         else                 go(mmq_i8_kernel<PM_Q6_K, 16>);
     }
     return 0;
@@ -898,6 +926,8 @@ int pm_launch_mmq_i8_dual(int ta, int na, const void * const * Wa, const int * N
         p.W = (const uint8_t *) Wb; p.row_stride = (long) pm_weight_row_stride(tb, K); p.N = Nb; p.K = K; p.T = T;
         p.xq = (const uint8_t *) xq; p.xq_stride = (long) xrow; p.bsT = pp.a.bsT; p.dT = pp.a.dT; p.qT = pp.a.qT;
         p.y = Yb; p.y_stride = Nb; p.bias = bb;
+        p.njobs = 1;
+        for (int j = 0; j < 3; ++j) { p.Wj[j] = p.W; p.yj[j] = Yb; p.bj[j] = bb; p.nj[j] = Nb; p.start[j] = j == 0 ? 0 : Nb; }
         const int rows = (Nb + gb - 1) / gb;
         p.rgb_log2 = rgb_log2_for((rows + 31) / 32);
     }

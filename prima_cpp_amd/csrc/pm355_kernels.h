@@ -49,6 +49,9 @@ static inline bool pm_type_is_repacked(int type) { return type == 12 || type == 
 struct pm_q8k_tables { uint8_t * base = nullptr; size_t tab_bytes = 0; int nsb = 0; uint8_t * qbase = nullptr; };
 void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStream_t st, pm_q8k_tables tab = {});
 void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStream_t st);
+// silu(gate) * up -> Q8_0, written into the Q8_0 small-batch mat-mul's activation tables (pm_mmq_i8_q80_tables); then pm_launch_mmq_i8(PM_Q8_0, ..., reuse_prep = 1)
+void pm_launch_silu_mul_q80_tab(const float * gate, const float * up, void * tab, size_t qtab_bytes, size_t dtab_bytes, int K, int rows, hipStream_t st);
+int pm_mmq_i8_q80_tables(int K, hipStream_t st, void ** tab, size_t * qtab_bytes, size_t * dtab_bytes);
 // Q8_K rows of silu(gate) * up (the ffn_down activations of a small batch), no f32 product in HBM
 void pm_launch_silu_mul_q8k(const float * gate, const float * up, void * y, int K, int rows, hipStream_t st, pm_q8k_tables tab = {});
 void pm_launch_rmsnorm_q8k(const float * x, const float * w, float * ynorm, void * yq, int K, int rows, float eps, hipStream_t st, void * ynorm_f16 = nullptr,

@@ -136,6 +136,35 @@ __global__ __launch_bounds__(256) void quantize_q80_kernel(const float * __restr
     if ((i4 & 7) == 0) ((uint16_t *) (ro + K))[i4 >> 3] = f2h(d);
 }
 
+// silu(gate) * up fused with the Q8_0 quantization of the product, written STRAIGHT into the small-batch mat-mul's activation tables (mmq_i8.hip, Q8_0 weights:
+// per 32-token pass [blk][64 lanes][16 B] values in A-operand order + [blk][32] f32 scales) - the ffn_down activations of the files whose n_ff is no multiple of
+// 256 (Qwen2.5-72B: K = 29568 falls back to Q8_0, src/llama.cpp:19447). Replaces three launches (silu_mul, quantize_q80, the mat-mul's table prologue).
+// Rows T .. 32 * passes - 1 write scale 0 (their values are never loaded).
+__global__ __launch_bounds__(256) void silu_mul_q80_tab_kernel(const float * __restrict__ gate, const float * __restrict__ up, uint8_t * __restrict__ tab,
+                                                               int K, int rows, int rows_padded, size_t pass_bytes, size_t qtab_bytes) {
+    const long t = (long) blockIdx.x * 256 + threadIdx.x;        // one thread = 4 values, 8 lanes = one block
+    const long per_row = K / 4;
+    if (t >= (long) rows_padded * per_row) return;
+    const int row = (int) (t / per_row), i4 = (int) (t % per_row);
+    const int blk = i4 >> 3, sub = i4 & 7;
+    uint8_t * base = tab + (size_t) (row >> 5) * pass_bytes;
+    float * dslot = (float *) (base + qtab_bytes) + ((size_t) blk * 32 + (row & 31));
+    if (row >= rows) { if (sub == 0) *dslot = 0.0f; return; }
+    const float4 g = ((const float4 *) (gate + (size_t) row * K))[i4];
+    const float4 u = ((const float4 *) (up + (size_t) row * K))[i4];
+    const float v[4] = {g.x / (1.0f + expf(-g.x)) * u.x, g.y / (1.0f + expf(-g.y)) * u.y, g.z / (1.0f + expf(-g.z)) * u.z, g.w / (1.0f + expf(-g.w)) * u.w};
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    amax = group8_max(amax);
+    const float d  = amax / 127;
+    const float id = d ? 1.0f / d : 0.0f;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) packed |= (uint32_t) ((int) roundf(v[i] * id) & 0xFF) << (8 * i);
+    // lane (token slot row % 32, half g = sub / 4) of block blk holds bytes [16 g, 16 g + 16) of the block
+    *(uint32_t *) (base + (size_t) blk * 1024 + (size_t) (32 * (sub >> 2) + (row & 31)) * 16 + 4 * (sub & 3)) = packed;
+    if (sub == 0) *dslot = h2f(f2h(d));
+}
+
 // rms_norm (+ weight) fused with Q8_K quantization. One 256-thread workgroup per row.
 // Optionally also writes the normalised f32 row (ynorm != nullptr).
 // NWV waves per row: 4 for many rows (prompts: one small workgroup per row fills the chip), 16 for a handful of rows (decode batches of 2..64
@@ -211,6 +240,12 @@ void pm_launch_quantize_q8k(const float * x, void * y, int K, int rows, hipStrea
 void pm_launch_silu_mul_q8k(const float * gate, const float * up, void * y, int K, int rows, hipStream_t st, pm_q8k_tables tab) {
     const long waves = (long) rows * (K / PM_QK_K);
     hipLaunchKernelGGL(silu_mul_q8k_kernel, dim3((unsigned) ((waves + 3) / 4)), dim3(256), 0, st, gate, up, (uint8_t *) y, K, rows, pm_q8k_row_bytes(K), tab);
+}
+void pm_launch_silu_mul_q80_tab(const float * gate, const float * up, void * tab, size_t qtab_bytes, size_t dtab_bytes, int K, int rows, hipStream_t st) {
+    const int rows_padded = (rows + 31) / 32 * 32;
+    const long n = (long) rows_padded * (K / 4);
+    hipLaunchKernelGGL(silu_mul_q80_tab_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, gate, up, (uint8_t *) tab, K, rows, rows_padded,
+                       qtab_bytes + dtab_bytes, qtab_bytes);
 }
 void pm_launch_quantize_q80(const float * x, void * y, int K, int rows, hipStream_t st) {
     const long n = (long) rows * (K / 4);

@@ -6,10 +6,11 @@ import torch
 import prima_cpp_amd.engine as E
 
 Ts = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "33,40,48,64").split(",")]
-hp = dict(E.LLAMA3_70B)
+QWEN = os.environ.get("PROBE_MODEL") == "qwen"
+hp = dict(E.QWEN25_72B if QWEN else E.LLAMA3_70B)
 hp["n_layer"] = 16
 from bench import model_cfg
-_, mixture, _ = model_cfg("llama3-70b")
+_, mixture, _ = model_cfg("qwen2.5-72b" if QWEN else "llama3-70b")
 w = E.Window(hp, n_ctx=1024)
 w.fill_synthetic(mixture, seed=1)
 w.finalize(max_tokens=max(Ts))
