@@ -42,7 +42,7 @@ struct PfJob {
     const uint8_t * W; float * Y; _Float16 * Yh; const float * bias; const float * resid; const float * silu_gate;
     long row_stride, ldy; int type, N, tile0;      // tile0: this job's first row tile in the launch's numbering of row tiles
 };
-struct PfP { PfJob job[PF_MAX_JOBS]; int njobs, nt_n, nt_t; const _Float16 * Xh; int K, T; int grp, pair; int splitk; float * ws; unsigned * cnt; unsigned long long * trace; };
+struct PfP { PfJob job[PF_MAX_JOBS]; int njobs, nt_n, nt_t; const _Float16 * Xh; int K, T; int grp, pair; int splitk, full; float * ws; unsigned * cnt; unsigned long long * trace; };
 // Ablations (measurement builds only: -DPM_GEMM_ABLATE=1 adds instantiations of the Q4_K 256-token kernel, PM355_GEMM_EXP=<bits> picks one; results are WRONG when set):
 // 1 no activation DMA, 2 no weight DMA, 4 no vmcnt wait / barrier, 8 no B fragment reads, 16 no dequantization, 32 no MFMA, 64 no stores;
 // 128: s_memtime stamps of super-block 5's second k-step (waves 0 and 4 of workgroup 0), printed by the launcher: the phase timeline
@@ -77,7 +77,7 @@ template <int TYPE> constexpr int pf_wave_bytes() { return 2 * PfT<TYPE>::NSTREA
 // role: 0 plain; 1 / 2 = the gate / up half of a PAIR tile (waves 0-3 multiply ffn_gate's rows [n0, n0 + 128), waves 4-7 the same rows of ffn_up; the gate
 // accumulators cross over through LDS after the k loop and the up waves store silu(gate) * up: ffn_gate's result never travels to HBM)
 template <int TYPE, int NT, int EXP>
-__device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const int n0, const int t0, uint8_t * smem, const int role, const int ks, const int tile_id) {
+__device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const int n0, const int t0, uint8_t * smem, const int role, const int ks, const int S, const int tile_id) {
     constexpr int BBUF = NT * 32 * 128;                       // one activation buffer: 32 NT tokens x 64 halfs
     constexpr int NSTREAM = PfT<TYPE>::NSTREAM, SLOT = NSTREAM * 1024, AW = pf_wave_bytes<TYPE>();   // per wave: two 128-k slots + two 512-byte header slots + EXTRA
     constexpr bool K45 = TYPE == PM_Q4_K || TYPE == PM_Q5_K, Q8 = TYPE == PM_Q8_0;
@@ -267,7 +267,7 @@ __device__ __forceinline__ void pf_body(const PfP & p, const PfJob & jb, const i
     // ---- prologue: super-block 0's header, piece 0, k-steps 0 and 1
     uint32_t rd = 0, nx = BBUF, wr = 2 * BBUF;                 // ring: buffer of step s, s + 1, s + 2
     // split K: slice ks of S takes the super-blocks [b0, b1); all indices below stay absolute (slot parities, look-ahead clamps)
-    const int S = p.splitk, b0 = (int) ((long) ks * nb / S), b1 = (int) ((long) (ks + 1) * nb / S);
+    const int b0 = (int) ((long) ks * nb / S), b1 = (int) ((long) (ks + 1) * nb / S);
     issue_H(b0); if (TYPE == PM_Q6_K) issue_D(b0 >> 3); if (TYPE == PM_Q5_K) issue_QH(b0);
 #pragma unroll
     for (int st = 0; st < NSTREAM; ++st) { if (Q8) { issue_A(4 * b0, 0, st); issue_A(4 * b0 + 1, 1, st); } else issue_A(2 * b0, 0, st); }
@@ -479,7 +479,11 @@ template <int TA, int TB, int NT, int EXP = 0>
 __global__ __launch_bounds__(PF_NTHR) void gemm_pf_kernel(PfP p) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t pf_smem[];
     const int id = (int) blockIdx.x, x = id & 7;
-    const int ks = (id >> 3) % p.splitk, slot = (id >> 3) / p.splitk;   // (the K slices of a tile are neighbours on one XCD: the reducer reads their slabs out of its own L2)
+    // slots [0, full) of an XCD run whole tiles; the slots behind them are split S ways along K, the slices of a tile neighbours on one XCD (the reducer reads
+    // their slabs out of its own L2). full = 0: every tile split (S = 1: none)
+    const int q = id >> 3;
+    const int S = q < p.full ? 1 : p.splitk;
+    const int ks = q < p.full ? 0 : (q - p.full) % p.splitk, slot = q < p.full ? q : p.full + (q - p.full) / p.splitk;
     const int per_x = (p.nt_n + 7 - x) >> 3;
     if (slot >= per_x * p.nt_t) return;
     const int tile_n = x + 8 * (slot / p.nt_t), tile_t = slot % p.nt_t;
@@ -495,9 +499,9 @@ __global__ __launch_bounds__(PF_NTHR) void gemm_pf_kernel(PfP p) {
         n0 = (tile_n - jb.tile0) * 256;
     }
     const int t0 = tile_t * 32 * NT;
-    const int tile_id = tile_n * p.nt_t + tile_t;
-    if (TA == TB || jb.type == TA) pf_body<TA, NT, EXP>(p, jb, n0, t0, pf_smem, role, ks, tile_id);
-    else pf_body<TB, NT, EXP>(p, jb, n0, t0, pf_smem, role, ks, tile_id);
+    const int tile_id = (slot - p.full) * 8 + x;                 // (split tiles only: slab and counter index)
+    if (TA == TB || jb.type == TA) pf_body<TA, NT, EXP>(p, jb, n0, t0, pf_smem, role, ks, S, tile_id);
+    else pf_body<TB, NT, EXP>(p, jb, n0, t0, pf_smem, role, ks, S, tile_id);
 }
 
 template <int TA, int TB, int NT> constexpr size_t pf_lds_bytes() { return (size_t) 3 * NT * 32 * 128 + (size_t) 8 * (pf_wave_bytes<TA>() > pf_wave_bytes<TB>() ? pf_wave_bytes<TA>() : pf_wave_bytes<TB>()); }
@@ -590,7 +594,9 @@ int pm_launch_gemm_pf_ex(const pm_gemm_pf_job * jobs, int njobs, const void * xh
     //  at 33-64 tokens, profiles/r06_small_batch.txt; one workgroup per CU it stays)
     const int slots_cu = cus;
     static const int force_s = [] { const char * e = getenv("PM355_GEMM_PF_SPLITK"); return e ? atoi(e) : 0; }();
-    int S = 1;
+    int S = 1, full = 0;
+    // per-XCD slot counts (XCD x owns the row tiles x, x + 8, ..)
+    const int minL = (tiles / 8) * p.nt_t, maxL = ((tiles + 7) / 8) * p.nt_t, cpx = cus / 8 > 0 ? cus / 8 : 1;
     {
         double best = (double) ((wgs + slots_cu - 1) / slots_cu) * nb;
         for (int q = 2; q <= 8; ++q) {
@@ -598,16 +604,31 @@ int pm_launch_gemm_pf_ex(const pm_gemm_pf_job * jobs, int njobs, const void * xh
             const double c = (double) ((wgs * q + slots_cu - 1) / slots_cu) * ((double) nb / q + 3.0);
             if (c < best * 0.97) { best = c; S = q; }
         }
-        if (force_s >= 1 && force_s <= 8 && nb / force_s >= 1) S = force_s;
+        // a launch of R full rounds + a short tail (wq | wk | wv at 2048 tokens: 320 tiles = 256 + 64; Qwen2.5-72B's ffn_gate | ffn_up: 1848 = 7 x 256 + 56): the
+        // full rounds run whole tiles, ONLY the tail's tiles are split - S' slices each, as many as fill the idle CUs of the last round. (Splitting every tile
+        // instead sends every partial tile through memory: 3 x 320 slabs of 256 KB for the qkv launch, 501 us = 685 TFLOP/s.)
+        static const bool no_mixed = [] { const char * e = getenv("PM355_GEMM_PF_MIXED"); return e && e[0] == '0'; }();
+        const int F = (minL / cpx) * cpx, rem = maxL - F;
+        if (!no_mixed && !(force_s >= 1 && force_s <= 8) && F > 0 && rem > 0 && 2 * rem <= cpx) {
+            int q = cpx / rem; if (q > 8) q = 8;
+            while (q >= 2 && nb / q < 4) --q;
+            if (q >= 2) {
+                const double c = (double) (F / cpx) * nb + ((double) nb / q + 3.0);
+                if (c < best * 0.97) { best = c; S = q; full = F; }
+            }
+        }
+        if (force_s >= 1 && force_s <= 8 && nb / force_s >= 1) { S = force_s; full = 0; }
     }
-    p.splitk = S;
+    p.splitk = S; p.full = full;
+    const int split_slots = maxL - full;                       // per XCD
     if (S > 1) {
-        const size_t slab = (size_t) 8 * nt * 4 * 64 * 16, need = 65536 + (size_t) wgs * S * slab;
+        const size_t slab = (size_t) 8 * nt * 4 * 64 * 16, need = 65536 + (size_t) 8 * split_slots * S * slab;
+        if ((size_t) 8 * split_slots > 16384) return -2;
         uint8_t * w = pf_workspace(st, need);
         if (!w) return -3;
         p.cnt = (unsigned *) w; p.ws = (float *) (w + 65536);
     }
-    const int slots = ((tiles + 7) / 8) * p.nt_t * S;
+    const int slots = full + split_slots * S;
     auto go = [&](auto kern, size_t lds) {
         pf_allow_lds((const void *) kern, lds);
         hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(PF_NTHR), lds, st, p);

@@ -609,6 +609,31 @@ def test_mfma_prefill_gemm_vs_oracle(P, oracle, t, K, N, T):
     assert nm_ref < 5e-4, nm_ref
 
 
+@pytest.mark.parametrize("t", [Q4_K, Q6_K])
+def test_prompt_gemm_tail_tiles_split_along_k(P, oracle, t):
+    """A launch of full rounds of workgroups + a short tail (17 row tiles x 16 token tiles: 32 whole-tile slots per XCD, then 16 slots on one XCD): only the
+    tail's tiles are split along K (two slices each, slabs summed in slice order by the last arriver) - against the exact f64 product of the dequantized
+    weights, whole tiles and split tiles separately, and bit-identical between two launches."""
+    torch = P.torch
+    rng = np.random.default_rng(91 + t)
+    K, N, T = 2048, 4352, 4096
+    blocks = rand_blocks(t, N, K, rng, scale=1.0)
+    w = P.upload_weight(t, blocks, K, N)
+    x = rng.normal(0, 1, (T, K)).astype(np.float32)
+    bias = rng.normal(0, 1, N).astype(np.float32)
+    xd, bd = _dev(P, x), _dev(P, bias)
+    got = P.mul_mat_mfma(w, xd, bias=bd)
+    again = P.mul_mat_mfma(w, xd, bias=bd)
+    assert torch.equal(got, again)
+    rs = row_size(t, K)
+    Wf = np.stack([oracle.dequantize_row(t, blocks[r * rs:(r + 1) * rs], K) for r in range(N)]).astype(np.float64)
+    exact = x.astype(np.float64) @ Wf.T + bias
+    g = got.cpu().numpy()
+    for lo, hi in ((0, 4096), (4096, N)):             # whole tiles | the split tail (row tile 16 = XCD 0's third)
+        nm = ((g[:, lo:hi] - exact[:, lo:hi]) ** 2).sum() / (exact[:, lo:hi] ** 2).sum()
+        assert nm < 1e-6, (lo, nm)
+
+
 @pytest.mark.parametrize("types", [(Q4_K, Q4_K, Q6_K), (Q4_K, Q4_K, Q5_K), (Q6_K, Q6_K, Q6_K), (Q5_K, Q6_K), (Q4_K,)])
 @pytest.mark.parametrize("T", [77, 300])
 def test_prompt_gemm_jobs_one_launch(P, oracle, types, T):
