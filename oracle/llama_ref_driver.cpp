@@ -15,11 +15,16 @@
 //   REFDRV_RM      "step,p0,p1": before generation step `step` positions [p0, p1) of the sequence are removed (llama_kv_cache_seq_rm): holes
 //   REFDRV_DEFRAG  "step": before generation step `step` llama_kv_cache_defrag + llama_kv_cache_update (build_defrag, src/llama.cpp:10721)
 //   REFDRV_CHUNK   prompt tokens per llama_decode call (default: all = one prefill batch; clamped to n_batch)
+//   REFDRV_LOUT    binary dump of every layer's output row of the FIRST single-token decode (the tensors llm_build_* names "l_out-<il>", src/llama.cpp:11177,
+//                  and "result_norm"), captured through the scheduler's eval callback (cparams.cb_eval, ggml_backend_sched_set_eval_callback src/llama.cpp:18457):
+//                  int32 {magic 0x54554f4c, n_rows, n_embd}, int32 layer[n_rows] (-1 = result_norm), float rows[n_rows][n_embd] - where two builds / backends
+//                  part, layer by layer, before a flipped token can cascade
 // Timing is wall-clock around llama_decode + llama_synchronize and the reference's llama_perf_context
 // (src/llama.cpp:23832-23862), printed as one JSON line on stdout.
 #include "arg.h"
 #include "common.h"
 #include "llama.h"
+#include "ggml-backend.h"
 
 #include <chrono>
 #include <cstdio>
@@ -41,6 +46,26 @@ static std::vector<int> parse_ids(const char * s) {
     return v;
 }
 
+// per-layer capture (REFDRV_LOUT): armed around one llama_decode only
+struct LoutCapture { bool armed = false; std::vector<int32_t> layer; std::vector<float> rows; int n_embd = 0; };
+static bool lout_cb(struct ggml_tensor * t, bool ask, void * ud) {
+    LoutCapture * c = (LoutCapture *) ud;
+    if (!c->armed) return false;
+    int il = -2;
+    if (strncmp(t->name, "l_out-", 6) == 0) il = atoi(t->name + 6);
+    else if (strcmp(t->name, "result_norm") == 0) il = -1;
+    if (il == -2) return false;
+    if (ask) return true;
+    if (t->type != GGML_TYPE_F32) return true;
+    const int64_t ne0 = t->ne[0], last = t->ne[1] - 1;              // the last token's row
+    c->n_embd = (int) ne0;
+    const size_t at = c->rows.size();
+    c->rows.resize(at + (size_t) ne0);
+    ggml_backend_tensor_get(t, c->rows.data() + at, (size_t) last * t->nb[1], (size_t) ne0 * sizeof(float));
+    c->layer.push_back(il);
+    return true;
+}
+
 static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -48,6 +73,8 @@ static double now_ms() {
 int main(int argc, char ** argv) {
     gpt_params params;
     if (!gpt_params_parse(argc, argv, params, LLAMA_EXAMPLE_COMMON)) return 2;
+    LoutCapture lout;
+    if (getenv("REFDRV_LOUT")) { params.cb_eval = lout_cb; params.cb_eval_user_data = &lout; }
     llama_backend_init();
     llama_numa_init(params.numa);
 
@@ -104,8 +131,10 @@ int main(int argc, char ** argv) {
         if (rm.size() == 3 && i == rm[0]) llama_kv_cache_seq_rm(ctx, 0, rm[1], rm[2]);
         if (defrag.size() == 1 && i == defrag[0]) { llama_kv_cache_defrag(ctx); llama_kv_cache_update(ctx); }
         const double t0 = now_ms();
+        lout.armed = i == 0 && getenv("REFDRV_LOUT") != nullptr;
         if (llama_decode(ctx, llama_batch_get_one(&next, 1, n_past, 0))) { fprintf(stderr, "refdrv: llama_decode(step %d) failed\n", i); return 5; }
         llama_synchronize(ctx);
+        lout.armed = false;
         step_ms.push_back(now_ms() - t0);
         n_past += 1;
     }
@@ -117,6 +146,16 @@ int main(int argc, char ** argv) {
         fwrite(hdr, 4, 4, f);
         fwrite(gen.data(), 4, gen.size(), f);
         fwrite(all_logits.data(), 4, all_logits.size(), f);
+        fclose(f);
+    }
+
+    if (const char * lo = getenv("REFDRV_LOUT")) {
+        FILE * f = fopen(lo, "wb");
+        if (!f) { fprintf(stderr, "refdrv: cannot write %s\n", lo); return 6; }
+        const int32_t hdr[3] = {0x54554f4c, (int32_t) lout.layer.size(), lout.n_embd};
+        fwrite(hdr, 4, 3, f);
+        fwrite(lout.layer.data(), 4, lout.layer.size(), f);
+        fwrite(lout.rows.data(), 4, lout.rows.size(), f);
         fclose(f);
     }
 

@@ -545,8 +545,10 @@ def llama_driver_path(flavour=None):
 
 
 def run_llama_driver(gguf_path, prompt, n_gen, ngl=0, n_ctx=64, threads=2, extra_args=(), force=None, env=None, timeout=600,
-                     chunk=None, flavour=None):
-    """Greedy decode through the reference's llama_init_from_gpt_params + llama_decode. Returns (tokens, logits, stats)."""
+                     chunk=None, flavour=None, lout=False):
+    """Greedy decode through the reference's llama_init_from_gpt_params + llama_decode. Returns (tokens, logits, stats).
+    lout: also capture every layer's output row of the first single-token decode (the driver's REFDRV_LOUT, scheduler eval callback):
+    stats["lout"] = {layer (-1 = result_norm): float32 row}."""
     import json
     import tempfile
     drv = llama_driver_path(flavour)
@@ -558,6 +560,10 @@ def run_llama_driver(gguf_path, prompt, n_gen, ngl=0, n_ctx=64, threads=2, extra
         e["REFDRV_FORCE"] = ",".join(str(int(t)) for t in force)
     if chunk:
         e["REFDRV_CHUNK"] = str(chunk)
+    lout_path = None
+    if lout:
+        lout_path = tempfile.NamedTemporaryFile(suffix=".lout", delete=False).name
+        e["REFDRV_LOUT"] = lout_path
     if ngl == 0:
         # a reference run: the host's arithmetic for EVERY batch. With the plug-in linked in, ggml_backend_sched would ship the >= 32-token batches of a
         # -ngl 0 run to the GPU (offload_op, as the CUDA plug-in does, ggml-cuda.cu:3201-3208) - round 6 found the 8200-token "CPU reference" doing that on the GPU box
@@ -576,4 +582,12 @@ def run_llama_driver(gguf_path, prompt, n_gen, ngl=0, n_ctx=64, threads=2, extra
     toks = np.fromfile(out, dtype=np.int32, offset=16, count=ng)
     logits = np.fromfile(out, dtype=np.float32, offset=16 + 4 * ng).reshape(ng, nv)
     os.unlink(out)
+    if lout_path:
+        h3 = np.fromfile(lout_path, dtype=np.int32, count=3)
+        assert h3[0] == 0x54554f4c
+        nr, ne = int(h3[1]), int(h3[2])
+        layers = np.fromfile(lout_path, dtype=np.int32, offset=12, count=nr)
+        rows = np.fromfile(lout_path, dtype=np.float32, offset=12 + 4 * nr).reshape(nr, ne) if nr else np.zeros((0, 0), np.float32)
+        stats["lout"] = {int(l): rows[i] for i, l in enumerate(layers)}
+        os.unlink(lout_path)
     return toks, logits, stats

@@ -305,6 +305,29 @@ def test_peaked_fixture_at_depth(gpu, tmp_path):
                 assert _nmse(l_, lr) <= 1.5 * max(nm_ref, 2e-5), (mode, _nmse(l_, lr), nm_ref)
         if st.get("decode_tok_s"):
             print(f"[8d 70b x {depth}] plug-in decode {st['decode_tok_s']:.1f} tok/s")
+        # layer by layer, BEFORE a flipped token could cascade: every layer's output row (l_out-<il>, then result_norm) of the first
+        # single-token decode, captured through the scheduler's eval callback in the reference's own driver - plug-in against the reference CPU, next to the
+        # reference's AVX2 build against the same (its own summation-order distance, growing with depth the same way)
+        _, _, s_ref = run_llama_driver(path, prompt, 2, ngl=0, n_ctx=N_CTX, threads=_threads(), flavour=best_ref_flavour(), timeout=3000, lout=True)
+        _, _, s_gpu = run_llama_driver(path, prompt, 2, ngl=99, n_ctx=N_CTX, threads=_threads(), timeout=1800, extra_args=GPU_ARGS, lout=True)
+        lo_r, lo_g = s_ref["lout"], s_gpu["lout"]
+        assert sorted(lo_r) == sorted(lo_g) == [-1] + list(range(depth)), (sorted(lo_r), sorted(lo_g))
+        lo_a = None
+        if have_ref("avx2") and best_ref_flavour() != "avx2":
+            _, _, s_a = run_llama_driver(path, prompt, 2, ngl=0, n_ctx=N_CTX, threads=_threads(), flavour="avx2", timeout=3000, lout=True)
+            lo_a = s_a["lout"]
+        order = list(range(depth)) + [-1]
+        nm_g = np.array([_nmse(lo_g[l], lo_r[l]) for l in order])
+        nm_a = np.array([_nmse(lo_a[l], lo_r[l]) for l in order]) if lo_a else None
+        print(f"[8d 70b x {depth}] per-layer l_out NMSE of the first decoded token vs the reference CPU ({best_ref_flavour()}); last entry = result_norm")
+        print("   plug-in : " + " ".join(f"{v:.1e}" for v in nm_g))
+        if nm_a is not None:
+            print("   ref AVX2: " + " ".join(f"{v:.1e}" for v in nm_a))
+        assert np.isfinite(nm_g).all() and nm_g.max() < 1e-3, nm_g.max()
+        if nm_a is not None:
+            # no layer further from the reference than a few times the reference's own two builds are from each other at that depth (floor: the first layers,
+            # where the AVX2 build's distance is a handful of rounding decisions)
+            assert (nm_g <= 5.0 * np.maximum(nm_a, 1e-6)).all(), (nm_g, nm_a)
     finally:
         try:
             os.unlink(path)
