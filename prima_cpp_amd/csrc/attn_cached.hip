@@ -22,7 +22,8 @@ namespace {
 // this token's (cos, sin) per rotation pair: one launch per token serves every layer's wq | wk | wv epilogue
 __global__ __launch_bounds__(128) void rope_table_kernel(RopeP r, const int32_t * pos_ptr, const int32_t * seq_ptr, const float * freq_factors, float * tab) {
     const int seq = seq_ptr ? *seq_ptr : 0;
-    const int pos = pos_ptr[seq];
+    const int pos = pos_ptr[seq] + (int) blockIdx.x;             // (blockIdx.x: token of a small batch, its table n_dims floats further on)
+    tab += (size_t) blockIdx.x * r.n_dims;
     for (int pair = threadIdx.x; pair < r.n_dims / 2; pair += blockDim.x) {
         float c, s;
         rope_cs(r, (float) pos, pair, freq_factors, c, s);
@@ -146,11 +147,11 @@ __global__ __launch_bounds__(256) void attn_cached_kernel(AttnP a_in) {
 
 } // namespace
 
-void pm_launch_rope_table(const pm_rope_cfg & c, const int32_t * pos, const int32_t * seq, const float * freq_factors, float * tab, hipStream_t st) {
+void pm_launch_rope_table(const pm_rope_cfg & c, const int32_t * pos, const int32_t * seq, const float * freq_factors, float * tab, hipStream_t st, int n_tok) {
     RopeP r;
     r.n_dims = c.n_dims; r.mode = c.mode; r.n_ctx_orig = c.n_ctx_orig; r.theta_scale = c.theta_scale;
     r.freq_scale = c.freq_scale; r.ext_factor = c.ext_factor; r.attn_factor = c.attn_factor; r.corr0 = c.corr0; r.corr1 = c.corr1;
-    hipLaunchKernelGGL(rope_table_kernel, dim3(1), dim3(128), 0, st, r, pos, seq, freq_factors, tab);
+    hipLaunchKernelGGL(rope_table_kernel, dim3(n_tok < 1 ? 1 : n_tok), dim3(128), 0, st, r, pos, seq, freq_factors, tab);
 }
 
 // q = rotated, F16-rounded query rows; caches already hold this token. Same arguments as pm_launch_attn_rope_fused otherwise.

@@ -48,6 +48,7 @@ struct pm355_model {
     bool no_fuse = false;                 // PM355_NO_FUSE=1: node-by-node kernels (debug / A-B)
     bool no_multi = false;                // PM355_NO_MMQ_MULTI=1
     bool no_small_cols = false;           // PM355_SMALL_COLS=0
+    bool no_small_epi = false;            // PM355_SMALL_ROPE_EPI=0: small batches run rope_kv_store as a launch of its own
     bool no_mmq = false;                  // PM355_NO_MMQ_I8=1: 4..64-token batches on the round-1 paths (mat-vec columns, F16 GEMM from 16 tokens)
     // single-token decode, short contexts, NORM-mode rope: RoPE + F16 KV store happen in the epilogue of the wq | wk | wv launch (per-token cos / sin
     // table `rope_tab`), the attention launch reads everything from the cache (attn_cached.hip). PM355_QKV_EPI=0: the round-2 form (raw q / k / v,
@@ -591,6 +592,11 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
     if (!cur) return seterr(m, PM355_E_SHAPE, "decode: neither tokens nor x_in");
     float * bufs[2] = {m->x, m->x1};
     int n_ss_head = 0; const double * ss_head = m->ss ? m->ss + 256 : nullptr;   // partials of the output row's sum of squares left by the last ffn_down (single-token path)
+    // small batches (2..32 tokens) with NORM rope: RoPE + KV store ride in the epilogue of the wq | wk | wv small-batch launch; the tokens' cos / sin tables
+    // are written here, once for all layers
+    const bool small_epi = T >= MMQ_MULTI_MIN_TOKENS && T <= 32 && T <= MMQ_MAX_TOKENS && !m->no_fuse && !m->no_mmq && !m->no_multi && !m->no_small_epi && m->qkv_epi && m->rope_tab &&
+                           m->rope.mode == 0 && m->hi > m->lo;
+    if (small_epi) pm_launch_rope_table(m->rope, m->d_pos, m->d_ctl, (const float *) m->rope_freqs.d, m->rope_tab, st, T);
     if (T == 1 && !m->no_fuse) {
         m->flash_cells = attn_regime(m); m->long_ctx = m->flash_cells != 0;
         // ---- single token: every activation transform is fused into a mat-vec prologue / epilogue, 5 launches per layer
@@ -734,20 +740,32 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         bool prepped = false;
         const bool small = T >= MMQ_MULTI_MIN_TOKENS && T <= MMQ_MAX_TOKENS && !m->no_mmq && a.k != nullptr;   // (single launches: from MMQ_MIN_TOKENS, in matmul_small)
         // matrices of one type that share the activations go out as ONE small-batch launch per 32 tokens: wq | wk (| wv), ffn_gate | ffn_up
-        auto multi = [&](std::initializer_list<const Tensor *> ws, std::initializer_list<float *> ys, std::initializer_list<const float *> bs) {
+        auto multi = [&](std::initializer_list<const Tensor *> ws, std::initializer_list<float *> ys, std::initializer_list<const float *> bs, const pm_qkv_epi * epi = nullptr) {
             const void * W[3]; int N[3]; float * Y[3]; const float * B[3]; int n = 0;
             for (const Tensor * w : ws) { W[n] = w->d; N[n] = (int) w->N; ++n; }
             n = 0; for (float * y : ys) Y[n++] = y;
             n = 0; for (const float * b : bs) B[n++] = b;
             const Tensor * w0 = *ws.begin();
-            return pm_launch_mmq_i8_multi(w0->type, n, W, N, Y, B, a.k, (int) w0->K, T, (prepped || a.tab) ? 1 : 0, st);
+            return pm_launch_mmq_i8_multi(w0->type, n, W, N, Y, B, a.k, (int) w0->K, T, (prepped || a.tab) ? 1 : 0, st, epi);
         };
+        // RoPE + KV store in the epilogue of the wq | wk | wv launch (NORM rope; the tokens' cos / sin tables were written once for this step): no
+        // rope_kv_store launch. PM355_SMALL_ROPE_EPI=0: the separate launch
+        const long kv_stride = (long) hp.n_ctx * Hkv * dh;
+        const pm_qkv_epi qe = {m->rope_tab, m->d_pos, m->d_ctl, nullptr, kv_stride, L.kc, L.vc, Hkv, dh, hp.n_ctx, m->rope.n_dims, 0, 0};
+        const pm_qkv_epi * epi = small_epi ? &qe : nullptr;
+        bool rope_done = false;
         const Tensor & wq_ = L.t[PM355_T_WQ], & wk_ = L.t[PM355_T_WK], & wv_ = L.t[PM355_T_WV];
         const float * bq_ = (const float *) L.t[PM355_T_BQ].d, * bk_ = (const float *) L.t[PM355_T_BK].d, * bv_ = (const float *) L.t[PM355_T_BV].d;
         bool qkv_done = false;
         if (small && T <= MMQ_MAX_TOKENS && !m->no_multi && wq_.type == wk_.type) {
             if (wv_.type == wq_.type) {
-                if (multi({&wq_, &wk_, &wv_}, {m->q, m->k, m->v}, {bq_, bk_, bv_}) == 0) qkv_done = true;
+                if (epi && multi({&wq_, &wk_, &wv_}, {m->q, m->k, m->v}, {bq_, bk_, bv_}, epi) == 0) qkv_done = rope_done = true;
+                else if (multi({&wq_, &wk_, &wv_}, {m->q, m->k, m->v}, {bq_, bk_, bv_}) == 0) qkv_done = true;
+            } else if (epi && [&] {
+                           const void * W[2] = {wq_.d, wk_.d}; const int N[2] = {(int) wq_.N, (int) wk_.N}; float * Y[2] = {m->q, m->k}; const float * B[2] = {bq_, bk_};
+                           return wv_.K == wq_.K && pm_launch_mmq_i8_dual(wq_.type, 2, W, N, Y, B, wv_.type, wv_.d, (int) wv_.N, m->v, bv_, a.k, (int) wq_.K, T, (prepped || a.tab) ? 1 : 0, st, epi) == 0;
+                       }()) {
+                qkv_done = rope_done = true;
             } else if ([&] {        // wv of another K-quant type (Q6_K / Q5_K in the Q4_K_M files): the same grid, its own workgroups (mmq_i8_dual_kernel)
                            const void * W[2] = {wq_.d, wk_.d}; const int N[2] = {(int) wq_.N, (int) wk_.N}; float * Y[2] = {m->q, m->k}; const float * B[2] = {bq_, bk_};
                            return wv_.K == wq_.K && pm_launch_mmq_i8_dual(wq_.type, 2, W, N, Y, B, wv_.type, wv_.d, (int) wv_.N, m->v, bv_, a.k, (int) wq_.K, T, (prepped || a.tab) ? 1 : 0, st) == 0;
@@ -764,7 +782,6 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         rc |= matmul_small(m, L.t[PM355_T_WV], a, T, m->v, (const float *) L.t[PM355_T_BV].d, nullptr, prepped, st);
         }
         if (rc) return seterr(m, rc, "decode: qkv gemv");
-        const long kv_stride = (long) hp.n_ctx * Hkv * dh;
         bool fused_attn = false;
         if (T == 1 && !m->no_fuse)
             fused_attn = pm_launch_attn_rope_fused(m->q, m->k, m->v, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride,
@@ -772,6 +789,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
         if (!fused_attn) {
         // q rotated AND rounded to F16, every token's K row / V column stored: the attention of a small batch then is the single-token kernel over
         // cached cells, one workgroup per (head, token) (attn_cached.hip: one barrier up to 64 cells; 11 -> ~4 us per layer at 2..8 tokens)
+        if (!rope_done)
         pm_launch_rope_kv_store(m->q, m->k, m->v, m->q, nullptr, L.kc, L.vc, m->d_pos, m->d_ctl, kv_stride,
                                 (const float *) m->rope_freqs.d, T, H, Hkv, dh, hp.n_ctx, m->rope, st, 1);
         // (a shape attn_cached refuses - head_dim other than 64 / 128 / 256, scores beyond 150 KiB of LDS - falls back to attn_decode, which rounds q to
@@ -862,6 +880,7 @@ pm355_model * pm355_model_new(const pm355_hparams * hp, int lo, int hi, int flag
     m->rope.ext_factor = 0.0f; m->rope.attn_factor = 1.0f; m->rope.beta_fast = 32.0f; m->rope.beta_slow = 1.0f;
     pm_rope_params(m->rope);
     { const char * e = getenv("PM355_NO_FUSE"); m->no_fuse = e && e[0] == '1'; }
+    { const char * e = getenv("PM355_SMALL_ROPE_EPI"); m->no_small_epi = e && e[0] == '0'; }
     { const char * e = getenv("PM355_SMALL_COLS"); m->no_small_cols = e && e[0] == '0'; }   // A/B: 2..4-token steps without the round-4 multi-column choices
     { const char * e = getenv("PM355_NO_MMQ_MULTI"); m->no_multi = e && e[0] == '1'; }   // small batches: one launch per matrix (A/B of the multi-job launches)
     { const char * e = getenv("PM355_NO_MMQ_I8"); m->no_mmq = e && e[0] == '1'; }     // 4..64-token batches: mat-vec columns / F16 GEMM from 16 (the round-1 paths)
@@ -991,7 +1010,7 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
               A((void **) &m->aq_k, T * pm_q8k_row_bytes((int) ((maxK + 255) / 256 * 256))) &&
               A((void **) &m->aq_0, T * pm_q80_row_bytes((int) ((maxK + 31) / 32 * 32))) &&
               A((void **) &m->d_pos, 64 * 4) && A((void **) &m->d_ctl, 64) && A((void **) &m->d_tok, 64 + T * 4) &&
-              A((void **) &m->rope_tab, (size_t) hp.head_dim * 4) && A((void **) &m->ss, 2 * 256 * sizeof(double)) &&
+              A((void **) &m->rope_tab, (size_t) hp.head_dim * 4 * 32) &&      // cos / sin tables of up to 32 tokens (small-batch epilogue) A((void **) &m->ss, 2 * 256 * sizeof(double)) &&
               A((void **) &m->att_tk, 65 * 4);
     if (ok) (void) hipMemset(m->att_tk, 0, 65 * 4);
     if (ok && T > MMQ_MAX_TOKENS && !m->no_big) ok = A((void **) &m->tab_big, pm_mmq_big_table_bytes((int) ((maxK + 255) / 256 * 256), (int) T));

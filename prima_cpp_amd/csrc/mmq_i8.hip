@@ -61,6 +61,11 @@ struct MmqP {
     // multi-job launches (MJ kernels): up to 3 matrices of one type and K that share the activations (wq | wk | wv, ffn_gate | ffn_up) form
     // ONE virtual row space [0, N): job j owns rows [start[j], start[j] + nj[j]); y / bias per job, output token stride nj[j]
     const uint8_t * Wj[3]; float * yj[3]; const float * bj[3]; int start[3], nj[3], njobs;
+    // wq | wk | wv epilogue (e_on; round 6): RoPE (NORM pairing: rows 2 i, 2 i + 1 of a head) with the per-token cos / sin tables of pm_launch_rope_table, q ->
+    // F16-rounded f32 into its y, k -> the F16 K-cache row of cell pos + t, v -> the transposed F16 V cache - what rope_kv_store_kernel (layer_ops.hip) does in a
+    // launch of its own, the same expressions (ggml_compute_forward_rope_f32 ggml.c:14224-14237; llm_build_kv_store src/llama.cpp:9688-9716).
+    // e_role[j]: 1 q, 2 k, 3 v (single-job launches: e_role[0]). Workgroup row slices start on even rows then.
+    int e_on, e_role[3]; const float * e_tab; const int32_t * e_pos, * e_seq; long e_seq_stride; uint16_t * e_kc, * e_vc; int e_dh, e_nctx, e_nrot, e_kvdim;
 };
 
 __device__ __forceinline__ long pk(uint32_t a, uint32_t b) { return (long) (((uint64_t) b << 32) | a); }
@@ -398,7 +403,9 @@ template <> struct MT<PM_Q8_0> {
 
 // ABL (measurement only, PM355_MMQ_ABL): 1 = no activation loads in the loop, 2 = no weight loads in the loop, 4 = no MFMA / VALU work
 // the work of workgroup w of G on the launch p (its own grid, or one part of a two-part launch)
-template <int TYPE, int NV, int ABL, bool MJ>                   // NV result registers per lane in use: 4 (<= 8 tokens), 8 (<= 16), 16 (<= 32)
+// EPI: the wq | wk | wv epilogue (MmqP::e_*) is compiled in - instantiations of their own: carried by every kernel as a run-time switch it cost the launches
+// that never use it 2-6 us per layer (Qwen2.5-72B, NEOX rope: 236 -> 242 us at 8 tokens)
+template <int TYPE, int NV, int ABL, bool MJ, bool EPI = false>  // NV result registers per lane in use: 4 (<= 8 tokens), 8 (<= 16), 16 (<= 32)
 __device__ __forceinline__ void mmq_i8_body(const MmqP & p, const int w, const int G, uint8_t * smem) {
     typedef MT<TYPE> M;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (a scalar: the K slice, the loop counters and the buffer loads' scalar offsets derive from it)
@@ -407,7 +414,8 @@ __device__ __forceinline__ void mmq_i8_body(const MmqP & p, const int w, const i
     const int nbw = Q80 ? p.K / 32 : nsb;                         // what the tile loader counts in: blocks of the row
     float * dTl = (float *) smem;                                 // activation scales [nsb + 1][32] (0 for token slots >= T; last row all 0)
     uint8_t * stage = smem + (Q80 ? 0 : (size_t) (nsb + 1) * 128);   // NWAVE x WAVE_LDS; afterwards the 32 KB reduction buffer
-    const int r0 = (int) ((long) p.N * w / G), r1 = (int) ((long) p.N * (w + 1) / G);      // (MJ: virtual rows over all jobs)
+    int r0 = (int) ((long) p.N * w / G), r1 = (int) ((long) p.N * (w + 1) / G);            // (MJ: virtual rows over all jobs)
+    if constexpr (EPI) { r0 &= ~1; r1 &= ~1; }                    // rotation pairs stay inside a workgroup (N and the job boundaries are even)
     const int nrg = (r1 - r0 + 31) >> 5;
     const int RGB = 1 << p.rgb_log2, KS = NWAVE >> p.rgb_log2;
     const int rgi = wave & (RGB - 1), ks = wave >> p.rgb_log2;
@@ -532,41 +540,60 @@ __device__ __forceinline__ void mmq_i8_body(const MmqP & p, const int w, const i
             float s = 0.0f;
             for (int k = 0; k < KS; ++k) s += red[(((k << p.rgb_log2) + gi) * 16 + v) * 64 + l];
             const int t = 8 * (v >> 2) + 4 * (l >> 5) + (v & 3), row = r0 + 32 * (rg0 + gi) + (l & 31);
-            if (t < p.T && row < r1) {
-                if constexpr (!MJ) {
-                    if (p.bias)  s += ld_g(p.bias + row);
-                    if (p.resid) s += ld_g(p.resid + (long) t * p.y_stride + row);
-                    st_g(p.y + (long) t * p.y_stride + row, s);
-                } else {
-                    const int j = (row >= p.start[1] && p.njobs > 1) + (row >= p.start[2] && p.njobs > 2);
-                    const int lr = row - (j == 0 ? 0 : j == 1 ? p.start[1] : p.start[2]), nj = j == 0 ? p.nj[0] : j == 1 ? p.nj[1] : p.nj[2];
-                    const float * bj = j == 0 ? p.bj[0] : j == 1 ? p.bj[1] : p.bj[2];
-                    float * yj = j == 0 ? p.yj[0] : j == 1 ? p.yj[1] : p.yj[2];
-                    if (bj) s += ld_g(bj + lr);
-                    if (p.resid) s += ld_g(p.resid + (long) t * nj + lr);          // (one-job launches of this form: wo / ffn_down with their residual)
-                    st_g(yj + (long) t * nj + lr, s);
+            const bool live = t < p.T && row < r1;
+            // the element's job: local row, output, bias
+            int j = 0, lr = row, nj = p.N; const float * bj = p.bias; float * yj = p.y;
+            if constexpr (MJ) {
+                j = (row >= p.start[1] && p.njobs > 1) + (row >= p.start[2] && p.njobs > 2);
+                lr = row - (j == 0 ? 0 : j == 1 ? p.start[1] : p.start[2]); nj = j == 0 ? p.nj[0] : j == 1 ? p.nj[1] : p.nj[2];
+                bj = j == 0 ? p.bj[0] : j == 1 ? p.bj[1] : p.bj[2];
+                yj = j == 0 ? p.yj[0] : j == 1 ? p.yj[1] : p.yj[2];
+            }
+            if (live && bj) s += ld_g(bj + lr);
+            if constexpr (EPI) {
+                const float sp = __shfl_xor(s, 1);                      // the pair's other row: the neighbouring lane (r0 even), same token
+                if (live) {
+                    const int role = j == 0 ? p.e_role[0] : j == 1 ? p.e_role[1] : p.e_role[2];
+                    const int seq = p.e_seq ? *p.e_seq : 0;
+                    const int pos = p.e_pos[seq] + t;
+                    const long kv_off = (long) seq * p.e_seq_stride;
+                    if (role == 3) p.e_vc[kv_off + (long) lr * p.e_nctx + pos] = f2h(s);
+                    else {
+                        const int d = lr % p.e_dh;
+                        float o = s;
+                        if (d < p.e_nrot) {
+                            const float c = ld_g(p.e_tab + (long) t * p.e_nrot + (d & ~1)), sn = ld_g(p.e_tab + (long) t * p.e_nrot + (d & ~1) + 1);
+                            o = (d & 1) ? sp * sn + s * c : s * c - sp * sn;          // o1 = x0 sin + x1 cos | o0 = x0 cos - x1 sin
+                        }
+                        const uint16_t hv = f2h(o);
+                        if (role == 2) p.e_kc[kv_off + (long) pos * p.e_kvdim + lr] = hv;
+                        else st_g(yj + (long) t * nj + lr, role == 1 ? h2f(hv) : o);
+                    }
                 }
+            } else if (live) {
+                if (p.resid) s += ld_g(p.resid + (long) t * (MJ ? nj : (int) p.y_stride) + lr);
+                st_g(yj + (long) t * (MJ ? nj : (int) p.y_stride) + lr, s);
             }
         }
         __syncthreads();
     }
 }
 
-template <int TYPE, int NV, int ABL = 0, bool MJ = false>
+template <int TYPE, int NV, int ABL = 0, bool MJ = false, bool EPI = false>
 __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_kernel(MmqP p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    mmq_i8_body<TYPE, NV, ABL, MJ>(p, (int) blockIdx.x, (int) gridDim.x, smem);
+    mmq_i8_body<TYPE, NV, ABL, MJ, EPI>(p, (int) blockIdx.x, (int) gridDim.x, smem);
 }
 
 // Two launches that share the activations as ONE grid: workgroups [0, ga) are the multi-job launch `a` (wq | wk, type TA), the rest the single matrix `b` of
 // another type (wv: Q6_K or Q5_K in the Q4_K_M files, src/llama.cpp:19447 use_more_bits) - by itself a 7 MB matrix is a launch of ~14 us that 32 workgroups
 // spend mostly on their fixed costs (profiles/r06_small_batch.txt); here it rides in the shadow of the large part.
 struct MmqP2 { MmqP a, b; int ga; };
-template <int TA, int TB, int NV>
+template <int TA, int TB, int NV, bool EPI = false>
 __global__ __launch_bounds__(BLOCK, 2) void mmq_i8_dual_kernel(MmqP2 pp) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if ((int) blockIdx.x < pp.ga) mmq_i8_body<TA, NV, 0, true>(pp.a, (int) blockIdx.x, pp.ga, smem);
-    else mmq_i8_body<TB, NV, 0, TB == PM_Q6_K>(pp.b, (int) blockIdx.x - pp.ga, (int) gridDim.x - pp.ga, smem);   // (Q6_K: the one-job multi-job form - no spills at 16 tokens)
+    if ((int) blockIdx.x < pp.ga) mmq_i8_body<TA, NV, 0, true, EPI>(pp.a, (int) blockIdx.x, pp.ga, smem);
+    else mmq_i8_body<TB, NV, 0, TB == PM_Q6_K, EPI>(pp.b, (int) blockIdx.x - pp.ga, (int) gridDim.x - pp.ga, smem);   // (Q6_K: the one-job multi-job form - no spills at 16 tokens)
 }
 
 // prologue: per super-block, the activation group sums as F16 in A-operand order and the transposed activation scales
@@ -834,12 +861,26 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
     return 0;
 }
 
+namespace {
+// wq | wk | wv epilogue of a launch (MmqP::e_*): NORM-mode rope, transposed F16 V cache, engine mode (cell = position). false: not served
+bool fill_epi(MmqP & p, const pm_qkv_epi * e, int r0, int r1, int r2) {
+    if (!e) return true;
+    if (e->neox || e->v_rowmajor || e->dyn || !e->tab || !e->pos || !e->kc || !e->vc || e->dh < 2 || (e->dh & 1) || (e->n_rot & 1)) return false;
+    p.e_on = 1; p.e_role[0] = r0; p.e_role[1] = r1; p.e_role[2] = r2;
+    p.e_tab = e->tab; p.e_pos = e->pos; p.e_seq = e->seq; p.e_seq_stride = e->seq_stride; p.e_kc = (uint16_t *) e->kc; p.e_vc = (uint16_t *) e->vc;
+    p.e_dh = e->dh; p.e_nctx = e->n_ctx; p.e_nrot = e->n_rot; p.e_kvdim = e->Hkv * e->dh;
+    return true;
+}
+}  // namespace
+
 // Up to 3 matrices of ONE type and K sharing the activations (wq | wk | wv, ffn_gate | ffn_up) in one launch: one fill / drain of the
 // step pipeline instead of two or three (~10 us each). T <= 64 in passes of 32 (round 4: with the operand-ordered activation table the 32-token
 // instantiations have the registers for per-lane row pointers: 238 / 250 VGPRs); -5: not served, launch the jobs one by one. y[j]: [T][N[j]].
 int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const int * N, float * const * Y, const float * const * bias, const void * xq,
-                           int K, int T, int reuse_prep, hipStream_t st) {
+                           int K, int T, int reuse_prep, hipStream_t st, const pm_qkv_epi * epi) {
     if (njobs < 2 || njobs > 3 || T > 64 || (type != PM_Q4_K && type != PM_Q6_K)) return -5;
+    // epi: the jobs are wq, wk, wv (three jobs, one pass, even row counts whose heads are whole)
+    if (epi && (njobs != 3 || T > 32 || N[0] % epi->dh || N[1] != epi->Hkv * epi->dh || N[2] != N[1])) return -5;
     long total = 0;
     for (int j = 0; j < njobs; ++j) { if (pm_mmq_i8_check(type, K, N[j], T)) return -5; total += N[j]; }
     int dev = 0;
@@ -864,6 +905,7 @@ int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const in
         if (j < njobs) at += N[j];
     }
     p.rgb_log2 = rgb_log2_for(nrg);
+    if (!fill_epi(p, epi, 1, 2, 3)) return -5;
     const size_t lds = pm_mmq_i8_lds_bytes(type, K);
     auto go = [&](auto kern) {
         pm_allow_big_lds((const void *) kern, 150 * 1024);
@@ -875,7 +917,9 @@ int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const in
         p.T = tn;
         p.bsT = sc->p + c * tab; p.dT = (const float *) (p.bsT + (size_t) nsb * 1024); p.qT = sc->p + scr_q_off(K) + (size_t) c * nsb * 8192;
         for (int j = 0; j < 3; ++j) { const int jj = j < njobs ? j : njobs - 1; p.yj[j] = Y[jj] + (size_t) t0 * N[jj]; }
-        if (type == PM_Q4_K) { if (tn <= 8) go(mmq_i8_kernel<PM_Q4_K, 4, 0, true>); else if (tn <= 16) go(mmq_i8_kernel<PM_Q4_K, 8, 0, true>); else go(mmq_i8_kernel<PM_Q4_K, 16, 0, true>); }
+        if (p.e_on && type == PM_Q4_K) { if (tn <= 8) go(mmq_i8_kernel<PM_Q4_K, 4, 0, true, true>); else if (tn <= 16) go(mmq_i8_kernel<PM_Q4_K, 8, 0, true, true>); else go(mmq_i8_kernel<PM_Q4_K, 16, 0, true, true>); }
+        else if (p.e_on)         { if (tn <= 8) go(mmq_i8_kernel<PM_Q6_K, 4, 0, true, true>); else if (tn <= 16) go(mmq_i8_kernel<PM_Q6_K, 8, 0, true, true>); else go(mmq_i8_kernel<PM_Q6_K, 16, 0, true, true>); }
+        else if (type == PM_Q4_K) { if (tn <= 8) go(mmq_i8_kernel<PM_Q4_K, 4, 0, true>); else if (tn <= 16) go(mmq_i8_kernel<PM_Q4_K, 8, 0, true>); else go(mmq_i8_kernel<PM_Q4_K, 16, 0, true>); }
         else                 { if (tn <= 8) go(mmq_i8_kernel<PM_Q6_K, 4, 0, true>); else if (tn <= 16) go(mmq_i8_kernel<PM_Q6_K, 8, 0, true>); else go(mmq_i8_kernel<PM_Q6_K, 16, 0, true>); }
     }
     return 0;
@@ -884,12 +928,15 @@ int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const in
 // wq | wk (na matrices of type ta = Q4_K, as in pm_launch_mmq_i8_multi) AND one matrix of another K-quant type (wv: Q6_K / Q5_K) over the same activations as
 // ONE grid (mmq_i8_dual_kernel): the device's workgroups are divided by weight bytes. T <= 32 (Q5_K: 16) - one pass; -5: not served, launch them separately.
 int pm_launch_mmq_i8_dual(int ta, int na, const void * const * Wa, const int * Na, float * const * Ya, const float * const * ba,
-                          int tb, const void * Wb, int Nb, float * Yb, const float * bb, const void * xq, int K, int T, int reuse_prep, hipStream_t st) {
+                          int tb, const void * Wb, int Nb, float * Yb, const float * bb, const void * xq, int K, int T, int reuse_prep, hipStream_t st,
+                          const pm_qkv_epi * epi) {
     static const bool off = [] { const char * e = getenv("PM355_MMQ_DUAL"); return e && e[0] == '0'; }();
     if (off || ta != PM_Q4_K || (tb != PM_Q6_K && tb != PM_Q5_K) || na < 1 || na > 3 || T < 1 || T > (tb == PM_Q5_K ? 16 : 32)) return -5;
     long total = 0;
     for (int j = 0; j < na; ++j) { if (pm_mmq_i8_check(ta, K, Na[j], T)) return -5; total += Na[j]; }
     if (pm_mmq_i8_check(tb, K, Nb, T)) return -5;
+    // epi: part a = wq, wk; part b = wv
+    if (epi && (na != 2 || Na[0] % epi->dh || Na[1] != epi->Hkv * epi->dh || Nb != Na[1])) return -5;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
     const int nsb = K / 256;
@@ -932,12 +979,17 @@ int pm_launch_mmq_i8_dual(int ta, int na, const void * const * Wa, const int * N
         p.rgb_log2 = rgb_log2_for((rows + 31) / 32);
     }
     pp.ga = ga;
+    if (!fill_epi(pp.a, epi, 1, 2, 0) || !fill_epi(pp.b, epi, 3, 0, 0)) return -5;
     const size_t la = pm_mmq_i8_lds_bytes(ta, K), lb = pm_mmq_i8_lds_bytes(tb, K), lds = la > lb ? la : lb;
     auto go = [&](auto kern) {
         pm_allow_big_lds((const void *) kern, 150 * 1024);
         hipLaunchKernelGGL(kern, dim3(ga + gb), dim3(BLOCK), lds, st, pp);
     };
-    if (tb == PM_Q6_K) { if (T <= 8) go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q6_K, 4>); else if (T <= 16) go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q6_K, 8>); else go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q6_K, 16>); }
+    if (epi) {
+        if (tb == PM_Q6_K) { if (T <= 8) go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q6_K, 4, true>); else if (T <= 16) go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q6_K, 8, true>); else go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q6_K, 16, true>); }
+        else               { if (T <= 8) go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q5_K, 4, true>); else go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q5_K, 8, true>); }
+    }
+    else if (tb == PM_Q6_K) { if (T <= 8) go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q6_K, 4>); else if (T <= 16) go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q6_K, 8>); else go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q6_K, 16>); }
     else               { if (T <= 8) go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q5_K, 4>); else go(mmq_i8_dual_kernel<PM_Q4_K, PM_Q5_K, 8>); }
     return 0;
 }

@@ -145,9 +145,10 @@ int pm_launch_mmq_i8(int type, const void * W, const void * xq, const float * x_
                      const float * bias, const float * resid, int reuse_prep, hipStream_t st);
 // 2 or 3 matrices of one type and K that share the activations, as one launch (T <= 16); -5: not served, launch them one by one
 int pm_launch_mmq_i8_multi(int type, int njobs, const void * const * W, const int * N, float * const * Y, const float * const * bias, const void * xq,
-                           int K, int T, int reuse_prep, hipStream_t st);
+                           int K, int T, int reuse_prep, hipStream_t st, const pm_qkv_epi * epi = nullptr);
 int pm_launch_mmq_i8_dual(int ta, int na, const void * const * Wa, const int * Na, float * const * Ya, const float * const * ba,
-                          int tb, const void * Wb, int Nb, float * Yb, const float * bb, const void * xq, int K, int T, int reuse_prep, hipStream_t st);
+                          int tb, const void * Wb, int Nb, float * Yb, const float * bb, const void * xq, int K, int T, int reuse_prep, hipStream_t st,
+                          const pm_qkv_epi * epi = nullptr);  // epi: RoPE + KV store in the launch's epilogue (NORM rope, transposed V, T <= 32)
 
 // prompt-sized batches (>= 128 tokens) on the integer matrix cores (mmq_big.hip): Q4_K / Q6_K weights x Q8_K activations, the CPU reference's
 // integer arithmetic. xq = T rows of row-SoA Q8_K, tab = the activation tables a quantizer wrote for them (pm_q8k_tables{tab, (K / 256) * 1152, K / 256};

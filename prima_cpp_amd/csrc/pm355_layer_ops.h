@@ -52,7 +52,8 @@ int  pm_launch_attn_rope_fused(const float * q, const float * k, const float * v
 // decode path with the RoPE + KV-store epilogue in the wq | wk | wv launch (mmvq_device.h QkvEpi): the per-token cos / sin table
 // (tab[2 i], tab[2 i + 1] for rotation pair i; position = pos[seq ? *seq : 0]) and the attention over cells that are all cached
 // (q = rotated, F16-rounded; attn_cached.hip). Remaining arguments as pm_launch_attn_rope_fused.
-void pm_launch_rope_table(const pm_rope_cfg & c, const int32_t * pos, const int32_t * seq, const float * freq_factors, float * tab, hipStream_t st);
+void pm_launch_rope_table(const pm_rope_cfg & c, const int32_t * pos, const int32_t * seq, const float * freq_factors, float * tab, hipStream_t st,
+                          int n_tok = 1);    // n_tok > 1: tables of the tokens pos .. pos + n_tok - 1, n_dims floats each
 int  pm_launch_attn_cached(const float * q, void * kc, void * vc, const int32_t * pos0, const int32_t * seq, long seq_stride, float * out,
                            int H, int Hkv, int dh, int n_ctx, float scale, hipStream_t st, const int32_t * dyn = nullptr,
                            const void * mask = nullptr, int max_keys = 0, int v_rowmajor = 0, int mask_f16 = 0,

@@ -172,3 +172,31 @@ def test_pair_and_qkv_kernels_at_model_k(P, oracle):
         for t, bl, n, b, yy in zip(ts, blocks, Ns, bias, ys):
             want = oracle.mul_mat(t, bl, K, n, xn)[0] + b
             assert np.allclose(yy.cpu().numpy(), want, rtol=2e-5, atol=2e-5), (t, np.abs(yy.cpu().numpy() - want).max())
+
+
+@pytest.mark.parametrize("tv,T", [(Q5_K, 5), (Q5_K, 16), (Q6_K, 9), (Q6_K, 24), (Q4_K, 2), (Q4_K, 32)])
+def test_small_batch_rope_and_kv_store_in_the_qkv_epilogue_same_bits(E, tv, T, monkeypatch):
+    """Round 6: small batches (2..32 tokens, NORM rope) rotate q / k and store K / V in the epilogue of the wq | wk | wv small-batch launch (mmq_i8.hip EPI
+    instantiations: the three-job launch, and the two-part grid when wv has another quant type) instead of a rope_kv_store launch of their own
+    (ggml_compute_forward_rope_f32 ggml.c:14224 + llm_build_kv_store src/llama.cpp:9688): hidden rows and logits of the batch AND of the next single token -
+    which reads the cache the batch wrote - are the same BITS as with PM355_SMALL_ROPE_EPI=0."""
+    torch = E.torch
+    arch, n_ff = 0, 28672
+    rng = np.random.default_rng(1000 + 37 * tv + T)
+    types = {"attn_v": tv, "ffn_down": Q6_K, "output": Q6_K}      # wv Q4_K: all three of one type = the three-job launch; Q5_K / Q6_K: the two-part grid
+    d = tiny_model(rng, arch=arch, n_layer=1, n_embd=8192, n_head=64, n_head_kv=8, n_ff=n_ff, n_vocab=512, n_ctx=128, rope_freqs=True, types=types)
+    toks = rng.integers(0, d.n_vocab, T + 1).astype(np.int32)
+    outs = []
+    for epi in ("1", "0"):
+        monkeypatch.setenv("PM355_SMALL_ROPE_EPI", epi)
+        w = E.Window(_hp(d), n_ctx=128)
+        w.load_desc(d)
+        w.finalize(max_tokens=32)
+        w.decode(tokens=torch.from_numpy(toks[:3]).cuda(), pos0=0)                        # cells 0..2, so that the batch starts at a position > 0
+        hb, lb, _ = w.decode(tokens=torch.from_numpy(toks[:T]).cuda(), pos0=3, want_argmax=True)
+        h1, l1, _ = w.decode(tokens=torch.from_numpy(toks[T:T + 1]).cuda(), pos0=3 + T, want_argmax=True)
+        outs.append((hb.clone(), lb.clone(), h1.clone(), l1.clone()))
+        w.close()
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b)
