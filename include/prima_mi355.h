@@ -468,6 +468,11 @@ PM355_API int pm355_model_decode_seq(pm355_model * m, int seq, const int32_t * d
                                      float * d_x_out, float * d_logits, int32_t * d_argmax, pm355_stream_t stream);
 PM355_API int pm355_model_n_embd(const pm355_model * m);
 PM355_API int pm355_model_n_seq(const pm355_model * m);          /* KV slabs the window was finalized for (pm355_model_finalize_seqs) */
+/* Launch geometry of the prompt GEMM (pm355_mul_mat_q_mfma and friends) for n_row_tiles tiles of 256 weight rows (pair launches: 128 rows of each matrix) x
+ * n_tokens x K on a device of n_cus CUs in 8 XCDs - host arithmetic only, no device needed (the reference's counterpart is the stream-k / tile choice of
+ * ggml-cuda/mmq.cuh:2583-2700). out5 = {tokens per tile (64 / 128 / 256), token tiles, K slices of a split tile, whole-tile slots per XCD in front of the split
+ * ones (0: every tile is split, or none when slices == 1), workgroups launched}. allow_tail_split = 0: the uniform split only. */
+PM355_API int pm355_gemm_plan(int64_t n_row_tiles, int64_t K, int64_t n_tokens, int n_cus, int allow_tail_split, int32_t * out5);
 /* Largest batch the library routes to the integer small-batch mat-mul (pm355_mul_mat_q_small: the CPU backend's Q8_K arithmetic, ggml/src/ggml.c:12377); larger
  * batches take the F16 prompt GEMM (pm355_mul_mat_q_mfma). 32 unless PM355_MMQ_MAX_TOKENS = 16 .. 64 says otherwise. */
 PM355_API int pm355_small_batch_max_tokens(void);

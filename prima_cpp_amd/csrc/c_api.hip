@@ -319,6 +319,13 @@ int pm355_mul_mat_q_small_mixed(const int * types, int njobs, const void * const
     HIP_TRY(hipGetLastError());
     return 0;
 }
+int pm355_gemm_plan(int64_t n_row_tiles, int64_t K, int64_t n_tokens, int n_cus, int allow_tail_split, int32_t * out5) {
+    if (n_row_tiles < 1 || K < 256 || n_tokens < 1 || n_cus < 8 || !out5) return fail(PM355_E_RANGE, "gemm_plan: n_row_tiles >= 1, K >= 256, n_tokens >= 1, n_cus >= 8");
+    pm_gemm_pf_plan_t pl;
+    pm_gemm_pf_plan((int) n_row_tiles, (int) K, (int) n_tokens, n_cus, 0, 0, allow_tail_split, &pl);
+    out5[0] = pl.nt * 32; out5[1] = pl.nt_t; out5[2] = pl.splitk; out5[3] = pl.full; out5[4] = pl.grid;
+    return 0;
+}
 int pm355_mul_mat_q_small_check(int type, int64_t K, int64_t N, int64_t n_tokens) {
     return pm_mmq_i8_check(type, (int) K, (int) N, (int) n_tokens) == 0 ? 0 : PM355_E_UNSUPPORTED;
 }

@@ -554,6 +554,42 @@ int pm_gemm_pf_check(int type, int K, int N, int T) {
     return 0;
 }
 
+// The launch geometry of `tiles` row tiles (256 rows; pair launches: 128 rows of each matrix) x T tokens over K on a device of `cus` CUs in 8 XCDs - host
+// arithmetic only (tests/test_host_logic.py plans the layer shapes without a device). nt: 32-token sub-tiles per workgroup tile (2 / 4 / 8 = 64 / 128 / 256
+// tokens: a dequantized operand serves nt MFMAs; smaller tiles only where the batch has no more tokens). Few tiles - wo / ffn_down / wq | wk | wv at the
+// reference's default n_ubatch 512 (common/common.h:178) are 64-80 tiles for 256 CUs - are split along K: S slices per tile, the slice count that minimises
+// rounds of workgroups x (super-blocks per slice + ~3 for prologue, slab traffic and the reducer's pass). A launch of R full rounds + a short tail (wq | wk | wv
+// at 2048 tokens: 320 tiles = 256 + 64; Qwen2.5-72B's ffn_gate | ffn_up: 1848 = 7 x 256 + 56) runs whole tiles in the full rounds and splits ONLY the tail's
+// tiles - as many slices as fill the idle CUs of the last round (`full` whole-tile slots per XCD come first in the grid). Splitting every tile instead sends
+// every partial tile through memory: 3 x 320 slabs of 256 KB for the qkv launch, 501 us = 685 TFLOP/s against 406 us = 846.
+void pm_gemm_pf_plan(int tiles, int K, int T, int cus, int force_nt, int force_s, int allow_mixed, pm_gemm_pf_plan_t * out) {
+    int nt = T <= 64 ? 2 : T <= 128 ? 4 : 8;
+    if (force_nt == 2 || force_nt == 4 || force_nt == 8) nt = force_nt;
+    const int nt_t = (T + 32 * nt - 1) / (32 * nt);
+    const long wgs = (long) tiles * nt_t;
+    const int nb = (K + 255) / 256;
+    if (cus < 8) cus = 8;
+    int S = 1, full = 0;
+    const int minL = (tiles / 8) * nt_t, maxL = ((tiles + 7) / 8) * nt_t, cpx = cus / 8;      // per-XCD slot counts (XCD x owns the row tiles x, x + 8, ..)
+    double best = (double) ((wgs + cus - 1) / cus) * nb;
+    for (int q = 2; q <= 8; ++q) {
+        if (nb / q < 4 || wgs * q > 16384) break;
+        const double c = (double) ((wgs * q + cus - 1) / cus) * ((double) nb / q + 3.0);
+        if (c < best * 0.97) { best = c; S = q; }
+    }
+    const int F = (minL / cpx) * cpx, rem = maxL - F;
+    if (allow_mixed && !(force_s >= 1 && force_s <= 8) && F > 0 && rem > 0 && 2 * rem <= cpx) {
+        int q = cpx / rem; if (q > 8) q = 8;
+        while (q >= 2 && nb / q < 4) --q;
+        if (q >= 2) {
+            const double c = (double) (F / cpx) * nb + ((double) nb / q + 3.0);
+            if (c < best * 0.97) { best = c; S = q; full = F; }
+        }
+    }
+    if (force_s >= 1 && force_s <= 8 && nb / force_s >= 1) { S = force_s; full = 0; }
+    out->nt = nt; out->nt_t = nt_t; out->splitk = S; out->full = full; out->grid = 8 * (full + (maxL - full) * S); out->cost = best;
+}
+
 // One launch over njobs <= 4 matrices that share the F16 activations xh [T][K]. Job j: Y_j[t][n] (f32, token stride ldy_j) or Yh_j (F16) =
 // W_j . x (+bias)(+resid)(x silu(gate)). 0, or -1 type / -2 shape
 int pm_launch_gemm_pf(const pm_gemm_pf_job * jobs, int njobs, const void * xh, int K, int T, hipStream_t st) { return pm_launch_gemm_pf_ex(jobs, njobs, xh, K, T, 0, st); }
@@ -581,44 +617,16 @@ int pm_launch_gemm_pf_ex(const pm_gemm_pf_job * jobs, int njobs, const void * xh
     p.grp = grp;
     p.njobs = njobs; p.nt_n = tiles; p.Xh = (const _Float16 *) xh; p.K = K; p.T = T;
     static const int force_nt = [] { const char * e = getenv("PM355_GEMM_PF_NT"); return e ? atoi(e) : 0; }();
+    static const int force_s = [] { const char * e = getenv("PM355_GEMM_PF_SPLITK"); return e ? atoi(e) : 0; }();
+    static const bool no_mixed = [] { const char * e = getenv("PM355_GEMM_PF_MIXED"); return e && e[0] == '0'; }();
     const int cus = pm_device_cus();
     // 256-token tiles (a dequantized operand serves 8 MFMAs; 128-token tiles only where the batch has no more tokens). Few tiles - wo / ffn_down / wq | wk | wv
     // at the reference's default n_ubatch 512 (common/common.h:178) are 64-80 tiles for 256 CUs - are split along K: S slices per tile, the slice count that
     // minimises  rounds of workgroups x (super-blocks per slice + ~3 for prologue, slab traffic and the reducer's pass)
-    int nt = T <= 64 ? 2 : T <= 128 ? 4 : 8;
-    if (force_nt == 2 || force_nt == 4 || force_nt == 8) nt = force_nt;
-    p.nt_t = (T + 32 * nt - 1) / (32 * nt);
-    const long wgs = (long) tiles * p.nt_t;
-    const int nb = (K + 255) / 256;
-    // (64-token tiles - 93-101 registers, 65 KB of LDS for Q4_K - with the K split sized for two workgroups per CU: measured 352 vs 312 us per 70B layer
-    //  at 33-64 tokens, profiles/r06_small_batch.txt; one workgroup per CU it stays)
-    const int slots_cu = cus;
-    static const int force_s = [] { const char * e = getenv("PM355_GEMM_PF_SPLITK"); return e ? atoi(e) : 0; }();
-    int S = 1, full = 0;
-    // per-XCD slot counts (XCD x owns the row tiles x, x + 8, ..)
-    const int minL = (tiles / 8) * p.nt_t, maxL = ((tiles + 7) / 8) * p.nt_t, cpx = cus / 8 > 0 ? cus / 8 : 1;
-    {
-        double best = (double) ((wgs + slots_cu - 1) / slots_cu) * nb;
-        for (int q = 2; q <= 8; ++q) {
-            if (nb / q < 4 || wgs * q > 16384) break;
-            const double c = (double) ((wgs * q + slots_cu - 1) / slots_cu) * ((double) nb / q + 3.0);
-            if (c < best * 0.97) { best = c; S = q; }
-        }
-        // a launch of R full rounds + a short tail (wq | wk | wv at 2048 tokens: 320 tiles = 256 + 64; Qwen2.5-72B's ffn_gate | ffn_up: 1848 = 7 x 256 + 56): the
-        // full rounds run whole tiles, ONLY the tail's tiles are split - S' slices each, as many as fill the idle CUs of the last round. (Splitting every tile
-        // instead sends every partial tile through memory: 3 x 320 slabs of 256 KB for the qkv launch, 501 us = 685 TFLOP/s.)
-        static const bool no_mixed = [] { const char * e = getenv("PM355_GEMM_PF_MIXED"); return e && e[0] == '0'; }();
-        const int F = (minL / cpx) * cpx, rem = maxL - F;
-        if (!no_mixed && !(force_s >= 1 && force_s <= 8) && F > 0 && rem > 0 && 2 * rem <= cpx) {
-            int q = cpx / rem; if (q > 8) q = 8;
-            while (q >= 2 && nb / q < 4) --q;
-            if (q >= 2) {
-                const double c = (double) (F / cpx) * nb + ((double) nb / q + 3.0);
-                if (c < best * 0.97) { best = c; S = q; full = F; }
-            }
-        }
-        if (force_s >= 1 && force_s <= 8 && nb / force_s >= 1) { S = force_s; full = 0; }
-    }
+    pm_gemm_pf_plan_t pl;
+    pm_gemm_pf_plan(tiles, K, T, cus, force_nt, force_s, no_mixed ? 0 : 1, &pl);
+    const int nt = pl.nt, S = pl.splitk, full = pl.full, maxL = ((tiles + 7) / 8) * pl.nt_t;
+    p.nt_t = pl.nt_t;
     p.splitk = S; p.full = full;
     const int split_slots = maxL - full;                       // per XCD
     if (S > 1) {

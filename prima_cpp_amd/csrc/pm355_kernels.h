@@ -121,6 +121,8 @@ int pm_launch_gemm_q_h(int type, const void * W, const float * X, const void * x
 // prompt GEMM, third generation (mmq_pf.hip): up to 4 matrices (Q4_K / Q6_K, at most two types per launch) that share the F16 activations xh [T][K]
 // go out as ONE launch. Job: Y[t * ldy + n] (f32) or, when Yh != null, Yh[t * ldy + n] (F16) = W . x (+ bias[n]) (+ resid[t * ldy + n]) (* silu(silu_gate[t * ldy + n]));
 // ldy == 0 means N. pm_gemm_pf_check: 0 when (type, K, N, T) is served, -1 type, -2 shape
+struct pm_gemm_pf_plan_t { int nt, nt_t, splitk, full, grid; double cost; };
+void pm_gemm_pf_plan(int tiles, int K, int T, int cus, int force_nt, int force_s, int allow_mixed, pm_gemm_pf_plan_t * out);   // host arithmetic only (mmq_pf.hip)
 struct pm_gemm_pf_job { int type; int N; const void * W; float * Y; void * Yh; const float * bias; const float * resid; const float * silu_gate; long ldy; };
 int pm_gemm_pf_check(int type, int K, int N, int T);
 bool pm_gemm_pf_enabled();      // false under PM355_GEMM_KERNEL=1 / 2 (A/B against the older prompt kernels)
