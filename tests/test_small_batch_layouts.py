@@ -133,3 +133,64 @@ def test_row_major_v_image_feeds_the_transposing_read(dh):
                 for col in range(16):                                 # lane `col` receives column col, rows 0..3
                     got = [block[(r, col)] for r in range(4)]
                     assert got == [(8 * lg + 4 * half + r, 16 * d + col) for r in range(4)], (lg, d, half, col, got)
+
+
+# ---- round 6: the wq | wk | wv epilogue of the small-batch launch (mmq_i8.hip EPI instantiations) and the two-part grid (mmq_i8_dual_kernel)
+
+def epi_slices(N, G):
+    """mmq_i8_body<.., EPI = true>: workgroup w of G owns virtual rows [r0, r1), both forced even."""
+    return [(((N * w) // G) & ~1, ((N * (w + 1)) // G) & ~1) for w in range(G)]
+
+
+@pytest.mark.parametrize("N,G", [(9216, 224), (9216, 220), (10240, 256), (10240, 255), (1280, 40), (8192 + 1024, 37), (2304, 9)])
+def test_rope_pairs_never_straddle_two_workgroups_and_every_row_is_owned_once(N, G):
+    sl = epi_slices(N, G)
+    assert sl[0][0] == 0 and sl[-1][1] == N                           # (N even: the last slice ends on N)
+    owner = {}
+    for w, (r0, r1) in enumerate(sl):
+        assert r0 % 2 == 0 and r1 % 2 == 0 and r0 <= r1
+        for row in range(r0, r1):
+            assert row not in owner
+            owner[row] = w
+    assert len(owner) == N
+    for row in range(0, N, 2):                                         # NORM rope: rows (2 i, 2 i + 1) of a head rotate together
+        assert owner[row] == owner[row + 1]
+
+
+def test_epilogue_thread_finds_its_pair_in_the_neighbouring_lane():
+    """The reduction loop's thread o = (row group gi, result register v, lane l) holds (row, token) = (r0 + 32 (rg0 + gi) + l % 32, 8 (v / 4) + 4 (l / 32) + v % 4);
+    lane l ^ 1 of the same (gi, v) holds row ^ 1 of the SAME token when r0 is even - the operand of __shfl_xor(s, 1)."""
+    for r0 in (0, 2, 46, 1000):
+        for rg in range(3):
+            for v in range(16):
+                for l in range(64):
+                    row = r0 + 32 * rg + (l & 31)
+                    t = 8 * (v >> 2) + 4 * (l >> 5) + (v & 3)
+                    lp = l ^ 1
+                    rowp = r0 + 32 * rg + (lp & 31)
+                    tp = 8 * (v >> 2) + 4 * (lp >> 5) + (v & 3)
+                    assert rowp == row ^ 1 and tp == t
+    # every (row of a 32-row group, token of 32) appears exactly once over (v, l)
+    seen = {(l & 31, 8 * (v >> 2) + 4 * (l >> 5) + (v & 3)) for v in range(16) for l in range(64)}
+    assert len(seen) == 32 * 32
+
+
+def dual_split(total_a, stride_a, Nb, stride_b, cus=256):
+    """pm_launch_mmq_i8_dual: the device's workgroups divided by weight bytes; neither part gets more workgroups than it has 32-row groups."""
+    ba, bb = total_a * stride_a, Nb * stride_b
+    gb = int(cus * bb / (ba + bb) + 0.5)
+    gb = max(gb, 1)
+    gb = min(gb, (Nb + 31) // 32)
+    ga = min(cus - gb, (total_a + 31) // 32)
+    return ga, gb
+
+
+@pytest.mark.parametrize("Na,Nb,K", [(9216, 1024, 8192), (4096 + 1024, 1024, 4096), (5120 + 1024, 1024, 5120), (300 + 70, 75, 1024), (2100 + 260, 300, 2048)])
+def test_two_part_grid_gives_every_part_workgroups_and_whole_row_groups(Na, Nb, K):
+    for stride_b in (K // 256 * 210, K // 256 * 176):                  # Q6_K / Q5_K rows against Q4_K's 144 bytes per super-block
+        ga, gb = dual_split(Na, K // 256 * 144, Nb, stride_b)
+        assert ga >= 1 and gb >= 1 and ga + gb <= 256
+        assert gb <= (Nb + 31) // 32 and ga <= (Na + 31) // 32
+        # the 70B shape: wq | wk take the bulk, wv (1024 rows) about one workgroup per 32 rows (Q6_K: 35.7 by bytes, capped at 32; Q5_K: 31)
+        if (Na, Nb, K) == (9216, 1024, 8192):
+            assert (ga, gb) == ((224, 32) if stride_b == K // 256 * 210 else (225, 31))
