@@ -288,7 +288,7 @@ def probe_prefill(hp, mixture, n_tok, small_batches=(2, 3, 4, 8, 16, 32, 64)):
                                    "gemm_tflops_whole_prompt": round(flop / (ms_ub / 1e3) / 1e12, 1)}
     except Exception as e:
         out["n_ubatch_512"] = {"error": str(e)[:300]}
-    # small batches through the same window (speculative decoding / parallel sequences / short prompts): 4..64 tokens per step take the
+    # small batches through the same window (speculative decoding / parallel sequences / short prompts): 2..32 tokens per step take the
     # integer-matrix-core mat-mul (mmq_i8.hip: one weight pass per 32 tokens), whole model, KV positions advancing
     try:
         sb = {}

@@ -74,7 +74,7 @@ struct pm355_model {
     // bits (two 70B layers differed from the launches by 1e-4, one by 1e-14: found on the hardware; round 1's persistent kernel had met the same).
     struct EnginePlan { const float * in; float * out; pm_eng_plan * plan; int n_ss_end; const double * ss_end; const float * end; float * act; double * ss_in0; };
     bool use_engine = false; std::vector<EnginePlan> eng_plans; bool eng_refused = false;
-    // PM355_PROMPT_I8=1: prompts (> 64 tokens) run their Q4_K / Q6_K matrices on the integer matrix cores over Q8_K activations (mmq_big.hip) - the CPU
+    // PM355_PROMPT_I8=1: prompts (> MMQ_MAX_TOKENS = 32 tokens) run their Q4_K / Q6_K matrices on the integer matrix cores over Q8_K activations (mmq_big.hip) - the CPU
     // reference's own arithmetic, at 0.6-0.75 of the F16 GEMMs' rate (mmq.hip, the default); tab_big = the activation tables of the current
     // activation set (pm_q8k_tables)
     bool no_big = true; uint8_t * tab_big = nullptr;
@@ -319,7 +319,7 @@ int gemv(const Tensor & w, const Tensor * w2, const ActQ & a, int T, float * y, 
     return pm_launch_gemv(g, st);
 }
 
-// 4..64 tokens: one pass over the weights per 32 tokens on the integer matrix cores (mmq_i8.hip) where the type / shape is served, else the mat-vec
+// 3..MMQ_MAX_TOKENS (32; on request 64) tokens: one pass over the weights per 32 tokens on the integer matrix cores (mmq_i8.hip) where the type / shape is served, else the mat-vec
 // (one to three passes per 8 columns). `prepped`: the kernel's activation tables already describe THIS activation set (set by the first
 // served call, cleared by the caller whenever the activations change)
 int matmul_small(pm355_model * m, const Tensor & w, const ActQ & a, int T, float * y, const float * bias, const float * resid, bool & prepped, hipStream_t st) {
@@ -624,7 +624,7 @@ int run_window(pm355_model * m, const int32_t * d_tokens, const float * d_x_in, 
     for (int il = m->lo; il < m->hi; ++il) {
         Layer Lv = layer_acquire(m, il, st); Layer & L = Lv;
         const Tensor * qkv[3] = {&L.t[PM355_T_WQ], &L.t[PM355_T_WK], &L.t[PM355_T_WV]};
-        // 16..64 tokens take the small-batch path below unless its per-token attention kernel cannot hold n_ctx scores in LDS
+        // batches up to MMQ_MAX_TOKENS take the small-batch path below unless its per-token attention kernel cannot hold n_ctx scores in LDS
         const bool small_attn_ok = (size_t) (dh + hp.n_ctx) * 4 <= 150 * 1024;
         bool small_ok = !m->no_mmq && small_attn_ok;              // ... and unless one of the layer's large matrices has a type neither small-batch path serves
         for (int k : {PM355_T_WQ, PM355_T_WO, PM355_T_FFN_GATE, PM355_T_FFN_UP, PM355_T_FFN_DOWN}) {
