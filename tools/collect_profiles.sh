@@ -42,7 +42,7 @@ PY
 # (3) prefill GEMM: achieved TFLOP/s + MFMA / VALU / LDS utilisation and wait counters, one pass per counter (SKIP_PREFILL=1: leave it out)
 [ "${SKIP_PREFILL:-0}" = 1 ] || { echo "prefill GEMM (ffn_gate shape, T = 2048), tools/gemm_probe.py; counters: separate rocprofv3 --pmc <counter> --kernel-trace passes, 4 launches each";
   echo "== default kernel selection (mmq_pf.hip); gate6 = the ffn_gate shape in Q6_K (Qwen2.5-72B file type); then the second generation (PM355_GEMM_KERNEL=2) on the same box"
-  for s in gate gate6 wo down wk; do python $OLDPWD/tools/gemm_probe.py 2048 $s 2>/dev/null; done
+  for s in gate gate6 wo down wk qkv gateq; do python $OLDPWD/tools/gemm_probe.py 2048 $s 2>/dev/null; done   # (qkv: wq | wk | wv as one launch; gateq: Qwen2.5-72B's gate | up pair launch)
   for s in gate gate6 wo down; do python $OLDPWD/tools/gemm_probe.py 512 $s 2>/dev/null; done
   for s in gate gate6 wo down; do echo -n "kernel2: "; PM355_GEMM_KERNEL=2 python $OLDPWD/tools/gemm_probe.py 2048 $s 2>/dev/null; done
   python $OLDPWD/tools/torch_gemm_ref.py 2>/dev/null

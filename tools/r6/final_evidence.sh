@@ -1,6 +1,8 @@
+#!/bin/bash
+# the round's closing evidence on the final code: smoke(), tools/collect_profiles.sh r06 (decode kernel table + timeline, PMC traffic of the dominant decode kernel,
+# prompt GEMM rates and counters) - copy gpurun_out/r06/* into profiles/ afterwards; tools/r6/suite_and_bench.sh is the other half (the -m gpu suite + the bench line)
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r6u
-timeout 900 python -u -m pytest tests/test_gpu_llama_decode.py -q -x -m gpu > gpurun_out/r6u/llama_decode.log 2>&1; echo "rc=$?" >> gpurun_out/r6u/llama_decode.log
-timeout 600 bash tools/r6/decode_env_ab.sh > gpurun_out/r6u/env_ab.log 2>&1
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r6u/smoke.log 2>&1; echo "rc=$?" >> gpurun_out/r6u/smoke.log
 timeout 1500 bash tools/collect_profiles.sh r06 > gpurun_out/r6u/collect.log 2>&1
-timeout 900 python bench.py > gpurun_out/r6u/bench.json 2> gpurun_out/r6u/bench.err
-tail -3 gpurun_out/r6u/llama_decode.log; cat gpurun_out/r6u/env_ab.log; tail -c 600 gpurun_out/r6u/bench.json
+tail -3 gpurun_out/r6u/smoke.log; tail -5 gpurun_out/r6u/collect.log
