@@ -1010,7 +1010,8 @@ int pm355_model_finalize_seqs(pm355_model * m, int max_tokens, int n_seq) {
               A((void **) &m->aq_k, T * pm_q8k_row_bytes((int) ((maxK + 255) / 256 * 256))) &&
               A((void **) &m->aq_0, T * pm_q80_row_bytes((int) ((maxK + 31) / 32 * 32))) &&
               A((void **) &m->d_pos, 64 * 4) && A((void **) &m->d_ctl, 64) && A((void **) &m->d_tok, 64 + T * 4) &&
-              A((void **) &m->rope_tab, (size_t) hp.head_dim * 4 * 32) &&      // cos / sin tables of up to 32 tokens (small-batch epilogue) A((void **) &m->ss, 2 * 256 * sizeof(double)) &&
+              A((void **) &m->rope_tab, (size_t) hp.head_dim * 4 * 32) &&      // cos / sin tables of up to 32 tokens (small-batch epilogue)
+              A((void **) &m->ss, 2 * 256 * sizeof(double)) &&
               A((void **) &m->att_tk, 65 * 4);
     if (ok) (void) hipMemset(m->att_tk, 0, 65 * 4);
     if (ok && T > MMQ_MAX_TOKENS && !m->no_big) ok = A((void **) &m->tab_big, pm_mmq_big_table_bytes((int) ((maxK + 255) / 256 * 256), (int) T));
