@@ -555,7 +555,7 @@ int pm_gemm_pf_check(int type, int K, int N, int T) {
 }
 
 // The launch geometry of `tiles` row tiles (256 rows; pair launches: 128 rows of each matrix) x T tokens over K on a device of `cus` CUs in 8 XCDs - host
-// arithmetic only (tests/test_host_logic.py plans the layer shapes without a device). nt: 32-token sub-tiles per workgroup tile (2 / 4 / 8 = 64 / 128 / 256
+// arithmetic only (tests/test_gemm_plan.py plans the layer shapes without a device). nt: 32-token sub-tiles per workgroup tile (2 / 4 / 8 = 64 / 128 / 256
 // tokens: a dequantized operand serves nt MFMAs; smaller tiles only where the batch has no more tokens). Few tiles - wo / ffn_down / wq | wk | wv at the
 // reference's default n_ubatch 512 (common/common.h:178) are 64-80 tiles for 256 CUs - are split along K: S slices per tile, the slice count that minimises
 // rounds of workgroups x (super-blocks per slice + ~3 for prologue, slab traffic and the reducer's pass). A launch of R full rounds + a short tail (wq | wk | wv
